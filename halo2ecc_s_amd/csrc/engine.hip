@@ -1,0 +1,821 @@
+// gfx950 witness engine: replays a witness tape (tape.h) for many instances / strands at once.
+//
+// Mapping: one lane per (instance, strand).  All lanes of a launch execute the same op at the same
+// time (the tape is wave-uniform, fetched through the scalar cache), so there is no divergence
+// except inside the two modular inversions.  Every lane streams its advice cells row-major into its
+// own row range of the instance's arrays — [row][col][4 x u64], canonical little-endian bn256-Fr —
+// exactly the rows the reference's forked context would have written (src/context.rs:610-632,
+// 803-815, 722-735).  Operands are read back from those arrays through cell references.
+#include <hip/hip_runtime.h>
+#include "tape.h"
+#include "wide_int.h"
+
+// ------------------------------------------------------------------------------------------------
+// field-pair traits (compile-time sizes; values come from H2EFieldConsts)
+struct FP_BN256_FQ {   // bn256 Fq over bn256 Fr
+    static constexpr int L = 3, WW = 4, K = 254, CEIL = 254, MC = 3, RC = 1, PW = 1;
+};
+struct FP_BLS_FQ {     // bls12_381 Fq over bn256 Fr
+    static constexpr int L = 4, WW = 6, K = 381, CEIL = 381, MC = 5, RC = 2, PW = 2;
+};
+struct FP_BLS_FR {     // bls12_381 Fr over bn256 Fr
+    static constexpr int L = 3, WW = 4, K = 255, CEIL = 255, MC = 3, RC = 1, PW = 1;
+};
+template <class FP>
+struct FPX {
+    static constexpr int S = 2 * FP::CEIL + 12;           // a*b < 2^S
+    static constexpr int XW = (S + 63) / 64;
+    static constexpr int QW = (S - FP::K + 1 + 63) / 64;  // words of a quotient d
+    static constexpr int AW = (FP::CEIL + 6 + 63) / 64;   // words of a composed operand (< 2^(CEIL+6))
+};
+static constexpr int NK = 254;  // bit length of bn256 Fr modulus
+
+typedef Wd<2> Limb;   // <= 114 bit
+typedef Wd<4> Fe;     // canonical bn256-Fr value
+
+struct InstanceDesc {
+    u64* base;          // [base_rows][5][4]
+    u64* range;         // [range_rows][3][4]
+    u64* select;        // [select_rows][2][4]
+    const u64* inputs;  // [n_slots][slot_words]
+    u32* status;
+};
+
+struct LC {  // lane context
+    u64* base;
+    u64* range;
+    u64* select;
+    const u64* inputs;
+    u32* status;
+    u32 ob, orr, os;       // strand offsets
+    const u32* params;     // this strand's parameter refs
+    const u32* aux;
+    const u64* pool;
+    const H2EFieldConsts* fc;
+    u32 strand, input_stride;
+};
+
+// ------------------------------------------------------------------------------------------------
+// cell I/O
+WI_INLINE u64* cell_ptr(const LC& c, u32 ref) {
+    if (H2E_REF_REGION(ref) == H2E_REGION_PARAM) ref = c.params[H2E_REF_ROW(ref)];
+    u32 region = H2E_REF_REGION(ref), col = H2E_REF_COL(ref), row = H2E_REF_ROW(ref);
+    bool rel = H2E_REF_REL(ref);
+    if (region == 0) return c.base + ((size_t)(row + (rel ? c.ob : 0)) * 5 + col) * 4;
+    if (region == 1) return c.range + ((size_t)(row + (rel ? c.orr : 0)) * 3 + col) * 4;
+    return c.select + ((size_t)(row + (rel ? c.os : 0)) * 2 + col) * 4;
+}
+WI_INLINE Fe ld_fe(const LC& c, u32 ref) {
+    const ulonglong2* p = (const ulonglong2*)cell_ptr(c, ref);
+    ulonglong2 a = p[0], b = p[1];
+    Fe r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
+    return r;
+}
+WI_INLINE Limb ld_limb(const LC& c, u32 ref) {  // values known to be < 2^128
+    const ulonglong2* p = (const ulonglong2*)cell_ptr(c, ref);
+    ulonglong2 a = p[0];
+    Limb r;
+    r.v[0] = a.x; r.v[1] = a.y;
+    return r;
+}
+WI_INLINE void st_cell(u64* p, const Fe& v) {
+    ulonglong2* q = (ulonglong2*)p;
+    q[0] = make_ulonglong2(v.v[0], v.v[1]);
+    q[1] = make_ulonglong2(v.v[2], v.v[3]);
+}
+WI_INLINE void stB(const LC& c, u32 row, int col, const Fe& v) { st_cell(c.base + ((size_t)(row + c.ob) * 5 + col) * 4, v); }
+WI_INLINE void stR(const LC& c, u32 row, int col, const Fe& v) { st_cell(c.range + ((size_t)(row + c.orr) * 3 + col) * 4, v); }
+WI_INLINE void stS(const LC& c, u32 row, int col, const Fe& v) { st_cell(c.select + ((size_t)(row + c.os) * 2 + col) * 4, v); }
+WI_INLINE Fe fe_of(const Limb& l) { return wd_resize<4>(l); }
+WI_INLINE Fe fe_u64(u64 x) { return wd_from_u64<4>(x); }
+WI_INLINE void flag(const LC& c, u32 bits) { atomicOr(c.status, bits); }
+
+// ------------------------------------------------------------------------------------------------
+// arithmetic mod n (bn256 Fr)
+WI_INLINE Fe n_of(const LC& c) { return wd_load<4>(c.fc->n); }
+template <int XW>
+WI_INLINE Fe mod_n(const LC& c, const Wd<XW>& x) {
+    static_assert(XW <= 8, "mod_n input too wide");
+    Wd<5> q;
+    Fe r;
+    wd_barrett_divrem<512, NK, 8, 4, 5>(wd_resize<8>(x), n_of(c), wd_load<5>(c.fc->n_mu), q, r);
+    return r;
+}
+WI_INLINE Fe addmod_n(const LC& c, const Fe& a, const Fe& b) {
+    Fe s = wd_add<4>(a, b);  // < 2n < 2^255
+    Fe n = n_of(c);
+    return wd_geq<4>(s, n) ? wd_sub<4>(s, n) : s;
+}
+WI_INLINE Fe submod_n(const LC& c, const Fe& a, const Fe& b) {
+    return wd_geq<4>(a, b) ? wd_sub<4>(a, b) : wd_sub<4>(wd_add<4>(a, n_of(c)), b);
+}
+WI_INLINE Fe mulmod_n(const LC& c, const Fe& a, const Fe& b) { return mod_n<8>(c, wd_mul<4, 4>(a, b)); }
+// signed 256-bit (two's complement, |x| < n) -> field element
+WI_INLINE Fe fe_of_signed(const LC& c, const Wd<4>& x) { return wd_is_neg<4>(x) ? wd_add<4>(x, n_of(c)) : x; }
+WI_INLINE Fe inv_n(const LC& c, const Fe& a) { return wd_inv_mod<4>(a, n_of(c)); }
+
+// ------------------------------------------------------------------------------------------------
+// range-chip row groups (src/context.rs:835-972, src/circuit/range_chip.rs:287-347)
+WI_INLINE u64 chunk18(const Limb& x, int i) {  // i-th 18-bit chunk of a <=128-bit value
+    int sh = 18 * i;
+    u64 lo = sh < 64 ? (x.v[0] >> sh) : 0;
+    if (sh < 64 && sh + 18 > 64) lo |= x.v[1] << (64 - sh);
+    if (sh >= 64) lo = x.v[1] >> (sh - 64);
+    return lo & 0x3ffffu;
+}
+// assign_nonleading_limb: 3 rows, 7 cells
+WI_INLINE void emit_limb3(const LC& c, u32 row, const Limb& x) {
+    stR(c, row, 0, fe_of(x));
+    stR(c, row, 1, fe_u64(chunk18(x, 3)));
+    stR(c, row, 2, fe_u64(chunk18(x, 0)));
+    stR(c, row + 1, 1, fe_u64(chunk18(x, 4)));
+    stR(c, row + 1, 2, fe_u64(chunk18(x, 1)));
+    stR(c, row + 2, 1, fe_u64(chunk18(x, 5)));
+    stR(c, row + 2, 2, fe_u64(chunk18(x, 2)));
+}
+// leading limb in a 2-line range value (36..72 bits): 2 rows, 5 cells
+WI_INLINE void emit_lead2(const LC& c, u32 row, const Limb& x) {
+    stR(c, row, 0, fe_of(x));
+    stR(c, row, 1, fe_u64(chunk18(x, 2)));
+    stR(c, row, 2, fe_u64(chunk18(x, 0)));
+    stR(c, row + 1, 1, fe_u64(chunk18(x, 3)));
+    stR(c, row + 1, 2, fe_u64(chunk18(x, 1)));
+}
+// assign_common: 1 row, 2 cells
+WI_INLINE void emit_common(const LC& c, u32 row, u64 x) {
+    stR(c, row, 0, fe_u64(x));
+    stR(c, row, 1, fe_u64(x));
+}
+
+template <class FP>
+struct IntVal {  // value of an AssignedInteger
+    Limb l[FP::L];
+    Fe native;
+};
+template <class FP>
+WI_INLINE IntVal<FP> ld_int(const LC& c, const u32* refs) {
+    IntVal<FP> r;
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) r.l[i] = ld_limb(c, refs[i]);
+    r.native = ld_fe(c, refs[FP::L]);
+    return r;
+}
+// Horner composition of limbs (integer_chip.rs:217-224): sum l_i * 2^(108 i)
+template <class FP, int OW>
+WI_INLINE Wd<OW> compose(const Limb* l) {
+    Wd<OW> r = wd_zero<OW>();
+    r = wd_add<OW>(r, wd_resize<OW>(l[0]));
+    r = wd_add<OW>(r, wd_shl<OW, 108>(l[1]));
+    r = wd_add<OW>(r, wd_shl<OW, 216>(l[2]));
+    if (FP::L > 3) r = wd_add<OW>(r, wd_shl<OW, 324>(l[FP::L - 1]));
+    return r;
+}
+// limb i of a canonical value: (x >> 108 i) & (2^108 - 1)
+template <int I, int N>
+WI_INLINE Limb limb_of(const Wd<N>& x) {
+    return wd_mask<108, 2>(wd_shr<2, 108 * I>(x));
+}
+template <class FP, int N>
+WI_INLINE void split_limbs(const Wd<N>& x, Limb* out) {
+    out[0] = limb_of<0>(x);
+    out[1] = limb_of<1>(x);
+    out[2] = limb_of<2>(x);
+    if (FP::L > 3) out[FP::L - 1] = limb_of<3>(x);
+}
+
+// assign_w / assign_d body: range rows for the limbs + the base row [limbs .. | native]
+// (integer_chip.rs:236-281).  Returns rows consumed in range.
+template <class FP>
+WI_INLINE u32 emit_assigned(const LC& c, u32 brow, u32 rrow, const Limb* l, const Fe& native) {
+    u32 r = rrow;
+#pragma unroll
+    for (int i = 0; i < FP::L - 1; i++) {
+        emit_limb3(c, r, l[i]);
+        r += 3;
+    }
+    emit_lead2(c, r, l[FP::L - 1]);
+    r += 2;
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) stB(c, brow, i, fe_of(l[i]));
+    stB(c, brow, 4, native);
+    return r - rrow;
+}
+
+template <class FP>
+WI_INLINE void divrem_w(const LC& c, const Wd<FPX<FP>::XW>& X, Wd<FPX<FP>::QW>& q, Wd<FP::WW>& r) {
+    wd_barrett_divrem<FPX<FP>::S, FP::K, FPX<FP>::XW, FP::WW, FPX<FP>::QW>(X, wd_load<FP::WW>(c.fc->w),
+                                                                             wd_load<FPX<FP>::QW>(c.fc->w_mu), q, r);
+}
+
+// limb product as a signed 256-bit value
+WI_INLINE Wd<4> lmul(const Limb& a, const Limb& b) { return wd_mul<2, 2>(a, b); }
+
+// The mul-equation rows (integer_chip.rs:73-215) for a*b = d*w + rem, with rem/d already assigned.
+// Writes base rows from `brow` and range rows from `rrow`.
+template <class FP>
+WI_INLINE void emit_mul_equation(const LC& c, u32 brow, u32 rrow, const IntVal<FP>& a, const IntVal<FP>& b,
+                                 const Limb* d, const Fe& d_native, const Limb* rem, const Fe& rem_native) {
+    constexpr int L = FP::L;
+    Wd<4> lv[FP::MC];
+    Limb wl[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) wl[i] = wd_load<2>(c.fc->w_limbs[i]);
+    // cross-product rows (mul_add_with_next_line, base_chip.rs:245-281)
+#pragma unroll
+    for (int pos = 0; pos < FP::MC; pos++) {
+        const int r_bound = (pos + 1 < L) ? pos + 1 : L;
+        const int l_bound = (pos >= L - 1) ? pos - (L - 1) : 0;
+        Wd<4> t = wd_zero<4>();
+        if (r_bound - l_bound == 1) {
+            const int i = l_bound;
+            t = wd_sub<4>(lmul(a.l[i], b.l[pos - i]), lmul(d[i], wl[pos - i]));
+            stB(c, brow, 0, fe_of(a.l[i]));
+            stB(c, brow, 1, fe_of(b.l[pos - i]));
+            stB(c, brow, 2, fe_of(d[i]));
+            stB(c, brow, 4, fe_of_signed(c, t));
+            brow += 1;
+        } else {
+#pragma unroll
+            for (int i = l_bound; i < r_bound; i++) {
+                stB(c, brow, 0, fe_of(a.l[i]));
+                stB(c, brow, 1, fe_of(b.l[pos - i]));
+                stB(c, brow, 2, fe_of(d[i]));
+                stB(c, brow, 4, fe_of_signed(c, t));
+                brow += 1;
+                t = wd_add<4>(t, wd_sub<4>(lmul(a.l[i], b.l[pos - i]), lmul(d[i], wl[pos - i])));
+            }
+            stB(c, brow, 4, fe_of_signed(c, t));
+            brow += 1;
+        }
+        lv[pos] = t;
+    }
+    // borrow = L * 2^108 + 2 ; K0 = 2^108 * borrow ; K1 = K0 - borrow     (integer_chip.rs:112-145)
+    Wd<4> borrow = wd_add<4>(wd_shl<4, 108>(wd_from_u64<1>((u64)L)), wd_from_u64<4>(2));
+    Wd<4> K0 = wd_shl<4, 108>(borrow);
+    Wd<4> K1 = wd_sub<4>(K0, borrow);
+    Limb v_l = wd_zero<2>();
+    u64 v_h = 0;
+#pragma unroll
+    for (int i = 0; i < FP::MC; i++) {
+        Wd<4> u;
+        if (i == 0) {
+            u = wd_add<4>(wd_sub<4>(lv[0], wd_resize<4>(rem[0])), K0);
+            stB(c, brow, 0, fe_of_signed(c, lv[0]));
+            stB(c, brow, 1, fe_of(rem[0]));
+        } else if (i < L) {
+            Wd<4> vprev = wd_add<4>(wd_shl<4, 108>(wd_from_u64<1>(v_h)), wd_resize<4>(v_l));
+            u = wd_add<4>(wd_add<4>(wd_sub<4>(lv[i], wd_resize<4>(rem[i])), vprev), K1);
+            stB(c, brow, 0, fe_of_signed(c, lv[i]));
+            stB(c, brow, 1, fe_of(rem[i]));
+            stB(c, brow, 2, fe_u64(v_h));
+            stB(c, brow, 3, fe_of(v_l));
+        } else {
+            Wd<4> vprev = wd_add<4>(wd_shl<4, 108>(wd_from_u64<1>(v_h)), wd_resize<4>(v_l));
+            u = wd_add<4>(wd_add<4>(lv[i], vprev), K1);
+            stB(c, brow, 0, fe_of_signed(c, lv[i]));
+            stB(c, brow, 1, fe_u64(v_h));
+            stB(c, brow, 2, fe_of(v_l));
+        }
+        stB(c, brow, 4, u);
+        brow += 1;
+        if (wd_is_neg<4>(u) || !wd_is_zero<2>(wd_mask<108, 2>(wd_resize<2>(u)))) flag(c, H2E_STATUS_ARITH);
+        Wd<4> v = wd_shr<4, 108>(u);
+        v_l = wd_mask<108, 2>(wd_resize<2>(v));
+        v_h = wd_shr<1, 108>(v).v[0];
+        emit_common(c, rrow, v_h);
+        emit_limb3(c, rrow + 1, v_l);
+        rrow += 4;
+        stB(c, brow, 0, fe_u64(v_h));
+        stB(c, brow, 1, fe_of(v_l));
+        stB(c, brow, 4, u);
+        brow += 1;
+    }
+    // native row (integer_chip.rs:195-215)
+    stB(c, brow, 0, a.native);
+    stB(c, brow, 1, b.native);
+    stB(c, brow, 2, d_native);
+    stB(c, brow, 3, rem_native);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ops
+template <class FP>
+WI_INLINE void op_assign_w(const LC& c, const H2EOp& op) {
+    u32 slot = op.imm + ((op.flags & H2E_FLAG_INPUT_STRIDED) ? c.strand * c.input_stride : 0);
+    Wd<FP::WW> x = wd_load<FP::WW>(c.inputs + (size_t)slot * FP::WW);
+    Limb l[FP::L];
+    split_limbs<FP>(x, l);
+    emit_assigned<FP>(c, op.base_row, op.range_row, l, mod_n<FP::WW>(c, x));
+}
+
+template <class FP>
+WI_INLINE void op_const_int(const LC& c, const H2EOp& op, bool from_input) {
+    Wd<FP::WW> x;
+    if (from_input) {
+        u32 slot = op.imm + ((op.flags & H2E_FLAG_INPUT_STRIDED) ? c.strand * c.input_stride : 0);
+        x = wd_load<FP::WW>(c.inputs + (size_t)slot * FP::WW);
+    } else {
+        x = wd_load<FP::WW>(c.pool + op.imm);
+    }
+    Limb l[FP::L];
+    split_limbs<FP>(x, l);
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) stB(c, op.base_row + i, 0, fe_of(l[i]));
+    stB(c, op.base_row + FP::L, 0, mod_n<FP::WW>(c, x));
+}
+
+template <class FP>
+WI_INLINE void op_int_add(const LC& c, const H2EOp& op) {
+    IntVal<FP> a = ld_int<FP>(c, op.refs), b = ld_int<FP>(c, op.refs + FP::L + 1);
+    u32 r = op.base_row;
+    Limb s[FP::L];
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) {
+        s[i] = wd_add<2>(a.l[i], b.l[i]);
+        stB(c, r + i, 0, fe_of(a.l[i]));
+        stB(c, r + i, 1, fe_of(b.l[i]));
+        stB(c, r + i, 4, fe_of(s[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) stB(c, r + FP::L, i, fe_of(s[i]));
+    stB(c, r + FP::L, 4, addmod_n(c, a.native, b.native));
+}
+
+template <class FP>
+WI_INLINE void op_int_sub(const LC& c, const H2EOp& op) {
+    IntVal<FP> a = ld_int<FP>(c, op.refs), b = ld_int<FP>(c, op.refs + FP::L + 1);
+    u32 r = op.base_row, t = op.imm;
+    Limb s[FP::L];
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) {
+        Limb U = wd_load<2>(c.fc->ceil_limbs[t][i]);
+        s[i] = wd_sub<2>(wd_add<2>(a.l[i], U), b.l[i]);
+        stB(c, r + i, 0, fe_of(a.l[i]));
+        stB(c, r + i, 1, fe_of(b.l[i]));
+        stB(c, r + i, 4, fe_of(s[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) stB(c, r + FP::L, i, fe_of(s[i]));
+    Fe un = wd_load<4>(c.fc->ceil_native[t]);
+    stB(c, r + FP::L, 4, addmod_n(c, submod_n(c, a.native, b.native), un));
+}
+
+template <class FP>
+WI_INLINE void op_int_neg(const LC& c, const H2EOp& op) {
+    IntVal<FP> a = ld_int<FP>(c, op.refs);
+    u32 r = op.base_row, t = op.imm;
+    Limb s[FP::L];
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) {
+        Limb U = wd_load<2>(c.fc->ceil_limbs[t][i]);
+        s[i] = wd_sub<2>(U, a.l[i]);
+        stB(c, r + i, 0, fe_of(a.l[i]));
+        stB(c, r + i, 4, fe_of(s[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) stB(c, r + FP::L, i, fe_of(s[i]));
+    Fe un = wd_load<4>(c.fc->ceil_native[t]);
+    stB(c, r + FP::L, 4, submod_n(c, un, a.native));
+}
+
+template <class FP>
+WI_INLINE void op_int_mul_small(const LC& c, const H2EOp& op) {
+    IntVal<FP> a = ld_int<FP>(c, op.refs);
+    u32 r = op.base_row;
+    Wd<1> k = wd_from_u64<1>(op.imm);
+    Limb s[FP::L];
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) {
+        s[i] = wd_resize<2>(wd_mul<2, 1>(a.l[i], k));
+        stB(c, r + i, 0, fe_of(a.l[i]));
+        stB(c, r + i, 4, fe_of(s[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) stB(c, r + FP::L, i, fe_of(s[i]));
+    stB(c, r + FP::L, 4, mod_n<5>(c, wd_mul<4, 1>(a.native, k)));
+}
+
+template <class FP>
+WI_INLINE void op_int_mul(const LC& c, const H2EOp& op) {
+    constexpr int L = FP::L;
+    IntVal<FP> a = ld_int<FP>(c, op.refs), b = ld_int<FP>(c, op.refs + L + 1);
+    Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
+    Wd<FPX<FP>::XW> X = wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW>(A, B));
+    Wd<FPX<FP>::QW> dq;
+    Wd<FP::WW> rem;
+    divrem_w<FP>(c, X, dq, rem);
+    Limb rl[L], dl[L];
+    split_limbs<FP>(rem, rl);
+    split_limbs<FP>(dq, dl);
+    Fe rem_native = mod_n<FP::WW>(c, rem), d_native = mod_n<FPX<FP>::QW>(c, dq);
+    u32 rr = op.range_row;
+    rr += emit_assigned<FP>(c, op.base_row, rr, rl, rem_native);
+    rr += emit_assigned<FP>(c, op.base_row + 1, rr, dl, d_native);
+    emit_mul_equation<FP>(c, op.base_row + 2, rr, a, b, dl, d_native, rl, rem_native);
+}
+
+template <class FP>
+WI_INLINE void op_reduce(const LC& c, const H2EOp& op) {
+    constexpr int L = FP::L;
+    IntVal<FP> a = ld_int<FP>(c, op.refs);
+    Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l);
+    Wd<FPX<FP>::QW> dq;
+    Wd<FP::WW> rem;
+    divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(A), dq, rem);
+    u64 d = dq.v[0];
+    Limb rl[L];
+    split_limbs<FP>(rem, rl);
+    Fe rem_native = mod_n<FP::WW>(c, rem);
+    u32 rr = op.range_row, br = op.base_row;
+    rr += emit_assigned<FP>(c, br, rr, rl, rem_native);
+    emit_common(c, rr, d);
+    rr += 1;
+    // native row: [d * w_native, rem.native * 1 | a.native * (-1)]   (integer_chip.rs:303-311)
+    stB(c, br + 1, 0, fe_u64(d));
+    stB(c, br + 1, 1, rem_native);
+    stB(c, br + 1, 4, a.native);
+    br += 2;
+    Limb last_v = wd_zero<2>();
+#pragma unroll
+    for (int i = 0; i < FP::RC; i++) {
+        // u = d*w_i + rem_i + 64*2^108 - a_i + carry - (i ? 64 : 0)     (integer_chip.rs:332-346)
+        Limb wl = wd_load<2>(c.fc->w_limbs[i]);
+        Wd<4> u = wd_resize<4>(wd_mul<2, 1>(wl, wd_from_u64<1>(d)));
+        u = wd_add<4>(u, wd_resize<4>(rl[i]));
+        u = wd_add<4>(u, wd_shl<4, 108>(wd_from_u64<1>(64)));
+        u = wd_sub<4>(u, wd_resize<4>(a.l[i]));
+        u = wd_add<4>(u, wd_resize<4>(last_v));
+        if (i != 0) u = wd_sub<4>(u, wd_from_u64<4>(64));
+        if (wd_is_neg<4>(u) || !wd_is_zero<2>(wd_mask<108, 2>(wd_resize<2>(u)))) flag(c, H2E_STATUS_ARITH);
+        Limb v = wd_resize<2>(wd_shr<4, 108>(u));
+        emit_limb3(c, rr, v);
+        rr += 3;
+        stB(c, br, 0, fe_u64(d));
+        stB(c, br, 1, fe_of(rl[i]));
+        stB(c, br, 2, fe_of(a.l[i]));
+        stB(c, br, 3, fe_of(last_v));  // pair!(zero, zero) placeholder for i == 0 (quirk Q5)
+        stB(c, br, 4, fe_of(v));
+        br += 1;
+        last_v = v;
+    }
+}
+
+// invert rows for one value (base_chip.rs:298-321): [a, c] ; [a, b | c]
+WI_INLINE void emit_invert(const LC& c, u32 row, const Fe& a, const Fe& inv) {
+    Fe cc = fe_u64(wd_is_zero<4>(a) ? 1 : 0);
+    stB(c, row, 0, a);
+    stB(c, row, 1, cc);
+    stB(c, row + 1, 0, a);
+    stB(c, row + 1, 1, inv);
+    stB(c, row + 1, 4, cc);
+}
+
+template <class FP>
+WI_INLINE void op_is_int_zero(const LC& c, const H2EOp& op) {
+    constexpr int L = FP::L, NI = 2 + FP::PW;
+    IntVal<FP> a = ld_int<FP>(c, op.refs);
+    // values whose inverses are witnessed
+    Fe x[NI];
+    Limb sum = a.l[0];
+#pragma unroll
+    for (int i = 1; i < L; i++) sum = wd_add<2>(sum, a.l[i]);
+    x[0] = fe_of(sum);
+    x[1] = submod_n(c, a.native, wd_load<4>(c.fc->w_native));
+#pragma unroll
+    for (int i = 0; i < FP::PW; i++) x[2 + i] = submod_n(c, fe_of(a.l[i]), fe_of(wd_load<2>(c.fc->w_limbs[i])));
+    // Montgomery's trick: one inversion for all of them (zeros are skipped)
+    Fe pre[NI];
+    Fe acc = fe_u64(1);
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        pre[i] = acc;
+        if (!wd_is_zero<4>(x[i])) acc = mulmod_n(c, acc, x[i]);
+    }
+    Fe ainv = inv_n(c, acc);
+    Fe inv[NI];
+#pragma unroll
+    for (int i = NI - 1; i >= 0; i--) {
+        if (wd_is_zero<4>(x[i])) {
+            inv[i] = wd_zero<4>();
+        } else {
+            inv[i] = mulmod_n(c, ainv, pre[i]);
+            ainv = mulmod_n(c, ainv, x[i]);
+        }
+    }
+    u32 r = op.base_row;
+    // is_pure_zero (integer_chip.rs:540-548)
+#pragma unroll
+    for (int i = 0; i < L; i++) stB(c, r, i, fe_of(a.l[i]));
+    stB(c, r, 4, x[0]);
+    emit_invert(c, r + 1, x[0], inv[0]);
+    u64 is_zero = wd_is_zero<4>(x[0]) ? 1 : 0;
+    r += 3;
+    // is_pure_w_modulus (integer_chip.rs:550-570)
+    stB(c, r, 0, a.native);
+    stB(c, r, 4, x[1]);
+    emit_invert(c, r + 1, x[1], inv[1]);
+    u64 is_eq = wd_is_zero<4>(x[1]) ? 1 : 0;
+    r += 3;
+#pragma unroll
+    for (int i = 0; i < FP::PW; i++) {
+        stB(c, r, 0, fe_of(a.l[i]));
+        stB(c, r, 4, x[2 + i]);
+        emit_invert(c, r + 1, x[2 + i], inv[2 + i]);
+        u64 is_limb_eq = wd_is_zero<4>(x[2 + i]) ? 1 : 0;
+        stB(c, r + 3, 0, fe_u64(is_eq));
+        stB(c, r + 3, 1, fe_u64(is_limb_eq));
+        stB(c, r + 3, 4, fe_u64(is_eq & is_limb_eq));
+        is_eq &= is_limb_eq;
+        r += 4;
+    }
+    // or (base_chip.rs:428-439)
+    stB(c, r, 0, fe_u64(is_zero));
+    stB(c, r, 1, fe_u64(is_eq));
+    stB(c, r, 4, fe_u64(is_zero | is_eq));
+}
+
+template <class FP>
+WI_INLINE void op_mask_int(const LC& c, const H2EOp& op) {
+    constexpr int L = FP::L;
+    IntVal<FP> a = ld_int<FP>(c, op.refs);
+    Fe coeff = ld_fe(c, op.refs[L + 1]);
+    bool keep = !wd_is_zero<4>(coeff);
+    u32 r = op.base_row;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+        stB(c, r + i, 0, fe_of(a.l[i]));
+        stB(c, r + i, 1, coeff);
+        stB(c, r + i, 4, keep ? fe_of(a.l[i]) : wd_zero<4>());
+    }
+    stB(c, r + L, 0, a.native);
+    stB(c, r + L, 1, coeff);
+    stB(c, r + L, 4, keep ? a.native : wd_zero<4>());
+}
+
+// int_div core (integer_chip.rs:522-535): refs = b (L+1), a' (L+1)
+template <class FP>
+WI_INLINE void op_div_core(const LC& c, const H2EOp& op) {
+    constexpr int L = FP::L;
+    IntVal<FP> b = ld_int<FP>(c, op.refs), a = ld_int<FP>(c, op.refs + L + 1);
+    Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
+    Wd<FP::WW> w = wd_load<FP::WW>(c.fc->w);
+    // canonical representatives mod w (bn_to_field::<W>)
+    Wd<FPX<FP>::QW> q0;
+    Wd<FP::WW> a_red, b_red;
+    divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(A), q0, a_red);
+    divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(B), q0, b_red);
+    Wd<FP::WW> binv = wd_inv_mod<FP::WW>(b_red, w);
+    Wd<FP::WW> cv;
+    divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FP::WW, FP::WW>(a_red, binv)), q0, cv);
+    // d = (b*c - a) / w   (exact)
+    Wd<FPX<FP>::XW> bc = wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FP::WW>(B, cv));
+    Wd<FPX<FP>::XW> num = wd_sub<FPX<FP>::XW>(bc, wd_resize<FPX<FP>::XW>(A));
+    Wd<FPX<FP>::QW> dq;
+    Wd<FP::WW> rz;
+    divrem_w<FP>(c, num, dq, rz);
+    if (wd_is_neg<FPX<FP>::XW>(num) || !wd_is_zero<FP::WW>(rz)) flag(c, H2E_STATUS_ARITH);
+    Limb cl[L], dl[L];
+    split_limbs<FP>(cv, cl);
+    split_limbs<FP>(dq, dl);
+    Fe c_native = mod_n<FP::WW>(c, cv), d_native = mod_n<FPX<FP>::QW>(c, dq);
+    u32 rr = op.range_row;
+    rr += emit_assigned<FP>(c, op.base_row, rr, cl, c_native);
+    rr += emit_assigned<FP>(c, op.base_row + 1, rr, dl, d_native);
+    IntVal<FP> cvv;
+#pragma unroll
+    for (int i = 0; i < L; i++) cvv.l[i] = cl[i];
+    cvv.native = c_native;
+    emit_mul_equation<FP>(c, op.base_row + 2, rr, b, cvv, dl, d_native, a.l, a.native);
+}
+
+template <class FP>
+WI_INLINE void op_bisec_int(const LC& c, const H2EOp& op) {
+    constexpr int L = FP::L;
+    Fe cond = ld_fe(c, op.refs[0]);
+    bool take_a = !wd_is_zero<4>(cond);
+    u32 r = op.base_row;
+#pragma unroll
+    for (int i = 0; i <= L; i++) {
+        Fe av = ld_fe(c, op.refs[1 + i]), bv = ld_fe(c, op.refs[1 + L + 1 + i]);
+        stB(c, r + i, 0, cond);
+        stB(c, r + i, 1, av);
+        stB(c, r + i, 2, cond);
+        stB(c, r + i, 3, bv);
+        stB(c, r + i, 4, take_a ? av : bv);
+    }
+}
+
+template <class FP>
+WI_INLINE void op_sum_limbs(const LC& c, const H2EOp& op) {
+    Limb sum = wd_zero<2>();
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) {
+        Limb l = ld_limb(c, op.refs[i]);
+        stB(c, op.base_row, i, fe_of(l));
+        sum = wd_add<2>(sum, l);
+    }
+    stB(c, op.base_row, 4, fe_of(sum));
+}
+
+WI_INLINE void op_assert_const(const LC& c, const H2EOp& op) {
+    Fe x = ld_fe(c, op.refs[0]);
+    stB(c, op.base_row, 0, x);
+    if (!wd_eq<4>(x, fe_u64(op.imm))) {
+        u32 bits = H2E_STATUS_ASSERT_FAILED;
+        if (op.flags & H2E_FLAG_UNSAFE_ADD) bits |= H2E_STATUS_RETRY_ADD_SAME_OR_NEG;
+        if (op.flags & H2E_FLAG_UNSAFE_DBL) bits |= H2E_STATUS_RETRY_ADD_IDENTITY;
+        flag(c, bits);
+    }
+}
+
+// native decompose_scalar::<1> (native_scalar_ecc_chip.rs:97-171): NUM_BITS/2 x [bit, bit, recombine] + assert
+WI_INLINE void op_decompose_native(const LC& c, const H2EOp& op) {
+    Fe s = ld_fe(c, op.refs[0]);
+    u32 r = op.base_row;
+    u32 nbits = op.imm;
+    Fe v = s;
+    for (u32 i = 0; i < nbits / 2; i++) {
+        u64 b0 = v.v[0] & 1, b1 = (v.v[0] >> 1) & 1;
+        Fe vn = wd_shr1<4>(wd_shr1<4>(v));
+        stB(c, r, 0, fe_u64(b0));
+        stB(c, r, 1, fe_u64(b0));
+        stB(c, r + 1, 0, fe_u64(b1));
+        stB(c, r + 1, 1, fe_u64(b1));
+        stB(c, r + 2, 0, vn);
+        stB(c, r + 2, 1, fe_u64(b1));
+        stB(c, r + 2, 2, fe_u64(b0));
+        stB(c, r + 2, 4, v);
+        r += 3;
+        v = vn;
+    }
+    // even NUM_BITS: assert_constant(v, 0); odd: assert_bit(v)
+    if (nbits & 1) {
+        stB(c, r, 0, v);
+        stB(c, r, 1, v);
+    } else {
+        stB(c, r, 0, v);
+        if (!wd_is_zero<4>(v)) flag(c, H2E_STATUS_ASSERT_FAILED);
+    }
+}
+
+// index = sum bit_i * 2^i over imm (<= 5) bit cells (ecc_chip.rs:941-948; sum_with_constant splits at 5 terms)
+WI_INLINE void op_pick_index(const LC& c, const H2EOp& op) {
+    u32 k = op.imm, r = op.base_row;
+    u64 bits[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) bits[i] = (i < (int)k) ? ld_fe(c, op.refs[i]).v[0] : 0;
+    if (k < 5) {
+        u64 idx = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (i < (int)k) {
+                stB(c, r, i, fe_u64(bits[i]));
+                idx |= bits[i] << i;
+            }
+        stB(c, r, 4, fe_u64(idx));
+    } else {
+        u64 acc = bits[0] | (bits[1] << 1) | (bits[2] << 2) | (bits[3] << 3);
+#pragma unroll
+        for (int i = 0; i < 4; i++) stB(c, r, i, fe_u64(bits[i]));
+        stB(c, r, 4, fe_u64(acc));
+        stB(c, r + 1, 0, fe_u64(bits[4]));
+        stB(c, r + 1, 1, fe_u64(acc));
+        stB(c, r + 1, 4, fe_u64(acc | (bits[4] << 4)));
+    }
+}
+
+template <class FP>
+WI_INLINE void op_cache_int(const LC& c, const H2EOp& op) {
+#pragma unroll
+    for (int i = 0; i <= FP::L; i++) stS(c, op.select_row + i, 0, ld_fe(c, op.refs[i]));
+}
+
+// assign_selected_point_non_zero: refs[0] = index cell, imm = aux offset of the candidate ref table
+// [n_candidates][2*(L+1)] (ecc_chip.rs:949-967)
+template <class FP>
+WI_INLINE void op_select_point(const LC& c, const H2EOp& op) {
+    constexpr int NC = 2 * (FP::L + 1);
+    Fe index = ld_fe(c, op.refs[0]);
+    u32 idx = (u32)(index.v[0] & 0xff);
+    const u32* tab = c.aux + op.imm + idx * NC;
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+        stS(c, op.select_row + j, 0, ld_fe(c, tab[j]));
+        stS(c, op.select_row + j, 1, index);
+    }
+}
+
+template <class FP>
+WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
+    switch (op.opcode) {
+        case H2E_OP_ASSIGN_W: op_assign_w<FP>(c, op); break;
+        case H2E_OP_ASSIGN: {
+            u32 slot = op.imm + ((op.flags & H2E_FLAG_INPUT_STRIDED) ? c.strand * c.input_stride : 0);
+            stB(c, op.base_row, 0, wd_load<4>(c.inputs + (size_t)slot * FP::WW));
+        } break;
+        case H2E_OP_ASSIGN_BIT: {
+            u32 slot = op.imm + ((op.flags & H2E_FLAG_INPUT_STRIDED) ? c.strand * c.input_stride : 0);
+            Fe v = wd_load<4>(c.inputs + (size_t)slot * FP::WW);
+            stB(c, op.base_row, 0, v);
+            stB(c, op.base_row, 1, v);
+        } break;
+        case H2E_OP_CONST_INT: op_const_int<FP>(c, op, false); break;
+        case H2E_OP_CONST_INT_INPUT: op_const_int<FP>(c, op, true); break;
+        case H2E_OP_CONST: stB(c, op.base_row, 0, wd_load<4>(c.pool + op.imm)); break;
+        case H2E_OP_INT_ADD: op_int_add<FP>(c, op); break;
+        case H2E_OP_INT_SUB: op_int_sub<FP>(c, op); break;
+        case H2E_OP_INT_NEG: op_int_neg<FP>(c, op); break;
+        case H2E_OP_INT_MUL_SMALL: op_int_mul_small<FP>(c, op); break;
+        case H2E_OP_INT_MUL: op_int_mul<FP>(c, op); break;
+        case H2E_OP_REDUCE: op_reduce<FP>(c, op); break;
+        case H2E_OP_IS_INT_ZERO: op_is_int_zero<FP>(c, op); break;
+        case H2E_OP_NOT: {
+            Fe x = ld_fe(c, op.refs[0]);
+            stB(c, op.base_row, 0, x);
+            stB(c, op.base_row, 4, submod_n(c, fe_u64(1), x));
+        } break;
+        case H2E_OP_MASK_INT: op_mask_int<FP>(c, op); break;
+        case H2E_OP_DIV_CORE: op_div_core<FP>(c, op); break;
+        case H2E_OP_BISEC_INT: op_bisec_int<FP>(c, op); break;
+        case H2E_OP_SUM_LIMBS: op_sum_limbs<FP>(c, op); break;
+        case H2E_OP_ASSERT_CONST: op_assert_const(c, op); break;
+        case H2E_OP_BISEC: {
+            Fe cond = ld_fe(c, op.refs[0]), a = ld_fe(c, op.refs[1]), b = ld_fe(c, op.refs[2]);
+            stB(c, op.base_row, 0, cond);
+            stB(c, op.base_row, 1, a);
+            stB(c, op.base_row, 2, cond);
+            stB(c, op.base_row, 3, b);
+            stB(c, op.base_row, 4, wd_is_zero<4>(cond) ? b : a);
+        } break;
+        case H2E_OP_AND: {
+            Fe a = ld_fe(c, op.refs[0]), b = ld_fe(c, op.refs[1]);
+            stB(c, op.base_row, 0, a);
+            stB(c, op.base_row, 1, b);
+            stB(c, op.base_row, 4, fe_u64(a.v[0] & b.v[0]));
+        } break;
+        case H2E_OP_OR: {
+            Fe a = ld_fe(c, op.refs[0]), b = ld_fe(c, op.refs[1]);
+            stB(c, op.base_row, 0, a);
+            stB(c, op.base_row, 1, b);
+            stB(c, op.base_row, 4, fe_u64(a.v[0] | b.v[0]));
+        } break;
+        case H2E_OP_XNOR: {
+            Fe a = ld_fe(c, op.refs[0]), b = ld_fe(c, op.refs[1]);
+            stB(c, op.base_row, 0, a);
+            stB(c, op.base_row, 1, b);
+            stB(c, op.base_row, 4, fe_u64(1 ^ a.v[0] ^ b.v[0]));
+        } break;
+        case H2E_OP_DECOMPOSE_NATIVE: op_decompose_native(c, op); break;
+        case H2E_OP_PICK_INDEX: op_pick_index(c, op); break;
+        case H2E_OP_CACHE_INT: op_cache_int<FP>(c, op); break;
+        case H2E_OP_SELECT_POINT: op_select_point<FP>(c, op); break;
+        default: break;
+    }
+}
+
+template <class FP>
+__global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDesc* inst, u32 n_instances,
+                                                   const H2EFieldConsts* fc) {
+    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 total = n_instances * L.n_strands;
+    if (gid >= total) return;
+    u32 instance = gid / L.n_strands, strand = gid % L.n_strands;
+    InstanceDesc d = inst[instance];
+    LC c;
+    c.base = d.base;
+    c.range = d.range;
+    c.select = d.select;
+    c.inputs = d.inputs;
+    c.status = d.status;
+    c.ob = L.strand_base0 + strand * L.delta_base;
+    c.orr = L.strand_range0 + strand * L.delta_range;
+    c.os = L.strand_select0 + strand * L.delta_select;
+    c.params = L.params + (size_t)strand * L.n_params;
+    c.aux = L.aux;
+    c.pool = L.const_pool;
+    c.fc = fc;
+    c.strand = strand;
+    c.input_stride = L.input_stride;
+    for (u32 i = 0; i < L.n_ops; i++) {
+        H2EOp op = L.tape[i];
+        exec_op<FP>(c, op);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-callable launcher (C linkage, used by the C-ABI layer in h2e_capi.cpp)
+extern "C" int h2e_engine_launch(int field_pair, const H2ELaunch* launch, const void* instances, uint32_t n_instances,
+                                 const H2EFieldConsts* fc_dev, hipStream_t stream) {
+    u32 total = n_instances * launch->n_strands;
+    if (total == 0 || launch->n_ops == 0) return 0;
+    dim3 block(64), grid((total + 63) / 64);
+    const InstanceDesc* inst = (const InstanceDesc*)instances;
+    switch (field_pair) {
+        case 0: hipLaunchKernelGGL(h2e_run_tape<FP_BN256_FQ>, grid, block, 0, stream, *launch, inst, n_instances, fc_dev); break;
+        case 1: hipLaunchKernelGGL(h2e_run_tape<FP_BLS_FQ>, grid, block, 0, stream, *launch, inst, n_instances, fc_dev); break;
+        case 2: hipLaunchKernelGGL(h2e_run_tape<FP_BLS_FR>, grid, block, 0, stream, *launch, inst, n_instances, fc_dev); break;
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}

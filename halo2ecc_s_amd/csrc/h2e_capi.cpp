@@ -1,0 +1,437 @@
+// C ABI of the witness engine (include/h2e.h): program recording (host) + execution (HIP).
+#include <hip/hip_runtime.h>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include "../../include/h2e.h"
+#include "recorder_pairing.hpp"
+
+extern "C" int h2e_engine_launch(int field_pair, const H2ELaunch* launch, const void* instances, uint32_t n_instances,
+                                 const H2EFieldConsts* fc_dev, hipStream_t stream);
+
+namespace {
+
+thread_local std::string g_last_error;
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) return fail(H2E_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+const h2e::FieldPair& field_pair(int id) {
+    static std::mutex mu;
+    static std::unique_ptr<h2e::FieldPair> fps[3];
+    std::lock_guard<std::mutex> g(mu);
+    if (!fps[id]) fps[id].reset(new h2e::FieldPair(id));
+    return *fps[id];
+}
+
+struct InstanceDescHost {  // must match engine.hip InstanceDesc
+    uint64_t* base;
+    uint64_t* range;
+    uint64_t* select;
+    const uint64_t* inputs;
+    uint32_t* status;
+};
+
+}  // namespace
+
+struct h2e_program {
+    int field_pair;
+    std::unique_ptr<h2e::Recorder> rec;
+    uint64_t base_rows = 0, range_rows = 0, select_rows = 0;
+    std::vector<uint32_t> perm_flat, patch_flat;
+    // device copies (per device), created on first run
+    int device = -1;
+    H2EOp* d_tape = nullptr;
+    uint32_t* d_aux = nullptr;
+    uint64_t* d_pool = nullptr;
+    uint32_t* d_params = nullptr;
+    InstanceDescHost* d_inst = nullptr;
+    uint32_t inst_cap = 0;
+    std::vector<InstanceDescHost> h_inst;
+
+    ~h2e_program() {
+        if (device >= 0) {
+            (void)hipFree(d_tape);
+            (void)hipFree(d_aux);
+            (void)hipFree(d_pool);
+            (void)hipFree(d_params);
+            (void)hipFree(d_inst);
+        }
+    }
+    void finish() {
+        h2e::Recorder& r = *rec;
+        r.close_segment();
+        base_rows = std::max<uint64_t>(r.base_height, r.base_offset) + 1;
+        range_rows = std::max<uint64_t>(r.range_height, r.range_offset) + 1;
+        select_rows = std::max<uint64_t>(r.select_height, r.select_offset) + 1;
+        if (r.emit_shape) {
+            r.base_fix.resize(base_rows * 9, 0);
+            r.range_fix.resize(range_rows * 2, 0);
+            r.select_fix.resize(select_rows * 2, 0);
+            r.base_flags.resize(base_rows * 5, 0);
+            r.range_flags.resize(range_rows * 3, 0);
+            r.select_flags.resize(select_rows * 2, 0);
+            perm_flat.reserve(r.permutations.size() * 2);
+            for (auto& p : r.permutations) {
+                perm_flat.push_back(p.first);
+                perm_flat.push_back(p.second);
+            }
+            for (auto& f : r.fixed_patches) {
+                patch_flat.push_back(f.row);
+                patch_flat.push_back(f.col);
+                patch_flat.push_back(f.input_slot);
+                patch_flat.push_back((uint32_t)f.limb);
+            }
+        }
+    }
+};
+
+struct h2e_ctx {
+    int device;
+    H2EFieldConsts* d_fc[3] = {nullptr, nullptr, nullptr};
+    std::map<std::string, h2e_program*> cache;
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;
+    uint32_t n_launches = 0;
+    ~h2e_ctx() {
+        for (auto& kv : cache) delete kv.second;
+        for (int i = 0; i < 3; i++)
+            if (d_fc[i]) (void)hipFree(d_fc[i]);
+        for (auto e : ev) (void)hipEventDestroy(e);
+    }
+};
+
+extern "C" {
+
+const char* h2e_last_error(void) { return g_last_error.c_str(); }
+const char* h2e_version(void) { return "h2e 0.1 (gfx950)"; }
+
+int h2e_ctx_create(int device, h2e_ctx** out) {
+    if (!out) return fail(H2E_ERR_INVALID, "out is null");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) return fail(H2E_ERR_HIP, "no HIP device available: the witness engine has no CPU fallback");
+    if (device < 0 || device >= count) return fail(H2E_ERR_INVALID, "bad device index");
+    h2e_ctx* c = new h2e_ctx();
+    c->device = device;
+    *out = c;
+    return 0;
+}
+void h2e_ctx_destroy(h2e_ctx* ctx) { delete ctx; }
+void h2e_program_destroy(h2e_program* p) { delete p; }
+
+static int new_program(int fp, int emit_shape, h2e_program** out, h2e_program*& p) {
+    if (!out) return fail(H2E_ERR_INVALID, "out is null");
+    if (fp < 0 || fp > 2) return fail(H2E_ERR_INVALID, "bad field pair");
+    p = new h2e_program();
+    p->field_pair = fp;
+    p->rec.reset(new h2e::Recorder(field_pair(fp)));
+    p->rec->emit_shape = emit_shape != 0;
+    return 0;
+}
+#define GUARDED(...)                                    \
+    try {                                               \
+        __VA_ARGS__                                     \
+    } catch (std::exception & e) {                      \
+        delete p;                                       \
+        return fail(H2E_ERR_SHAPE, e.what());           \
+    }
+
+int h2e_program_int_mul_batch(int fp, uint32_t n, int emit_shape, h2e_program** out) {
+    h2e_program* p = nullptr;
+    int rc = new_program(fp, emit_shape, out, p);
+    if (rc) return rc;
+    GUARDED({
+        h2e::Recorder& r = *p->rec;
+        uint32_t s0 = r.alloc_inputs(2 * n);
+        r.fork(n, 2, [&](uint32_t) {
+            h2e::AssignedInteger a = r.assign_w(s0, true);
+            h2e::AssignedInteger b = r.assign_w(s0 + 1, true);
+            r.int_mul(a, b);
+        });
+        p->finish();
+    })
+    *out = p;
+    return 0;
+}
+
+int h2e_program_integer_chip_st(int fp, int emit_shape, h2e_program** out) {
+    h2e_program* p = nullptr;
+    int rc = new_program(fp, emit_shape, out, p);
+    if (rc) return rc;
+    GUARDED({
+        h2e::Recorder& r = *p->rec;
+        uint32_t s = r.alloc_inputs(6);
+        h2e::AssignedInteger a = r.assign_w(s + 0), b = r.assign_w(s + 1);
+        h2e::AssignedInteger c1 = r.assign_w(s + 2);
+        h2e::AssignedInteger c2 = r.int_add(a, b);
+        r.assert_int_equal(c1, c2);
+        h2e::AssignedInteger d1 = r.assign_w(s + 3);
+        h2e::AssignedInteger d2 = r.int_sub(a, b);
+        r.assert_int_equal(d1, d2);
+        h2e::AssignedInteger e1 = r.assign_w(s + 4);
+        h2e::AssignedInteger e2 = r.int_mul(a, b);
+        r.assert_int_equal(e1, e2);
+        h2e::AssignedInteger f1 = r.assign_w(s + 5);
+        h2e::AssignedInteger f2 = r.int_div(a, b).second;
+        r.assert_int_equal(f1, f2);
+        h2e::AssignedInteger zero = r.int_sub(a, a);
+        auto g = r.int_div(a, zero);
+        r.assert_true(g.first);
+        p->finish();
+    })
+    *out = p;
+    return 0;
+}
+
+int h2e_program_msm_bn256_tile(uint32_t n, int emit_shape, h2e_program** out) {
+    h2e_program* p = nullptr;
+    if (n == 0) return fail(H2E_ERR_INVALID, "n_points must be > 0");
+    int rc = new_program(H2E_FIELD_BN256_FQ, emit_shape, out, p);
+    if (rc) return rc;
+    GUARDED({
+        h2e::Recorder& r = *p->rec;
+        uint32_t s = r.alloc_inputs(4 * n + 9);
+        h2e::NativeScalarEccContext ecc(r, h2e::bn256_g1_params(), 0);
+        h2e::NativeScalarEccContext::MsmInputs mi{s + 4 * n + 2, s + 4 * n + 3, s + 4 * n + 4, s + 4 * n + 5};
+        h2e::AssignedPoint res = ecc.msm_unsafe_from_inputs(n, s, mi, s + 4 * n, s + 4 * n + 1);
+        h2e::AssignedPoint res_expect = ecc.assign_point(h2e::PointInput{s + 4 * n + 6, s + 4 * n + 7, s + 4 * n + 8, false});
+        ecc.ecc_assert_equal(res, res_expect);
+        p->finish();
+    })
+    *out = p;
+    return 0;
+}
+
+int h2e_program_pairing_check_bn256(int emit_shape, h2e_program** out) {
+    h2e_program* p = nullptr;
+    int rc = new_program(H2E_FIELD_BN256_FQ, emit_shape, out, p);
+    if (rc) return rc;
+    GUARDED({
+        h2e::Recorder& r = *p->rec;
+        uint32_t s = r.alloc_inputs(10);
+        h2e::NativeScalarEccContext ecc(r, h2e::bn256_g1_params(), 0);
+        h2e::Bn256PairingOps po(r);
+        h2e::AssignedFq2 bx{r.assign_int_constant_input(s + 0), r.assign_int_constant_input(s + 1)};
+        h2e::AssignedFq2 by{r.assign_int_constant_input(s + 2), r.assign_int_constant_input(s + 3)};
+        h2e::AssignedG2Affine B{bx, by, h2e::AssignedCondition{r.assign_constant_u64(0)}};
+        h2e::AssignedPoint neg_a = ecc.assign_point(h2e::PointInput{s + 4, s + 5, s + 6, false});
+        h2e::AssignedPoint a = ecc.assign_point(h2e::PointInput{s + 7, s + 8, s + 9, false});
+        po.check_pairing({h2e::PairingOps::Term(&a, &B), h2e::PairingOps::Term(&neg_a, &B)});
+        p->finish();
+    })
+    *out = p;
+    return 0;
+}
+
+int h2e_program_pairing_check_bls12_381(int emit_shape, h2e_program** out) {
+    h2e_program* p = nullptr;
+    int rc = new_program(H2E_FIELD_BLS12_381_FQ, emit_shape, out, p);
+    if (rc) return rc;
+    GUARDED({
+        h2e::Recorder& r = *p->rec;
+        uint32_t s = r.alloc_inputs(14);
+        h2e::NativeScalarEccContext ecc(r, h2e::bls12_381_g1_params(), 0);  // EccChipBaseOps of GeneralScalarEccContext
+        h2e::Bls12381PairingOps po(r);
+        h2e::AssignedFq2 bx{r.assign_int_constant_input(s + 0), r.assign_int_constant_input(s + 1)};
+        h2e::AssignedFq2 by{r.assign_int_constant_input(s + 2), r.assign_int_constant_input(s + 3)};
+        h2e::AssignedG2Affine B{bx, by, h2e::AssignedCondition{r.assign_constant_u64(0)}};
+        h2e::AssignedFq2 bcx{r.assign_int_constant_input(s + 4), r.assign_int_constant_input(s + 5)};
+        h2e::AssignedFq2 bcy{r.assign_int_constant_input(s + 6), r.assign_int_constant_input(s + 7)};
+        h2e::AssignedG2Affine BC{bcx, bcy, h2e::AssignedCondition{r.assign_constant_u64(0)}};
+        h2e::AssignedPoint neg_a = ecc.assign_point(h2e::PointInput{s + 8, s + 9, s + 10, false});
+        h2e::AssignedPoint ac = ecc.assign_point(h2e::PointInput{s + 11, s + 12, s + 13, false});
+        po.check_pairing({h2e::PairingOps::Term(&ac, &B), h2e::PairingOps::Term(&neg_a, &BC)});
+        p->finish();
+    })
+    *out = p;
+    return 0;
+}
+
+int h2e_program_shape(const h2e_program* p, h2e_shape* out) {
+    if (!p || !out) return fail(H2E_ERR_INVALID, "null argument");
+    const h2e::Recorder& r = *p->rec;
+    std::memset(out, 0, sizeof(*out));
+    out->field_pair = p->field_pair;
+    out->slot_words = r.fp.w_words;
+    out->n_input_slots = r.n_input_slots;
+    out->base_offset = r.base_offset;
+    out->range_offset = r.range_offset;
+    out->select_offset = r.select_offset;
+    out->base_height = r.base_height;
+    out->range_height = r.range_height;
+    out->select_height = r.select_height;
+    out->base_rows = p->base_rows;
+    out->range_rows = p->range_rows;
+    out->select_rows = p->select_rows;
+    out->n_advice_cells = r.n_advice_cells;
+    out->n_permutations = r.permutations.size();
+    out->n_dict = r.dict.size();
+    out->n_fixed_patches = r.fixed_patches.size();
+    uint32_t nseg = 0;
+    for (auto& s : r.segments)
+        if (s.tape_end > s.tape_begin) nseg++;
+    out->n_segments = nseg;
+    out->n_ops = r.tape.size();
+    if (r.emit_shape) {
+        out->dict = (const uint64_t*)r.dict.data();
+        out->base_fix = r.base_fix.data();
+        out->range_fix = r.range_fix.data();
+        out->select_fix = r.select_fix.data();
+        out->base_flags = r.base_flags.data();
+        out->range_flags = r.range_flags.data();
+        out->select_flags = r.select_flags.data();
+        out->permutations = p->perm_flat.data();
+        out->fixed_patches = p->patch_flat.data();
+    }
+    return 0;
+}
+
+static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
+    if (p->device == ctx->device) return 0;
+    if (p->device >= 0) return fail(H2E_ERR_INVALID, "program already bound to another device");
+    h2e::Recorder& r = *p->rec;
+    HIP_TRY(hipSetDevice(ctx->device));
+    auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
+        if (bytes == 0) bytes = 16;
+        hipError_t e = hipMalloc(d, bytes);
+        if (e != hipSuccess) return e;
+        if (h) return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+        return hipSuccess;
+    };
+    HIP_TRY(up((void**)&p->d_tape, r.tape.empty() ? nullptr : r.tape.data(), r.tape.size() * sizeof(H2EOp)));
+    HIP_TRY(up((void**)&p->d_aux, r.aux.empty() ? nullptr : r.aux.data(), r.aux.size() * 4));
+    HIP_TRY(up((void**)&p->d_pool, r.pool.empty() ? nullptr : r.pool.data(), r.pool.size() * 8));
+    HIP_TRY(up((void**)&p->d_params, r.params.empty() ? nullptr : r.params.data(), r.params.size() * 4));
+    p->device = ctx->device;
+    return 0;
+}
+
+int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
+            void* d_select, void* d_status, void* stream_) {
+    if (!ctx || !p) return fail(H2E_ERR_INVALID, "null ctx/program");
+    if (n_instances == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_device_program(ctx, p);
+    if (rc) return rc;
+    int fp = p->field_pair;
+    if (!ctx->d_fc[fp]) {
+        HIP_TRY(hipMalloc((void**)&ctx->d_fc[fp], sizeof(H2EFieldConsts)));
+        HIP_TRY(hipMemcpy(ctx->d_fc[fp], &field_pair(fp).fc, sizeof(H2EFieldConsts), hipMemcpyHostToDevice));
+    }
+    h2e::Recorder& r = *p->rec;
+    // instance descriptors
+    if (p->inst_cap < n_instances) {
+        if (p->d_inst) HIP_TRY(hipFree(p->d_inst));
+        HIP_TRY(hipMalloc((void**)&p->d_inst, (size_t)n_instances * sizeof(InstanceDescHost)));
+        p->inst_cap = n_instances;
+    }
+    p->h_inst.resize(n_instances);
+    size_t slot_words = r.fp.w_words;
+    for (uint32_t i = 0; i < n_instances; i++) {
+        InstanceDescHost& d = p->h_inst[i];
+        d.base = (uint64_t*)d_base + (size_t)i * p->base_rows * 5 * 4;
+        d.range = (uint64_t*)d_range + (size_t)i * p->range_rows * 3 * 4;
+        d.select = (uint64_t*)d_select + (size_t)i * p->select_rows * 2 * 4;
+        d.inputs = (const uint64_t*)d_inputs + (size_t)i * r.n_input_slots * slot_words;
+        d.status = (uint32_t*)d_status + i;
+    }
+    HIP_TRY(hipMemcpyAsync(p->d_inst, p->h_inst.data(), (size_t)n_instances * sizeof(InstanceDescHost),
+                           hipMemcpyHostToDevice, stream));
+    ctx->n_launches = 0;
+    for (auto& s : r.segments) {
+        if (s.tape_end <= s.tape_begin) continue;
+        H2ELaunch L;
+        L.tape = p->d_tape + s.tape_begin;
+        L.n_ops = s.tape_end - s.tape_begin;
+        L.n_strands = s.n_strands;
+        L.strand_base0 = s.base0;
+        L.strand_range0 = s.range0;
+        L.strand_select0 = s.select0;
+        L.delta_base = s.dbase;
+        L.delta_range = s.drange;
+        L.delta_select = s.dselect;
+        L.input_stride = s.input_stride;
+        L.n_params = s.n_params;
+        L.params = p->d_params + s.params_begin;
+        L.aux = p->d_aux;
+        L.const_pool = p->d_pool;
+        if (ctx->profiling) {
+            while (ctx->ev.size() < 2 * (size_t)(ctx->n_launches + 1)) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreate(&e));
+                ctx->ev.push_back(e);
+            }
+            HIP_TRY(hipEventRecord(ctx->ev[2 * ctx->n_launches], stream));
+        }
+        int lrc = h2e_engine_launch(fp, &L, p->d_inst, n_instances, ctx->d_fc[fp], stream);
+        if (lrc != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)lrc));
+        if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[2 * ctx->n_launches + 1], stream));
+        ctx->n_launches++;
+    }
+    return 0;
+}
+
+int h2e_set_profiling(h2e_ctx* ctx, int enable) {
+    if (!ctx) return fail(H2E_ERR_INVALID, "null ctx");
+    ctx->profiling = enable != 0;
+    return 0;
+}
+int h2e_last_run_launch_ms(h2e_ctx* ctx, float* ms, uint32_t cap) {
+    if (!ctx) return fail(H2E_ERR_INVALID, "null ctx");
+    if (!ctx->profiling) return 0;
+    for (uint32_t i = 0; i < ctx->n_launches && i < cap; i++) {
+        float t = 0;
+        hipError_t e = hipEventElapsedTime(&t, ctx->ev[2 * i], ctx->ev[2 * i + 1]);
+        if (e != hipSuccess) return fail(H2E_ERR_HIP, hipGetErrorString(e));
+        ms[i] = t;
+    }
+    return (int)ctx->n_launches;
+}
+
+static int cached_run(h2e_ctx* ctx, const std::string& key, std::function<int(h2e_program**)> make, uint32_t n_instances,
+                      const void* d_inputs, void* d_base, void* d_range, void* d_select, void* d_status, void* stream) {
+    if (!ctx) return fail(H2E_ERR_INVALID, "null ctx");
+    auto it = ctx->cache.find(key);
+    if (it == ctx->cache.end()) {
+        h2e_program* p = nullptr;
+        int rc = make(&p);
+        if (rc) return rc;
+        it = ctx->cache.emplace(key, p).first;
+    }
+    return h2e_run(ctx, it->second, n_instances, d_inputs, d_base, d_range, d_select, d_status, stream);
+}
+
+int h2e_int_mul_batch(h2e_ctx* ctx, int fp, uint32_t n, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
+                      void* d_select, void* d_status, void* stream) {
+    return cached_run(ctx, "int_mul_batch/" + std::to_string(fp) + "/" + std::to_string(n),
+                      [&](h2e_program** p) { return h2e_program_int_mul_batch(fp, n, 0, p); }, n_instances, d_inputs, d_base,
+                      d_range, d_select, d_status, stream);
+}
+int h2e_msm_bn256_tile(h2e_ctx* ctx, uint32_t n_points, uint32_t n_tiles, const void* d_inputs, void* d_base, void* d_range,
+                       void* d_select, void* d_status, void* stream) {
+    return cached_run(ctx, "msm_bn256_tile/" + std::to_string(n_points),
+                      [&](h2e_program** p) { return h2e_program_msm_bn256_tile(n_points, 0, p); }, n_tiles, d_inputs, d_base,
+                      d_range, d_select, d_status, stream);
+}
+int h2e_pairing_check_bn256(h2e_ctx* ctx, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
+                            void* d_select, void* d_status, void* stream) {
+    return cached_run(ctx, "pairing_check_bn256", [&](h2e_program** p) { return h2e_program_pairing_check_bn256(0, p); },
+                      n_instances, d_inputs, d_base, d_range, d_select, d_status, stream);
+}
+int h2e_pairing_check_bls12_381(h2e_ctx* ctx, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
+                                void* d_select, void* d_status, void* stream) {
+    return cached_run(ctx, "pairing_check_bls12_381",
+                      [&](h2e_program** p) { return h2e_program_pairing_check_bls12_381(0, p); }, n_instances, d_inputs,
+                      d_base, d_range, d_select, d_status, stream);
+}
+
+}  // extern "C"

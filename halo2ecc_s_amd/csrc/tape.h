@@ -1,0 +1,121 @@
+// Witness tape: the static (shape-only) op stream the host recorder emits and the HIP engine replays.
+//
+// The reference's witness program is static: every branch in L1-L4 depends only on shape (`times`,
+// limb counts, group sizes, NAF digits), never on field values, except the *value* picked by
+// `pick_candidate_non_zero` (src/circuit/ecc_chip.rs:935-953) and abort flags.  So one recording of
+// the chip-level calls (at IntegerChipOps granularity, src/circuit/integer_chip.rs:15-70) is replayed
+// for any number of instances; forked sub-contexts (`ParallelClone`, src/circuit/ecc_chip.rs:64-77)
+// become "strands": one recording replayed at row offsets strand*delta.
+#pragma once
+#include <stdint.h>
+
+// ---- cell reference (32 bit) -------------------------------------------------------------------
+//  [31:30] region: 0 base, 1 range, 2 select, 3 = per-strand parameter (index in [25:0])
+//  [29:27] column
+//  [26]    1 = row is relative to the strand's starting offset of that region
+//  [25:0]  row
+#define H2E_REF_REGION(r) ((r) >> 30)
+#define H2E_REF_COL(r) (((r) >> 27) & 7u)
+#define H2E_REF_REL(r) (((r) >> 26) & 1u)
+#define H2E_REF_ROW(r) ((r)&0x3ffffffu)
+#define H2E_MAKE_REF(region, col, rel, row) \
+    (((uint32_t)(region) << 30) | ((uint32_t)(col) << 27) | ((uint32_t)(rel) << 26) | ((uint32_t)(row)&0x3ffffffu))
+#define H2E_REGION_PARAM 3u
+#define H2E_NO_REF 0xffffffffu
+
+enum H2EOpcode {
+    H2E_OP_NOP = 0,
+    // values entering from the instance input vector (imm = input slot, + strand*input_stride if flag)
+    H2E_OP_ASSIGN_W,          // assign_w(input)                    integer_chip.rs:236-258
+    H2E_OP_ASSIGN,            // base_chip assign(input Fr)          base_chip.rs:351-355
+    H2E_OP_ASSIGN_BIT,        // assign_bit(input bit)               base_chip.rs:357-367
+    H2E_OP_CONST_INT,         // assign_int_constant(pool const)     integer_chip.rs:580-598
+    H2E_OP_CONST_INT_INPUT,   // assign_int_constant(input W value)  (G2 / expected-result constants)
+    H2E_OP_CONST,             // assign_constant(pool Fr const)      base_chip.rs:344-349
+    // integer chip
+    H2E_OP_INT_ADD,           // integer_chip.rs:384-406 (without the conditional reduce)
+    H2E_OP_INT_SUB,           // :408-437   imm = b.times
+    H2E_OP_INT_NEG,           // :439-464   imm = a.times
+    H2E_OP_INT_MUL_SMALL,     // :618-658   imm = k
+    H2E_OP_INT_MUL,           // :466-483 + :73-215
+    H2E_OP_REDUCE,            // :283-373
+    H2E_OP_IS_INT_ZERO,       // :540-578 on an already reduced operand (is_pure_zero | is_pure_w_modulus, or)
+    H2E_OP_NOT,               // base_chip.rs:398-403
+    H2E_OP_MASK_INT,          // int_div's a' = a * not(is_b_zero), limb-wise + native   :511-520
+    H2E_OP_DIV_CORE,          // int_div's c,d hints + assign_w/assign_d + mul equation  :522-535
+    H2E_OP_BISEC_INT,         // :660-681
+    H2E_OP_SUM_LIMBS,         // sum_with_constant(limbs, 1) of assert_int_equal  :607-610
+    // base chip rows
+    H2E_OP_ASSERT_CONST,      // assert_constant(x, imm in {0,1})    base_chip.rs:375-379 ; flags a status on mismatch
+    H2E_OP_BISEC,             // base_chip.rs:574-604
+    H2E_OP_AND,               // :392-396
+    H2E_OP_OR,                // :428-439
+    H2E_OP_XNOR,              // :455-467
+    H2E_OP_DECOMPOSE_NATIVE,  // native_scalar_ecc_chip.rs:97-171 (WINDOW_SIZE = 1), imm = NUM_BITS
+    H2E_OP_PICK_INDEX,        // pick_candidate_non_zero's index row(s)  ecc_chip.rs:941-948
+    // select chip
+    H2E_OP_CACHE_INT,         // assign_cache_integer      ecc_chip.rs:734-751
+    H2E_OP_SELECT_POINT,      // assign_selected_point_non_zero  ecc_chip.rs:955-967 (value picked by index cell)
+    H2E_OP_COUNT
+};
+
+// status bits (per instance), or-ed by the engine
+#define H2E_STATUS_OK 0u
+#define H2E_STATUS_ASSERT_FAILED 1u        // an assert_constant / assert_true / assert_false would have panicked
+#define H2E_STATUS_RETRY_ADD_SAME_OR_NEG 2u  // UnsafeError::AddSameOrNegPoint  ecc_chip.rs:853-857
+#define H2E_STATUS_RETRY_ADD_IDENTITY 4u     // UnsafeError::AddIdentity        ecc_chip.rs:877-881
+#define H2E_STATUS_ARITH 8u                // an internal exactness check failed (u % 2^108 != 0, ...)
+
+// flags in H2EOp.flags
+#define H2E_FLAG_INPUT_STRIDED 1u   // input slot = imm + strand * input_stride
+#define H2E_FLAG_UNSAFE_ADD 2u      // ASSERT_CONST failure reports RETRY_ADD_SAME_OR_NEG
+#define H2E_FLAG_UNSAFE_DBL 4u      // ASSERT_CONST failure reports RETRY_ADD_IDENTITY
+
+#define H2E_OP_MAX_REFS 11
+typedef struct H2EOp {
+    uint16_t opcode;
+    uint16_t flags;
+    uint32_t imm;         // opcode specific
+    uint32_t base_row;    // first base row written (strand relative if the tape is a strand tape)
+    uint32_t range_row;   // first range row written
+    uint32_t select_row;  // first select row written
+    uint32_t refs[H2E_OP_MAX_REFS];
+} H2EOp;  // 64 bytes
+
+// Field-pair constants the engine needs (derived on the host from RangeInfo, src/range_info.rs:77-184).
+// All multiword integers little-endian 64-bit words.
+#define H2E_MAX_L 4
+#define H2E_W_WORDS_MAX 6
+typedef struct H2EFieldConsts {
+    uint32_t limbs;                 // L (3 or 4)
+    uint32_t w_words;               // 4 or 6
+    uint32_t w_bits;                // bit length of w (k)
+    uint32_t w_ceil_bits;
+    uint32_t d_bits;
+    uint32_t w_lead_bits, d_lead_bits;     // bits of the leading limb of a W element / of a quotient
+    uint32_t mul_check_limbs, reduce_check_limbs, pure_w_check_limbs;
+    uint32_t barrett_s;             // X < 2^s for the w-Barrett (= 2*w_ceil_bits + 2*overflow_bits)
+    uint32_t input_bytes;           // 32 or 48: size of a W value in the input vector
+    uint64_t w[H2E_W_WORDS_MAX];    // modulus of W
+    uint64_t w_mu[8];               // floor(2^s / w)
+    uint64_t w_limbs[H2E_MAX_L][2]; // limbs of w (108 bit)
+    uint64_t n[4];                  // bn256 Fr modulus
+    uint64_t n_mu[5];               // floor(2^512 / n)
+    uint64_t w_native[4];           // w mod n
+    uint64_t ceil_limbs[64][H2E_MAX_L][2];  // find_w_modulus_of_ceil_times(t) limbs (range_info.rs:334-359)
+    uint64_t ceil_native[64][4];            // their composition mod n
+} H2EFieldConsts;
+
+// One launch: a tape replayed by n_instances * n_strands lanes.
+typedef struct H2ELaunch {
+    const H2EOp* tape;
+    uint32_t n_ops;
+    uint32_t n_strands;           // strands per instance (1 for the main context)
+    uint32_t strand_base0, strand_range0, strand_select0;   // offsets of strand 0
+    uint32_t delta_base, delta_range, delta_select;         // per-strand Offset (ecc_chip.rs:36-41)
+    uint32_t input_stride;        // input slots per strand (for H2E_FLAG_INPUT_STRIDED)
+    uint32_t n_params;            // parameter refs per strand
+    const uint32_t* params;       // [n_strands][n_params]
+    const uint32_t* aux;          // candidate tables etc.
+    const uint64_t* const_pool;   // 32-byte (Fr) or w_words*8-byte (W) constants, word indexed
+} H2ELaunch;

@@ -1,0 +1,296 @@
+// Fixed-width multi-word integers for the gfx950 witness engine (64-bit words, fully unrolled so
+// every word lives in a VGPR).  These replace num-bigint on the reference's witness path
+// (src/circuit/integer_chip.rs:472-474, :296-297, :524-529).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+#define WI_INLINE __device__ __forceinline__
+
+template <int N>
+struct Wd {
+    u64 v[N];
+};
+
+template <int N>
+WI_INLINE Wd<N> wd_zero() {
+    Wd<N> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = 0;
+    return r;
+}
+template <int N>
+WI_INLINE Wd<N> wd_from_u64(u64 x) {
+    Wd<N> r = wd_zero<N>();
+    r.v[0] = x;
+    return r;
+}
+template <int N>
+WI_INLINE Wd<N> wd_load(const u64* p) {
+    Wd<N> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = p[i];
+    return r;
+}
+// resize (zero-extend or truncate)
+template <int M, int N>
+WI_INLINE Wd<M> wd_resize(const Wd<N>& a) {
+    Wd<M> r;
+#pragma unroll
+    for (int i = 0; i < M; i++) r.v[i] = (i < N) ? a.v[i] : 0;
+    return r;
+}
+template <int N>
+WI_INLINE bool wd_is_zero(const Wd<N>& a) {
+    u64 o = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) o |= a.v[i];
+    return o == 0;
+}
+template <int N>
+WI_INLINE bool wd_eq(const Wd<N>& a, const Wd<N>& b) {
+    u64 o = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+}
+// a >= b
+template <int N>
+WI_INLINE bool wd_geq(const Wd<N>& a, const Wd<N>& b) {
+    u64 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        u64 d = a.v[i] - b.v[i];
+        u64 b1 = a.v[i] < b.v[i];
+        u64 b2 = d < borrow;
+        borrow = b1 | b2;
+    }
+    return borrow == 0;
+}
+template <int N>
+WI_INLINE Wd<N> wd_add(const Wd<N>& a, const Wd<N>& b) {
+    Wd<N> r;
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        u64 s = a.v[i] + b.v[i];
+        u64 c1 = s < a.v[i];
+        u64 s2 = s + c;
+        u64 c2 = s2 < s;
+        r.v[i] = s2;
+        c = c1 | c2;
+    }
+    return r;
+}
+template <int N>
+WI_INLINE Wd<N> wd_add_c(const Wd<N>& a, const Wd<N>& b, u64& carry_out) {
+    Wd<N> r;
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        u64 s = a.v[i] + b.v[i];
+        u64 c1 = s < a.v[i];
+        u64 s2 = s + c;
+        u64 c2 = s2 < s;
+        r.v[i] = s2;
+        c = c1 | c2;
+    }
+    carry_out = c;
+    return r;
+}
+template <int N>
+WI_INLINE Wd<N> wd_sub(const Wd<N>& a, const Wd<N>& b) {
+    Wd<N> r;
+    u64 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        u64 d = a.v[i] - b.v[i];
+        u64 b1 = a.v[i] < b.v[i];
+        u64 d2 = d - borrow;
+        u64 b2 = d < borrow;
+        r.v[i] = d2;
+        borrow = b1 | b2;
+    }
+    return r;
+}
+template <int N>
+WI_INLINE Wd<N> wd_neg(const Wd<N>& a) {
+    return wd_sub<N>(wd_zero<N>(), a);
+}
+template <int N>
+WI_INLINE bool wd_is_neg(const Wd<N>& a) {  // two's complement sign
+    return (a.v[N - 1] >> 63) != 0;
+}
+// full product
+template <int NA, int NB>
+WI_INLINE Wd<NA + NB> wd_mul(const Wd<NA>& a, const Wd<NB>& b) {
+    Wd<NA + NB> r = wd_zero<NA + NB>();
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        u64 carry = 0;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            u64 lo = a.v[i] * b.v[j];
+            u64 hi = __umul64hi(a.v[i], b.v[j]);
+            u64 s = r.v[i + j] + lo;
+            hi += (s < lo);
+            u64 s2 = s + carry;
+            hi += (s2 < s);
+            r.v[i + j] = s2;
+            carry = hi;
+        }
+        r.v[i + NB] = carry;
+    }
+    return r;
+}
+// low NR words of the product
+template <int NR, int NA, int NB>
+WI_INLINE Wd<NR> wd_mul_lo(const Wd<NA>& a, const Wd<NB>& b) {
+    Wd<NR> r = wd_zero<NR>();
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        u64 carry = 0;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            if (i + j < NR) {
+                u64 lo = a.v[i] * b.v[j];
+                u64 hi = (i + j + 1 < NR) ? __umul64hi(a.v[i], b.v[j]) : 0;
+                u64 s = r.v[i + j] + lo;
+                hi += (s < lo);
+                u64 s2 = s + carry;
+                hi += (s2 < s);
+                r.v[i + j] = s2;
+                carry = hi;
+            }
+        }
+        if (i + NB < NR) r.v[i + NB] = carry;
+    }
+    return r;
+}
+// (a >> SH) truncated / zero-extended to M words; SH compile-time
+template <int M, int SH, int N>
+WI_INLINE Wd<M> wd_shr(const Wd<N>& a) {
+    Wd<M> r;
+    constexpr int ws = SH / 64, bs = SH % 64;
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        u64 lo = (i + ws < N) ? a.v[i + ws] : 0;
+        u64 hi = (i + ws + 1 < N) ? a.v[i + ws + 1] : 0;
+        r.v[i] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+    }
+    return r;
+}
+// (a << SH) into M words; SH compile-time
+template <int M, int SH, int N>
+WI_INLINE Wd<M> wd_shl(const Wd<N>& a) {
+    Wd<M> r;
+    constexpr int ws = SH / 64, bs = SH % 64;
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        u64 lo = (i - ws >= 0 && i - ws < N) ? a.v[i - ws] : 0;
+        u64 pl = (i - ws - 1 >= 0 && i - ws - 1 < N) ? a.v[i - ws - 1] : 0;
+        r.v[i] = bs ? ((lo << bs) | (pl >> (64 - bs))) : lo;
+    }
+    return r;
+}
+// keep the low BITS bits
+template <int BITS, int N>
+WI_INLINE Wd<N> wd_mask(const Wd<N>& a) {
+    Wd<N> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if ((i + 1) * 64 <= BITS)
+            r.v[i] = a.v[i];
+        else if (i * 64 >= BITS)
+            r.v[i] = 0;
+        else
+            r.v[i] = a.v[i] & ((1ull << (BITS - i * 64)) - 1);
+    }
+    return r;
+}
+template <int N>
+WI_INLINE Wd<N> wd_shr1(const Wd<N>& a) {
+    Wd<N> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = (a.v[i] >> 1) | ((i + 1 < N) ? (a.v[i + 1] << 63) : 0);
+    return r;
+}
+template <int N>
+WI_INLINE Wd<N> wd_select(bool c, const Wd<N>& a, const Wd<N>& b) {
+    Wd<N> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = c ? a.v[i] : b.v[i];
+    return r;
+}
+
+// Exact floor division by Barrett reduction.
+//   X < 2^S, modulus m with bit length K, mu = floor(2^S / m) (S-K+1 bits).
+//   returns q = floor(X / m) (QW words) and r = X mod m (MW words).
+// q3 = floor(floor(X / 2^(K-1)) * mu / 2^(S-K+1)) satisfies q-2 <= q3 <= q; two conditional
+// subtractions finish.
+template <int S, int K, int XW, int MW, int QW>
+WI_INLINE void wd_barrett_divrem(const Wd<XW>& X, const Wd<MW>& m, const Wd<QW>& mu, Wd<QW>& q, Wd<MW>& r) {
+    Wd<QW> q1 = wd_shr<QW, K - 1>(X);
+    Wd<2 * QW> q2 = wd_mul<QW, QW>(q1, mu);
+    Wd<QW> q3 = wd_shr<QW, S - K + 1>(q2);
+    // r = X - q3*m on MW+1 words (true value < 3m)
+    Wd<MW + 1> qm = wd_mul_lo<MW + 1, QW, MW>(q3, m);
+    Wd<MW + 1> rr = wd_sub<MW + 1>(wd_resize<MW + 1>(X), qm);
+    Wd<MW + 1> me = wd_resize<MW + 1>(m);
+    Wd<QW> one = wd_from_u64<QW>(1);
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        bool ge = wd_geq<MW + 1>(rr, me);
+        rr = wd_select<MW + 1>(ge, wd_sub<MW + 1>(rr, me), rr);
+        q3 = wd_select<QW>(ge, wd_add<QW>(q3, one), q3);
+    }
+    q = q3;
+    r = wd_resize<MW>(rr);
+}
+
+// Modular inverse by the binary extended Euclidean algorithm (p odd, 0 < a < p).
+// Returns 0 for a == 0 (Field::invert() -> None, mapped to zero by the callers exactly as the
+// reference does: base_chip.rs:301, integer_chip.rs:524-527).
+template <int N>
+WI_INLINE Wd<N> wd_inv_mod(const Wd<N>& a, const Wd<N>& p) {
+    if (wd_is_zero<N>(a)) return wd_zero<N>();
+    Wd<N> u = a, v = p;
+    Wd<N> x1 = wd_from_u64<N>(1), x2 = wd_zero<N>();
+    Wd<N> one = wd_from_u64<N>(1);
+    // invariants: x1*a == u, x2*a == v (mod p); x1, x2 in [0, p)
+    while (!wd_eq<N>(u, one) && !wd_eq<N>(v, one)) {
+        while ((u.v[0] & 1) == 0) {
+            u = wd_shr1<N>(u);
+            if (x1.v[0] & 1) {
+                u64 c;
+                Wd<N> t = wd_add_c<N>(x1, p, c);
+                x1 = wd_shr1<N>(t);
+                x1.v[N - 1] |= c << 63;
+            } else {
+                x1 = wd_shr1<N>(x1);
+            }
+        }
+        while ((v.v[0] & 1) == 0) {
+            v = wd_shr1<N>(v);
+            if (x2.v[0] & 1) {
+                u64 c;
+                Wd<N> t = wd_add_c<N>(x2, p, c);
+                x2 = wd_shr1<N>(t);
+                x2.v[N - 1] |= c << 63;
+            } else {
+                x2 = wd_shr1<N>(x2);
+            }
+        }
+        if (wd_geq<N>(u, v)) {
+            u = wd_sub<N>(u, v);
+            x1 = wd_geq<N>(x1, x2) ? wd_sub<N>(x1, x2) : wd_sub<N>(wd_add<N>(x1, p), x2);
+        } else {
+            v = wd_sub<N>(v, u);
+            x2 = wd_geq<N>(x2, x1) ? wd_sub<N>(x2, x1) : wd_sub<N>(wd_add<N>(x2, p), x1);
+        }
+    }
+    return wd_eq<N>(u, one) ? x1 : x2;
+}

@@ -1,0 +1,133 @@
+/* h2e — C ABI of the MI355X witness-generation engine for the halo2ecc-s hot path.
+ *
+ * Drop-in boundary.  The reference has no FFI layer; its mechanism for running a
+ * sub-computation elsewhere and splicing the result back is `ParallelClone` (fork a context at a row
+ * offset, let it write its disjoint rows, merge: src/circuit/ecc_chip.rs:64-77, used at :289-352).
+ * The engine plugs in at that seam: a *program* is the recorded shape of a chip-level computation
+ * (rows, fixed cells, permutations, heights = everything in `Records` that does not depend on field
+ * values, src/context.rs:241-301), and `h2e_run` fills the advice values of N instances of it on the
+ * GPU.  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions
+ *  - all multi-word integers are little-endian arrays of uint64_t; advice cells are canonical bn256-Fr
+ *    values (what `field_to_bn` sees, src/utils.rs:4-8), 4 words each;
+ *  - advice arrays are row-major like the reference's `Vec<[(Option<N>, bool); COLS]>`
+ *    (src/context.rs:243-251): base [rows][5][4], range [rows][3][4], select [rows][2][4] words; cells the
+ *    shape leaves unassigned are never written (allocate zero-filled);
+ *  - inputs: [n_instances][n_input_slots][slot_words] words; a slot holds one W value (canonical) or one
+ *    Fr value / flag in its first 4 words;
+ *  - device pointers are plain `void*` from any allocator (hipMalloc, torch); the engine never frees
+ *    caller memory; `stream` is a hipStream_t passed as void*;
+ *  - every function returns 0 on success, a negative H2E_ERR_* otherwise; h2e_last_error() has text.
+ */
+#ifndef H2E_H
+#define H2E_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define H2E_ERR_INVALID (-1)
+#define H2E_ERR_HIP (-2)
+#define H2E_ERR_SHAPE (-3)
+
+/* field pairs: RangeInfo::<W, N> instances the reference constructs (src/range_info.rs:362-387) */
+#define H2E_FIELD_BN256_FQ 0       /* bn256 Fq over bn256 Fr: 3 limbs */
+#define H2E_FIELD_BLS12_381_FQ 1   /* bls12_381 Fq over bn256 Fr: 4 limbs */
+#define H2E_FIELD_BLS12_381_FR 2   /* bls12_381 Fr over bn256 Fr: 3 limbs */
+
+/* per-instance status bits (would-be panics / UnsafeError of the reference, src/circuit/ecc_chip.rs:23-34) */
+#define H2E_ST_OK 0u
+#define H2E_ST_ASSERT_FAILED 1u
+#define H2E_ST_RETRY_ADD_SAME_OR_NEG_POINT 2u
+#define H2E_ST_RETRY_ADD_IDENTITY 4u
+#define H2E_ST_ARITH 8u
+
+typedef struct h2e_ctx h2e_ctx;          /* device + constant tables; one per GPU, re-entrant per ctx */
+typedef struct h2e_program h2e_program;  /* recorded shape of one workload */
+
+const char* h2e_last_error(void);
+const char* h2e_version(void);
+
+/* replaces: Context::new + IntegerContext::new + RangeInfo::new (src/context.rs:136-143, :173-187) */
+int h2e_ctx_create(int device, h2e_ctx** out);
+void h2e_ctx_destroy(h2e_ctx* ctx);
+
+/* ---- programs (shape recording; host only, no GPU needed) ------------------------------------- */
+/* `emit_shape` = 0 records only the tape (values can be generated, no fixed/permutation artefacts). */
+
+/* n independent `assign_w(a); assign_w(b); int_mul(a, b)` (IntegerChipOps::int_mul, src/circuit/integer_chip.rs:466-483).
+ * inputs per instance: slots 2k, 2k+1 = a_k, b_k. */
+int h2e_program_int_mul_batch(int field_pair, uint32_t n, int emit_shape, h2e_program** out);
+/* body of test_integer_chip_st (src/tests/integer_chip.rs:11-55): add/sub/mul/div + div by zero.
+ * inputs: a, b, c=a+b, d=a-b, e=a*b, f=a/b (6 slots). */
+int h2e_program_integer_chip_st(int field_pair, int emit_shape, h2e_program** out);
+/* body of test_native_ecc_chip_with_select_chip (src/tests/native_scalar_ecc_chip.rs:34-47) for one tile of
+ * n points: assign_point x n, assign x n, msm_unsafe (EccChipScalarOps::msm_unsafe, src/circuit/ecc_chip.rs:373-408),
+ * assign_point(expected), ecc_assert_equal.
+ * inputs: 3n slots (x, y, z-flag) per point, n scalars, generator (x,y), r1 (x,y), r2 (x,y), expected (x,y,z). */
+int h2e_program_msm_bn256_tile(uint32_t n_points, int emit_shape, h2e_program** out);
+/* check_pairing([(a, b), (-a, b)]) with G2 as constants (PairingChipOps::check_pairing,
+ * src/circuit/pairing_chip.rs:173-176; shape of src/tests/native_scalar_pairing_chip.rs:67-97).
+ * inputs: b.x.c0, b.x.c1, b.y.c0, b.y.c1, (-a).x, (-a).y, (-a).z, a.x, a.y, a.z. */
+int h2e_program_pairing_check_bn256(int emit_shape, h2e_program** out);
+/* check_pairing([(ac, b), (-a, bc)]) (shape of src/tests/general_scalar_pairing_chip.rs:74-105).
+ * inputs: b.x.c0,b.x.c1,b.y.c0,b.y.c1, bc.x.c0,bc.x.c1,bc.y.c0,bc.y.c1, (-a).x,(-a).y,(-a).z, ac.x,ac.y,ac.z. */
+int h2e_program_pairing_check_bls12_381(int emit_shape, h2e_program** out);
+void h2e_program_destroy(h2e_program* p);
+
+/* ---- shape artefacts: what Records holds besides advice values -------------------------------- */
+typedef struct h2e_shape {
+    int field_pair;
+    uint32_t slot_words;        /* words per input slot (4 or 6) */
+    uint32_t n_input_slots;
+    uint64_t base_offset, range_offset, select_offset;   /* Context cursors after the run (src/context.rs:43-45) */
+    uint64_t base_height, range_height, select_height;   /* Records heights (src/context.rs:297-299) */
+    uint64_t base_rows, range_rows, select_rows;          /* rows to allocate per instance */
+    uint64_t n_advice_cells;    /* assigned advice cells per instance (0 if emit_shape was 0) */
+    uint64_t n_permutations;
+    uint64_t n_dict;            /* fixed-value dictionary entries (entry 0 = None) */
+    uint64_t n_fixed_patches;
+    uint32_t n_segments;        /* engine launches per run */
+    uint64_t n_ops;
+    /* host arrays owned by the program (NULL when emit_shape was 0) */
+    const uint64_t* dict;            /* [n_dict][4] canonical values */
+    const uint32_t* base_fix;        /* [base_height][9] dictionary ids: coeff0..4, mul0, mul1, next, constant */
+    const uint32_t* range_fix;       /* [range_height+1][2]: acc_lines, tag */
+    const uint32_t* select_fix;      /* [select_height][2]: encode, is_lookup */
+    const uint8_t* base_flags;       /* [base_height][5] bit0 = assigned, bit1 = permute (the bool of (Option<N>, bool)) */
+    const uint8_t* range_flags;      /* [range_height+1][3] */
+    const uint8_t* select_flags;     /* [select_height][2] */
+    const uint32_t* permutations;    /* [n_permutations][2] cells: region<<30 | col<<27 | row (src/context.rs:300) */
+    const uint32_t* fixed_patches;   /* [n_fixed_patches][4]: base row, fixed col, input slot, limb (-1 = value mod n) */
+} h2e_shape;
+int h2e_program_shape(const h2e_program* p, h2e_shape* out);
+
+/* ---- execution --------------------------------------------------------------------------------- */
+/* Fill the advice values of n_instances instances.  d_base/d_range/d_select: device arrays of
+ * n_instances * rows * cols * 4 words (instance-major); d_inputs as described above; d_status:
+ * n_instances uint32 (or-ed, zero it first).  Asynchronous on `stream`. */
+int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
+            void* d_select, void* d_status, void* stream);
+
+/* Named entry points of SURVEY.md §8(b): build-or-reuse the program for the shape, then run it. */
+int h2e_int_mul_batch(h2e_ctx* ctx, int field_pair, uint32_t n, uint32_t n_instances, const void* d_inputs, void* d_base,
+                      void* d_range, void* d_select, void* d_status, void* stream);
+int h2e_msm_bn256_tile(h2e_ctx* ctx, uint32_t n_points, uint32_t n_tiles, const void* d_inputs, void* d_base, void* d_range,
+                       void* d_select, void* d_status, void* stream);
+int h2e_pairing_check_bn256(h2e_ctx* ctx, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
+                            void* d_select, void* d_status, void* stream);
+int h2e_pairing_check_bls12_381(h2e_ctx* ctx, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
+                                void* d_select, void* d_status, void* stream);
+
+/* Timing hook used by bench.py: HIP events recorded by the engine around each launch of the last
+ * h2e_run on `stream`; returns the number of launches and fills ms[i] (call after synchronising). */
+int h2e_last_run_launch_ms(h2e_ctx* ctx, float* ms, uint32_t cap);
+int h2e_set_profiling(h2e_ctx* ctx, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* H2E_H */

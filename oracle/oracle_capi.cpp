@@ -1,0 +1,299 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md). Not part of the product path.
+//
+// C entry points used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg (ctypes).
+// Each run_* builds the same workload the engine's h2e_program_* describes, from the same input
+// vector, with the CPU restatement, and keeps the resulting Records for export / checking.
+#include <chrono>
+#include <cstring>
+#include "checker.hpp"
+#include "pairing.hpp"
+#include "testutil.hpp"
+
+using namespace h2o;
+
+namespace {
+struct Run {
+    std::shared_ptr<Context> ctx;
+    int status = 0;  // 0 ok, 1 panic, 2 UnsafeError
+    std::string error;
+    double seconds = 0;
+};
+const BigUint& wmod(int fp) { return fp == 0 ? BnFq::modulus() : fp == 1 ? BlsFq::modulus() : BlsFr::modulus(); }
+int slot_words(int fp) { return fp == 1 ? 6 : 4; }
+struct Inputs {
+    const uint64_t* p;
+    int sw;
+    BigUint w(uint32_t slot) const { return BigUint::from_limbs(p + (size_t)slot * sw, sw); }
+    Fr fr(uint32_t slot) const { return Fr::from_bn(BigUint::from_limbs(p + (size_t)slot * sw, 4)); }
+    NativePoint point(uint32_t xs, uint32_t ys, uint32_t zs) const {
+        NativePoint n;
+        n.x = w(xs);
+        n.y = w(ys);
+        n.is_identity = !w(zs).is_zero();
+        return n;
+    }
+};
+template <class F>
+Run* guarded(F f) {
+    init_fields();
+    Run* r = new Run();
+    r->ctx = std::make_shared<Context>();
+    auto t0 = std::chrono::steady_clock::now();
+    try {
+        f(*r);
+    } catch (UnsafeError& e) {
+        r->status = 2;
+        r->error = "UnsafeError";
+    } catch (std::exception& e) {
+        r->status = 1;
+        r->error = e.what();
+    }
+    r->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return r;
+}
+uint32_t enc(const Cell& c) { return ((uint32_t)c.region << 30) | ((uint32_t)c.col << 27) | c.row; }
+}  // namespace
+
+extern "C" {
+
+void* oracle_run_int_mul_batch(int fp, uint32_t n, const uint64_t* inputs) {
+    return guarded([&](Run& r) {
+        IntegerContext ic(r.ctx, wmod(fp));
+        Inputs in{inputs, slot_words(fp)};
+        for (uint32_t k = 0; k < n; k++) {
+            AssignedInteger a = ic.assign_w(in.w(2 * k));
+            AssignedInteger b = ic.assign_w(in.w(2 * k + 1));
+            ic.int_mul(a, b);
+        }
+    });
+}
+
+// src/tests/integer_chip.rs:11-55
+void* oracle_run_integer_chip_st(int fp, const uint64_t* inputs) {
+    return guarded([&](Run& r) {
+        IntegerContext ic(r.ctx, wmod(fp));
+        Inputs in{inputs, slot_words(fp)};
+        AssignedInteger a = ic.assign_w(in.w(0)), b = ic.assign_w(in.w(1));
+        AssignedInteger c1 = ic.assign_w(in.w(2));
+        AssignedInteger c2 = ic.int_add(a, b);
+        ic.assert_int_equal(c1, c2);
+        AssignedInteger d1 = ic.assign_w(in.w(3));
+        AssignedInteger d2 = ic.int_sub(a, b);
+        ic.assert_int_equal(d1, d2);
+        AssignedInteger e1 = ic.assign_w(in.w(4));
+        AssignedInteger e2 = ic.int_mul(a, b);
+        ic.assert_int_equal(e1, e2);
+        AssignedInteger f1 = ic.assign_w(in.w(5));
+        AssignedInteger f2 = ic.int_div(a, b).second;
+        ic.assert_int_equal(f1, f2);
+        AssignedInteger zero = ic.int_sub(a, a);
+        auto g = ic.int_div(a, zero);
+        r.ctx->assert_true(g.first);
+    });
+}
+
+// src/tests/native_scalar_ecc_chip.rs:34-47 for one tile
+void* oracle_run_msm_bn256_tile(uint32_t n, const uint64_t* inputs, int threads) {
+    return guarded([&](Run& r) {
+        IntegerContext ic(r.ctx, BnFq::modulus());
+        Inputs in{inputs, 4};
+        NativeScalarEccContext ecc = NativeScalarEccContext::new_with_select_chip(ic, bn256_g1_params());
+        ecc.n_threads = threads;
+        // the generator comes in as an input too (slots 4n, 4n+1); it must be C::generator()
+        ecc.curve.generator = in.point(4 * n, 4 * n + 1, 4 * n + 8);
+        ecc.curve.generator.is_identity = false;
+        std::vector<AssignedPoint> ap;
+        std::vector<AssignedValue> as;
+        for (uint32_t k = 0; k < n; k++) ap.push_back(ecc.assign_point(in.point(3 * k, 3 * k + 1, 3 * k + 2)));
+        for (uint32_t k = 0; k < n; k++) as.push_back(r.ctx->assign(in.fr(3 * n + k)));
+        NativePoint r1 = in.point(4 * n + 2, 4 * n + 3, 4 * n + 8), r2 = in.point(4 * n + 4, 4 * n + 5, 4 * n + 8);
+        r1.is_identity = r2.is_identity = false;
+        AssignedPoint res = ecc.msm_unsafe(ap, as, r1, r2);
+        AssignedPoint res_expect = ecc.assign_point(in.point(4 * n + 6, 4 * n + 7, 4 * n + 8));
+        ecc.ecc_assert_equal(res, res_expect);
+    });
+}
+
+// second block of src/tests/native_scalar_pairing_chip.rs:67-97
+void* oracle_run_pairing_check_bn256(const uint64_t* inputs) {
+    return guarded([&](Run& r) {
+        IntegerContext ic(r.ctx, BnFq::modulus());
+        Inputs in{inputs, 4};
+        NativeScalarEccContext ecc(ic, bn256_g1_params(), 0);
+        Bn256PairingOps po(ecc.base);
+        AssignedFq2 bx = po.fq2_assign_constant(Fq2Const{in.w(0), in.w(1)});
+        AssignedFq2 by = po.fq2_assign_constant(Fq2Const{in.w(2), in.w(3)});
+        AssignedG2Affine B{bx, by, AssignedCondition(r.ctx->assign_constant(Fr::zero()))};
+        AssignedPoint neg_a = ecc.assign_point(in.point(4, 5, 6));
+        AssignedPoint a = ecc.assign_point(in.point(7, 8, 9));
+        po.check_pairing({PairingOps::Term(&a, &B), PairingOps::Term(&neg_a, &B)});
+    });
+}
+
+// second block of src/tests/general_scalar_pairing_chip.rs:74-105
+void* oracle_run_pairing_check_bls12_381(const uint64_t* inputs) {
+    return guarded([&](Run& r) {
+        IntegerContext ic(r.ctx, BlsFq::modulus());
+        IntegerContext sc(r.ctx, BlsFr::modulus());  // GeneralScalarEccContext::new builds both (context.rs:230-239)
+        (void)sc;
+        Inputs in{inputs, 6};
+        NativeScalarEccContext ecc(ic, bls12_381_g1_params(), 0);
+        Bls12381PairingOps po(ecc.base);
+        AssignedFq2 bx = po.fq2_assign_constant(Fq2Const{in.w(0), in.w(1)});
+        AssignedFq2 by = po.fq2_assign_constant(Fq2Const{in.w(2), in.w(3)});
+        AssignedG2Affine B{bx, by, AssignedCondition(r.ctx->assign_constant(Fr::zero()))};
+        AssignedFq2 bcx = po.fq2_assign_constant(Fq2Const{in.w(4), in.w(5)});
+        AssignedFq2 bcy = po.fq2_assign_constant(Fq2Const{in.w(6), in.w(7)});
+        AssignedG2Affine BC{bcx, bcy, AssignedCondition(r.ctx->assign_constant(Fr::zero()))};
+        AssignedPoint neg_a = ecc.assign_point(in.point(8, 9, 10));
+        AssignedPoint ac = ecc.assign_point(in.point(11, 12, 13));
+        po.check_pairing({PairingOps::Term(&ac, &B), PairingOps::Term(&neg_a, &BC)});
+    });
+}
+
+struct OracleInfo {
+    uint64_t base_offset, range_offset, select_offset;
+    uint64_t base_height, range_height, select_height;
+    uint64_t n_permutations, n_advice_cells;
+    int32_t status;
+    double seconds;
+};
+void oracle_info(void* h, OracleInfo* out) {
+    Run* r = (Run*)h;
+    Context& c = *r->ctx;
+    out->base_offset = c.base_offset;
+    out->range_offset = c.range_offset;
+    out->select_offset = c.select_offset;
+    out->base_height = c.records.base_height;
+    out->range_height = c.records.range_height;
+    out->select_height = c.records.select_height;
+    out->n_permutations = c.records.permutations.size();
+    size_t cells = 0;
+    RecordsInner& in = *c.records.inner;
+    for (auto& x : in.base_adv) cells += x.present;
+    for (auto& x : in.range_adv) cells += x.present;
+    for (auto& x : in.select_adv) cells += x.present;
+    out->n_advice_cells = cells;
+    out->status = r->status;
+    out->seconds = r->seconds;
+}
+const char* oracle_error(void* h) { return ((Run*)h)->error.c_str(); }
+
+// region 0/1/2; out[rows][cols][4] canonical, flags[rows][cols] bit0 assigned bit1 permute; rows beyond storage = 0
+void oracle_export_adv(void* h, int region, uint64_t* out, uint8_t* flags, uint64_t rows) {
+    Run* r = (Run*)h;
+    RecordsInner& in = *r->ctx->records.inner;
+    const std::vector<AdvCell>& v = region == 0 ? in.base_adv : region == 1 ? in.range_adv : in.select_adv;
+    int cols = region == 0 ? 5 : region == 1 ? 3 : 2;
+    size_t have = v.size() / cols;
+    for (uint64_t row = 0; row < rows; row++)
+        for (int c = 0; c < cols; c++) {
+            uint64_t* o = out + (row * cols + c) * 4;
+            if (row < have && v[row * cols + c].present) {
+                v[row * cols + c].val.to_canonical(o);
+            } else {
+                o[0] = o[1] = o[2] = o[3] = 0;
+            }
+            flags[row * cols + c] = row < have ? (uint8_t)(v[row * cols + c].present | (v[row * cols + c].permute << 1)) : 0;
+        }
+}
+void oracle_export_fix(void* h, int region, uint64_t* out, uint8_t* present, uint64_t rows) {
+    Run* r = (Run*)h;
+    RecordsInner& in = *r->ctx->records.inner;
+    const std::vector<FixCell>& v = region == 0 ? in.base_fix : region == 1 ? in.range_fix : in.select_fix;
+    int cols = region == 0 ? 9 : 2;
+    size_t have = v.size() / cols;
+    for (uint64_t row = 0; row < rows; row++)
+        for (int c = 0; c < cols; c++) {
+            uint64_t* o = out + (row * cols + c) * 4;
+            bool p = row < have && v[row * cols + c].present;
+            if (p)
+                v[row * cols + c].val.to_canonical(o);
+            else
+                o[0] = o[1] = o[2] = o[3] = 0;
+            present[row * cols + c] = p;
+        }
+}
+void oracle_export_permutations(void* h, uint32_t* out) {
+    Run* r = (Run*)h;
+    size_t i = 0;
+    for (auto& p : r->ctx->records.permutations) {
+        out[i++] = enc(p.first);
+        out[i++] = enc(p.second);
+    }
+}
+// constraint checker: 0 = all satisfied
+int oracle_check(void* h, char* msg, int cap) {
+    Run* r = (Run*)h;
+    CheckReport rep = check_records(r->ctx->records);
+    if (msg && cap > 0) {
+        std::strncpy(msg, rep.first_error.c_str(), cap - 1);
+        msg[cap - 1] = 0;
+    }
+    return rep.ok() ? 0 : 1;
+}
+// flip one advice cell (for checker self-tests)
+void oracle_corrupt_adv(void* h, int region, uint64_t row, int col) {
+    Run* r = (Run*)h;
+    RecordsInner& in = *r->ctx->records.inner;
+    std::vector<AdvCell>& v = region == 0 ? in.base_adv : region == 1 ? in.range_adv : in.select_adv;
+    int cols = region == 0 ? 5 : region == 1 ? 3 : 2;
+    v[row * cols + col].val = v[row * cols + col].val + Fr::one();
+}
+void oracle_free(void* h) { delete (Run*)h; }
+
+// ---- native helpers for input generation (not chip code) -----------------------------------------
+// k * P on bn256 G1 / bls12_381 G1 / G2 with canonical little-endian words; returns 1 if the result is identity
+int oracle_bn256_g1_mul(const uint64_t* px, const uint64_t* py, const uint64_t* k, uint64_t* ox, uint64_t* oy) {
+    init_fields();
+    BnG1 p{BnFq::from_bn(BigUint::from_limbs(px, 4)), BnFq::from_bn(BigUint::from_limbs(py, 4)), false};
+    BnG1 q = JacT<BnFq>::from_affine(p).mul(BigUint::from_limbs(k, 4)).to_affine();
+    if (q.inf) return 1;
+    q.x.to_canonical(ox);
+    q.y.to_canonical(oy);
+    return 0;
+}
+// sum_i k_i * P_i on bn256 G1
+int oracle_bn256_g1_msm(uint32_t n, const uint64_t* pts /*[n][2][4]*/, const uint64_t* ks /*[n][4]*/, uint64_t* ox, uint64_t* oy) {
+    init_fields();
+    JacT<BnFq> acc = JacT<BnFq>::identity();
+    for (uint32_t i = 0; i < n; i++) {
+        BnG1 p{BnFq::from_bn(BigUint::from_limbs(pts + i * 8, 4)), BnFq::from_bn(BigUint::from_limbs(pts + i * 8 + 4, 4)), false};
+        acc = acc.add(JacT<BnFq>::from_affine(p).mul(BigUint::from_limbs(ks + i * 4, 4)));
+    }
+    BnG1 q = acc.to_affine();
+    if (q.inf) return 1;
+    q.x.to_canonical(ox);
+    q.y.to_canonical(oy);
+    return 0;
+}
+int oracle_bn256_g2_mul_gen(const uint64_t* k, uint64_t* out /*x.c0,x.c1,y.c0,y.c1 each 4 words*/) {
+    init_fields();
+    BnG2 q = JacT<BnFq2>::from_affine(bn_g2_generator()).mul(BigUint::from_limbs(k, 4)).to_affine();
+    if (q.inf) return 1;
+    q.x.c0.to_canonical(out);
+    q.x.c1.to_canonical(out + 4);
+    q.y.c0.to_canonical(out + 8);
+    q.y.c1.to_canonical(out + 12);
+    return 0;
+}
+int oracle_bls12_381_g1_mul_gen(const uint64_t* k, uint64_t* out /*x,y each 6 words*/) {
+    init_fields();
+    BlsG1 q = JacT<BlsFq>::from_affine(bls_g1_generator()).mul(BigUint::from_limbs(k, 4)).to_affine();
+    if (q.inf) return 1;
+    q.x.to_canonical(out);
+    q.y.to_canonical(out + 6);
+    return 0;
+}
+int oracle_bls12_381_g2_mul_gen(const uint64_t* k, uint64_t* out /*x.c0,x.c1,y.c0,y.c1 each 6 words*/) {
+    init_fields();
+    BlsG2 q = JacT<BlsFq2>::from_affine(bls_g2_generator()).mul(BigUint::from_limbs(k, 4)).to_affine();
+    if (q.inf) return 1;
+    q.x.c0.to_canonical(out);
+    q.x.c1.to_canonical(out + 6);
+    q.y.c0.to_canonical(out + 12);
+    q.y.c1.to_canonical(out + 18);
+    return 0;
+}
+
+}  // extern "C"

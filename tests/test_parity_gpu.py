@@ -1,0 +1,91 @@
+"""GPU parity tests: every advice cell the HIP engine writes must equal the oracle's, bit for bit
+(integer work: no tolerance).  All calls go through the C ABI (libh2e.so)."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from halo2ecc_s_amd import Program, synth
+from parity import compare_advice, compare_shape
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(engine, prog, inputs_list):
+    inputs = np.stack(inputs_list)
+    d_in = engine.upload_inputs(prog, inputs)
+    base, rng, sel, status = engine.alloc(prog, len(inputs_list))
+    engine.run(prog, d_in, base, rng, sel, status)
+    engine.torch.cuda.synchronize()
+    return base, rng, sel, status.cpu().numpy()
+
+
+@pytest.mark.parametrize("fp", [0, 1, 2])
+def test_int_mul_batch(engine, oracle, fp):
+    n = 70  # more than one wave of strands
+    ins = [synth.int_mul_batch_inputs(fp, n, seed_index=10 + k) for k in range(3)]
+    prog = Program.int_mul_batch(fp, n)
+    base, rng, sel, status = _run(engine, prog, ins)
+    assert (status == 0).all()
+    for k, inp in enumerate(ins):
+        orun = oracle_lib.run_int_mul_batch(fp, n, inp)
+        compare_advice(prog, orun, base, rng, sel, instance=k)
+
+
+@pytest.mark.parametrize("fp", [0, 1, 2])
+def test_integer_chip_st(engine, oracle, fp):
+    ins = [synth.integer_chip_st_inputs(fp, seed_index=20 + k) for k in range(4)]
+    prog = Program.integer_chip_st(fp)
+    base, rng, sel, status = _run(engine, prog, ins)
+    assert (status == 0).all(), status
+    for k, inp in enumerate(ins):
+        orun = oracle_lib.run_integer_chip_st(fp, inp)
+        assert orun.info.status == 0
+        compare_advice(prog, orun, base, rng, sel, instance=k)
+
+
+def test_int_mul_edge_values(engine, oracle):
+    """operands 0, 1, w-1 and values just below 2^w_ceil_bits"""
+    for fp in (0, 1, 2):
+        w = synth.W_MODULUS[fp]
+        top = (1 << (w.bit_length())) - 1
+        vals = [0, 0, 1, w - 1, w - 1, w - 1, top, top, w, 1, 0, w - 1]
+        n = len(vals) // 2
+        inp = synth.pack(vals, synth.SLOT_WORDS[fp])
+        prog = Program.int_mul_batch(fp, n)
+        base, rng, sel, status = _run(engine, prog, [inp])
+        assert (status == 0).all()
+        orun = oracle_lib.run_int_mul_batch(fp, n, inp)
+        assert orun.info.status == 0
+        compare_advice(prog, orun, base, rng, sel)
+
+
+@pytest.mark.parametrize("n", [1, 6, 12])
+def test_msm_tile(engine, oracle, n):
+    ins = [synth.msm_bn256_tile_inputs(n, tile=t)[0] for t in range(2)]
+    prog = Program.msm_bn256_tile(n)
+    base, rng, sel, status = _run(engine, prog, ins)
+    assert (status == 0).all(), status
+    for k, inp in enumerate(ins):
+        orun = oracle_lib.run_msm_bn256_tile(n, inp)
+        assert orun.info.status == 0, orun.error
+        compare_advice(prog, orun, base, rng, sel, instance=k)
+
+
+def test_msm_tile_with_identity_inputs(engine, oracle):
+    """identity points go through ecc_bisec_to_non_zero_point / ecc_bisec_scalar (quirk Q9)"""
+    n = 6
+    inp, _ = synth.msm_bn256_tile_inputs(n, seed_index=7, identity_at=(1, 4))
+    prog = Program.msm_bn256_tile(n)
+    base, rng, sel, status = _run(engine, prog, [inp])
+    assert (status == 0).all(), status
+    orun = oracle_lib.run_msm_bn256_tile(n, inp)
+    assert orun.info.status == 0, orun.error
+    compare_advice(prog, orun, base, rng, sel)
+
+
+def test_msm_wrong_expected_sets_status(engine):
+    n = 3
+    inp, _ = synth.msm_bn256_tile_inputs(n, with_expected=False)
+    prog = Program.msm_bn256_tile(n, emit_shape=False)
+    base, rng, sel, status = _run(engine, prog, [inp])
+    assert status[0] & 1  # ASSERT_FAILED, like the reference's assert_true panic

@@ -1,0 +1,42 @@
+"""CPU tests: the recorder's shape artefacts (everything in Records except advice values) must equal
+the oracle's, and the oracle must satisfy the reference's constraint system on the same inputs."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from halo2ecc_s_amd import Program, synth
+from parity import compare_shape
+
+
+@pytest.mark.parametrize("fp", [0, 1, 2])
+def test_int_mul_batch_shape(oracle, h2e_built, fp):
+    n = 5
+    inputs = synth.int_mul_batch_inputs(fp, n)
+    prog = Program.int_mul_batch(fp, n)
+    orun = oracle_lib.run_int_mul_batch(fp, n, inputs)
+    ok, msg = orun.check()
+    assert ok, msg
+    compare_shape(prog, orun)
+    # config 1 of BASELINE.json: one bn256 modmul = 17 base + 28 range rows (+ 2 x assign_w)
+    if fp == 0:
+        assert prog.base_offset == n * (17 + 2) and prog.range_offset == n * (28 + 16)
+
+
+@pytest.mark.parametrize("fp", [0, 1, 2])
+def test_integer_chip_st_shape(oracle, h2e_built, fp):
+    inputs = synth.integer_chip_st_inputs(fp)
+    prog = Program.integer_chip_st(fp)
+    orun = oracle_lib.run_integer_chip_st(fp, inputs)
+    ok, msg = orun.check()
+    assert ok, msg
+    compare_shape(prog, orun)
+
+
+@pytest.mark.parametrize("n", [1, 4, 7, 11])
+def test_msm_tile_shape(oracle, h2e_built, n):
+    inputs, _ = synth.msm_bn256_tile_inputs(n)
+    prog = Program.msm_bn256_tile(n)
+    orun = oracle_lib.run_msm_bn256_tile(n, inputs)
+    ok, msg = orun.check()
+    assert ok, msg
+    compare_shape(prog, orun)
