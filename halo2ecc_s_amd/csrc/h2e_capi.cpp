@@ -204,6 +204,11 @@ int h2e_program_msm_bn256_tile(uint32_t n, int emit_shape, h2e_program** out) {
         h2e::AssignedPoint res = ecc.msm_unsafe_from_inputs(n, s, mi, s + 4 * n, s + 4 * n + 1);
         h2e::AssignedPoint res_expect = ecc.assign_point(h2e::PointInput{s + 4 * n + 6, s + 4 * n + 7, s + 4 * n + 8, false});
         ecc.ecc_assert_equal(res, res_expect);
+        for (int i = 0; i < r.fp.limbs; i++) r.outputs.push_back(res.x.limbs_le[i]);
+        r.outputs.push_back(res.x.native);
+        for (int i = 0; i < r.fp.limbs; i++) r.outputs.push_back(res.y.limbs_le[i]);
+        r.outputs.push_back(res.y.native);
+        r.outputs.push_back(res.z.v.ref);
         p->finish();
     })
     *out = p;
@@ -378,6 +383,34 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         ctx->n_launches++;
     }
     return 0;
+}
+
+int h2e_program_outputs(const h2e_program* p, uint32_t* refs, uint32_t cap) {
+    if (!p) return fail(H2E_ERR_INVALID, "null program");
+    const h2e::Recorder& r = *p->rec;
+    for (uint32_t i = 0; i < r.outputs.size() && i < cap; i++) refs[i] = r.outputs[i];
+    return (int)r.outputs.size();
+}
+int h2e_program_launches(const h2e_program* p, uint64_t* out, uint32_t cap) {
+    if (!p) return fail(H2E_ERR_INVALID, "null program");
+    const h2e::Recorder& r = *p->rec;
+    uint32_t k = 0;
+    for (auto& s : r.segments) {
+        if (s.tape_end <= s.tape_begin) continue;
+        if (k < cap) {
+            uint64_t* o = out + (size_t)k * 8;
+            o[0] = s.n_strands;
+            o[1] = s.tape_end - s.tape_begin;
+            o[2] = s.cells;
+            o[3] = s.dbase;
+            o[4] = s.drange;
+            o[5] = s.dselect;
+            o[6] = s.n_params;
+            o[7] = s.base0;
+        }
+        k++;
+    }
+    return (int)k;
 }
 
 int h2e_set_profiling(h2e_ctx* ctx, int enable) {

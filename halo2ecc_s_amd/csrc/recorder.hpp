@@ -161,6 +161,7 @@ struct Segment {  // one engine launch
     uint32_t input_stride = 0;
     uint32_t n_params = 0;
     uint32_t params_begin = 0;
+    uint64_t cells = 0;  // advice cells written by this launch, per instance (needs emit_shape)
 };
 
 struct FixedPatch {  // a fixed cell whose value is an instance input (constants made from inputs)
@@ -188,7 +189,9 @@ struct Recorder {
     std::vector<uint32_t> params;
     std::vector<Segment> segments;
     std::vector<FixedPatch> fixed_patches;
+    std::vector<uint32_t> outputs;  // absolute refs of the workload's result cells (program specific)
     uint32_t n_input_slots = 0;
+    uint64_t seg_cells_start = 0;
     // ---- shape artefacts (Records minus advice values) ----
     bool emit_shape = true;
     std::vector<FrVal> dict;  // dict[0] unused: index 0 = None
@@ -258,8 +261,12 @@ struct Recorder {
         Segment s;
         s.tape_begin = s.tape_end = (uint32_t)tape.size();
         segments.push_back(s);
+        seg_cells_start = n_advice_cells;
     }
-    void close_segment() { segments.back().tape_end = (uint32_t)tape.size(); }
+    void close_segment() {
+        segments.back().tape_end = (uint32_t)tape.size();
+        segments.back().cells = n_advice_cells - seg_cells_start;
+    }
 
     Offset offset() const {
         Offset o;
@@ -285,6 +292,7 @@ struct Recorder {
         seg.input_stride = input_stride;
         seg.params_begin = (uint32_t)params.size();
         size_t b0 = base_offset, r0 = range_offset, s0 = select_offset;
+        seg_cells_start = n_advice_cells;
         in_strand = true;
         strand_params_begin = seg.params_begin;
         for (uint32_t k = 0; k < n_strands; k++) {
@@ -318,6 +326,7 @@ struct Recorder {
         seg.drange = (uint32_t)delta.range_offset_diff;
         seg.dselect = (uint32_t)delta.select_offset_diff;
         seg.n_params = strand_n_params;
+        seg.cells = n_advice_cells - seg_cells_start;
         segments.push_back(seg);
         // apply_offset_diff(delta.scale(n)) (ecc_chip.rs:352)
         base_offset = b0 + n_strands * delta.base_offset_diff;

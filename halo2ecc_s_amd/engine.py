@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "h2e_program_integer_chip_st", "h2e_program_msm_bn256_tile", "h2e_program_pairing_check_bn256",
     "h2e_program_pairing_check_bls12_381", "h2e_program_destroy", "h2e_program_shape", "h2e_run",
     "h2e_int_mul_batch", "h2e_msm_bn256_tile", "h2e_pairing_check_bn256", "h2e_pairing_check_bls12_381",
-    "h2e_last_run_launch_ms", "h2e_set_profiling",
+    "h2e_last_run_launch_ms", "h2e_set_profiling", "h2e_program_outputs", "h2e_program_launches",
 ]
 
 
@@ -78,6 +78,8 @@ def lib():
     L.h2e_pairing_check_bls12_381.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     L.h2e_last_run_launch_ms.argtypes = [vp, C.POINTER(C.c_float), u32]
     L.h2e_set_profiling.argtypes = [vp, i32]
+    L.h2e_program_outputs.argtypes = [vp, C.POINTER(u32), u32]
+    L.h2e_program_launches.argtypes = [vp, C.POINTER(C.c_uint64), u32]
     _lib = L
     return L
 
@@ -158,6 +160,19 @@ class Program:
 
     def fixed_patches(self):
         return _view(self.shape.fixed_patches, self.n_fixed_patches * 4, np.uint32).reshape(-1, 4)
+
+    def outputs(self):
+        buf = (C.c_uint32 * 64)()
+        n = lib().h2e_program_outputs(self._h, buf, 64)
+        return [int(buf[i]) for i in range(n)]
+
+    def launches(self):
+        """per engine launch: dict(n_strands, n_ops, cells, dbase, drange, dselect, n_params, base0)"""
+        cap = 256
+        buf = (C.c_uint64 * (8 * cap))()
+        n = lib().h2e_program_launches(self._h, buf, cap)
+        keys = ("n_strands", "n_ops", "cells", "dbase", "drange", "dselect", "n_params", "base0")
+        return [dict(zip(keys, [int(buf[8 * i + j]) for j in range(8)])) for i in range(n)]
 
     def close(self):
         if self._h:

@@ -105,6 +105,13 @@ typedef struct h2e_shape {
 } h2e_shape;
 int h2e_program_shape(const h2e_program* p, h2e_shape* out);
 
+/* Result cells of the workload as cell references (region<<30 | col<<27 | row), program specific:
+ * msm tile: res.x limbs, res.x native, res.y limbs, res.y native, res.z.  Returns the count. */
+int h2e_program_outputs(const h2e_program* p, uint32_t* refs, uint32_t cap);
+/* One entry of 8 words per engine launch of a run: n_strands, n_ops, advice cells written per instance
+ * (0 unless emit_shape), per-strand Offset (base, range, select), n_params, first base row.  Returns the count. */
+int h2e_program_launches(const h2e_program* p, uint64_t* out, uint32_t cap);
+
 /* ---- execution --------------------------------------------------------------------------------- */
 /* Fill the advice values of n_instances instances.  d_base/d_range/d_select: device arrays of
  * n_instances * rows * cols * 4 words (instance-major); d_inputs as described above; d_status:

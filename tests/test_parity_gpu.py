@@ -89,3 +89,26 @@ def test_msm_wrong_expected_sets_status(engine):
     prog = Program.msm_bn256_tile(n, emit_shape=False)
     base, rng, sel, status = _run(engine, prog, [inp])
     assert status[0] & 1  # ASSERT_FAILED, like the reference's assert_true panic
+
+
+def test_pairing_check_bn256(engine, oracle):
+    """config 4 unit: check_pairing([(a,b),(-a,b)]) — 6.17M advice cells per instance, bit-exact"""
+    ins = [synth.pairing_check_bn256_inputs(instance=k) for k in range(2)]
+    prog = Program.pairing_check_bn256(emit_shape=False)
+    base, rng, sel, status = _run(engine, prog, ins)
+    assert (status == 0).all(), status
+    orun = oracle_lib.run_pairing_check_bn256(ins[1])
+    assert orun.info.status == 0, orun.error
+    assert (prog.base_offset, prog.range_offset) == (orun.info.base_offset, orun.info.range_offset)
+    compare_advice(prog, orun, base, rng, sel, instance=1)
+
+
+def test_pairing_check_bls12_381(engine, oracle):
+    """config 5 unit: check_pairing([(ac,b),(-a,bc)]) over the 4-limb bls12_381 Fq — 7.95M cells, bit-exact"""
+    ins = [synth.pairing_check_bls12_381_inputs(instance=k) for k in range(2)]
+    prog = Program.pairing_check_bls12_381(emit_shape=False)
+    base, rng, sel, status = _run(engine, prog, ins)
+    assert (status == 0).all(), status
+    orun = oracle_lib.run_pairing_check_bls12_381(ins[0])
+    assert orun.info.status == 0, orun.error
+    compare_advice(prog, orun, base, rng, sel, instance=0)

@@ -40,3 +40,13 @@ def test_msm_tile_shape(oracle, h2e_built, n):
     ok, msg = orun.check()
     assert ok, msg
     compare_shape(prog, orun)
+
+
+def test_pairing_check_bn256_shape(oracle, h2e_built):
+    """config 4 unit (2-pair bn256 check_pairing, G2 as per-instance constants -> fixed patches)"""
+    inputs = synth.pairing_check_bn256_inputs()
+    prog = Program.pairing_check_bn256()
+    orun = oracle_lib.run_pairing_check_bn256(inputs)
+    assert orun.info.status == 0, orun.error   # e(a,b) * e(-a,b) == 1 held in-circuit
+    compare_shape(prog, orun, patches_inputs=inputs)
+    assert prog.n_advice_cells == 6165013
