@@ -112,3 +112,24 @@ def test_pairing_check_bls12_381(engine, oracle):
     orun = oracle_lib.run_pairing_check_bls12_381(ins[0])
     assert orun.info.status == 0, orun.error
     compare_advice(prog, orun, base, rng, sel, instance=0)
+
+
+import golden_util  # noqa: E402
+
+
+@pytest.mark.parametrize("doc", golden_util.load_all(), ids=lambda d: d["name"])
+def test_engine_matches_golden_fixtures(engine, doc):
+    """committed fixtures (inputs + SHA-256 of each advice array) reproduced by the HIP engine"""
+    k, p = doc["kind"], doc["params"]
+    prog = {"int_mul_batch": lambda: Program.int_mul_batch(p["field_pair"], p["n"]),
+            "integer_chip_st": lambda: Program.integer_chip_st(p["field_pair"]),
+            "msm_bn256_tile": lambda: Program.msm_bn256_tile(p["n"])}[k]()
+    assert [prog.base_rows, prog.range_rows, prog.select_rows] == doc["rows"]
+    assert prog.n_advice_cells == doc["n_advice_cells"] and prog.n_permutations == doc["n_permutations"]
+    base, rng, sel, status = _run(engine, prog, [golden_util.inputs_of(doc)])
+    assert (status == 0).all()
+    for t, name in ((base, "base"), (rng, "range"), (sel, "select")):
+        assert golden_util.sha(t[0].cpu().numpy().view(np.uint64)) == doc[name + "_adv_sha256"]
+    flags = (prog.base_flags(), prog.range_flags(), prog.select_flags())
+    for f, name in zip(flags, ("base", "range", "select")):
+        assert golden_util.sha(f) == doc[name + "_flags_sha256"]
