@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--points", type=int, default=1024, help="points per tile")
     ap.add_argument("--cpu-sample-points", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="A/B experiments with deliberately broken arithmetic")
     args = ap.parse_args()
 
     import torch
@@ -116,7 +117,8 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    assert int(status.abs().max()) == 0, f"tile status {status.cpu().numpy()}"
+    if args.warmup > 0 and not args.no_check:
+        assert int(status.abs().max()) == 0, f"tile status {status.cpu().numpy()}"
 
     eng.set_profiling(True)
     if world > 1:
@@ -133,7 +135,8 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    assert int(status.abs().max()) == 0, f"tile status {status.cpu().numpy()}"
+    if not args.no_check:
+        assert int(status.abs().max()) == 0, f"tile status {status.cpu().numpy()}"
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -39,6 +39,9 @@ struct InstanceDesc {
     u64* select;        // [select_rows][2][4]
     const u64* inputs;  // [n_slots][slot_words]
     u32* status;
+    u64* hints;         // [n_hint_slots][4]   quotient hints for H2E_OP_DIV_CORE (canonical values)
+    u64* nd;            // [n_hint_slots][2][4] numerator / denominator pairs (Montgomery form) of the V kernels
+    u64* jac;           // [n_jac_slots][3][WW] Jacobian scratch of the V kernels
 };
 
 struct LC {  // lane context
@@ -53,6 +56,8 @@ struct LC {  // lane context
     const u64* pool;
     const H2EFieldConsts* fc;
     u32 strand, input_stride;
+    const u64* hints;
+    u32 hint_stride;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -462,13 +467,12 @@ WI_INLINE void op_reduce(const LC& c, const H2EOp& op) {
 }
 
 // invert rows for one value (base_chip.rs:298-321): [a, c] ; [a, b | c]
-WI_INLINE void emit_invert(const LC& c, u32 row, const Fe& a, const Fe& inv) {
+WI_INLINE void emit_invert(const LC& c, u32 row, const Fe& a) {
     Fe cc = fe_u64(wd_is_zero<4>(a) ? 1 : 0);
     stB(c, row, 0, a);
     stB(c, row, 1, cc);
     stB(c, row + 1, 0, a);
-    stB(c, row + 1, 1, inv);
-    stB(c, row + 1, 4, cc);
+    stB(c, row + 1, 4, cc);  // (row+1, col 1) = a^-1 comes from the fix-up kernel
 }
 
 template <class FP>
@@ -484,44 +488,27 @@ WI_INLINE void op_is_int_zero(const LC& c, const H2EOp& op) {
     x[1] = submod_n(c, a.native, wd_load<4>(c.fc->w_native));
 #pragma unroll
     for (int i = 0; i < FP::PW; i++) x[2 + i] = submod_n(c, fe_of(a.l[i]), fe_of(wd_load<2>(c.fc->w_limbs[i])));
-    // Montgomery's trick: one inversion for all of them (zeros are skipped)
-    Fe pre[NI];
-    Fe acc = fe_u64(1);
-#pragma unroll
-    for (int i = 0; i < NI; i++) {
-        pre[i] = acc;
-        if (!wd_is_zero<4>(x[i])) acc = mulmod_n(c, acc, x[i]);
-    }
-    Fe ainv = inv_n(c, acc);
-    Fe inv[NI];
-#pragma unroll
-    for (int i = NI - 1; i >= 0; i--) {
-        if (wd_is_zero<4>(x[i])) {
-            inv[i] = wd_zero<4>();
-        } else {
-            inv[i] = mulmod_n(c, ainv, pre[i]);
-            ainv = mulmod_n(c, ainv, x[i]);
-        }
-    }
+    // The inverse witnesses (col 1 of each second invert row) are NOT written here: nothing downstream reads
+    // them, so they are filled afterwards by h2e_fixup_inverses with one batched inversion per 64 cells.
     u32 r = op.base_row;
     // is_pure_zero (integer_chip.rs:540-548)
 #pragma unroll
     for (int i = 0; i < L; i++) stB(c, r, i, fe_of(a.l[i]));
     stB(c, r, 4, x[0]);
-    emit_invert(c, r + 1, x[0], inv[0]);
+    emit_invert(c, r + 1, x[0]);
     u64 is_zero = wd_is_zero<4>(x[0]) ? 1 : 0;
     r += 3;
     // is_pure_w_modulus (integer_chip.rs:550-570)
     stB(c, r, 0, a.native);
     stB(c, r, 4, x[1]);
-    emit_invert(c, r + 1, x[1], inv[1]);
+    emit_invert(c, r + 1, x[1]);
     u64 is_eq = wd_is_zero<4>(x[1]) ? 1 : 0;
     r += 3;
 #pragma unroll
     for (int i = 0; i < FP::PW; i++) {
         stB(c, r, 0, fe_of(a.l[i]));
         stB(c, r, 4, x[2 + i]);
-        emit_invert(c, r + 1, x[2 + i], inv[2 + i]);
+        emit_invert(c, r + 1, x[2 + i]);
         u64 is_limb_eq = wd_is_zero<4>(x[2 + i]) ? 1 : 0;
         stB(c, r + 3, 0, fe_u64(is_eq));
         stB(c, r + 3, 1, fe_u64(is_limb_eq));
@@ -565,9 +552,17 @@ WI_INLINE void op_div_core(const LC& c, const H2EOp& op) {
     Wd<FP::WW> a_red, b_red;
     divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(A), q0, a_red);
     divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(B), q0, b_red);
-    Wd<FP::WW> binv = wd_inv_mod<FP::WW>(b_red, w);
     Wd<FP::WW> cv;
-    divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FP::WW, FP::WW>(a_red, binv)), q0, cv);
+    if (op.flags & H2E_FLAG_HINTED) {
+        // c = a * b^-1 mod w was predicted by the V kernels (native Montgomery arithmetic + batch inversion);
+        // a wrong hint cannot go unnoticed: (b*c - a) must be an exact multiple of w below.
+        u32 slot = op.imm + ((op.flags & H2E_FLAG_HINT_STRIDED) ? c.strand * c.hint_stride : 0);
+        cv = wd_load<FP::WW>(c.hints + (size_t)slot * H2E_W_WORDS_MAX);
+        if (wd_is_zero<FP::WW>(b_red)) cv = wd_zero<FP::WW>();
+    } else {
+        Wd<FP::WW> binv = wd_inv_mod<FP::WW>(b_red, w);
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FP::WW, FP::WW>(a_red, binv)), q0, cv);
+    }
     // d = (b*c - a) / w   (exact)
     Wd<FPX<FP>::XW> bc = wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FP::WW>(B, cv));
     Wd<FPX<FP>::XW> num = wd_sub<FPX<FP>::XW>(bc, wd_resize<FPX<FP>::XW>(A));
@@ -797,9 +792,377 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     c.fc = fc;
     c.strand = strand;
     c.input_stride = L.input_stride;
+    c.hints = d.hints;
+    c.hint_stride = L.hint_stride;
     for (u32 i = 0; i < L.n_ops; i++) {
         H2EOp op = L.tape[i];
         exec_op<FP>(c, op);
+    }
+}
+
+// ================================================================================================
+// Montgomery arithmetic (R = 2^(64 N)) — used by the value-predictor kernels (mod w) and the inverse fix-up (mod n)
+template <int N>
+struct Mont {
+    Wd<N> p, r2, r1;
+    u64 minv;
+};
+WI_INLINE void mac64(u64 a, u64 b, u64 c, u64& carry, u64& out) {  // out = low(a*b + c + carry); carry = high
+    u64 lo = a * b, hi = __umul64hi(a, b);
+    lo += c;
+    hi += (lo < c);
+    lo += carry;
+    hi += (lo < carry);
+    out = lo;
+    carry = hi;
+}
+template <int N>
+WI_INLINE Wd<N> mont_mul(const Mont<N>& M, const Wd<N>& a, const Wd<N>& b) {
+    u64 t[N + 2];
+#pragma unroll
+    for (int i = 0; i < N + 2; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) mac64(a.v[j], b.v[i], t[j], c, t[j]);
+        u64 s = t[N] + c;
+        t[N + 1] = (s < c);
+        t[N] = s;
+        u64 m = t[0] * M.minv, dummy;
+        c = 0;
+        mac64(m, M.p.v[0], t[0], c, dummy);
+#pragma unroll
+        for (int j = 1; j < N; j++) mac64(m, M.p.v[j], t[j], c, t[j - 1]);
+        s = t[N] + c;
+        u64 c2 = (s < c);
+        t[N - 1] = s;
+        t[N] = t[N + 1] + c2;
+    }
+    Wd<N> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = t[i];
+    bool ge = t[N] != 0 || wd_geq<N>(r, M.p);
+    return ge ? wd_sub<N>(r, M.p) : r;
+}
+template <int N>
+WI_INLINE Wd<N> mont_add(const Mont<N>& M, const Wd<N>& a, const Wd<N>& b) {
+    u64 c;
+    Wd<N> s = wd_add_c<N>(a, b, c);
+    return (c || wd_geq<N>(s, M.p)) ? wd_sub<N>(s, M.p) : s;
+}
+template <int N>
+WI_INLINE Wd<N> mont_sub(const Mont<N>& M, const Wd<N>& a, const Wd<N>& b) {
+    return wd_geq<N>(a, b) ? wd_sub<N>(a, b) : wd_sub<N>(wd_add<N>(a, M.p), b);
+}
+template <int N>
+WI_INLINE Wd<N> mont_dbl(const Mont<N>& M, const Wd<N>& a) { return mont_add<N>(M, a, a); }
+template <int N>
+WI_INLINE Wd<N> to_mont(const Mont<N>& M, const Wd<N>& a) { return mont_mul<N>(M, a, M.r2); }
+template <int N>
+WI_INLINE Wd<N> from_mont(const Mont<N>& M, const Wd<N>& a) { return mont_mul<N>(M, a, wd_from_u64<N>(1)); }
+// inverse in the Montgomery domain (0 -> 0)
+template <int N>
+WI_INLINE Wd<N> mont_inv(const Mont<N>& M, const Wd<N>& a) {
+    return to_mont<N>(M, wd_inv_mod<N>(from_mont<N>(M, a), M.p));
+}
+template <class FP>
+WI_INLINE Mont<FP::WW> mont_w(const H2EFieldConsts* fc) {
+    Mont<FP::WW> M;
+    M.p = wd_load<FP::WW>(fc->w);
+    M.r2 = wd_load<FP::WW>(fc->w_r2);
+    M.r1 = wd_load<FP::WW>(fc->w_r1);
+    M.minv = fc->w_minv;
+    return M;
+}
+WI_INLINE Mont<4> mont_n(const H2EFieldConsts* fc) {
+    Mont<4> M;
+    M.p = wd_load<4>(fc->n);
+    M.r2 = wd_load<4>(fc->n_r2);
+    M.r1 = wd_load<4>(fc->n_r1);
+    M.minv = fc->n_minv;
+    return M;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fix-up of the is_zero inverse witnesses (base_chip.rs:298-321: b = a^-1 or 0), batched with Montgomery's
+// trick: one lane owns FIXUP_K consecutive cells of one strand's list; the destination cells themselves hold
+// the running prefix products between the forward and the backward pass.
+static constexpr int FIXUP_K = 32;
+__global__ void __launch_bounds__(64) h2e_fixup_inverses(H2ELaunch L, const InstanceDesc* inst, u32 n_instances,
+                                                         const H2EFieldConsts* fc) {
+    u32 chunks = (L.n_fixups + FIXUP_K - 1) / FIXUP_K;
+    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 total = n_instances * L.n_strands * chunks;
+    if (gid >= total) return;
+    u32 chunk = gid % chunks, strand = (gid / chunks) % L.n_strands, instance = gid / (chunks * L.n_strands);
+    u64* base = inst[instance].base;
+    u32 ob = L.strand_base0 + strand * L.delta_base;
+    Mont<4> M = mont_n(fc);
+    u32 lo = chunk * FIXUP_K, hi = min(lo + FIXUP_K, L.n_fixups);
+    Fe acc = M.r1;  // Montgomery one
+    for (u32 i = lo; i < hi; i++) {
+        u64* row = base + (size_t)(L.fixups[i] + ob) * 5 * 4;
+        Fe x = wd_load<4>(row);
+        st_cell(row + 4, acc);  // prefix product of the non-zero values before i
+        if (!wd_is_zero<4>(x)) acc = mont_mul<4>(M, acc, to_mont<4>(M, x));
+    }
+    Fe ainv = mont_inv<4>(M, acc);
+    for (u32 i = hi; i-- > lo;) {
+        u64* row = base + (size_t)(L.fixups[i] + ob) * 5 * 4;
+        Fe x = wd_load<4>(row);
+        Fe pre = wd_load<4>(row + 4);
+        Fe out = wd_zero<4>();
+        if (!wd_is_zero<4>(x)) {
+            out = from_mont<4>(M, mont_mul<4>(M, ainv, pre));
+            ainv = mont_mul<4>(M, ainv, to_mont<4>(M, x));
+        }
+        st_cell(row + 4, out);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Value-predictor ("V") kernels: native Jacobian arithmetic over W (a = 0 curves) in Montgomery form.
+template <int N>
+struct Jac {
+    Wd<N> x, y, z;
+};
+template <int N>
+WI_INLINE Jac<N> jac_dbl(const Mont<N>& M, const Jac<N>& p, Wd<N>& num) {  // num = 3 X^2 ; denominator = result z = 2 Y Z
+    Wd<N> a = mont_mul<N>(M, p.x, p.x), b = mont_mul<N>(M, p.y, p.y), cc = mont_mul<N>(M, b, b);
+    Wd<N> xb = mont_add<N>(M, p.x, b);
+    Wd<N> d = mont_dbl<N>(M, mont_sub<N>(M, mont_sub<N>(M, mont_mul<N>(M, xb, xb), a), cc));
+    Wd<N> e = mont_add<N>(M, mont_dbl<N>(M, a), a);
+    Wd<N> f = mont_mul<N>(M, e, e);
+    Jac<N> r;
+    r.x = mont_sub<N>(M, f, mont_dbl<N>(M, d));
+    Wd<N> c8 = mont_dbl<N>(M, mont_dbl<N>(M, mont_dbl<N>(M, cc)));
+    r.y = mont_sub<N>(M, mont_mul<N>(M, e, mont_sub<N>(M, d, r.x)), c8);
+    r.z = mont_dbl<N>(M, mont_mul<N>(M, p.y, p.z));
+    num = e;
+    return r;
+}
+// p (Jacobian) + q (affine).  num = S2 - Y1 ; denominator = result z = Z1 * H   (lambda = num / z3 in either order)
+template <int N>
+WI_INLINE Jac<N> jac_madd(const Mont<N>& M, const Jac<N>& p, const Wd<N>& qx, const Wd<N>& qy, Wd<N>& num) {
+    Wd<N> z1z1 = mont_mul<N>(M, p.z, p.z);
+    Wd<N> u2 = mont_mul<N>(M, qx, z1z1);
+    Wd<N> s2 = mont_mul<N>(M, mont_mul<N>(M, qy, p.z), z1z1);
+    Wd<N> h = mont_sub<N>(M, u2, p.x), r = mont_sub<N>(M, s2, p.y);
+    Wd<N> hh = mont_mul<N>(M, h, h), hhh = mont_mul<N>(M, hh, h), v = mont_mul<N>(M, p.x, hh);
+    Jac<N> o;
+    o.x = mont_sub<N>(M, mont_sub<N>(M, mont_mul<N>(M, r, r), hhh), mont_dbl<N>(M, v));
+    o.y = mont_sub<N>(M, mont_mul<N>(M, r, mont_sub<N>(M, v, o.x)), mont_mul<N>(M, p.y, hhh));
+    o.z = mont_mul<N>(M, p.z, h);
+    num = r;
+    return o;
+}
+// p + q, both Jacobian.  num = S2 - S1 ; denominator = result z = Z1 Z2 H
+template <int N>
+WI_INLINE Jac<N> jac_add(const Mont<N>& M, const Jac<N>& p, const Jac<N>& q, Wd<N>& num) {
+    Wd<N> z1z1 = mont_mul<N>(M, p.z, p.z), z2z2 = mont_mul<N>(M, q.z, q.z);
+    Wd<N> u1 = mont_mul<N>(M, p.x, z2z2), u2 = mont_mul<N>(M, q.x, z1z1);
+    Wd<N> s1 = mont_mul<N>(M, mont_mul<N>(M, p.y, q.z), z2z2), s2 = mont_mul<N>(M, mont_mul<N>(M, q.y, p.z), z1z1);
+    Wd<N> h = mont_sub<N>(M, u2, u1), r = mont_sub<N>(M, s2, s1);
+    Wd<N> hh = mont_mul<N>(M, h, h), hhh = mont_mul<N>(M, hh, h), v = mont_mul<N>(M, u1, hh);
+    Jac<N> o;
+    o.x = mont_sub<N>(M, mont_sub<N>(M, mont_mul<N>(M, r, r), hhh), mont_dbl<N>(M, v));
+    o.y = mont_sub<N>(M, mont_mul<N>(M, r, mont_sub<N>(M, v, o.x)), mont_mul<N>(M, s1, hhh));
+    o.z = mont_mul<N>(M, mont_mul<N>(M, p.z, q.z), h);
+    num = r;
+    return o;
+}
+
+struct VC {  // V-kernel lane context
+    LC c;
+    u64* nd;
+    u64* jac;
+};
+// canonical W value of an assigned (reduced, times == 1) integer from its limb cells -> Montgomery form
+template <class FP>
+WI_INLINE Wd<FP::WW> ld_w_mont(const LC& c, const Mont<FP::WW>& M, const u32* limb_refs) {
+    Limb l[FP::L];
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) l[i] = ld_limb(c, limb_refs[i]);
+    return to_mont<FP::WW>(M, wd_resize<FP::WW>(compose<FP, FPX<FP>::AW>(l)));
+}
+template <class FP>
+WI_INLINE void st_nd(const VC& v, u32 slot, const Wd<FP::WW>& num, const Wd<FP::WW>& den) {
+    u64* p = v.nd + (size_t)slot * 2 * H2E_W_WORDS_MAX;
+#pragma unroll
+    for (int i = 0; i < FP::WW; i++) {
+        p[i] = num.v[i];
+        p[H2E_W_WORDS_MAX + i] = den.v[i];
+    }
+}
+template <class FP>
+WI_INLINE void st_jac(const VC& v, u32 slot, const Jac<FP::WW>& p) {
+    u64* q = v.jac + (size_t)slot * 3 * H2E_W_WORDS_MAX;
+#pragma unroll
+    for (int i = 0; i < FP::WW; i++) {
+        q[i] = p.x.v[i];
+        q[H2E_W_WORDS_MAX + i] = p.y.v[i];
+        q[2 * H2E_W_WORDS_MAX + i] = p.z.v[i];
+    }
+}
+template <class FP>
+WI_INLINE Jac<FP::WW> ld_jac(const VC& v, u32 slot) {
+    const u64* q = v.jac + (size_t)slot * 3 * H2E_W_WORDS_MAX;
+    Jac<FP::WW> p;
+    p.x = wd_load<FP::WW>(q);
+    p.y = wd_load<FP::WW>(q + H2E_W_WORDS_MAX);
+    p.z = wd_load<FP::WW>(q + 2 * H2E_W_WORDS_MAX);
+    return p;
+}
+
+// args of the V kernels (uint32 arrays, absolute cell refs unless noted)
+//  CANDIDATES: [0] group size sz; then, per lane, a ref table of sz*2*(L+1) point refs + 2*(L+1) init refs taken
+//              from the params table (same layout as the X strand's parameters).  hints: 2^sz - 1 per lane.
+//              jac scratch: 2^sz slots per lane.
+//  WINDOWS:    [0] n_groups, [1] group_size, [2] n_points, [3..3+2(L+1)) refs of -r1 (x limbs, x native, y limbs,
+//              y native), then n_groups aux offsets of the candidate tables.  params: bit cell of point j = param j.
+//              hints: n_groups per lane.  jac scratch: 1 slot per lane (the window's final sum).
+//  TAIL:       [0] windows, [1] odd-groups flag, [2..) refs of r1, then refs of -r2 (2(L+1) each),
+//              [last] jac scratch slot of window 0's sum.  hints: windows * (2 + odd).
+template <class FP>
+__global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* args, const u32* params_all, const u32* aux,
+                                                  const InstanceDesc* inst, u32 n_instances, const H2EFieldConsts* fc) {
+    constexpr int L = FP::L, NW = FP::WW, NR = 2 * (L + 1);
+    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_instances * K.n_lanes) return;
+    u32 instance = gid / K.n_lanes, lane = gid % K.n_lanes;
+    InstanceDesc d = inst[instance];
+    VC v;
+    v.c.base = d.base;
+    v.c.range = d.range;
+    v.c.select = d.select;
+    v.c.inputs = d.inputs;
+    v.c.status = d.status;
+    v.c.ob = v.c.orr = v.c.os = 0;
+    v.c.params = params_all + K.params_begin + (size_t)lane * K.n_params;
+    v.c.aux = aux;
+    v.c.pool = nullptr;
+    v.c.fc = fc;
+    v.c.strand = lane;
+    v.c.input_stride = 0;
+    v.c.hints = nullptr;
+    v.c.hint_stride = 0;
+    v.nd = d.nd;
+    v.jac = d.jac;
+    const u32* a = args + K.args_begin;
+    Mont<NW> M = mont_w<FP>(fc);
+    u32 hint0 = K.hint_base + lane * K.hints_per_lane;
+    if (K.kind == H2E_PRE_MSM_CANDIDATES) {
+        // cl[i] = cl[i - lowbit(i)] + pts[ctz(i)]   (ecc_chip.rs:266-272), a = cl[other] Jacobian, b = pts affine
+        u32 sz = a[0];
+        u32 j0 = K.scratch_begin + lane * (1u << sz);
+        const u32* prm = v.c.params;
+        Wd<NW> px[5], py[5];
+        for (u32 j = 0; j < sz && j < 5; j++) {
+            px[j] = ld_w_mont<FP>(v.c, M, prm + j * NR);
+            py[j] = ld_w_mont<FP>(v.c, M, prm + j * NR + L + 1);
+        }
+        Jac<NW> init;
+        init.x = ld_w_mont<FP>(v.c, M, prm + sz * NR);
+        init.y = ld_w_mont<FP>(v.c, M, prm + sz * NR + L + 1);
+        init.z = M.r1;
+        st_jac<FP>(v, j0, init);
+        for (u32 i = 1; i < (1u << sz); i++) {
+            u32 pos = __builtin_ctz(i), other = i - (1u << pos);
+            Jac<NW> p = ld_jac<FP>(v, j0 + other);
+            Wd<NW> qx = px[0], qy = py[0];
+#pragma unroll
+            for (int j = 1; j < 5; j++)
+                if ((u32)j == pos) {
+                    qx = px[j];
+                    qy = py[j];
+                }
+            Wd<NW> num;
+            Jac<NW> r = jac_madd<NW>(M, p, qx, qy, num);
+            st_nd<FP>(v, hint0 + i - 1, num, r.z);
+            st_jac<FP>(v, j0 + i, r);
+        }
+    } else if (K.kind == H2E_PRE_MSM_WINDOWS) {
+        // acc = -r1; acc = C_g[idx] + acc for every group   (ecc_chip.rs:320-336), a = candidate affine, b = acc Jacobian
+        u32 n_groups = a[0], group_size = a[1], n_points = a[2];
+        const u32* neg_r1 = a + 3;
+        const u32* tables = a + 3 + NR;
+        Jac<NW> acc;
+        acc.x = ld_w_mont<FP>(v.c, M, neg_r1);
+        acc.y = ld_w_mont<FP>(v.c, M, neg_r1 + L + 1);
+        acc.z = M.r1;
+        for (u32 g = 0; g < n_groups; g++) {
+            u32 lo = g * group_size, hi = min(n_points, lo + group_size), idx = 0;
+            for (u32 j = lo; j < hi; j++) idx |= (u32)(ld_limb(v.c, H2E_MAKE_REF(H2E_REGION_PARAM, 0, 0, j)).v[0] & 1) << (j - lo);
+            const u32* tab = aux + tables[g] + idx * NR;
+            Wd<NW> cx = ld_w_mont<FP>(v.c, M, tab), cy = ld_w_mont<FP>(v.c, M, tab + L + 1);
+            Wd<NW> num;
+            acc = jac_madd<NW>(M, acc, cx, cy, num);
+            st_nd<FP>(v, hint0 + g, num, acc.z);
+        }
+        st_jac<FP>(v, K.scratch_begin + lane, acc);
+    } else if (K.kind == H2E_PRE_MSM_TAIL) {
+        // acc = r1; per window: acc = 2 acc; acc = line_w + acc; [acc = acc + (-r2)]   (ecc_chip.rs:355-362)
+        u32 windows = a[0], odd = a[1];
+        const u32* r1 = a + 2;
+        const u32* neg_r2 = a + 2 + NR;
+        u32 line0 = a[2 + 2 * NR];
+        Jac<NW> acc;
+        acc.x = ld_w_mont<FP>(v.c, M, r1);
+        acc.y = ld_w_mont<FP>(v.c, M, r1 + L + 1);
+        acc.z = M.r1;
+        Wd<NW> bx = ld_w_mont<FP>(v.c, M, neg_r2), by = ld_w_mont<FP>(v.c, M, neg_r2 + L + 1);
+        u32 h = hint0;
+        for (u32 w = 0; w < windows; w++) {
+            Wd<NW> num;
+            acc = jac_dbl<NW>(M, acc, num);
+            st_nd<FP>(v, h++, num, acc.z);
+            Jac<NW> line = ld_jac<FP>(v, line0 + w);
+            acc = jac_add<NW>(M, line, acc, num);
+            st_nd<FP>(v, h++, num, acc.z);
+            if (odd) {
+                acc = jac_madd<NW>(M, acc, bx, by, num);
+                st_nd<FP>(v, h++, num, acc.z);
+            }
+        }
+    }
+}
+
+// lambda = num / den for a run of hint slots: Montgomery's trick over HINT_K consecutive slots per lane, the
+// hint cells hold the prefix products between the two passes; output canonical (what assign_w(c) expects).
+static constexpr int HINT_K = 32;
+template <class FP>
+__global__ void __launch_bounds__(64) h2e_finalize_hints(u32 hint_base, u32 n_hints, const InstanceDesc* inst,
+                                                         u32 n_instances, const H2EFieldConsts* fc) {
+    constexpr int NW = FP::WW;
+    u32 chunks = (n_hints + HINT_K - 1) / HINT_K;
+    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_instances * chunks) return;
+    u32 instance = gid / chunks, chunk = gid % chunks;
+    InstanceDesc d = inst[instance];
+    Mont<NW> M = mont_w<FP>(fc);
+    u32 lo = hint_base + chunk * HINT_K, hi = min(lo + HINT_K, hint_base + n_hints);
+    Wd<NW> acc = M.r1;
+    for (u32 s = lo; s < hi; s++) {
+        Wd<NW> den = wd_load<NW>(d.nd + (size_t)s * 2 * H2E_W_WORDS_MAX + H2E_W_WORDS_MAX);
+        u64* hp = d.hints + (size_t)s * H2E_W_WORDS_MAX;
+#pragma unroll
+        for (int i = 0; i < NW; i++) hp[i] = acc.v[i];
+        if (!wd_is_zero<NW>(den)) acc = mont_mul<NW>(M, acc, den);
+    }
+    Wd<NW> ainv = mont_inv<NW>(M, acc);
+    for (u32 s = hi; s-- > lo;) {
+        const u64* np = d.nd + (size_t)s * 2 * H2E_W_WORDS_MAX;
+        Wd<NW> num = wd_load<NW>(np), den = wd_load<NW>(np + H2E_W_WORDS_MAX);
+        u64* hp = d.hints + (size_t)s * H2E_W_WORDS_MAX;
+        Wd<NW> out = wd_zero<NW>();
+        if (!wd_is_zero<NW>(den)) {
+            Wd<NW> dinv = mont_mul<NW>(M, ainv, wd_load<NW>(hp));
+            ainv = mont_mul<NW>(M, ainv, den);
+            out = from_mont<NW>(M, mont_mul<NW>(M, num, dinv));
+        }
+#pragma unroll
+        for (int i = 0; i < NW; i++) hp[i] = out.v[i];
     }
 }
 
@@ -815,6 +1178,40 @@ extern "C" int h2e_engine_launch(int field_pair, const H2ELaunch* launch, const 
         case 0: hipLaunchKernelGGL(h2e_run_tape<FP_BN256_FQ>, grid, block, 0, stream, *launch, inst, n_instances, fc_dev); break;
         case 1: hipLaunchKernelGGL(h2e_run_tape<FP_BLS_FQ>, grid, block, 0, stream, *launch, inst, n_instances, fc_dev); break;
         case 2: hipLaunchKernelGGL(h2e_run_tape<FP_BLS_FR>, grid, block, 0, stream, *launch, inst, n_instances, fc_dev); break;
+        default: return -1;
+    }
+    if ((int)hipGetLastError() != 0) return (int)hipGetLastError();
+    if (launch->n_fixups) {
+        u32 chunks = (launch->n_fixups + FIXUP_K - 1) / FIXUP_K;
+        u32 lanes = n_instances * launch->n_strands * chunks;
+        hipLaunchKernelGGL(h2e_fixup_inverses, dim3((lanes + 63) / 64), dim3(64), 0, stream, *launch, inst, n_instances, fc_dev);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int h2e_engine_predict(int field_pair, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,
+                                  const uint32_t* aux_dev, const void* instances, uint32_t n_instances,
+                                  const H2EFieldConsts* fc_dev, hipStream_t stream) {
+    const InstanceDesc* inst = (const InstanceDesc*)instances;
+    u32 lanes = n_instances * k->n_lanes;
+    if (lanes == 0) return 0;
+    dim3 block(64), grid((lanes + 63) / 64);
+    u32 n_hints = k->n_lanes * k->hints_per_lane;
+    u32 chunks = (n_hints + HINT_K - 1) / HINT_K;
+    dim3 grid2((n_instances * chunks + 63) / 64);
+    switch (field_pair) {
+        case 0:
+            hipLaunchKernelGGL(h2e_predict<FP_BN256_FQ>, grid, block, 0, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev);
+            hipLaunchKernelGGL(h2e_finalize_hints<FP_BN256_FQ>, grid2, block, 0, stream, k->hint_base, n_hints, inst, n_instances, fc_dev);
+            break;
+        case 1:
+            hipLaunchKernelGGL(h2e_predict<FP_BLS_FQ>, grid, block, 0, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev);
+            hipLaunchKernelGGL(h2e_finalize_hints<FP_BLS_FQ>, grid2, block, 0, stream, k->hint_base, n_hints, inst, n_instances, fc_dev);
+            break;
+        case 2:
+            hipLaunchKernelGGL(h2e_predict<FP_BLS_FR>, grid, block, 0, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev);
+            hipLaunchKernelGGL(h2e_finalize_hints<FP_BLS_FR>, grid2, block, 0, stream, k->hint_base, n_hints, inst, n_instances, fc_dev);
+            break;
         default: return -1;
     }
     return (int)hipGetLastError();

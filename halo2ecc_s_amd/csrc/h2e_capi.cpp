@@ -9,6 +9,9 @@
 
 extern "C" int h2e_engine_launch(int field_pair, const H2ELaunch* launch, const void* instances, uint32_t n_instances,
                                  const H2EFieldConsts* fc_dev, hipStream_t stream);
+extern "C" int h2e_engine_predict(int field_pair, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,
+                                  const uint32_t* aux_dev, const void* instances, uint32_t n_instances,
+                                  const H2EFieldConsts* fc_dev, hipStream_t stream);
 
 namespace {
 
@@ -37,6 +40,9 @@ struct InstanceDescHost {  // must match engine.hip InstanceDesc
     uint64_t* select;
     const uint64_t* inputs;
     uint32_t* status;
+    uint64_t* hints;
+    uint64_t* nd;
+    uint64_t* jac;
 };
 
 }  // namespace
@@ -52,6 +58,8 @@ struct h2e_program {
     uint32_t* d_aux = nullptr;
     uint64_t* d_pool = nullptr;
     uint32_t* d_params = nullptr;
+    uint32_t* d_fixups = nullptr;
+    uint32_t* d_pre_args = nullptr;
     InstanceDescHost* d_inst = nullptr;
     uint32_t inst_cap = 0;
     std::vector<InstanceDescHost> h_inst;
@@ -62,6 +70,8 @@ struct h2e_program {
             (void)hipFree(d_aux);
             (void)hipFree(d_pool);
             (void)hipFree(d_params);
+            (void)hipFree(d_fixups);
+            (void)hipFree(d_pre_args);
             (void)hipFree(d_inst);
         }
     }
@@ -98,6 +108,9 @@ struct h2e_ctx {
     H2EFieldConsts* d_fc[3] = {nullptr, nullptr, nullptr};
     std::map<std::string, h2e_program*> cache;
     bool profiling = false;
+    // engine workspace (grow-only): quotient hints, numerator/denominator pairs, Jacobian scratch
+    uint64_t *ws_hints = nullptr, *ws_nd = nullptr, *ws_jac = nullptr;
+    size_t ws_hints_words = 0, ws_nd_words = 0, ws_jac_words = 0;
     std::vector<hipEvent_t> ev;
     uint32_t n_launches = 0;
     ~h2e_ctx() {
@@ -105,6 +118,9 @@ struct h2e_ctx {
         for (int i = 0; i < 3; i++)
             if (d_fc[i]) (void)hipFree(d_fc[i]);
         for (auto e : ev) (void)hipEventDestroy(e);
+        (void)hipFree(ws_hints);
+        (void)hipFree(ws_nd);
+        (void)hipFree(ws_jac);
     }
 };
 
@@ -315,6 +331,8 @@ static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
     HIP_TRY(up((void**)&p->d_aux, r.aux.empty() ? nullptr : r.aux.data(), r.aux.size() * 4));
     HIP_TRY(up((void**)&p->d_pool, r.pool.empty() ? nullptr : r.pool.data(), r.pool.size() * 8));
     HIP_TRY(up((void**)&p->d_params, r.params.empty() ? nullptr : r.params.data(), r.params.size() * 4));
+    HIP_TRY(up((void**)&p->d_fixups, r.fixups.empty() ? nullptr : r.fixups.data(), r.fixups.size() * 4));
+    HIP_TRY(up((void**)&p->d_pre_args, r.pre_args.empty() ? nullptr : r.pre_args.data(), r.pre_args.size() * 4));
     p->device = ctx->device;
     return 0;
 }
@@ -341,6 +359,24 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
     }
     p->h_inst.resize(n_instances);
     size_t slot_words = r.fp.w_words;
+    // workspace
+    auto grow = [&](uint64_t** buf, size_t* have, size_t need) -> hipError_t {
+        if (need <= *have) return hipSuccess;
+        if (*buf) {
+            hipError_t e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return e;
+            (void)hipFree(*buf);
+            *buf = nullptr;
+        }
+        hipError_t e = hipMalloc((void**)buf, need * 8);
+        if (e == hipSuccess) *have = need;
+        return e;
+    };
+    size_t hint_words = (size_t)r.n_hint_slots * H2E_W_WORDS_MAX, nd_words = hint_words * 2,
+           jac_words = (size_t)r.n_jac_slots * 3 * H2E_W_WORDS_MAX;
+    HIP_TRY(grow(&ctx->ws_hints, &ctx->ws_hints_words, std::max<size_t>(1, hint_words * n_instances)));
+    HIP_TRY(grow(&ctx->ws_nd, &ctx->ws_nd_words, std::max<size_t>(1, nd_words * n_instances)));
+    HIP_TRY(grow(&ctx->ws_jac, &ctx->ws_jac_words, std::max<size_t>(1, jac_words * n_instances)));
     for (uint32_t i = 0; i < n_instances; i++) {
         InstanceDescHost& d = p->h_inst[i];
         d.base = (uint64_t*)d_base + (size_t)i * p->base_rows * 5 * 4;
@@ -348,12 +384,22 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         d.select = (uint64_t*)d_select + (size_t)i * p->select_rows * 2 * 4;
         d.inputs = (const uint64_t*)d_inputs + (size_t)i * r.n_input_slots * slot_words;
         d.status = (uint32_t*)d_status + i;
+        d.hints = ctx->ws_hints + (size_t)i * hint_words;
+        d.nd = ctx->ws_nd + (size_t)i * nd_words;
+        d.jac = ctx->ws_jac + (size_t)i * jac_words;
     }
     HIP_TRY(hipMemcpyAsync(p->d_inst, p->h_inst.data(), (size_t)n_instances * sizeof(InstanceDescHost),
                            hipMemcpyHostToDevice, stream));
     ctx->n_launches = 0;
-    for (auto& s : r.segments) {
+    for (size_t si = 0; si < r.segments.size(); si++) {
+        const h2e::Segment& s = r.segments[si];
         if (s.tape_end <= s.tape_begin) continue;
+        for (auto& pk : r.pre_kernels) {
+            if (pk.before_segment != si) continue;
+            int prc = h2e_engine_predict(fp, &pk.k, p->d_pre_args, p->d_params, p->d_aux, p->d_inst, n_instances,
+                                         ctx->d_fc[fp], stream);
+            if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
+        }
         H2ELaunch L;
         L.tape = p->d_tape + s.tape_begin;
         L.n_ops = s.tape_end - s.tape_begin;
@@ -369,6 +415,9 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         L.params = p->d_params + s.params_begin;
         L.aux = p->d_aux;
         L.const_pool = p->d_pool;
+        L.hint_stride = s.hint_stride;
+        L.n_fixups = s.n_fixups;
+        L.fixups = p->d_fixups + s.fixups_begin;
         if (ctx->profiling) {
             while (ctx->ev.size() < 2 * (size_t)(ctx->n_launches + 1)) {
                 hipEvent_t e;

@@ -135,6 +135,22 @@ struct FieldPair {
             }
             (comp % n).to_words(fc.ceil_native[t], 4);
         }
+        // Montgomery constants, R = 2^(64 * words)
+        auto minv = [](uint64_t p0) {
+            uint64_t inv = 1;
+            for (int i = 0; i < 63; i++) {
+                inv = inv * inv;
+                inv = inv * p0;
+            }
+            return (uint64_t)0 - inv;
+        };
+        HBig Rw = HBig(1).shl(64 * w_words), Rn = HBig(1).shl(256);
+        fc.w_minv = minv(w.word(0));
+        ((Rw * Rw) % w).to_words(fc.w_r2, H2E_W_WORDS_MAX);
+        (Rw % w).to_words(fc.w_r1, H2E_W_WORDS_MAX);
+        fc.n_minv = minv(n.word(0));
+        ((Rn * Rn) % n).to_words(fc.n_r2, 4);
+        (Rn % n).to_words(fc.n_r1, 4);
     }
 };
 
@@ -162,6 +178,13 @@ struct Segment {  // one engine launch
     uint32_t n_params = 0;
     uint32_t params_begin = 0;
     uint64_t cells = 0;  // advice cells written by this launch, per instance (needs emit_shape)
+    uint32_t hint_stride = 0;
+    uint32_t fixups_begin = 0, n_fixups = 0;
+};
+
+struct PreKernel {  // a value-predictor launch that must run before segment `before_segment`
+    H2EPreKernel k;
+    uint32_t before_segment;
 };
 
 struct FixedPatch {  // a fixed cell whose value is an instance input (constants made from inputs)
@@ -190,6 +213,13 @@ struct Recorder {
     std::vector<Segment> segments;
     std::vector<FixedPatch> fixed_patches;
     std::vector<uint32_t> outputs;  // absolute refs of the workload's result cells (program specific)
+    std::vector<uint32_t> fixups;   // per segment: strand-relative base rows of the second invert row (see tape.h)
+    std::vector<PreKernel> pre_kernels;
+    std::vector<uint32_t> pre_args;
+    uint32_t n_hint_slots = 0, n_jac_slots = 0;
+    // hinted-division state: while hint_on, every int_div takes its quotient from slot hint_base + hint_count++
+    bool hint_on = false;
+    uint32_t hint_base = 0, hint_count = 0;
     uint32_t n_input_slots = 0;
     uint64_t seg_cells_start = 0;
     // ---- shape artefacts (Records minus advice values) ----
@@ -260,12 +290,24 @@ struct Recorder {
     void begin_segment() {
         Segment s;
         s.tape_begin = s.tape_end = (uint32_t)tape.size();
+        s.fixups_begin = (uint32_t)fixups.size();
         segments.push_back(s);
         seg_cells_start = n_advice_cells;
     }
     void close_segment() {
         segments.back().tape_end = (uint32_t)tape.size();
         segments.back().cells = n_advice_cells - seg_cells_start;
+        segments.back().n_fixups = (uint32_t)fixups.size() - segments.back().fixups_begin;
+    }
+    // hinted divisions (quotients predicted by the V kernels): slots are consecutive in call order
+    void begin_hints(uint32_t base) {
+        hint_on = true;
+        hint_base = base;
+        hint_count = 0;
+    }
+    uint32_t end_hints() {
+        hint_on = false;
+        return hint_count;
     }
 
     Offset offset() const {
@@ -291,6 +333,7 @@ struct Recorder {
         seg.select0 = (uint32_t)select_offset;
         seg.input_stride = input_stride;
         seg.params_begin = (uint32_t)params.size();
+        seg.fixups_begin = (uint32_t)fixups.size();
         size_t b0 = base_offset, r0 = range_offset, s0 = select_offset;
         seg_cells_start = n_advice_cells;
         in_strand = true;
@@ -302,6 +345,7 @@ struct Recorder {
             strand_off[2] = select_offset = s0 + k * delta.select_offset_diff;
             strand_param_cursor = 0;
             record_tape = (k == 0);
+            hint_count = 0;
             if (k > 0 && !emit_shape && strand_n_params == 0) break;  // nothing left to learn from further strands
             if (k > 0) params.resize(params.size() + strand_n_params, H2E_NO_REF);
             body(k);
@@ -310,6 +354,7 @@ struct Recorder {
                 delta.range_offset_diff = range_offset - r0;
                 delta.select_offset_diff = select_offset - s0;
                 strand_n_params = strand_param_cursor;
+                seg.hint_stride = hint_on ? hint_count : 0;
             } else {
                 Offset d;
                 d.base_offset_diff = base_offset - strand_off[0];
@@ -326,6 +371,7 @@ struct Recorder {
         seg.drange = (uint32_t)delta.range_offset_diff;
         seg.dselect = (uint32_t)delta.select_offset_diff;
         seg.n_params = strand_n_params;
+        seg.n_fixups = (uint32_t)fixups.size() - seg.fixups_begin;
         seg.cells = n_advice_cells - seg_cells_start;
         segments.push_back(seg);
         // apply_offset_diff(delta.scale(n)) (ecc_chip.rs:352)
@@ -837,6 +883,7 @@ struct Recorder {
         size_t r0 = base_line({A(a, id_zero), U(id_zero)}, none(), id_one);
         uint32_t c = mk(0, 1, r0);
         size_t r1 = base_line({A(a, id_zero), U(id_zero)}, A(c, id_one), id_one, 0, 0, id_neg_one);
+        if (record_tape) fixups.push_back((uint32_t)(r1 - (in_strand ? strand_off[0] : 0)));  // b = a^-1 filled by the fix-up kernel
         return mk(0, 4, r1);
     }
     // is_int_zero on a reduced operand (integer_chip.rs:540-578)
@@ -884,6 +931,10 @@ struct Recorder {
             a.times = ar.times;
         }
         H2EOp op = new_op(H2E_OP_DIV_CORE);
+        if (hint_on) {
+            op.flags |= H2E_FLAG_HINTED | (in_strand ? H2E_FLAG_HINT_STRIDED : 0);
+            op.imm = hint_base + hint_count++;
+        }
         put_int(op, 0, b);
         put_int(op, fp.limbs + 1, a);
         push(op);

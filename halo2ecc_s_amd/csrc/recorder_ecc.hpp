@@ -291,6 +291,13 @@ struct NativeScalarEccContext {
     }
     AssignedValue ecc_assign_constant_zero_scalar() { return ctx.assign_constant_u64(0); }
 
+    void push_point_refs(std::vector<uint32_t>& v, const AssignedNonZeroPoint& p) const {
+        for (int j = 0; j < ctx.fp.limbs; j++) v.push_back(p.x.limbs_le[j]);
+        v.push_back(p.x.native);
+        for (int j = 0; j < ctx.fp.limbs; j++) v.push_back(p.y.limbs_le[j]);
+        v.push_back(p.y.native);
+    }
+
     struct MsmInputs {
         uint32_t r1_x, r1_y, r2_x, r2_y;  // blinding points `generator * Scalar::rand()` made explicit (quirk Q1)
     };
@@ -387,7 +394,26 @@ struct NativeScalarEccContext {
         };
         // full groups: strands (the init point alternates r2 / -r2 with the group parity -> a parameter)
         std::vector<AssignedNonZeroPoint> cl0;
+        auto add_candidates_pre = [&](uint32_t n_lanes, uint32_t sz, uint32_t hint_base, uint32_t params_begin, uint32_t n_params) {
+            PreKernel pk;
+            std::memset(&pk, 0, sizeof(pk));
+            pk.k.kind = H2E_PRE_MSM_CANDIDATES;
+            pk.k.n_lanes = n_lanes;
+            pk.k.hint_base = hint_base;
+            pk.k.hints_per_lane = (1u << sz) - 1;
+            pk.k.args_begin = (uint32_t)c.pre_args.size();
+            c.pre_args.push_back(sz);
+            pk.k.n_params = n_params;
+            pk.k.params_begin = params_begin;
+            pk.k.scratch_begin = c.n_jac_slots;
+            c.n_jac_slots += n_lanes << sz;
+            return pk;
+        };
         if (n_full > 0) {
+            uint32_t hbase = c.n_hint_slots;
+            c.n_hint_slots += (uint32_t)n_full * ((1u << group_size) - 1);
+            uint32_t seg_index = (uint32_t)c.segments.size();  // index the fork segment will get
+            c.begin_hints(hbase);
             c.fork((uint32_t)n_full, 0, [&](uint32_t g) {
                 std::vector<AssignedNonZeroPoint> pts;
                 for (size_t j = 0; j < group_size; j++) {
@@ -400,7 +426,13 @@ struct NativeScalarEccContext {
                 build_group(g, pts, cl, init, init, true);
                 if (g == 0) cl0 = cl;
             });
+            c.end_hints();
             Segment seg_groups = c.segments[c.segments.size() - 2];
+            {
+                PreKernel pk = add_candidates_pre((uint32_t)n_full, (uint32_t)group_size, hbase, seg_groups.params_begin, seg_groups.n_params);
+                pk.before_segment = seg_index;
+                c.pre_kernels.push_back(pk);
+            }
             for (size_t g = 0; g < n_full; g++) {
                 const AssignedNonZeroPoint& init_abs = (g % 2 == 0) ? rand_line_point : rand_line_point_neg;
                 write_table_entry(table_aux[g], init_abs);
@@ -415,7 +447,21 @@ struct NativeScalarEccContext {
             std::vector<AssignedNonZeroPoint> pts;
             for (size_t j = g * group_size; j < n; j++) pts.push_back(point_k((uint32_t)j));
             std::vector<AssignedNonZeroPoint> cl;
+            {   // one-lane predictor for the remainder group: its ref table lives in the parameter array
+                uint32_t hbase = c.n_hint_slots;
+                c.n_hint_slots += (1u << pts.size()) - 1;
+                uint32_t pbegin = (uint32_t)c.params.size();
+                std::vector<uint32_t> refs;
+                for (auto& p : pts) push_point_refs(refs, p);
+                push_point_refs(refs, (g % 2 == 0) ? rand_line_point : rand_line_point_neg);
+                c.params.insert(c.params.end(), refs.begin(), refs.end());
+                PreKernel pk = add_candidates_pre(1, (uint32_t)pts.size(), hbase, pbegin, (uint32_t)refs.size());
+                pk.before_segment = (uint32_t)c.segments.size() - 1;  // the current main segment
+                c.pre_kernels.push_back(pk);
+                c.begin_hints(hbase);
+            }
             build_group(g, pts, cl, rand_line_point, rand_line_point_neg, false);
+            c.end_hints();
             for (size_t i = 0; i < cl.size(); i++) write_table_entry(table_aux[g] + (uint32_t)i * NC, cl[i]);
         }
 
@@ -432,6 +478,12 @@ struct NativeScalarEccContext {
 
         // windows (ecc_chip.rs:289-352): predict_ops + clones == strands 0..windows-1
         AssignedNonZeroPoint line_acc0;
+        uint32_t win_hbase = c.n_hint_slots;
+        c.n_hint_slots += (uint32_t)(windows * n_groups);
+        uint32_t win_seg_index = (uint32_t)c.segments.size();
+        uint32_t win_jac = c.n_jac_slots;
+        c.n_jac_slots += (uint32_t)windows;
+        c.begin_hints(win_hbase);
         c.fork((uint32_t)windows, 0, [&](uint32_t wi) {
             AssignedNonZeroPoint acc = rand_acc_point_neg;
             for (size_t group_index = 0; group_index < n_groups; group_index++) {
@@ -444,7 +496,45 @@ struct NativeScalarEccContext {
             }
             if (wi == 0) line_acc0 = acc;
         });
+        c.end_hints();
         Segment seg_windows = c.segments[c.segments.size() - 2];
+        {
+            PreKernel pk;
+            std::memset(&pk, 0, sizeof(pk));
+            pk.k.kind = H2E_PRE_MSM_WINDOWS;
+            pk.k.n_lanes = (uint32_t)windows;
+            pk.k.hint_base = win_hbase;
+            pk.k.hints_per_lane = (uint32_t)n_groups;
+            pk.k.args_begin = (uint32_t)c.pre_args.size();
+            c.pre_args.push_back((uint32_t)n_groups);
+            c.pre_args.push_back((uint32_t)group_size);
+            c.pre_args.push_back(n);
+            push_point_refs(c.pre_args, rand_acc_point_neg);
+            for (size_t g = 0; g < n_groups; g++) c.pre_args.push_back(table_aux[g]);
+            pk.k.n_params = seg_windows.n_params;
+            pk.k.params_begin = seg_windows.params_begin;
+            pk.k.scratch_begin = win_jac;
+            pk.before_segment = win_seg_index;
+            c.pre_kernels.push_back(pk);
+        }
+        {   // tail predictor: runs before the main segment that holds the accumulation loop
+            PreKernel pk;
+            std::memset(&pk, 0, sizeof(pk));
+            pk.k.kind = H2E_PRE_MSM_TAIL;
+            pk.k.n_lanes = 1;
+            pk.k.hint_base = c.n_hint_slots;
+            pk.k.hints_per_lane = (uint32_t)(windows * (2 + (n_groups % 2)));
+            pk.k.args_begin = (uint32_t)c.pre_args.size();
+            c.pre_args.push_back((uint32_t)windows);
+            c.pre_args.push_back((uint32_t)(n_groups % 2));
+            push_point_refs(c.pre_args, rand_acc_point);
+            push_point_refs(c.pre_args, rand_line_point_neg);
+            c.pre_args.push_back(win_jac);
+            pk.before_segment = (uint32_t)c.segments.size() - 1;
+            c.pre_kernels.push_back(pk);
+            c.begin_hints(c.n_hint_slots);
+            c.n_hint_slots += pk.k.hints_per_lane;
+        }
 
         // accumulate windows (ecc_chip.rs:354-362)
         AssignedNonZeroPoint acc = rand_acc_point;
@@ -454,6 +544,7 @@ struct NativeScalarEccContext {
             acc = ecc_add_unsafe(line, acc);
             if (n_groups % 2 == 1) acc = ecc_add_unsafe(acc, rand_line_point_neg);
         }
+        c.end_hints();
         AssignedPoint accp = ecc_non_zero_point_downgrade(acc);
         AssignedPointWithCurvature accc = to_point_with_curvature(accp);
         AssignedPoint carry = ecc_non_zero_point_downgrade(rand_acc_point_neg);

@@ -70,6 +70,8 @@ enum H2EOpcode {
 #define H2E_FLAG_INPUT_STRIDED 1u   // input slot = imm + strand * input_stride
 #define H2E_FLAG_UNSAFE_ADD 2u      // ASSERT_CONST failure reports RETRY_ADD_SAME_OR_NEG
 #define H2E_FLAG_UNSAFE_DBL 4u      // ASSERT_CONST failure reports RETRY_ADD_IDENTITY
+#define H2E_FLAG_HINTED 8u          // DIV_CORE: quotient c = a/b comes from the hint buffer, slot = imm (+ strand*hint_stride)
+#define H2E_FLAG_HINT_STRIDED 16u
 
 #define H2E_OP_MAX_REFS 11
 typedef struct H2EOp {
@@ -104,6 +106,13 @@ typedef struct H2EFieldConsts {
     uint64_t w_native[4];           // w mod n
     uint64_t ceil_limbs[64][H2E_MAX_L][2];  // find_w_modulus_of_ceil_times(t) limbs (range_info.rs:334-359)
     uint64_t ceil_native[64][4];            // their composition mod n
+    // Montgomery constants (R = 2^(64*words)) for the value-predictor kernels and the inverse fix-up
+    uint64_t w_minv;                        // -w^-1 mod 2^64
+    uint64_t w_r2[H2E_W_WORDS_MAX];         // R^2 mod w
+    uint64_t w_r1[H2E_W_WORDS_MAX];         // R mod w
+    uint64_t n_minv;                        // -n^-1 mod 2^64
+    uint64_t n_r2[4];                       // R^2 mod n
+    uint64_t n_r1[4];                       // R mod n
 } H2EFieldConsts;
 
 // One launch: a tape replayed by n_instances * n_strands lanes.
@@ -118,4 +127,23 @@ typedef struct H2ELaunch {
     const uint32_t* params;       // [n_strands][n_params]
     const uint32_t* aux;          // candidate tables etc.
     const uint64_t* const_pool;   // 32-byte (Fr) or w_words*8-byte (W) constants, word indexed
+    uint32_t hint_stride;         // hint slots per strand (for H2E_FLAG_HINT_STRIDED)
+    uint32_t n_fixups;            // is_zero inverse cells per strand filled by the fix-up kernel after this launch
+    const uint32_t* fixups;       // [n_fixups] strand-relative base rows: x = (row, col 0), inverse -> (row, col 1)
 } H2ELaunch;
+
+// ---- value-predictor ("V") kernels for the MSM ---------------------------------------------------
+// They run native Montgomery / Jacobian arithmetic over the same inputs, write numerator/denominator pairs of
+// every lambda = dy/dx the ecc_add_unsafe / ecc_double_unsafe chain will divide (src/circuit/ecc_chip.rs:840-882),
+// and one batch inversion turns them into hints for H2E_OP_DIV_CORE.
+enum H2EPreKind { H2E_PRE_MSM_CANDIDATES = 1, H2E_PRE_MSM_WINDOWS = 2, H2E_PRE_MSM_TAIL = 3 };
+typedef struct H2EPreKernel {
+    uint32_t kind;
+    uint32_t n_lanes;        // lanes per instance (groups / windows / 1)
+    uint32_t hint_base;      // first hint slot written
+    uint32_t hints_per_lane; // consecutive hint slots per lane
+    uint32_t args_begin;     // index into the pre-kernel args array (uint32)
+    uint32_t n_params;       // parameter refs per lane (reuses the X segment's parameter table)
+    uint32_t params_begin;
+    uint32_t scratch_begin;  // per-instance Jacobian scratch: first slot (96-byte slots)
+} H2EPreKernel;
