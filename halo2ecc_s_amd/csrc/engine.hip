@@ -701,8 +701,96 @@ WI_INLINE void op_select_point(const LC& c, const H2EOp& op) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Values-only replay: heavy ops write only the cells later ops can reference (result limbs + native, or the
+// condition cell); every other cell of their rows is produced later by the full expansion, which may then
+// run in any order because its operands are already in place.
 template <class FP>
+WI_INLINE void st_result_int(const LC& c, u32 brow, u32 rrow, const Limb* l, const Fe& native) {
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) stR(c, rrow + 3 * i, 0, fe_of(l[i]));
+    stB(c, brow, 4, native);
+}
+template <class FP>
+WI_INLINE void opv_int_mul(const LC& c, const H2EOp& op) {
+    constexpr int L = FP::L;
+    IntVal<FP> a = ld_int<FP>(c, op.refs), b = ld_int<FP>(c, op.refs + L + 1);
+    Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
+    Wd<FPX<FP>::XW> X = wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW>(A, B));
+    Wd<FPX<FP>::QW> dq;
+    Wd<FP::WW> rem;
+    divrem_w<FP>(c, X, dq, rem);
+    Limb rl[L];
+    split_limbs<FP>(rem, rl);
+    st_result_int<FP>(c, op.base_row, op.range_row, rl, mod_n<FP::WW>(c, rem));
+}
+template <class FP>
+WI_INLINE void opv_reduce(const LC& c, const H2EOp& op) {
+    constexpr int L = FP::L;
+    IntVal<FP> a = ld_int<FP>(c, op.refs);
+    Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l);
+    Wd<FPX<FP>::QW> dq;
+    Wd<FP::WW> rem;
+    divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(A), dq, rem);
+    Limb rl[L];
+    split_limbs<FP>(rem, rl);
+    st_result_int<FP>(c, op.base_row, op.range_row, rl, mod_n<FP::WW>(c, rem));
+}
+template <class FP>
+WI_INLINE void opv_div_core(const LC& c, const H2EOp& op) {
+    constexpr int L = FP::L;
+    IntVal<FP> b = ld_int<FP>(c, op.refs);
+    Wd<FP::WW> cv;
+    if (op.flags & H2E_FLAG_HINTED) {
+        u32 slot = op.imm + ((op.flags & H2E_FLAG_HINT_STRIDED) ? c.strand * c.hint_stride : 0);
+        cv = wd_load<FP::WW>(c.hints + (size_t)slot * H2E_W_WORDS_MAX);
+        bool bz = true;
+#pragma unroll
+        for (int i = 0; i < L; i++) bz = bz && wd_is_zero<2>(b.l[i]);
+        // b is reduced: it is zero mod w iff its limbs are all zero or it equals w
+        Wd<FPX<FP>::AW> B = compose<FP, FPX<FP>::AW>(b.l);
+        if (bz || wd_eq<FPX<FP>::AW>(B, wd_resize<FPX<FP>::AW>(wd_load<FP::WW>(c.fc->w)))) cv = wd_zero<FP::WW>();
+    } else {
+        IntVal<FP> a = ld_int<FP>(c, op.refs + L + 1);
+        Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
+        Wd<FPX<FP>::QW> q0;
+        Wd<FP::WW> a_red, b_red;
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(A), q0, a_red);
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(B), q0, b_red);
+        Wd<FP::WW> binv = wd_inv_mod<FP::WW>(b_red, wd_load<FP::WW>(c.fc->w));
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FP::WW, FP::WW>(a_red, binv)), q0, cv);
+    }
+    Limb cl[L];
+    split_limbs<FP>(cv, cl);
+    st_result_int<FP>(c, op.base_row, op.range_row, cl, mod_n<FP::WW>(c, cv));
+}
+template <class FP>
+WI_INLINE void opv_is_int_zero(const LC& c, const H2EOp& op) {
+    constexpr int L = FP::L;
+    IntVal<FP> a = ld_int<FP>(c, op.refs);
+    bool all_zero = true;
+#pragma unroll
+    for (int i = 0; i < L; i++) all_zero = all_zero && wd_is_zero<2>(a.l[i]);
+    bool is_w = wd_eq<4>(a.native, wd_load<4>(c.fc->w_native));
+#pragma unroll
+    for (int i = 0; i < FP::PW; i++) is_w = is_w && wd_eq<2>(a.l[i], wd_load<2>(c.fc->w_limbs[i]));
+    stB(c, op.base_row + 6 + 4 * FP::PW, 4, fe_u64((all_zero || is_w) ? 1 : 0));
+}
+
+template <class FP, bool VALUES_ONLY>
 WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
+    if (VALUES_ONLY) {
+        switch (op.opcode) {
+            case H2E_OP_INT_MUL: opv_int_mul<FP>(c, op); return;
+            case H2E_OP_REDUCE: opv_reduce<FP>(c, op); return;
+            case H2E_OP_DIV_CORE: opv_div_core<FP>(c, op); return;
+            case H2E_OP_IS_INT_ZERO: opv_is_int_zero<FP>(c, op); return;
+            case H2E_OP_ASSERT_CONST:
+            case H2E_OP_CACHE_INT:
+            case H2E_OP_SUM_LIMBS: return;
+            default: break;  // light ops: the full version is already just their result rows
+        }
+    }
     switch (op.opcode) {
         case H2E_OP_ASSIGN_W: op_assign_w<FP>(c, op); break;
         case H2E_OP_ASSIGN: {
@@ -769,13 +857,21 @@ WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
     }
 }
 
-template <class FP>
+template <class FP, bool VALUES_ONLY>
 __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDesc* inst, u32 n_instances,
                                                    const H2EFieldConsts* fc) {
+    // lanes: [sub-range][instance][strand], each sub-range padded to whole waves so a wave replays one op range
+    u32 per_sub = n_instances * L.n_strands;
+    u32 per_sub_padded = (per_sub + 63) / 64 * 64;
     u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 total = n_instances * L.n_strands;
-    if (gid >= total) return;
-    u32 instance = gid / L.n_strands, strand = gid % L.n_strands;
+    u32 sub = gid / per_sub_padded, idx = gid % per_sub_padded;
+    if (idx >= per_sub) return;
+    u32 instance = idx / L.n_strands, strand = idx % L.n_strands;
+    u32 op_lo = 0, op_hi = L.n_ops;
+    if (!VALUES_ONLY && L.n_sub > 1) {
+        op_lo = L.sub[sub];
+        op_hi = L.sub[sub + 1];
+    }
     InstanceDesc d = inst[instance];
     LC c;
     c.base = d.base;
@@ -794,9 +890,9 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     c.input_stride = L.input_stride;
     c.hints = d.hints;
     c.hint_stride = L.hint_stride;
-    for (u32 i = 0; i < L.n_ops; i++) {
+    for (u32 i = op_lo; i < op_hi; i++) {
         H2EOp op = L.tape[i];
-        exec_op<FP>(c, op);
+        exec_op<FP, VALUES_ONLY>(c, op);
     }
 }
 
@@ -1170,16 +1266,22 @@ __global__ void __launch_bounds__(64) h2e_finalize_hints(u32 hint_base, u32 n_hi
 // host-callable launcher (C linkage, used by the C-ABI layer in h2e_capi.cpp)
 extern "C" int h2e_engine_launch(int field_pair, const H2ELaunch* launch, const void* instances, uint32_t n_instances,
                                  const H2EFieldConsts* fc_dev, hipStream_t stream) {
-    u32 total = n_instances * launch->n_strands;
-    if (total == 0 || launch->n_ops == 0) return 0;
-    dim3 block(64), grid((total + 63) / 64);
+    u32 per_sub = n_instances * launch->n_strands;
+    if (per_sub == 0 || launch->n_ops == 0) return 0;
+    u32 per_sub_padded = (per_sub + 63) / 64 * 64;
+    u32 n_sub = launch->n_sub > 1 ? launch->n_sub : 1;
+    dim3 block(64), grid1(per_sub_padded / 64), grid(per_sub_padded / 64 * n_sub);
     const InstanceDesc* inst = (const InstanceDesc*)instances;
+#define H2E_LAUNCH_FP(FP)                                                                                                 \
+    if (n_sub > 1) hipLaunchKernelGGL((h2e_run_tape<FP, true>), grid1, block, 0, stream, *launch, inst, n_instances, fc_dev); \
+    hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid, block, 0, stream, *launch, inst, n_instances, fc_dev);
     switch (field_pair) {
-        case 0: hipLaunchKernelGGL(h2e_run_tape<FP_BN256_FQ>, grid, block, 0, stream, *launch, inst, n_instances, fc_dev); break;
-        case 1: hipLaunchKernelGGL(h2e_run_tape<FP_BLS_FQ>, grid, block, 0, stream, *launch, inst, n_instances, fc_dev); break;
-        case 2: hipLaunchKernelGGL(h2e_run_tape<FP_BLS_FR>, grid, block, 0, stream, *launch, inst, n_instances, fc_dev); break;
+        case 0: { H2E_LAUNCH_FP(FP_BN256_FQ) } break;
+        case 1: { H2E_LAUNCH_FP(FP_BLS_FQ) } break;
+        case 2: { H2E_LAUNCH_FP(FP_BLS_FR) } break;
         default: return -1;
     }
+#undef H2E_LAUNCH_FP
     if ((int)hipGetLastError() != 0) return (int)hipGetLastError();
     if (launch->n_fixups) {
         u32 chunks = (launch->n_fixups + FIXUP_K - 1) / FIXUP_K;

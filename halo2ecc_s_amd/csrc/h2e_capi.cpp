@@ -60,6 +60,10 @@ struct h2e_program {
     uint32_t* d_params = nullptr;
     uint32_t* d_fixups = nullptr;
     uint32_t* d_pre_args = nullptr;
+    uint32_t* d_subs = nullptr;
+    std::vector<uint32_t> h_subs;          // per segment with cuts: [0, cut_1, ..., n_ops]
+    std::vector<uint32_t> seg_sub_begin;   // per segment: index into h_subs (or ~0u)
+    std::vector<uint32_t> seg_n_sub;
     InstanceDescHost* d_inst = nullptr;
     uint32_t inst_cap = 0;
     std::vector<InstanceDescHost> h_inst;
@@ -72,6 +76,7 @@ struct h2e_program {
             (void)hipFree(d_params);
             (void)hipFree(d_fixups);
             (void)hipFree(d_pre_args);
+            (void)hipFree(d_subs);
             (void)hipFree(d_inst);
         }
     }
@@ -333,6 +338,27 @@ static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
     HIP_TRY(up((void**)&p->d_params, r.params.empty() ? nullptr : r.params.data(), r.params.size() * 4));
     HIP_TRY(up((void**)&p->d_fixups, r.fixups.empty() ? nullptr : r.fixups.data(), r.fixups.size() * 4));
     HIP_TRY(up((void**)&p->d_pre_args, r.pre_args.empty() ? nullptr : r.pre_args.data(), r.pre_args.size() * 4));
+    p->h_subs.clear();
+    p->seg_sub_begin.assign(r.segments.size(), ~0u);
+    p->seg_n_sub.assign(r.segments.size(), 0);
+    for (size_t si = 0; si < r.segments.size(); si++) {
+        const h2e::Segment& sg = r.segments[si];
+        uint32_t n_ops = sg.tape_end - sg.tape_begin;
+        if (sg.n_cuts == 0 || n_ops == 0) continue;
+        p->seg_sub_begin[si] = (uint32_t)p->h_subs.size();
+        p->h_subs.push_back(0);
+        uint32_t n = 0;
+        for (uint32_t k = 0; k < sg.n_cuts; k++) {
+            uint32_t at = r.cuts[sg.cuts_begin + k];
+            if (at > p->h_subs.back() && at < n_ops) {
+                p->h_subs.push_back(at);
+                n++;
+            }
+        }
+        p->h_subs.push_back(n_ops);
+        p->seg_n_sub[si] = n + 1;
+    }
+    HIP_TRY(up((void**)&p->d_subs, p->h_subs.empty() ? nullptr : p->h_subs.data(), p->h_subs.size() * 4));
     p->device = ctx->device;
     return 0;
 }
@@ -418,6 +444,8 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         L.hint_stride = s.hint_stride;
         L.n_fixups = s.n_fixups;
         L.fixups = p->d_fixups + s.fixups_begin;
+        L.n_sub = p->seg_n_sub[si];
+        L.sub = L.n_sub > 1 ? p->d_subs + p->seg_sub_begin[si] : nullptr;
         if (ctx->profiling) {
             while (ctx->ev.size() < 2 * (size_t)(ctx->n_launches + 1)) {
                 hipEvent_t e;

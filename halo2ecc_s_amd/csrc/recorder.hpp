@@ -180,6 +180,7 @@ struct Segment {  // one engine launch
     uint64_t cells = 0;  // advice cells written by this launch, per instance (needs emit_shape)
     uint32_t hint_stride = 0;
     uint32_t fixups_begin = 0, n_fixups = 0;
+    uint32_t cuts_begin = 0, n_cuts = 0;  // op indices (relative to tape_begin) where the expansion may be split
 };
 
 struct PreKernel {  // a value-predictor launch that must run before segment `before_segment`
@@ -214,6 +215,8 @@ struct Recorder {
     std::vector<FixedPatch> fixed_patches;
     std::vector<uint32_t> outputs;  // absolute refs of the workload's result cells (program specific)
     std::vector<uint32_t> fixups;   // per segment: strand-relative base rows of the second invert row (see tape.h)
+    std::vector<uint32_t> cuts;     // per segment: op indices where the full expansion may be split into sub-ranges
+    uint32_t cur_tape_begin = 0;
     std::vector<PreKernel> pre_kernels;
     std::vector<uint32_t> pre_args;
     uint32_t n_hint_slots = 0, n_jac_slots = 0;
@@ -291,6 +294,8 @@ struct Recorder {
         Segment s;
         s.tape_begin = s.tape_end = (uint32_t)tape.size();
         s.fixups_begin = (uint32_t)fixups.size();
+        s.cuts_begin = (uint32_t)cuts.size();
+        cur_tape_begin = s.tape_begin;
         segments.push_back(s);
         seg_cells_start = n_advice_cells;
     }
@@ -298,7 +303,18 @@ struct Recorder {
         segments.back().tape_end = (uint32_t)tape.size();
         segments.back().cells = n_advice_cells - seg_cells_start;
         segments.back().n_fixups = (uint32_t)fixups.size() - segments.back().fixups_begin;
+        segments.back().n_cuts = (uint32_t)cuts.size() - segments.back().cuts_begin;
     }
+    // Mark a point where the full expansion of the current segment may be split (see H2ELaunch.sub).
+    void cut() {
+        if (!record_tape) return;
+        uint32_t at = (uint32_t)tape.size() - cur_tape_begin;
+        if (at == 0) return;
+        if (!cuts.empty() && cuts.size() > segments_cut_floor() && cuts.back() == at) return;
+        cuts.push_back(at);
+    }
+    size_t segments_cut_floor() const { return in_strand ? fork_cuts_begin : segments.back().cuts_begin; }
+    uint32_t fork_cuts_begin = 0;
     // hinted divisions (quotients predicted by the V kernels): slots are consecutive in call order
     void begin_hints(uint32_t base) {
         hint_on = true;
@@ -334,6 +350,8 @@ struct Recorder {
         seg.input_stride = input_stride;
         seg.params_begin = (uint32_t)params.size();
         seg.fixups_begin = (uint32_t)fixups.size();
+        seg.cuts_begin = fork_cuts_begin = (uint32_t)cuts.size();
+        cur_tape_begin = seg.tape_begin;
         size_t b0 = base_offset, r0 = range_offset, s0 = select_offset;
         seg_cells_start = n_advice_cells;
         in_strand = true;
@@ -372,6 +390,7 @@ struct Recorder {
         seg.dselect = (uint32_t)delta.select_offset_diff;
         seg.n_params = strand_n_params;
         seg.n_fixups = (uint32_t)fixups.size() - seg.fixups_begin;
+        seg.n_cuts = (uint32_t)cuts.size() - seg.cuts_begin;
         seg.cells = n_advice_cells - seg_cells_start;
         segments.push_back(seg);
         // apply_offset_diff(delta.scale(n)) (ecc_chip.rs:352)

@@ -390,6 +390,7 @@ struct NativeScalarEccContext {
                 p = ecc_reduce_non_zero(p);
                 assign_cache_point_non_zero(p, group_prefix + group_index, i);
                 cl.push_back(p);
+                ctx.cut();
             }
         };
         // full groups: strands (the init point alternates r2 / -r2 with the group parity -> a parameter)
@@ -493,6 +494,7 @@ struct NativeScalarEccContext {
                     group_bits.push_back(AssignedCondition{c.param(AssignedValue{c.strand_ref(bits0[wi].v.ref, seg_bits, (uint32_t)j)})});
                 AssignedNonZeroPoint ci = pick_and_select(table_aux[group_index], group_bits, group_index + group_prefix);
                 acc = ecc_add_unsafe(ci, acc);
+                c.cut();
             }
             if (wi == 0) line_acc0 = acc;
         });
@@ -540,9 +542,14 @@ struct NativeScalarEccContext {
         AssignedNonZeroPoint acc = rand_acc_point;
         for (size_t wi = 0; wi < windows; wi++) {
             acc = ecc_double_unsafe(acc);
+            c.cut();
             AssignedNonZeroPoint line{c.strand_int(line_acc0.x, seg_windows, (uint32_t)wi), c.strand_int(line_acc0.y, seg_windows, (uint32_t)wi)};
             acc = ecc_add_unsafe(line, acc);
-            if (n_groups % 2 == 1) acc = ecc_add_unsafe(acc, rand_line_point_neg);
+            c.cut();
+            if (n_groups % 2 == 1) {
+                acc = ecc_add_unsafe(acc, rand_line_point_neg);
+                c.cut();
+            }
         }
         c.end_hints();
         AssignedPoint accp = ecc_non_zero_point_downgrade(acc);

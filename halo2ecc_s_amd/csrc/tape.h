@@ -130,6 +130,10 @@ typedef struct H2ELaunch {
     uint32_t hint_stride;         // hint slots per strand (for H2E_FLAG_HINT_STRIDED)
     uint32_t n_fixups;            // is_zero inverse cells per strand filled by the fix-up kernel after this launch
     const uint32_t* fixups;       // [n_fixups] strand-relative base rows: x = (row, col 0), inverse -> (row, col 1)
+    // Sub-ranges: after a values-only replay of the whole tape has put every *result* cell in place, the full
+    // expansion of op ranges [sub[k], sub[k+1]) is independent for different k and runs as separate lanes.
+    uint32_t n_sub;               // 0/1 = the whole tape per lane
+    const uint32_t* sub;          // [n_sub + 1] op indices relative to `tape`
 } H2ELaunch;
 
 // ---- value-predictor ("V") kernels for the MSM ---------------------------------------------------
