@@ -701,96 +701,269 @@ WI_INLINE void op_select_point(const LC& c, const H2EOp& op) {
     }
 }
 
+template <class FP, bool UNUSED>
+WI_INLINE void exec_op(const LC& c, const H2EOp& op);
+
 // ------------------------------------------------------------------------------------------------
-// Values-only replay: heavy ops write only the cells later ops can reference (result limbs + native, or the
-// condition cell); every other cell of their rows is produced later by the full expansion, which may then
-// run in any order because its operands are already in place.
+// Values-only replay: every op writes only the cells later ops can reference (result limbs + native, or a
+// condition / index cell); all other cells of its rows are produced afterwards by the full expansion, which
+// may then run in any order because its operands are already in place.
+//
+// The replay is one dependent chain per lane, so a round trip through HBM for every operand would dominate it.
+// Results therefore also go into an LDS cache: the directory (tags = the cell ref later ops will quote) is
+// wave-uniform because the tape is, the data is per lane ([entry][word][lane], conflict-free).
 template <class FP>
-WI_INLINE void st_result_int(const LC& c, u32 brow, u32 rrow, const Limb* l, const Fe& native) {
-#pragma unroll
-    for (int i = 0; i < FP::L; i++) stR(c, rrow + 3 * i, 0, fe_of(l[i]));
-    stB(c, brow, 4, native);
-}
+struct VCache {
+    static constexpr int R = 12, W = 2 * FP::L + 4, S = 8;
+    u64 data[R][W][64];
+    u64 sdata[S][4][64];
+    u32 tags[R];
+    u32 stags[S];
+    u32 head, shead;
+};
 template <class FP>
-WI_INLINE void opv_int_mul(const LC& c, const H2EOp& op) {
-    constexpr int L = FP::L;
-    IntVal<FP> a = ld_int<FP>(c, op.refs), b = ld_int<FP>(c, op.refs + L + 1);
-    Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
-    Wd<FPX<FP>::XW> X = wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW>(A, B));
-    Wd<FPX<FP>::QW> dq;
-    Wd<FP::WW> rem;
-    divrem_w<FP>(c, X, dq, rem);
-    Limb rl[L];
-    split_limbs<FP>(rem, rl);
-    st_result_int<FP>(c, op.base_row, op.range_row, rl, mod_n<FP::WW>(c, rem));
-}
-template <class FP>
-WI_INLINE void opv_reduce(const LC& c, const H2EOp& op) {
-    constexpr int L = FP::L;
-    IntVal<FP> a = ld_int<FP>(c, op.refs);
-    Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l);
-    Wd<FPX<FP>::QW> dq;
-    Wd<FP::WW> rem;
-    divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(A), dq, rem);
-    Limb rl[L];
-    split_limbs<FP>(rem, rl);
-    st_result_int<FP>(c, op.base_row, op.range_row, rl, mod_n<FP::WW>(c, rem));
-}
-template <class FP>
-WI_INLINE void opv_div_core(const LC& c, const H2EOp& op) {
-    constexpr int L = FP::L;
-    IntVal<FP> b = ld_int<FP>(c, op.refs);
-    Wd<FP::WW> cv;
-    if (op.flags & H2E_FLAG_HINTED) {
-        u32 slot = op.imm + ((op.flags & H2E_FLAG_HINT_STRIDED) ? c.strand * c.hint_stride : 0);
-        cv = wd_load<FP::WW>(c.hints + (size_t)slot * H2E_W_WORDS_MAX);
-        bool bz = true;
-#pragma unroll
-        for (int i = 0; i < L; i++) bz = bz && wd_is_zero<2>(b.l[i]);
-        // b is reduced: it is zero mod w iff its limbs are all zero or it equals w
-        Wd<FPX<FP>::AW> B = compose<FP, FPX<FP>::AW>(b.l);
-        if (bz || wd_eq<FPX<FP>::AW>(B, wd_resize<FPX<FP>::AW>(wd_load<FP::WW>(c.fc->w)))) cv = wd_zero<FP::WW>();
-    } else {
-        IntVal<FP> a = ld_int<FP>(c, op.refs + L + 1);
-        Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
-        Wd<FPX<FP>::QW> q0;
-        Wd<FP::WW> a_red, b_red;
-        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(A), q0, a_red);
-        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(B), q0, b_red);
-        Wd<FP::WW> binv = wd_inv_mod<FP::WW>(b_red, wd_load<FP::WW>(c.fc->w));
-        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FP::WW, FP::WW>(a_red, binv)), q0, cv);
+WI_INLINE void vc_init(VCache<FP>* vc) {
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < VCache<FP>::R; k++) vc->tags[k] = H2E_NO_REF;
+        for (int k = 0; k < VCache<FP>::S; k++) vc->stags[k] = H2E_NO_REF;
+        vc->head = 0;
+        vc->shead = 0;
     }
-    Limb cl[L];
-    split_limbs<FP>(cv, cl);
-    st_result_int<FP>(c, op.base_row, op.range_row, cl, mod_n<FP::WW>(c, cv));
+    __syncthreads();
 }
 template <class FP>
-WI_INLINE void opv_is_int_zero(const LC& c, const H2EOp& op) {
-    constexpr int L = FP::L;
-    IntVal<FP> a = ld_int<FP>(c, op.refs);
-    bool all_zero = true;
+WI_INLINE void vc_put_int(VCache<FP>* vc, u32 tag, const Limb* l, const Fe& native) {
+    u32 k = vc->head;
+    u32 lane = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < L; i++) all_zero = all_zero && wd_is_zero<2>(a.l[i]);
-    bool is_w = wd_eq<4>(a.native, wd_load<4>(c.fc->w_native));
+    for (int i = 0; i < FP::L; i++) {
+        vc->data[k][2 * i][lane] = l[i].v[0];
+        vc->data[k][2 * i + 1][lane] = l[i].v[1];
+    }
 #pragma unroll
-    for (int i = 0; i < FP::PW; i++) is_w = is_w && wd_eq<2>(a.l[i], wd_load<2>(c.fc->w_limbs[i]));
-    stB(c, op.base_row + 6 + 4 * FP::PW, 4, fe_u64((all_zero || is_w) ? 1 : 0));
+    for (int i = 0; i < 4; i++) vc->data[k][2 * FP::L + i][lane] = native.v[i];
+    __syncthreads();  // single-wave workgroup: orders the directory update after every lane's data
+    if (lane == 0) {
+        vc->tags[k] = tag;
+        vc->head = (k + 1) % VCache<FP>::R;
+    }
+    __syncthreads();
+}
+template <class FP>
+WI_INLINE void vc_put_fe(VCache<FP>* vc, u32 tag, const Fe& v) {
+    u32 k = vc->shead;
+    u32 lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; i++) vc->sdata[k][i][lane] = v.v[i];
+    __syncthreads();
+    if (lane == 0) {
+        vc->stags[k] = tag;
+        vc->shead = (k + 1) % VCache<FP>::S;
+    }
+    __syncthreads();
+}
+template <class FP>
+WI_INLINE IntVal<FP> vc_ld_int(VCache<FP>* vc, const LC& c, const u32* refs) {
+    u32 tag = refs[0];
+    int hit = -1;
+    for (int k = 0; k < VCache<FP>::R; k++)
+        if (vc->tags[k] == tag) hit = k;
+    if (hit < 0) return ld_int<FP>(c, refs);
+    IntVal<FP> r;
+    u32 lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) {
+        r.l[i].v[0] = vc->data[hit][2 * i][lane];
+        r.l[i].v[1] = vc->data[hit][2 * i + 1][lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.native.v[i] = vc->data[hit][2 * FP::L + i][lane];
+    return r;
+}
+template <class FP>
+WI_INLINE Fe vc_ld_fe(VCache<FP>* vc, const LC& c, u32 ref) {
+    int hit = -1;
+    for (int k = 0; k < VCache<FP>::S; k++)
+        if (vc->stags[k] == ref) hit = k;
+    if (hit < 0) return ld_fe(c, ref);
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.v[i] = vc->sdata[hit][i][threadIdx.x];
+    return r;
+}
+// result of a "mul-like" op: limbs are range acc cells, native a base cell
+template <class FP>
+WI_INLINE void v_result_mul(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 rel, const Limb* l, const Fe& native) {
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) stR(c, op.range_row + 3 * i, 0, fe_of(l[i]));
+    stB(c, op.base_row, 4, native);
+    vc_put_int<FP>(vc, H2E_MAKE_REF(1, 0, rel, op.range_row), l, native);
+}
+// result of an "add-like" op: limb i in (base_row + i, col 4), native in (base_row + L, col 4)
+template <class FP>
+WI_INLINE void v_result_add(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 rel, const Limb* l, const Fe& native) {
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) stB(c, op.base_row + i, 4, fe_of(l[i]));
+    stB(c, op.base_row + FP::L, 4, native);
+    vc_put_int<FP>(vc, H2E_MAKE_REF(0, 4, rel, op.base_row), l, native);
+}
+template <class FP>
+WI_INLINE void v_result_fe(VCache<FP>* vc, const LC& c, u32 row, int col, u32 rel, const Fe& v) {
+    stB(c, row, col, v);
+    vc_put_fe<FP>(vc, H2E_MAKE_REF(0, col, rel, row), v);
 }
 
-template <class FP, bool VALUES_ONLY>
-WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
-    if (VALUES_ONLY) {
-        switch (op.opcode) {
-            case H2E_OP_INT_MUL: opv_int_mul<FP>(c, op); return;
-            case H2E_OP_REDUCE: opv_reduce<FP>(c, op); return;
-            case H2E_OP_DIV_CORE: opv_div_core<FP>(c, op); return;
-            case H2E_OP_IS_INT_ZERO: opv_is_int_zero<FP>(c, op); return;
-            case H2E_OP_ASSERT_CONST:
-            case H2E_OP_CACHE_INT:
-            case H2E_OP_SUM_LIMBS: return;
-            default: break;  // light ops: the full version is already just their result rows
-        }
+template <class FP>
+WI_INLINE void exec_op_values(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 rel) {
+    constexpr int L = FP::L;
+    switch (op.opcode) {
+        case H2E_OP_INT_MUL: {
+            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs), b = vc_ld_int<FP>(vc, c, op.refs + L + 1);
+            Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
+            Wd<FPX<FP>::QW> dq;
+            Wd<FP::WW> rem;
+            divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW>(A, B)), dq, rem);
+            Limb rl[L];
+            split_limbs<FP>(rem, rl);
+            v_result_mul<FP>(vc, c, op, rel, rl, mod_n<FP::WW>(c, rem));
+        } break;
+        case H2E_OP_REDUCE: {
+            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs);
+            Wd<FPX<FP>::QW> dq;
+            Wd<FP::WW> rem;
+            divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(compose<FP, FPX<FP>::AW>(a.l)), dq, rem);
+            Limb rl[L];
+            split_limbs<FP>(rem, rl);
+            v_result_mul<FP>(vc, c, op, rel, rl, mod_n<FP::WW>(c, rem));
+        } break;
+        case H2E_OP_DIV_CORE: {
+            IntVal<FP> b = vc_ld_int<FP>(vc, c, op.refs);
+            Wd<FP::WW> cv;
+            if (op.flags & H2E_FLAG_HINTED) {
+                u32 slot = op.imm + ((op.flags & H2E_FLAG_HINT_STRIDED) ? c.strand * c.hint_stride : 0);
+                cv = wd_load<FP::WW>(c.hints + (size_t)slot * H2E_W_WORDS_MAX);
+                // b is reduced: zero mod w iff all limbs are zero or it equals w
+                bool bz = true;
+#pragma unroll
+                for (int i = 0; i < L; i++) bz = bz && wd_is_zero<2>(b.l[i]);
+                Wd<FPX<FP>::AW> B = compose<FP, FPX<FP>::AW>(b.l);
+                if (bz || wd_eq<FPX<FP>::AW>(B, wd_resize<FPX<FP>::AW>(wd_load<FP::WW>(c.fc->w)))) cv = wd_zero<FP::WW>();
+            } else {
+                IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs + L + 1);
+                Wd<FPX<FP>::QW> q0;
+                Wd<FP::WW> a_red, b_red;
+                divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(compose<FP, FPX<FP>::AW>(a.l)), q0, a_red);
+                divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(compose<FP, FPX<FP>::AW>(b.l)), q0, b_red);
+                Wd<FP::WW> binv = wd_inv_mod<FP::WW>(b_red, wd_load<FP::WW>(c.fc->w));
+                divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FP::WW, FP::WW>(a_red, binv)), q0, cv);
+            }
+            Limb cl[L];
+            split_limbs<FP>(cv, cl);
+            v_result_mul<FP>(vc, c, op, rel, cl, mod_n<FP::WW>(c, cv));
+        } break;
+        case H2E_OP_IS_INT_ZERO: {
+            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs);
+            bool all_zero = true;
+#pragma unroll
+            for (int i = 0; i < L; i++) all_zero = all_zero && wd_is_zero<2>(a.l[i]);
+            bool is_w = wd_eq<4>(a.native, wd_load<4>(c.fc->w_native));
+#pragma unroll
+            for (int i = 0; i < FP::PW; i++) is_w = is_w && wd_eq<2>(a.l[i], wd_load<2>(c.fc->w_limbs[i]));
+            v_result_fe<FP>(vc, c, op.base_row + 6 + 4 * FP::PW, 4, rel, fe_u64((all_zero || is_w) ? 1 : 0));
+        } break;
+        case H2E_OP_INT_ADD: {
+            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs), b = vc_ld_int<FP>(vc, c, op.refs + L + 1);
+            Limb s[L];
+#pragma unroll
+            for (int i = 0; i < L; i++) s[i] = wd_add<2>(a.l[i], b.l[i]);
+            v_result_add<FP>(vc, c, op, rel, s, addmod_n(c, a.native, b.native));
+        } break;
+        case H2E_OP_INT_SUB: {
+            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs), b = vc_ld_int<FP>(vc, c, op.refs + L + 1);
+            Limb s[L];
+#pragma unroll
+            for (int i = 0; i < L; i++) s[i] = wd_sub<2>(wd_add<2>(a.l[i], wd_load<2>(c.fc->ceil_limbs[op.imm][i])), b.l[i]);
+            v_result_add<FP>(vc, c, op, rel, s, addmod_n(c, submod_n(c, a.native, b.native), wd_load<4>(c.fc->ceil_native[op.imm])));
+        } break;
+        case H2E_OP_INT_NEG: {
+            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs);
+            Limb s[L];
+#pragma unroll
+            for (int i = 0; i < L; i++) s[i] = wd_sub<2>(wd_load<2>(c.fc->ceil_limbs[op.imm][i]), a.l[i]);
+            v_result_add<FP>(vc, c, op, rel, s, submod_n(c, wd_load<4>(c.fc->ceil_native[op.imm]), a.native));
+        } break;
+        case H2E_OP_INT_MUL_SMALL: {
+            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs);
+            Wd<1> k = wd_from_u64<1>(op.imm);
+            Limb s[L];
+#pragma unroll
+            for (int i = 0; i < L; i++) s[i] = wd_resize<2>(wd_mul<2, 1>(a.l[i], k));
+            v_result_add<FP>(vc, c, op, rel, s, mod_n<5>(c, wd_mul<4, 1>(a.native, k)));
+        } break;
+        case H2E_OP_MASK_INT: {
+            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs);
+            Fe coeff = vc_ld_fe<FP>(vc, c, op.refs[L + 1]);
+            bool keep = !wd_is_zero<4>(coeff);
+            Limb s[L];
+#pragma unroll
+            for (int i = 0; i < L; i++) s[i] = keep ? a.l[i] : wd_zero<2>();
+            v_result_add<FP>(vc, c, op, rel, s, keep ? a.native : wd_zero<4>());
+        } break;
+        case H2E_OP_BISEC_INT: {
+            Fe cond = vc_ld_fe<FP>(vc, c, op.refs[0]);
+            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs + 1), b = vc_ld_int<FP>(vc, c, op.refs + L + 2);
+            bool take_a = !wd_is_zero<4>(cond);
+            Limb s[L];
+#pragma unroll
+            for (int i = 0; i < L; i++) s[i] = take_a ? a.l[i] : b.l[i];
+            v_result_add<FP>(vc, c, op, rel, s, take_a ? a.native : b.native);
+        } break;
+        case H2E_OP_NOT: {
+            Fe x = vc_ld_fe<FP>(vc, c, op.refs[0]);
+            v_result_fe<FP>(vc, c, op.base_row, 4, rel, submod_n(c, fe_u64(1), x));
+        } break;
+        case H2E_OP_AND:
+        case H2E_OP_OR:
+        case H2E_OP_XNOR: {
+            Fe a = vc_ld_fe<FP>(vc, c, op.refs[0]), b = vc_ld_fe<FP>(vc, c, op.refs[1]);
+            u64 r = op.opcode == H2E_OP_AND ? (a.v[0] & b.v[0]) : op.opcode == H2E_OP_OR ? (a.v[0] | b.v[0]) : (1 ^ a.v[0] ^ b.v[0]);
+            v_result_fe<FP>(vc, c, op.base_row, 4, rel, fe_u64(r));
+        } break;
+        case H2E_OP_PICK_INDEX: {
+            u32 k = op.imm;
+            u64 idx = 0;
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+                if (i < (int)k) idx |= (ld_fe(c, op.refs[i]).v[0] & 1) << i;
+            v_result_fe<FP>(vc, c, op.base_row + (k < 5 ? 0 : 1), 4, rel, fe_u64(idx));
+        } break;
+        case H2E_OP_SELECT_POINT: {
+            constexpr int NC = 2 * (L + 1);
+            Fe index = vc_ld_fe<FP>(vc, c, op.refs[0]);
+            u32 idx = (u32)(index.v[0] & 0xff);
+            const u32* tab = c.aux + op.imm + idx * NC;
+            Fe v[NC];
+#pragma unroll
+            for (int j = 0; j < NC; j++) v[j] = ld_fe(c, tab[j]);
+#pragma unroll
+            for (int j = 0; j < NC; j++) stS(c, op.select_row + j, 0, v[j]);
+#pragma unroll
+            for (int which = 0; which < 2; which++) {
+                Limb l[L];
+#pragma unroll
+                for (int i = 0; i < L; i++) l[i] = wd_resize<2>(v[which * (L + 1) + i]);
+                vc_put_int<FP>(vc, H2E_MAKE_REF(2, 0, rel, op.select_row + which * (L + 1)), l, v[which * (L + 1) + L]);
+            }
+        } break;
+        case H2E_OP_ASSERT_CONST:
+        case H2E_OP_CACHE_INT:
+        case H2E_OP_SUM_LIMBS: break;
+        default: exec_op<FP, false>(c, op); break;  // inputs / constants / bisec / decompose: their rows are their results
     }
+}
+
+template <class FP, bool UNUSED>
+WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
     switch (op.opcode) {
         case H2E_OP_ASSIGN_W: op_assign_w<FP>(c, op); break;
         case H2E_OP_ASSIGN: {
@@ -857,14 +1030,34 @@ WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
     }
 }
 
+// Tape ops are wave-uniform: fetch them through the scalar cache into SGPRs (one s_load_dwordx16 per op), so
+// the opcode switch is a scalar branch and the refs / rows are scalar operands of the address arithmetic.
+typedef u32 u32x16 __attribute__((ext_vector_type(16)));
+WI_INLINE H2EOp fetch_op(const H2EOp* tape, u32 i) {
+    u64 addr = (u64)(tape + i);
+    u32 lo = __builtin_amdgcn_readfirstlane((u32)addr), hi = __builtin_amdgcn_readfirstlane((u32)(addr >> 32));
+    const u32x16* p = (const u32x16*)(((u64)hi << 32) | lo);
+    u32x16 v;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    H2EOp op;
+    op.opcode = (uint16_t)(v[0] & 0xffffu);
+    op.flags = (uint16_t)(v[0] >> 16);
+    op.imm = v[1];
+    op.base_row = v[2];
+    op.range_row = v[3];
+    op.select_row = v[4];
+#pragma unroll
+    for (int k = 0; k < H2E_OP_MAX_REFS; k++) op.refs[k] = v[5 + k];
+    return op;
+}
+
 template <class FP, bool VALUES_ONLY>
 __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDesc* inst, u32 n_instances,
                                                    const H2EFieldConsts* fc) {
     // lanes: [sub-range][instance][strand], each sub-range padded to whole waves so a wave replays one op range
     u32 per_sub = n_instances * L.n_strands;
-    u32 per_sub_padded = (per_sub + 63) / 64 * 64;
-    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 sub = gid / per_sub_padded, idx = gid % per_sub_padded;
+    u32 blocks_per_sub = (per_sub + 63) / 64;
+    u32 sub = blockIdx.x / blocks_per_sub, idx = (blockIdx.x % blocks_per_sub) * 64 + threadIdx.x;  // sub is wave-uniform
     if (idx >= per_sub) return;
     u32 instance = idx / L.n_strands, strand = idx % L.n_strands;
     u32 op_lo = 0, op_hi = L.n_ops;
@@ -890,9 +1083,18 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     c.input_stride = L.input_stride;
     c.hints = d.hints;
     c.hint_stride = L.hint_stride;
-    for (u32 i = op_lo; i < op_hi; i++) {
-        H2EOp op = L.tape[i];
-        exec_op<FP, VALUES_ONLY>(c, op);
+    if constexpr (VALUES_ONLY) {
+        __shared__ VCache<FP> vcache;
+        vc_init<FP>(&vcache);
+        for (u32 i = op_lo; i < op_hi; i++) {
+            H2EOp op = fetch_op(L.tape, i);
+            exec_op_values<FP>(&vcache, c, op, L.rel_refs);
+        }
+    } else {
+        for (u32 i = op_lo; i < op_hi; i++) {
+            H2EOp op = fetch_op(L.tape, i);
+            exec_op<FP, false>(c, op);
+        }
     }
 }
 

@@ -444,6 +444,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         L.hint_stride = s.hint_stride;
         L.n_fixups = s.n_fixups;
         L.fixups = p->d_fixups + s.fixups_begin;
+        L.rel_refs = s.is_fork ? 1 : 0;
         L.n_sub = p->seg_n_sub[si];
         L.sub = L.n_sub > 1 ? p->d_subs + p->seg_sub_begin[si] : nullptr;
         if (ctx->profiling) {

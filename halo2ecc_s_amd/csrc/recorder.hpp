@@ -181,6 +181,7 @@ struct Segment {  // one engine launch
     uint32_t hint_stride = 0;
     uint32_t fixups_begin = 0, n_fixups = 0;
     uint32_t cuts_begin = 0, n_cuts = 0;  // op indices (relative to tape_begin) where the expansion may be split
+    bool is_fork = false;
 };
 
 struct PreKernel {  // a value-predictor launch that must run before segment `before_segment`
@@ -343,6 +344,7 @@ struct Recorder {
         close_segment();
         Segment seg;
         seg.tape_begin = (uint32_t)tape.size();
+        seg.is_fork = true;
         seg.n_strands = n_strands;
         seg.base0 = (uint32_t)base_offset;
         seg.range0 = (uint32_t)range_offset;

@@ -132,6 +132,7 @@ typedef struct H2ELaunch {
     const uint32_t* fixups;       // [n_fixups] strand-relative base rows: x = (row, col 0), inverse -> (row, col 1)
     // Sub-ranges: after a values-only replay of the whole tape has put every *result* cell in place, the full
     // expansion of op ranges [sub[k], sub[k+1]) is independent for different k and runs as separate lanes.
+    uint32_t rel_refs;            // 1 = cells created by this tape are strand-relative refs (fork segment)
     uint32_t n_sub;               // 0/1 = the whole tape per lane
     const uint32_t* sub;          // [n_sub + 1] op indices relative to `tape`
 } H2ELaunch;
