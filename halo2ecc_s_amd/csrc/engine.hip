@@ -14,12 +14,15 @@
 // field-pair traits (compile-time sizes; values come from H2EFieldConsts)
 struct FP_BN256_FQ {   // bn256 Fq over bn256 Fr
     static constexpr int L = 3, WW = 4, K = 254, CEIL = 254, MC = 3, RC = 1, PW = 1;
+    static constexpr int NSUB = 1;   // a canonical W value is < 2n: "mod n" is one conditional subtraction
 };
 struct FP_BLS_FQ {     // bls12_381 Fq over bn256 Fr
     static constexpr int L = 4, WW = 6, K = 381, CEIL = 381, MC = 5, RC = 2, PW = 2;
+    static constexpr int NSUB = 0;   // needs a real reduction
 };
 struct FP_BLS_FR {     // bls12_381 Fr over bn256 Fr
     static constexpr int L = 3, WW = 4, K = 255, CEIL = 255, MC = 3, RC = 1, PW = 1;
+    static constexpr int NSUB = 2;   // bls12_381 r < 3n
 };
 template <class FP>
 struct FPX {
@@ -106,6 +109,18 @@ WI_INLINE Fe mod_n(const LC& c, const Wd<XW>& x) {
     Fe r;
     wd_barrett_divrem<512, NK, 8, 4, 5>(wd_resize<8>(x), n_of(c), wd_load<5>(c.fc->n_mu), q, r);
     return r;
+}
+// native (value mod n) of a canonical W element
+template <class FP>
+WI_INLINE Fe native_of_w(const LC& c, const Wd<FP::WW>& x) {
+    if constexpr (FP::NSUB > 0) {
+        Fe r = wd_resize<4>(x), n = n_of(c);
+#pragma unroll
+        for (int i = 0; i < FP::NSUB; i++) r = wd_geq<4>(r, n) ? wd_sub<4>(r, n) : r;
+        return r;
+    } else {
+        return mod_n<FP::WW>(c, x);
+    }
 }
 WI_INLINE Fe addmod_n(const LC& c, const Fe& a, const Fe& b) {
     Fe s = wd_add<4>(a, b);  // < 2n < 2^255
@@ -213,6 +228,27 @@ WI_INLINE void divrem_w(const LC& c, const Wd<FPX<FP>::XW>& X, Wd<FPX<FP>::QW>& 
                                                                              wd_load<FPX<FP>::QW>(c.fc->w_mu), q, r);
 }
 
+// floor division of a composed operand A < 2^(CEIL+6) by w: the quotient is < 2^7, so estimate it from the top
+// 64 bits and correct (reduce: integer_chip.rs:296-297; also the canonical representatives in int_div).
+template <class FP>
+WI_INLINE void divrem_small(const LC& c, const Wd<FPX<FP>::AW>& A, u64& q, Wd<FP::WW>& r) {
+    constexpr int AW = FPX<FP>::AW;
+    constexpr int SH = FP::K - 57;                    // keep 57 significant bits of w
+    Wd<AW> w = wd_resize<AW>(wd_load<FP::WW>(c.fc->w));
+    u64 a_top = wd_shr<1, SH>(A).v[0];               // < 2^(CEIL + 6 - K + 57) <= 2^63
+    u64 w_top = wd_shr<1, SH>(w).v[0];               // in [2^56, 2^57)
+    u64 qe = a_top / (w_top + 1);                     // never over-estimates; under-estimates by at most 1
+    Wd<AW> rr = wd_sub<AW>(A, wd_resize<AW>(wd_mul<AW, 1>(w, wd_from_u64<1>(qe))));
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        bool ge = wd_geq<AW>(rr, w);
+        rr = wd_select<AW>(ge, wd_sub<AW>(rr, w), rr);
+        qe += ge ? 1 : 0;
+    }
+    q = qe;
+    r = wd_resize<FP::WW>(rr);
+}
+
 // limb product as a signed 256-bit value
 WI_INLINE Wd<4> lmul(const Limb& a, const Limb& b) { return wd_mul<2, 2>(a, b); }
 
@@ -311,7 +347,7 @@ WI_INLINE void op_assign_w(const LC& c, const H2EOp& op) {
     Wd<FP::WW> x = wd_load<FP::WW>(c.inputs + (size_t)slot * FP::WW);
     Limb l[FP::L];
     split_limbs<FP>(x, l);
-    emit_assigned<FP>(c, op.base_row, op.range_row, l, mod_n<FP::WW>(c, x));
+    emit_assigned<FP>(c, op.base_row, op.range_row, l, native_of_w<FP>(c, x));
 }
 
 template <class FP>
@@ -413,7 +449,7 @@ WI_INLINE void op_int_mul(const LC& c, const H2EOp& op) {
     Limb rl[L], dl[L];
     split_limbs<FP>(rem, rl);
     split_limbs<FP>(dq, dl);
-    Fe rem_native = mod_n<FP::WW>(c, rem), d_native = mod_n<FPX<FP>::QW>(c, dq);
+    Fe rem_native = native_of_w<FP>(c, rem), d_native = mod_n<FPX<FP>::QW>(c, dq);
     u32 rr = op.range_row;
     rr += emit_assigned<FP>(c, op.base_row, rr, rl, rem_native);
     rr += emit_assigned<FP>(c, op.base_row + 1, rr, dl, d_native);
@@ -425,13 +461,12 @@ WI_INLINE void op_reduce(const LC& c, const H2EOp& op) {
     constexpr int L = FP::L;
     IntVal<FP> a = ld_int<FP>(c, op.refs);
     Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l);
-    Wd<FPX<FP>::QW> dq;
     Wd<FP::WW> rem;
-    divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(A), dq, rem);
-    u64 d = dq.v[0];
+    u64 d;
+    divrem_small<FP>(c, A, d, rem);
     Limb rl[L];
     split_limbs<FP>(rem, rl);
-    Fe rem_native = mod_n<FP::WW>(c, rem);
+    Fe rem_native = native_of_w<FP>(c, rem);
     u32 rr = op.range_row, br = op.base_row;
     rr += emit_assigned<FP>(c, br, rr, rl, rem_native);
     emit_common(c, rr, d);
@@ -550,8 +585,9 @@ WI_INLINE void op_div_core(const LC& c, const H2EOp& op) {
     // canonical representatives mod w (bn_to_field::<W>)
     Wd<FPX<FP>::QW> q0;
     Wd<FP::WW> a_red, b_red;
-    divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(A), q0, a_red);
-    divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(B), q0, b_red);
+    u64 qs;
+    divrem_small<FP>(c, A, qs, a_red);
+    divrem_small<FP>(c, B, qs, b_red);
     Wd<FP::WW> cv;
     if (op.flags & H2E_FLAG_HINTED) {
         // c = a * b^-1 mod w was predicted by the V kernels (native Montgomery arithmetic + batch inversion);
@@ -573,7 +609,7 @@ WI_INLINE void op_div_core(const LC& c, const H2EOp& op) {
     Limb cl[L], dl[L];
     split_limbs<FP>(cv, cl);
     split_limbs<FP>(dq, dl);
-    Fe c_native = mod_n<FP::WW>(c, cv), d_native = mod_n<FPX<FP>::QW>(c, dq);
+    Fe c_native = native_of_w<FP>(c, cv), d_native = mod_n<FPX<FP>::QW>(c, dq);
     u32 rr = op.range_row;
     rr += emit_assigned<FP>(c, op.base_row, rr, cl, c_native);
     rr += emit_assigned<FP>(c, op.base_row + 1, rr, dl, d_native);
@@ -825,16 +861,16 @@ WI_INLINE void exec_op_values(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 
             divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW>(A, B)), dq, rem);
             Limb rl[L];
             split_limbs<FP>(rem, rl);
-            v_result_mul<FP>(vc, c, op, rel, rl, mod_n<FP::WW>(c, rem));
+            v_result_mul<FP>(vc, c, op, rel, rl, native_of_w<FP>(c, rem));
         } break;
         case H2E_OP_REDUCE: {
             IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs);
-            Wd<FPX<FP>::QW> dq;
             Wd<FP::WW> rem;
-            divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(compose<FP, FPX<FP>::AW>(a.l)), dq, rem);
+            u64 dsmall;
+            divrem_small<FP>(c, compose<FP, FPX<FP>::AW>(a.l), dsmall, rem);
             Limb rl[L];
             split_limbs<FP>(rem, rl);
-            v_result_mul<FP>(vc, c, op, rel, rl, mod_n<FP::WW>(c, rem));
+            v_result_mul<FP>(vc, c, op, rel, rl, native_of_w<FP>(c, rem));
         } break;
         case H2E_OP_DIV_CORE: {
             IntVal<FP> b = vc_ld_int<FP>(vc, c, op.refs);
@@ -859,7 +895,7 @@ WI_INLINE void exec_op_values(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 
             }
             Limb cl[L];
             split_limbs<FP>(cv, cl);
-            v_result_mul<FP>(vc, c, op, rel, cl, mod_n<FP::WW>(c, cv));
+            v_result_mul<FP>(vc, c, op, rel, cl, native_of_w<FP>(c, cv));
         } break;
         case H2E_OP_IS_INT_ZERO: {
             IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs);
@@ -1084,6 +1120,8 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     c.hints = d.hints;
     c.hint_stride = L.hint_stride;
     if constexpr (VALUES_ONLY) {
+        // the value chain is the critical path and may share its SIMD with expansion waves of an earlier segment
+        __builtin_amdgcn_s_setprio(3);
         __shared__ VCache<FP> vcache;
         vc_init<FP>(&vcache);
         for (u32 i = op_lo; i < op_hi; i++) {
@@ -1106,7 +1144,8 @@ struct Mont {
     u64 minv;
 };
 WI_INLINE void mac64(u64 a, u64 b, u64 c, u64& carry, u64& out) {  // out = low(a*b + c + carry); carry = high
-    u64 lo = a * b, hi = __umul64hi(a, b);
+    u64 lo, hi;
+    mul_wide64(a, b, lo, hi);
     lo += c;
     hi += (lo < c);
     lo += carry;
@@ -1326,6 +1365,7 @@ template <class FP>
 __global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* args, const u32* params_all, const u32* aux,
                                                   const InstanceDesc* inst, u32 n_instances, const H2EFieldConsts* fc) {
     constexpr int L = FP::L, NW = FP::WW, NR = 2 * (L + 1);
+    __builtin_amdgcn_s_setprio(3);  // value chain: critical path (see h2e_run_tape<.., true>)
     u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_instances * K.n_lanes) return;
     u32 instance = gid / K.n_lanes, lane = gid % K.n_lanes;
@@ -1466,17 +1506,18 @@ __global__ void __launch_bounds__(64) h2e_finalize_hints(u32 hint_base, u32 n_hi
 
 // ------------------------------------------------------------------------------------------------
 // host-callable launcher (C linkage, used by the C-ABI layer in h2e_capi.cpp)
-extern "C" int h2e_engine_launch(int field_pair, const H2ELaunch* launch, const void* instances, uint32_t n_instances,
-                                 const H2EFieldConsts* fc_dev, hipStream_t stream) {
+// mode: 1 = values-only replay (whole tape per lane), 2 = full expansion (sub-ranges if any), 4 = inverse fix-up
+extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
+                                 uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream) {
     u32 per_sub = n_instances * launch->n_strands;
     if (per_sub == 0 || launch->n_ops == 0) return 0;
-    u32 per_sub_padded = (per_sub + 63) / 64 * 64;
+    u32 blocks_per_sub = (per_sub + 63) / 64;
     u32 n_sub = launch->n_sub > 1 ? launch->n_sub : 1;
-    dim3 block(64), grid1(per_sub_padded / 64), grid(per_sub_padded / 64 * n_sub);
+    dim3 block(64), grid1(blocks_per_sub), grid(blocks_per_sub * n_sub);
     const InstanceDesc* inst = (const InstanceDesc*)instances;
-#define H2E_LAUNCH_FP(FP)                                                                                                 \
-    if (n_sub > 1) hipLaunchKernelGGL((h2e_run_tape<FP, true>), grid1, block, 0, stream, *launch, inst, n_instances, fc_dev); \
-    hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid, block, 0, stream, *launch, inst, n_instances, fc_dev);
+#define H2E_LAUNCH_FP(FP)                                                                                                     \
+    if (mode & 1) hipLaunchKernelGGL((h2e_run_tape<FP, true>), grid1, block, 0, stream, *launch, inst, n_instances, fc_dev); \
+    if (mode & 2) hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid, block, 0, stream, *launch, inst, n_instances, fc_dev);
     switch (field_pair) {
         case 0: { H2E_LAUNCH_FP(FP_BN256_FQ) } break;
         case 1: { H2E_LAUNCH_FP(FP_BLS_FQ) } break;
@@ -1485,7 +1526,7 @@ extern "C" int h2e_engine_launch(int field_pair, const H2ELaunch* launch, const 
     }
 #undef H2E_LAUNCH_FP
     if ((int)hipGetLastError() != 0) return (int)hipGetLastError();
-    if (launch->n_fixups) {
+    if ((mode & 4) && launch->n_fixups) {
         u32 chunks = (launch->n_fixups + FIXUP_K - 1) / FIXUP_K;
         u32 lanes = n_instances * launch->n_strands * chunks;
         hipLaunchKernelGGL(h2e_fixup_inverses, dim3((lanes + 63) / 64), dim3(64), 0, stream, *launch, inst, n_instances, fc_dev);

@@ -7,8 +7,8 @@
 #include "../../include/h2e.h"
 #include "recorder_pairing.hpp"
 
-extern "C" int h2e_engine_launch(int field_pair, const H2ELaunch* launch, const void* instances, uint32_t n_instances,
-                                 const H2EFieldConsts* fc_dev, hipStream_t stream);
+extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
+                                 uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream);
 extern "C" int h2e_engine_predict(int field_pair, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,
                                   const uint32_t* aux_dev, const void* instances, uint32_t n_instances,
                                   const H2EFieldConsts* fc_dev, hipStream_t stream);
@@ -116,13 +116,17 @@ struct h2e_ctx {
     // engine workspace (grow-only): quotient hints, numerator/denominator pairs, Jacobian scratch
     uint64_t *ws_hints = nullptr, *ws_nd = nullptr, *ws_jac = nullptr;
     size_t ws_hints_words = 0, ws_nd_words = 0, ws_jac_words = 0;
-    std::vector<hipEvent_t> ev;
+    std::vector<hipEvent_t> ev;       // profiling: 4 per launched segment (value-chain begin/end, expansion begin/end)
+    std::vector<hipEvent_t> sync_ev;  // cross-stream dependencies
+    hipStream_t expand_stream = nullptr;
     uint32_t n_launches = 0;
     ~h2e_ctx() {
         for (auto& kv : cache) delete kv.second;
         for (int i = 0; i < 3; i++)
             if (d_fc[i]) (void)hipFree(d_fc[i]);
         for (auto e : ev) (void)hipEventDestroy(e);
+        for (auto e : sync_ev) (void)hipEventDestroy(e);
+        if (expand_stream) (void)hipStreamDestroy(expand_stream);
         (void)hipFree(ws_hints);
         (void)hipFree(ws_nd);
         (void)hipFree(ws_jac);
@@ -416,14 +420,63 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
     }
     HIP_TRY(hipMemcpyAsync(p->d_inst, p->h_inst.data(), (size_t)n_instances * sizeof(InstanceDescHost),
                            hipMemcpyHostToDevice, stream));
+    // Two streams.  The *value chain* (predictor kernels + values-only replay, or the plain tape for segments
+    // without cuts) runs on the caller's stream: it is what later segments depend on.  The full expansion of a
+    // cut segment only needs the value chain up to that segment, so it runs on a second stream and overlaps the
+    // value chain of the following segments (e.g. the MSM windows' expansion hides the serial tail's replay).
+    if (!ctx->expand_stream) {
+        // Keep a few CUs out of the expansion stream's mask so the (latency-bound, few-wave) value chain on the
+        // caller's stream always finds an idle CU instead of queueing behind millions of expansion lanes.
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+        int cus = prop.multiProcessorCount;
+        const char* env = getenv("H2E_RESERVED_CUS");
+        int reserved = env ? atoi(env) : 16;
+        std::vector<uint32_t> mask((cus + 31) / 32, 0);
+        for (int i = 0; i < cus; i++) {
+            // CU ids are dealt round-robin over the 8 XCDs; reserve the last `reserved` ids (2 per XCD for 16)
+            if (i < cus - reserved) mask[i / 32] |= 1u << (i % 32);
+        }
+        hipError_t me = reserved > 0 ? hipExtStreamCreateWithCUMask(&ctx->expand_stream, (uint32_t)mask.size(), mask.data())
+                                     : hipErrorNotSupported;
+        if (me != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipStreamCreateWithFlags(&ctx->expand_stream, hipStreamNonBlocking));
+        }
+    }
+    hipStream_t sa = stream, sb = ctx->expand_stream;
+    size_t n_sync = 0;
+    auto sync_event = [&]() -> hipEvent_t {
+        if (n_sync == ctx->sync_ev.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            ctx->sync_ev.push_back(e);
+        }
+        return ctx->sync_ev[n_sync++];
+    };
+    auto prof_event = [&](uint32_t k) -> hipEvent_t {
+        while (ctx->ev.size() <= k) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            ctx->ev.push_back(e);
+        }
+        return ctx->ev[k];
+    };
+    {   // the expansion stream starts after everything already queued on the caller's stream
+        hipEvent_t e = sync_event();
+        HIP_TRY(hipEventRecord(e, sa));
+        HIP_TRY(hipStreamWaitEvent(sb, e, 0));
+    }
     ctx->n_launches = 0;
     for (size_t si = 0; si < r.segments.size(); si++) {
         const h2e::Segment& s = r.segments[si];
         if (s.tape_end <= s.tape_begin) continue;
+        uint32_t li = ctx->n_launches;
+        if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 0), sa));
         for (auto& pk : r.pre_kernels) {
             if (pk.before_segment != si) continue;
             int prc = h2e_engine_predict(fp, &pk.k, p->d_pre_args, p->d_params, p->d_aux, p->d_inst, n_instances,
-                                         ctx->d_fc[fp], stream);
+                                         ctx->d_fc[fp], sa);
             if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
         }
         H2ELaunch L;
@@ -447,18 +500,31 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         L.rel_refs = s.is_fork ? 1 : 0;
         L.n_sub = p->seg_n_sub[si];
         L.sub = L.n_sub > 1 ? p->d_subs + p->seg_sub_begin[si] : nullptr;
-        if (ctx->profiling) {
-            while (ctx->ev.size() < 2 * (size_t)(ctx->n_launches + 1)) {
-                hipEvent_t e;
-                HIP_TRY(hipEventCreate(&e));
-                ctx->ev.push_back(e);
-            }
-            HIP_TRY(hipEventRecord(ctx->ev[2 * ctx->n_launches], stream));
+        int lrc;
+        if (L.n_sub > 1) {
+            lrc = h2e_engine_launch(fp, 1, &L, p->d_inst, n_instances, ctx->d_fc[fp], sa);
+            if (lrc != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)lrc));
+            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
+            hipEvent_t e = sync_event();
+            HIP_TRY(hipEventRecord(e, sa));
+            HIP_TRY(hipStreamWaitEvent(sb, e, 0));
+            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sb));
+            lrc = h2e_engine_launch(fp, 2 | 4, &L, p->d_inst, n_instances, ctx->d_fc[fp], sb);
+            if (lrc != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)lrc));
+            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sb));
+        } else {
+            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
+            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sa));
+            lrc = h2e_engine_launch(fp, 2 | 4, &L, p->d_inst, n_instances, ctx->d_fc[fp], sa);
+            if (lrc != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)lrc));
+            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sa));
         }
-        int lrc = h2e_engine_launch(fp, &L, p->d_inst, n_instances, ctx->d_fc[fp], stream);
-        if (lrc != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)lrc));
-        if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[2 * ctx->n_launches + 1], stream));
         ctx->n_launches++;
+    }
+    {   // join: the caller's stream completes when the expansion stream does
+        hipEvent_t e = sync_event();
+        HIP_TRY(hipEventRecord(e, sb));
+        HIP_TRY(hipStreamWaitEvent(sa, e, 0));
     }
     return 0;
 }
@@ -499,11 +565,14 @@ int h2e_set_profiling(h2e_ctx* ctx, int enable) {
 int h2e_last_run_launch_ms(h2e_ctx* ctx, float* ms, uint32_t cap) {
     if (!ctx) return fail(H2E_ERR_INVALID, "null ctx");
     if (!ctx->profiling) return 0;
-    for (uint32_t i = 0; i < ctx->n_launches && i < cap; i++) {
-        float t = 0;
-        hipError_t e = hipEventElapsedTime(&t, ctx->ev[2 * i], ctx->ev[2 * i + 1]);
+    // two numbers per launched segment: value chain (predictors + values-only replay), expansion (+ fix-up)
+    for (uint32_t i = 0; i < ctx->n_launches && 2 * i + 1 < cap; i++) {
+        float t0 = 0, t1 = 0;
+        hipError_t e = hipEventElapsedTime(&t0, ctx->ev[4 * i], ctx->ev[4 * i + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t1, ctx->ev[4 * i + 2], ctx->ev[4 * i + 3]);
         if (e != hipSuccess) return fail(H2E_ERR_HIP, hipGetErrorString(e));
-        ms[i] = t;
+        ms[2 * i] = t0;
+        ms[2 * i + 1] = t1;
     }
     return (int)ctx->n_launches;
 }

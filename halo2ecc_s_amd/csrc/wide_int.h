@@ -15,6 +15,21 @@ struct Wd {
     u64 v[N];
 };
 
+// 64 x 64 -> 128 from four 32 x 32 -> 64 products (each one v_mad_u64_u32 / v_mul_{lo,hi}_u32 pair); the
+// compiler's own lowering of `a * b` next to `__umul64hi(a, b)` repeats the partial products.
+WI_INLINE void mul_wide64(u64 a, u64 b, u64& lo, u64& hi) {
+#ifdef H2E_COMPILER_MUL64
+    lo = a * b;
+    hi = __umul64hi(a, b);
+    return;
+#endif
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p00 = (u64)a0 * b0, p01 = (u64)a0 * b1, p10 = (u64)a1 * b0, p11 = (u64)a1 * b1;
+    u64 mid = (p00 >> 32) + (u32)p01 + (u32)p10;
+    lo = (p00 & 0xffffffffull) | (mid << 32);
+    hi = p11 + (p01 >> 32) + (p10 >> 32) + (mid >> 32);
+}
+
 template <int N>
 WI_INLINE Wd<N> wd_zero() {
     Wd<N> r;
@@ -133,8 +148,8 @@ WI_INLINE Wd<NA + NB> wd_mul(const Wd<NA>& a, const Wd<NB>& b) {
         u64 carry = 0;
 #pragma unroll
         for (int j = 0; j < NB; j++) {
-            u64 lo = a.v[i] * b.v[j];
-            u64 hi = __umul64hi(a.v[i], b.v[j]);
+            u64 lo, hi;
+            mul_wide64(a.v[i], b.v[j], lo, hi);
             u64 s = r.v[i + j] + lo;
             hi += (s < lo);
             u64 s2 = s + carry;
@@ -156,8 +171,13 @@ WI_INLINE Wd<NR> wd_mul_lo(const Wd<NA>& a, const Wd<NB>& b) {
 #pragma unroll
         for (int j = 0; j < NB; j++) {
             if (i + j < NR) {
-                u64 lo = a.v[i] * b.v[j];
-                u64 hi = (i + j + 1 < NR) ? __umul64hi(a.v[i], b.v[j]) : 0;
+                u64 lo, hi;
+                if (i + j + 1 < NR) {
+                    mul_wide64(a.v[i], b.v[j], lo, hi);
+                } else {
+                    lo = a.v[i] * b.v[j];
+                    hi = 0;
+                }
                 u64 s = r.v[i + j] + lo;
                 hi += (s < lo);
                 u64 s2 = s + carry;

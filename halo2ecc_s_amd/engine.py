@@ -27,7 +27,8 @@ class H2EError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libh2e.so")
+    # H2E_LIB: another build of the same sources (A/B timing experiments only)
+    return os.environ.get("H2E_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libh2e.so")
 
 
 class _Shape(C.Structure):
@@ -226,12 +227,13 @@ class Engine:
     def set_profiling(self, on):
         _check(lib().h2e_set_profiling(self._h, int(on)))
 
-    def last_run_launch_ms(self, cap=64):
+    def last_run_launch_ms(self, cap=128):
+        """per launched segment: (value-chain ms, expansion ms), from HIP events on the launching streams"""
         buf = (C.c_float * cap)()
         n = lib().h2e_last_run_launch_ms(self._h, buf, cap)
         if n < 0:
             _check(n)
-        return [buf[i] for i in range(min(n, cap))]
+        return [(buf[2 * i], buf[2 * i + 1]) for i in range(min(n, cap // 2))]
 
     def close(self):
         if self._h:

@@ -129,8 +129,9 @@ int h2e_pairing_check_bn256(h2e_ctx* ctx, uint32_t n_instances, const void* d_in
 int h2e_pairing_check_bls12_381(h2e_ctx* ctx, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
                                 void* d_select, void* d_status, void* stream);
 
-/* Timing hook used by bench.py: HIP events recorded by the engine around each launch of the last
- * h2e_run on `stream`; returns the number of launches and fills ms[i] (call after synchronising). */
+/* Timing hook used by bench.py: HIP events recorded by the engine on the stream each kernel group is launched
+ * on.  Returns the number of launched segments and fills two numbers per segment: ms[2i] = value chain
+ * (predictor kernels + values-only replay), ms[2i+1] = full expansion + inverse fix-up (call after synchronising). */
 int h2e_last_run_launch_ms(h2e_ctx* ctx, float* ms, uint32_t cap);
 int h2e_set_profiling(h2e_ctx* ctx, int enable);
 
