@@ -778,12 +778,14 @@ WI_INLINE void vc_put_int(VCache<FP>* vc, u32 tag, const Limb* l, const Fe& nati
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) vc->data[k][2 * FP::L + i][lane] = native.v[i];
-    __syncthreads();  // single-wave workgroup: orders the directory update after every lane's data
+    // one wave per workgroup: LDS operations of a wave complete in order, so no barrier is needed (and
+    // __syncthreads() would also wait for every outstanding global store); just keep the compiler from reordering
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) {
         vc->tags[k] = tag;
         vc->head = (k + 1) % VCache<FP>::R;
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 template <class FP>
 WI_INLINE void vc_put_fe(VCache<FP>* vc, u32 tag, const Fe& v) {
@@ -791,12 +793,12 @@ WI_INLINE void vc_put_fe(VCache<FP>* vc, u32 tag, const Fe& v) {
     u32 lane = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; i++) vc->sdata[k][i][lane] = v.v[i];
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) {
         vc->stags[k] = tag;
         vc->shead = (k + 1) % VCache<FP>::S;
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 template <class FP>
 WI_INLINE IntVal<FP> vc_ld_int(VCache<FP>* vc, const LC& c, const u32* refs) {
@@ -804,7 +806,12 @@ WI_INLINE IntVal<FP> vc_ld_int(VCache<FP>* vc, const LC& c, const u32* refs) {
     int hit = -1;
     for (int k = 0; k < VCache<FP>::R; k++)
         if (vc->tags[k] == tag) hit = k;
-    if (hit < 0) return ld_int<FP>(c, refs);
+    if (hit < 0) {
+        // first use of a value produced outside this replay (e.g. -r2, a window's sum): keep it for re-use
+        IntVal<FP> g = ld_int<FP>(c, refs);
+        if (H2E_REF_REGION(tag) != H2E_REGION_PARAM) vc_put_int<FP>(vc, tag, g.l, g.native);
+        return g;
+    }
     IntVal<FP> r;
     u32 lane = threadIdx.x;
 #pragma unroll
@@ -1155,31 +1162,41 @@ WI_INLINE void mac64(u64 a, u64 b, u64 c, u64& carry, u64& out) {  // out = low(
 }
 template <int N>
 WI_INLINE Wd<N> mont_mul(const Mont<N>& M, const Wd<N>& a, const Wd<N>& b) {
-    u64 t[N + 2];
+    // CIOS over 32-bit limbs: every inner step is one v_mad_u64_u32 plus a carry add
+    constexpr int L32 = 2 * N;
+    u32 t[L32 + 2];
 #pragma unroll
-    for (int i = 0; i < N + 2; i++) t[i] = 0;
+    for (int i = 0; i < L32 + 2; i++) t[i] = 0;
+    u32 minv = (u32)M.minv;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
+    for (int i = 0; i < L32; i++) {
+        u32 bi = limb32<N>(b, i);
         u64 c = 0;
 #pragma unroll
-        for (int j = 0; j < N; j++) mac64(a.v[j], b.v[i], t[j], c, t[j]);
-        u64 s = t[N] + c;
-        t[N + 1] = (s < c);
-        t[N] = s;
-        u64 m = t[0] * M.minv, dummy;
-        c = 0;
-        mac64(m, M.p.v[0], t[0], c, dummy);
+        for (int j = 0; j < L32; j++) {
+            u64 s = (u64)limb32<N>(a, j) * bi + t[j] + c;
+            t[j] = (u32)s;
+            c = s >> 32;
+        }
+        u64 s = (u64)t[L32] + c;
+        t[L32] = (u32)s;
+        t[L32 + 1] = (u32)(s >> 32);
+        u32 m = t[0] * minv;
+        c = ((u64)m * limb32<N>(M.p, 0) + t[0]) >> 32;
 #pragma unroll
-        for (int j = 1; j < N; j++) mac64(m, M.p.v[j], t[j], c, t[j - 1]);
-        s = t[N] + c;
-        u64 c2 = (s < c);
-        t[N - 1] = s;
-        t[N] = t[N + 1] + c2;
+        for (int j = 1; j < L32; j++) {
+            u64 s2 = (u64)m * limb32<N>(M.p, j) + t[j] + c;
+            t[j - 1] = (u32)s2;
+            c = s2 >> 32;
+        }
+        s = (u64)t[L32] + c;
+        t[L32 - 1] = (u32)s;
+        t[L32] = t[L32 + 1] + (u32)(s >> 32);
     }
     Wd<N> r;
 #pragma unroll
-    for (int i = 0; i < N; i++) r.v[i] = t[i];
-    bool ge = t[N] != 0 || wd_geq<N>(r, M.p);
+    for (int i = 0; i < N; i++) r.v[i] = (u64)t[2 * i] | ((u64)t[2 * i + 1] << 32);
+    bool ge = t[L32] != 0 || wd_geq<N>(r, M.p);
     return ge ? wd_sub<N>(r, M.p) : r;
 }
 template <int N>

@@ -139,55 +139,61 @@ template <int N>
 WI_INLINE bool wd_is_neg(const Wd<N>& a) {  // two's complement sign
     return (a.v[N - 1] >> 63) != 0;
 }
-// full product
+// 32-bit limb view of a word array
+template <int N>
+WI_INLINE u32 limb32(const Wd<N>& a, int k) {
+    return (k & 1) ? (u32)(a.v[k >> 1] >> 32) : (u32)a.v[k >> 1];
+}
+// full product: schoolbook over 32-bit limbs; every step `(u64)a*b + acc` is one v_mad_u64_u32
 template <int NA, int NB>
 WI_INLINE Wd<NA + NB> wd_mul(const Wd<NA>& a, const Wd<NB>& b) {
-    Wd<NA + NB> r = wd_zero<NA + NB>();
+    constexpr int LA = 2 * NA, LB = 2 * NB;
+    u32 t[LA + LB];
 #pragma unroll
-    for (int i = 0; i < NA; i++) {
-        u64 carry = 0;
+    for (int i = 0; i < LA + LB; i++) t[i] = 0;
 #pragma unroll
-        for (int j = 0; j < NB; j++) {
-            u64 lo, hi;
-            mul_wide64(a.v[i], b.v[j], lo, hi);
-            u64 s = r.v[i + j] + lo;
-            hi += (s < lo);
-            u64 s2 = s + carry;
-            hi += (s2 < s);
-            r.v[i + j] = s2;
-            carry = hi;
+    for (int i = 0; i < LA; i++) {
+        u32 ai = limb32<NA>(a, i);
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < LB; j++) {
+            u64 s = (u64)ai * limb32<NB>(b, j) + t[i + j] + c;
+            t[i + j] = (u32)s;
+            c = s >> 32;
         }
-        r.v[i + NB] = carry;
+        t[i + LB] = (u32)c;
     }
+    Wd<NA + NB> r;
+#pragma unroll
+    for (int i = 0; i < NA + NB; i++) r.v[i] = (u64)t[2 * i] | ((u64)t[2 * i + 1] << 32);
     return r;
 }
 // low NR words of the product
 template <int NR, int NA, int NB>
 WI_INLINE Wd<NR> wd_mul_lo(const Wd<NA>& a, const Wd<NB>& b) {
-    Wd<NR> r = wd_zero<NR>();
+    constexpr int LA = 2 * NA, LB = 2 * NB, LR = 2 * NR;
+    u32 t[LR];
 #pragma unroll
-    for (int i = 0; i < NA; i++) {
-        u64 carry = 0;
+    for (int i = 0; i < LR; i++) t[i] = 0;
 #pragma unroll
-        for (int j = 0; j < NB; j++) {
-            if (i + j < NR) {
-                u64 lo, hi;
-                if (i + j + 1 < NR) {
-                    mul_wide64(a.v[i], b.v[j], lo, hi);
-                } else {
-                    lo = a.v[i] * b.v[j];
-                    hi = 0;
+    for (int i = 0; i < LA; i++) {
+        if (i < LR) {
+            u32 ai = limb32<NA>(a, i);
+            u64 c = 0;
+#pragma unroll
+            for (int j = 0; j < LB; j++) {
+                if (i + j < LR) {
+                    u64 s = (u64)ai * limb32<NB>(b, j) + t[i + j] + c;
+                    t[i + j] = (u32)s;
+                    c = s >> 32;
                 }
-                u64 s = r.v[i + j] + lo;
-                hi += (s < lo);
-                u64 s2 = s + carry;
-                hi += (s2 < s);
-                r.v[i + j] = s2;
-                carry = hi;
             }
+            if (i + LB < LR) t[i + LB] = (u32)c;
         }
-        if (i + NB < NR) r.v[i + NB] = carry;
     }
+    Wd<NR> r;
+#pragma unroll
+    for (int i = 0; i < NR; i++) r.v[i] = (u64)t[2 * i] | ((u64)t[2 * i + 1] << 32);
     return r;
 }
 // (a >> SH) truncated / zero-extended to M words; SH compile-time
