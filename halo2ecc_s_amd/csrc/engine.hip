@@ -61,6 +61,8 @@ struct LC {  // lane context
     u32 strand, input_stride;
     const u64* hints;
     u32 hint_stride;
+    struct Stage* st;   // LDS row staging (see rowB)
+    bool active;        // false for the padding lanes of the last wave: compute, but store nothing
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -136,6 +138,87 @@ WI_INLINE Fe fe_of_signed(const LC& c, const Wd<4>& x) { return wd_is_neg<4>(x) 
 WI_INLINE Fe inv_n(const LC& c, const Fe& a) { return wd_inv_mod<4>(a, n_of(c)); }
 
 // ------------------------------------------------------------------------------------------------
+// Row emission.  A lane owns whole rows (every row is written by exactly one op), and different lanes of a wave
+// write rows that are far apart, so storing cell by cell makes every 16-byte store its own L1->L2 request
+// (measured: TCP stalled ~100 % of the expansion kernel, 4.05 G write requests for 65 GB).  Instead each lane
+// drops its row into LDS and the wave flushes the 64 rows together: consecutive lanes store consecutive 16-byte
+// pieces of the same row, so one request carries a 64-byte run.  `mask` = assigned columns.  Whole rows are
+// stored (unassigned cells as zero, which is what they hold anyway): rows with holes made ~half of the HBM write
+// requests 32-byte partial lines, and the same kernel ran 25 % faster writing 40 % more bytes without them.
+struct Stage {  // one buffer, used for one row kind at a time (12 KB per wave keeps 13 waves per CU resident)
+    union {
+        u64 b[64][22];  // base row: 5 cells x 32 B, lane stride 176 B (conflict-free for 128-bit LDS access)
+        u64 r[64][14];  // range row: 3 cells, lane stride 112 B
+        u64 s[64][10];  // select row: 2 cells, lane stride 80 B
+    };
+    u64* ptr[64];
+};
+WI_INLINE void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+WI_INLINE void stage_cell(u64* dst, const Fe& v) {
+    ulonglong2* q = (ulonglong2*)dst;
+    q[0] = make_ulonglong2(v.v[0], v.v[1]);
+    q[1] = make_ulonglong2(v.v[2], v.v[3]);
+}
+template <int CELLS, int STRIDE64>
+WI_INLINE void flush_rows(u64 (*buf)[STRIDE64], u64** ptrs, u32 mask) {
+    constexpr int PIECES = CELLS * 2;  // 16-byte pieces per row
+    u32 lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < PIECES; i++) {
+        u32 chunk = i * 64 + lane;
+        u32 r = chunk / PIECES, piece = chunk - r * PIECES;
+        u64* p = ptrs[r];
+        if (p != nullptr && ((mask >> (piece >> 1)) & 1)) {
+            ulonglong2 v = *(const ulonglong2*)&buf[r][piece * 2];
+            *(ulonglong2*)(p + piece * 2) = v;
+        }
+    }
+}
+WI_INLINE void rowB(const LC& c, u32 row, u32 mask, const Fe& v0, const Fe& v1, const Fe& v2, const Fe& v3, const Fe& v4) {
+    Stage* st = c.st;
+    u32 lane = threadIdx.x;
+    mask = 0x1f;  // always store the whole row (see "pieces of unassigned cells" above)
+    if (mask & 1) stage_cell(&st->b[lane][0], v0);
+    if (mask & 2) stage_cell(&st->b[lane][4], v1);
+    if (mask & 4) stage_cell(&st->b[lane][8], v2);
+    if (mask & 8) stage_cell(&st->b[lane][12], v3);
+    if (mask & 16) stage_cell(&st->b[lane][16], v4);
+    st->ptr[lane] = c.active ? c.base + (size_t)(row + c.ob) * 20 : nullptr;
+    lds_fence();
+    flush_rows<5, 22>(st->b, st->ptr, mask);
+    lds_fence();
+}
+WI_INLINE void rowR(const LC& c, u32 row, u32 mask, const Fe& acc, const Fe& tagged, const Fe& common) {
+    Stage* st = c.st;
+    u32 lane = threadIdx.x;
+    mask = 7;
+    if (mask & 1) stage_cell(&st->r[lane][0], acc);
+    if (mask & 2) stage_cell(&st->r[lane][4], tagged);
+    if (mask & 4) stage_cell(&st->r[lane][8], common);
+    st->ptr[lane] = c.active ? c.range + (size_t)(row + c.orr) * 12 : nullptr;
+    lds_fence();
+    flush_rows<3, 14>(st->r, st->ptr, mask);
+    lds_fence();
+}
+WI_INLINE void rowS(const LC& c, u32 row, u32 mask, const Fe& value, const Fe& selector) {
+    Stage* st = c.st;
+    u32 lane = threadIdx.x;
+    mask = 3;
+    if (mask & 1) stage_cell(&st->s[lane][0], value);
+    if (mask & 2) stage_cell(&st->s[lane][4], selector);
+    st->ptr[lane] = c.active ? c.select + (size_t)(row + c.os) * 8 : nullptr;
+    lds_fence();
+    flush_rows<2, 10>(st->s, st->ptr, mask);
+    lds_fence();
+}
+static __device__ const Fe FE0 = {{0, 0, 0, 0}};
+// base row with cols 0..k-1 and/or the last column
+#define ROW_B1(c, row, a, last) rowB(c, row, 0x11, a, FE0, FE0, FE0, last)
+#define ROW_B2(c, row, a, b, last) rowB(c, row, 0x13, a, b, FE0, FE0, last)
+#define ROW_B3(c, row, a, b, d, last) rowB(c, row, 0x17, a, b, d, FE0, last)
+#define ROW_B4(c, row, a, b, d, e, last) rowB(c, row, 0x1f, a, b, d, e, last)
+
+// ------------------------------------------------------------------------------------------------
 // range-chip row groups (src/context.rs:835-972, src/circuit/range_chip.rs:287-347)
 WI_INLINE u64 chunk18(const Limb& x, int i) {  // i-th 18-bit chunk of a <=128-bit value
     int sh = 18 * i;
@@ -146,27 +229,17 @@ WI_INLINE u64 chunk18(const Limb& x, int i) {  // i-th 18-bit chunk of a <=128-b
 }
 // assign_nonleading_limb: 3 rows, 7 cells
 WI_INLINE void emit_limb3(const LC& c, u32 row, const Limb& x) {
-    stR(c, row, 0, fe_of(x));
-    stR(c, row, 1, fe_u64(chunk18(x, 3)));
-    stR(c, row, 2, fe_u64(chunk18(x, 0)));
-    stR(c, row + 1, 1, fe_u64(chunk18(x, 4)));
-    stR(c, row + 1, 2, fe_u64(chunk18(x, 1)));
-    stR(c, row + 2, 1, fe_u64(chunk18(x, 5)));
-    stR(c, row + 2, 2, fe_u64(chunk18(x, 2)));
+    rowR(c, row, 7, fe_of(x), fe_u64(chunk18(x, 3)), fe_u64(chunk18(x, 0)));
+    rowR(c, row + 1, 6, FE0, fe_u64(chunk18(x, 4)), fe_u64(chunk18(x, 1)));
+    rowR(c, row + 2, 6, FE0, fe_u64(chunk18(x, 5)), fe_u64(chunk18(x, 2)));
 }
 // leading limb in a 2-line range value (36..72 bits): 2 rows, 5 cells
 WI_INLINE void emit_lead2(const LC& c, u32 row, const Limb& x) {
-    stR(c, row, 0, fe_of(x));
-    stR(c, row, 1, fe_u64(chunk18(x, 2)));
-    stR(c, row, 2, fe_u64(chunk18(x, 0)));
-    stR(c, row + 1, 1, fe_u64(chunk18(x, 3)));
-    stR(c, row + 1, 2, fe_u64(chunk18(x, 1)));
+    rowR(c, row, 7, fe_of(x), fe_u64(chunk18(x, 2)), fe_u64(chunk18(x, 0)));
+    rowR(c, row + 1, 6, FE0, fe_u64(chunk18(x, 3)), fe_u64(chunk18(x, 1)));
 }
 // assign_common: 1 row, 2 cells
-WI_INLINE void emit_common(const LC& c, u32 row, u64 x) {
-    stR(c, row, 0, fe_u64(x));
-    stR(c, row, 1, fe_u64(x));
-}
+WI_INLINE void emit_common(const LC& c, u32 row, u64 x) { rowR(c, row, 3, fe_u64(x), fe_u64(x), FE0); }
 
 template <class FP>
 struct IntVal {  // value of an AssignedInteger
@@ -203,6 +276,14 @@ WI_INLINE void split_limbs(const Wd<N>& x, Limb* out) {
     out[2] = limb_of<2>(x);
     if (FP::L > 3) out[FP::L - 1] = limb_of<3>(x);
 }
+// base row [limb_0 .. limb_{L-1} | last]
+template <class FP>
+WI_INLINE void row_limbs(const LC& c, u32 row, const Limb* l, const Fe& last) {
+    if (FP::L == 3)
+        ROW_B3(c, row, fe_of(l[0]), fe_of(l[1]), fe_of(l[2]), last);
+    else
+        ROW_B4(c, row, fe_of(l[0]), fe_of(l[1]), fe_of(l[2]), fe_of(l[FP::L - 1]), last);
+}
 
 // assign_w / assign_d body: range rows for the limbs + the base row [limbs .. | native]
 // (integer_chip.rs:236-281).  Returns rows consumed in range.
@@ -216,9 +297,7 @@ WI_INLINE u32 emit_assigned(const LC& c, u32 brow, u32 rrow, const Limb* l, cons
     }
     emit_lead2(c, r, l[FP::L - 1]);
     r += 2;
-#pragma unroll
-    for (int i = 0; i < FP::L; i++) stB(c, brow, i, fe_of(l[i]));
-    stB(c, brow, 4, native);
+    row_limbs<FP>(c, brow, l, native);
     return r - rrow;
 }
 
@@ -271,22 +350,16 @@ WI_INLINE void emit_mul_equation(const LC& c, u32 brow, u32 rrow, const IntVal<F
         if (r_bound - l_bound == 1) {
             const int i = l_bound;
             t = wd_sub<4>(lmul(a.l[i], b.l[pos - i]), lmul(d[i], wl[pos - i]));
-            stB(c, brow, 0, fe_of(a.l[i]));
-            stB(c, brow, 1, fe_of(b.l[pos - i]));
-            stB(c, brow, 2, fe_of(d[i]));
-            stB(c, brow, 4, fe_of_signed(c, t));
+            ROW_B3(c, brow, fe_of(a.l[i]), fe_of(b.l[pos - i]), fe_of(d[i]), fe_of_signed(c, t));
             brow += 1;
         } else {
 #pragma unroll
             for (int i = l_bound; i < r_bound; i++) {
-                stB(c, brow, 0, fe_of(a.l[i]));
-                stB(c, brow, 1, fe_of(b.l[pos - i]));
-                stB(c, brow, 2, fe_of(d[i]));
-                stB(c, brow, 4, fe_of_signed(c, t));
+                ROW_B3(c, brow, fe_of(a.l[i]), fe_of(b.l[pos - i]), fe_of(d[i]), fe_of_signed(c, t));
                 brow += 1;
                 t = wd_add<4>(t, wd_sub<4>(lmul(a.l[i], b.l[pos - i]), lmul(d[i], wl[pos - i])));
             }
-            stB(c, brow, 4, fe_of_signed(c, t));
+            rowB(c, brow, 0x10, FE0, FE0, FE0, FE0, fe_of_signed(c, t));
             brow += 1;
         }
         lv[pos] = t;
@@ -302,23 +375,16 @@ WI_INLINE void emit_mul_equation(const LC& c, u32 brow, u32 rrow, const IntVal<F
         Wd<4> u;
         if (i == 0) {
             u = wd_add<4>(wd_sub<4>(lv[0], wd_resize<4>(rem[0])), K0);
-            stB(c, brow, 0, fe_of_signed(c, lv[0]));
-            stB(c, brow, 1, fe_of(rem[0]));
+            ROW_B2(c, brow, fe_of_signed(c, lv[0]), fe_of(rem[0]), u);
         } else if (i < L) {
             Wd<4> vprev = wd_add<4>(wd_shl<4, 108>(wd_from_u64<1>(v_h)), wd_resize<4>(v_l));
             u = wd_add<4>(wd_add<4>(wd_sub<4>(lv[i], wd_resize<4>(rem[i])), vprev), K1);
-            stB(c, brow, 0, fe_of_signed(c, lv[i]));
-            stB(c, brow, 1, fe_of(rem[i]));
-            stB(c, brow, 2, fe_u64(v_h));
-            stB(c, brow, 3, fe_of(v_l));
+            ROW_B4(c, brow, fe_of_signed(c, lv[i]), fe_of(rem[i]), fe_u64(v_h), fe_of(v_l), u);
         } else {
             Wd<4> vprev = wd_add<4>(wd_shl<4, 108>(wd_from_u64<1>(v_h)), wd_resize<4>(v_l));
             u = wd_add<4>(wd_add<4>(lv[i], vprev), K1);
-            stB(c, brow, 0, fe_of_signed(c, lv[i]));
-            stB(c, brow, 1, fe_u64(v_h));
-            stB(c, brow, 2, fe_of(v_l));
+            ROW_B3(c, brow, fe_of_signed(c, lv[i]), fe_u64(v_h), fe_of(v_l), u);
         }
-        stB(c, brow, 4, u);
         brow += 1;
         if (wd_is_neg<4>(u) || !wd_is_zero<2>(wd_mask<108, 2>(wd_resize<2>(u)))) flag(c, H2E_STATUS_ARITH);
         Wd<4> v = wd_shr<4, 108>(u);
@@ -327,16 +393,11 @@ WI_INLINE void emit_mul_equation(const LC& c, u32 brow, u32 rrow, const IntVal<F
         emit_common(c, rrow, v_h);
         emit_limb3(c, rrow + 1, v_l);
         rrow += 4;
-        stB(c, brow, 0, fe_u64(v_h));
-        stB(c, brow, 1, fe_of(v_l));
-        stB(c, brow, 4, u);
+        ROW_B2(c, brow, fe_u64(v_h), fe_of(v_l), u);
         brow += 1;
     }
     // native row (integer_chip.rs:195-215)
-    stB(c, brow, 0, a.native);
-    stB(c, brow, 1, b.native);
-    stB(c, brow, 2, d_native);
-    stB(c, brow, 3, rem_native);
+    rowB(c, brow, 0x0f, a.native, b.native, d_native, rem_native, FE0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -362,8 +423,8 @@ WI_INLINE void op_const_int(const LC& c, const H2EOp& op, bool from_input) {
     Limb l[FP::L];
     split_limbs<FP>(x, l);
 #pragma unroll
-    for (int i = 0; i < FP::L; i++) stB(c, op.base_row + i, 0, fe_of(l[i]));
-    stB(c, op.base_row + FP::L, 0, mod_n<FP::WW>(c, x));
+    for (int i = 0; i < FP::L; i++) rowB(c, op.base_row + i, 1, fe_of(l[i]), FE0, FE0, FE0, FE0);
+    rowB(c, op.base_row + FP::L, 1, mod_n<FP::WW>(c, x), FE0, FE0, FE0, FE0);
 }
 
 template <class FP>
@@ -374,13 +435,9 @@ WI_INLINE void op_int_add(const LC& c, const H2EOp& op) {
 #pragma unroll
     for (int i = 0; i < FP::L; i++) {
         s[i] = wd_add<2>(a.l[i], b.l[i]);
-        stB(c, r + i, 0, fe_of(a.l[i]));
-        stB(c, r + i, 1, fe_of(b.l[i]));
-        stB(c, r + i, 4, fe_of(s[i]));
+        ROW_B2(c, r + i, fe_of(a.l[i]), fe_of(b.l[i]), fe_of(s[i]));
     }
-#pragma unroll
-    for (int i = 0; i < FP::L; i++) stB(c, r + FP::L, i, fe_of(s[i]));
-    stB(c, r + FP::L, 4, addmod_n(c, a.native, b.native));
+    row_limbs<FP>(c, r + FP::L, s, addmod_n(c, a.native, b.native));
 }
 
 template <class FP>
@@ -392,14 +449,10 @@ WI_INLINE void op_int_sub(const LC& c, const H2EOp& op) {
     for (int i = 0; i < FP::L; i++) {
         Limb U = wd_load<2>(c.fc->ceil_limbs[t][i]);
         s[i] = wd_sub<2>(wd_add<2>(a.l[i], U), b.l[i]);
-        stB(c, r + i, 0, fe_of(a.l[i]));
-        stB(c, r + i, 1, fe_of(b.l[i]));
-        stB(c, r + i, 4, fe_of(s[i]));
+        ROW_B2(c, r + i, fe_of(a.l[i]), fe_of(b.l[i]), fe_of(s[i]));
     }
-#pragma unroll
-    for (int i = 0; i < FP::L; i++) stB(c, r + FP::L, i, fe_of(s[i]));
     Fe un = wd_load<4>(c.fc->ceil_native[t]);
-    stB(c, r + FP::L, 4, addmod_n(c, submod_n(c, a.native, b.native), un));
+    row_limbs<FP>(c, r + FP::L, s, addmod_n(c, submod_n(c, a.native, b.native), un));
 }
 
 template <class FP>
@@ -411,13 +464,10 @@ WI_INLINE void op_int_neg(const LC& c, const H2EOp& op) {
     for (int i = 0; i < FP::L; i++) {
         Limb U = wd_load<2>(c.fc->ceil_limbs[t][i]);
         s[i] = wd_sub<2>(U, a.l[i]);
-        stB(c, r + i, 0, fe_of(a.l[i]));
-        stB(c, r + i, 4, fe_of(s[i]));
+        ROW_B1(c, r + i, fe_of(a.l[i]), fe_of(s[i]));
     }
-#pragma unroll
-    for (int i = 0; i < FP::L; i++) stB(c, r + FP::L, i, fe_of(s[i]));
     Fe un = wd_load<4>(c.fc->ceil_native[t]);
-    stB(c, r + FP::L, 4, submod_n(c, un, a.native));
+    row_limbs<FP>(c, r + FP::L, s, submod_n(c, un, a.native));
 }
 
 template <class FP>
@@ -429,12 +479,9 @@ WI_INLINE void op_int_mul_small(const LC& c, const H2EOp& op) {
 #pragma unroll
     for (int i = 0; i < FP::L; i++) {
         s[i] = wd_resize<2>(wd_mul<2, 1>(a.l[i], k));
-        stB(c, r + i, 0, fe_of(a.l[i]));
-        stB(c, r + i, 4, fe_of(s[i]));
+        ROW_B1(c, r + i, fe_of(a.l[i]), fe_of(s[i]));
     }
-#pragma unroll
-    for (int i = 0; i < FP::L; i++) stB(c, r + FP::L, i, fe_of(s[i]));
-    stB(c, r + FP::L, 4, mod_n<5>(c, wd_mul<4, 1>(a.native, k)));
+    row_limbs<FP>(c, r + FP::L, s, mod_n<5>(c, wd_mul<4, 1>(a.native, k)));
 }
 
 template <class FP>
@@ -472,9 +519,7 @@ WI_INLINE void op_reduce(const LC& c, const H2EOp& op) {
     emit_common(c, rr, d);
     rr += 1;
     // native row: [d * w_native, rem.native * 1 | a.native * (-1)]   (integer_chip.rs:303-311)
-    stB(c, br + 1, 0, fe_u64(d));
-    stB(c, br + 1, 1, rem_native);
-    stB(c, br + 1, 4, a.native);
+    ROW_B2(c, br + 1, fe_u64(d), rem_native, a.native);
     br += 2;
     Limb last_v = wd_zero<2>();
 #pragma unroll
@@ -491,70 +536,53 @@ WI_INLINE void op_reduce(const LC& c, const H2EOp& op) {
         Limb v = wd_resize<2>(wd_shr<4, 108>(u));
         emit_limb3(c, rr, v);
         rr += 3;
-        stB(c, br, 0, fe_u64(d));
-        stB(c, br, 1, fe_of(rl[i]));
-        stB(c, br, 2, fe_of(a.l[i]));
-        stB(c, br, 3, fe_of(last_v));  // pair!(zero, zero) placeholder for i == 0 (quirk Q5)
-        stB(c, br, 4, fe_of(v));
+        // 4th operand is pair!(zero, zero) for i == 0 (quirk Q5): the cell is assigned, value 0
+        ROW_B4(c, br, fe_u64(d), fe_of(rl[i]), fe_of(a.l[i]), fe_of(last_v), fe_of(v));
         br += 1;
         last_v = v;
     }
 }
 
-// invert rows for one value (base_chip.rs:298-321): [a, c] ; [a, b | c]
+// invert rows for one value (base_chip.rs:298-321): [a, c] ; [a, b | c].  b = a^-1 (row + 1, col 1) is left to
+// the fix-up kernel.
 WI_INLINE void emit_invert(const LC& c, u32 row, const Fe& a) {
     Fe cc = fe_u64(wd_is_zero<4>(a) ? 1 : 0);
-    stB(c, row, 0, a);
-    stB(c, row, 1, cc);
-    stB(c, row + 1, 0, a);
-    stB(c, row + 1, 4, cc);  // (row+1, col 1) = a^-1 comes from the fix-up kernel
+    rowB(c, row, 0x03, a, cc, FE0, FE0, FE0);
+    rowB(c, row + 1, 0x11, a, FE0, FE0, FE0, cc);
 }
 
 template <class FP>
 WI_INLINE void op_is_int_zero(const LC& c, const H2EOp& op) {
-    constexpr int L = FP::L, NI = 2 + FP::PW;
+    constexpr int L = FP::L;
     IntVal<FP> a = ld_int<FP>(c, op.refs);
-    // values whose inverses are witnessed
-    Fe x[NI];
     Limb sum = a.l[0];
 #pragma unroll
     for (int i = 1; i < L; i++) sum = wd_add<2>(sum, a.l[i]);
-    x[0] = fe_of(sum);
-    x[1] = submod_n(c, a.native, wd_load<4>(c.fc->w_native));
-#pragma unroll
-    for (int i = 0; i < FP::PW; i++) x[2 + i] = submod_n(c, fe_of(a.l[i]), fe_of(wd_load<2>(c.fc->w_limbs[i])));
-    // The inverse witnesses (col 1 of each second invert row) are NOT written here: nothing downstream reads
-    // them, so they are filled afterwards by h2e_fixup_inverses with one batched inversion per 64 cells.
+    Fe x0 = fe_of(sum);
+    Fe x1 = submod_n(c, a.native, wd_load<4>(c.fc->w_native));
     u32 r = op.base_row;
     // is_pure_zero (integer_chip.rs:540-548)
-#pragma unroll
-    for (int i = 0; i < L; i++) stB(c, r, i, fe_of(a.l[i]));
-    stB(c, r, 4, x[0]);
-    emit_invert(c, r + 1, x[0]);
-    u64 is_zero = wd_is_zero<4>(x[0]) ? 1 : 0;
+    row_limbs<FP>(c, r, a.l, x0);
+    emit_invert(c, r + 1, x0);
+    u64 is_zero = wd_is_zero<4>(x0) ? 1 : 0;
     r += 3;
     // is_pure_w_modulus (integer_chip.rs:550-570)
-    stB(c, r, 0, a.native);
-    stB(c, r, 4, x[1]);
-    emit_invert(c, r + 1, x[1]);
-    u64 is_eq = wd_is_zero<4>(x[1]) ? 1 : 0;
+    ROW_B1(c, r, a.native, x1);
+    emit_invert(c, r + 1, x1);
+    u64 is_eq = wd_is_zero<4>(x1) ? 1 : 0;
     r += 3;
 #pragma unroll
     for (int i = 0; i < FP::PW; i++) {
-        stB(c, r, 0, fe_of(a.l[i]));
-        stB(c, r, 4, x[2 + i]);
-        emit_invert(c, r + 1, x[2 + i]);
-        u64 is_limb_eq = wd_is_zero<4>(x[2 + i]) ? 1 : 0;
-        stB(c, r + 3, 0, fe_u64(is_eq));
-        stB(c, r + 3, 1, fe_u64(is_limb_eq));
-        stB(c, r + 3, 4, fe_u64(is_eq & is_limb_eq));
+        Fe xi = submod_n(c, fe_of(a.l[i]), fe_of(wd_load<2>(c.fc->w_limbs[i])));
+        ROW_B1(c, r, fe_of(a.l[i]), xi);
+        emit_invert(c, r + 1, xi);
+        u64 is_limb_eq = wd_is_zero<4>(xi) ? 1 : 0;
+        ROW_B2(c, r + 3, fe_u64(is_eq), fe_u64(is_limb_eq), fe_u64(is_eq & is_limb_eq));
         is_eq &= is_limb_eq;
         r += 4;
     }
     // or (base_chip.rs:428-439)
-    stB(c, r, 0, fe_u64(is_zero));
-    stB(c, r, 1, fe_u64(is_eq));
-    stB(c, r, 4, fe_u64(is_zero | is_eq));
+    ROW_B2(c, r, fe_u64(is_zero), fe_u64(is_eq), fe_u64(is_zero | is_eq));
 }
 
 template <class FP>
@@ -565,14 +593,8 @@ WI_INLINE void op_mask_int(const LC& c, const H2EOp& op) {
     bool keep = !wd_is_zero<4>(coeff);
     u32 r = op.base_row;
 #pragma unroll
-    for (int i = 0; i < L; i++) {
-        stB(c, r + i, 0, fe_of(a.l[i]));
-        stB(c, r + i, 1, coeff);
-        stB(c, r + i, 4, keep ? fe_of(a.l[i]) : wd_zero<4>());
-    }
-    stB(c, r + L, 0, a.native);
-    stB(c, r + L, 1, coeff);
-    stB(c, r + L, 4, keep ? a.native : wd_zero<4>());
+    for (int i = 0; i < L; i++) ROW_B2(c, r + i, fe_of(a.l[i]), coeff, keep ? fe_of(a.l[i]) : wd_zero<4>());
+    ROW_B2(c, r + L, a.native, coeff, keep ? a.native : wd_zero<4>());
 }
 
 // int_div core (integer_chip.rs:522-535): refs = b (L+1), a' (L+1)
@@ -629,30 +651,26 @@ WI_INLINE void op_bisec_int(const LC& c, const H2EOp& op) {
 #pragma unroll
     for (int i = 0; i <= L; i++) {
         Fe av = ld_fe(c, op.refs[1 + i]), bv = ld_fe(c, op.refs[1 + L + 1 + i]);
-        stB(c, r + i, 0, cond);
-        stB(c, r + i, 1, av);
-        stB(c, r + i, 2, cond);
-        stB(c, r + i, 3, bv);
-        stB(c, r + i, 4, take_a ? av : bv);
+        ROW_B4(c, r + i, cond, av, cond, bv, take_a ? av : bv);
     }
 }
 
 template <class FP>
 WI_INLINE void op_sum_limbs(const LC& c, const H2EOp& op) {
+    Limb l[FP::L];
     Limb sum = wd_zero<2>();
 #pragma unroll
     for (int i = 0; i < FP::L; i++) {
-        Limb l = ld_limb(c, op.refs[i]);
-        stB(c, op.base_row, i, fe_of(l));
-        sum = wd_add<2>(sum, l);
+        l[i] = ld_limb(c, op.refs[i]);
+        sum = wd_add<2>(sum, l[i]);
     }
-    stB(c, op.base_row, 4, fe_of(sum));
+    row_limbs<FP>(c, op.base_row, l, fe_of(sum));
 }
 
 WI_INLINE void op_assert_const(const LC& c, const H2EOp& op) {
     Fe x = ld_fe(c, op.refs[0]);
-    stB(c, op.base_row, 0, x);
-    if (!wd_eq<4>(x, fe_u64(op.imm))) {
+    rowB(c, op.base_row, 1, x, FE0, FE0, FE0, FE0);
+    if (c.active && !wd_eq<4>(x, fe_u64(op.imm))) {
         u32 bits = H2E_STATUS_ASSERT_FAILED;
         if (op.flags & H2E_FLAG_UNSAFE_ADD) bits |= H2E_STATUS_RETRY_ADD_SAME_OR_NEG;
         if (op.flags & H2E_FLAG_UNSAFE_DBL) bits |= H2E_STATUS_RETRY_ADD_IDENTITY;
@@ -669,24 +687,18 @@ WI_INLINE void op_decompose_native(const LC& c, const H2EOp& op) {
     for (u32 i = 0; i < nbits / 2; i++) {
         u64 b0 = v.v[0] & 1, b1 = (v.v[0] >> 1) & 1;
         Fe vn = wd_shr1<4>(wd_shr1<4>(v));
-        stB(c, r, 0, fe_u64(b0));
-        stB(c, r, 1, fe_u64(b0));
-        stB(c, r + 1, 0, fe_u64(b1));
-        stB(c, r + 1, 1, fe_u64(b1));
-        stB(c, r + 2, 0, vn);
-        stB(c, r + 2, 1, fe_u64(b1));
-        stB(c, r + 2, 2, fe_u64(b0));
-        stB(c, r + 2, 4, v);
+        rowB(c, r, 3, fe_u64(b0), fe_u64(b0), FE0, FE0, FE0);
+        rowB(c, r + 1, 3, fe_u64(b1), fe_u64(b1), FE0, FE0, FE0);
+        ROW_B3(c, r + 2, vn, fe_u64(b1), fe_u64(b0), v);
         r += 3;
         v = vn;
     }
     // even NUM_BITS: assert_constant(v, 0); odd: assert_bit(v)
     if (nbits & 1) {
-        stB(c, r, 0, v);
-        stB(c, r, 1, v);
+        rowB(c, r, 3, v, v, FE0, FE0, FE0);
     } else {
-        stB(c, r, 0, v);
-        if (!wd_is_zero<4>(v)) flag(c, H2E_STATUS_ASSERT_FAILED);
+        rowB(c, r, 1, v, FE0, FE0, FE0, FE0);
+        if (c.active && !wd_is_zero<4>(v)) flag(c, H2E_STATUS_ASSERT_FAILED);
     }
 }
 
@@ -696,30 +708,19 @@ WI_INLINE void op_pick_index(const LC& c, const H2EOp& op) {
     u64 bits[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) bits[i] = (i < (int)k) ? ld_fe(c, op.refs[i]).v[0] : 0;
+    u64 acc = bits[0] | (bits[1] << 1) | (bits[2] << 2) | (bits[3] << 3);
     if (k < 5) {
-        u64 idx = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (i < (int)k) {
-                stB(c, r, i, fe_u64(bits[i]));
-                idx |= bits[i] << i;
-            }
-        stB(c, r, 4, fe_u64(idx));
+        rowB(c, r, ((1u << k) - 1) | 0x10, fe_u64(bits[0]), fe_u64(bits[1]), fe_u64(bits[2]), fe_u64(bits[3]), fe_u64(acc));
     } else {
-        u64 acc = bits[0] | (bits[1] << 1) | (bits[2] << 2) | (bits[3] << 3);
-#pragma unroll
-        for (int i = 0; i < 4; i++) stB(c, r, i, fe_u64(bits[i]));
-        stB(c, r, 4, fe_u64(acc));
-        stB(c, r + 1, 0, fe_u64(bits[4]));
-        stB(c, r + 1, 1, fe_u64(acc));
-        stB(c, r + 1, 4, fe_u64(acc | (bits[4] << 4)));
+        ROW_B4(c, r, fe_u64(bits[0]), fe_u64(bits[1]), fe_u64(bits[2]), fe_u64(bits[3]), fe_u64(acc));
+        ROW_B2(c, r + 1, fe_u64(bits[4]), fe_u64(acc), fe_u64(acc | (bits[4] << 4)));
     }
 }
 
 template <class FP>
 WI_INLINE void op_cache_int(const LC& c, const H2EOp& op) {
 #pragma unroll
-    for (int i = 0; i <= FP::L; i++) stS(c, op.select_row + i, 0, ld_fe(c, op.refs[i]));
+    for (int i = 0; i <= FP::L; i++) rowS(c, op.select_row + i, 1, ld_fe(c, op.refs[i]), FE0);
 }
 
 // assign_selected_point_non_zero: refs[0] = index cell, imm = aux offset of the candidate ref table
@@ -730,11 +731,11 @@ WI_INLINE void op_select_point(const LC& c, const H2EOp& op) {
     Fe index = ld_fe(c, op.refs[0]);
     u32 idx = (u32)(index.v[0] & 0xff);
     const u32* tab = c.aux + op.imm + idx * NC;
+    Fe v[NC];
 #pragma unroll
-    for (int j = 0; j < NC; j++) {
-        stS(c, op.select_row + j, 0, ld_fe(c, tab[j]));
-        stS(c, op.select_row + j, 1, index);
-    }
+    for (int j = 0; j < NC; j++) v[j] = ld_fe(c, tab[j]);
+#pragma unroll
+    for (int j = 0; j < NC; j++) rowS(c, op.select_row + j, 3, v[j], index);
 }
 
 template <class FP, bool UNUSED>
@@ -1011,17 +1012,16 @@ WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
         case H2E_OP_ASSIGN_W: op_assign_w<FP>(c, op); break;
         case H2E_OP_ASSIGN: {
             u32 slot = op.imm + ((op.flags & H2E_FLAG_INPUT_STRIDED) ? c.strand * c.input_stride : 0);
-            stB(c, op.base_row, 0, wd_load<4>(c.inputs + (size_t)slot * FP::WW));
+            rowB(c, op.base_row, 1, wd_load<4>(c.inputs + (size_t)slot * FP::WW), FE0, FE0, FE0, FE0);
         } break;
         case H2E_OP_ASSIGN_BIT: {
             u32 slot = op.imm + ((op.flags & H2E_FLAG_INPUT_STRIDED) ? c.strand * c.input_stride : 0);
             Fe v = wd_load<4>(c.inputs + (size_t)slot * FP::WW);
-            stB(c, op.base_row, 0, v);
-            stB(c, op.base_row, 1, v);
+            rowB(c, op.base_row, 3, v, v, FE0, FE0, FE0);
         } break;
         case H2E_OP_CONST_INT: op_const_int<FP>(c, op, false); break;
         case H2E_OP_CONST_INT_INPUT: op_const_int<FP>(c, op, true); break;
-        case H2E_OP_CONST: stB(c, op.base_row, 0, wd_load<4>(c.pool + op.imm)); break;
+        case H2E_OP_CONST: rowB(c, op.base_row, 1, wd_load<4>(c.pool + op.imm), FE0, FE0, FE0, FE0); break;
         case H2E_OP_INT_ADD: op_int_add<FP>(c, op); break;
         case H2E_OP_INT_SUB: op_int_sub<FP>(c, op); break;
         case H2E_OP_INT_NEG: op_int_neg<FP>(c, op); break;
@@ -1031,8 +1031,7 @@ WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
         case H2E_OP_IS_INT_ZERO: op_is_int_zero<FP>(c, op); break;
         case H2E_OP_NOT: {
             Fe x = ld_fe(c, op.refs[0]);
-            stB(c, op.base_row, 0, x);
-            stB(c, op.base_row, 4, submod_n(c, fe_u64(1), x));
+            ROW_B1(c, op.base_row, x, submod_n(c, fe_u64(1), x));
         } break;
         case H2E_OP_MASK_INT: op_mask_int<FP>(c, op); break;
         case H2E_OP_DIV_CORE: op_div_core<FP>(c, op); break;
@@ -1041,29 +1040,19 @@ WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
         case H2E_OP_ASSERT_CONST: op_assert_const(c, op); break;
         case H2E_OP_BISEC: {
             Fe cond = ld_fe(c, op.refs[0]), a = ld_fe(c, op.refs[1]), b = ld_fe(c, op.refs[2]);
-            stB(c, op.base_row, 0, cond);
-            stB(c, op.base_row, 1, a);
-            stB(c, op.base_row, 2, cond);
-            stB(c, op.base_row, 3, b);
-            stB(c, op.base_row, 4, wd_is_zero<4>(cond) ? b : a);
+            ROW_B4(c, op.base_row, cond, a, cond, b, wd_is_zero<4>(cond) ? b : a);
         } break;
         case H2E_OP_AND: {
             Fe a = ld_fe(c, op.refs[0]), b = ld_fe(c, op.refs[1]);
-            stB(c, op.base_row, 0, a);
-            stB(c, op.base_row, 1, b);
-            stB(c, op.base_row, 4, fe_u64(a.v[0] & b.v[0]));
+            ROW_B2(c, op.base_row, a, b, fe_u64(a.v[0] & b.v[0]));
         } break;
         case H2E_OP_OR: {
             Fe a = ld_fe(c, op.refs[0]), b = ld_fe(c, op.refs[1]);
-            stB(c, op.base_row, 0, a);
-            stB(c, op.base_row, 1, b);
-            stB(c, op.base_row, 4, fe_u64(a.v[0] | b.v[0]));
+            ROW_B2(c, op.base_row, a, b, fe_u64(a.v[0] | b.v[0]));
         } break;
         case H2E_OP_XNOR: {
             Fe a = ld_fe(c, op.refs[0]), b = ld_fe(c, op.refs[1]);
-            stB(c, op.base_row, 0, a);
-            stB(c, op.base_row, 1, b);
-            stB(c, op.base_row, 4, fe_u64(1 ^ a.v[0] ^ b.v[0]));
+            ROW_B2(c, op.base_row, a, b, fe_u64(1 ^ a.v[0] ^ b.v[0]));
         } break;
         case H2E_OP_DECOMPOSE_NATIVE: op_decompose_native(c, op); break;
         case H2E_OP_PICK_INDEX: op_pick_index(c, op); break;
@@ -1101,7 +1090,10 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     u32 per_sub = n_instances * L.n_strands;
     u32 blocks_per_sub = (per_sub + 63) / 64;
     u32 sub = blockIdx.x / blocks_per_sub, idx = (blockIdx.x % blocks_per_sub) * 64 + threadIdx.x;  // sub is wave-uniform
-    if (idx >= per_sub) return;
+    // padding lanes of the last wave replay the last valid lane's work but store nothing: every lane must take
+    // part in the cooperative row flushes
+    bool active = idx < per_sub;
+    if (!active) idx = per_sub - 1;
     u32 instance = idx / L.n_strands, strand = idx % L.n_strands;
     u32 op_lo = 0, op_hi = L.n_ops;
     if (!VALUES_ONLY && L.n_sub > 1) {
@@ -1126,6 +1118,9 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     c.input_stride = L.input_stride;
     c.hints = d.hints;
     c.hint_stride = L.hint_stride;
+    __shared__ Stage stage;
+    c.st = &stage;
+    c.active = active;
     if constexpr (VALUES_ONLY) {
         // the value chain is the critical path and may share its SIMD with expansion waves of an earlier segment
         __builtin_amdgcn_s_setprio(3);
