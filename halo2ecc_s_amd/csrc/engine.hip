@@ -1062,15 +1062,32 @@ WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
     }
 }
 
-// Tape ops are wave-uniform: fetch them through the scalar cache into SGPRs (one s_load_dwordx16 per op), so
-// the opcode switch is a scalar branch and the refs / rows are scalar operands of the address arithmetic.
-typedef u32 u32x16 __attribute__((ext_vector_type(16)));
-WI_INLINE H2EOp fetch_op(const H2EOp* tape, u32 i) {
-    u64 addr = (u64)(tape + i);
-    u32 lo = __builtin_amdgcn_readfirstlane((u32)addr), hi = __builtin_amdgcn_readfirstlane((u32)(addr >> 32));
-    const u32x16* p = (const u32x16*)(((u64)hi << 32) | lo);
-    u32x16 v;
-    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+// Tape ops are wave-uniform.  A wave pulls 64 ops (4 KB) into LDS with one coalesced load - one HBM/L2 round
+// trip per 64 ops instead of one per op, which matters for the latency-bound value chain - and each op is then
+// read from LDS at a uniform address and moved to SGPRs, so the opcode switch is a scalar branch and refs / rows
+// are scalar operands of the address arithmetic.
+struct TapeChunk {
+    uint4 w[64][4];  // [op in chunk][4 x 16 bytes]
+};
+WI_INLINE void load_chunk(TapeChunk* tc, const H2EOp* tape, u32 first, u32 end) {
+    u32 lane = threadIdx.x;
+    if (first + lane < end) {
+        const uint4* src = (const uint4*)(tape + first + lane);
+#pragma unroll
+        for (int k = 0; k < 4; k++) tc->w[lane][k] = src[k];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+WI_INLINE H2EOp chunk_op(const TapeChunk* tc, u32 k) {
+    u32 v[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint4 x = tc->w[k][q];
+        v[4 * q + 0] = __builtin_amdgcn_readfirstlane(x.x);
+        v[4 * q + 1] = __builtin_amdgcn_readfirstlane(x.y);
+        v[4 * q + 2] = __builtin_amdgcn_readfirstlane(x.z);
+        v[4 * q + 3] = __builtin_amdgcn_readfirstlane(x.w);
+    }
     H2EOp op;
     op.opcode = (uint16_t)(v[0] & 0xffffu);
     op.flags = (uint16_t)(v[0] >> 16);
@@ -1079,7 +1096,7 @@ WI_INLINE H2EOp fetch_op(const H2EOp* tape, u32 i) {
     op.range_row = v[3];
     op.select_row = v[4];
 #pragma unroll
-    for (int k = 0; k < H2E_OP_MAX_REFS; k++) op.refs[k] = v[5 + k];
+    for (int k2 = 0; k2 < H2E_OP_MAX_REFS; k2++) op.refs[k2] = v[5 + k2];
     return op;
 }
 
@@ -1119,6 +1136,7 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     c.hints = d.hints;
     c.hint_stride = L.hint_stride;
     __shared__ Stage stage;
+    __shared__ TapeChunk chunk;
     c.st = &stage;
     c.active = active;
     if constexpr (VALUES_ONLY) {
@@ -1126,14 +1144,22 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
         __builtin_amdgcn_s_setprio(3);
         __shared__ VCache<FP> vcache;
         vc_init<FP>(&vcache);
-        for (u32 i = op_lo; i < op_hi; i++) {
-            H2EOp op = fetch_op(L.tape, i);
-            exec_op_values<FP>(&vcache, c, op, L.rel_refs);
+        for (u32 i0 = op_lo; i0 < op_hi; i0 += 64) {
+            load_chunk(&chunk, L.tape, i0, op_hi);
+            u32 n = min(64u, op_hi - i0);
+            for (u32 k = 0; k < n; k++) {
+                H2EOp op = chunk_op(&chunk, k);
+                exec_op_values<FP>(&vcache, c, op, L.rel_refs);
+            }
         }
     } else {
-        for (u32 i = op_lo; i < op_hi; i++) {
-            H2EOp op = fetch_op(L.tape, i);
-            exec_op<FP, false>(c, op);
+        for (u32 i0 = op_lo; i0 < op_hi; i0 += 64) {
+            load_chunk(&chunk, L.tape, i0, op_hi);
+            u32 n = min(64u, op_hi - i0);
+            for (u32 k = 0; k < n; k++) {
+                H2EOp op = chunk_op(&chunk, k);
+                exec_op<FP, false>(c, op);
+            }
         }
     }
 }
