@@ -751,7 +751,7 @@ WI_INLINE void exec_op(const LC& c, const H2EOp& op);
 // wave-uniform because the tape is, the data is per lane ([entry][word][lane], conflict-free).
 template <class FP>
 struct VCache {
-    static constexpr int R = 12, W = 2 * FP::L + 4, S = 8;
+    static constexpr int R = (FP::L == 3 ? 22 : 18), W = 2 * FP::L + 4, S = 8;
     u64 data[R][W][64];
     u64 sdata[S][4][64];
     u32 tags[R];
