@@ -57,9 +57,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tiles", type=int, default=64, help="tiles per GPU (64 x 1024 = 2^16 points)")
     ap.add_argument("--points", type=int, default=1024, help="points per tile")
-    ap.add_argument("--cpu-sample-points", type=int, default=256)
+    ap.add_argument("--cpu-sample-points", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="A/B experiments with deliberately broken arithmetic")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on GPUs; gloo only to exercise the N>1 path on one GPU")
+    ap.add_argument("--device", type=int, default=None, help="override the CUDA device index (default: LOCAL_RANK)")
     args = ap.parse_args()
 
     import torch
@@ -69,11 +71,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.device is not None:
+        local_rank = args.device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
+    coll_dev = dev if args.dist_backend == "nccl" else "cpu"
 
     n, tiles = args.points, args.tiles
     eng = Engine(local_rank)
@@ -111,8 +119,9 @@ def main():
         status.zero_()
         eng.run(prog, d_in, base, rng, sel, status)
         if world > 1:  # final gather of per-tile status words (the only collective on the path)
-            gathered = [torch.empty_like(status) for _ in range(world)]
-            dist.all_gather(gathered, status)
+            st = status.to(coll_dev)
+            gathered = [torch.empty_like(st) for _ in range(world)]
+            dist.all_gather(gathered, st)
 
     for _ in range(args.warmup):
         step()
@@ -138,7 +147,7 @@ def main():
     if not args.no_check:
         assert int(status.abs().max()) == 0, f"tile status {status.cpu().numpy()}"
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

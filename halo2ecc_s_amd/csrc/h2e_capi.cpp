@@ -246,6 +246,7 @@ int h2e_program_pairing_check_bn256(int emit_shape, h2e_program** out) {
     if (rc) return rc;
     GUARDED({
         h2e::Recorder& r = *p->rec;
+        r.auto_cut_every = 16;
         uint32_t s = r.alloc_inputs(10);
         h2e::NativeScalarEccContext ecc(r, h2e::bn256_g1_params(), 0);
         h2e::Bn256PairingOps po(r);
@@ -267,6 +268,7 @@ int h2e_program_pairing_check_bls12_381(int emit_shape, h2e_program** out) {
     if (rc) return rc;
     GUARDED({
         h2e::Recorder& r = *p->rec;
+        r.auto_cut_every = 16;
         uint32_t s = r.alloc_inputs(14);
         h2e::NativeScalarEccContext ecc(r, h2e::bls12_381_g1_params(), 0);  // EccChipBaseOps of GeneralScalarEccContext
         h2e::Bls12381PairingOps po(r);
@@ -431,7 +433,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
         int cus = prop.multiProcessorCount;
         const char* env = getenv("H2E_RESERVED_CUS");
-        int reserved = env ? atoi(env) : 16;
+        int reserved = env ? atoi(env) : 0;  // measured: a CU-masked stream serialises against the other stream on this stack
         std::vector<uint32_t> mask((cus + 31) / 32, 0);
         for (int i = 0; i < cus; i++) {
             // CU ids are dealt round-robin over the 8 XCDs; reserve the last `reserved` ids (2 per XCD for 16)

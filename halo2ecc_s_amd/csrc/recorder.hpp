@@ -639,8 +639,17 @@ struct Recorder {
         for (int i = 0; i < H2E_OP_MAX_REFS; i++) op.refs[i] = H2E_NO_REF;
         return op;
     }
+    // auto_cut_every > 0: in the main context, allow the expansion to be split every that many ops (any op
+    // boundary is a valid cut once the values-only replay has run; see H2ELaunch.sub)
+    uint32_t auto_cut_every = 0;
     void push(const H2EOp& op) {
-        if (record_tape) tape.push_back(op);
+        if (!record_tape) return;
+        tape.push_back(op);
+        if (auto_cut_every && !in_strand) {
+            uint32_t at = (uint32_t)tape.size() - cur_tape_begin;
+            uint32_t last = cuts.size() > segments.back().cuts_begin ? cuts.back() : 0;
+            if (at - last >= auto_cut_every) cuts.push_back(at);
+        }
     }
     void put_int(H2EOp& op, int at, const AssignedInteger& a) const {
         for (int i = 0; i < fp.limbs; i++) op.refs[at + i] = a.limbs_le[i];
