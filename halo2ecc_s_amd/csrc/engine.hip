@@ -751,20 +751,23 @@ WI_INLINE void exec_op(const LC& c, const H2EOp& op);
 // wave-uniform because the tape is, the data is per lane ([entry][word][lane], conflict-free).
 template <class FP>
 struct VCache {
-    static constexpr int R = (FP::L == 3 ? 22 : 18), W = 2 * FP::L + 4, S = 8;
-    u64 data[R][W][64];
+    static constexpr int R = (FP::L == 3 ? 20 : 16), W = 2 * FP::L + 4, S = 8, G = 4;
+    u64 data[R + G][W][64];   // entries [R, R+G): values first seen as global loads (e.g. -r2, a window's sum), LRU
     u64 sdata[S][4][64];
-    u32 tags[R];
+    u32 tags[R + G];
+    u32 gage[G];
     u32 stags[S];
-    u32 head, shead;
+    u32 head, shead, gclock;
 };
 template <class FP>
 WI_INLINE void vc_init(VCache<FP>* vc) {
     if (threadIdx.x == 0) {
-        for (int k = 0; k < VCache<FP>::R; k++) vc->tags[k] = H2E_NO_REF;
+        for (int k = 0; k < VCache<FP>::R + VCache<FP>::G; k++) vc->tags[k] = H2E_NO_REF;
+        for (int k = 0; k < VCache<FP>::G; k++) vc->gage[k] = 0;
         for (int k = 0; k < VCache<FP>::S; k++) vc->stags[k] = H2E_NO_REF;
         vc->head = 0;
         vc->shead = 0;
+        vc->gclock = 1;
     }
     __syncthreads();
 }
@@ -803,18 +806,36 @@ WI_INLINE void vc_put_fe(VCache<FP>* vc, u32 tag, const Fe& v) {
 }
 template <class FP>
 WI_INLINE IntVal<FP> vc_ld_int(VCache<FP>* vc, const LC& c, const u32* refs) {
+    constexpr int R = VCache<FP>::R, G = VCache<FP>::G;
     u32 tag = refs[0];
     int hit = -1;
-    for (int k = 0; k < VCache<FP>::R; k++)
+    for (int k = 0; k < R + G; k++)
         if (vc->tags[k] == tag) hit = k;
+    u32 lane = threadIdx.x;
     if (hit < 0) {
-        // first use of a value produced outside this replay (e.g. -r2, a window's sum): keep it for re-use
+        // first use of a value produced outside this replay: keep it in the small LRU part for re-use
         IntVal<FP> g = ld_int<FP>(c, refs);
-        if (H2E_REF_REGION(tag) != H2E_REGION_PARAM) vc_put_int<FP>(vc, tag, g.l, g.native);
+        if (H2E_REF_REGION(tag) == H2E_REGION_PARAM) return g;
+        int victim = 0;
+        for (int k = 1; k < G; k++)
+            if (vc->gage[k] < vc->gage[victim]) victim = k;
+#pragma unroll
+        for (int i = 0; i < FP::L; i++) {
+            vc->data[R + victim][2 * i][lane] = g.l[i].v[0];
+            vc->data[R + victim][2 * i + 1][lane] = g.l[i].v[1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) vc->data[R + victim][2 * FP::L + i][lane] = g.native.v[i];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            vc->tags[R + victim] = tag;
+            vc->gage[victim] = vc->gclock++;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         return g;
     }
+    if (hit >= R && lane == 0) vc->gage[hit - R] = vc->gclock++;
     IntVal<FP> r;
-    u32 lane = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < FP::L; i++) {
         r.l[i].v[0] = vc->data[hit][2 * i][lane];
@@ -857,8 +878,15 @@ WI_INLINE void v_result_fe(VCache<FP>* vc, const LC& c, u32 row, int col, u32 re
     vc_put_fe<FP>(vc, H2E_MAKE_REF(0, col, rel, row), v);
 }
 
+// the next hinted division of a strand uses the next hint slot: fetch it one division ahead so the load is
+// long finished when it is needed (under a saturated memory system a dependent load costs ~10 us)
 template <class FP>
-WI_INLINE void exec_op_values(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 rel) {
+struct HintPrefetch {
+    u32 slot;
+    Wd<FP::WW> v;
+};
+template <class FP>
+WI_INLINE void exec_op_values(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 rel, HintPrefetch<FP>& hp) {
     constexpr int L = FP::L;
     switch (op.opcode) {
         case H2E_OP_INT_MUL: {
@@ -885,7 +913,9 @@ WI_INLINE void exec_op_values(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 
             Wd<FP::WW> cv;
             if (op.flags & H2E_FLAG_HINTED) {
                 u32 slot = op.imm + ((op.flags & H2E_FLAG_HINT_STRIDED) ? c.strand * c.hint_stride : 0);
-                cv = wd_load<FP::WW>(c.hints + (size_t)slot * H2E_W_WORDS_MAX);
+                cv = (slot == hp.slot) ? hp.v : wd_load<FP::WW>(c.hints + (size_t)slot * H2E_W_WORDS_MAX);
+                hp.slot = slot + 1;
+                hp.v = wd_load<FP::WW>(c.hints + (size_t)(slot + 1) * H2E_W_WORDS_MAX);  // workspace has one spare slot
                 // b is reduced: zero mod w iff all limbs are zero or it equals w
                 bool bz = true;
 #pragma unroll
@@ -1144,12 +1174,15 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
         __builtin_amdgcn_s_setprio(3);
         __shared__ VCache<FP> vcache;
         vc_init<FP>(&vcache);
+        HintPrefetch<FP> hp;
+        hp.slot = 0xffffffffu;
+        hp.v = wd_zero<FP::WW>();
         for (u32 i0 = op_lo; i0 < op_hi; i0 += 64) {
             load_chunk(&chunk, L.tape, i0, op_hi);
             u32 n = min(64u, op_hi - i0);
             for (u32 k = 0; k < n; k++) {
                 H2EOp op = chunk_op(&chunk, k);
-                exec_op_values<FP>(&vcache, c, op, L.rel_refs);
+                exec_op_values<FP>(&vcache, c, op, L.rel_refs, hp);
             }
         }
     } else {
@@ -1579,20 +1612,23 @@ extern "C" int h2e_engine_predict(int field_pair, const H2EPreKernel* k, const u
     u32 lanes = n_instances * k->n_lanes;
     if (lanes == 0) return 0;
     dim3 block(64), grid((lanes + 63) / 64);
+    // A latency-bound predictor (few waves) must not share its CU with expansion waves of another stream: ask
+    // for most of the CU's LDS so that nothing else fits next to it.
+    size_t lds_reserve = grid.x <= 512 ? 140 * 1024 : 0;
     u32 n_hints = k->n_lanes * k->hints_per_lane;
     u32 chunks = (n_hints + HINT_K - 1) / HINT_K;
     dim3 grid2((n_instances * chunks + 63) / 64);
     switch (field_pair) {
         case 0:
-            hipLaunchKernelGGL(h2e_predict<FP_BN256_FQ>, grid, block, 0, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev);
+            hipLaunchKernelGGL(h2e_predict<FP_BN256_FQ>, grid, block, lds_reserve, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev);
             hipLaunchKernelGGL(h2e_finalize_hints<FP_BN256_FQ>, grid2, block, 0, stream, k->hint_base, n_hints, inst, n_instances, fc_dev);
             break;
         case 1:
-            hipLaunchKernelGGL(h2e_predict<FP_BLS_FQ>, grid, block, 0, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev);
+            hipLaunchKernelGGL(h2e_predict<FP_BLS_FQ>, grid, block, lds_reserve, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev);
             hipLaunchKernelGGL(h2e_finalize_hints<FP_BLS_FQ>, grid2, block, 0, stream, k->hint_base, n_hints, inst, n_instances, fc_dev);
             break;
         case 2:
-            hipLaunchKernelGGL(h2e_predict<FP_BLS_FR>, grid, block, 0, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev);
+            hipLaunchKernelGGL(h2e_predict<FP_BLS_FR>, grid, block, lds_reserve, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev);
             hipLaunchKernelGGL(h2e_finalize_hints<FP_BLS_FR>, grid2, block, 0, stream, k->hint_base, n_hints, inst, n_instances, fc_dev);
             break;
         default: return -1;

@@ -119,6 +119,7 @@ struct h2e_ctx {
     std::vector<hipEvent_t> ev;       // profiling: 4 per launched segment (value-chain begin/end, expansion begin/end)
     std::vector<hipEvent_t> sync_ev;  // cross-stream dependencies
     hipStream_t expand_stream = nullptr;
+    hipStream_t early_stream = nullptr;
     uint32_t n_launches = 0;
     ~h2e_ctx() {
         for (auto& kv : cache) delete kv.second;
@@ -127,6 +128,7 @@ struct h2e_ctx {
         for (auto e : ev) (void)hipEventDestroy(e);
         for (auto e : sync_ev) (void)hipEventDestroy(e);
         if (expand_stream) (void)hipStreamDestroy(expand_stream);
+        if (early_stream) (void)hipStreamDestroy(early_stream);
         (void)hipFree(ws_hints);
         (void)hipFree(ws_nd);
         (void)hipFree(ws_jac);
@@ -404,7 +406,8 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         if (e == hipSuccess) *have = need;
         return e;
     };
-    size_t hint_words = (size_t)r.n_hint_slots * H2E_W_WORDS_MAX, nd_words = hint_words * 2,
+    size_t hint_words = ((size_t)r.n_hint_slots + 1) * H2E_W_WORDS_MAX,  // + 1: the replay prefetches slot + 1
+           nd_words = hint_words * 2,
            jac_words = (size_t)r.n_jac_slots * 3 * H2E_W_WORDS_MAX;
     HIP_TRY(grow(&ctx->ws_hints, &ctx->ws_hints_words, std::max<size_t>(1, hint_words * n_instances)));
     HIP_TRY(grow(&ctx->ws_nd, &ctx->ws_nd_words, std::max<size_t>(1, nd_words * n_instances)));
@@ -446,7 +449,9 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
             HIP_TRY(hipStreamCreateWithFlags(&ctx->expand_stream, hipStreamNonBlocking));
         }
     }
-    hipStream_t sa = stream, sb = ctx->expand_stream;
+    if (!ctx->early_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->early_stream, hipStreamNonBlocking));
+    hipStream_t sa = stream, sb = ctx->expand_stream, sc = ctx->early_stream;
+    std::vector<hipEvent_t> early_done(r.pre_kernels.size(), nullptr);
     size_t n_sync = 0;
     auto sync_event = [&]() -> hipEvent_t {
         if (n_sync == ctx->sync_ev.size()) {
@@ -475,11 +480,30 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         if (s.tape_end <= s.tape_begin) continue;
         uint32_t li = ctx->n_launches;
         if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 0), sa));
-        for (auto& pk : r.pre_kernels) {
+        for (size_t pi = 0; pi < r.pre_kernels.size(); pi++) {
+            const h2e::PreKernel& pk = r.pre_kernels[pi];
             if (pk.before_segment != si) continue;
+            if (early_done[pi]) {  // already running on the side stream: just wait for it
+                HIP_TRY(hipStreamWaitEvent(sa, early_done[pi], 0));
+                continue;
+            }
             int prc = h2e_engine_predict(fp, &pk.k, p->d_pre_args, p->d_params, p->d_aux, p->d_inst, n_instances,
                                          ctx->d_fc[fp], sa);
             if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
+        }
+        // predictors of later segments that only depend on this segment's predictors start now, on the side stream
+        for (size_t pi = 0; pi < r.pre_kernels.size(); pi++) {
+            const h2e::PreKernel& pk = r.pre_kernels[pi];
+            if (pk.early_after_segment != (int32_t)si || pk.before_segment <= si) continue;
+            hipEvent_t e0 = sync_event();
+            HIP_TRY(hipEventRecord(e0, sa));
+            HIP_TRY(hipStreamWaitEvent(sc, e0, 0));
+            int prc = h2e_engine_predict(fp, &pk.k, p->d_pre_args, p->d_params, p->d_aux, p->d_inst, n_instances,
+                                         ctx->d_fc[fp], sc);
+            if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
+            hipEvent_t e1 = sync_event();
+            HIP_TRY(hipEventRecord(e1, sc));
+            early_done[pi] = e1;
         }
         H2ELaunch L;
         L.tape = p->d_tape + s.tape_begin;

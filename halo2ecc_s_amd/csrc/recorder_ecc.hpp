@@ -533,6 +533,7 @@ struct NativeScalarEccContext {
             push_point_refs(c.pre_args, rand_line_point_neg);
             c.pre_args.push_back(win_jac);
             pk.before_segment = (uint32_t)c.segments.size() - 1;
+            pk.early_after_segment = (int32_t)win_seg_index;
             c.pre_kernels.push_back(pk);
             c.begin_hints(c.n_hint_slots);
             c.n_hint_slots += pk.k.hints_per_lane;
