@@ -859,22 +859,26 @@ WI_INLINE Fe vc_ld_fe(VCache<FP>* vc, const LC& c, u32 ref) {
 // result of a "mul-like" op: limbs are range acc cells, native a base cell
 template <class FP>
 WI_INLINE void v_result_mul(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 rel, const Limb* l, const Fe& native) {
+    if (!(op.flags & H2E_FLAG_LOCAL_RESULT)) {
 #pragma unroll
-    for (int i = 0; i < FP::L; i++) stR(c, op.range_row + 3 * i, 0, fe_of(l[i]));
-    stB(c, op.base_row, 4, native);
+        for (int i = 0; i < FP::L; i++) stR(c, op.range_row + 3 * i, 0, fe_of(l[i]));
+        stB(c, op.base_row, 4, native);
+    }
     vc_put_int<FP>(vc, H2E_MAKE_REF(1, 0, rel, op.range_row), l, native);
 }
 // result of an "add-like" op: limb i in (base_row + i, col 4), native in (base_row + L, col 4)
 template <class FP>
 WI_INLINE void v_result_add(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 rel, const Limb* l, const Fe& native) {
+    if (!(op.flags & H2E_FLAG_LOCAL_RESULT)) {
 #pragma unroll
-    for (int i = 0; i < FP::L; i++) stB(c, op.base_row + i, 4, fe_of(l[i]));
-    stB(c, op.base_row + FP::L, 4, native);
+        for (int i = 0; i < FP::L; i++) stB(c, op.base_row + i, 4, fe_of(l[i]));
+        stB(c, op.base_row + FP::L, 4, native);
+    }
     vc_put_int<FP>(vc, H2E_MAKE_REF(0, 4, rel, op.base_row), l, native);
 }
 template <class FP>
-WI_INLINE void v_result_fe(VCache<FP>* vc, const LC& c, u32 row, int col, u32 rel, const Fe& v) {
-    stB(c, row, col, v);
+WI_INLINE void v_result_fe(VCache<FP>* vc, const LC& c, u32 row, int col, u32 rel, const Fe& v, bool local = false) {
+    if (!local) stB(c, row, col, v);
     vc_put_fe<FP>(vc, H2E_MAKE_REF(0, col, rel, row), v);
 }
 
@@ -943,7 +947,8 @@ WI_INLINE void exec_op_values(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 
             bool is_w = wd_eq<4>(a.native, wd_load<4>(c.fc->w_native));
 #pragma unroll
             for (int i = 0; i < FP::PW; i++) is_w = is_w && wd_eq<2>(a.l[i], wd_load<2>(c.fc->w_limbs[i]));
-            v_result_fe<FP>(vc, c, op.base_row + 6 + 4 * FP::PW, 4, rel, fe_u64((all_zero || is_w) ? 1 : 0));
+            v_result_fe<FP>(vc, c, op.base_row + 6 + 4 * FP::PW, 4, rel, fe_u64((all_zero || is_w) ? 1 : 0),
+                            (op.flags & H2E_FLAG_LOCAL_RESULT) != 0);
         } break;
         case H2E_OP_INT_ADD: {
             IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs), b = vc_ld_int<FP>(vc, c, op.refs + L + 1);
@@ -994,7 +999,7 @@ WI_INLINE void exec_op_values(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 
         } break;
         case H2E_OP_NOT: {
             Fe x = vc_ld_fe<FP>(vc, c, op.refs[0]);
-            v_result_fe<FP>(vc, c, op.base_row, 4, rel, submod_n(c, fe_u64(1), x));
+            v_result_fe<FP>(vc, c, op.base_row, 4, rel, submod_n(c, fe_u64(1), x), (op.flags & H2E_FLAG_LOCAL_RESULT) != 0);
         } break;
         case H2E_OP_AND:
         case H2E_OP_OR:

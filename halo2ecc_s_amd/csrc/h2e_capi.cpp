@@ -1,6 +1,7 @@
 // C ABI of the witness engine (include/h2e.h): program recording (host) + execution (HIP).
 #include <hip/hip_runtime.h>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -80,9 +81,155 @@ struct h2e_program {
             (void)hipFree(d_inst);
         }
     }
+    // Liveness over sub-ranges: an arithmetic op whose result cells are only read by ops of its own sub-range gets
+    // H2E_FLAG_LOCAL_RESULT, so the values-only replay keeps that result in LDS and does not store it (the full
+    // expansion of the sub-range recomputes and stores it anyway).  Row ownership: an op owns the rows from its
+    // first row up to the next op's first row.  Every reference that can reach a cut segment is considered: op
+    // refs of all segments, candidate tables (aux), strand parameters and the program's outputs.
+    void mark_local_results() {
+        h2e::Recorder& r = *rec;
+        // a sub-range's integer results must all fit the replay's LDS ring (VCache::R in engine.hip)
+        const uint32_t ring = r.fp.limbs == 3 ? 20 : 16;
+        auto puts = [](const H2EOp& op) -> uint32_t {
+            switch (op.opcode) {
+                case H2E_OP_SELECT_POINT: return 2;
+                case H2E_OP_INT_ADD: case H2E_OP_INT_SUB: case H2E_OP_INT_NEG: case H2E_OP_INT_MUL_SMALL: case H2E_OP_INT_MUL:
+                case H2E_OP_REDUCE: case H2E_OP_DIV_CORE: case H2E_OP_MASK_INT: case H2E_OP_BISEC_INT: return 1;
+                default: return 0;
+            }
+        };
+        struct CutSeg {
+            const h2e::Segment* sg;
+            H2EOp* ops;
+            uint32_t n_ops;
+            std::vector<uint32_t> sub_of;
+            std::vector<uint8_t> escapes;
+            uint32_t first[3], last[3];
+        };
+        std::vector<CutSeg> cs;
+        for (auto& sg : r.segments) {
+            uint32_t n_ops = sg.tape_end - sg.tape_begin;
+            if (sg.n_cuts == 0 || n_ops == 0) continue;
+            CutSeg c;
+            c.sg = &sg;
+            c.ops = r.tape.data() + sg.tape_begin;
+            c.n_ops = n_ops;
+            std::vector<uint32_t> bounds;
+            uint32_t lastb = 0;
+            for (uint32_t k = 0; k < sg.n_cuts; k++) {
+                uint32_t at = r.cuts[sg.cuts_begin + k];
+                if (at > lastb && at < n_ops) {
+                    bounds.push_back(at);
+                    lastb = at;
+                }
+            }
+            bounds.push_back(n_ops);
+            bool ok = true;
+            uint32_t prev = 0;
+            for (uint32_t bnd : bounds) {
+                uint32_t np = 0, nsingle = 0;
+                for (uint32_t i = prev; i < bnd; i++) {
+                    np += puts(c.ops[i]);
+                    uint16_t oc = c.ops[i].opcode;
+                    if (oc == H2E_OP_IS_INT_ZERO || oc == H2E_OP_NOT || oc == H2E_OP_AND || oc == H2E_OP_OR || oc == H2E_OP_XNOR ||
+                        oc == H2E_OP_PICK_INDEX)
+                        nsingle++;
+                }
+                if (np > ring || nsingle > 8) ok = false;
+                prev = bnd;
+            }
+            if (!ok) continue;  // too many results per sub-range: every result stays stored
+            c.sub_of.assign(n_ops, 0);
+            uint32_t sub = 0;
+            for (uint32_t i = 0; i < n_ops; i++) {
+                while (i >= bounds[sub]) sub++;
+                c.sub_of[i] = sub;
+            }
+            c.escapes.assign(n_ops, 0);
+            for (int reg = 0; reg < 3; reg++) {
+                auto row_of = [&](uint32_t i) { return reg == 0 ? c.ops[i].base_row : reg == 1 ? c.ops[i].range_row : c.ops[i].select_row; };
+                c.first[reg] = row_of(0);
+                c.last[reg] = row_of(n_ops - 1) + 256;  // the last op writes < 256 rows
+            }
+            cs.push_back(std::move(c));
+        }
+        if (cs.empty()) return;
+        // producer of a row (strand-relative row for forks, absolute row for the main context) inside a cut segment
+        auto producer = [&](const CutSeg& c, uint32_t region, uint32_t row) -> int {
+            int lo = 0, hi = (int)c.n_ops - 1, ans = -1;
+            while (lo <= hi) {
+                int mid = (lo + hi) / 2;
+                uint32_t first = region == 0 ? c.ops[mid].base_row : region == 1 ? c.ops[mid].range_row : c.ops[mid].select_row;
+                if (first <= row) {
+                    ans = mid;
+                    lo = mid + 1;
+                } else {
+                    hi = mid - 1;
+                }
+            }
+            return ans;
+        };
+        // an absolute reference from anywhere
+        auto quote_abs = [&](uint32_t ref) {
+            if (ref == H2E_NO_REF || H2E_REF_REGION(ref) == H2E_REGION_PARAM || H2E_REF_REL(ref)) return;
+            uint32_t region = H2E_REF_REGION(ref), row = H2E_REF_ROW(ref);
+            for (auto& c : cs) {
+                const h2e::Segment& sg = *c.sg;
+                if (sg.is_fork) {
+                    uint32_t b0 = region == 0 ? sg.base0 : region == 1 ? sg.range0 : sg.select0;
+                    uint32_t d = region == 0 ? sg.dbase : region == 1 ? sg.drange : sg.dselect;
+                    if (d == 0 || row < b0 || row >= b0 + (uint64_t)d * sg.n_strands) continue;
+                    int pidx = producer(c, region, (row - b0) % d);
+                    if (pidx >= 0) c.escapes[pidx] = 1;
+                } else {
+                    if (row < c.first[region] || row >= c.last[region]) continue;
+                    int pidx = producer(c, region, row);
+                    if (pidx >= 0) c.escapes[pidx] = 1;  // refined below for same-segment consumers
+                }
+            }
+        };
+        // 1. consumers inside the same segment (same addressing mode): only a different sub-range makes it escape
+        for (auto& c : cs) {
+            uint32_t rel = c.sg->is_fork ? 1 : 0;
+            for (uint32_t i = 0; i < c.n_ops; i++)
+                for (int k = 0; k < H2E_OP_MAX_REFS; k++) {
+                    uint32_t ref = c.ops[i].refs[k];
+                    if (ref == H2E_NO_REF || H2E_REF_REGION(ref) == H2E_REGION_PARAM) continue;
+                    if (H2E_REF_REL(ref) != rel) continue;
+                    uint32_t region = H2E_REF_REGION(ref), row = H2E_REF_ROW(ref);
+                    if (!rel && (row < c.first[region] || row >= c.last[region])) continue;
+                    int pidx = producer(c, region, row);
+                    if (pidx >= 0 && c.sub_of[pidx] != c.sub_of[i]) c.escapes[pidx] = 1;
+                }
+        }
+        // 2. every absolute reference from other places
+        for (auto& sg : r.segments) {
+            bool is_cut_main = false;
+            for (auto& c : cs)
+                if (c.sg == &sg && !sg.is_fork) is_cut_main = true;
+            if (is_cut_main) continue;  // its own absolute refs were handled in step 1
+            for (uint32_t i = sg.tape_begin; i < sg.tape_end; i++)
+                for (int k = 0; k < H2E_OP_MAX_REFS; k++) quote_abs(r.tape[i].refs[k]);
+        }
+        for (uint32_t ref : r.aux) quote_abs(ref);
+        for (uint32_t ref : r.params) quote_abs(ref);
+        for (uint32_t ref : r.outputs) quote_abs(ref);
+        for (uint32_t ref : r.pre_args) quote_abs(ref);  // (small integers in there never alias region/row of a cut segment)
+        // 3. flag
+        for (auto& c : cs)
+            for (uint32_t i = 0; i < c.n_ops; i++) {
+                uint16_t oc = c.ops[i].opcode;
+                bool arithmetic = oc == H2E_OP_INT_ADD || oc == H2E_OP_INT_SUB || oc == H2E_OP_INT_NEG || oc == H2E_OP_INT_MUL_SMALL ||
+                                  oc == H2E_OP_INT_MUL || oc == H2E_OP_REDUCE || oc == H2E_OP_DIV_CORE || oc == H2E_OP_MASK_INT ||
+                                  oc == H2E_OP_IS_INT_ZERO || oc == H2E_OP_NOT;
+                if (arithmetic && !c.escapes[i]) c.ops[i].flags |= H2E_FLAG_LOCAL_RESULT;
+            }
+    }
+
     void finish() {
         h2e::Recorder& r = *rec;
         r.close_segment();
+        mark_local_results();
         base_rows = std::max<uint64_t>(r.base_height, r.base_offset) + 1;
         range_rows = std::max<uint64_t>(r.range_height, r.range_offset) + 1;
         select_rows = std::max<uint64_t>(r.select_height, r.select_offset) + 1;

@@ -72,6 +72,8 @@ enum H2EOpcode {
 #define H2E_FLAG_UNSAFE_DBL 4u      // ASSERT_CONST failure reports RETRY_ADD_IDENTITY
 #define H2E_FLAG_HINTED 8u          // DIV_CORE: quotient c = a/b comes from the hint buffer, slot = imm (+ strand*hint_stride)
 #define H2E_FLAG_HINT_STRIDED 16u
+#define H2E_FLAG_LOCAL_RESULT 32u   // the result is only read inside the op's own sub-range: the values-only replay
+                                    // keeps it in LDS and does not store it (set by the recorder's liveness pass)
 
 #define H2E_OP_MAX_REFS 11
 typedef struct H2EOp {
