@@ -7,20 +7,24 @@
 // exactly the rows the reference's forked context would have written (src/context.rs:610-632,
 // 803-815, 722-735).  Operands are read back from those arrays through cell references.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "tape.h"
 #include "wide_int.h"
 
 // ------------------------------------------------------------------------------------------------
 // field-pair traits (compile-time sizes; values come from H2EFieldConsts)
 struct FP_BN256_FQ {   // bn256 Fq over bn256 Fr
+    static constexpr int ID = 0;
     static constexpr int L = 3, WW = 4, K = 254, CEIL = 254, MC = 3, RC = 1, PW = 1;
     static constexpr int NSUB = 1;   // a canonical W value is < 2n: "mod n" is one conditional subtraction
 };
 struct FP_BLS_FQ {     // bls12_381 Fq over bn256 Fr
+    static constexpr int ID = 1;
     static constexpr int L = 4, WW = 6, K = 381, CEIL = 381, MC = 5, RC = 2, PW = 2;
     static constexpr int NSUB = 0;   // needs a real reduction
 };
 struct FP_BLS_FR {     // bls12_381 Fr over bn256 Fr
+    static constexpr int ID = 2;
     static constexpr int L = 3, WW = 4, K = 255, CEIL = 255, MC = 3, RC = 1, PW = 1;
     static constexpr int NSUB = 2;   // bls12_381 r < 3n
 };
@@ -32,6 +36,12 @@ struct FPX {
     static constexpr int AW = (FP::CEIL + 6 + 63) / 64;   // words of a composed operand (< 2^(CEIL+6))
 };
 static constexpr int NK = 254;  // bit length of bn256 Fr modulus
+
+// Field-pair constants live in constant memory: every access has a wave-uniform address, so the compiler emits
+// scalar loads (s_load through the scalar cache into SGPRs) instead of per-lane global loads.  With a plain
+// device pointer each modulus / Barrett / ceil-table word was a dependent VMEM round trip: ~90 of them per
+// ecc_add_unsafe in the value chain (PMC: 47 % of that kernel's cycles in s_waitcnt).
+__constant__ H2EFieldConsts g_fc[3];
 
 typedef Wd<2> Limb;   // <= 114 bit
 typedef Wd<4> Fe;     // canonical bn256-Fr value
@@ -1165,7 +1175,7 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     c.params = L.params + (size_t)strand * L.n_params;
     c.aux = L.aux;
     c.pool = L.const_pool;
-    c.fc = fc;
+    c.fc = &g_fc[FP::ID];   // constant address space -> scalar loads (the `fc` argument serves the other kernels)
     c.strand = strand;
     c.input_stride = L.input_stride;
     c.hints = d.hints;
@@ -1340,48 +1350,65 @@ template <int N>
 struct Jac {
     Wd<N> x, y, z;
 };
+// The predictors' chains are single waves that run next to the bandwidth-bound expansion of an earlier segment.
+// With every field multiplication inlined one loop iteration is ~260 KB of straight-line code that streams
+// through the instruction cache from L2 - fine alone, 3.5x slower once L2 is saturated by the other kernel.
+// A called multiplication keeps the loop inside the instruction cache.
+template <class FP>
+struct MontW : Mont<FP::WW> {};
+template <class FP>
+__device__ __attribute__((noinline)) Wd<FP::WW> mont_mul_w(Wd<FP::WW> a, Wd<FP::WW> b) {
+    Mont<FP::WW> M;
+    M.p = wd_load<FP::WW>(g_fc[FP::ID].w);
+    M.minv = g_fc[FP::ID].w_minv;
+    return mont_mul<FP::WW>(M, a, b);
+}
 template <int N>
-WI_INLINE Jac<N> jac_dbl(const Mont<N>& M, const Jac<N>& p, Wd<N>& num) {  // num = 3 X^2 ; denominator = result z = 2 Y Z
-    Wd<N> a = mont_mul<N>(M, p.x, p.x), b = mont_mul<N>(M, p.y, p.y), cc = mont_mul<N>(M, b, b);
+WI_INLINE Wd<N> mm(const Mont<N>& M, const Wd<N>& a, const Wd<N>& b) { return mont_mul<N>(M, a, b); }
+template <class FP>
+WI_INLINE Wd<FP::WW> mm(const MontW<FP>& M, const Wd<FP::WW>& a, const Wd<FP::WW>& b) { return mont_mul_w<FP>(a, b); }
+template <class MT, int N>
+WI_INLINE Jac<N> jac_dbl(const MT& M, const Jac<N>& p, Wd<N>& num) {  // num = 3 X^2 ; denominator = result z = 2 Y Z
+    Wd<N> a = mm(M, p.x, p.x), b = mm(M, p.y, p.y), cc = mm(M, b, b);
     Wd<N> xb = mont_add<N>(M, p.x, b);
-    Wd<N> d = mont_dbl<N>(M, mont_sub<N>(M, mont_sub<N>(M, mont_mul<N>(M, xb, xb), a), cc));
+    Wd<N> d = mont_dbl<N>(M, mont_sub<N>(M, mont_sub<N>(M, mm(M, xb, xb), a), cc));
     Wd<N> e = mont_add<N>(M, mont_dbl<N>(M, a), a);
-    Wd<N> f = mont_mul<N>(M, e, e);
+    Wd<N> f = mm(M, e, e);
     Jac<N> r;
     r.x = mont_sub<N>(M, f, mont_dbl<N>(M, d));
     Wd<N> c8 = mont_dbl<N>(M, mont_dbl<N>(M, mont_dbl<N>(M, cc)));
-    r.y = mont_sub<N>(M, mont_mul<N>(M, e, mont_sub<N>(M, d, r.x)), c8);
-    r.z = mont_dbl<N>(M, mont_mul<N>(M, p.y, p.z));
+    r.y = mont_sub<N>(M, mm(M, e, mont_sub<N>(M, d, r.x)), c8);
+    r.z = mont_dbl<N>(M, mm(M, p.y, p.z));
     num = e;
     return r;
 }
 // p (Jacobian) + q (affine).  num = S2 - Y1 ; denominator = result z = Z1 * H   (lambda = num / z3 in either order)
-template <int N>
-WI_INLINE Jac<N> jac_madd(const Mont<N>& M, const Jac<N>& p, const Wd<N>& qx, const Wd<N>& qy, Wd<N>& num) {
-    Wd<N> z1z1 = mont_mul<N>(M, p.z, p.z);
-    Wd<N> u2 = mont_mul<N>(M, qx, z1z1);
-    Wd<N> s2 = mont_mul<N>(M, mont_mul<N>(M, qy, p.z), z1z1);
+template <class MT, int N>
+WI_INLINE Jac<N> jac_madd(const MT& M, const Jac<N>& p, const Wd<N>& qx, const Wd<N>& qy, Wd<N>& num) {
+    Wd<N> z1z1 = mm(M, p.z, p.z);
+    Wd<N> u2 = mm(M, qx, z1z1);
+    Wd<N> s2 = mm(M, mm(M, qy, p.z), z1z1);
     Wd<N> h = mont_sub<N>(M, u2, p.x), r = mont_sub<N>(M, s2, p.y);
-    Wd<N> hh = mont_mul<N>(M, h, h), hhh = mont_mul<N>(M, hh, h), v = mont_mul<N>(M, p.x, hh);
+    Wd<N> hh = mm(M, h, h), hhh = mm(M, hh, h), v = mm(M, p.x, hh);
     Jac<N> o;
-    o.x = mont_sub<N>(M, mont_sub<N>(M, mont_mul<N>(M, r, r), hhh), mont_dbl<N>(M, v));
-    o.y = mont_sub<N>(M, mont_mul<N>(M, r, mont_sub<N>(M, v, o.x)), mont_mul<N>(M, p.y, hhh));
-    o.z = mont_mul<N>(M, p.z, h);
+    o.x = mont_sub<N>(M, mont_sub<N>(M, mm(M, r, r), hhh), mont_dbl<N>(M, v));
+    o.y = mont_sub<N>(M, mm(M, r, mont_sub<N>(M, v, o.x)), mm(M, p.y, hhh));
+    o.z = mm(M, p.z, h);
     num = r;
     return o;
 }
 // p + q, both Jacobian.  num = S2 - S1 ; denominator = result z = Z1 Z2 H
-template <int N>
-WI_INLINE Jac<N> jac_add(const Mont<N>& M, const Jac<N>& p, const Jac<N>& q, Wd<N>& num) {
-    Wd<N> z1z1 = mont_mul<N>(M, p.z, p.z), z2z2 = mont_mul<N>(M, q.z, q.z);
-    Wd<N> u1 = mont_mul<N>(M, p.x, z2z2), u2 = mont_mul<N>(M, q.x, z1z1);
-    Wd<N> s1 = mont_mul<N>(M, mont_mul<N>(M, p.y, q.z), z2z2), s2 = mont_mul<N>(M, mont_mul<N>(M, q.y, p.z), z1z1);
+template <class MT, int N>
+WI_INLINE Jac<N> jac_add(const MT& M, const Jac<N>& p, const Jac<N>& q, Wd<N>& num) {
+    Wd<N> z1z1 = mm(M, p.z, p.z), z2z2 = mm(M, q.z, q.z);
+    Wd<N> u1 = mm(M, p.x, z2z2), u2 = mm(M, q.x, z1z1);
+    Wd<N> s1 = mm(M, mm(M, p.y, q.z), z2z2), s2 = mm(M, mm(M, q.y, p.z), z1z1);
     Wd<N> h = mont_sub<N>(M, u2, u1), r = mont_sub<N>(M, s2, s1);
-    Wd<N> hh = mont_mul<N>(M, h, h), hhh = mont_mul<N>(M, hh, h), v = mont_mul<N>(M, u1, hh);
+    Wd<N> hh = mm(M, h, h), hhh = mm(M, hh, h), v = mm(M, u1, hh);
     Jac<N> o;
-    o.x = mont_sub<N>(M, mont_sub<N>(M, mont_mul<N>(M, r, r), hhh), mont_dbl<N>(M, v));
-    o.y = mont_sub<N>(M, mont_mul<N>(M, r, mont_sub<N>(M, v, o.x)), mont_mul<N>(M, s1, hhh));
-    o.z = mont_mul<N>(M, mont_mul<N>(M, p.z, q.z), h);
+    o.x = mont_sub<N>(M, mont_sub<N>(M, mm(M, r, r), hhh), mont_dbl<N>(M, v));
+    o.y = mont_sub<N>(M, mm(M, r, mont_sub<N>(M, v, o.x)), mm(M, s1, hhh));
+    o.z = mm(M, mm(M, p.z, q.z), h);
     num = r;
     return o;
 }
@@ -1464,7 +1491,8 @@ __global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* arg
     v.nd = d.nd;
     v.jac = d.jac;
     const u32* a = args + K.args_begin;
-    Mont<NW> M = mont_w<FP>(fc);
+    MontW<FP> M;
+    (Mont<NW>&)M = mont_w<FP>(fc);
     u32 hint0 = K.hint_base + lane * K.hints_per_lane;
     if (K.kind == H2E_PRE_MSM_CANDIDATES) {
         // cl[i] = cl[i - lowbit(i)] + pts[ctz(i)]   (ecc_chip.rs:266-272), a = cl[other] Jacobian, b = pts affine
@@ -1492,7 +1520,7 @@ __global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* arg
                     qy = py[j];
                 }
             Wd<NW> num;
-            Jac<NW> r = jac_madd<NW>(M, p, qx, qy, num);
+            Jac<NW> r = jac_madd(M, p, qx, qy, num);
             st_nd<FP>(v, hint0 + i - 1, num, r.z);
             st_jac<FP>(v, j0 + i, r);
         }
@@ -1511,7 +1539,7 @@ __global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* arg
             const u32* tab = aux + tables[g] + idx * NR;
             Wd<NW> cx = ld_w_mont<FP>(v.c, M, tab), cy = ld_w_mont<FP>(v.c, M, tab + L + 1);
             Wd<NW> num;
-            acc = jac_madd<NW>(M, acc, cx, cy, num);
+            acc = jac_madd(M, acc, cx, cy, num);
             st_nd<FP>(v, hint0 + g, num, acc.z);
         }
         st_jac<FP>(v, K.scratch_begin + lane, acc);
@@ -1527,15 +1555,20 @@ __global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* arg
         acc.z = M.r1;
         Wd<NW> bx = ld_w_mont<FP>(v.c, M, neg_r2), by = ld_w_mont<FP>(v.c, M, neg_r2 + L + 1);
         u32 h = hint0;
+        // the next window's sum is fetched one iteration ahead (a dependent load on gfx9 also waits for every older
+        // store of the wave); the loop is kept rolled so that its code stays inside the instruction cache
+        Jac<NW> next = ld_jac<FP>(v, line0);
         for (u32 w = 0; w < windows; w++) {
+            Jac<NW> line = next;
+            next = ld_jac<FP>(v, line0 + min(w + 1, windows - 1));
+            asm volatile("" ::: "memory");
             Wd<NW> num;
-            acc = jac_dbl<NW>(M, acc, num);
+            acc = jac_dbl(M, acc, num);
             st_nd<FP>(v, h++, num, acc.z);
-            Jac<NW> line = ld_jac<FP>(v, line0 + w);
-            acc = jac_add<NW>(M, line, acc, num);
+            acc = jac_add(M, line, acc, num);
             st_nd<FP>(v, h++, num, acc.z);
             if (odd) {
-                acc = jac_madd<NW>(M, acc, bx, by, num);
+                acc = jac_madd(M, acc, bx, by, num);
                 st_nd<FP>(v, h++, num, acc.z);
             }
         }
@@ -1582,6 +1615,12 @@ __global__ void __launch_bounds__(64) h2e_finalize_hints(u32 hint_base, u32 n_hi
 
 // ------------------------------------------------------------------------------------------------
 // host-callable launcher (C linkage, used by the C-ABI layer in h2e_capi.cpp)
+extern "C" int h2e_engine_set_consts(int field_pair, const H2EFieldConsts* host) {
+    if (field_pair < 0 || field_pair > 2) return -1;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fc), host, sizeof(H2EFieldConsts), (size_t)field_pair * sizeof(H2EFieldConsts),
+                                  hipMemcpyHostToDevice);
+}
+
 // mode: 1 = values-only replay (whole tape per lane), 2 = full expansion (sub-ranges if any), 4 = inverse fix-up
 extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
                                  uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream) {
@@ -1591,9 +1630,12 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
     u32 n_sub = launch->n_sub > 1 ? launch->n_sub : 1;
     dim3 block(64), grid1(blocks_per_sub), grid(blocks_per_sub * n_sub);
     const InstanceDesc* inst = (const InstanceDesc*)instances;
+    // experiment knob: cap the expansion's waves per CU by padding its LDS footprint (H2E_X_LDS_PAD bytes)
+    static const size_t x_pad = getenv("H2E_X_LDS_PAD") ? (size_t)atol(getenv("H2E_X_LDS_PAD")) : 0;
+    size_t xlds = grid.x > 4096 ? x_pad : 0;
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
     if (mode & 1) hipLaunchKernelGGL((h2e_run_tape<FP, true>), grid1, block, 0, stream, *launch, inst, n_instances, fc_dev); \
-    if (mode & 2) hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid, block, 0, stream, *launch, inst, n_instances, fc_dev);
+    if (mode & 2) hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid, block, xlds, stream, *launch, inst, n_instances, fc_dev);
     switch (field_pair) {
         case 0: { H2E_LAUNCH_FP(FP_BN256_FQ) } break;
         case 1: { H2E_LAUNCH_FP(FP_BLS_FQ) } break;

@@ -8,6 +8,7 @@
 #include "../../include/h2e.h"
 #include "recorder_pairing.hpp"
 
+extern "C" int h2e_engine_set_consts(int field_pair, const H2EFieldConsts* host);
 extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
                                  uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream);
 extern "C" int h2e_engine_predict(int field_pair, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,
@@ -103,7 +104,7 @@ struct h2e_program {
             H2EOp* ops;
             uint32_t n_ops;
             std::vector<uint32_t> sub_of;
-            std::vector<uint8_t> escapes;
+            std::vector<uint8_t> escapes, sub_fits;
             uint32_t first[3], last[3];
         };
         std::vector<CutSeg> cs;
@@ -124,7 +125,7 @@ struct h2e_program {
                 }
             }
             bounds.push_back(n_ops);
-            bool ok = true;
+            bool any = false;
             uint32_t prev = 0;
             for (uint32_t bnd : bounds) {
                 uint32_t np = 0, nsingle = 0;
@@ -135,10 +136,12 @@ struct h2e_program {
                         oc == H2E_OP_PICK_INDEX)
                         nsingle++;
                 }
-                if (np > ring || nsingle > 8) ok = false;
+                // too many results in a sub-range: all of its results stay stored
+                c.sub_fits.push_back(np <= ring && nsingle <= 8);
+                any = any || c.sub_fits.back();
                 prev = bnd;
             }
-            if (!ok) continue;  // too many results per sub-range: every result stays stored
+            if (!any) continue;
             c.sub_of.assign(n_ops, 0);
             uint32_t sub = 0;
             for (uint32_t i = 0; i < n_ops; i++) {
@@ -222,7 +225,7 @@ struct h2e_program {
                 bool arithmetic = oc == H2E_OP_INT_ADD || oc == H2E_OP_INT_SUB || oc == H2E_OP_INT_NEG || oc == H2E_OP_INT_MUL_SMALL ||
                                   oc == H2E_OP_INT_MUL || oc == H2E_OP_REDUCE || oc == H2E_OP_DIV_CORE || oc == H2E_OP_MASK_INT ||
                                   oc == H2E_OP_IS_INT_ZERO || oc == H2E_OP_NOT;
-                if (arithmetic && !c.escapes[i]) c.ops[i].flags |= H2E_FLAG_LOCAL_RESULT;
+                if (arithmetic && !c.escapes[i] && c.sub_fits[c.sub_of[i]]) c.ops[i].flags |= H2E_FLAG_LOCAL_RESULT;
             }
     }
 
@@ -530,6 +533,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
     if (!ctx->d_fc[fp]) {
         HIP_TRY(hipMalloc((void**)&ctx->d_fc[fp], sizeof(H2EFieldConsts)));
         HIP_TRY(hipMemcpy(ctx->d_fc[fp], &field_pair(fp).fc, sizeof(H2EFieldConsts), hipMemcpyHostToDevice));
+        HIP_TRY((hipError_t)h2e_engine_set_consts(fp, &field_pair(fp).fc));
     }
     h2e::Recorder& r = *p->rec;
     // instance descriptors
