@@ -494,6 +494,19 @@ WI_INLINE void op_int_mul_small(const LC& c, const H2EOp& op) {
     row_limbs<FP>(c, r + FP::L, s, mod_n<5>(c, wd_mul<4, 1>(a.native, k)));
 }
 
+// A hinted INT_MUL / REDUCE: the values-only replay took the result from the hint slot, so every later op was fed
+// that value; the expansion computes the real one and a difference must not go unnoticed.
+template <class FP>
+WI_INLINE u32 hint_slot_of(const LC& c, const H2EOp& op) {
+    return op.imm + ((op.flags & H2E_FLAG_HINT_STRIDED) ? c.strand * c.hint_stride : 0);
+}
+template <class FP>
+WI_INLINE void check_value_hint(const LC& c, const H2EOp& op, const Wd<FP::WW>& rem) {
+    if (op.flags & H2E_FLAG_HINTED) {
+        Wd<FP::WW> h = wd_load<FP::WW>(c.hints + (size_t)hint_slot_of<FP>(c, op) * H2E_W_WORDS_MAX);
+        if (!wd_eq<FP::WW>(h, rem)) flag(c, H2E_STATUS_ARITH);
+    }
+}
 template <class FP>
 WI_INLINE void op_int_mul(const LC& c, const H2EOp& op) {
     constexpr int L = FP::L;
@@ -503,6 +516,7 @@ WI_INLINE void op_int_mul(const LC& c, const H2EOp& op) {
     Wd<FPX<FP>::QW> dq;
     Wd<FP::WW> rem;
     divrem_w<FP>(c, X, dq, rem);
+    check_value_hint<FP>(c, op, rem);
     Limb rl[L], dl[L];
     split_limbs<FP>(rem, rl);
     split_limbs<FP>(dq, dl);
@@ -521,6 +535,7 @@ WI_INLINE void op_reduce(const LC& c, const H2EOp& op) {
     Wd<FP::WW> rem;
     u64 d;
     divrem_small<FP>(c, A, d, rem);
+    check_value_hint<FP>(c, op, rem);
     Limb rl[L];
     split_limbs<FP>(rem, rl);
     Fe rem_native = native_of_w<FP>(c, rem);
@@ -892,16 +907,49 @@ WI_INLINE void v_result_fe(VCache<FP>* vc, const LC& c, u32 row, int col, u32 re
     vc_put_fe<FP>(vc, H2E_MAKE_REF(0, col, rel, row), v);
 }
 
-// the next hinted division of a strand uses the next hint slot: fetch it one division ahead so the load is
-// long finished when it is needed (under a saturated memory system a dependent load costs ~10 us)
+// Hints are read in a dependent chain; under a saturated memory system such a load costs ~10-100 us.  The ops of
+// consecutive ecc ops read the same slots of consecutive 8-slot blocks (tape.h; blocks are 8-aligned), so whenever
+// one of the slots the replay needs (lambda^2, t2*lambda, c.x, c.y) is read, the load of the same slot of the
+// next block is issued into that slot's register set: it is long finished when the next ecc op asks for it.
 template <class FP>
 struct HintPrefetch {
-    u32 slot;
-    Wd<FP::WW> v;
+    static constexpr int E = 4;
+    u32 slot[E];
+    Wd<FP::WW> v[E];
 };
+template <class FP>
+WI_INLINE Wd<FP::WW> hint_value(const LC& c, HintPrefetch<FP>& hp, u32 slot) {
+    u32 k = slot & (H2E_ECC_HINT_SLOTS - 1);
+    int e = k == H2E_HINT_LAMBDA2 ? 0 : k == H2E_HINT_T2L ? 1 : k == H2E_HINT_XC ? 2 : k == H2E_HINT_YC ? 3 : -1;   // wave-uniform
+    Wd<FP::WW> r;
+    bool hit = false;
+#pragma unroll
+    for (int i = 0; i < HintPrefetch<FP>::E; i++)
+        if (i == e && hp.slot[i] == slot) {
+            r = hp.v[i];
+            hit = true;
+        }
+    if (!hit) r = wd_load<FP::WW>(c.hints + (size_t)slot * H2E_W_WORDS_MAX);
+#pragma unroll
+    for (int i = 0; i < HintPrefetch<FP>::E; i++)
+        if (i == e) {
+            hp.slot[i] = slot + H2E_ECC_HINT_SLOTS;
+            hp.v[i] = wd_load<FP::WW>(c.hints + (size_t)(slot + H2E_ECC_HINT_SLOTS) * H2E_W_WORDS_MAX);  // workspace has spare slots
+        }
+    return r;
+}
 template <class FP>
 WI_INLINE void exec_op_values(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 rel, HintPrefetch<FP>& hp) {
     constexpr int L = FP::L;
+    if (op.flags & H2E_FLAG_VALUES_SKIP) return;
+    if ((op.flags & H2E_FLAG_HINTED) && (op.opcode == H2E_OP_INT_MUL || op.opcode == H2E_OP_REDUCE || op.opcode == H2E_OP_DIV_CORE)) {
+        // the canonical result comes from the predictors (b == 0 in a division already gives the hint 0)
+        Wd<FP::WW> cv = hint_value<FP>(c, hp, hint_slot_of<FP>(c, op));
+        Limb cl[L];
+        split_limbs<FP>(cv, cl);
+        v_result_mul<FP>(vc, c, op, rel, cl, native_of_w<FP>(c, cv));
+        return;
+    }
     switch (op.opcode) {
         case H2E_OP_INT_MUL: {
             IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs), b = vc_ld_int<FP>(vc, c, op.refs + L + 1);
@@ -925,18 +973,7 @@ WI_INLINE void exec_op_values(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 
         case H2E_OP_DIV_CORE: {
             IntVal<FP> b = vc_ld_int<FP>(vc, c, op.refs);
             Wd<FP::WW> cv;
-            if (op.flags & H2E_FLAG_HINTED) {
-                u32 slot = op.imm + ((op.flags & H2E_FLAG_HINT_STRIDED) ? c.strand * c.hint_stride : 0);
-                cv = (slot == hp.slot) ? hp.v : wd_load<FP::WW>(c.hints + (size_t)slot * H2E_W_WORDS_MAX);
-                hp.slot = slot + 1;
-                hp.v = wd_load<FP::WW>(c.hints + (size_t)(slot + 1) * H2E_W_WORDS_MAX);  // workspace has one spare slot
-                // b is reduced: zero mod w iff all limbs are zero or it equals w
-                bool bz = true;
-#pragma unroll
-                for (int i = 0; i < L; i++) bz = bz && wd_is_zero<2>(b.l[i]);
-                Wd<FPX<FP>::AW> B = compose<FP, FPX<FP>::AW>(b.l);
-                if (bz || wd_eq<FPX<FP>::AW>(B, wd_resize<FPX<FP>::AW>(wd_load<FP::WW>(c.fc->w)))) cv = wd_zero<FP::WW>();
-            } else {
+            {
                 IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs + L + 1);
                 Wd<FPX<FP>::QW> q0;
                 Wd<FP::WW> a_red, b_red;
@@ -1190,8 +1227,11 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
         __shared__ VCache<FP> vcache;
         vc_init<FP>(&vcache);
         HintPrefetch<FP> hp;
-        hp.slot = 0xffffffffu;
-        hp.v = wd_zero<FP::WW>();
+#pragma unroll
+        for (int i = 0; i < HintPrefetch<FP>::E; i++) {
+            hp.slot[i] = 0xffffffffu;
+            hp.v[i] = wd_zero<FP::WW>();
+        }
         for (u32 i0 = op_lo; i0 < op_hi; i0 += 64) {
             load_chunk(&chunk, L.tape, i0, op_hi);
             u32 n = min(64u, op_hi - i0);
@@ -1435,6 +1475,14 @@ WI_INLINE void st_nd(const VC& v, u32 slot, const Wd<FP::WW>& num, const Wd<FP::
         p[H2E_W_WORDS_MAX + i] = den.v[i];
     }
 }
+// record of one ecc op of a fully hinted chain, kept in the nd area of the op's hint block: (numerator, z of the
+// result = denominator, Jacobian x, y of the result), Montgomery form
+template <class FP>
+WI_INLINE void st_rec(const VC& v, u32 block_slot, const Wd<FP::WW>& num, const Wd<FP::WW>& z, const Wd<FP::WW>& x,
+                      const Wd<FP::WW>& y) {
+    st_nd<FP>(v, block_slot, num, z);
+    st_nd<FP>(v, block_slot + 1, x, y);
+}
 template <class FP>
 WI_INLINE void st_jac(const VC& v, u32 slot, const Jac<FP::WW>& p) {
     u64* q = v.jac + (size_t)slot * 3 * H2E_W_WORDS_MAX;
@@ -1533,6 +1581,7 @@ __global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* arg
         acc.x = ld_w_mont<FP>(v.c, M, neg_r1);
         acc.y = ld_w_mont<FP>(v.c, M, neg_r1 + L + 1);
         acc.z = M.r1;
+        st_rec<FP>(v, hint0 + H2E_ECC_HINT_SLOTS * n_groups, acc.x, acc.z, acc.x, acc.y);   // the chain's initial point
         for (u32 g = 0; g < n_groups; g++) {
             u32 lo = g * group_size, hi = min(n_points, lo + group_size), idx = 0;
             for (u32 j = lo; j < hi; j++) idx |= (u32)(ld_limb(v.c, H2E_MAKE_REF(H2E_REGION_PARAM, 0, 0, j)).v[0] & 1) << (j - lo);
@@ -1540,7 +1589,7 @@ __global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* arg
             Wd<NW> cx = ld_w_mont<FP>(v.c, M, tab), cy = ld_w_mont<FP>(v.c, M, tab + L + 1);
             Wd<NW> num;
             acc = jac_madd(M, acc, cx, cy, num);
-            st_nd<FP>(v, hint0 + g, num, acc.z);
+            st_rec<FP>(v, hint0 + H2E_ECC_HINT_SLOTS * g, num, acc.z, acc.x, acc.y);
         }
         st_jac<FP>(v, K.scratch_begin + lane, acc);
     } else if (K.kind == H2E_PRE_MSM_TAIL) {
@@ -1557,6 +1606,7 @@ __global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* arg
         u32 h = hint0;
         // the next window's sum is fetched one iteration ahead (a dependent load on gfx9 also waits for every older
         // store of the wave); the loop is kept rolled so that its code stays inside the instruction cache
+        st_rec<FP>(v, hint0 + H2E_ECC_HINT_SLOTS * K.ecc_ops, acc.x, acc.z, acc.x, acc.y);   // the chain's initial point
         Jac<NW> next = ld_jac<FP>(v, line0);
         for (u32 w = 0; w < windows; w++) {
             Jac<NW> line = next;
@@ -1564,12 +1614,15 @@ __global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* arg
             asm volatile("" ::: "memory");
             Wd<NW> num;
             acc = jac_dbl(M, acc, num);
-            st_nd<FP>(v, h++, num, acc.z);
+            st_rec<FP>(v, h, num, acc.z, acc.x, acc.y);
+            h += H2E_ECC_HINT_SLOTS;
             acc = jac_add(M, line, acc, num);
-            st_nd<FP>(v, h++, num, acc.z);
+            st_rec<FP>(v, h, num, acc.z, acc.x, acc.y);
+            h += H2E_ECC_HINT_SLOTS;
             if (odd) {
                 acc = jac_madd(M, acc, bx, by, num);
-                st_nd<FP>(v, h++, num, acc.z);
+                st_rec<FP>(v, h, num, acc.z, acc.x, acc.y);
+                h += H2E_ECC_HINT_SLOTS;
             }
         }
     }
@@ -1610,6 +1663,93 @@ __global__ void __launch_bounds__(64) h2e_finalize_hints(u32 hint_base, u32 n_hi
         }
 #pragma unroll
         for (int i = 0; i < NW; i++) hp[i] = out.v[i];
+    }
+}
+
+// Full value hints of an MSM chain (tape.h): from the records the predictor left per ecc op - numerator of lambda
+// and the Jacobian result (X, Y, Z), Z being lambda's denominator - one batch inversion per ECC_CH ops gives every
+// affine intermediate point, and from those the canonical value of every mul-like result of the op.  Parallel over
+// (instance, chain, chunk): the chain itself was only walked by the predictor.
+static constexpr int ECC_CH = 32;
+template <class FP>
+__global__ void __launch_bounds__(64) h2e_finalize_ecc(H2EPreKernel K, const InstanceDesc* inst, u32 n_instances,
+                                                       const H2EFieldConsts* fc) {
+    constexpr int NW = FP::WW;
+    u32 chunks = (K.ecc_ops + ECC_CH - 1) / ECC_CH;
+    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_instances * K.n_lanes * chunks) return;
+    u32 chunk = gid % chunks, lane = (gid / chunks) % K.n_lanes, instance = gid / (chunks * K.n_lanes);
+    InstanceDesc d = inst[instance];
+    MontW<FP> M;
+    (Mont<NW>&)M = mont_w<FP>(fc);
+    u32 hint0 = K.hint_base + lane * K.hints_per_lane;
+    int lo = (int)(chunk * ECC_CH), hi = min(lo + ECC_CH, (int)K.ecc_ops);
+    // element e in [lo - 1, hi): e = -1 is the chain's initial point (block ecc_ops)
+    auto rec = [&](int e) -> u64* { return d.nd + (size_t)(hint0 + H2E_ECC_HINT_SLOTS * (e < 0 ? K.ecc_ops : (u32)e)) * 2 * H2E_W_WORDS_MAX; };
+    auto hint = [&](int e, u32 k) -> u64* { return d.hints + (size_t)(hint0 + H2E_ECC_HINT_SLOTS * (u32)e + k) * H2E_W_WORDS_MAX; };
+    Wd<NW> acc = M.r1;
+    for (int e = lo - 1; e < hi; e++) {
+        u64* r = rec(e);
+        Wd<NW> den = wd_load<NW>(r + H2E_W_WORDS_MAX);
+        // prefix product -> third pair of the block's nd area (element lo - 1 also belongs to the previous chunk's
+        // lane, which keeps its own prefix in the first half of that pair)
+        u64* pp = r + (e == lo - 1 ? 5 : 4) * H2E_W_WORDS_MAX;
+#pragma unroll
+        for (int i = 0; i < NW; i++) pp[i] = acc.v[i];
+        if (!wd_is_zero<NW>(den)) acc = mm(M, acc, den);
+    }
+    Wd<NW> ainv = mont_inv<NW>(M, acc);
+    Wd<NW> xn = wd_zero<NW>(), yn = xn, ln = xn;   // op e + 1: affine result and lambda
+    for (int e = hi - 1; e >= lo - 1; e--) {
+        const u64* r = rec(e);
+        Wd<NW> num = wd_load<NW>(r), den = wd_load<NW>(r + H2E_W_WORDS_MAX);
+        Wd<NW> X = wd_load<NW>(r + 2 * H2E_W_WORDS_MAX), Y = wd_load<NW>(r + 3 * H2E_W_WORDS_MAX);
+        Wd<NW> dinv = wd_zero<NW>();
+        if (!wd_is_zero<NW>(den)) {
+            dinv = mm(M, ainv, wd_load<NW>(r + (e == lo - 1 ? 5 : 4) * H2E_W_WORDS_MAX));
+            ainv = mm(M, ainv, den);
+        }
+        Wd<NW> zi2 = mm(M, dinv, dinv);
+        Wd<NW> xe = mm(M, X, zi2), ye = mm(M, Y, mm(M, zi2, dinv)), le = mm(M, num, dinv);
+        if (e < hi - 1) {
+            // op k = e + 1: c = (xn, yn), lambda = ln, prev = (xe, ye)
+            u32 k = (u32)(e + 1);
+            u32 kind = (K.pattern >> (2 * (k % K.pattern_len))) & 3u;
+            Wd<NW> l2 = mm(M, ln, ln);
+            Wd<NW> xa, aux0, aux1 = wd_zero<NW>();
+            if (kind == H2E_ECC_ADD_EXT_PREV) {
+                xa = mont_sub<NW>(M, mont_sub<NW>(M, l2, xn), xe);      // x_a = lambda^2 - x_c - x_b
+                aux0 = mont_sub<NW>(M, xa, xe);                        // x_a - x_b
+            } else if (kind == H2E_ECC_ADD_PREV_EXT) {
+                xa = xe;
+                Wd<NW> xb = mont_sub<NW>(M, mont_sub<NW>(M, l2, xn), xa);
+                aux0 = mont_sub<NW>(M, xa, xb);
+            } else {
+                xa = xe;
+                aux0 = mm(M, xa, xa);                                   // x_a^2
+                aux1 = mont_dbl<NW>(M, ye);                             // 2 y_a
+            }
+            Wd<NW> t2 = mont_sub<NW>(M, xa, xn);
+            Wd<NW> t2l = mm(M, t2, ln);
+            Wd<NW> one = wd_from_u64<NW>(1);
+            auto put = [&](u32 slot, const Wd<NW>& vm) {
+                Wd<NW> cv = mm(M, vm, one);   // out of the Montgomery domain: canonical
+                u64* hp = hint((int)k, slot);
+#pragma unroll
+                for (int i = 0; i < NW; i++) hp[i] = cv.v[i];
+            };
+            put(H2E_HINT_LAMBDA, ln);
+            put(H2E_HINT_LAMBDA2, l2);
+            put(H2E_HINT_XC, xn);
+            put(H2E_HINT_YC, yn);
+            put(H2E_HINT_T2L, t2l);
+            put(H2E_HINT_T2, t2);
+            put(H2E_HINT_AUX0, aux0);
+            put(H2E_HINT_AUX1, aux1);
+        }
+        xn = xe;
+        yn = ye;
+        ln = le;
     }
 }
 
@@ -1665,20 +1805,20 @@ extern "C" int h2e_engine_predict(int field_pair, const H2EPreKernel* k, const u
     u32 n_hints = k->n_lanes * k->hints_per_lane;
     u32 chunks = (n_hints + HINT_K - 1) / HINT_K;
     dim3 grid2((n_instances * chunks + 63) / 64);
+    u32 ecc_chunks = (k->ecc_ops + ECC_CH - 1) / ECC_CH;
+    dim3 grid3((n_instances * k->n_lanes * ecc_chunks + 63) / 64);
+#define H2E_PREDICT_FP(FP)                                                                                                          \
+    hipLaunchKernelGGL(h2e_predict<FP>, grid, block, lds_reserve, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev); \
+    if (k->ecc_ops)                                                                                                                 \
+        hipLaunchKernelGGL(h2e_finalize_ecc<FP>, grid3, block, 0, stream, *k, inst, n_instances, fc_dev);                           \
+    else                                                                                                                            \
+        hipLaunchKernelGGL(h2e_finalize_hints<FP>, grid2, block, 0, stream, k->hint_base, n_hints, inst, n_instances, fc_dev);
     switch (field_pair) {
-        case 0:
-            hipLaunchKernelGGL(h2e_predict<FP_BN256_FQ>, grid, block, lds_reserve, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev);
-            hipLaunchKernelGGL(h2e_finalize_hints<FP_BN256_FQ>, grid2, block, 0, stream, k->hint_base, n_hints, inst, n_instances, fc_dev);
-            break;
-        case 1:
-            hipLaunchKernelGGL(h2e_predict<FP_BLS_FQ>, grid, block, lds_reserve, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev);
-            hipLaunchKernelGGL(h2e_finalize_hints<FP_BLS_FQ>, grid2, block, 0, stream, k->hint_base, n_hints, inst, n_instances, fc_dev);
-            break;
-        case 2:
-            hipLaunchKernelGGL(h2e_predict<FP_BLS_FR>, grid, block, lds_reserve, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev);
-            hipLaunchKernelGGL(h2e_finalize_hints<FP_BLS_FR>, grid2, block, 0, stream, k->hint_base, n_hints, inst, n_instances, fc_dev);
-            break;
+        case 0: { H2E_PREDICT_FP(FP_BN256_FQ) } break;
+        case 1: { H2E_PREDICT_FP(FP_BLS_FQ) } break;
+        case 2: { H2E_PREDICT_FP(FP_BLS_FR) } break;
         default: return -1;
     }
+#undef H2E_PREDICT_FP
     return (int)hipGetLastError();
 }

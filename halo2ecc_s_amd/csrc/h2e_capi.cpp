@@ -219,14 +219,65 @@ struct h2e_program {
         for (uint32_t ref : r.outputs) quote_abs(ref);
         for (uint32_t ref : r.pre_args) quote_abs(ref);  // (small integers in there never alias region/row of a cut segment)
         // 3. flag
+        auto is_arithmetic = [](uint16_t oc) {
+            return oc == H2E_OP_INT_ADD || oc == H2E_OP_INT_SUB || oc == H2E_OP_INT_NEG || oc == H2E_OP_INT_MUL_SMALL ||
+                   oc == H2E_OP_INT_MUL || oc == H2E_OP_REDUCE || oc == H2E_OP_DIV_CORE || oc == H2E_OP_MASK_INT ||
+                   oc == H2E_OP_IS_INT_ZERO || oc == H2E_OP_NOT;
+        };
         for (auto& c : cs)
-            for (uint32_t i = 0; i < c.n_ops; i++) {
-                uint16_t oc = c.ops[i].opcode;
-                bool arithmetic = oc == H2E_OP_INT_ADD || oc == H2E_OP_INT_SUB || oc == H2E_OP_INT_NEG || oc == H2E_OP_INT_MUL_SMALL ||
-                                  oc == H2E_OP_INT_MUL || oc == H2E_OP_REDUCE || oc == H2E_OP_DIV_CORE || oc == H2E_OP_MASK_INT ||
-                                  oc == H2E_OP_IS_INT_ZERO || oc == H2E_OP_NOT;
-                if (arithmetic && !c.escapes[i] && c.sub_fits[c.sub_of[i]]) c.ops[i].flags |= H2E_FLAG_LOCAL_RESULT;
+            for (uint32_t i = 0; i < c.n_ops; i++)
+                if (is_arithmetic(c.ops[i].opcode) && !c.escapes[i] && c.sub_fits[c.sub_of[i]]) c.ops[i].flags |= H2E_FLAG_LOCAL_RESULT;
+        // 4. dead ops of the values-only replay: a local result that no op the replay has to execute reads.  What an
+        // op reads *in values mode* (exec_op_values): a hinted INT_MUL / REDUCE / DIV_CORE reads nothing.
+        const int L = r.fp.limbs;
+        for (auto& c : cs) {
+            uint32_t rel = c.sg->is_fork ? 1 : 0;
+            std::vector<uint8_t> used(c.n_ops, 0);
+            for (uint32_t i = c.n_ops; i-- > 0;) {
+                H2EOp& op = c.ops[i];
+                bool needed = !(op.flags & H2E_FLAG_LOCAL_RESULT) || used[i];
+                if (!needed) {
+                    op.flags |= H2E_FLAG_VALUES_SKIP;
+                    continue;
+                }
+                uint32_t reads[H2E_OP_MAX_REFS];
+                int nr = 0;
+                bool hinted = (op.flags & H2E_FLAG_HINTED) != 0;
+                switch (op.opcode) {
+                    case H2E_OP_INT_MUL:
+                        if (!hinted) { reads[nr++] = op.refs[0]; reads[nr++] = op.refs[L + 1]; }
+                        break;
+                    case H2E_OP_REDUCE:
+                        if (!hinted) reads[nr++] = op.refs[0];
+                        break;
+                    case H2E_OP_DIV_CORE:
+                        if (!hinted) { reads[nr++] = op.refs[0]; reads[nr++] = op.refs[L + 1]; }
+                        break;
+                    case H2E_OP_INT_ADD: case H2E_OP_INT_SUB:
+                        reads[nr++] = op.refs[0]; reads[nr++] = op.refs[L + 1];
+                        break;
+                    case H2E_OP_INT_NEG: case H2E_OP_INT_MUL_SMALL: case H2E_OP_IS_INT_ZERO:
+                        reads[nr++] = op.refs[0];
+                        break;
+                    case H2E_OP_MASK_INT:
+                        reads[nr++] = op.refs[0]; reads[nr++] = op.refs[L + 1];
+                        break;
+                    case H2E_OP_ASSERT_CONST: case H2E_OP_CACHE_INT: case H2E_OP_SUM_LIMBS:
+                        break;   // nothing in values mode
+                    default:     // everything else: every reference
+                        for (int k = 0; k < H2E_OP_MAX_REFS; k++) reads[nr++] = op.refs[k];
+                        break;
+                }
+                for (int k = 0; k < nr; k++) {
+                    uint32_t ref = reads[k];
+                    if (ref == H2E_NO_REF || H2E_REF_REGION(ref) == H2E_REGION_PARAM || H2E_REF_REL(ref) != rel) continue;
+                    uint32_t region = H2E_REF_REGION(ref), row = H2E_REF_ROW(ref);
+                    if (!rel && (row < c.first[region] || row >= c.last[region])) continue;
+                    int pidx = producer(c, region, row);
+                    if (pidx >= 0 && (uint32_t)pidx < i) used[pidx] = 1;
+                }
             }
+        }
     }
 
     void finish() {
@@ -557,7 +608,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         if (e == hipSuccess) *have = need;
         return e;
     };
-    size_t hint_words = ((size_t)r.n_hint_slots + 1) * H2E_W_WORDS_MAX,  // + 1: the replay prefetches slot + 1
+    size_t hint_words = ((size_t)r.n_hint_slots + H2E_ECC_HINT_SLOTS) * H2E_W_WORDS_MAX,  // spare: the replay prefetches slot + 8
            nd_words = hint_words * 2,
            jac_words = (size_t)r.n_jac_slots * 3 * H2E_W_WORDS_MAX;
     HIP_TRY(grow(&ctx->ws_hints, &ctx->ws_hints_words, std::max<size_t>(1, hint_words * n_instances)));

@@ -165,6 +165,10 @@ struct AssignedInteger {  // assign.rs:31-37
     uint32_t limbs_le[H2E_MAX_L] = {H2E_NO_REF, H2E_NO_REF, H2E_NO_REF, H2E_NO_REF};
     uint32_t native = H2E_NO_REF;
     uint64_t times = 1;
+    // value tag: hint slot that holds the canonical W value this integer is congruent to (H2E_NO_REF = unknown).
+    // A later reduce() of a tagged integer takes its result from that slot in the values-only replay.
+    uint32_t vtag = H2E_NO_REF;
+    bool vtag_strided = false;
 };
 
 enum Chip { BaseChip = 0, RangeChip = 1, SelectChip = 2 };
@@ -227,6 +231,12 @@ struct Recorder {
     // hinted-division state: while hint_on, every int_div takes its quotient from slot hint_base + hint_count++
     bool hint_on = false;
     uint32_t hint_base = 0, hint_count = 0;
+    // hint_mode 2 ("full value hints", MSM chains): every ecc op owns a block of H2E_ECC_HINT_SLOTS slots that the
+    // predictor + finalize kernels fill with the canonical value of every mul-like result of that op (tape.h);
+    // hint_count then counts blocks and block `n_blocks` of a strand holds the chain's initial point.
+    int hint_mode = 0;
+    uint32_t ecc_block = H2E_NO_REF;   // first slot of the current ecc op's block
+    uint32_t next_vtag = H2E_NO_REF;   // tag for the result of the next integer op
     uint32_t n_input_slots = 0;
     uint64_t seg_cells_start = 0;
     // ---- shape artefacts (Records minus advice values) ----
@@ -320,14 +330,30 @@ struct Recorder {
     size_t segments_cut_floor() const { return in_strand ? fork_cuts_begin : segments.back().cuts_begin; }
     uint32_t fork_cuts_begin = 0;
     // hinted divisions (quotients predicted by the V kernels): slots are consecutive in call order
-    void begin_hints(uint32_t base) {
+    void begin_hints(uint32_t base, int mode = 1) {
         hint_on = true;
+        hint_mode = mode;
         hint_base = base;
         hint_count = 0;
     }
     uint32_t end_hints() {
         hint_on = false;
+        hint_mode = 0;
+        ecc_block = next_vtag = H2E_NO_REF;
         return hint_count;
+    }
+    uint32_t hint_slots_used() const { return hint_mode == 2 ? H2E_ECC_HINT_SLOTS * (hint_count + 1) : hint_count; }
+    void begin_ecc_op() {
+        if (hint_on && hint_mode == 2) ecc_block = hint_base + H2E_ECC_HINT_SLOTS * hint_count++;
+    }
+    void end_ecc_op() { ecc_block = next_vtag = H2E_NO_REF; }
+    void expect(uint32_t k) {  // the next integer result is congruent to slot k of the current ecc block
+        if (ecc_block != H2E_NO_REF) next_vtag = ecc_block + k;
+    }
+    void take_vtag(AssignedInteger& r) {
+        r.vtag = next_vtag;
+        r.vtag_strided = in_strand;
+        next_vtag = H2E_NO_REF;
     }
 
     Offset offset() const {
@@ -377,7 +403,7 @@ struct Recorder {
                 delta.range_offset_diff = range_offset - r0;
                 delta.select_offset_diff = select_offset - s0;
                 strand_n_params = strand_param_cursor;
-                seg.hint_stride = hint_on ? hint_count : 0;
+                seg.hint_stride = hint_on ? hint_slots_used() : 0;
             } else {
                 Offset d;
                 d.base_offset_diff = base_offset - strand_off[0];
@@ -439,6 +465,7 @@ struct Recorder {
         AssignedInteger r = a;
         for (int i = 0; i < fp.limbs; i++) r.limbs_le[i] = strand_ref(a.limbs_le[i], seg, k);
         r.native = strand_ref(a.native, seg, k);
+        r.vtag = H2E_NO_REF;
         return r;
     }
 
@@ -830,9 +857,15 @@ struct Recorder {
         if (a.times == 1) return a;
         if (!(a.times < (uint64_t)OVERFLOW_LIMIT)) throw std::runtime_error("reduce: times >= overflow_limit");
         H2EOp op = new_op(H2E_OP_REDUCE);
+        if (a.vtag != H2E_NO_REF) {
+            op.flags |= H2E_FLAG_HINTED | (a.vtag_strided ? H2E_FLAG_HINT_STRIDED : 0);
+            op.imm = a.vtag;
+        }
         put_int(op, 0, a);
         push(op);
         AssignedInteger rem = shape_assigned(false);
+        rem.vtag = a.vtag;
+        rem.vtag_strided = a.vtag_strided;
         uint32_t d = assign_common();
         base_line({A(d, id_w_native), A(rem.native, id_one)}, A(a.native, id_neg_one));
         uint32_t last_v = H2E_NO_REF;
@@ -859,6 +892,7 @@ struct Recorder {
             r.limbs_le[i] = mk(0, 4, base_line({A(a.limbs_le[i], id_one), A(b.limbs_le[i], id_one)}, U(id_neg_one)));
         r.native = shape_native_row(r.limbs_le);
         r.times = a.times + b.times;
+        take_vtag(r);
         return conditionally_reduce(r);
     }
     AssignedInteger int_sub(const AssignedInteger& a, const AssignedInteger& b) {  // :408-437
@@ -873,6 +907,7 @@ struct Recorder {
                                                id_ceil[b.times][i]));
         r.native = shape_native_row(r.limbs_le);
         r.times = a.times + b.times + 1;
+        take_vtag(r);
         return conditionally_reduce(r);
     }
     AssignedInteger int_neg(const AssignedInteger& a) {  // :439-464
@@ -885,14 +920,20 @@ struct Recorder {
             r.limbs_le[i] = mk(0, 4, base_line({A(a.limbs_le[i], id_neg_one)}, U(id_neg_one), 0, 0, 0, id_ceil[a.times][i]));
         r.native = shape_native_row(r.limbs_le);
         r.times = a.times + 1;
+        take_vtag(r);
         return conditionally_reduce(r);
     }
     AssignedInteger int_mul(const AssignedInteger& a, const AssignedInteger& b) {  // :466-483
         H2EOp op = new_op(H2E_OP_INT_MUL);
+        if (next_vtag != H2E_NO_REF) {
+            op.flags |= H2E_FLAG_HINTED | (in_strand ? H2E_FLAG_HINT_STRIDED : 0);
+            op.imm = next_vtag;
+        }
         put_int(op, 0, a);
         put_int(op, fp.limbs + 1, b);
         push(op);
         AssignedInteger rem = shape_assigned(false);
+        take_vtag(rem);
         AssignedInteger d = shape_assigned(true);
         shape_mul_equation(a, b, d, rem);
         return rem;
@@ -909,6 +950,7 @@ struct Recorder {
         for (int i = 0; i < fp.limbs; i++) r.limbs_le[i] = mk(0, 4, base_line({A(a.limbs_le[i], id_small[b])}, U(id_neg_one)));
         r.native = shape_native_row(r.limbs_le);
         r.times = a.times * b;
+        take_vtag(r);
         return conditionally_reduce(r);
     }
     // invert rows (base_chip.rs:298-321): returns the condition cell (col 4 of the second row)
@@ -964,7 +1006,11 @@ struct Recorder {
             a.times = ar.times;
         }
         H2EOp op = new_op(H2E_OP_DIV_CORE);
-        if (hint_on) {
+        next_vtag = H2E_NO_REF;
+        if (hint_on && hint_mode == 2 && ecc_block != H2E_NO_REF) {
+            op.flags |= H2E_FLAG_HINTED | (in_strand ? H2E_FLAG_HINT_STRIDED : 0);
+            op.imm = ecc_block + H2E_HINT_LAMBDA;
+        } else if (hint_on && hint_mode == 1) {
             op.flags |= H2E_FLAG_HINTED | (in_strand ? H2E_FLAG_HINT_STRIDED : 0);
             op.imm = hint_base + hint_count++;
         }
@@ -972,6 +1018,10 @@ struct Recorder {
         put_int(op, fp.limbs + 1, a);
         push(op);
         AssignedInteger c = shape_assigned(false);
+        if (op.flags & H2E_FLAG_HINTED) {
+            c.vtag = op.imm;
+            c.vtag_strided = (op.flags & H2E_FLAG_HINT_STRIDED) != 0;
+        }
         AssignedInteger d = shape_assigned(true);
         shape_mul_equation(b, c, d, a);
         return std::make_pair(is_b_zero, c);

@@ -177,32 +177,47 @@ struct NativeScalarEccContext {
         assign_cache_integer(p.y, sc, g, i);
     }
     // ecc_chip.rs:814-838
+    // (the expect() calls name the hint slot of each result's value while full value hints are on: recorder.hpp)
     AssignedNonZeroPoint lambda_to_point_non_zero(const AssignedInteger& l, const AssignedNonZeroPoint& a,
                                                   const AssignedNonZeroPoint& b) {
+        ctx.expect(H2E_HINT_LAMBDA2);
         AssignedInteger l_square = ctx.int_square(l);
         AssignedInteger t = ctx.int_sub(l_square, a.x);
+        ctx.expect(H2E_HINT_XC);
         AssignedInteger cx = ctx.int_sub(t, b.x);
+        ctx.expect(H2E_HINT_T2);
         AssignedInteger t2 = ctx.int_sub(a.x, cx);
+        ctx.expect(H2E_HINT_T2L);
         t2 = ctx.int_mul(t2, l);
+        ctx.expect(H2E_HINT_YC);
         AssignedInteger cy = ctx.int_sub(t2, a.y);
         return AssignedNonZeroPoint{cx, cy};
     }
     // ecc_chip.rs:840-858 — a failing instance reports H2E_STATUS_RETRY_ADD_SAME_OR_NEG
     AssignedNonZeroPoint ecc_add_unsafe(const AssignedNonZeroPoint& a, const AssignedNonZeroPoint& b) {
+        ctx.begin_ecc_op();
+        ctx.expect(H2E_HINT_AUX0);
         AssignedInteger diff_x = ctx.int_sub(a.x, b.x);
         AssignedInteger diff_y = ctx.int_sub(a.y, b.y);
         auto dv = ctx.int_div(diff_y, diff_x);
         ctx.try_assert_false(dv.first, H2E_FLAG_UNSAFE_ADD);
-        return lambda_to_point_non_zero(dv.second, a, b);
+        AssignedNonZeroPoint r = lambda_to_point_non_zero(dv.second, a, b);
+        ctx.end_ecc_op();
+        return r;
     }
     // ecc_chip.rs:860-882 — a failing instance reports H2E_STATUS_RETRY_ADD_IDENTITY
     AssignedNonZeroPoint ecc_double_unsafe(const AssignedNonZeroPoint& a) {
+        ctx.begin_ecc_op();
+        ctx.expect(H2E_HINT_AUX0);
         AssignedInteger x_square = ctx.int_square(a.x);
         AssignedInteger numerator = ctx.int_mul_small_constant(x_square, 3);
+        ctx.expect(H2E_HINT_AUX1);
         AssignedInteger denominator = ctx.int_mul_small_constant(a.y, 2);
         auto zv = ctx.int_div(numerator, denominator);
         ctx.try_assert_false(zv.first, H2E_FLAG_UNSAFE_DBL);
-        return lambda_to_point_non_zero(zv.second, a, a);
+        AssignedNonZeroPoint r = lambda_to_point_non_zero(zv.second, a, a);
+        ctx.end_ecc_op();
+        return r;
     }
     AssignedNonZeroPoint ecc_neg_non_zero(const AssignedNonZeroPoint& a) {  // :884-889
         return AssignedNonZeroPoint{a.x, ctx.int_neg(a.y)};
@@ -479,12 +494,15 @@ struct NativeScalarEccContext {
 
         // windows (ecc_chip.rs:289-352): predict_ops + clones == strands 0..windows-1
         AssignedNonZeroPoint line_acc0;
+        // full value hints: a block of 8 slots per ecc_add_unsafe + one block for the chain's initial point
+        const uint32_t win_hints_per_lane = H2E_ECC_HINT_SLOTS * ((uint32_t)n_groups + 1);
+        c.n_hint_slots = (c.n_hint_slots + H2E_ECC_HINT_SLOTS - 1) / H2E_ECC_HINT_SLOTS * H2E_ECC_HINT_SLOTS;   // blocks are 8-aligned
         uint32_t win_hbase = c.n_hint_slots;
-        c.n_hint_slots += (uint32_t)(windows * n_groups);
+        c.n_hint_slots += (uint32_t)windows * win_hints_per_lane;
         uint32_t win_seg_index = (uint32_t)c.segments.size();
         uint32_t win_jac = c.n_jac_slots;
         c.n_jac_slots += (uint32_t)windows;
-        c.begin_hints(win_hbase);
+        c.begin_hints(win_hbase, 2);
         c.fork((uint32_t)windows, 0, [&](uint32_t wi) {
             AssignedNonZeroPoint acc = rand_acc_point_neg;
             for (size_t group_index = 0; group_index < n_groups; group_index++) {
@@ -506,7 +524,10 @@ struct NativeScalarEccContext {
             pk.k.kind = H2E_PRE_MSM_WINDOWS;
             pk.k.n_lanes = (uint32_t)windows;
             pk.k.hint_base = win_hbase;
-            pk.k.hints_per_lane = (uint32_t)n_groups;
+            pk.k.hints_per_lane = win_hints_per_lane;
+            pk.k.ecc_ops = (uint32_t)n_groups;
+            pk.k.pattern_len = 1;
+            pk.k.pattern = H2E_ECC_ADD_EXT_PREV;
             pk.k.args_begin = (uint32_t)c.pre_args.size();
             c.pre_args.push_back((uint32_t)n_groups);
             c.pre_args.push_back((uint32_t)group_size);
@@ -525,7 +546,10 @@ struct NativeScalarEccContext {
             pk.k.kind = H2E_PRE_MSM_TAIL;
             pk.k.n_lanes = 1;
             pk.k.hint_base = c.n_hint_slots;
-            pk.k.hints_per_lane = (uint32_t)(windows * (2 + (n_groups % 2)));
+            pk.k.ecc_ops = (uint32_t)(windows * (2 + (n_groups % 2)));
+            pk.k.hints_per_lane = H2E_ECC_HINT_SLOTS * (pk.k.ecc_ops + 1);
+            pk.k.pattern_len = 2 + (uint32_t)(n_groups % 2);
+            pk.k.pattern = H2E_ECC_DBL | (H2E_ECC_ADD_EXT_PREV << 2) | (H2E_ECC_ADD_PREV_EXT << 4);
             pk.k.args_begin = (uint32_t)c.pre_args.size();
             c.pre_args.push_back((uint32_t)windows);
             c.pre_args.push_back((uint32_t)(n_groups % 2));
@@ -535,7 +559,7 @@ struct NativeScalarEccContext {
             pk.before_segment = (uint32_t)c.segments.size() - 1;
             pk.early_after_segment = (int32_t)win_seg_index;
             c.pre_kernels.push_back(pk);
-            c.begin_hints(c.n_hint_slots);
+            c.begin_hints(c.n_hint_slots, 2);
             c.n_hint_slots += pk.k.hints_per_lane;
         }
 

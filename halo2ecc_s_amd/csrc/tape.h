@@ -71,9 +71,29 @@ enum H2EOpcode {
 #define H2E_FLAG_UNSAFE_ADD 2u      // ASSERT_CONST failure reports RETRY_ADD_SAME_OR_NEG
 #define H2E_FLAG_UNSAFE_DBL 4u      // ASSERT_CONST failure reports RETRY_ADD_IDENTITY
 #define H2E_FLAG_HINTED 8u          // DIV_CORE: quotient c = a/b comes from the hint buffer, slot = imm (+ strand*hint_stride)
+                                    // INT_MUL / REDUCE: the values-only replay takes the (canonical) result from that
+                                    // slot; the full expansion computes it and checks the hint (H2E_STATUS_ARITH)
 #define H2E_FLAG_HINT_STRIDED 16u
 #define H2E_FLAG_LOCAL_RESULT 32u   // the result is only read inside the op's own sub-range: the values-only replay
                                     // keeps it in LDS and does not store it (set by the recorder's liveness pass)
+
+#define H2E_FLAG_VALUES_SKIP 64u    // nothing the values-only replay has to produce depends on this op (host DCE pass)
+
+// "full value hints" of an MSM chain: every ecc_add_unsafe / ecc_double_unsafe owns a block of 8 hint slots with the
+// canonical W value of each mul-like result of src/circuit/ecc_chip.rs:814-882 (a = first argument, c = result):
+#define H2E_ECC_HINT_SLOTS 8u
+#define H2E_HINT_LAMBDA 0u    // int_div quotient
+#define H2E_HINT_LAMBDA2 1u   // int_square(lambda)
+#define H2E_HINT_XC 2u        // c.x   (a later reduce of cx)
+#define H2E_HINT_YC 3u        // c.y
+#define H2E_HINT_T2L 4u       // (a.x - c.x) * lambda
+#define H2E_HINT_T2 5u        // a.x - c.x
+#define H2E_HINT_AUX0 6u      // add: a.x - b.x (reduce inside int_div)   double: a.x^2
+#define H2E_HINT_AUX1 7u      // double: 2 a.y ; scratch of the finalize kernel otherwise
+// ecc op kinds of a chain (2 bits each in H2EPreKernel.pattern), "prev" = the previous result of the chain
+#define H2E_ECC_DBL 0u            // a = b = prev
+#define H2E_ECC_ADD_EXT_PREV 1u   // a = external point, b = prev
+#define H2E_ECC_ADD_PREV_EXT 2u   // a = prev, b = external point
 
 #define H2E_OP_MAX_REFS 11
 typedef struct H2EOp {
@@ -153,4 +173,9 @@ typedef struct H2EPreKernel {
     uint32_t n_params;       // parameter refs per lane (reuses the X segment's parameter table)
     uint32_t params_begin;
     uint32_t scratch_begin;  // per-instance Jacobian scratch: first slot (96-byte slots)
+    // full value hints (0 = quotient hints only): ecc ops per lane, hints_per_lane = 8 * (ecc_ops + 1); the op kinds
+    // repeat with period pattern_len (2 bits each, first op in the low bits)
+    uint32_t ecc_ops;
+    uint32_t pattern_len;
+    uint32_t pattern;
 } H2EPreKernel;
