@@ -1253,6 +1253,348 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
 }
 
 // ================================================================================================
+// Compiled values-only replay (tape.h "V-tape"): the critical path of every cut segment.  One wave walks the
+// record stream; operands and results live in statically allocated LDS slots ([slot][word][lane], conflict-free),
+// so an op is: read its header (LDS, uniform address -> SGPRs), read operands (one LDS round trip), compute,
+// write the slot and - only where the host's liveness analysis says someone else needs it - the cells.
+template <class FP>
+struct VSlots {
+    static constexpr int W = 2 * FP::L + 4, NS = (FP::L == 3 ? 22 : 18), NF = 8;
+    u64 ints[NS][W][64];
+    u64 fes[NF][4][64];
+};
+template <class FP>
+WI_INLINE IntVal<FP> vs_ld_int(const VSlots<FP>* vs, u32 slot) {
+    IntVal<FP> r;
+    u32 lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) {
+        r.l[i].v[0] = vs->ints[slot][2 * i][lane];
+        r.l[i].v[1] = vs->ints[slot][2 * i + 1][lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.native.v[i] = vs->ints[slot][2 * FP::L + i][lane];
+    return r;
+}
+template <class FP>
+WI_INLINE void vs_st_int(VSlots<FP>* vs, u32 slot, const Limb* l, const Fe& native) {
+    u32 lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) {
+        vs->ints[slot][2 * i][lane] = l[i].v[0];
+        vs->ints[slot][2 * i + 1][lane] = l[i].v[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) vs->ints[slot][2 * FP::L + i][lane] = native.v[i];
+}
+template <class FP>
+WI_INLINE Fe vs_ld_fe(const VSlots<FP>* vs, u32 slot) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.v[i] = vs->fes[slot][i][threadIdx.x];
+    return r;
+}
+template <class FP>
+WI_INLINE void vs_st_fe(VSlots<FP>* vs, u32 slot, const Fe& v) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) vs->fes[slot][i][threadIdx.x] = v.v[i];
+}
+struct VHdr {
+    u32 w[8];
+};
+WI_INLINE VHdr vrec_read(const H2EVRec* rec) {  // uniform address: every lane reads the same record
+    const uint4* q = (const uint4*)rec;
+    uint4 a = q[0], b = q[1];
+    VHdr h;
+    h.w[0] = __builtin_amdgcn_readfirstlane(a.x);
+    h.w[1] = __builtin_amdgcn_readfirstlane(a.y);
+    h.w[2] = __builtin_amdgcn_readfirstlane(a.z);
+    h.w[3] = __builtin_amdgcn_readfirstlane(a.w);
+    h.w[4] = __builtin_amdgcn_readfirstlane(b.x);
+    h.w[5] = __builtin_amdgcn_readfirstlane(b.y);
+    h.w[6] = __builtin_amdgcn_readfirstlane(b.z);
+    h.w[7] = __builtin_amdgcn_readfirstlane(b.w);
+    return h;
+}
+template <class FP>
+WI_INLINE IntVal<FP> v_src_int(const VSlots<FP>* vs, const LC& c, const VHdr& h, int which, const H2EVRec* ext) {
+    u32 kind = (h.w[7] >> (2 * which)) & 3u, word = h.w[2 + which];
+    if (kind == H2E_VSRC_INT_SLOT) return vs_ld_int<FP>(vs, word);
+    u32 refs[FP::L + 1];
+    const u32* e = (const u32*)ext + word;
+#pragma unroll
+    for (int j = 0; j <= FP::L; j++) refs[j] = __builtin_amdgcn_readfirstlane(e[j]);
+    return ld_int<FP>(c, refs);
+}
+template <class FP>
+WI_INLINE Fe v_src_fe(const VSlots<FP>* vs, const LC& c, const VHdr& h, int which) {
+    u32 kind = (h.w[7] >> (2 * which)) & 3u, word = h.w[2 + which];
+    if (kind == H2E_VSRC_FE_SLOT) return vs_ld_fe<FP>(vs, word);
+    return ld_fe(c, word);
+}
+// result cells: mul-like = limbs in range acc cells + native in a base cell; add-like = base column 4
+template <class FP>
+WI_INLINE void v_out_mul(VSlots<FP>* vs, const LC& c, const VHdr& h, const Limb* l, const Fe& native) {
+    if ((h.w[0] >> 8) & H2E_VFLAG_STORE) {
+#pragma unroll
+        for (int i = 0; i < FP::L; i++) stR(c, h.w[6] + 3 * i, 0, fe_of(l[i]));
+        stB(c, h.w[5], 4, native);
+    }
+    u32 dst = (h.w[0] >> 16) & 0xffu;
+    if (dst != H2E_V_NO_SLOT) vs_st_int<FP>(vs, dst, l, native);
+}
+template <class FP>
+WI_INLINE void v_out_add(VSlots<FP>* vs, const LC& c, const VHdr& h, const Limb* l, const Fe& native) {
+    if ((h.w[0] >> 8) & H2E_VFLAG_STORE) {
+#pragma unroll
+        for (int i = 0; i < FP::L; i++) stB(c, h.w[5] + i, 4, fe_of(l[i]));
+        stB(c, h.w[5] + FP::L, 4, native);
+    }
+    u32 dst = (h.w[0] >> 16) & 0xffu;
+    if (dst != H2E_V_NO_SLOT) vs_st_int<FP>(vs, dst, l, native);
+}
+template <class FP>
+WI_INLINE void v_out_fe(VSlots<FP>* vs, const LC& c, const VHdr& h, const Fe& v) {
+    if ((h.w[0] >> 8) & H2E_VFLAG_STORE) stB(c, h.w[5], 4, v);
+    u32 dst = (h.w[0] >> 16) & 0xffu;
+    if (dst != H2E_V_NO_SLOT) vs_st_fe<FP>(vs, dst, v);
+}
+template <class FP>
+WI_INLINE void v_out_w(VSlots<FP>* vs, const LC& c, const VHdr& h, const Wd<FP::WW>& x) {  // canonical W value
+    Limb l[FP::L];
+    split_limbs<FP>(x, l);
+    v_out_mul<FP>(vs, c, h, l, native_of_w<FP>(c, x));
+}
+
+template <class FP>
+WI_INLINE void exec_vop(VSlots<FP>* vs, const LC& c, const VHdr& h, const H2EVRec* ext, HintPrefetch<FP>& hp) {
+    constexpr int L = FP::L;
+    u32 opc = h.w[0] & 0xffu, imm = h.w[1];
+    if (opc == H2E_V_HINT) {
+        u32 slot = imm + ((((h.w[0] >> 8) & H2E_VFLAG_HINT_STRIDED) != 0) ? c.strand * c.hint_stride : 0);
+        v_out_w<FP>(vs, c, h, hint_value<FP>(c, hp, slot));
+        return;
+    }
+    if (opc == H2E_V_SUB) {
+        IntVal<FP> a = v_src_int<FP>(vs, c, h, 0, ext), b = v_src_int<FP>(vs, c, h, 1, ext);
+        Limb s[L];
+#pragma unroll
+        for (int i = 0; i < L; i++) s[i] = wd_sub<2>(wd_add<2>(a.l[i], wd_load<2>(c.fc->ceil_limbs[imm][i])), b.l[i]);
+        v_out_add<FP>(vs, c, h, s, addmod_n(c, submod_n(c, a.native, b.native), wd_load<4>(c.fc->ceil_native[imm])));
+        return;
+    }
+    if (opc == H2E_V_ADD) {
+        IntVal<FP> a = v_src_int<FP>(vs, c, h, 0, ext), b = v_src_int<FP>(vs, c, h, 1, ext);
+        Limb s[L];
+#pragma unroll
+        for (int i = 0; i < L; i++) s[i] = wd_add<2>(a.l[i], b.l[i]);
+        v_out_add<FP>(vs, c, h, s, addmod_n(c, a.native, b.native));
+        return;
+    }
+    if (opc == H2E_V_MUL) {
+        IntVal<FP> a = v_src_int<FP>(vs, c, h, 0, ext), b = v_src_int<FP>(vs, c, h, 1, ext);
+        Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
+        Wd<FPX<FP>::QW> dq;
+        Wd<FP::WW> rem;
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW>(A, B)), dq, rem);
+        v_out_w<FP>(vs, c, h, rem);
+        return;
+    }
+    if (opc == H2E_V_REDUCE) {
+        IntVal<FP> a = v_src_int<FP>(vs, c, h, 0, ext);
+        Wd<FP::WW> rem;
+        u64 dsmall;
+        divrem_small<FP>(c, compose<FP, FPX<FP>::AW>(a.l), dsmall, rem);
+        v_out_w<FP>(vs, c, h, rem);
+        return;
+    }
+    if (opc == H2E_V_NEG) {
+        IntVal<FP> a = v_src_int<FP>(vs, c, h, 0, ext);
+        Limb s[L];
+#pragma unroll
+        for (int i = 0; i < L; i++) s[i] = wd_sub<2>(wd_load<2>(c.fc->ceil_limbs[imm][i]), a.l[i]);
+        v_out_add<FP>(vs, c, h, s, submod_n(c, wd_load<4>(c.fc->ceil_native[imm]), a.native));
+        return;
+    }
+    if (opc == H2E_V_MUL_SMALL) {
+        IntVal<FP> a = v_src_int<FP>(vs, c, h, 0, ext);
+        Wd<1> k = wd_from_u64<1>(imm);
+        Limb s[L];
+#pragma unroll
+        for (int i = 0; i < L; i++) s[i] = wd_resize<2>(wd_mul<2, 1>(a.l[i], k));
+        v_out_add<FP>(vs, c, h, s, mod_n<5>(c, wd_mul<4, 1>(a.native, k)));
+        return;
+    }
+    if (opc == H2E_V_DIV) {  // unhinted division: b, a
+        IntVal<FP> b = v_src_int<FP>(vs, c, h, 0, ext), a = v_src_int<FP>(vs, c, h, 1, ext);
+        Wd<FPX<FP>::QW> q0;
+        Wd<FP::WW> a_red, b_red, cv;
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(compose<FP, FPX<FP>::AW>(a.l)), q0, a_red);
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(compose<FP, FPX<FP>::AW>(b.l)), q0, b_red);
+        Wd<FP::WW> binv = wd_inv_mod<FP::WW>(b_red, wd_load<FP::WW>(c.fc->w));
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FP::WW, FP::WW>(a_red, binv)), q0, cv);
+        v_out_w<FP>(vs, c, h, cv);
+        return;
+    }
+    if (opc == H2E_V_MASK) {
+        IntVal<FP> a = v_src_int<FP>(vs, c, h, 0, ext);
+        Fe coeff = v_src_fe<FP>(vs, c, h, 1);
+        bool keep = !wd_is_zero<4>(coeff);
+        Limb s[L];
+#pragma unroll
+        for (int i = 0; i < L; i++) s[i] = keep ? a.l[i] : wd_zero<2>();
+        v_out_add<FP>(vs, c, h, s, keep ? a.native : wd_zero<4>());
+        return;
+    }
+    if (opc == H2E_V_BISEC_INT) {
+        Fe cond = v_src_fe<FP>(vs, c, h, 0);
+        IntVal<FP> a = v_src_int<FP>(vs, c, h, 1, ext), b = v_src_int<FP>(vs, c, h, 2, ext);
+        bool take_a = !wd_is_zero<4>(cond);
+        Limb s[L];
+#pragma unroll
+        for (int i = 0; i < L; i++) s[i] = take_a ? a.l[i] : b.l[i];
+        v_out_add<FP>(vs, c, h, s, take_a ? a.native : b.native);
+        return;
+    }
+    if (opc == H2E_V_IS_ZERO) {
+        IntVal<FP> a = v_src_int<FP>(vs, c, h, 0, ext);
+        bool all_zero = true;
+#pragma unroll
+        for (int i = 0; i < L; i++) all_zero = all_zero && wd_is_zero<2>(a.l[i]);
+        bool is_w = wd_eq<4>(a.native, wd_load<4>(c.fc->w_native));
+#pragma unroll
+        for (int i = 0; i < FP::PW; i++) is_w = is_w && wd_eq<2>(a.l[i], wd_load<2>(c.fc->w_limbs[i]));
+        v_out_fe<FP>(vs, c, h, fe_u64((all_zero || is_w) ? 1 : 0));
+        return;
+    }
+    if (opc == H2E_V_NOT) {
+        v_out_fe<FP>(vs, c, h, submod_n(c, fe_u64(1), v_src_fe<FP>(vs, c, h, 0)));
+        return;
+    }
+    if (opc == H2E_V_AND || opc == H2E_V_OR || opc == H2E_V_XNOR) {
+        Fe a = v_src_fe<FP>(vs, c, h, 0), b = v_src_fe<FP>(vs, c, h, 1);
+        u64 r = opc == H2E_V_AND ? (a.v[0] & b.v[0]) : opc == H2E_V_OR ? (a.v[0] | b.v[0]) : (1 ^ a.v[0] ^ b.v[0]);
+        v_out_fe<FP>(vs, c, h, fe_u64(r));
+        return;
+    }
+    if (opc == H2E_V_PICK_INDEX) {  // imm = k, the bit cells' refs are the first k extension words
+        u64 idx = 0;
+        const u32* e = (const u32*)ext;
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+            if (i < (int)imm) idx |= (ld_fe(c, __builtin_amdgcn_readfirstlane(e[i])).v[0] & 1) << i;
+        v_out_fe<FP>(vs, c, h, fe_u64(idx));
+        return;
+    }
+    if (opc == H2E_V_SELECT_POINT) {  // src0 = index, imm = aux offset of the candidate table, w[6] = select row
+        constexpr int NC = 2 * (L + 1);
+        Fe index = v_src_fe<FP>(vs, c, h, 0);
+        u32 idx = (u32)(index.v[0] & 0xff);
+        const u32* tab = c.aux + imm + idx * NC;
+        Fe v[NC];
+#pragma unroll
+        for (int j = 0; j < NC; j++) v[j] = ld_fe(c, tab[j]);
+        if ((h.w[0] >> 8) & H2E_VFLAG_STORE) {
+#pragma unroll
+            for (int j = 0; j < NC; j++) stS(c, h.w[6] + j, 0, v[j]);
+        }
+        u32 dst[2] = {(h.w[0] >> 16) & 0xffu, (h.w[7] >> 8) & 0xffu};
+#pragma unroll
+        for (int which = 0; which < 2; which++) {
+            Limb l[L];
+#pragma unroll
+            for (int i = 0; i < L; i++) l[i] = wd_resize<2>(v[which * (L + 1) + i]);
+            if (dst[which] != H2E_V_NO_SLOT) vs_st_int<FP>(vs, dst[which], l, v[which * (L + 1) + L]);
+        }
+        return;
+    }
+    if (opc == H2E_V_FULL) {  // the tape op itself (64 bytes = two extension records)
+        const u32* e = (const u32*)ext;
+        u32 v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = __builtin_amdgcn_readfirstlane(e[q]);
+        H2EOp op;
+        op.opcode = (uint16_t)(v[0] & 0xffffu);
+        op.flags = (uint16_t)(v[0] >> 16);
+        op.imm = v[1];
+        op.base_row = v[2];
+        op.range_row = v[3];
+        op.select_row = v[4];
+#pragma unroll
+        for (int k2 = 0; k2 < H2E_OP_MAX_REFS; k2++) op.refs[k2] = v[5 + k2];
+        exec_op<FP, false>(c, op);
+        return;
+    }
+}
+
+template <class FP>
+__global__ void __launch_bounds__(64) h2e_replay(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
+    u32 per = n_instances * L.n_strands;
+    u32 idx = blockIdx.x * 64 + threadIdx.x;
+    bool active = idx < per;
+    if (!active) idx = per - 1;   // padding lanes repeat the last lane's work (same values to the same cells)
+    u32 instance = idx / L.n_strands, strand = idx % L.n_strands;
+    InstanceDesc d = inst[instance];
+    LC c;
+    c.base = d.base;
+    c.range = d.range;
+    c.select = d.select;
+    c.inputs = d.inputs;
+    c.status = d.status;
+    c.ob = L.strand_base0 + strand * L.delta_base;
+    c.orr = L.strand_range0 + strand * L.delta_range;
+    c.os = L.strand_select0 + strand * L.delta_select;
+    c.params = L.params + (size_t)strand * L.n_params;
+    c.aux = L.aux;
+    c.pool = L.const_pool;
+    c.fc = &g_fc[FP::ID];
+    c.strand = strand;
+    c.input_stride = L.input_stride;
+    c.hints = d.hints;
+    c.hint_stride = L.hint_stride;
+    __shared__ Stage stage;
+    __shared__ VSlots<FP> slots;
+    __shared__ H2EVRec chunk[2][H2E_VCHUNK];
+    c.st = &stage;
+    c.active = active;
+    __builtin_amdgcn_s_setprio(3);   // the value chain is the critical path
+    HintPrefetch<FP> hp;
+#pragma unroll
+    for (int i = 0; i < HintPrefetch<FP>::E; i++) {
+        hp.slot[i] = 0xffffffffu;
+        hp.v[i] = wd_zero<FP::WW>();
+    }
+    // records stream through two LDS chunk buffers: the next chunk's global loads are in flight while this one runs
+    u32 lane = threadIdx.x;
+    auto fetch = [&](u32 first, uint4* r) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            u32 rec = first + 2 * lane + (u32)(q >> 1);
+            r[q] = rec < L.n_vrec ? ((const uint4*)(L.vtape + rec))[q & 1] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto commit = [&](u32 buf, const uint4* r) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) ((uint4*)&chunk[buf][2 * lane + (q >> 1)])[q & 1] = r[q];
+        lds_fence();
+    };
+    uint4 nxt[4];
+    fetch(0, nxt);
+    commit(0, nxt);
+    for (u32 c0 = 0, buf = 0; c0 < L.n_vrec; c0 += H2E_VCHUNK, buf ^= 1) {
+        bool more = c0 + H2E_VCHUNK < L.n_vrec;
+        if (more) fetch(c0 + H2E_VCHUNK, nxt);
+        u32 n = min(H2E_VCHUNK, L.n_vrec - c0);
+        for (u32 k = 0; k < n;) {
+            VHdr h = vrec_read(&chunk[buf][k]);
+            exec_vop<FP>(&slots, c, h, &chunk[buf][k + 1], hp);
+            k += 1 + (h.w[0] >> 24);
+        }
+        if (more) commit(buf ^ 1, nxt);
+    }
+}
+
+// ================================================================================================
 // Montgomery arithmetic (R = 2^(64 N)) — used by the value-predictor kernels (mod w) and the inverse fix-up (mod n)
 template <int N>
 struct Mont {
@@ -1774,7 +2116,8 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
     static const size_t x_pad = getenv("H2E_X_LDS_PAD") ? (size_t)atol(getenv("H2E_X_LDS_PAD")) : 0;
     size_t xlds = grid.x > 4096 ? x_pad : 0;
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
-    if (mode & 1) hipLaunchKernelGGL((h2e_run_tape<FP, true>), grid1, block, 0, stream, *launch, inst, n_instances, fc_dev); \
+    if ((mode & 1) && launch->vtape) hipLaunchKernelGGL(h2e_replay<FP>, grid1, block, 0, stream, *launch, inst, n_instances); \
+    if ((mode & 1) && !launch->vtape) hipLaunchKernelGGL((h2e_run_tape<FP, true>), grid1, block, 0, stream, *launch, inst, n_instances, fc_dev); \
     if (mode & 2) hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid, block, xlds, stream, *launch, inst, n_instances, fc_dev);
     switch (field_pair) {
         case 0: { H2E_LAUNCH_FP(FP_BN256_FQ) } break;

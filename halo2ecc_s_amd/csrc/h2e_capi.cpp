@@ -1,6 +1,8 @@
 // C ABI of the witness engine (include/h2e.h): program recording (host) + execution (HIP).
 #include <hip/hip_runtime.h>
+#include <functional>
 #include <map>
+#include <array>
 #include <set>
 #include <memory>
 #include <mutex>
@@ -66,6 +68,10 @@ struct h2e_program {
     std::vector<uint32_t> h_subs;          // per segment with cuts: [0, cut_1, ..., n_ops]
     std::vector<uint32_t> seg_sub_begin;   // per segment: index into h_subs (or ~0u)
     std::vector<uint32_t> seg_n_sub;
+    // compiled values-only replay (tape.h "V-tape"), per cut segment
+    std::vector<H2EVRec> h_vtape;
+    std::vector<uint32_t> seg_v_begin, seg_v_count;
+    H2EVRec* d_vtape = nullptr;
     InstanceDescHost* d_inst = nullptr;
     uint32_t inst_cap = 0;
     std::vector<InstanceDescHost> h_inst;
@@ -79,6 +85,7 @@ struct h2e_program {
             (void)hipFree(d_fixups);
             (void)hipFree(d_pre_args);
             (void)hipFree(d_subs);
+            (void)hipFree(d_vtape);
             (void)hipFree(d_inst);
         }
     }
@@ -278,12 +285,301 @@ struct h2e_program {
                 }
             }
         }
+        // 5. compile the values-only replay of every cut segment
+        seg_v_begin.assign(r.segments.size(), 0);
+        seg_v_count.assign(r.segments.size(), 0);
+        for (auto& c : cs) compile_replay(c.sg, c.ops, c.n_ops, c.first, c.last, [&](uint32_t region, uint32_t row) { return producer(c, region, row); });
+    }
+
+    // Compile one cut segment into V-tape records (tape.h).  Values = results of alive ops; each gets an LDS slot for
+    // as long as later ops of the replay read it (furthest-next-use eviction when the slots run out: an evicted or
+    // never cached value goes through its cells, so its producer stores it).
+    void compile_replay(const h2e::Segment* sg, const H2EOp* ops, uint32_t n_ops, const uint32_t* first, const uint32_t* last,
+                        const std::function<int(uint32_t, uint32_t)>& producer) {
+        h2e::Recorder& r = *rec;
+        const int L = r.fp.limbs;
+        const uint32_t NS = L == 3 ? 22 : 18, NF = 8;   // VSlots in engine.hip
+        const uint32_t rel = sg->is_fork ? 1 : 0;
+        enum { K_NONE, K_MUL, K_ADD, K_FE, K_SEL, K_FULL };
+        auto kind_of = [](const H2EOp& op) -> int {
+            switch (op.opcode) {
+                case H2E_OP_INT_MUL: case H2E_OP_REDUCE: case H2E_OP_DIV_CORE: return K_MUL;
+                case H2E_OP_INT_ADD: case H2E_OP_INT_SUB: case H2E_OP_INT_NEG: case H2E_OP_INT_MUL_SMALL: case H2E_OP_MASK_INT:
+                case H2E_OP_BISEC_INT: return K_ADD;
+                case H2E_OP_IS_INT_ZERO: case H2E_OP_NOT: case H2E_OP_AND: case H2E_OP_OR: case H2E_OP_XNOR: case H2E_OP_PICK_INDEX:
+                    return K_FE;
+                case H2E_OP_SELECT_POINT: return K_SEL;
+                case H2E_OP_ASSERT_CONST: case H2E_OP_CACHE_INT: case H2E_OP_SUM_LIMBS: case H2E_OP_NOP: return K_NONE;
+                default: return K_FULL;
+            }
+        };
+        auto fe_row = [&](const H2EOp& op) -> uint32_t {
+            if (op.opcode == H2E_OP_IS_INT_ZERO) return op.base_row + 6 + 4 * (uint32_t)r.fp.pure_w_check_limbs;
+            if (op.opcode == H2E_OP_PICK_INDEX) return op.base_row + (op.imm < 5 ? 0 : 1);
+            return op.base_row;
+        };
+        struct Opd { uint32_t ref; bool is_int; int refpos; };
+        auto operands = [&](const H2EOp& op, Opd* o) -> int {
+            bool hinted = (op.flags & H2E_FLAG_HINTED) != 0;
+            int n = 0;
+            switch (op.opcode) {
+                case H2E_OP_INT_MUL: case H2E_OP_DIV_CORE:
+                    if (!hinted) { o[n++] = {op.refs[0], true, 0}; o[n++] = {op.refs[L + 1], true, L + 1}; }
+                    break;
+                case H2E_OP_REDUCE:
+                    if (!hinted) o[n++] = {op.refs[0], true, 0};
+                    break;
+                case H2E_OP_INT_ADD: case H2E_OP_INT_SUB:
+                    o[n++] = {op.refs[0], true, 0}; o[n++] = {op.refs[L + 1], true, L + 1};
+                    break;
+                case H2E_OP_INT_NEG: case H2E_OP_INT_MUL_SMALL: case H2E_OP_IS_INT_ZERO:
+                    o[n++] = {op.refs[0], true, 0};
+                    break;
+                case H2E_OP_MASK_INT:
+                    o[n++] = {op.refs[0], true, 0}; o[n++] = {op.refs[L + 1], false, L + 1};
+                    break;
+                case H2E_OP_BISEC_INT:
+                    o[n++] = {op.refs[0], false, 0}; o[n++] = {op.refs[1], true, 1}; o[n++] = {op.refs[L + 2], true, L + 2};
+                    break;
+                case H2E_OP_NOT: case H2E_OP_SELECT_POINT:
+                    o[n++] = {op.refs[0], false, 0};
+                    break;
+                case H2E_OP_AND: case H2E_OP_OR: case H2E_OP_XNOR:
+                    o[n++] = {op.refs[0], false, 0}; o[n++] = {op.refs[1], false, 1};
+                    break;
+                default: break;
+            }
+            return n;
+        };
+        // value id = 2 * op + which; -1: not a value of this replay (read from its cell)
+        auto value_of = [&](uint32_t ref, bool is_int) -> int {
+            if (ref == H2E_NO_REF || H2E_REF_REGION(ref) == H2E_REGION_PARAM || H2E_REF_REL(ref) != rel) return -1;
+            uint32_t region = H2E_REF_REGION(ref), row = H2E_REF_ROW(ref), col = H2E_REF_COL(ref);
+            if (!rel && (row < first[region] || row >= last[region])) return -1;
+            int p = producer(region, row);
+            if (p < 0) return -1;
+            const H2EOp& po = ops[p];
+            int pk = kind_of(po);
+            if (pk == K_FULL) return -1;   // its rows are written for real
+            if (is_int) {
+                if (pk == K_MUL && region == 1 && col == 0 && row == po.range_row) return 2 * p;
+                if (pk == K_ADD && region == 0 && col == 4 && row == po.base_row) return 2 * p;
+                if (pk == K_SEL && region == 2 && col == 0 && row == po.select_row) return 2 * p;
+                if (pk == K_SEL && region == 2 && col == 0 && row == po.select_row + (uint32_t)L + 1) return 2 * p + 1;
+            } else {
+                if (pk == K_FE && region == 0 && col == 4 && row == fe_row(po)) return 2 * p;
+            }
+            return -2;   // a cell the values-only replay never writes
+        };
+        struct Val {
+            std::vector<uint32_t> uses;   // positions (alive order) of the consumers that can read a slot
+            size_t next = 0;
+            int slot = -1;
+            bool resident = false, force_store = false;
+        };
+        std::vector<Val> vals(2 * (size_t)n_ops);
+        std::vector<uint32_t> alive;
+        for (uint32_t i = 0; i < n_ops; i++)
+            if (!(ops[i].flags & H2E_FLAG_VALUES_SKIP) && kind_of(ops[i]) != K_NONE) alive.push_back(i);
+        // pass 1: uses
+        for (uint32_t pos = 0; pos < alive.size(); pos++) {
+            const H2EOp& op = ops[alive[pos]];
+            int k = kind_of(op);
+            if (k == K_FULL || op.opcode == H2E_OP_PICK_INDEX) {   // reads cells: whatever it reads must be stored
+                for (int q = 0; q < H2E_OP_MAX_REFS; q++)
+                    for (int as_int = 0; as_int < 2; as_int++) {
+                        int v = value_of(op.refs[q], as_int != 0);
+                        if (v >= 0) vals[v].force_store = true;
+                    }
+                continue;
+            }
+            Opd o[3];
+            int n = operands(op, o);
+            for (int q = 0; q < n; q++) {
+                int v = value_of(o[q].ref, o[q].is_int);
+                if (v == -2) throw std::runtime_error("replay compile: operand is not a replay result");
+                if (v >= 0) {
+                    if (ops[v / 2].flags & H2E_FLAG_VALUES_SKIP) throw std::runtime_error("replay compile: live operand of a dead op");
+                    vals[v].uses.push_back(pos);
+                }
+            }
+        }
+        // pass 2: slot allocation
+        struct Dec {
+            uint8_t kind[3] = {0, 0, 0};
+            uint32_t word[3] = {0, 0, 0};
+            int val[3] = {-1, -1, -1};
+            int dst[2] = {-1, -1};
+        };
+        std::vector<Dec> dec(alive.size());
+        std::vector<int> int_owner(NS, -1), fe_owner(NF, -1);
+        auto next_use = [&](int v) -> uint32_t { return vals[v].next < vals[v].uses.size() ? vals[v].uses[vals[v].next] : 0xffffffffu; };
+        auto take_slot = [&](std::vector<int>& owner, int v) -> int {
+            for (size_t sl = 0; sl < owner.size(); sl++)
+                if (owner[sl] < 0) {
+                    owner[sl] = v;
+                    return (int)sl;
+                }
+            size_t victim = 0;
+            for (size_t sl = 1; sl < owner.size(); sl++)
+                if (next_use(owner[sl]) > next_use(owner[victim])) victim = sl;
+            if (next_use(owner[victim]) <= next_use(v)) return -1;   // the new value is the one needed last
+            Val& ev = vals[owner[victim]];
+            ev.resident = false;
+            ev.force_store = true;
+            ev.slot = -1;
+            owner[victim] = v;
+            return (int)victim;
+        };
+        for (uint32_t pos = 0; pos < alive.size(); pos++) {
+            uint32_t i = alive[pos];
+            const H2EOp& op = ops[i];
+            int k = kind_of(op);
+            Dec& d = dec[pos];
+            if (k != K_FULL && op.opcode != H2E_OP_PICK_INDEX) {
+                Opd o[3];
+                int n = operands(op, o);
+                for (int q = 0; q < n; q++) {
+                    int v = value_of(o[q].ref, o[q].is_int);
+                    d.val[q] = v;
+                    if (v >= 0 && vals[v].resident) {
+                        d.kind[q] = o[q].is_int ? H2E_VSRC_INT_SLOT : H2E_VSRC_FE_SLOT;
+                        d.word[q] = (uint32_t)vals[v].slot;
+                    } else {
+                        d.kind[q] = H2E_VSRC_GLOBAL;
+                        if (v >= 0) vals[v].force_store = true;
+                    }
+                }
+                for (int q = 0; q < n; q++) {
+                    int v = d.val[q];
+                    if (v < 0) continue;
+                    if (vals[v].next < vals[v].uses.size() && vals[v].uses[vals[v].next] == pos) vals[v].next++;
+                }
+                for (int q = 0; q < n; q++) {
+                    int v = d.val[q];
+                    if (v < 0 || !vals[v].resident) continue;
+                    if (vals[v].next >= vals[v].uses.size()) {   // last use: free the slot
+                        auto& owner = (kind_of(ops[v / 2]) == K_FE) ? fe_owner : int_owner;
+                        owner[vals[v].slot] = -1;
+                        vals[v].resident = false;
+                    }
+                }
+            }
+            int nres = k == K_SEL ? 2 : (k == K_MUL || k == K_ADD || k == K_FE) ? 1 : 0;
+            for (int w = 0; w < nres; w++) {
+                int v = 2 * (int)i + w;
+                if (vals[v].uses.empty()) continue;
+                int sl = take_slot(k == K_FE ? fe_owner : int_owner, v);
+                if (sl < 0) {
+                    vals[v].force_store = true;
+                } else {
+                    vals[v].slot = sl;
+                    vals[v].resident = true;
+                    d.dst[w] = sl;
+                }
+            }
+        }
+        // emit
+        std::vector<H2EVRec> out;
+        auto pad_to = [&](size_t need) {
+            size_t in_chunk = out.size() % H2E_VCHUNK;
+            if (in_chunk + need > H2E_VCHUNK)
+                while (out.size() % H2E_VCHUNK) out.push_back(H2EVRec{{H2E_V_NOP, 0, 0, 0, 0, 0, 0, 0}});
+        };
+        for (uint32_t pos = 0; pos < alive.size(); pos++) {
+            uint32_t i = alive[pos];
+            const H2EOp& op = ops[i];
+            int k = kind_of(op);
+            const Dec& d = dec[pos];
+            std::vector<uint32_t> ext;
+            H2EVRec h{{0, 0, 0, 0, 0, 0, 0, 0}};
+            uint32_t vop = H2E_V_NOP, vflags = 0, dst = d.dst[0] >= 0 ? (uint32_t)d.dst[0] : H2E_V_NO_SLOT;
+            bool hinted = (op.flags & H2E_FLAG_HINTED) != 0;
+            switch (op.opcode) {
+                case H2E_OP_INT_MUL: vop = hinted ? H2E_V_HINT : H2E_V_MUL; break;
+                case H2E_OP_REDUCE: vop = hinted ? H2E_V_HINT : H2E_V_REDUCE; break;
+                case H2E_OP_DIV_CORE: vop = hinted ? H2E_V_HINT : H2E_V_DIV; break;
+                case H2E_OP_INT_ADD: vop = H2E_V_ADD; break;
+                case H2E_OP_INT_SUB: vop = H2E_V_SUB; break;
+                case H2E_OP_INT_NEG: vop = H2E_V_NEG; break;
+                case H2E_OP_INT_MUL_SMALL: vop = H2E_V_MUL_SMALL; break;
+                case H2E_OP_MASK_INT: vop = H2E_V_MASK; break;
+                case H2E_OP_BISEC_INT: vop = H2E_V_BISEC_INT; break;
+                case H2E_OP_IS_INT_ZERO: vop = H2E_V_IS_ZERO; break;
+                case H2E_OP_NOT: vop = H2E_V_NOT; break;
+                case H2E_OP_AND: vop = H2E_V_AND; break;
+                case H2E_OP_OR: vop = H2E_V_OR; break;
+                case H2E_OP_XNOR: vop = H2E_V_XNOR; break;
+                case H2E_OP_PICK_INDEX: vop = H2E_V_PICK_INDEX; break;
+                case H2E_OP_SELECT_POINT: vop = H2E_V_SELECT_POINT; break;
+                default: vop = H2E_V_FULL; break;
+            }
+            if (hinted && (op.flags & H2E_FLAG_HINT_STRIDED)) vflags |= H2E_VFLAG_HINT_STRIDED;
+            bool store = !(op.flags & H2E_FLAG_LOCAL_RESULT) || vals[2 * (size_t)i].force_store || vals[2 * (size_t)i + 1].force_store;
+            if (k == K_SEL || op.opcode == H2E_OP_AND || op.opcode == H2E_OP_OR || op.opcode == H2E_OP_XNOR || op.opcode == H2E_OP_PICK_INDEX ||
+                op.opcode == H2E_OP_BISEC_INT)
+                store = true;   // never flagged local
+            if (store) vflags |= H2E_VFLAG_STORE;
+            h.w[1] = op.imm;
+            h.w[5] = k == K_FE ? fe_row(op) : op.base_row;
+            h.w[6] = k == K_SEL ? op.select_row : op.range_row;
+            if (vop == H2E_V_FULL) {
+                const uint32_t* raw = (const uint32_t*)&op;
+                ext.assign(raw, raw + 16);
+            } else if (vop == H2E_V_PICK_INDEX) {
+                for (uint32_t q = 0; q < op.imm && q < 5; q++) ext.push_back(op.refs[q]);
+            } else {
+                Opd o[3];
+                int n = operands(op, o);
+                for (int q = 0; q < n; q++) {
+                    h.w[7] |= (uint32_t)d.kind[q] << (2 * q);
+                    if (d.kind[q] != H2E_VSRC_GLOBAL) {
+                        h.w[2 + q] = d.word[q];
+                    } else if (o[q].is_int) {
+                        h.w[2 + q] = (uint32_t)ext.size();
+                        for (int j = 0; j <= L; j++) ext.push_back(op.refs[o[q].refpos + j]);
+                    } else {
+                        h.w[2 + q] = o[q].ref;
+                    }
+                }
+                if (k == K_SEL) h.w[7] |= (d.dst[1] >= 0 ? (uint32_t)d.dst[1] : H2E_V_NO_SLOT) << 8;
+            }
+            uint32_t n_ext = (uint32_t)((ext.size() + 7) / 8);
+            h.w[0] = vop | (vflags << 8) | (dst << 16) | (n_ext << 24);
+            pad_to(1 + n_ext);
+            out.push_back(h);
+            ext.resize((size_t)n_ext * 8, H2E_NO_REF);
+            for (uint32_t e = 0; e < n_ext; e++) {
+                H2EVRec x;
+                for (int j = 0; j < 8; j++) x.w[j] = ext[e * 8 + j];
+                out.push_back(x);
+            }
+        }
+        size_t si = (size_t)(sg - r.segments.data());
+        seg_v_begin[si] = (uint32_t)h_vtape.size();
+        seg_v_count[si] = (uint32_t)out.size();
+        h_vtape.insert(h_vtape.end(), out.begin(), out.end());
     }
 
     void finish() {
         h2e::Recorder& r = *rec;
         r.close_segment();
         mark_local_results();
+        if (getenv("H2E_DUMP_TAPE")) {   // debugging aid: per segment, ops by opcode (alive / skipped by the values replay)
+            for (size_t si = 0; si < r.segments.size(); si++) {
+                auto& sg = r.segments[si];
+                std::map<int, std::array<uint32_t, 4>> h;
+                for (uint32_t i = sg.tape_begin; i < sg.tape_end; i++) {
+                    auto& e = h[r.tape[i].opcode];
+                    e[(r.tape[i].flags & H2E_FLAG_VALUES_SKIP) ? 1 : 0]++;
+                    if (!(r.tape[i].flags & H2E_FLAG_VALUES_SKIP) && (r.tape[i].flags & H2E_FLAG_HINTED)) e[2]++;
+                    if (!(r.tape[i].flags & H2E_FLAG_VALUES_SKIP) && !(r.tape[i].flags & H2E_FLAG_LOCAL_RESULT)) e[3]++;
+                }
+                fprintf(stderr, "segment %zu: ops %u strands %u cuts %u fork %d\n", si, sg.tape_end - sg.tape_begin, sg.n_strands, sg.n_cuts, (int)sg.is_fork);
+                for (auto& kv : h)
+                    fprintf(stderr, "   opcode %2d alive %6u (hinted %6u, stored %6u) skipped %6u\n", kv.first, kv.second[0], kv.second[2], kv.second[3], kv.second[1]);
+            }
+        }
         base_rows = std::max<uint64_t>(r.base_height, r.base_offset) + 1;
         range_rows = std::max<uint64_t>(r.range_height, r.range_offset) + 1;
         select_rows = std::max<uint64_t>(r.select_height, r.select_offset) + 1;
@@ -568,6 +864,7 @@ static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
         p->seg_n_sub[si] = n + 1;
     }
     HIP_TRY(up((void**)&p->d_subs, p->h_subs.empty() ? nullptr : p->h_subs.data(), p->h_subs.size() * 4));
+    HIP_TRY(up((void**)&p->d_vtape, p->h_vtape.empty() ? nullptr : p->h_vtape.data(), p->h_vtape.size() * sizeof(H2EVRec)));
     p->device = ctx->device;
     return 0;
 }
@@ -728,6 +1025,9 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         L.rel_refs = s.is_fork ? 1 : 0;
         L.n_sub = p->seg_n_sub[si];
         L.sub = L.n_sub > 1 ? p->d_subs + p->seg_sub_begin[si] : nullptr;
+        bool compiled = si < p->seg_v_count.size() && p->seg_v_count[si] > 0;
+        L.vtape = compiled ? p->d_vtape + p->seg_v_begin[si] : nullptr;
+        L.n_vrec = compiled ? p->seg_v_count[si] : 0;
         int lrc;
         if (L.n_sub > 1) {
             lrc = h2e_engine_launch(fp, 1, &L, p->d_inst, n_instances, ctx->d_fc[fp], sa);

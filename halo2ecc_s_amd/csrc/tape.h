@@ -137,6 +137,7 @@ typedef struct H2EFieldConsts {
     uint64_t n_r1[4];                       // R mod n
 } H2EFieldConsts;
 
+struct H2EVRec;
 // One launch: a tape replayed by n_instances * n_strands lanes.
 typedef struct H2ELaunch {
     const H2EOp* tape;
@@ -157,7 +158,41 @@ typedef struct H2ELaunch {
     uint32_t rel_refs;            // 1 = cells created by this tape are strand-relative refs (fork segment)
     uint32_t n_sub;               // 0/1 = the whole tape per lane
     const uint32_t* sub;          // [n_sub + 1] op indices relative to `tape`
+    const struct H2EVRec* vtape;  // compiled values-only replay of this segment (cut segments only)
+    uint32_t n_vrec;
 } H2ELaunch;
+
+// ---- compiled values-only replay ("V-tape") ----------------------------------------------------
+// The values-only replay of a cut segment does not interpret the witness tape: the host compiles it (once per
+// shape) into a stream of 32-byte records that holds only the ops whose results something depends on, with every
+// operand already resolved to either an LDS slot (static allocation by live range, spilled values go through
+// their cells) or a cell reference.  An op = one header record + n_ext extension records of 8 words.
+//   w[0] = vopcode | vflags << 8 | dst slot << 16 | n_ext << 24        (dst 0xff: result not kept in a slot)
+//   w[1] = imm            (times / k / hint slot / aux offset)
+//   w[2..4] = src0..2     int in a slot: slot; fe in a slot: slot; global fe: the cell ref;
+//                         global int: word offset into the op's extension records of its L+1 cell refs
+//   w[5] = base row, w[6] = range (SELECT_POINT: select) row of the result cells (strand relative like the tape's)
+//   w[7] = operand kinds, 2 bits per source (H2E_VSRC_*); SELECT_POINT: bits 8..15 second dst slot
+typedef struct H2EVRec {
+    uint32_t w[8];
+} H2EVRec;
+#define H2E_VCHUNK 128u   // records per LDS chunk; an op never straddles a chunk boundary (host pads with H2E_V_NOP)
+enum H2EVOpcode {
+    H2E_V_NOP = 0,
+    H2E_V_HINT,          // mul-like result := hint[imm]               (hinted INT_MUL / REDUCE / DIV_CORE)
+    H2E_V_MUL, H2E_V_REDUCE, H2E_V_DIV,
+    H2E_V_ADD, H2E_V_SUB, H2E_V_NEG, H2E_V_MUL_SMALL, H2E_V_MASK, H2E_V_BISEC_INT,
+    H2E_V_IS_ZERO, H2E_V_NOT, H2E_V_AND, H2E_V_OR, H2E_V_XNOR, H2E_V_PICK_INDEX,
+    H2E_V_SELECT_POINT,
+    H2E_V_FULL           // run the tape op held in the 2 extension records as it is (its rows are its results)
+};
+#define H2E_VFLAG_STORE 1u          // the result is also written to its cells
+#define H2E_VFLAG_HINT_STRIDED 2u
+#define H2E_VSRC_NONE 0u
+#define H2E_VSRC_INT_SLOT 1u
+#define H2E_VSRC_FE_SLOT 2u
+#define H2E_VSRC_GLOBAL 3u
+#define H2E_V_NO_SLOT 0xffu
 
 // ---- value-predictor ("V") kernels for the MSM ---------------------------------------------------
 // They run native Montgomery / Jacobian arithmetic over the same inputs, write numerator/denominator pairs of
