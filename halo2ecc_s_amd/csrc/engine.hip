@@ -1529,10 +1529,14 @@ WI_INLINE void exec_vop(VSlots<FP>* vs, const LC& c, const VHdr& h, const H2EVRe
 
 template <class FP>
 __global__ void __launch_bounds__(64) h2e_replay(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
+    // lanes: [piece][instance][strand]; pieces are independent stretches of the replay (host: compile_replay)
     u32 per = n_instances * L.n_strands;
-    u32 idx = blockIdx.x * 64 + threadIdx.x;
+    u32 blocks_per = (per + 63) / 64;
+    u32 piece = blockIdx.x / blocks_per;
+    u32 idx = (blockIdx.x % blocks_per) * 64 + threadIdx.x;
     bool active = idx < per;
     if (!active) idx = per - 1;   // padding lanes repeat the last lane's work (same values to the same cells)
+    u32 rec0 = L.vpieces[2 * piece], rec1 = L.vpieces[2 * piece + 1];
     u32 instance = idx / L.n_strands, strand = idx % L.n_strands;
     InstanceDesc d = inst[instance];
     LC c;
@@ -1570,7 +1574,7 @@ __global__ void __launch_bounds__(64) h2e_replay(H2ELaunch L, const InstanceDesc
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             u32 rec = first + 2 * lane + (u32)(q >> 1);
-            r[q] = rec < L.n_vrec ? ((const uint4*)(L.vtape + rec))[q & 1] : make_uint4(0, 0, 0, 0);
+            r[q] = rec < rec1 ? ((const uint4*)(L.vtape + rec))[q & 1] : make_uint4(0, 0, 0, 0);
         }
     };
     auto commit = [&](u32 buf, const uint4* r) {
@@ -1579,12 +1583,12 @@ __global__ void __launch_bounds__(64) h2e_replay(H2ELaunch L, const InstanceDesc
         lds_fence();
     };
     uint4 nxt[4];
-    fetch(0, nxt);
+    fetch(rec0, nxt);
     commit(0, nxt);
-    for (u32 c0 = 0, buf = 0; c0 < L.n_vrec; c0 += H2E_VCHUNK, buf ^= 1) {
-        bool more = c0 + H2E_VCHUNK < L.n_vrec;
+    for (u32 c0 = rec0, buf = 0; c0 < rec1; c0 += H2E_VCHUNK, buf ^= 1) {
+        bool more = c0 + H2E_VCHUNK < rec1;
         if (more) fetch(c0 + H2E_VCHUNK, nxt);
-        u32 n = min(H2E_VCHUNK, L.n_vrec - c0);
+        u32 n = min(H2E_VCHUNK, rec1 - c0);
         for (u32 k = 0; k < n;) {
             VHdr h = vrec_read(&chunk[buf][k]);
             exec_vop<FP>(&slots, c, h, &chunk[buf][k + 1], hp);
@@ -2116,7 +2120,7 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
     static const size_t x_pad = getenv("H2E_X_LDS_PAD") ? (size_t)atol(getenv("H2E_X_LDS_PAD")) : 0;
     size_t xlds = grid.x > 4096 ? x_pad : 0;
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
-    if ((mode & 1) && launch->vtape) hipLaunchKernelGGL(h2e_replay<FP>, grid1, block, 0, stream, *launch, inst, n_instances); \
+    if ((mode & 1) && launch->vtape) hipLaunchKernelGGL(h2e_replay<FP>, dim3(blocks_per_sub * launch->n_vpieces), block, 0, stream, *launch, inst, n_instances); \
     if ((mode & 1) && !launch->vtape) hipLaunchKernelGGL((h2e_run_tape<FP, true>), grid1, block, 0, stream, *launch, inst, n_instances, fc_dev); \
     if (mode & 2) hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid, block, xlds, stream, *launch, inst, n_instances, fc_dev);
     switch (field_pair) {

@@ -70,8 +70,10 @@ struct h2e_program {
     std::vector<uint32_t> seg_n_sub;
     // compiled values-only replay (tape.h "V-tape"), per cut segment
     std::vector<H2EVRec> h_vtape;
-    std::vector<uint32_t> seg_v_begin, seg_v_count;
+    std::vector<uint32_t> seg_piece_begin, seg_n_pieces;   // per segment: pieces = [first record, end record) pairs in h_vpieces
+    std::vector<uint32_t> h_vpieces;
     H2EVRec* d_vtape = nullptr;
+    uint32_t* d_vpieces = nullptr;
     InstanceDescHost* d_inst = nullptr;
     uint32_t inst_cap = 0;
     std::vector<InstanceDescHost> h_inst;
@@ -86,6 +88,7 @@ struct h2e_program {
             (void)hipFree(d_pre_args);
             (void)hipFree(d_subs);
             (void)hipFree(d_vtape);
+            (void)hipFree(d_vpieces);
             (void)hipFree(d_inst);
         }
     }
@@ -286,8 +289,8 @@ struct h2e_program {
             }
         }
         // 5. compile the values-only replay of every cut segment
-        seg_v_begin.assign(r.segments.size(), 0);
-        seg_v_count.assign(r.segments.size(), 0);
+        seg_piece_begin.assign(r.segments.size(), 0);
+        seg_n_pieces.assign(r.segments.size(), 0);
         for (auto& c : cs) compile_replay(c.sg, c.ops, c.n_ops, c.first, c.last, [&](uint32_t region, uint32_t row) { return producer(c, region, row); });
     }
 
@@ -376,6 +379,9 @@ struct h2e_program {
             size_t next = 0;
             int slot = -1;
             bool resident = false, force_store = false;
+            int dst_slot = -1;                    // the slot it was given when produced
+            bool evicted = false;                 // lost its slot before its last use
+            uint32_t cell_use_last = 0xffffffffu; // last alive position of an op that reads its *cell* (V_FULL, PICK_INDEX)
         };
         std::vector<Val> vals(2 * (size_t)n_ops);
         std::vector<uint32_t> alive;
@@ -389,7 +395,10 @@ struct h2e_program {
                 for (int q = 0; q < H2E_OP_MAX_REFS; q++)
                     for (int as_int = 0; as_int < 2; as_int++) {
                         int v = value_of(op.refs[q], as_int != 0);
-                        if (v >= 0) vals[v].force_store = true;
+                        if (v >= 0) {
+                            vals[v].force_store = true;
+                            vals[v].cell_use_last = pos;
+                        }
                     }
                 continue;
             }
@@ -427,6 +436,7 @@ struct h2e_program {
             Val& ev = vals[owner[victim]];
             ev.resident = false;
             ev.force_store = true;
+            ev.evicted = true;
             ev.slot = -1;
             owner[victim] = v;
             return (int)victim;
@@ -447,7 +457,10 @@ struct h2e_program {
                         d.word[q] = (uint32_t)vals[v].slot;
                     } else {
                         d.kind[q] = H2E_VSRC_GLOBAL;
-                        if (v >= 0) vals[v].force_store = true;
+                        if (v >= 0) {
+                            vals[v].force_store = true;
+                            vals[v].cell_use_last = pos;   // read through its cell
+                        }
                     }
                 }
                 for (int q = 0; q < n; q++) {
@@ -474,26 +487,119 @@ struct h2e_program {
                     vals[v].force_store = true;
                 } else {
                     vals[v].slot = sl;
+                    vals[v].dst_slot = sl;
                     vals[v].resident = true;
                     d.dst[w] = sl;
                 }
             }
         }
-        // emit
-        std::vector<H2EVRec> out;
-        auto pad_to = [&](size_t need) {
-            size_t in_chunk = out.size() % H2E_VCHUNK;
-            if (in_chunk + need > H2E_VCHUNK)
-                while (out.size() % H2E_VCHUNK) out.push_back(H2EVRec{{H2E_V_NOP, 0, 0, 0, 0, 0, 0, 0}});
-        };
+        // ---- pieces ------------------------------------------------------------------------------------------
+        // The replay is one dependent chain only through values.  Where every value that is live across a position
+        // can be rebuilt from hints / external cells by a few ops (its producers' closure), the chain is cut there:
+        // the next piece starts with that closure as a prologue (results not stored) and runs in its own lanes.
+        std::vector<uint32_t> pos_of_op(n_ops, 0xffffffffu);
+        for (uint32_t pos = 0; pos < alive.size(); pos++) pos_of_op[alive[pos]] = pos;
+        const uint32_t INF = 0xffffffffu;
+        auto prod_pos = [&](int v) { return pos_of_op[v / 2]; };
+        auto last_use = [&](int v) -> uint32_t { return vals[v].uses.empty() ? 0 : vals[v].uses.back(); };
+        // values produced by the replay in program order, for the live-set scan
+        std::vector<int> produced;
         for (uint32_t pos = 0; pos < alive.size(); pos++) {
+            int k = kind_of(ops[alive[pos]]);
+            int nres = k == K_SEL ? 2 : (k == K_MUL || k == K_ADD || k == K_FE) ? 1 : 0;
+            for (int w = 0; w < nres; w++) produced.push_back(2 * (int)alive[pos] + w);
+        }
+        auto is_fe_val = [&](int v) { return kind_of(ops[v / 2]) == K_FE; };
+        struct Restart {
+            uint32_t pos;
+            std::vector<uint32_t> prologue;            // alive positions, program order
+            std::map<int, int> slot_of;                // value -> slot during the prologue
+        };
+        const uint32_t PIECE_TARGET = 96, PIECE_BUDGET = 40;
+        static const bool pieces_on = !getenv("H2E_NO_PIECES");
+        auto try_restart = [&](uint32_t p, Restart& rs) -> bool {
+            // live set
+            std::vector<int> live;
+            for (int v : produced) {
+                if (prod_pos(v) >= p) break;
+                if (vals[v].cell_use_last != INF && vals[v].cell_use_last >= p) return false;   // a later op reads its cell
+                if (!vals[v].uses.empty() && last_use(v) >= p) {
+                    if (vals[v].dst_slot < 0 || vals[v].evicted) return false;
+                    live.push_back(v);
+                }
+            }
+            std::set<uint32_t> closure;
+            std::set<int> cvals;
+            std::vector<int> work(live.begin(), live.end());
+            while (!work.empty()) {
+                int v = work.back();
+                work.pop_back();
+                uint32_t q = prod_pos(v);
+                // (both results of a SELECT_POINT come from one op)
+                cvals.insert(v);
+                if (!closure.insert(q).second) continue;
+                if (closure.size() > PIECE_BUDGET) return false;
+                if (kind_of(ops[alive[q]]) == K_FULL) return false;
+                for (int j = 0; j < 3; j++)
+                    if (dec[q].val[j] >= 0) work.push_back(dec[q].val[j]);
+            }
+            rs.pos = p;
+            rs.prologue.assign(closure.begin(), closure.end());
+            std::vector<bool> int_used(NS, false), fe_used(NF, false);
+            for (int v : live) {
+                rs.slot_of[v] = vals[v].dst_slot;
+                (is_fe_val(v) ? fe_used : int_used)[vals[v].dst_slot] = true;
+            }
+            for (int v : cvals) {
+                if (rs.slot_of.count(v)) continue;
+                auto& used = is_fe_val(v) ? fe_used : int_used;
+                int sl = -1;
+                for (size_t t = 0; t < used.size(); t++)
+                    if (!used[t]) {
+                        sl = (int)t;
+                        break;
+                    }
+                if (sl < 0) return false;
+                used[sl] = true;
+                rs.slot_of[v] = sl;
+            }
+            return true;
+        };
+        std::vector<Restart> restarts;
+        if (pieces_on) {
+            uint32_t since = 0;
+            for (uint32_t pos = 1; pos < alive.size(); pos++) {
+                since++;
+                if (since < PIECE_TARGET) continue;
+                Restart rs;
+                if (try_restart(pos, rs)) {
+                    restarts.push_back(std::move(rs));
+                    since = 0;
+                }
+            }
+        }
+        // ---- emit ------------------------------------------------------------------------------------------------
+        std::vector<H2EVRec> out;
+        auto pad_chunk = [&]() {
+            while (out.size() % H2E_VCHUNK) out.push_back(H2EVRec{{H2E_V_NOP, 0, 0, 0, 0, 0, 0, 0}});
+        };
+        auto pad_to = [&](size_t need) {
+            if (out.size() % H2E_VCHUNK + need > H2E_VCHUNK) pad_chunk();
+        };
+        // remap: nullptr = the op in its own place; else the prologue copy (slots from the map, nothing stored)
+        auto emit = [&](uint32_t pos, const std::map<int, int>* remap) {
             uint32_t i = alive[pos];
             const H2EOp& op = ops[i];
             int k = kind_of(op);
             const Dec& d = dec[pos];
             std::vector<uint32_t> ext;
             H2EVRec h{{0, 0, 0, 0, 0, 0, 0, 0}};
-            uint32_t vop = H2E_V_NOP, vflags = 0, dst = d.dst[0] >= 0 ? (uint32_t)d.dst[0] : H2E_V_NO_SLOT;
+            auto dst_of = [&](int w) -> uint32_t {
+                if (!remap) return d.dst[w] >= 0 ? (uint32_t)d.dst[w] : H2E_V_NO_SLOT;
+                auto it = remap->find(2 * (int)i + w);
+                return it == remap->end() ? H2E_V_NO_SLOT : (uint32_t)it->second;
+            };
+            uint32_t vop = H2E_V_NOP, vflags = 0, dst = dst_of(0);
             bool hinted = (op.flags & H2E_FLAG_HINTED) != 0;
             switch (op.opcode) {
                 case H2E_OP_INT_MUL: vop = hinted ? H2E_V_HINT : H2E_V_MUL; break;
@@ -519,7 +625,7 @@ struct h2e_program {
             if (k == K_SEL || op.opcode == H2E_OP_AND || op.opcode == H2E_OP_OR || op.opcode == H2E_OP_XNOR || op.opcode == H2E_OP_PICK_INDEX ||
                 op.opcode == H2E_OP_BISEC_INT)
                 store = true;   // never flagged local
-            if (store) vflags |= H2E_VFLAG_STORE;
+            if (store && !remap) vflags |= H2E_VFLAG_STORE;
             h.w[1] = op.imm;
             h.w[5] = k == K_FE ? fe_row(op) : op.base_row;
             h.w[6] = k == K_SEL ? op.select_row : op.range_row;
@@ -532,9 +638,14 @@ struct h2e_program {
                 Opd o[3];
                 int n = operands(op, o);
                 for (int q = 0; q < n; q++) {
-                    h.w[7] |= (uint32_t)d.kind[q] << (2 * q);
-                    if (d.kind[q] != H2E_VSRC_GLOBAL) {
-                        h.w[2 + q] = d.word[q];
+                    uint32_t kind = d.kind[q], word = d.word[q];
+                    if (remap && d.val[q] >= 0) {   // a value of the closure: in the slot the prologue gave it
+                        kind = o[q].is_int ? H2E_VSRC_INT_SLOT : H2E_VSRC_FE_SLOT;
+                        word = (uint32_t)remap->at(d.val[q]);
+                    }
+                    h.w[7] |= kind << (2 * q);
+                    if (kind != H2E_VSRC_GLOBAL) {
+                        h.w[2 + q] = word;
                     } else if (o[q].is_int) {
                         h.w[2 + q] = (uint32_t)ext.size();
                         for (int j = 0; j <= L; j++) ext.push_back(op.refs[o[q].refpos + j]);
@@ -542,7 +653,7 @@ struct h2e_program {
                         h.w[2 + q] = o[q].ref;
                     }
                 }
-                if (k == K_SEL) h.w[7] |= (d.dst[1] >= 0 ? (uint32_t)d.dst[1] : H2E_V_NO_SLOT) << 8;
+                if (k == K_SEL) h.w[7] |= dst_of(1) << 8;
             }
             uint32_t n_ext = (uint32_t)((ext.size() + 7) / 8);
             h.w[0] = vop | (vflags << 8) | (dst << 16) | (n_ext << 24);
@@ -554,11 +665,30 @@ struct h2e_program {
                 for (int j = 0; j < 8; j++) x.w[j] = ext[e * 8 + j];
                 out.push_back(x);
             }
-        }
+        };
         size_t si = (size_t)(sg - r.segments.data());
-        seg_v_begin[si] = (uint32_t)h_vtape.size();
-        seg_v_count[si] = (uint32_t)out.size();
+        uint32_t vbase = (uint32_t)h_vtape.size();   // multiple of H2E_VCHUNK
+        seg_piece_begin[si] = (uint32_t)h_vpieces.size() / 2;
+        size_t next_restart = 0;
+        uint32_t piece_first = 0;
+        for (uint32_t pos = 0; pos < alive.size(); pos++) {
+            if (next_restart < restarts.size() && restarts[next_restart].pos == pos) {
+                h_vpieces.push_back(vbase + piece_first);
+                h_vpieces.push_back(vbase + (uint32_t)out.size());
+                pad_chunk();
+                piece_first = (uint32_t)out.size();
+                for (uint32_t q : restarts[next_restart].prologue) emit(q, &restarts[next_restart].slot_of);
+                next_restart++;
+            }
+            emit(pos, nullptr);
+        }
+        h_vpieces.push_back(vbase + piece_first);
+        h_vpieces.push_back(vbase + (uint32_t)out.size());
+        pad_chunk();
+        seg_n_pieces[si] = (uint32_t)h_vpieces.size() / 2 - seg_piece_begin[si];
         h_vtape.insert(h_vtape.end(), out.begin(), out.end());
+        if (getenv("H2E_DUMP_TAPE"))
+            fprintf(stderr, "segment %zu: replay %zu alive ops, %zu records, %u pieces\n", si, alive.size(), out.size(), seg_n_pieces[si]);
     }
 
     void finish() {
@@ -865,6 +995,7 @@ static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
     }
     HIP_TRY(up((void**)&p->d_subs, p->h_subs.empty() ? nullptr : p->h_subs.data(), p->h_subs.size() * 4));
     HIP_TRY(up((void**)&p->d_vtape, p->h_vtape.empty() ? nullptr : p->h_vtape.data(), p->h_vtape.size() * sizeof(H2EVRec)));
+    HIP_TRY(up((void**)&p->d_vpieces, p->h_vpieces.empty() ? nullptr : p->h_vpieces.data(), p->h_vpieces.size() * 4));
     p->device = ctx->device;
     return 0;
 }
@@ -1025,9 +1156,10 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         L.rel_refs = s.is_fork ? 1 : 0;
         L.n_sub = p->seg_n_sub[si];
         L.sub = L.n_sub > 1 ? p->d_subs + p->seg_sub_begin[si] : nullptr;
-        bool compiled = si < p->seg_v_count.size() && p->seg_v_count[si] > 0;
-        L.vtape = compiled ? p->d_vtape + p->seg_v_begin[si] : nullptr;
-        L.n_vrec = compiled ? p->seg_v_count[si] : 0;
+        bool compiled = si < p->seg_n_pieces.size() && p->seg_n_pieces[si] > 0;
+        L.vtape = compiled ? p->d_vtape : nullptr;
+        L.vpieces = compiled ? p->d_vpieces + 2 * (size_t)p->seg_piece_begin[si] : nullptr;
+        L.n_vpieces = compiled ? p->seg_n_pieces[si] : 0;
         int lrc;
         if (L.n_sub > 1) {
             lrc = h2e_engine_launch(fp, 1, &L, p->d_inst, n_instances, ctx->d_fc[fp], sa);

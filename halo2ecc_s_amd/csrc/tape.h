@@ -158,8 +158,9 @@ typedef struct H2ELaunch {
     uint32_t rel_refs;            // 1 = cells created by this tape are strand-relative refs (fork segment)
     uint32_t n_sub;               // 0/1 = the whole tape per lane
     const uint32_t* sub;          // [n_sub + 1] op indices relative to `tape`
-    const struct H2EVRec* vtape;  // compiled values-only replay of this segment (cut segments only)
-    uint32_t n_vrec;
+    const struct H2EVRec* vtape;  // compiled values-only replay (cut segments only): the program's record array
+    const uint32_t* vpieces;      // [n_vpieces][2] first / end record of each independent piece of this segment's replay
+    uint32_t n_vpieces;
 } H2ELaunch;
 
 // ---- compiled values-only replay ("V-tape") ----------------------------------------------------
