@@ -103,6 +103,8 @@ def main():
     # ecc_assert_equal holds in every timed pass (the reference test computes it with the native library)
     eng.run(prog, d_in, base, rng, sel, status)
     torch.cuda.synchronize()
+    if os.environ.get("H2E_DEBUG_BENCH"):
+        print("pass 0 status", status.cpu().numpy()[:8], file=sys.stderr)
     exp = np.zeros((tiles, 3, 4), dtype=np.uint64)
     for t in range(tiles):
         xs = [read_cell(base[t], r) for r in out_refs[0:L]]

@@ -1258,46 +1258,79 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
 // so an op is: read its header (LDS, uniform address -> SGPRs), read operands (one LDS round trip), compute,
 // write the slot and - only where the host's liveness analysis says someone else needs it - the cells.
 template <class FP>
-struct VSlots {
-    static constexpr int W = 2 * FP::L + 4, NS = (FP::L == 3 ? 22 : 18), NF = 8;
-    u64 ints[NS][W][64];
-    u64 fes[NF][4][64];
+struct VSlots {   // views into the kernel's dynamic LDS
+    static constexpr int W = 2 * FP::L + 4, NF = 4;
+    static constexpr int INT_UNITS = FP::L + 2, HINT_UNITS = FP::WW / 2;   // 16-byte staging units of an integer / a hint
+    u64* ints;          // [n_int_slots][W][64]
+    u64* fes;           // [NF][4][64]
+    ulonglong2* stage;  // [n_units][64]
 };
 template <class FP>
-WI_INLINE IntVal<FP> vs_ld_int(const VSlots<FP>* vs, u32 slot) {
+WI_INLINE IntVal<FP> vs_ld_int(const VSlots<FP>& vs, u32 slot) {
     IntVal<FP> r;
-    u32 lane = threadIdx.x;
+    const u64* p = vs.ints + (size_t)slot * VSlots<FP>::W * 64 + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < FP::L; i++) {
-        r.l[i].v[0] = vs->ints[slot][2 * i][lane];
-        r.l[i].v[1] = vs->ints[slot][2 * i + 1][lane];
+        r.l[i].v[0] = p[(2 * i) * 64];
+        r.l[i].v[1] = p[(2 * i + 1) * 64];
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) r.native.v[i] = vs->ints[slot][2 * FP::L + i][lane];
+    for (int i = 0; i < 4; i++) r.native.v[i] = p[(2 * FP::L + i) * 64];
     return r;
 }
 template <class FP>
-WI_INLINE void vs_st_int(VSlots<FP>* vs, u32 slot, const Limb* l, const Fe& native) {
-    u32 lane = threadIdx.x;
+WI_INLINE void vs_st_int(const VSlots<FP>& vs, u32 slot, const Limb* l, const Fe& native) {
+    u64* p = vs.ints + (size_t)slot * VSlots<FP>::W * 64 + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < FP::L; i++) {
-        vs->ints[slot][2 * i][lane] = l[i].v[0];
-        vs->ints[slot][2 * i + 1][lane] = l[i].v[1];
+        p[(2 * i) * 64] = l[i].v[0];
+        p[(2 * i + 1) * 64] = l[i].v[1];
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) vs->ints[slot][2 * FP::L + i][lane] = native.v[i];
+    for (int i = 0; i < 4; i++) p[(2 * FP::L + i) * 64] = native.v[i];
 }
 template <class FP>
-WI_INLINE Fe vs_ld_fe(const VSlots<FP>* vs, u32 slot) {
+WI_INLINE Fe vs_ld_fe(const VSlots<FP>& vs, u32 slot) {
     Fe r;
 #pragma unroll
-    for (int i = 0; i < 4; i++) r.v[i] = vs->fes[slot][i][threadIdx.x];
+    for (int i = 0; i < 4; i++) r.v[i] = vs.fes[(slot * 4 + i) * 64 + threadIdx.x];
     return r;
 }
 template <class FP>
-WI_INLINE void vs_st_fe(VSlots<FP>* vs, u32 slot, const Fe& v) {
+WI_INLINE void vs_st_fe(const VSlots<FP>& vs, u32 slot, const Fe& v) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) vs->fes[slot][i][threadIdx.x] = v.v[i];
+    for (int i = 0; i < 4; i++) vs.fes[(slot * 4 + i) * 64 + threadIdx.x] = v.v[i];
+}
+template <class FP>
+WI_INLINE IntVal<FP> vs_stage_int(const VSlots<FP>& vs, u32 unit) {   // L limb units + 2 native units
+    IntVal<FP> r;
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) {
+        ulonglong2 q = vs.stage[(unit + i) * 64 + threadIdx.x];
+        r.l[i].v[0] = q.x;
+        r.l[i].v[1] = q.y;
+    }
+    ulonglong2 a = vs.stage[(unit + FP::L) * 64 + threadIdx.x], b = vs.stage[(unit + FP::L + 1) * 64 + threadIdx.x];
+    r.native.v[0] = a.x; r.native.v[1] = a.y; r.native.v[2] = b.x; r.native.v[3] = b.y;
+    return r;
+}
+template <class FP>
+WI_INLINE Fe vs_stage_fe(const VSlots<FP>& vs, u32 unit) {
+    ulonglong2 a = vs.stage[unit * 64 + threadIdx.x], b = vs.stage[(unit + 1) * 64 + threadIdx.x];
+    Fe r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
+    return r;
+}
+template <class FP>
+WI_INLINE Wd<FP::WW> vs_stage_w(const VSlots<FP>& vs, u32 unit) {
+    Wd<FP::WW> r;
+#pragma unroll
+    for (int i = 0; i < FP::WW / 2; i++) {
+        ulonglong2 q = vs.stage[(unit + i) * 64 + threadIdx.x];
+        r.v[2 * i] = q.x;
+        r.v[2 * i + 1] = q.y;
+    }
+    return r;
 }
 struct VHdr {
     u32 w[8];
@@ -1317,9 +1350,10 @@ WI_INLINE VHdr vrec_read(const H2EVRec* rec) {  // uniform address: every lane r
     return h;
 }
 template <class FP>
-WI_INLINE IntVal<FP> v_src_int(const VSlots<FP>* vs, const LC& c, const VHdr& h, int which, const H2EVRec* ext) {
-    u32 kind = (h.w[7] >> (2 * which)) & 3u, word = h.w[2 + which];
+WI_INLINE IntVal<FP> v_src_int(const VSlots<FP>& vs, const LC& c, const VHdr& h, int which, const H2EVRec* ext) {
+    u32 kind = (h.w[7] >> (3 * which)) & 7u, word = h.w[2 + which];
     if (kind == H2E_VSRC_INT_SLOT) return vs_ld_int<FP>(vs, word);
+    if (kind == H2E_VSRC_STAGE) return vs_stage_int<FP>(vs, word);
     u32 refs[FP::L + 1];
     const u32* e = (const u32*)ext + word;
 #pragma unroll
@@ -1327,14 +1361,15 @@ WI_INLINE IntVal<FP> v_src_int(const VSlots<FP>* vs, const LC& c, const VHdr& h,
     return ld_int<FP>(c, refs);
 }
 template <class FP>
-WI_INLINE Fe v_src_fe(const VSlots<FP>* vs, const LC& c, const VHdr& h, int which) {
-    u32 kind = (h.w[7] >> (2 * which)) & 3u, word = h.w[2 + which];
+WI_INLINE Fe v_src_fe(const VSlots<FP>& vs, const LC& c, const VHdr& h, int which) {
+    u32 kind = (h.w[7] >> (3 * which)) & 7u, word = h.w[2 + which];
     if (kind == H2E_VSRC_FE_SLOT) return vs_ld_fe<FP>(vs, word);
+    if (kind == H2E_VSRC_STAGE) return vs_stage_fe<FP>(vs, word);
     return ld_fe(c, word);
 }
 // result cells: mul-like = limbs in range acc cells + native in a base cell; add-like = base column 4
 template <class FP>
-WI_INLINE void v_out_mul(VSlots<FP>* vs, const LC& c, const VHdr& h, const Limb* l, const Fe& native) {
+WI_INLINE void v_out_mul(const VSlots<FP>& vs, const LC& c, const VHdr& h, const Limb* l, const Fe& native) {
     if ((h.w[0] >> 8) & H2E_VFLAG_STORE) {
 #pragma unroll
         for (int i = 0; i < FP::L; i++) stR(c, h.w[6] + 3 * i, 0, fe_of(l[i]));
@@ -1344,7 +1379,7 @@ WI_INLINE void v_out_mul(VSlots<FP>* vs, const LC& c, const VHdr& h, const Limb*
     if (dst != H2E_V_NO_SLOT) vs_st_int<FP>(vs, dst, l, native);
 }
 template <class FP>
-WI_INLINE void v_out_add(VSlots<FP>* vs, const LC& c, const VHdr& h, const Limb* l, const Fe& native) {
+WI_INLINE void v_out_add(const VSlots<FP>& vs, const LC& c, const VHdr& h, const Limb* l, const Fe& native) {
     if ((h.w[0] >> 8) & H2E_VFLAG_STORE) {
 #pragma unroll
         for (int i = 0; i < FP::L; i++) stB(c, h.w[5] + i, 4, fe_of(l[i]));
@@ -1354,25 +1389,50 @@ WI_INLINE void v_out_add(VSlots<FP>* vs, const LC& c, const VHdr& h, const Limb*
     if (dst != H2E_V_NO_SLOT) vs_st_int<FP>(vs, dst, l, native);
 }
 template <class FP>
-WI_INLINE void v_out_fe(VSlots<FP>* vs, const LC& c, const VHdr& h, const Fe& v) {
+WI_INLINE void v_out_fe(const VSlots<FP>& vs, const LC& c, const VHdr& h, const Fe& v) {
     if ((h.w[0] >> 8) & H2E_VFLAG_STORE) stB(c, h.w[5], 4, v);
     u32 dst = (h.w[0] >> 16) & 0xffu;
     if (dst != H2E_V_NO_SLOT) vs_st_fe<FP>(vs, dst, v);
 }
 template <class FP>
-WI_INLINE void v_out_w(VSlots<FP>* vs, const LC& c, const VHdr& h, const Wd<FP::WW>& x) {  // canonical W value
+WI_INLINE void v_out_w(const VSlots<FP>& vs, const LC& c, const VHdr& h, const Wd<FP::WW>& x) {  // canonical W value
     Limb l[FP::L];
     split_limbs<FP>(x, l);
     v_out_mul<FP>(vs, c, h, l, native_of_w<FP>(c, x));
 }
 
 template <class FP>
-WI_INLINE void exec_vop(VSlots<FP>* vs, const LC& c, const VHdr& h, const H2EVRec* ext, HintPrefetch<FP>& hp) {
+WI_INLINE void exec_vop(const VSlots<FP>& vs, const LC& c, const VHdr& h, const H2EVRec* ext, HintPrefetch<FP>& hp) {
     constexpr int L = FP::L;
     u32 opc = h.w[0] & 0xffu, imm = h.w[1];
     if (opc == H2E_V_HINT) {
-        u32 slot = imm + ((((h.w[0] >> 8) & H2E_VFLAG_HINT_STRIDED) != 0) ? c.strand * c.hint_stride : 0);
-        v_out_w<FP>(vs, c, h, hint_value<FP>(c, hp, slot));
+        if ((h.w[0] >> 8) & H2E_VFLAG_STAGED) {
+            v_out_w<FP>(vs, c, h, vs_stage_w<FP>(vs, imm));
+        } else {
+            u32 slot = imm + ((((h.w[0] >> 8) & H2E_VFLAG_HINT_STRIDED) != 0) ? c.strand * c.hint_stride : 0);
+            v_out_w<FP>(vs, c, h, hint_value<FP>(c, hp, slot));
+        }
+        return;
+    }
+    if (opc == H2E_V_GATHER) {   // asynchronous global -> LDS loads of this piece's inputs (16 bytes per lane and unit)
+        u32 n = (h.w[0] >> 8) & 0xffu;
+#pragma unroll
+        for (u32 e = 0; e < 3; e++)
+            if (e < n) {
+                u32 meta = h.w[2 + 2 * e], ref = h.w[3 + 2 * e];
+                const u64* src;
+                if (meta & 1u)
+                    src = c.hints + (size_t)(ref + ((meta & 0x100u) ? c.strand * c.hint_stride : 0)) * H2E_W_WORDS_MAX;
+                else
+                    src = cell_ptr(c, ref);
+                src += ((meta >> 4) & 0xfu) * 2;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(vs.stage + (size_t)(h.w[1] + e) * 64), 16, 0, 0);
+            }
+        return;
+    }
+    if (opc == H2E_V_GATHER_WAIT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
     if (opc == H2E_V_SUB) {
@@ -1498,7 +1558,7 @@ WI_INLINE void exec_vop(VSlots<FP>* vs, const LC& c, const VHdr& h, const H2EVRe
 #pragma unroll
             for (int j = 0; j < NC; j++) stS(c, h.w[6] + j, 0, v[j]);
         }
-        u32 dst[2] = {(h.w[0] >> 16) & 0xffu, (h.w[7] >> 8) & 0xffu};
+        u32 dst[2] = {(h.w[0] >> 16) & 0xffu, (h.w[7] >> 16) & 0xffu};
 #pragma unroll
         for (int which = 0; which < 2; which++) {
             Limb l[L];
@@ -1557,8 +1617,12 @@ __global__ void __launch_bounds__(64) h2e_replay(H2ELaunch L, const InstanceDesc
     c.hints = d.hints;
     c.hint_stride = L.hint_stride;
     __shared__ Stage stage;
-    __shared__ VSlots<FP> slots;
     __shared__ H2EVRec chunk[2][H2E_VCHUNK];
+    extern __shared__ ulonglong2 v_dyn[];
+    VSlots<FP> slots;
+    slots.stage = v_dyn;
+    slots.ints = (u64*)(v_dyn + (size_t)L.v_units * 64);
+    slots.fes = slots.ints + (size_t)L.v_int_slots * VSlots<FP>::W * 64;
     c.st = &stage;
     c.active = active;
     __builtin_amdgcn_s_setprio(3);   // the value chain is the critical path
@@ -1591,7 +1655,7 @@ __global__ void __launch_bounds__(64) h2e_replay(H2ELaunch L, const InstanceDesc
         u32 n = min(H2E_VCHUNK, rec1 - c0);
         for (u32 k = 0; k < n;) {
             VHdr h = vrec_read(&chunk[buf][k]);
-            exec_vop<FP>(&slots, c, h, &chunk[buf][k + 1], hp);
+            exec_vop<FP>(slots, c, h, &chunk[buf][k + 1], hp);
             k += 1 + (h.w[0] >> 24);
         }
         if (more) commit(buf ^ 1, nxt);
@@ -2120,7 +2184,10 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
     static const size_t x_pad = getenv("H2E_X_LDS_PAD") ? (size_t)atol(getenv("H2E_X_LDS_PAD")) : 0;
     size_t xlds = grid.x > 4096 ? x_pad : 0;
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
-    if ((mode & 1) && launch->vtape) hipLaunchKernelGGL(h2e_replay<FP>, dim3(blocks_per_sub * launch->n_vpieces), block, 0, stream, *launch, inst, n_instances); \
+    if ((mode & 1) && launch->vtape)                                                                                           \
+        hipLaunchKernelGGL(h2e_replay<FP>, dim3(blocks_per_sub * launch->n_vpieces), block,                                    \
+                           ((size_t)launch->v_units * 2 + ((size_t)launch->v_int_slots * VSlots<FP>::W + VSlots<FP>::NF * 4)) * 64 * 8, \
+                           stream, *launch, inst, n_instances);                                                                \
     if ((mode & 1) && !launch->vtape) hipLaunchKernelGGL((h2e_run_tape<FP, true>), grid1, block, 0, stream, *launch, inst, n_instances, fc_dev); \
     if (mode & 2) hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid, block, xlds, stream, *launch, inst, n_instances, fc_dev);
     switch (field_pair) {
@@ -2139,7 +2206,8 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
     return (int)hipGetLastError();
 }
 
-extern "C" int h2e_engine_predict(int field_pair, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,
+// phase: 1 = the predictor chain, 2 = its finalize (batch inversion -> hints), 3 = both
+extern "C" int h2e_engine_predict(int field_pair, int phase, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,
                                   const uint32_t* aux_dev, const void* instances, uint32_t n_instances,
                                   const H2EFieldConsts* fc_dev, hipStream_t stream) {
     const InstanceDesc* inst = (const InstanceDesc*)instances;
@@ -2155,10 +2223,11 @@ extern "C" int h2e_engine_predict(int field_pair, const H2EPreKernel* k, const u
     u32 ecc_chunks = (k->ecc_ops + ECC_CH - 1) / ECC_CH;
     dim3 grid3((n_instances * k->n_lanes * ecc_chunks + 63) / 64);
 #define H2E_PREDICT_FP(FP)                                                                                                          \
-    hipLaunchKernelGGL(h2e_predict<FP>, grid, block, lds_reserve, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev); \
-    if (k->ecc_ops)                                                                                                                 \
+    if (phase & 1)                                                                                                                  \
+        hipLaunchKernelGGL(h2e_predict<FP>, grid, block, lds_reserve, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev); \
+    if ((phase & 2) && k->ecc_ops)                                                                                                  \
         hipLaunchKernelGGL(h2e_finalize_ecc<FP>, grid3, block, 0, stream, *k, inst, n_instances, fc_dev);                           \
-    else                                                                                                                            \
+    if ((phase & 2) && !k->ecc_ops)                                                                                                 \
         hipLaunchKernelGGL(h2e_finalize_hints<FP>, grid2, block, 0, stream, k->hint_base, n_hints, inst, n_instances, fc_dev);
     switch (field_pair) {
         case 0: { H2E_PREDICT_FP(FP_BN256_FQ) } break;

@@ -13,7 +13,7 @@
 extern "C" int h2e_engine_set_consts(int field_pair, const H2EFieldConsts* host);
 extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
                                  uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream);
-extern "C" int h2e_engine_predict(int field_pair, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,
+extern "C" int h2e_engine_predict(int field_pair, int phase, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,
                                   const uint32_t* aux_dev, const void* instances, uint32_t n_instances,
                                   const H2EFieldConsts* fc_dev, hipStream_t stream);
 
@@ -68,8 +68,10 @@ struct h2e_program {
     std::vector<uint32_t> h_subs;          // per segment with cuts: [0, cut_1, ..., n_ops]
     std::vector<uint32_t> seg_sub_begin;   // per segment: index into h_subs (or ~0u)
     std::vector<uint32_t> seg_n_sub;
+    std::vector<uint8_t> seg_deferrable;   // a segment without cuts whose cells no later kernel reads: runs off the critical stream
     // compiled values-only replay (tape.h "V-tape"), per cut segment
     std::vector<H2EVRec> h_vtape;
+    std::vector<uint32_t> seg_v_slots, seg_v_units;        // per segment: LDS sizing of the replay kernel
     std::vector<uint32_t> seg_piece_begin, seg_n_pieces;   // per segment: pieces = [first record, end record) pairs in h_vpieces
     std::vector<uint32_t> h_vpieces;
     H2EVRec* d_vtape = nullptr;
@@ -183,11 +185,12 @@ struct h2e_program {
             return ans;
         };
         // an absolute reference from anywhere
-        auto quote_abs = [&](uint32_t ref) {
+        auto quote_abs = [&](uint32_t ref, const h2e::Segment* own = nullptr) {
             if (ref == H2E_NO_REF || H2E_REF_REGION(ref) == H2E_REGION_PARAM || H2E_REF_REL(ref)) return;
             uint32_t region = H2E_REF_REGION(ref), row = H2E_REF_ROW(ref);
             for (auto& c : cs) {
                 const h2e::Segment& sg = *c.sg;
+                if (&sg == own) continue;   // references inside the quoting segment itself are refined in step 1
                 if (sg.is_fork) {
                     uint32_t b0 = region == 0 ? sg.base0 : region == 1 ? sg.range0 : sg.select0;
                     uint32_t d = region == 0 ? sg.dbase : region == 1 ? sg.drange : sg.dselect;
@@ -220,9 +223,10 @@ struct h2e_program {
             bool is_cut_main = false;
             for (auto& c : cs)
                 if (c.sg == &sg && !sg.is_fork) is_cut_main = true;
-            if (is_cut_main) continue;  // its own absolute refs were handled in step 1
+            // a cut main-context segment: its references into itself were handled in step 1, those into other cut
+            // segments (the MSM tail reads the windows' sums) count like anybody else's
             for (uint32_t i = sg.tape_begin; i < sg.tape_end; i++)
-                for (int k = 0; k < H2E_OP_MAX_REFS; k++) quote_abs(r.tape[i].refs[k]);
+                for (int k = 0; k < H2E_OP_MAX_REFS; k++) quote_abs(r.tape[i].refs[k], is_cut_main ? &sg : nullptr);
         }
         for (uint32_t ref : r.aux) quote_abs(ref);
         for (uint32_t ref : r.params) quote_abs(ref);
@@ -291,6 +295,8 @@ struct h2e_program {
         // 5. compile the values-only replay of every cut segment
         seg_piece_begin.assign(r.segments.size(), 0);
         seg_n_pieces.assign(r.segments.size(), 0);
+        seg_v_slots.assign(r.segments.size(), 1);
+        seg_v_units.assign(r.segments.size(), 1);
         for (auto& c : cs) compile_replay(c.sg, c.ops, c.n_ops, c.first, c.last, [&](uint32_t region, uint32_t row) { return producer(c, region, row); });
     }
 
@@ -301,7 +307,7 @@ struct h2e_program {
                         const std::function<int(uint32_t, uint32_t)>& producer) {
         h2e::Recorder& r = *rec;
         const int L = r.fp.limbs;
-        const uint32_t NS = L == 3 ? 22 : 18, NF = 8;   // VSlots in engine.hip
+        const uint32_t NS = L == 3 ? 22 : 18, NF = 4;   // VSlots in engine.hip (NF) and the LDS budget (NS)
         const uint32_t rel = sg->is_fork ? 1 : 0;
         enum { K_NONE, K_MUL, K_ADD, K_FE, K_SEL, K_FULL };
         auto kind_of = [](const H2EOp& op) -> int {
@@ -374,6 +380,13 @@ struct h2e_program {
             }
             return -2;   // a cell the values-only replay never writes
         };
+        // the op of this segment (index into ops) that writes a referenced cell, or -1
+        auto writer_of = [&](uint32_t ref) -> int {
+            if (ref == H2E_NO_REF || H2E_REF_REGION(ref) == H2E_REGION_PARAM || H2E_REF_REL(ref) != rel) return -1;
+            uint32_t region = H2E_REF_REGION(ref), row = H2E_REF_ROW(ref);
+            if (!rel && (row < first[region] || row >= last[region])) return -1;
+            return producer(region, row);
+        };
         struct Val {
             std::vector<uint32_t> uses;   // positions (alive order) of the consumers that can read a slot
             size_t next = 0;
@@ -388,9 +401,16 @@ struct h2e_program {
         for (uint32_t i = 0; i < n_ops; i++)
             if (!(ops[i].flags & H2E_FLAG_VALUES_SKIP) && kind_of(ops[i]) != K_NONE) alive.push_back(i);
         // pass 1: uses
+        std::vector<uint32_t> full_read_last(n_ops, 0);   // per op written "for real" (V_FULL): last alive position reading its rows
+        std::vector<uint32_t> alive_pos(n_ops, 0xffffffffu);
+        for (uint32_t pos = 0; pos < alive.size(); pos++) alive_pos[alive[pos]] = pos;
         for (uint32_t pos = 0; pos < alive.size(); pos++) {
             const H2EOp& op = ops[alive[pos]];
             int k = kind_of(op);
+            for (int q = 0; q < H2E_OP_MAX_REFS; q++) {
+                int wtr = writer_of(op.refs[q]);
+                if (wtr >= 0 && (uint32_t)wtr != alive[pos] && kind_of(ops[wtr]) == K_FULL) full_read_last[wtr] = std::max(full_read_last[wtr], pos);
+            }
             if (k == K_FULL || op.opcode == H2E_OP_PICK_INDEX) {   // reads cells: whatever it reads must be stored
                 for (int q = 0; q < H2E_OP_MAX_REFS; q++)
                     for (int as_int = 0; as_int < 2; as_int++) {
@@ -517,7 +537,10 @@ struct h2e_program {
         };
         const uint32_t PIECE_TARGET = 96, PIECE_BUDGET = 40;
         static const bool pieces_on = !getenv("H2E_NO_PIECES");
+        static const bool stage_on = !getenv("H2E_NO_STAGE");
         auto try_restart = [&](uint32_t p, Restart& rs) -> bool {
+            for (uint32_t q = 0; q < p; q++)
+                if (kind_of(ops[alive[q]]) == K_FULL && full_read_last[alive[q]] >= p) return false;   // its rows are read across the cut
             // live set
             std::vector<int> live;
             for (int v : produced) {
@@ -566,15 +589,30 @@ struct h2e_program {
             return true;
         };
         std::vector<Restart> restarts;
+        const uint32_t INT_UNITS = (uint32_t)L + 2, HINT_UNITS = (uint32_t)r.fp.w_words / 2, FE_UNITS = 2;
+        const uint32_t UNIT_TARGET = 44, UNIT_MAX = 64;   // staging units (16 bytes per lane) a piece may gather
+        auto stageable = [&](uint32_t ref) { return ref != H2E_NO_REF && H2E_REF_REGION(ref) != H2E_REGION_PARAM && writer_of(ref) < 0; };
+        auto units_of = [&](uint32_t pos) -> uint32_t {   // upper estimate of the memory inputs of one op
+            const H2EOp& op = ops[alive[pos]];
+            if ((op.flags & H2E_FLAG_HINTED) && kind_of(op) == K_MUL) return HINT_UNITS;
+            Opd o[3];
+            int n = operands(op, o);
+            uint32_t u = 0;
+            for (int q = 0; q < n; q++)
+                if (dec[pos].val[q] < 0 && stageable(o[q].ref)) u += o[q].is_int ? INT_UNITS : FE_UNITS;
+            return u;
+        };
         if (pieces_on) {
-            uint32_t since = 0;
+            uint32_t since = 0, units = 0;
             for (uint32_t pos = 1; pos < alive.size(); pos++) {
                 since++;
-                if (since < PIECE_TARGET) continue;
+                units += units_of(pos - 1);
+                if (since < PIECE_TARGET && units < UNIT_TARGET) continue;
                 Restart rs;
                 if (try_restart(pos, rs)) {
                     restarts.push_back(std::move(rs));
                     since = 0;
+                    units = 0;
                 }
             }
         }
@@ -587,7 +625,11 @@ struct h2e_program {
             if (out.size() % H2E_VCHUNK + need > H2E_VCHUNK) pad_chunk();
         };
         // remap: nullptr = the op in its own place; else the prologue copy (slots from the map, nothing stored)
-        auto emit = [&](uint32_t pos, const std::map<int, int>* remap) {
+        struct StageMap {
+            std::map<uint32_t, uint32_t> hint, cells;   // hint slot | strided << 31 -> unit ; first cell ref -> unit
+            uint32_t units = 0;
+        };
+        auto emit = [&](uint32_t pos, const std::map<int, int>* remap, const StageMap& sm) {
             uint32_t i = alive[pos];
             const H2EOp& op = ops[i];
             int k = kind_of(op);
@@ -621,12 +663,20 @@ struct h2e_program {
                 default: vop = H2E_V_FULL; break;
             }
             if (hinted && (op.flags & H2E_FLAG_HINT_STRIDED)) vflags |= H2E_VFLAG_HINT_STRIDED;
+            uint32_t imm = op.imm;
+            if (vop == H2E_V_HINT) {
+                auto it = sm.hint.find(op.imm | ((op.flags & H2E_FLAG_HINT_STRIDED) ? 0x80000000u : 0));
+                if (it != sm.hint.end()) {
+                    vflags |= H2E_VFLAG_STAGED;
+                    imm = it->second;
+                }
+            }
             bool store = !(op.flags & H2E_FLAG_LOCAL_RESULT) || vals[2 * (size_t)i].force_store || vals[2 * (size_t)i + 1].force_store;
             if (k == K_SEL || op.opcode == H2E_OP_AND || op.opcode == H2E_OP_OR || op.opcode == H2E_OP_XNOR || op.opcode == H2E_OP_PICK_INDEX ||
                 op.opcode == H2E_OP_BISEC_INT)
                 store = true;   // never flagged local
             if (store && !remap) vflags |= H2E_VFLAG_STORE;
-            h.w[1] = op.imm;
+            h.w[1] = imm;
             h.w[5] = k == K_FE ? fe_row(op) : op.base_row;
             h.w[6] = k == K_SEL ? op.select_row : op.range_row;
             if (vop == H2E_V_FULL) {
@@ -643,7 +693,14 @@ struct h2e_program {
                         kind = o[q].is_int ? H2E_VSRC_INT_SLOT : H2E_VSRC_FE_SLOT;
                         word = (uint32_t)remap->at(d.val[q]);
                     }
-                    h.w[7] |= kind << (2 * q);
+                    if (kind == H2E_VSRC_GLOBAL && d.val[q] < 0) {   // an input from memory: staged by this piece's gather?
+                        auto it = sm.cells.find(o[q].ref);
+                        if (it != sm.cells.end()) {
+                            kind = H2E_VSRC_STAGE;
+                            word = it->second;
+                        }
+                    }
+                    h.w[7] |= kind << (3 * q);
                     if (kind != H2E_VSRC_GLOBAL) {
                         h.w[2 + q] = word;
                     } else if (o[q].is_int) {
@@ -653,7 +710,7 @@ struct h2e_program {
                         h.w[2 + q] = o[q].ref;
                     }
                 }
-                if (k == K_SEL) h.w[7] |= dst_of(1) << 8;
+                if (k == K_SEL) h.w[7] |= dst_of(1) << 16;
             }
             uint32_t n_ext = (uint32_t)((ext.size() + 7) / 8);
             h.w[0] = vop | (vflags << 8) | (dst << 16) | (n_ext << 24);
@@ -669,32 +726,137 @@ struct h2e_program {
         size_t si = (size_t)(sg - r.segments.data());
         uint32_t vbase = (uint32_t)h_vtape.size();   // multiple of H2E_VCHUNK
         seg_piece_begin[si] = (uint32_t)h_vpieces.size() / 2;
-        size_t next_restart = 0;
-        uint32_t piece_first = 0;
-        for (uint32_t pos = 0; pos < alive.size(); pos++) {
-            if (next_restart < restarts.size() && restarts[next_restart].pos == pos) {
-                h_vpieces.push_back(vbase + piece_first);
-                h_vpieces.push_back(vbase + (uint32_t)out.size());
-                pad_chunk();
-                piece_first = (uint32_t)out.size();
-                for (uint32_t q : restarts[next_restart].prologue) emit(q, &restarts[next_restart].slot_of);
-                next_restart++;
+        uint32_t max_units = 0;
+        // LDS sizing: integer slots actually used; what is left of 140 KB (20 KB are static) bounds the staging units
+        uint32_t used_slots = 1;
+        for (auto& d : dec)
+            for (int w = 0; w < 2; w++)
+                if (d.dst[w] >= 0 && kind_of(ops[alive[&d - dec.data()]]) != K_FE) used_slots = std::max(used_slots, (uint32_t)d.dst[w] + 1);
+        for (auto& rs : restarts)
+            for (auto& kv : rs.slot_of)
+                if (!is_fe_val(kv.first)) used_slots = std::max(used_slots, (uint32_t)kv.second + 1);
+        const uint32_t slot_bytes = (2 * (uint32_t)L + 4) * 512;
+        const uint32_t unit_cap = std::min<uint32_t>(UNIT_MAX, (140u * 1024 - 8192 - used_slots * slot_bytes) / 1024);
+        // one piece: gather records for its memory inputs, the prologue (if it restarts), the body
+        auto emit_piece = [&](const Restart* rs, uint32_t pos_begin, uint32_t pos_end) {
+            uint32_t piece_first = (uint32_t)out.size();
+            StageMap sm;
+            struct GEntry { uint32_t meta, ref; };
+            std::vector<GEntry> gl;
+            auto consider = [&](uint32_t pos, bool in_prologue) {
+                const H2EOp& op = ops[alive[pos]];
+                if ((op.flags & H2E_FLAG_HINTED) && kind_of(op) == K_MUL) {
+                    uint32_t key = op.imm | ((op.flags & H2E_FLAG_HINT_STRIDED) ? 0x80000000u : 0);
+                    if (sm.hint.count(key) || sm.units + HINT_UNITS > unit_cap) return;
+                    sm.hint[key] = sm.units;
+                    for (uint32_t hf = 0; hf < HINT_UNITS; hf++)
+                        gl.push_back(GEntry{1u | (hf << 4) | ((op.flags & H2E_FLAG_HINT_STRIDED) ? 0x100u : 0), op.imm});
+                    sm.units += HINT_UNITS;
+                    return;
+                }
+                if (kind_of(op) == K_FULL || op.opcode == H2E_OP_PICK_INDEX) return;
+                Opd o[3];
+                int n = operands(op, o);
+                for (int q = 0; q < n; q++) {
+                    bool external = dec[pos].val[q] < 0;
+                    (void)in_prologue;
+                    if (!external || !stageable(o[q].ref) || sm.cells.count(o[q].ref)) continue;
+                    uint32_t need = o[q].is_int ? INT_UNITS : FE_UNITS;
+                    bool ok = sm.units + need <= unit_cap;
+                    if (o[q].is_int)
+                        for (int j = 0; j <= L; j++) ok = ok && stageable(op.refs[o[q].refpos + j]);
+                    if (!ok) continue;
+                    sm.cells[o[q].ref] = sm.units;
+                    if (o[q].is_int) {
+                        for (int j = 0; j < L; j++) gl.push_back(GEntry{0u, op.refs[o[q].refpos + j]});   // low 16 bytes of a limb cell
+                        gl.push_back(GEntry{0u, op.refs[o[q].refpos + L]});
+                        gl.push_back(GEntry{0u | (1u << 4), op.refs[o[q].refpos + L]});
+                    } else {
+                        gl.push_back(GEntry{0u, o[q].ref});
+                        gl.push_back(GEntry{0u | (1u << 4), o[q].ref});
+                    }
+                    sm.units += need;
+                }
+            };
+            if (rs)
+                for (uint32_t q : rs->prologue) consider(q, true);
+            for (uint32_t pos = pos_begin; pos < pos_end; pos++) consider(pos, false);
+            if (!stage_on) {
+                sm = StageMap();
+                gl.clear();
             }
-            emit(pos, nullptr);
+            for (size_t e = 0; e < gl.size(); e += 3) {
+                uint32_t n = (uint32_t)std::min<size_t>(3, gl.size() - e);
+                H2EVRec g{{H2E_V_GATHER | (n << 8), (uint32_t)e, 0, 0, 0, 0, 0, 0}};
+                for (uint32_t j = 0; j < n; j++) {
+                    g.w[2 + 2 * j] = gl[e + j].meta;
+                    g.w[3 + 2 * j] = gl[e + j].ref;
+                }
+                out.push_back(g);
+            }
+            if (!gl.empty()) out.push_back(H2EVRec{{H2E_V_GATHER_WAIT, 0, 0, 0, 0, 0, 0, 0}});
+            max_units = std::max(max_units, sm.units);
+            if (rs)
+                for (uint32_t q : rs->prologue) emit(q, &rs->slot_of, sm);
+            for (uint32_t pos = pos_begin; pos < pos_end; pos++) emit(pos, nullptr, sm);
+            h_vpieces.push_back(vbase + piece_first);
+            h_vpieces.push_back(vbase + (uint32_t)out.size());
+            pad_chunk();
+        };
+        {
+            uint32_t begin = 0;
+            for (size_t ri = 0; ri <= restarts.size(); ri++) {
+                uint32_t end = ri < restarts.size() ? restarts[ri].pos : (uint32_t)alive.size();
+                emit_piece(ri == 0 ? nullptr : &restarts[ri - 1], begin, end);
+                begin = end;
+            }
         }
-        h_vpieces.push_back(vbase + piece_first);
-        h_vpieces.push_back(vbase + (uint32_t)out.size());
-        pad_chunk();
         seg_n_pieces[si] = (uint32_t)h_vpieces.size() / 2 - seg_piece_begin[si];
+        seg_v_slots[si] = used_slots;
+        seg_v_units[si] = std::max(1u, max_units);
         h_vtape.insert(h_vtape.end(), out.begin(), out.end());
         if (getenv("H2E_DUMP_TAPE"))
-            fprintf(stderr, "segment %zu: replay %zu alive ops, %zu records, %u pieces\n", si, alive.size(), out.size(), seg_n_pieces[si]);
+            fprintf(stderr, "segment %zu: replay %zu alive ops, %zu records, %u pieces, %u int slots, %u staging units\n", si, alive.size(),
+                    out.size(), seg_n_pieces[si], seg_v_slots[si], seg_v_units[si]);
+    }
+
+    // A segment without cuts normally runs on the caller's (critical) stream because later value-chain kernels may
+    // read any of its cells.  If no reference anywhere (later ops, strand parameters, candidate tables, predictor
+    // arguments, outputs) points into its rows, it can run on the expansion stream instead.
+    void mark_deferrable() {
+        h2e::Recorder& r = *rec;
+        seg_deferrable.assign(r.segments.size(), 0);
+        for (size_t si = 0; si < r.segments.size(); si++) {
+            const h2e::Segment& sg = r.segments[si];
+            if (sg.n_cuts != 0 || sg.tape_end <= sg.tape_begin || !sg.is_fork) continue;
+            uint32_t lo[3] = {sg.base0, sg.range0, sg.select0};
+            uint64_t hi[3] = {sg.base0 + (uint64_t)sg.dbase * sg.n_strands, sg.range0 + (uint64_t)sg.drange * sg.n_strands,
+                              sg.select0 + (uint64_t)sg.dselect * sg.n_strands};
+            auto hits = [&](uint32_t ref) {
+                if (ref == H2E_NO_REF || H2E_REF_REGION(ref) == H2E_REGION_PARAM || H2E_REF_REL(ref)) return false;
+                uint32_t region = H2E_REF_REGION(ref), row = H2E_REF_ROW(ref);
+                return row >= lo[region] && row < hi[region];
+            };
+            bool referenced = false;
+            for (size_t sj = 0; sj < r.segments.size() && !referenced; sj++) {
+                if (sj == si) continue;
+                for (uint32_t i = r.segments[sj].tape_begin; i < r.segments[sj].tape_end && !referenced; i++)
+                    for (int k = 0; k < H2E_OP_MAX_REFS; k++) referenced = referenced || hits(r.tape[i].refs[k]);
+            }
+            for (uint32_t ref : r.aux) referenced = referenced || hits(ref);
+            for (uint32_t ref : r.params) referenced = referenced || hits(ref);
+            for (uint32_t ref : r.outputs) referenced = referenced || hits(ref);
+            for (uint32_t ref : r.pre_args) referenced = referenced || hits(ref);
+            seg_deferrable[si] = referenced ? 0 : 1;
+            if (getenv("H2E_DUMP_TAPE")) fprintf(stderr, "segment %zu deferrable %d\n", si, (int)seg_deferrable[si]);
+        }
     }
 
     void finish() {
         h2e::Recorder& r = *rec;
         r.close_segment();
         mark_local_results();
+        mark_deferrable();
         if (getenv("H2E_DUMP_TAPE")) {   // debugging aid: per segment, ops by opcode (alive / skipped by the values replay)
             for (size_t si = 0; si < r.segments.size(); si++) {
                 auto& sg = r.segments[si];
@@ -747,6 +909,7 @@ struct h2e_ctx {
     std::vector<hipEvent_t> sync_ev;  // cross-stream dependencies
     hipStream_t expand_stream = nullptr;
     hipStream_t early_stream = nullptr;
+    hipStream_t fixup_stream = nullptr;
     uint32_t n_launches = 0;
     ~h2e_ctx() {
         for (auto& kv : cache) delete kv.second;
@@ -756,6 +919,7 @@ struct h2e_ctx {
         for (auto e : sync_ev) (void)hipEventDestroy(e);
         if (expand_stream) (void)hipStreamDestroy(expand_stream);
         if (early_stream) (void)hipStreamDestroy(early_stream);
+        if (fixup_stream) (void)hipStreamDestroy(fixup_stream);
         (void)hipFree(ws_hints);
         (void)hipFree(ws_nd);
         (void)hipFree(ws_jac);
@@ -1080,7 +1244,11 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         }
     }
     if (!ctx->early_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->early_stream, hipStreamNonBlocking));
-    hipStream_t sa = stream, sb = ctx->expand_stream, sc = ctx->early_stream;
+    if (!ctx->fixup_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->fixup_stream, hipStreamNonBlocking));
+    hipStream_t sa = stream, sb = ctx->expand_stream, sc = ctx->early_stream, sd = ctx->fixup_stream;
+    if (getenv("H2E_DEBUG_ONE_STREAM")) sb = sc = sd = sa;   // debugging aid: everything in program order
+    if (getenv("H2E_DEBUG_NO_FIXUP_STREAM")) sd = sb;
+    bool used_sd = false;
     std::vector<hipEvent_t> early_done(r.pre_kernels.size(), nullptr);
     size_t n_sync = 0;
     auto sync_event = [&]() -> hipEvent_t {
@@ -1110,6 +1278,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         if (s.tape_end <= s.tape_begin) continue;
         uint32_t li = ctx->n_launches;
         if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 0), sa));
+        // this segment's predictors: chains first, then (after the early starters below) their finalize kernels
         for (size_t pi = 0; pi < r.pre_kernels.size(); pi++) {
             const h2e::PreKernel& pk = r.pre_kernels[pi];
             if (pk.before_segment != si) continue;
@@ -1117,23 +1286,27 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
                 HIP_TRY(hipStreamWaitEvent(sa, early_done[pi], 0));
                 continue;
             }
-            int prc = h2e_engine_predict(fp, &pk.k, p->d_pre_args, p->d_params, p->d_aux, p->d_inst, n_instances,
-                                         ctx->d_fc[fp], sa);
+            int prc = h2e_engine_predict(fp, 1, &pk.k, p->d_pre_args, p->d_params, p->d_aux, p->d_inst, n_instances, ctx->d_fc[fp], sa);
             if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
         }
-        // predictors of later segments that only depend on this segment's predictors start now, on the side stream
+        // predictors of later segments that only depend on this segment's predictor chains start now, on the side stream
         for (size_t pi = 0; pi < r.pre_kernels.size(); pi++) {
             const h2e::PreKernel& pk = r.pre_kernels[pi];
-            if (pk.early_after_segment != (int32_t)si || pk.before_segment <= si) continue;
+            if (pk.early_after_segment != (int32_t)si || pk.before_segment <= si || getenv("H2E_DEBUG_NO_EARLY")) continue;
             hipEvent_t e0 = sync_event();
             HIP_TRY(hipEventRecord(e0, sa));
             HIP_TRY(hipStreamWaitEvent(sc, e0, 0));
-            int prc = h2e_engine_predict(fp, &pk.k, p->d_pre_args, p->d_params, p->d_aux, p->d_inst, n_instances,
-                                         ctx->d_fc[fp], sc);
+            int prc = h2e_engine_predict(fp, 3, &pk.k, p->d_pre_args, p->d_params, p->d_aux, p->d_inst, n_instances, ctx->d_fc[fp], sc);
             if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
             hipEvent_t e1 = sync_event();
             HIP_TRY(hipEventRecord(e1, sc));
             early_done[pi] = e1;
+        }
+        for (size_t pi = 0; pi < r.pre_kernels.size(); pi++) {
+            const h2e::PreKernel& pk = r.pre_kernels[pi];
+            if (pk.before_segment != si || early_done[pi]) continue;
+            int prc = h2e_engine_predict(fp, 2, &pk.k, p->d_pre_args, p->d_params, p->d_aux, p->d_inst, n_instances, ctx->d_fc[fp], sa);
+            if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
         }
         H2ELaunch L;
         L.tape = p->d_tape + s.tape_begin;
@@ -1160,31 +1333,74 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         L.vtape = compiled ? p->d_vtape : nullptr;
         L.vpieces = compiled ? p->d_vpieces + 2 * (size_t)p->seg_piece_begin[si] : nullptr;
         L.n_vpieces = compiled ? p->seg_n_pieces[si] : 0;
+        L.v_int_slots = compiled ? p->seg_v_slots[si] : 0;
+        L.v_units = compiled ? p->seg_v_units[si] : 0;
         int lrc;
+        auto launch = [&](int mode, hipStream_t st) -> int {
+            int rc2 = h2e_engine_launch(fp, mode, &L, p->d_inst, n_instances, ctx->d_fc[fp], st);
+            if (rc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc2));
+            return 0;
+        };
+        // the inverse fix-up of a segment only touches cells nothing else reads or writes: own stream, after the expansion
+        auto fixup_after = [&](hipStream_t st) -> int {
+            if (!s.n_fixups) return 0;
+            hipEvent_t e = sync_event();
+            HIP_TRY(hipEventRecord(e, st));
+            HIP_TRY(hipStreamWaitEvent(sd, e, 0));
+            used_sd = true;
+            return launch(4, sd);
+        };
         if (L.n_sub > 1) {
-            lrc = h2e_engine_launch(fp, 1, &L, p->d_inst, n_instances, ctx->d_fc[fp], sa);
-            if (lrc != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)lrc));
+            if ((lrc = launch(1, sa))) return lrc;
             if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, sa));
             HIP_TRY(hipStreamWaitEvent(sb, e, 0));
             if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sb));
-            lrc = h2e_engine_launch(fp, 2 | 4, &L, p->d_inst, n_instances, ctx->d_fc[fp], sb);
-            if (lrc != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)lrc));
+            // test hook: leave out the expansion of cut segment <si> (or, with -1, of every cut segment but the last):
+            // whatever the value chain reads must have been stored by the value chain itself (tests/test_parity_gpu.py)
+            bool skip_x = false;
+            if (const char* sx = getenv("H2E_DEBUG_SKIP_X")) {
+                bool later_cut = false;
+                for (size_t sj = si + 1; sj < r.segments.size(); sj++) later_cut = later_cut || p->seg_n_sub[sj] > 1;
+                skip_x = atoi(sx) == (int)si || (atoi(sx) == -1 && later_cut);
+            }
+            if (!skip_x && (lrc = launch(2, sb))) return lrc;
             if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sb));
+            if (!skip_x && (lrc = fixup_after(sb))) return lrc;
+        } else if (p->seg_deferrable[si]) {
+            // nothing later reads this segment's cells: off the critical stream
+            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
+            hipEvent_t e = sync_event();
+            HIP_TRY(hipEventRecord(e, sa));
+            HIP_TRY(hipStreamWaitEvent(sb, e, 0));
+            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sb));
+            if ((lrc = launch(2, sb))) return lrc;
+            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sb));
+            if ((lrc = fixup_after(sb))) return lrc;
         } else {
             if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
             if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sa));
-            lrc = h2e_engine_launch(fp, 2 | 4, &L, p->d_inst, n_instances, ctx->d_fc[fp], sa);
-            if (lrc != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)lrc));
+            if ((lrc = launch(2, sa))) return lrc;
             if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sa));
+            if ((lrc = fixup_after(sa))) return lrc;
+        }
+        if (getenv("H2E_DEBUG_JOIN_AFTER") && (int)si == atoi(getenv("H2E_DEBUG_JOIN_AFTER"))) {   // debugging aid
+            hipEvent_t e = sync_event();
+            HIP_TRY(hipEventRecord(e, sb));
+            HIP_TRY(hipStreamWaitEvent(sa, e, 0));
         }
         ctx->n_launches++;
     }
-    {   // join: the caller's stream completes when the expansion stream does
+    {   // join: the caller's stream completes when the expansion and fix-up streams do
         hipEvent_t e = sync_event();
         HIP_TRY(hipEventRecord(e, sb));
         HIP_TRY(hipStreamWaitEvent(sa, e, 0));
+        if (used_sd) {
+            hipEvent_t e2 = sync_event();
+            HIP_TRY(hipEventRecord(e2, sd));
+            HIP_TRY(hipStreamWaitEvent(sa, e2, 0));
+        }
     }
     return 0;
 }

@@ -161,6 +161,7 @@ typedef struct H2ELaunch {
     const struct H2EVRec* vtape;  // compiled values-only replay (cut segments only): the program's record array
     const uint32_t* vpieces;      // [n_vpieces][2] first / end record of each independent piece of this segment's replay
     uint32_t n_vpieces;
+    uint32_t v_int_slots, v_units; // LDS sizing of the replay kernel: integer slots and 16-byte staging units per lane
 } H2ELaunch;
 
 // ---- compiled values-only replay ("V-tape") ----------------------------------------------------
@@ -169,11 +170,16 @@ typedef struct H2ELaunch {
 // operand already resolved to either an LDS slot (static allocation by live range, spilled values go through
 // their cells) or a cell reference.  An op = one header record + n_ext extension records of 8 words.
 //   w[0] = vopcode | vflags << 8 | dst slot << 16 | n_ext << 24        (dst 0xff: result not kept in a slot)
-//   w[1] = imm            (times / k / hint slot / aux offset)
-//   w[2..4] = src0..2     int in a slot: slot; fe in a slot: slot; global fe: the cell ref;
+//   w[1] = imm            (times / k / hint slot or staging unit / aux offset)
+//   w[2..4] = src0..2     int / fe in a slot: slot; staged int / fe: first staging unit; global fe: the cell ref;
 //                         global int: word offset into the op's extension records of its L+1 cell refs
 //   w[5] = base row, w[6] = range (SELECT_POINT: select) row of the result cells (strand relative like the tape's)
-//   w[7] = operand kinds, 2 bits per source (H2E_VSRC_*); SELECT_POINT: bits 8..15 second dst slot
+//   w[7] = operand kinds, 3 bits per source (H2E_VSRC_*); SELECT_POINT: bits 16..23 second dst slot
+// Inputs that come from memory (hints, cells written by other kernels) are *staged*: each piece of the replay starts
+// with H2E_V_GATHER records listing them in 16-byte units; the kernel issues them as asynchronous global->LDS loads
+// and waits once (H2E_V_GATHER_WAIT), so the dependent chain itself never waits for memory.
+//   gather record: w[0] = H2E_V_GATHER | n << 8 (n <= 3 entries), w[1] = first staging unit,
+//                  w[2 + 2e] = kind (0 cell, 1 hint) | 16-byte piece << 4 | strided << 8, w[3 + 2e] = cell ref / hint slot
 typedef struct H2EVRec {
     uint32_t w[8];
 } H2EVRec;
@@ -185,14 +191,17 @@ enum H2EVOpcode {
     H2E_V_ADD, H2E_V_SUB, H2E_V_NEG, H2E_V_MUL_SMALL, H2E_V_MASK, H2E_V_BISEC_INT,
     H2E_V_IS_ZERO, H2E_V_NOT, H2E_V_AND, H2E_V_OR, H2E_V_XNOR, H2E_V_PICK_INDEX,
     H2E_V_SELECT_POINT,
-    H2E_V_FULL           // run the tape op held in the 2 extension records as it is (its rows are its results)
+    H2E_V_FULL,          // run the tape op held in the 2 extension records as it is (its rows are its results)
+    H2E_V_GATHER, H2E_V_GATHER_WAIT
 };
 #define H2E_VFLAG_STORE 1u          // the result is also written to its cells
 #define H2E_VFLAG_HINT_STRIDED 2u
+#define H2E_VFLAG_STAGED 4u         // H2E_V_HINT: imm is a staging unit
 #define H2E_VSRC_NONE 0u
 #define H2E_VSRC_INT_SLOT 1u
 #define H2E_VSRC_FE_SLOT 2u
 #define H2E_VSRC_GLOBAL 3u
+#define H2E_VSRC_STAGE 4u
 #define H2E_V_NO_SLOT 0xffu
 
 // ---- value-predictor ("V") kernels for the MSM ---------------------------------------------------

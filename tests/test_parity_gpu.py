@@ -71,6 +71,27 @@ def test_msm_tile(engine, oracle, n):
         compare_advice(prog, orun, base, rng, sel, instance=k)
 
 
+def test_msm_value_chain_does_not_depend_on_expansion(engine, oracle, monkeypatch):
+    """The expansion of a cut segment runs on its own stream, concurrently with the value chain of the following
+    segments, so the value chain may only read cells the value chain itself stored.  With the expansion of every
+    cut segment but the last left out (test hook), the last segment - the MSM tail, which reads the windows' sums -
+    must still come out exactly right.  (Regression: the tail's references into the windows were not counted.)"""
+    n = 24
+    inp, _ = synth.msm_bn256_tile_inputs(n, tile=3)
+    prog = Program.msm_bn256_tile(n)
+    monkeypatch.setenv("H2E_DEBUG_SKIP_X", "-1")
+    base, rng, sel, status = _run(engine, prog, [inp])
+    monkeypatch.delenv("H2E_DEBUG_SKIP_X")
+    assert (status == 0).all(), status
+    orun = oracle_lib.run_msm_bn256_tile(n, inp)
+    assert orun.info.status == 0, orun.error
+    win = prog.launches()[-2]
+    tail0 = win["base0"] + win["dbase"] * win["n_strands"]
+    ovals, _ = orun.adv(0, prog.base_rows)
+    got = base[0].cpu().numpy().view(np.uint64)
+    assert np.array_equal(got[tail0:], ovals[tail0:]), "tail differs when the windows' expansion is left out"
+
+
 def test_msm_tile_with_identity_inputs(engine, oracle):
     """identity points go through ecc_bisec_to_non_zero_point / ecc_bisec_scalar (quirk Q9)"""
     n = 6
