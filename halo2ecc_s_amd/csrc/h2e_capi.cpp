@@ -843,12 +843,100 @@ struct h2e_program {
                 for (uint32_t i = r.segments[sj].tape_begin; i < r.segments[sj].tape_end && !referenced; i++)
                     for (int k = 0; k < H2E_OP_MAX_REFS; k++) referenced = referenced || hits(r.tape[i].refs[k]);
             }
-            for (uint32_t ref : r.aux) referenced = referenced || hits(ref);
-            for (uint32_t ref : r.params) referenced = referenced || hits(ref);
+            bool dbg = getenv("H2E_DUMP_TAPE") != nullptr;
+            if (dbg && referenced) fprintf(stderr, "segment %zu referenced by ops\n", si);
+            for (uint32_t ref : r.aux) if (hits(ref)) { if (dbg && !referenced) fprintf(stderr, "segment %zu referenced by aux %08x\n", si, ref); referenced = true; }
+            for (uint32_t ref : r.params) if (hits(ref)) { if (dbg && !referenced) fprintf(stderr, "segment %zu referenced by params %08x\n", si, ref); referenced = true; }
             for (uint32_t ref : r.outputs) referenced = referenced || hits(ref);
-            for (uint32_t ref : r.pre_args) referenced = referenced || hits(ref);
+            for (uint32_t ref : r.pre_args) if (hits(ref)) { if (dbg && !referenced) fprintf(stderr, "segment %zu referenced by pre_args %08x\n", si, ref); referenced = true; }
             seg_deferrable[si] = referenced ? 0 : 1;
             if (getenv("H2E_DUMP_TAPE")) fprintf(stderr, "segment %zu deferrable %d\n", si, (int)seg_deferrable[si]);
+        }
+    }
+
+    // A fork segment without cuts that only reads segments without cuts (the scalar decomposition: it reads the
+    // assigned scalars, and only the MSM windows read its bits) need not sit in the value chain between its neighbours:
+    // it runs on a side stream as soon as the last segment it reads is done, and the first segment that reads it waits.
+    std::vector<int32_t> seg_side_dep;      // -2: not a side segment; else index of the last segment it depends on (-1: none)
+    std::vector<uint32_t> seg_first_reader; // for side segments: first later segment that references its rows
+    void mark_side_segments() {
+        h2e::Recorder& r = *rec;
+        size_t ns = r.segments.size();
+        seg_side_dep.assign(ns, -2);
+        seg_first_reader.assign(ns, (uint32_t)ns);
+        // first rows of every non-empty segment, per region (rows are handed out in program order)
+        std::vector<uint32_t> ids;
+        std::vector<std::array<uint32_t, 3>> start;
+        for (size_t si = 0; si < ns; si++) {
+            const h2e::Segment& sg = r.segments[si];
+            if (sg.tape_end <= sg.tape_begin) continue;
+            std::array<uint32_t, 3> st;
+            if (sg.is_fork) st = {sg.base0, sg.range0, sg.select0};
+            else st = {r.tape[sg.tape_begin].base_row, r.tape[sg.tape_begin].range_row, r.tape[sg.tape_begin].select_row};
+            ids.push_back((uint32_t)si);
+            start.push_back(st);
+        }
+        auto segment_of = [&](uint32_t ref) -> int {
+            if (ref == H2E_NO_REF || H2E_REF_REGION(ref) == H2E_REGION_PARAM || H2E_REF_REL(ref)) return -1;
+            uint32_t region = H2E_REF_REGION(ref), row = H2E_REF_ROW(ref);
+            int ans = -1;
+            for (size_t k = 0; k < ids.size(); k++)
+                if (start[k][region] <= row) ans = (int)ids[k];
+            return ans;
+        };
+        for (size_t si = 0; si < ns; si++) {
+            const h2e::Segment& sg = r.segments[si];
+            if (sg.n_cuts != 0 || sg.tape_end <= sg.tape_begin || !sg.is_fork) continue;
+            bool has_pre = false;
+            for (auto& pk : r.pre_kernels) has_pre = has_pre || pk.before_segment == si;
+            if (has_pre) continue;
+            int last_dep = -1;
+            bool ok = true;
+            auto dep = [&](uint32_t ref) {
+                int sj = segment_of(ref);
+                if (sj < 0) return;
+                if ((size_t)sj >= si) { ok = false; return; }
+                if (r.segments[sj].n_cuts != 0) ok = false;
+                if (seg_side_dep[sj] != -2) return;   // another side segment: the side stream runs them in order
+                last_dep = std::max(last_dep, sj);
+            };
+            for (uint32_t i = sg.tape_begin; i < sg.tape_end; i++)
+                for (int k = 0; k < H2E_OP_MAX_REFS; k++) dep(r.tape[i].refs[k]);
+            for (size_t q = 0; q < (size_t)sg.n_params * sg.n_strands; q++)
+                if (sg.params_begin + q < r.params.size()) dep(r.params[sg.params_begin + q]);
+            if (!ok) continue;
+            // first later reader
+            uint32_t lo[3] = {sg.base0, sg.range0, sg.select0};
+            uint64_t hi[3] = {sg.base0 + (uint64_t)sg.dbase * sg.n_strands, sg.range0 + (uint64_t)sg.drange * sg.n_strands,
+                              sg.select0 + (uint64_t)sg.dselect * sg.n_strands};
+            auto hits = [&](uint32_t ref) {
+                if (ref == H2E_NO_REF || H2E_REF_REGION(ref) == H2E_REGION_PARAM || H2E_REF_REL(ref)) return false;
+                uint32_t region = H2E_REF_REGION(ref), row = H2E_REF_ROW(ref);
+                return row >= lo[region] && row < hi[region];
+            };
+            uint32_t first_reader = (uint32_t)ns;
+            for (size_t sj = si + 1; sj < ns && first_reader == ns; sj++) {
+                const h2e::Segment& sr = r.segments[sj];
+                bool reads = false;
+                for (uint32_t i = sr.tape_begin; i < sr.tape_end && !reads; i++)
+                    for (int k = 0; k < H2E_OP_MAX_REFS; k++) reads = reads || hits(r.tape[i].refs[k]);
+                for (size_t q = 0; q < (size_t)sr.n_params * sr.n_strands && !reads; q++)
+                    if (sr.params_begin + q < r.params.size()) reads = hits(r.params[sr.params_begin + q]);
+                for (auto& pk : r.pre_kernels) {
+                    if (pk.before_segment != sj || reads) continue;
+                    for (uint32_t q = 0; q < pk.k.n_params * pk.k.n_lanes && !reads; q++)
+                        if (pk.k.params_begin + q < r.params.size()) reads = hits(r.params[pk.k.params_begin + q]);
+                    reads = reads || true;   // predictor arguments are not delimited per kernel: be conservative
+                }
+                if (reads) first_reader = (uint32_t)sj;
+            }
+            bool in_aux = false;
+            for (uint32_t ref : r.aux) in_aux = in_aux || hits(ref);
+            if (in_aux) first_reader = std::min<uint32_t>(first_reader, (uint32_t)si + 1);
+            if (first_reader <= si + 1) continue;   // nothing to overlap with
+            seg_side_dep[si] = last_dep;
+            seg_first_reader[si] = first_reader;
+            if (getenv("H2E_DUMP_TAPE")) fprintf(stderr, "segment %zu: side stream after segment %d, first reader %u\n", si, last_dep, first_reader);
         }
     }
 
@@ -857,6 +945,7 @@ struct h2e_program {
         r.close_segment();
         mark_local_results();
         mark_deferrable();
+        mark_side_segments();
         if (getenv("H2E_DUMP_TAPE")) {   // debugging aid: per segment, ops by opcode (alive / skipped by the values replay)
             for (size_t si = 0; si < r.segments.size(); si++) {
                 auto& sg = r.segments[si];
@@ -910,6 +999,7 @@ struct h2e_ctx {
     hipStream_t expand_stream = nullptr;
     hipStream_t early_stream = nullptr;
     hipStream_t fixup_stream = nullptr;
+    hipStream_t side_stream = nullptr;
     uint32_t n_launches = 0;
     ~h2e_ctx() {
         for (auto& kv : cache) delete kv.second;
@@ -920,6 +1010,7 @@ struct h2e_ctx {
         if (expand_stream) (void)hipStreamDestroy(expand_stream);
         if (early_stream) (void)hipStreamDestroy(early_stream);
         if (fixup_stream) (void)hipStreamDestroy(fixup_stream);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
         (void)hipFree(ws_hints);
         (void)hipFree(ws_nd);
         (void)hipFree(ws_jac);
@@ -1273,9 +1364,21 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         HIP_TRY(hipStreamWaitEvent(sb, e, 0));
     }
     ctx->n_launches = 0;
+    if (!ctx->side_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    hipStream_t se = getenv("H2E_DEBUG_ONE_STREAM") ? sa : ctx->side_stream;
+    std::vector<hipEvent_t> seg_ev(r.segments.size(), nullptr), side_done(r.segments.size(), nullptr);
+    hipEvent_t run_begin = sync_event();
+    HIP_TRY(hipEventRecord(run_begin, sa));
+    bool used_se = false;
     for (size_t si = 0; si < r.segments.size(); si++) {
         const h2e::Segment& s = r.segments[si];
         if (s.tape_end <= s.tape_begin) continue;
+        // side segments this one reads must be done
+        for (size_t sj = 0; sj < si; sj++)
+            if (side_done[sj] && p->seg_first_reader[sj] <= si) {
+                HIP_TRY(hipStreamWaitEvent(sa, side_done[sj], 0));
+                side_done[sj] = nullptr;
+            }
         uint32_t li = ctx->n_launches;
         if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 0), sa));
         // this segment's predictors: chains first, then (after the early starters below) their finalize kernels
@@ -1368,6 +1471,18 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
             if (!skip_x && (lrc = launch(2, sb))) return lrc;
             if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sb));
             if (!skip_x && (lrc = fixup_after(sb))) return lrc;
+        } else if (p->seg_side_dep[si] != -2 && !getenv("H2E_DEBUG_NO_SIDE")) {
+            // runs beside the value chain: after the last segment it reads, before the first segment that reads it
+            int32_t depi = p->seg_side_dep[si];
+            HIP_TRY(hipStreamWaitEvent(se, depi >= 0 && seg_ev[depi] ? seg_ev[depi] : run_begin, 0));
+            used_se = true;
+            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
+            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), se));
+            if ((lrc = launch(2, se))) return lrc;
+            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), se));
+            if ((lrc = fixup_after(se))) return lrc;
+            side_done[si] = sync_event();
+            HIP_TRY(hipEventRecord(side_done[si], se));
         } else if (p->seg_deferrable[si]) {
             // nothing later reads this segment's cells: off the critical stream
             if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
@@ -1385,6 +1500,8 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
             if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sa));
             if ((lrc = fixup_after(sa))) return lrc;
         }
+        seg_ev[si] = sync_event();
+        HIP_TRY(hipEventRecord(seg_ev[si], sa));
         if (getenv("H2E_DEBUG_JOIN_AFTER") && (int)si == atoi(getenv("H2E_DEBUG_JOIN_AFTER"))) {   // debugging aid
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, sb));
@@ -1400,6 +1517,11 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
             hipEvent_t e2 = sync_event();
             HIP_TRY(hipEventRecord(e2, sd));
             HIP_TRY(hipStreamWaitEvent(sa, e2, 0));
+        }
+        if (used_se) {
+            hipEvent_t e3 = sync_event();
+            HIP_TRY(hipEventRecord(e3, se));
+            HIP_TRY(hipStreamWaitEvent(sa, e3, 0));
         }
     }
     return 0;

@@ -425,10 +425,12 @@ struct NativeScalarEccContext {
             c.n_jac_slots += n_lanes << sz;
             return pk;
         };
+        int32_t full_seg_index = -1;
         if (n_full > 0) {
             uint32_t hbase = c.n_hint_slots;
             c.n_hint_slots += (uint32_t)n_full * ((1u << group_size) - 1);
             uint32_t seg_index = (uint32_t)c.segments.size();  // index the fork segment will get
+            full_seg_index = (int32_t)seg_index;
             c.begin_hints(hbase);
             c.fork((uint32_t)n_full, 0, [&](uint32_t g) {
                 std::vector<AssignedNonZeroPoint> pts;
@@ -473,6 +475,8 @@ struct NativeScalarEccContext {
                 c.params.insert(c.params.end(), refs.begin(), refs.end());
                 PreKernel pk = add_candidates_pre(1, (uint32_t)pts.size(), hbase, pbegin, (uint32_t)refs.size());
                 pk.before_segment = (uint32_t)c.segments.size() - 1;  // the current main segment
+                // it only reads the points and the random line point, like the full groups' predictor: side stream
+                pk.early_after_segment = full_seg_index;
                 c.pre_kernels.push_back(pk);
                 c.begin_hints(hbase);
             }
