@@ -999,7 +999,6 @@ struct h2e_ctx {
     hipStream_t expand_stream = nullptr;
     hipStream_t early_stream = nullptr;
     hipStream_t fixup_stream = nullptr;
-    hipStream_t side_stream = nullptr;
     uint32_t n_launches = 0;
     ~h2e_ctx() {
         for (auto& kv : cache) delete kv.second;
@@ -1010,7 +1009,6 @@ struct h2e_ctx {
         if (expand_stream) (void)hipStreamDestroy(expand_stream);
         if (early_stream) (void)hipStreamDestroy(early_stream);
         if (fixup_stream) (void)hipStreamDestroy(fixup_stream);
-        if (side_stream) (void)hipStreamDestroy(side_stream);
         (void)hipFree(ws_hints);
         (void)hipFree(ws_nd);
         (void)hipFree(ws_jac);
@@ -1364,12 +1362,16 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         HIP_TRY(hipStreamWaitEvent(sb, e, 0));
     }
     ctx->n_launches = 0;
-    if (!ctx->side_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-    hipStream_t se = getenv("H2E_DEBUG_ONE_STREAM") ? sa : ctx->side_stream;
+    // (the runtime maps streams onto 4 hardware queues by default: a fifth stream would share one and serialise behind
+    // it, so the side segments use the early-predictor stream)
+    hipStream_t se = sc;
     std::vector<hipEvent_t> seg_ev(r.segments.size(), nullptr), side_done(r.segments.size(), nullptr);
     hipEvent_t run_begin = sync_event();
     HIP_TRY(hipEventRecord(run_begin, sa));
     bool used_se = false;
+    H2ELaunch pending_L;
+    uint32_t pending_li = 0;
+    bool have_pending = false;
     for (size_t si = 0; si < r.segments.size(); si++) {
         const h2e::Segment& s = r.segments[si];
         if (s.tape_end <= s.tape_begin) continue;
@@ -1456,6 +1458,33 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         if (L.n_sub > 1) {
             if ((lrc = launch(1, sa))) return lrc;
             if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
+            if (have_pending) {   // the previous segment's expansion was held back behind this (tiny) value chain
+                hipEvent_t e0 = sync_event();
+                HIP_TRY(hipEventRecord(e0, sa));
+                HIP_TRY(hipStreamWaitEvent(sb, e0, 0));
+                if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 2), sb));
+                int prc2 = h2e_engine_launch(fp, 2, &pending_L, p->d_inst, n_instances, ctx->d_fc[fp], sb);
+                if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
+                if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 3), sb));
+                if (pending_L.n_fixups) {
+                    hipEvent_t e1 = sync_event();
+                    HIP_TRY(hipEventRecord(e1, sb));
+                    HIP_TRY(hipStreamWaitEvent(sd, e1, 0));
+                    used_sd = true;
+                    prc2 = h2e_engine_launch(fp, 4, &pending_L, p->d_inst, n_instances, ctx->d_fc[fp], sd);
+                    if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
+                }
+                have_pending = false;
+            }
+            if (s.expand_after_next && si + 1 < r.segments.size() && p->seg_n_sub[si + 1] > 1 && !getenv("H2E_DEBUG_NO_HOLD")) {
+                pending_L = L;
+                pending_li = li;
+                have_pending = true;
+                ctx->n_launches++;
+                seg_ev[si] = sync_event();
+                HIP_TRY(hipEventRecord(seg_ev[si], sa));
+                continue;
+            }
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, sa));
             HIP_TRY(hipStreamWaitEvent(sb, e, 0));
@@ -1509,6 +1538,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         }
         ctx->n_launches++;
     }
+    if (have_pending) return fail(H2E_ERR_INVALID, "internal: a held-back expansion was never launched");
     {   // join: the caller's stream completes when the expansion and fix-up streams do
         hipEvent_t e = sync_event();
         HIP_TRY(hipEventRecord(e, sb));

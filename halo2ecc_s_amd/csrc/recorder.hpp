@@ -186,6 +186,9 @@ struct Segment {  // one engine launch
     uint32_t fixups_begin = 0, n_fixups = 0;
     uint32_t cuts_begin = 0, n_cuts = 0;  // op indices (relative to tape_begin) where the expansion may be split
     bool is_fork = false;
+    // scheduling hint: the next segment's value chain is tiny (a handful of waves that need most of a CU's LDS); this
+    // segment's bandwidth-bound expansion would starve it, so the expansion is launched behind that chain
+    bool expand_after_next = false;
 };
 
 struct PreKernel {  // a value-predictor launch that must run before segment `before_segment`

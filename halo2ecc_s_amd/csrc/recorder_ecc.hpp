@@ -445,6 +445,7 @@ struct NativeScalarEccContext {
                 if (g == 0) cl0 = cl;
             });
             c.end_hints();
+            if (n_chunks > n_full) c.segments[c.segments.size() - 2].expand_after_next = true;   // the remainder group's one-lane chain follows
             Segment seg_groups = c.segments[c.segments.size() - 2];
             {
                 PreKernel pk = add_candidates_pre((uint32_t)n_full, (uint32_t)group_size, hbase, seg_groups.params_begin, seg_groups.n_params);
