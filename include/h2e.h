@@ -13,7 +13,8 @@
  *    values (what `field_to_bn` sees, src/utils.rs:4-8), 4 words each;
  *  - advice arrays are row-major like the reference's `Vec<[(Option<N>, bool); COLS]>`
  *    (src/context.rs:243-251): base [rows][5][4], range [rows][3][4], select [rows][2][4] words; cells the
- *    shape leaves unassigned are never written (allocate zero-filled);
+ *    shape leaves unassigned are written as zero (the engine stores whole rows: rows with holes cost HBM
+ *    bandwidth), so the arrays need no initialisation;
  *  - inputs: [n_instances][n_input_slots][slot_words] words; a slot holds one W value (canonical) or one
  *    Fr value / flag in its first 4 words;
  *  - device pointers are plain `void*` from any allocator (hipMalloc, torch); the engine never frees
@@ -115,7 +116,9 @@ int h2e_program_launches(const h2e_program* p, uint64_t* out, uint32_t cap);
 /* ---- execution --------------------------------------------------------------------------------- */
 /* Fill the advice values of n_instances instances.  d_base/d_range/d_select: device arrays of
  * n_instances * rows * cols * 4 words (instance-major); d_inputs as described above; d_status:
- * n_instances uint32 (or-ed, zero it first).  Asynchronous on `stream`. */
+ * n_instances uint32 (or-ed, zero it first).  Asynchronous on `stream`: the engine fans the work out over
+ * three internal streams of the context (expansion, early predictors / side segments, inverse fix-up), all of them
+ * ordered after what is already queued on `stream`, and `stream` completes only when all of them have. */
 int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
             void* d_select, void* d_status, void* stream);
 
@@ -131,7 +134,7 @@ int h2e_pairing_check_bls12_381(h2e_ctx* ctx, uint32_t n_instances, const void* 
 
 /* Timing hook used by bench.py: HIP events recorded by the engine on the stream each kernel group is launched
  * on.  Returns the number of launched segments and fills two numbers per segment: ms[2i] = value chain
- * (predictor kernels + values-only replay), ms[2i+1] = full expansion + inverse fix-up (call after synchronising). */
+ * (predictor kernels + values-only replay), ms[2i+1] = full expansion (the inverse fix-up runs on its own stream and is not included; call after synchronising). */
 int h2e_last_run_launch_ms(h2e_ctx* ctx, float* ms, uint32_t cap);
 int h2e_set_profiling(h2e_ctx* ctx, int enable);
 
