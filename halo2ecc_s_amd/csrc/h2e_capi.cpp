@@ -538,18 +538,30 @@ struct h2e_program {
         const uint32_t PIECE_TARGET = 96, PIECE_BUDGET = 40;
         static const bool pieces_on = !getenv("H2E_NO_PIECES");
         static const bool stage_on = !getenv("H2E_NO_STAGE");
-        auto try_restart = [&](uint32_t p, Restart& rs) -> bool {
-            for (uint32_t q = 0; q < p; q++)
-                if (kind_of(ops[alive[q]]) == K_FULL && full_read_last[alive[q]] >= p) return false;   // its rows are read across the cut
-            // live set
+        // positions that can never be cut: an op at or after p reads a *cell* written before p (rows of a V_FULL op, or
+        // a value that lost / never had its slot) - difference arrays over (writer, last reader]
+        std::vector<int32_t> blocked(alive.size() + 2, 0);
+        for (uint32_t q = 0; q < alive.size(); q++)
+            if (kind_of(ops[alive[q]]) == K_FULL && full_read_last[alive[q]] > q) {
+                blocked[q + 1]++;
+                blocked[full_read_last[alive[q]] + 1]--;
+            }
+        for (int v : produced)
+            if (vals[v].cell_use_last != INF && vals[v].cell_use_last > prod_pos(v)) {
+                blocked[prod_pos(v) + 1]++;
+                blocked[vals[v].cell_use_last + 1]--;
+            }
+        for (size_t q = 1; q < blocked.size(); q++) blocked[q] += blocked[q - 1];
+        // values whose last slot-use is at a given position (to keep the live set incrementally)
+        std::vector<std::vector<int>> expires(alive.size() + 1);
+        for (int v : produced)
+            if (!vals[v].uses.empty()) expires[last_use(v)].push_back(v);
+        auto try_restart = [&](uint32_t p, const std::set<int>& live_set, Restart& rs) -> bool {
+            if (blocked[p] > 0) return false;
             std::vector<int> live;
-            for (int v : produced) {
-                if (prod_pos(v) >= p) break;
-                if (vals[v].cell_use_last != INF && vals[v].cell_use_last >= p) return false;   // a later op reads its cell
-                if (!vals[v].uses.empty() && last_use(v) >= p) {
-                    if (vals[v].dst_slot < 0 || vals[v].evicted) return false;
-                    live.push_back(v);
-                }
+            for (int v : live_set) {
+                if (vals[v].dst_slot < 0 || vals[v].evicted) return false;
+                live.push_back(v);
             }
             std::set<uint32_t> closure;
             std::set<int> cvals;
@@ -603,16 +615,27 @@ struct h2e_program {
             return u;
         };
         if (pieces_on) {
-            uint32_t since = 0, units = 0;
+            uint32_t since = 0, units = 0, retry_at = 0;
+            std::set<int> live_set;   // values produced before pos with a slot-use at or after pos
             for (uint32_t pos = 1; pos < alive.size(); pos++) {
+                {   // advance the live set from pos - 1 to pos
+                    uint32_t i = alive[pos - 1];
+                    int k = kind_of(ops[i]);
+                    int nres = k == K_SEL ? 2 : (k == K_MUL || k == K_ADD || k == K_FE) ? 1 : 0;
+                    for (int w = 0; w < nres; w++)
+                        if (!vals[2 * (size_t)i + w].uses.empty() && last_use(2 * (int)i + w) >= pos) live_set.insert(2 * (int)i + w);
+                    for (int v : expires[pos - 1]) live_set.erase(v);
+                }
                 since++;
                 units += units_of(pos - 1);
-                if (since < PIECE_TARGET && units < UNIT_TARGET) continue;
+                if ((since < PIECE_TARGET && units < UNIT_TARGET) || pos < retry_at) continue;
                 Restart rs;
-                if (try_restart(pos, rs)) {
+                if (try_restart(pos, live_set, rs)) {
                     restarts.push_back(std::move(rs));
                     since = 0;
                     units = 0;
+                } else {
+                    retry_at = pos + 4;   // (a failed attempt costs a closure walk: do not try every position)
                 }
             }
         }
