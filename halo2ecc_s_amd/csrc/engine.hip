@@ -55,6 +55,7 @@ struct InstanceDesc {
     u64* hints;         // [n_hint_slots][4]   quotient hints for H2E_OP_DIV_CORE (canonical values)
     u64* nd;            // [n_hint_slots][2][4] numerator / denominator pairs (Montgomery form) of the V kernels
     u64* jac;           // [n_jac_slots][3][WW] Jacobian scratch of the V kernels
+    u64* sel;           // [n_sel_slots][H2E_SEL_WORDS] points picked by the select pre-kernel
 };
 
 struct LC {  // lane context
@@ -71,6 +72,8 @@ struct LC {  // lane context
     u32 strand, input_stride;
     const u64* hints;
     u32 hint_stride;
+    const u64* sel;     // selection buffer (H2E_FLAG_PRESELECTED)
+    u32 sel_stride;
     struct Stage* st;   // LDS row staging (see rowB)
     bool active;        // false for the padding lanes of the last wave: compute, but store nothing
 };
@@ -1421,8 +1424,10 @@ WI_INLINE void exec_vop(const VSlots<FP>& vs, const LC& c, const VHdr& h, const 
             if (e < n) {
                 u32 meta = h.w[2 + 2 * e], ref = h.w[3 + 2 * e];
                 const u64* src;
-                if (meta & 1u)
+                if ((meta & 3u) == 1u)
                     src = c.hints + (size_t)(ref + ((meta & 0x100u) ? c.strand * c.hint_stride : 0)) * H2E_W_WORDS_MAX;
+                else if ((meta & 3u) == 2u)
+                    src = c.sel + (size_t)(ref + c.strand * c.sel_stride) * H2E_SEL_WORDS;
                 else
                     src = cell_ptr(c, ref);
                 src += ((meta >> 4) & 0xfu) * 2;
@@ -1568,6 +1573,25 @@ WI_INLINE void exec_vop(const VSlots<FP>& vs, const LC& c, const VHdr& h, const 
         }
         return;
     }
+    if (opc == H2E_V_LOAD_SEL) {   // a point picked by the select pre-kernel: x, y canonical -> two integer slots
+        Wd<FP::WW> xy[2];
+        if (((h.w[7]) & 7u) == H2E_VSRC_STAGE) {
+            xy[0] = vs_stage_w<FP>(vs, h.w[2]);
+            xy[1] = vs_stage_w<FP>(vs, h.w[2] + VSlots<FP>::HINT_UNITS);
+        } else {
+            const u64* p = c.sel + (size_t)(h.w[2] + c.strand * c.sel_stride) * H2E_SEL_WORDS;
+            xy[0] = wd_load<FP::WW>(p);
+            xy[1] = wd_load<FP::WW>(p + H2E_W_WORDS_MAX);
+        }
+        u32 dst[2] = {(h.w[0] >> 16) & 0xffu, (h.w[7] >> 16) & 0xffu};
+#pragma unroll
+        for (int which = 0; which < 2; which++) {
+            Limb l[L];
+            split_limbs<FP>(xy[which], l);
+            if (dst[which] != H2E_V_NO_SLOT) vs_st_int<FP>(vs, dst[which], l, native_of_w<FP>(c, xy[which]));
+        }
+        return;
+    }
     if (opc == H2E_V_FULL) {  // the tape op itself (64 bytes = two extension records)
         const u32* e = (const u32*)ext;
         u32 v[16];
@@ -1616,6 +1640,8 @@ __global__ void __launch_bounds__(64) h2e_replay(H2ELaunch L, const InstanceDesc
     c.input_stride = L.input_stride;
     c.hints = d.hints;
     c.hint_stride = L.hint_stride;
+    c.sel = d.sel;
+    c.sel_stride = L.sel_stride;
     __shared__ Stage stage;
     __shared__ H2EVRec chunk[2][H2E_VCHUNK];
     extern __shared__ ulonglong2 v_dyn[];
@@ -1992,11 +2018,18 @@ __global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* arg
         acc.y = ld_w_mont<FP>(v.c, M, neg_r1 + L + 1);
         acc.z = M.r1;
         st_rec<FP>(v, hint0 + H2E_ECC_HINT_SLOTS * n_groups, acc.x, acc.z, acc.x, acc.y);   // the chain's initial point
+        // the candidates were picked by the select pre-kernel (one lane per window and group): no data-dependent
+        // addresses in this chain, and the next group's point is fetched one iteration ahead
+        (void)group_size; (void)n_points; (void)tables;
+        const u64* selp = d.sel + (size_t)(K.sel_begin + lane * n_groups) * H2E_SEL_WORDS;
+        Wd<NW> nx = wd_load<NW>(selp), ny = wd_load<NW>(selp + H2E_W_WORDS_MAX);
         for (u32 g = 0; g < n_groups; g++) {
-            u32 lo = g * group_size, hi = min(n_points, lo + group_size), idx = 0;
-            for (u32 j = lo; j < hi; j++) idx |= (u32)(ld_limb(v.c, H2E_MAKE_REF(H2E_REGION_PARAM, 0, 0, j)).v[0] & 1) << (j - lo);
-            const u32* tab = aux + tables[g] + idx * NR;
-            Wd<NW> cx = ld_w_mont<FP>(v.c, M, tab), cy = ld_w_mont<FP>(v.c, M, tab + L + 1);
+            Wd<NW> sx = nx, sy = ny;
+            const u64* np = selp + (size_t)min(g + 1, n_groups - 1) * H2E_SEL_WORDS;
+            nx = wd_load<NW>(np);
+            ny = wd_load<NW>(np + H2E_W_WORDS_MAX);
+            asm volatile("" ::: "memory");
+            Wd<NW> cx = to_mont<NW>(M, sx), cy = to_mont<NW>(M, sy);
             Wd<NW> num;
             acc = jac_madd(M, acc, cx, cy, num);
             st_rec<FP>(v, hint0 + H2E_ECC_HINT_SLOTS * g, num, acc.z, acc.x, acc.y);
@@ -2035,6 +2068,43 @@ __global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* arg
                 h += H2E_ECC_HINT_SLOTS;
             }
         }
+    }
+}
+
+// Select pre-kernel of the MSM windows: one lane per (instance, window, group) does pick_candidate_non_zero
+// (ecc_chip.rs:935-953) natively - index from the window's bit cells, candidate through the group's table - and leaves
+// the point (canonical x, y) in the selection buffer.  The serial kernels of the value chain (windows predictor,
+// replay) then only read static addresses.  Arguments as for H2E_PRE_MSM_WINDOWS.
+template <class FP>
+__global__ void __launch_bounds__(64) h2e_select(H2EPreKernel K, const u32* args, const u32* params_all, const u32* aux,
+                                                 const InstanceDesc* inst, u32 n_instances) {
+    constexpr int L = FP::L, NW = FP::WW, NR = 2 * (L + 1);
+    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_instances * K.n_lanes) return;
+    u32 instance = gid / K.n_lanes, lane = gid % K.n_lanes;
+    const u32* a = args + K.args_begin;
+    u32 n_groups = a[0], group_size = a[1], n_points = a[2];
+    const u32* tables = a + 3 + NR;
+    u32 w = lane / n_groups, g = lane % n_groups;
+    InstanceDesc d = inst[instance];
+    LC c;
+    c.base = d.base;
+    c.range = d.range;
+    c.select = d.select;
+    c.ob = c.orr = c.os = 0;
+    c.params = params_all + K.params_begin + (size_t)w * K.n_params;
+    u32 lo = g * group_size, hi = min(n_points, lo + group_size), idx = 0;
+    for (u32 j = lo; j < hi; j++) idx |= (u32)(ld_limb(c, H2E_MAKE_REF(H2E_REGION_PARAM, 0, 0, j)).v[0] & 1) << (j - lo);
+    const u32* tab = aux + tables[g] + idx * NR;
+    u64* out = d.sel + (size_t)(K.sel_begin + w * n_groups + g) * H2E_SEL_WORDS;
+#pragma unroll
+    for (int which = 0; which < 2; which++) {
+        Limb l[L];
+#pragma unroll
+        for (int i = 0; i < L; i++) l[i] = ld_limb(c, tab[which * (L + 1) + i]);
+        Wd<NW> v = wd_resize<NW>(compose<FP, FPX<FP>::AW>(l));
+#pragma unroll
+        for (int i = 0; i < NW; i++) out[which * H2E_W_WORDS_MAX + i] = v.v[i];
     }
 }
 
@@ -2223,6 +2293,10 @@ extern "C" int h2e_engine_predict(int field_pair, int phase, const H2EPreKernel*
     u32 ecc_chunks = (k->ecc_ops + ECC_CH - 1) / ECC_CH;
     dim3 grid3((n_instances * k->n_lanes * ecc_chunks + 63) / 64);
 #define H2E_PREDICT_FP(FP)                                                                                                          \
+    if (k->kind == H2E_PRE_MSM_SELECT) {                                                                                            \
+        if (phase & 1) hipLaunchKernelGGL(h2e_select<FP>, grid, block, 0, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances); \
+        break;                                                                                                                      \
+    }                                                                                                                               \
     if (phase & 1)                                                                                                                  \
         hipLaunchKernelGGL(h2e_predict<FP>, grid, block, lds_reserve, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev); \
     if ((phase & 2) && k->ecc_ops)                                                                                                  \

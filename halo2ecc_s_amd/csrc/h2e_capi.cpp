@@ -47,6 +47,7 @@ struct InstanceDescHost {  // must match engine.hip InstanceDesc
     uint64_t* hints;
     uint64_t* nd;
     uint64_t* jac;
+    uint64_t* sel;
 };
 
 }  // namespace
@@ -250,6 +251,7 @@ struct h2e_program {
             for (uint32_t i = c.n_ops; i-- > 0;) {
                 H2EOp& op = c.ops[i];
                 bool needed = !(op.flags & H2E_FLAG_LOCAL_RESULT) || used[i];
+                if (op.opcode == H2E_OP_PICK_INDEX && (op.flags & H2E_FLAG_PRESELECTED)) needed = false;   // the select pre-kernel did it
                 if (!needed) {
                     op.flags |= H2E_FLAG_VALUES_SKIP;
                     continue;
@@ -278,6 +280,9 @@ struct h2e_program {
                         break;
                     case H2E_OP_ASSERT_CONST: case H2E_OP_CACHE_INT: case H2E_OP_SUM_LIMBS:
                         break;   // nothing in values mode
+                    case H2E_OP_SELECT_POINT:
+                        if (!(op.flags & H2E_FLAG_PRESELECTED)) reads[nr++] = op.refs[0];
+                        break;
                     default:     // everything else: every reference
                         for (int k = 0; k < H2E_OP_MAX_REFS; k++) reads[nr++] = op.refs[k];
                         break;
@@ -350,7 +355,10 @@ struct h2e_program {
                 case H2E_OP_BISEC_INT:
                     o[n++] = {op.refs[0], false, 0}; o[n++] = {op.refs[1], true, 1}; o[n++] = {op.refs[L + 2], true, L + 2};
                     break;
-                case H2E_OP_NOT: case H2E_OP_SELECT_POINT:
+                case H2E_OP_SELECT_POINT:
+                    if (!(op.flags & H2E_FLAG_PRESELECTED)) o[n++] = {op.refs[0], false, 0};
+                    break;
+                case H2E_OP_NOT:
                     o[n++] = {op.refs[0], false, 0};
                     break;
                 case H2E_OP_AND: case H2E_OP_OR: case H2E_OP_XNOR:
@@ -607,6 +615,7 @@ struct h2e_program {
         auto units_of = [&](uint32_t pos) -> uint32_t {   // upper estimate of the memory inputs of one op
             const H2EOp& op = ops[alive[pos]];
             if ((op.flags & H2E_FLAG_HINTED) && kind_of(op) == K_MUL) return HINT_UNITS;
+            if (op.opcode == H2E_OP_SELECT_POINT && (op.flags & H2E_FLAG_PRESELECTED)) return 2 * HINT_UNITS;
             Opd o[3];
             int n = operands(op, o);
             uint32_t u = 0;
@@ -649,7 +658,7 @@ struct h2e_program {
         };
         // remap: nullptr = the op in its own place; else the prologue copy (slots from the map, nothing stored)
         struct StageMap {
-            std::map<uint32_t, uint32_t> hint, cells;   // hint slot | strided << 31 -> unit ; first cell ref -> unit
+            std::map<uint32_t, uint32_t> hint, cells, sel;   // hint slot | strided << 31 -> unit ; first cell ref -> unit ; selection entry -> unit
             uint32_t units = 0;
         };
         auto emit = [&](uint32_t pos, const std::map<int, int>* remap, const StageMap& sm) {
@@ -682,7 +691,7 @@ struct h2e_program {
                 case H2E_OP_OR: vop = H2E_V_OR; break;
                 case H2E_OP_XNOR: vop = H2E_V_XNOR; break;
                 case H2E_OP_PICK_INDEX: vop = H2E_V_PICK_INDEX; break;
-                case H2E_OP_SELECT_POINT: vop = H2E_V_SELECT_POINT; break;
+                case H2E_OP_SELECT_POINT: vop = (op.flags & H2E_FLAG_PRESELECTED) ? H2E_V_LOAD_SEL : H2E_V_SELECT_POINT; break;
                 default: vop = H2E_V_FULL; break;
             }
             if (hinted && (op.flags & H2E_FLAG_HINT_STRIDED)) vflags |= H2E_VFLAG_HINT_STRIDED;
@@ -698,6 +707,7 @@ struct h2e_program {
             if (k == K_SEL || op.opcode == H2E_OP_AND || op.opcode == H2E_OP_OR || op.opcode == H2E_OP_XNOR || op.opcode == H2E_OP_PICK_INDEX ||
                 op.opcode == H2E_OP_BISEC_INT)
                 store = true;   // never flagged local
+            if (vop == H2E_V_LOAD_SEL) store = false;   // the expansion writes the select rows
             if (store && !remap) vflags |= H2E_VFLAG_STORE;
             h.w[1] = imm;
             h.w[5] = k == K_FE ? fe_row(op) : op.base_row;
@@ -707,6 +717,16 @@ struct h2e_program {
                 ext.assign(raw, raw + 16);
             } else if (vop == H2E_V_PICK_INDEX) {
                 for (uint32_t q = 0; q < op.imm && q < 5; q++) ext.push_back(op.refs[q]);
+            } else if (vop == H2E_V_LOAD_SEL) {
+                auto it = sm.sel.find(op.refs[1]);
+                if (it != sm.sel.end()) {
+                    h.w[2] = it->second;
+                    h.w[7] |= H2E_VSRC_STAGE;
+                } else {
+                    h.w[2] = op.refs[1];
+                    h.w[7] |= H2E_VSRC_GLOBAL;
+                }
+                h.w[7] |= dst_of(1) << 16;
             } else {
                 Opd o[3];
                 int n = operands(op, o);
@@ -778,6 +798,15 @@ struct h2e_program {
                     return;
                 }
                 if (kind_of(op) == K_FULL || op.opcode == H2E_OP_PICK_INDEX) return;
+                if (op.opcode == H2E_OP_SELECT_POINT && (op.flags & H2E_FLAG_PRESELECTED)) {
+                    if (sm.sel.count(op.refs[1]) || sm.units + 2 * HINT_UNITS > unit_cap) return;
+                    sm.sel[op.refs[1]] = sm.units;
+                    for (uint32_t which = 0; which < 2; which++)
+                        for (uint32_t hf = 0; hf < HINT_UNITS; hf++)
+                            gl.push_back(GEntry{2u | ((which * (H2E_W_WORDS_MAX / 2) + hf) << 4), op.refs[1]});
+                    sm.units += 2 * HINT_UNITS;
+                    return;
+                }
                 Opd o[3];
                 int n = operands(op, o);
                 for (int q = 0; q < n; q++) {
@@ -1015,8 +1044,8 @@ struct h2e_ctx {
     std::map<std::string, h2e_program*> cache;
     bool profiling = false;
     // engine workspace (grow-only): quotient hints, numerator/denominator pairs, Jacobian scratch
-    uint64_t *ws_hints = nullptr, *ws_nd = nullptr, *ws_jac = nullptr;
-    size_t ws_hints_words = 0, ws_nd_words = 0, ws_jac_words = 0;
+    uint64_t *ws_hints = nullptr, *ws_nd = nullptr, *ws_jac = nullptr, *ws_sel = nullptr;
+    size_t ws_hints_words = 0, ws_nd_words = 0, ws_jac_words = 0, ws_sel_words = 0;
     std::vector<hipEvent_t> ev;       // profiling: 4 per launched segment (value-chain begin/end, expansion begin/end)
     std::vector<hipEvent_t> sync_ev;  // cross-stream dependencies
     hipStream_t expand_stream = nullptr;
@@ -1035,6 +1064,7 @@ struct h2e_ctx {
         (void)hipFree(ws_hints);
         (void)hipFree(ws_nd);
         (void)hipFree(ws_jac);
+        (void)hipFree(ws_sel);
     }
 };
 
@@ -1314,10 +1344,12 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
     };
     size_t hint_words = ((size_t)r.n_hint_slots + H2E_ECC_HINT_SLOTS) * H2E_W_WORDS_MAX,  // spare: the replay prefetches slot + 8
            nd_words = hint_words * 2,
-           jac_words = (size_t)r.n_jac_slots * 3 * H2E_W_WORDS_MAX;
+           jac_words = (size_t)r.n_jac_slots * 3 * H2E_W_WORDS_MAX,
+           sel_words = (size_t)r.n_sel_slots * H2E_SEL_WORDS;
     HIP_TRY(grow(&ctx->ws_hints, &ctx->ws_hints_words, std::max<size_t>(1, hint_words * n_instances)));
     HIP_TRY(grow(&ctx->ws_nd, &ctx->ws_nd_words, std::max<size_t>(1, nd_words * n_instances)));
     HIP_TRY(grow(&ctx->ws_jac, &ctx->ws_jac_words, std::max<size_t>(1, jac_words * n_instances)));
+    HIP_TRY(grow(&ctx->ws_sel, &ctx->ws_sel_words, std::max<size_t>(1, sel_words * n_instances)));
     for (uint32_t i = 0; i < n_instances; i++) {
         InstanceDescHost& d = p->h_inst[i];
         d.base = (uint64_t*)d_base + (size_t)i * p->base_rows * 5 * 4;
@@ -1328,6 +1360,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         d.hints = ctx->ws_hints + (size_t)i * hint_words;
         d.nd = ctx->ws_nd + (size_t)i * nd_words;
         d.jac = ctx->ws_jac + (size_t)i * jac_words;
+        d.sel = ctx->ws_sel + (size_t)i * sel_words;
     }
     HIP_TRY(hipMemcpyAsync(p->d_inst, p->h_inst.data(), (size_t)n_instances * sizeof(InstanceDescHost),
                            hipMemcpyHostToDevice, stream));
@@ -1463,6 +1496,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         L.n_vpieces = compiled ? p->seg_n_pieces[si] : 0;
         L.v_int_slots = compiled ? p->seg_v_slots[si] : 0;
         L.v_units = compiled ? p->seg_v_units[si] : 0;
+        L.sel_stride = s.sel_stride;
         int lrc;
         auto launch = [&](int mode, hipStream_t st) -> int {
             int rc2 = h2e_engine_launch(fp, mode, &L, p->d_inst, n_instances, ctx->d_fc[fp], st);

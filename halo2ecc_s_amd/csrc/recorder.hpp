@@ -189,6 +189,7 @@ struct Segment {  // one engine launch
     // scheduling hint: the next segment's value chain is tiny (a handful of waves that need most of a CU's LDS); this
     // segment's bandwidth-bound expansion would starve it, so the expansion is launched behind that chain
     bool expand_after_next = false;
+    uint32_t sel_stride = 0;   // selection-buffer entries per strand (segments with pre-selected points)
 };
 
 struct PreKernel {  // a value-predictor launch that must run before segment `before_segment`
@@ -230,7 +231,7 @@ struct Recorder {
     uint32_t cur_tape_begin = 0;
     std::vector<PreKernel> pre_kernels;
     std::vector<uint32_t> pre_args;
-    uint32_t n_hint_slots = 0, n_jac_slots = 0;
+    uint32_t n_hint_slots = 0, n_jac_slots = 0, n_sel_slots = 0;
     // hinted-division state: while hint_on, every int_div takes its quotient from slot hint_base + hint_count++
     bool hint_on = false;
     uint32_t hint_base = 0, hint_count = 0;

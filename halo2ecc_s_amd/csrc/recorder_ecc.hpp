@@ -239,10 +239,10 @@ struct NativeScalarEccContext {
         return AssignedNonZeroPoint{x, y};
     }
     // pick_candidate_non_zero's in-circuit part (ecc_chip.rs:941-948): index = sum bit_i 2^i
-    AssignedValue pick_index(const std::vector<AssignedCondition>& group_bits) {
+    AssignedValue pick_index(const std::vector<AssignedCondition>& group_bits, bool preselected = false) {
         size_t k = group_bits.size();
         if (k > 5) throw std::runtime_error("pick_index: more than 5 bits");
-        H2EOp op = ctx.new_op(H2E_OP_PICK_INDEX, (uint32_t)k);
+        H2EOp op = ctx.new_op(H2E_OP_PICK_INDEX, (uint32_t)k, preselected ? H2E_FLAG_PRESELECTED : 0);
         for (size_t i = 0; i < k; i++) op.refs[i] = group_bits[i].v.ref;
         ctx.push(op);
         Recorder::Col cols[4];
@@ -258,10 +258,13 @@ struct NativeScalarEccContext {
     }
     // pick_candidate_non_zero + assign_selected_point_non_zero (ecc_chip.rs:935-967): the candidate is
     // picked *by value* on the device; `table_aux` is the aux offset of the group's candidate ref table.
-    AssignedNonZeroPoint pick_and_select(uint32_t table_aux, const std::vector<AssignedCondition>& group_bits, size_t g) {
-        AssignedValue index = pick_index(group_bits);
-        H2EOp op = ctx.new_op(H2E_OP_SELECT_POINT, table_aux);
+    // sel_entry >= 0: a select pre-kernel picks this point into selection-buffer entry sel_entry (+ strand * stride)
+    AssignedNonZeroPoint pick_and_select(uint32_t table_aux, const std::vector<AssignedCondition>& group_bits, size_t g,
+                                         int64_t sel_entry = -1) {
+        AssignedValue index = pick_index(group_bits, sel_entry >= 0);
+        H2EOp op = ctx.new_op(H2E_OP_SELECT_POINT, table_aux, sel_entry >= 0 ? H2E_FLAG_PRESELECTED : 0);
         op.refs[0] = index.ref;
+        if (sel_entry >= 0) op.refs[1] = (uint32_t)sel_entry;
         ctx.push(op);
         AssignedNonZeroPoint r;
         size_t i = 0;
@@ -413,6 +416,7 @@ struct NativeScalarEccContext {
         auto add_candidates_pre = [&](uint32_t n_lanes, uint32_t sz, uint32_t hint_base, uint32_t params_begin, uint32_t n_params) {
             PreKernel pk;
             std::memset(&pk, 0, sizeof(pk));
+            pk.early_after_segment = -1;
             pk.k.kind = H2E_PRE_MSM_CANDIDATES;
             pk.k.n_lanes = n_lanes;
             pk.k.hint_base = hint_base;
@@ -507,6 +511,8 @@ struct NativeScalarEccContext {
         uint32_t win_seg_index = (uint32_t)c.segments.size();
         uint32_t win_jac = c.n_jac_slots;
         c.n_jac_slots += (uint32_t)windows;
+        uint32_t win_sel = c.n_sel_slots;
+        c.n_sel_slots += (uint32_t)(windows * n_groups);
         c.begin_hints(win_hbase, 2);
         c.fork((uint32_t)windows, 0, [&](uint32_t wi) {
             AssignedNonZeroPoint acc = rand_acc_point_neg;
@@ -515,18 +521,37 @@ struct NativeScalarEccContext {
                 std::vector<AssignedCondition> group_bits;
                 for (size_t j = lo; j < hi; j++)
                     group_bits.push_back(AssignedCondition{c.param(AssignedValue{c.strand_ref(bits0[wi].v.ref, seg_bits, (uint32_t)j)})});
-                AssignedNonZeroPoint ci = pick_and_select(table_aux[group_index], group_bits, group_index + group_prefix);
+                AssignedNonZeroPoint ci = pick_and_select(table_aux[group_index], group_bits, group_index + group_prefix,
+                                                          (int64_t)(win_sel + group_index));
                 acc = ecc_add_unsafe(ci, acc);
                 c.cut();
             }
             if (wi == 0) line_acc0 = acc;
         });
         c.end_hints();
+        c.segments[c.segments.size() - 2].sel_stride = (uint32_t)n_groups;
         Segment seg_windows = c.segments[c.segments.size() - 2];
+        uint32_t win_args = (uint32_t)c.pre_args.size();
+        {   // select pre-kernel: one lane per (window, group) picks the candidate -> selection buffer (same arguments)
+            PreKernel pk;
+            std::memset(&pk, 0, sizeof(pk));
+            pk.early_after_segment = -1;
+            pk.k.kind = H2E_PRE_MSM_SELECT;
+            pk.k.n_lanes = (uint32_t)(windows * n_groups);
+            pk.k.args_begin = win_args;
+            pk.k.n_params = seg_windows.n_params;
+            pk.k.params_begin = seg_windows.params_begin;
+            pk.k.sel_begin = win_sel;
+            pk.before_segment = win_seg_index;
+            pk.early_after_segment = -1;
+            c.pre_kernels.push_back(pk);
+        }
         {
             PreKernel pk;
             std::memset(&pk, 0, sizeof(pk));
+            pk.early_after_segment = -1;
             pk.k.kind = H2E_PRE_MSM_WINDOWS;
+            pk.k.sel_begin = win_sel;
             pk.k.n_lanes = (uint32_t)windows;
             pk.k.hint_base = win_hbase;
             pk.k.hints_per_lane = win_hints_per_lane;
@@ -548,6 +573,7 @@ struct NativeScalarEccContext {
         {   // tail predictor: runs before the main segment that holds the accumulation loop
             PreKernel pk;
             std::memset(&pk, 0, sizeof(pk));
+            pk.early_after_segment = -1;
             pk.k.kind = H2E_PRE_MSM_TAIL;
             pk.k.n_lanes = 1;
             pk.k.hint_base = c.n_hint_slots;

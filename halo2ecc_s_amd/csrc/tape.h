@@ -78,6 +78,9 @@ enum H2EOpcode {
                                     // keeps it in LDS and does not store it (set by the recorder's liveness pass)
 
 #define H2E_FLAG_VALUES_SKIP 64u    // nothing the values-only replay has to produce depends on this op (host DCE pass)
+#define H2E_FLAG_PRESELECTED 128u   // PICK_INDEX / SELECT_POINT of an MSM window: a select pre-kernel (H2E_PRE_MSM_SELECT) has
+                                    // already picked the candidate into the selection buffer, entry refs[1] (+ strand * stride),
+                                    // so the value chain has no data-dependent addresses; the expansion ignores the flag
 
 // "full value hints" of an MSM chain: every ecc_add_unsafe / ecc_double_unsafe owns a block of 8 hint slots with the
 // canonical W value of each mul-like result of src/circuit/ecc_chip.rs:814-882 (a = first argument, c = result):
@@ -162,6 +165,7 @@ typedef struct H2ELaunch {
     const uint32_t* vpieces;      // [n_vpieces][2] first / end record of each independent piece of this segment's replay
     uint32_t n_vpieces;
     uint32_t v_int_slots, v_units; // LDS sizing of the replay kernel: integer slots and 16-byte staging units per lane
+    uint32_t sel_stride;          // selection-buffer entries per strand (H2E_FLAG_PRESELECTED)
 } H2ELaunch;
 
 // ---- compiled values-only replay ("V-tape") ----------------------------------------------------
@@ -179,7 +183,8 @@ typedef struct H2ELaunch {
 // with H2E_V_GATHER records listing them in 16-byte units; the kernel issues them as asynchronous global->LDS loads
 // and waits once (H2E_V_GATHER_WAIT), so the dependent chain itself never waits for memory.
 //   gather record: w[0] = H2E_V_GATHER | n << 8 (n <= 3 entries), w[1] = first staging unit,
-//                  w[2 + 2e] = kind (0 cell, 1 hint) | 16-byte piece << 4 | strided << 8, w[3 + 2e] = cell ref / hint slot
+//                  w[2 + 2e] = kind (0 cell, 1 hint, 2 selection entry) | 16-byte piece << 4 | strided << 8,
+//                  w[3 + 2e] = cell ref / hint slot / selection entry
 typedef struct H2EVRec {
     uint32_t w[8];
 } H2EVRec;
@@ -192,7 +197,8 @@ enum H2EVOpcode {
     H2E_V_IS_ZERO, H2E_V_NOT, H2E_V_AND, H2E_V_OR, H2E_V_XNOR, H2E_V_PICK_INDEX,
     H2E_V_SELECT_POINT,
     H2E_V_FULL,          // run the tape op held in the 2 extension records as it is (its rows are its results)
-    H2E_V_GATHER, H2E_V_GATHER_WAIT
+    H2E_V_GATHER, H2E_V_GATHER_WAIT,
+    H2E_V_LOAD_SEL       // both coordinates of a pre-selected point: src0 = staging unit (or selection entry), two dst slots
 };
 #define H2E_VFLAG_STORE 1u          // the result is also written to its cells
 #define H2E_VFLAG_HINT_STRIDED 2u
@@ -208,7 +214,9 @@ enum H2EVOpcode {
 // They run native Montgomery / Jacobian arithmetic over the same inputs, write numerator/denominator pairs of
 // every lambda = dy/dx the ecc_add_unsafe / ecc_double_unsafe chain will divide (src/circuit/ecc_chip.rs:840-882),
 // and one batch inversion turns them into hints for H2E_OP_DIV_CORE.
-enum H2EPreKind { H2E_PRE_MSM_CANDIDATES = 1, H2E_PRE_MSM_WINDOWS = 2, H2E_PRE_MSM_TAIL = 3 };
+enum H2EPreKind { H2E_PRE_MSM_CANDIDATES = 1, H2E_PRE_MSM_WINDOWS = 2, H2E_PRE_MSM_TAIL = 3, H2E_PRE_MSM_SELECT = 4 };
+// selection buffer: per (strand, group) the picked candidate, x then y, canonical, H2E_W_WORDS_MAX words each
+#define H2E_SEL_WORDS (2 * H2E_W_WORDS_MAX)
 typedef struct H2EPreKernel {
     uint32_t kind;
     uint32_t n_lanes;        // lanes per instance (groups / windows / 1)
@@ -223,4 +231,5 @@ typedef struct H2EPreKernel {
     uint32_t ecc_ops;
     uint32_t pattern_len;
     uint32_t pattern;
+    uint32_t sel_begin;      // first entry of this kernel's strands in the selection buffer (SELECT writes, WINDOWS reads)
 } H2EPreKernel;
