@@ -158,6 +158,9 @@ WI_INLINE Fe inv_n(const LC& c, const Fe& a) { return wd_inv_mod<4>(a, n_of(c));
 // pieces of the same row, so one request carries a 64-byte run.  `mask` = assigned columns.  Whole rows are
 // stored (unassigned cells as zero, which is what they hold anyway): rows with holes made ~half of the HBM write
 // requests 32-byte partial lines, and the same kernel ran 25 % faster writing 40 % more bytes without them.
+// (Tried: collecting 2-3 consecutive rows per lane and kind before flushing.  exp/ubench/segwrite.hip says HBM write
+// throughput follows the contiguous segment size - 160 B: 2.9 TB/s, 640 B: 5.8 TB/s - but in this kernel the larger
+// staging buffers cut the waves per CU from 10 to 3 and the expansion got 25 % slower; one row per flush it is.)
 struct Stage {  // one buffer, used for one row kind at a time (12 KB per wave keeps 13 waves per CU resident)
     union {
         u64 b[64][22];  // base row: 5 cells x 32 B, lane stride 176 B (conflict-free for 128-bit LDS access)
@@ -769,147 +772,6 @@ WI_INLINE void op_select_point(const LC& c, const H2EOp& op) {
 template <class FP, bool UNUSED>
 WI_INLINE void exec_op(const LC& c, const H2EOp& op);
 
-// ------------------------------------------------------------------------------------------------
-// Values-only replay: every op writes only the cells later ops can reference (result limbs + native, or a
-// condition / index cell); all other cells of its rows are produced afterwards by the full expansion, which
-// may then run in any order because its operands are already in place.
-//
-// The replay is one dependent chain per lane, so a round trip through HBM for every operand would dominate it.
-// Results therefore also go into an LDS cache: the directory (tags = the cell ref later ops will quote) is
-// wave-uniform because the tape is, the data is per lane ([entry][word][lane], conflict-free).
-template <class FP>
-struct VCache {
-    static constexpr int R = (FP::L == 3 ? 20 : 16), W = 2 * FP::L + 4, S = 8, G = 4;
-    u64 data[R + G][W][64];   // entries [R, R+G): values first seen as global loads (e.g. -r2, a window's sum), LRU
-    u64 sdata[S][4][64];
-    u32 tags[R + G];
-    u32 gage[G];
-    u32 stags[S];
-    u32 head, shead, gclock;
-};
-template <class FP>
-WI_INLINE void vc_init(VCache<FP>* vc) {
-    if (threadIdx.x == 0) {
-        for (int k = 0; k < VCache<FP>::R + VCache<FP>::G; k++) vc->tags[k] = H2E_NO_REF;
-        for (int k = 0; k < VCache<FP>::G; k++) vc->gage[k] = 0;
-        for (int k = 0; k < VCache<FP>::S; k++) vc->stags[k] = H2E_NO_REF;
-        vc->head = 0;
-        vc->shead = 0;
-        vc->gclock = 1;
-    }
-    __syncthreads();
-}
-template <class FP>
-WI_INLINE void vc_put_int(VCache<FP>* vc, u32 tag, const Limb* l, const Fe& native) {
-    u32 k = vc->head;
-    u32 lane = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < FP::L; i++) {
-        vc->data[k][2 * i][lane] = l[i].v[0];
-        vc->data[k][2 * i + 1][lane] = l[i].v[1];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) vc->data[k][2 * FP::L + i][lane] = native.v[i];
-    // one wave per workgroup: LDS operations of a wave complete in order, so no barrier is needed (and
-    // __syncthreads() would also wait for every outstanding global store); just keep the compiler from reordering
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) {
-        vc->tags[k] = tag;
-        vc->head = (k + 1) % VCache<FP>::R;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-template <class FP>
-WI_INLINE void vc_put_fe(VCache<FP>* vc, u32 tag, const Fe& v) {
-    u32 k = vc->shead;
-    u32 lane = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 4; i++) vc->sdata[k][i][lane] = v.v[i];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) {
-        vc->stags[k] = tag;
-        vc->shead = (k + 1) % VCache<FP>::S;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-template <class FP>
-WI_INLINE IntVal<FP> vc_ld_int(VCache<FP>* vc, const LC& c, const u32* refs) {
-    constexpr int R = VCache<FP>::R, G = VCache<FP>::G;
-    u32 tag = refs[0];
-    int hit = -1;
-    for (int k = 0; k < R + G; k++)
-        if (vc->tags[k] == tag) hit = k;
-    u32 lane = threadIdx.x;
-    if (hit < 0) {
-        // first use of a value produced outside this replay: keep it in the small LRU part for re-use
-        IntVal<FP> g = ld_int<FP>(c, refs);
-        if (H2E_REF_REGION(tag) == H2E_REGION_PARAM) return g;
-        int victim = 0;
-        for (int k = 1; k < G; k++)
-            if (vc->gage[k] < vc->gage[victim]) victim = k;
-#pragma unroll
-        for (int i = 0; i < FP::L; i++) {
-            vc->data[R + victim][2 * i][lane] = g.l[i].v[0];
-            vc->data[R + victim][2 * i + 1][lane] = g.l[i].v[1];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) vc->data[R + victim][2 * FP::L + i][lane] = g.native.v[i];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) {
-            vc->tags[R + victim] = tag;
-            vc->gage[victim] = vc->gclock++;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        return g;
-    }
-    if (hit >= R && lane == 0) vc->gage[hit - R] = vc->gclock++;
-    IntVal<FP> r;
-#pragma unroll
-    for (int i = 0; i < FP::L; i++) {
-        r.l[i].v[0] = vc->data[hit][2 * i][lane];
-        r.l[i].v[1] = vc->data[hit][2 * i + 1][lane];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) r.native.v[i] = vc->data[hit][2 * FP::L + i][lane];
-    return r;
-}
-template <class FP>
-WI_INLINE Fe vc_ld_fe(VCache<FP>* vc, const LC& c, u32 ref) {
-    int hit = -1;
-    for (int k = 0; k < VCache<FP>::S; k++)
-        if (vc->stags[k] == ref) hit = k;
-    if (hit < 0) return ld_fe(c, ref);
-    Fe r;
-#pragma unroll
-    for (int i = 0; i < 4; i++) r.v[i] = vc->sdata[hit][i][threadIdx.x];
-    return r;
-}
-// result of a "mul-like" op: limbs are range acc cells, native a base cell
-template <class FP>
-WI_INLINE void v_result_mul(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 rel, const Limb* l, const Fe& native) {
-    if (!(op.flags & H2E_FLAG_LOCAL_RESULT)) {
-#pragma unroll
-        for (int i = 0; i < FP::L; i++) stR(c, op.range_row + 3 * i, 0, fe_of(l[i]));
-        stB(c, op.base_row, 4, native);
-    }
-    vc_put_int<FP>(vc, H2E_MAKE_REF(1, 0, rel, op.range_row), l, native);
-}
-// result of an "add-like" op: limb i in (base_row + i, col 4), native in (base_row + L, col 4)
-template <class FP>
-WI_INLINE void v_result_add(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 rel, const Limb* l, const Fe& native) {
-    if (!(op.flags & H2E_FLAG_LOCAL_RESULT)) {
-#pragma unroll
-        for (int i = 0; i < FP::L; i++) stB(c, op.base_row + i, 4, fe_of(l[i]));
-        stB(c, op.base_row + FP::L, 4, native);
-    }
-    vc_put_int<FP>(vc, H2E_MAKE_REF(0, 4, rel, op.base_row), l, native);
-}
-template <class FP>
-WI_INLINE void v_result_fe(VCache<FP>* vc, const LC& c, u32 row, int col, u32 rel, const Fe& v, bool local = false) {
-    if (!local) stB(c, row, col, v);
-    vc_put_fe<FP>(vc, H2E_MAKE_REF(0, col, rel, row), v);
-}
-
 // Hints are read in a dependent chain; under a saturated memory system such a load costs ~10-100 us.  The ops of
 // consecutive ecc ops read the same slots of consecutive 8-slot blocks (tape.h; blocks are 8-aligned), so whenever
 // one of the slots the replay needs (lambda^2, t2*lambda, c.x, c.y) is read, the load of the same slot of the
@@ -941,156 +803,6 @@ WI_INLINE Wd<FP::WW> hint_value(const LC& c, HintPrefetch<FP>& hp, u32 slot) {
         }
     return r;
 }
-template <class FP>
-WI_INLINE void exec_op_values(VCache<FP>* vc, const LC& c, const H2EOp& op, u32 rel, HintPrefetch<FP>& hp) {
-    constexpr int L = FP::L;
-    if (op.flags & H2E_FLAG_VALUES_SKIP) return;
-    if ((op.flags & H2E_FLAG_HINTED) && (op.opcode == H2E_OP_INT_MUL || op.opcode == H2E_OP_REDUCE || op.opcode == H2E_OP_DIV_CORE)) {
-        // the canonical result comes from the predictors (b == 0 in a division already gives the hint 0)
-        Wd<FP::WW> cv = hint_value<FP>(c, hp, hint_slot_of<FP>(c, op));
-        Limb cl[L];
-        split_limbs<FP>(cv, cl);
-        v_result_mul<FP>(vc, c, op, rel, cl, native_of_w<FP>(c, cv));
-        return;
-    }
-    switch (op.opcode) {
-        case H2E_OP_INT_MUL: {
-            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs), b = vc_ld_int<FP>(vc, c, op.refs + L + 1);
-            Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
-            Wd<FPX<FP>::QW> dq;
-            Wd<FP::WW> rem;
-            divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW>(A, B)), dq, rem);
-            Limb rl[L];
-            split_limbs<FP>(rem, rl);
-            v_result_mul<FP>(vc, c, op, rel, rl, native_of_w<FP>(c, rem));
-        } break;
-        case H2E_OP_REDUCE: {
-            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs);
-            Wd<FP::WW> rem;
-            u64 dsmall;
-            divrem_small<FP>(c, compose<FP, FPX<FP>::AW>(a.l), dsmall, rem);
-            Limb rl[L];
-            split_limbs<FP>(rem, rl);
-            v_result_mul<FP>(vc, c, op, rel, rl, native_of_w<FP>(c, rem));
-        } break;
-        case H2E_OP_DIV_CORE: {
-            IntVal<FP> b = vc_ld_int<FP>(vc, c, op.refs);
-            Wd<FP::WW> cv;
-            {
-                IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs + L + 1);
-                Wd<FPX<FP>::QW> q0;
-                Wd<FP::WW> a_red, b_red;
-                divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(compose<FP, FPX<FP>::AW>(a.l)), q0, a_red);
-                divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(compose<FP, FPX<FP>::AW>(b.l)), q0, b_red);
-                Wd<FP::WW> binv = wd_inv_mod<FP::WW>(b_red, wd_load<FP::WW>(c.fc->w));
-                divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FP::WW, FP::WW>(a_red, binv)), q0, cv);
-            }
-            Limb cl[L];
-            split_limbs<FP>(cv, cl);
-            v_result_mul<FP>(vc, c, op, rel, cl, native_of_w<FP>(c, cv));
-        } break;
-        case H2E_OP_IS_INT_ZERO: {
-            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs);
-            bool all_zero = true;
-#pragma unroll
-            for (int i = 0; i < L; i++) all_zero = all_zero && wd_is_zero<2>(a.l[i]);
-            bool is_w = wd_eq<4>(a.native, wd_load<4>(c.fc->w_native));
-#pragma unroll
-            for (int i = 0; i < FP::PW; i++) is_w = is_w && wd_eq<2>(a.l[i], wd_load<2>(c.fc->w_limbs[i]));
-            v_result_fe<FP>(vc, c, op.base_row + 6 + 4 * FP::PW, 4, rel, fe_u64((all_zero || is_w) ? 1 : 0),
-                            (op.flags & H2E_FLAG_LOCAL_RESULT) != 0);
-        } break;
-        case H2E_OP_INT_ADD: {
-            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs), b = vc_ld_int<FP>(vc, c, op.refs + L + 1);
-            Limb s[L];
-#pragma unroll
-            for (int i = 0; i < L; i++) s[i] = wd_add<2>(a.l[i], b.l[i]);
-            v_result_add<FP>(vc, c, op, rel, s, addmod_n(c, a.native, b.native));
-        } break;
-        case H2E_OP_INT_SUB: {
-            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs), b = vc_ld_int<FP>(vc, c, op.refs + L + 1);
-            Limb s[L];
-#pragma unroll
-            for (int i = 0; i < L; i++) s[i] = wd_sub<2>(wd_add<2>(a.l[i], wd_load<2>(c.fc->ceil_limbs[op.imm][i])), b.l[i]);
-            v_result_add<FP>(vc, c, op, rel, s, addmod_n(c, submod_n(c, a.native, b.native), wd_load<4>(c.fc->ceil_native[op.imm])));
-        } break;
-        case H2E_OP_INT_NEG: {
-            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs);
-            Limb s[L];
-#pragma unroll
-            for (int i = 0; i < L; i++) s[i] = wd_sub<2>(wd_load<2>(c.fc->ceil_limbs[op.imm][i]), a.l[i]);
-            v_result_add<FP>(vc, c, op, rel, s, submod_n(c, wd_load<4>(c.fc->ceil_native[op.imm]), a.native));
-        } break;
-        case H2E_OP_INT_MUL_SMALL: {
-            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs);
-            Wd<1> k = wd_from_u64<1>(op.imm);
-            Limb s[L];
-#pragma unroll
-            for (int i = 0; i < L; i++) s[i] = wd_resize<2>(wd_mul<2, 1>(a.l[i], k));
-            v_result_add<FP>(vc, c, op, rel, s, mod_n<5>(c, wd_mul<4, 1>(a.native, k)));
-        } break;
-        case H2E_OP_MASK_INT: {
-            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs);
-            Fe coeff = vc_ld_fe<FP>(vc, c, op.refs[L + 1]);
-            bool keep = !wd_is_zero<4>(coeff);
-            Limb s[L];
-#pragma unroll
-            for (int i = 0; i < L; i++) s[i] = keep ? a.l[i] : wd_zero<2>();
-            v_result_add<FP>(vc, c, op, rel, s, keep ? a.native : wd_zero<4>());
-        } break;
-        case H2E_OP_BISEC_INT: {
-            Fe cond = vc_ld_fe<FP>(vc, c, op.refs[0]);
-            IntVal<FP> a = vc_ld_int<FP>(vc, c, op.refs + 1), b = vc_ld_int<FP>(vc, c, op.refs + L + 2);
-            bool take_a = !wd_is_zero<4>(cond);
-            Limb s[L];
-#pragma unroll
-            for (int i = 0; i < L; i++) s[i] = take_a ? a.l[i] : b.l[i];
-            v_result_add<FP>(vc, c, op, rel, s, take_a ? a.native : b.native);
-        } break;
-        case H2E_OP_NOT: {
-            Fe x = vc_ld_fe<FP>(vc, c, op.refs[0]);
-            v_result_fe<FP>(vc, c, op.base_row, 4, rel, submod_n(c, fe_u64(1), x), (op.flags & H2E_FLAG_LOCAL_RESULT) != 0);
-        } break;
-        case H2E_OP_AND:
-        case H2E_OP_OR:
-        case H2E_OP_XNOR: {
-            Fe a = vc_ld_fe<FP>(vc, c, op.refs[0]), b = vc_ld_fe<FP>(vc, c, op.refs[1]);
-            u64 r = op.opcode == H2E_OP_AND ? (a.v[0] & b.v[0]) : op.opcode == H2E_OP_OR ? (a.v[0] | b.v[0]) : (1 ^ a.v[0] ^ b.v[0]);
-            v_result_fe<FP>(vc, c, op.base_row, 4, rel, fe_u64(r));
-        } break;
-        case H2E_OP_PICK_INDEX: {
-            u32 k = op.imm;
-            u64 idx = 0;
-#pragma unroll
-            for (int i = 0; i < 5; i++)
-                if (i < (int)k) idx |= (ld_fe(c, op.refs[i]).v[0] & 1) << i;
-            v_result_fe<FP>(vc, c, op.base_row + (k < 5 ? 0 : 1), 4, rel, fe_u64(idx));
-        } break;
-        case H2E_OP_SELECT_POINT: {
-            constexpr int NC = 2 * (L + 1);
-            Fe index = vc_ld_fe<FP>(vc, c, op.refs[0]);
-            u32 idx = (u32)(index.v[0] & 0xff);
-            const u32* tab = c.aux + op.imm + idx * NC;
-            Fe v[NC];
-#pragma unroll
-            for (int j = 0; j < NC; j++) v[j] = ld_fe(c, tab[j]);
-#pragma unroll
-            for (int j = 0; j < NC; j++) stS(c, op.select_row + j, 0, v[j]);
-#pragma unroll
-            for (int which = 0; which < 2; which++) {
-                Limb l[L];
-#pragma unroll
-                for (int i = 0; i < L; i++) l[i] = wd_resize<2>(v[which * (L + 1) + i]);
-                vc_put_int<FP>(vc, H2E_MAKE_REF(2, 0, rel, op.select_row + which * (L + 1)), l, v[which * (L + 1) + L]);
-            }
-        } break;
-        case H2E_OP_ASSERT_CONST:
-        case H2E_OP_CACHE_INT:
-        case H2E_OP_SUM_LIMBS: break;
-        default: exec_op<FP, false>(c, op); break;  // inputs / constants / bisec / decompose: their rows are their results
-    }
-}
-
 template <class FP, bool UNUSED>
 WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
     switch (op.opcode) {
@@ -1224,26 +936,7 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     __shared__ TapeChunk chunk;
     c.st = &stage;
     c.active = active;
-    if constexpr (VALUES_ONLY) {
-        // the value chain is the critical path and may share its SIMD with expansion waves of an earlier segment
-        __builtin_amdgcn_s_setprio(3);
-        __shared__ VCache<FP> vcache;
-        vc_init<FP>(&vcache);
-        HintPrefetch<FP> hp;
-#pragma unroll
-        for (int i = 0; i < HintPrefetch<FP>::E; i++) {
-            hp.slot[i] = 0xffffffffu;
-            hp.v[i] = wd_zero<FP::WW>();
-        }
-        for (u32 i0 = op_lo; i0 < op_hi; i0 += 64) {
-            load_chunk(&chunk, L.tape, i0, op_hi);
-            u32 n = min(64u, op_hi - i0);
-            for (u32 k = 0; k < n; k++) {
-                H2EOp op = chunk_op(&chunk, k);
-                exec_op_values<FP>(&vcache, c, op, L.rel_refs, hp);
-            }
-        }
-    } else {
+    {
         for (u32 i0 = op_lo; i0 < op_hi; i0 += 64) {
             load_chunk(&chunk, L.tape, i0, op_hi);
             u32 n = min(64u, op_hi - i0);
@@ -2258,7 +1951,7 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
         hipLaunchKernelGGL(h2e_replay<FP>, dim3(blocks_per_sub * launch->n_vpieces), block,                                    \
                            ((size_t)launch->v_units * 2 + ((size_t)launch->v_int_slots * VSlots<FP>::W + VSlots<FP>::NF * 4)) * 64 * 8, \
                            stream, *launch, inst, n_instances);                                                                \
-    if ((mode & 1) && !launch->vtape) hipLaunchKernelGGL((h2e_run_tape<FP, true>), grid1, block, 0, stream, *launch, inst, n_instances, fc_dev); \
+    if ((mode & 1) && !launch->vtape) return -2;   /* a values-only replay always runs from the compiled V-tape */          \
     if (mode & 2) hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid, block, xlds, stream, *launch, inst, n_instances, fc_dev);
     switch (field_pair) {
         case 0: { H2E_LAUNCH_FP(FP_BN256_FQ) } break;
