@@ -1428,6 +1428,29 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
     H2ELaunch pending_L;
     uint32_t pending_li = 0;
     bool have_pending = false;
+    // a held-back expansion goes out once the next long predictor chain (a segment with pre-selected points: the MSM
+    // windows) is queued - next to that chain it costs 1 ms less than next to the select kernel before it - or, if there
+    // is no such segment, right behind the next value chain
+    bool hold_longer = false;
+    auto flush_pending = [&]() -> int {   // launch an expansion that was held back behind a later value chain
+        hipEvent_t e0 = sync_event();
+        HIP_TRY(hipEventRecord(e0, sa));
+        HIP_TRY(hipStreamWaitEvent(sb, e0, 0));
+        if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 2), sb));
+        int prc2 = h2e_engine_launch(fp, 2, &pending_L, p->d_inst, n_instances, ctx->d_fc[fp], sb);
+        if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
+        if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 3), sb));
+        if (pending_L.n_fixups) {
+            hipEvent_t e1 = sync_event();
+            HIP_TRY(hipEventRecord(e1, sb));
+            HIP_TRY(hipStreamWaitEvent(sd, e1, 0));
+            used_sd = true;
+            prc2 = h2e_engine_launch(fp, 4, &pending_L, p->d_inst, n_instances, ctx->d_fc[fp], sd);
+            if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
+        }
+        have_pending = false;
+        return 0;
+    };
     for (size_t si = 0; si < r.segments.size(); si++) {
         const h2e::Segment& s = r.segments[si];
         if (s.tape_end <= s.tape_begin) continue;
@@ -1449,6 +1472,10 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
             }
             int prc = h2e_engine_predict(fp, 1, &pk.k, p->d_pre_args, p->d_params, p->d_aux, p->d_inst, n_instances, ctx->d_fc[fp], sa);
             if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
+        }
+        if (have_pending && hold_longer && s.sel_stride) {
+            int frc = flush_pending();
+            if (frc) return frc;
         }
         // predictors of later segments that only depend on this segment's predictor chains start now, on the side stream
         for (size_t pi = 0; pi < r.pre_kernels.size(); pi++) {
@@ -1515,28 +1542,13 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         if (L.n_sub > 1) {
             if ((lrc = launch(1, sa))) return lrc;
             if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
-            if (have_pending) {   // the previous segment's expansion was held back behind this (tiny) value chain
-                hipEvent_t e0 = sync_event();
-                HIP_TRY(hipEventRecord(e0, sa));
-                HIP_TRY(hipStreamWaitEvent(sb, e0, 0));
-                if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 2), sb));
-                int prc2 = h2e_engine_launch(fp, 2, &pending_L, p->d_inst, n_instances, ctx->d_fc[fp], sb);
-                if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
-                if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 3), sb));
-                if (pending_L.n_fixups) {
-                    hipEvent_t e1 = sync_event();
-                    HIP_TRY(hipEventRecord(e1, sb));
-                    HIP_TRY(hipStreamWaitEvent(sd, e1, 0));
-                    used_sd = true;
-                    prc2 = h2e_engine_launch(fp, 4, &pending_L, p->d_inst, n_instances, ctx->d_fc[fp], sd);
-                    if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
-                }
-                have_pending = false;
-            }
+            if (have_pending && !hold_longer && (lrc = flush_pending())) return lrc;
             if (s.expand_after_next && si + 1 < r.segments.size() && p->seg_n_sub[si + 1] > 1 && !getenv("H2E_DEBUG_NO_HOLD")) {
                 pending_L = L;
                 pending_li = li;
                 have_pending = true;
+                hold_longer = false;
+                for (size_t sj = si + 1; sj < r.segments.size() && !getenv("H2E_NO_HOLD_LONGER"); sj++) hold_longer = hold_longer || r.segments[sj].sel_stride != 0;
                 ctx->n_launches++;
                 seg_ev[si] = sync_event();
                 HIP_TRY(hipEventRecord(seg_ev[si], sa));
