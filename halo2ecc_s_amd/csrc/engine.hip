@@ -166,6 +166,8 @@ struct Stage {  // one buffer, used for one row kind at a time (12 KB per wave k
         u64 b[64][22];  // base row: 5 cells x 32 B, lane stride 176 B (conflict-free for 128-bit LDS access)
         u64 r[64][14];  // range row: 3 cells, lane stride 112 B
         u64 s[64][10];  // select row: 2 cells, lane stride 80 B
+        u64 r3[64][38]; // the 3 (or 2) range rows of one limb, written as one 288-byte (192-byte) segment: HBM write
+                        // throughput follows the contiguous segment size (exp/ubench/segwrite.hip); lane stride 304 B
     };
     u64* ptr[64];
 };
@@ -243,16 +245,52 @@ WI_INLINE u64 chunk18(const Limb& x, int i) {  // i-th 18-bit chunk of a <=128-b
     if (sh >= 64) lo = x.v[1] >> (sh - 64);
     return lo & 0x3ffffu;
 }
+// (a rolled loop: these are expanded at ~20 places each, and 18 unrolled pieces in flight cost registers)
+template <int PIECES>
+WI_INLINE void flush_range_group(Stage* st) {
+    lds_fence();
+    u32 lane = threadIdx.x;
+#pragma unroll 1
+    for (int i = 0; i < PIECES; i++) {
+        u32 chunk = i * 64 + lane;
+        u32 r = chunk / PIECES, piece = chunk - r * PIECES;
+        u64* p = st->ptr[r];
+        if (p != nullptr) *(ulonglong2*)(p + piece * 2) = *(const ulonglong2*)&st->r3[r][piece * 2];
+    }
+    lds_fence();
+}
+WI_INLINE void flush_range3(Stage* st) { flush_range_group<18>(st); }
+WI_INLINE void flush_range2(Stage* st) { flush_range_group<12>(st); }
 // assign_nonleading_limb: 3 rows, 7 cells
 WI_INLINE void emit_limb3(const LC& c, u32 row, const Limb& x) {
-    rowR(c, row, 7, fe_of(x), fe_u64(chunk18(x, 3)), fe_u64(chunk18(x, 0)));
-    rowR(c, row + 1, 6, FE0, fe_u64(chunk18(x, 4)), fe_u64(chunk18(x, 1)));
-    rowR(c, row + 2, 6, FE0, fe_u64(chunk18(x, 5)), fe_u64(chunk18(x, 2)));
+    Stage* st = c.st;
+    u32 lane = threadIdx.x;
+    u64* d = st->r3[lane];
+    stage_cell(d + 0, fe_of(x));
+    stage_cell(d + 4, fe_u64(chunk18(x, 3)));
+    stage_cell(d + 8, fe_u64(chunk18(x, 0)));
+    stage_cell(d + 12, FE0);
+    stage_cell(d + 16, fe_u64(chunk18(x, 4)));
+    stage_cell(d + 20, fe_u64(chunk18(x, 1)));
+    stage_cell(d + 24, FE0);
+    stage_cell(d + 28, fe_u64(chunk18(x, 5)));
+    stage_cell(d + 32, fe_u64(chunk18(x, 2)));
+    st->ptr[lane] = c.active ? c.range + (size_t)(row + c.orr) * 12 : nullptr;
+    flush_range3(st);
 }
 // leading limb in a 2-line range value (36..72 bits): 2 rows, 5 cells
 WI_INLINE void emit_lead2(const LC& c, u32 row, const Limb& x) {
-    rowR(c, row, 7, fe_of(x), fe_u64(chunk18(x, 2)), fe_u64(chunk18(x, 0)));
-    rowR(c, row + 1, 6, FE0, fe_u64(chunk18(x, 3)), fe_u64(chunk18(x, 1)));
+    Stage* st = c.st;
+    u32 lane = threadIdx.x;
+    u64* d = st->r3[lane];
+    stage_cell(d + 0, fe_of(x));
+    stage_cell(d + 4, fe_u64(chunk18(x, 2)));
+    stage_cell(d + 8, fe_u64(chunk18(x, 0)));
+    stage_cell(d + 12, FE0);
+    stage_cell(d + 16, fe_u64(chunk18(x, 3)));
+    stage_cell(d + 20, fe_u64(chunk18(x, 1)));
+    st->ptr[lane] = c.active ? c.range + (size_t)(row + c.orr) * 12 : nullptr;
+    flush_range2(st);
 }
 // assign_common: 1 row, 2 cells
 WI_INLINE void emit_common(const LC& c, u32 row, u64 x) { rowR(c, row, 3, fe_u64(x), fe_u64(x), FE0); }
@@ -1947,6 +1985,10 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
     static const size_t x_pad = getenv("H2E_X_LDS_PAD") ? (size_t)atol(getenv("H2E_X_LDS_PAD")) : 0;
     size_t xlds = grid.x > 4096 ? x_pad : 0;
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
+    if ((mode & 1) && launch->vtape &&                                                                                         \
+        ((size_t)launch->v_units * 2 + ((size_t)launch->v_int_slots * VSlots<FP>::W + VSlots<FP>::NF * 4)) * 64 * 8 +           \
+                sizeof(Stage) + 2 * H2E_VCHUNK * sizeof(H2EVRec) > 160 * 1024)                                                  \
+        return -3;   /* the host compiler's LDS budget and the kernel's static LDS disagree */                                 \
     if ((mode & 1) && launch->vtape)                                                                                           \
         hipLaunchKernelGGL(h2e_replay<FP>, dim3(blocks_per_sub * launch->n_vpieces), block,                                    \
                            ((size_t)launch->v_units * 2 + ((size_t)launch->v_int_slots * VSlots<FP>::W + VSlots<FP>::NF * 4)) * 64 * 8, \

@@ -770,7 +770,8 @@ struct h2e_program {
         uint32_t vbase = (uint32_t)h_vtape.size();   // multiple of H2E_VCHUNK
         seg_piece_begin[si] = (uint32_t)h_vpieces.size() / 2;
         uint32_t max_units = 0;
-        // LDS sizing: integer slots actually used; what is left of 140 KB (20 KB are static) bounds the staging units
+        // LDS sizing: integer slots actually used; what is left of 130 KB (28 KB are static: row staging for H2E_V_FULL ops,
+        // record chunks; h2e_engine_launch re-checks the sum) bounds the staging units
         uint32_t used_slots = 1;
         for (auto& d : dec)
             for (int w = 0; w < 2; w++)
@@ -779,7 +780,7 @@ struct h2e_program {
             for (auto& kv : rs.slot_of)
                 if (!is_fe_val(kv.first)) used_slots = std::max(used_slots, (uint32_t)kv.second + 1);
         const uint32_t slot_bytes = (2 * (uint32_t)L + 4) * 512;
-        const uint32_t unit_cap = std::min<uint32_t>(UNIT_MAX, (140u * 1024 - 8192 - used_slots * slot_bytes) / 1024);
+        const uint32_t unit_cap = std::min<uint32_t>(UNIT_MAX, (130u * 1024 - 8192 - used_slots * slot_bytes) / 1024);
         // one piece: gather records for its memory inputs, the prologue (if it restarts), the body
         auto emit_piece = [&](const Restart* rs, uint32_t pos_begin, uint32_t pos_end) {
             uint32_t piece_first = (uint32_t)out.size();
