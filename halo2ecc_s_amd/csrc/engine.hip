@@ -1965,6 +1965,48 @@ __global__ void __launch_bounds__(64) h2e_finalize_ecc(H2EPreKernel K, const Ins
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row-major advice rows -> one array per column (what halo2's advice columns are; context.rs:310-541 does this cell by
+// cell on the host).  A wave takes 64 rows: the 64 x COLS x 32 bytes are contiguous on the way in, each column's
+// 64 x 32 bytes contiguous on the way out; LDS in between.  HBM bound, 2 x 32 B per cell.
+template <int COLS>
+__global__ void __launch_bounds__(64) h2e_columns(const ulonglong2* __restrict__ in, ulonglong2* __restrict__ out, u64 rows,
+                                                  u64 tiles_per_instance) {
+    __shared__ ulonglong2 tile[64][COLS * 2 + 1];
+    u64 instance = blockIdx.x / tiles_per_instance, t = blockIdx.x % tiles_per_instance;
+    u64 row0 = t * 64;
+    u32 n = (u32)min((u64)64, rows - row0), lane = threadIdx.x;
+    const ulonglong2* src = in + (instance * rows + row0) * (COLS * 2);
+#pragma unroll
+    for (int k = 0; k < COLS * 2; k++) {
+        u32 piece = k * 64 + lane;
+        if (piece < n * COLS * 2) tile[piece / (COLS * 2)][piece % (COLS * 2)] = src[piece];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int col = 0; col < COLS; col++) {
+        ulonglong2* dst = out + ((instance * COLS + col) * rows + row0) * 2;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            u32 piece = k * 64 + lane;
+            if (piece < n * 2) dst[piece] = tile[piece / 2][col * 2 + (piece & 1)];
+        }
+    }
+}
+extern "C" int h2e_engine_columns(uint32_t cols, const void* in, void* out, uint64_t rows, uint32_t n_instances, hipStream_t stream) {
+    if (rows == 0 || n_instances == 0) return 0;
+    u64 tiles = (rows + 63) / 64;
+    if (tiles * n_instances > 0x7fffffffull) return -1;
+    dim3 grid((u32)(tiles * n_instances)), block(64);
+    switch (cols) {
+        case 5: hipLaunchKernelGGL(h2e_columns<5>, grid, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, rows, tiles); break;
+        case 3: hipLaunchKernelGGL(h2e_columns<3>, grid, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, rows, tiles); break;
+        case 2: hipLaunchKernelGGL(h2e_columns<2>, grid, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, rows, tiles); break;
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-callable launcher (C linkage, used by the C-ABI layer in h2e_capi.cpp)
 extern "C" int h2e_engine_set_consts(int field_pair, const H2EFieldConsts* host) {
     if (field_pair < 0 || field_pair > 2) return -1;

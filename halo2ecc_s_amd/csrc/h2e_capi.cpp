@@ -11,6 +11,7 @@
 #include "recorder_pairing.hpp"
 
 extern "C" int h2e_engine_set_consts(int field_pair, const H2EFieldConsts* host);
+extern "C" int h2e_engine_columns(uint32_t cols, const void* in, void* out, uint64_t rows, uint32_t n_instances, hipStream_t stream);
 extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
                                  uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream);
 extern "C" int h2e_engine_predict(int field_pair, int phase, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,
@@ -1653,6 +1654,16 @@ int h2e_program_launches(const h2e_program* p, uint64_t* out, uint32_t cap) {
         k++;
     }
     return (int)k;
+}
+
+int h2e_export_columns(h2e_ctx* ctx, uint32_t n_instances, uint64_t rows, uint32_t cols, const void* d_rows, void* d_columns,
+                       void* stream) {
+    if (!ctx || !d_rows || !d_columns) return fail(H2E_ERR_INVALID, "null argument");
+    if (cols != 5 && cols != 3 && cols != 2) return fail(H2E_ERR_INVALID, "cols must be 5 (base), 3 (range) or 2 (select)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = h2e_engine_columns(cols, d_rows, d_columns, rows, n_instances, (hipStream_t)stream);
+    if (rc != 0) return fail(H2E_ERR_HIP, rc < 0 ? "export: bad geometry" : std::string("export launch failed: ") + hipGetErrorString((hipError_t)rc));
+    return 0;
 }
 
 int h2e_set_profiling(h2e_ctx* ctx, int enable) {

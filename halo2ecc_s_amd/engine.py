@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "h2e_program_integer_chip_st", "h2e_program_msm_bn256_tile", "h2e_program_pairing_check_bn256",
     "h2e_program_pairing_check_bls12_381", "h2e_program_destroy", "h2e_program_shape", "h2e_run",
     "h2e_int_mul_batch", "h2e_msm_bn256_tile", "h2e_pairing_check_bn256", "h2e_pairing_check_bls12_381",
-    "h2e_last_run_launch_ms", "h2e_set_profiling", "h2e_program_outputs", "h2e_program_launches",
+    "h2e_last_run_launch_ms", "h2e_set_profiling", "h2e_program_outputs", "h2e_program_launches", "h2e_export_columns",
 ]
 
 
@@ -81,6 +81,7 @@ def lib():
     L.h2e_set_profiling.argtypes = [vp, i32]
     L.h2e_program_outputs.argtypes = [vp, C.POINTER(u32), u32]
     L.h2e_program_launches.argtypes = [vp, C.POINTER(C.c_uint64), u32]
+    L.h2e_export_columns.argtypes = [vp, u32, C.c_uint64, u32, vp, vp, vp]
     _lib = L
     return L
 
@@ -223,6 +224,17 @@ class Engine:
         s = stream if stream is not None else t.cuda.current_stream(self.device)
         _check(lib().h2e_run(self._h, program._h, n, d_inputs.data_ptr(), base.data_ptr(), rng.data_ptr(),
                              sel.data_ptr(), status.data_ptr(), s.cuda_stream))
+
+    def export_columns(self, rows_major, stream=None):
+        """row-major advice tensor [instances][rows][cols][4] -> column-major [instances][cols][rows][4] on the device
+        (h2e_export_columns: the halo2 side keeps one array per advice column)"""
+        t = self.torch
+        n, rows, cols, w = rows_major.shape
+        assert w == 4 and rows_major.is_contiguous()
+        out = t.empty((n, cols, rows, 4), dtype=rows_major.dtype, device=rows_major.device)
+        s = stream if stream is not None else t.cuda.current_stream(self.device)
+        _check(lib().h2e_export_columns(self._h, n, rows, cols, rows_major.data_ptr(), out.data_ptr(), s.cuda_stream))
+        return out
 
     def set_profiling(self, on):
         _check(lib().h2e_set_profiling(self._h, int(on)))

@@ -132,6 +132,15 @@ int h2e_pairing_check_bn256(h2e_ctx* ctx, uint32_t n_instances, const void* d_in
 int h2e_pairing_check_bls12_381(h2e_ctx* ctx, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
                                 void* d_select, void* d_status, void* stream);
 
+/* ---- hand-off to the halo2 side (device half) --------------------------------
+ * halo2 keeps one array per advice column; the reference's Records::_assign_to_{base,range,select}_chip
+ * (src/context.rs:310-541) copy the row-major `[(Option<N>, bool); COLS]` cells into them one by one.
+ * Transposes row-major advice arrays [instance][row][cols][4 words] into column-major
+ * [instance][cols][row][4 words] on the device (cols = 5 base, 3 range, 2 select); the assigned / permute flags and
+ * the fixed columns are shape artefacts (h2e_program_shape).  Asynchronous on `stream`. */
+int h2e_export_columns(h2e_ctx* ctx, uint32_t n_instances, uint64_t rows, uint32_t cols, const void* d_rows, void* d_columns,
+                       void* stream);
+
 /* Timing hook used by bench.py: HIP events recorded by the engine on the stream each kernel group is launched
  * on.  Returns the number of launched segments and fills two numbers per segment: ms[2i] = value chain
  * (predictor kernels + values-only replay), ms[2i+1] = full expansion (the inverse fix-up runs on its own stream and is not included; call after synchronising). */

@@ -71,6 +71,68 @@ def test_msm_tile(engine, oracle, n):
         compare_advice(prog, orun, base, rng, sel, instance=k)
 
 
+def test_msm_tile_full_size(engine, oracle):
+    """BASELINE configs[1]'s tile - 1024 points, 38.1 M advice cells - cell for cell against the oracle (which takes a
+    few seconds over all host cores), on the last of several tiles so that the multi-wave paths are exercised"""
+    import os
+    n, tiles = 1024, 3
+    ins = [synth.msm_bn256_tile_inputs(n, tile=100 + t, cheap_points=True)[0] for t in range(tiles)]
+    prog = Program.msm_bn256_tile(n)
+    base, rng, sel, status = _run(engine, prog, ins)
+    assert (status == 0).all(), status
+    orun = oracle_lib.run_msm_bn256_tile(n, ins[tiles - 1], threads=os.cpu_count())
+    assert orun.info.status == 0, orun.error
+    compare_advice(prog, orun, base, rng, sel, instance=tiles - 1)
+
+
+def test_msm_alternating_inputs_reuse_buffers(engine, oracle):
+    """Runs with different inputs into the same arrays and workspace: nothing may survive from the previous run (a
+    missing cross-stream dependency once passed every same-input repetition)."""
+    n, tiles = 96, 4
+    prog = Program.msm_bn256_tile(n, emit_shape=False)
+    sets = [[synth.msm_bn256_tile_inputs(n, tile=10 * k + t, cheap_points=True)[0] for t in range(tiles)] for k in range(2)]
+    d_in = [engine.upload_inputs(prog, np.stack(s)) for s in sets]
+    base, rng, sel, status = engine.alloc(prog, tiles)
+    for rep in range(4):
+        k = rep % 2
+        status.zero_()
+        engine.run(prog, d_in[k], base, rng, sel, status)
+        engine.torch.cuda.synchronize()
+        assert (status.cpu().numpy() == 0).all(), (rep, status.cpu().numpy())
+    orun = oracle_lib.run_msm_bn256_tile(n, sets[1][tiles - 1])
+    assert orun.info.status == 0, orun.error
+    compare_advice(prog, orun, base, rng, sel, instance=tiles - 1)
+
+
+@pytest.mark.parametrize("cols", [5, 3, 2])
+def test_export_columns(engine, cols):
+    """h2e_export_columns (SURVEY §8f-1, device half): row-major advice rows -> one array per column, bit exact;
+    row counts that are not a multiple of the 64-row tile, several instances"""
+    t = engine.torch
+    for rows in (1, 63, 64, 1000, 4099):
+        g = t.Generator(device="cuda").manual_seed(rows + cols)
+        x = t.randint(-2**62, 2**62, (3, rows, cols, 4), dtype=t.int64, device="cuda", generator=g)
+        y = engine.export_columns(x)
+        t.cuda.synchronize()
+        assert t.equal(y, x.permute(0, 2, 1, 3).contiguous())
+
+
+def test_export_columns_of_a_witness(engine, oracle):
+    """the exported columns of an MSM tile equal the oracle's Records columns"""
+    n = 6
+    inp, _ = synth.msm_bn256_tile_inputs(n, tile=5)
+    prog = Program.msm_bn256_tile(n)
+    base, rng, sel, status = _run(engine, prog, [inp])
+    assert (status == 0).all()
+    orun = oracle_lib.run_msm_bn256_tile(n, inp)
+    for region, arr in enumerate((base, rng, sel)):
+        cols = engine.export_columns(arr)
+        engine.torch.cuda.synchronize()
+        ovals, _ = orun.adv(region, arr.shape[1])
+        got = cols[0].cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, np.ascontiguousarray(ovals.transpose(1, 0, 2)))
+
+
 def test_msm_value_chain_does_not_depend_on_expansion(engine, oracle, monkeypatch):
     """The expansion of a cut segment runs on its own stream, concurrently with the value chain of the following
     segments, so the value chain may only read cells the value chain itself stored.  With the expansion of every
