@@ -1153,7 +1153,12 @@ int h2e_program_integer_chip_st(int fp, int emit_shape, h2e_program** out) {
     return 0;
 }
 
-int h2e_program_msm_bn256_tile(uint32_t n, int emit_shape, h2e_program** out) {
+static int program_msm_bn256_tile(uint32_t n, int emit_shape, bool with_select, h2e_program** out);
+int h2e_program_msm_bn256_tile(uint32_t n, int emit_shape, h2e_program** out) { return program_msm_bn256_tile(n, emit_shape, true, out); }
+int h2e_program_msm_bn256_tile_no_select(uint32_t n, int emit_shape, h2e_program** out) {
+    return program_msm_bn256_tile(n, emit_shape, false, out);
+}
+static int program_msm_bn256_tile(uint32_t n, int emit_shape, bool with_select, h2e_program** out) {
     h2e_program* p = nullptr;
     if (n == 0) return fail(H2E_ERR_INVALID, "n_points must be > 0");
     int rc = new_program(H2E_FIELD_BN256_FQ, emit_shape, out, p);
@@ -1162,6 +1167,7 @@ int h2e_program_msm_bn256_tile(uint32_t n, int emit_shape, h2e_program** out) {
         h2e::Recorder& r = *p->rec;
         uint32_t s = r.alloc_inputs(4 * n + 9);
         h2e::NativeScalarEccContext ecc(r, h2e::bn256_g1_params(), 0);
+        ecc.with_select = with_select;
         h2e::NativeScalarEccContext::MsmInputs mi{s + 4 * n + 2, s + 4 * n + 3, s + 4 * n + 4, s + 4 * n + 5};
         h2e::AssignedPoint res = ecc.msm_unsafe_from_inputs(n, s, mi, s + 4 * n, s + 4 * n + 1);
         h2e::AssignedPoint res_expect = ecc.assign_point(h2e::PointInput{s + 4 * n + 6, s + 4 * n + 7, s + 4 * n + 8, false});

@@ -323,6 +323,31 @@ struct NativeScalarEccContext {
     // The reference's test body (src/tests/native_scalar_ecc_chip.rs:34-47): assign_point x n, assign x n,
     // msm_unsafe, with forks where the reference loops over independent items.
     // Input layout: slots [0, 3n) = (x, y, z) per point, [3n, 4n) = scalars, then r1, r2 as given.
+    // false: msm_batch_on_group_non_zero_without_select_chip (ecc_chip.rs:91-221): groups of 2 points, the candidate is
+    // chosen by a bisection tree (bisec_candidate_non_zero, :913-933) instead of a select-chip lookup, no cache rows
+    bool with_select = true;
+    // ecc_chip.rs:901-911
+    AssignedNonZeroPoint ecc_bisec_non_zero_point(const AssignedCondition& cond, const AssignedNonZeroPoint& a,
+                                                  const AssignedNonZeroPoint& b) {
+        AssignedInteger x = ctx.bisec_int(cond, a.x, b.x);
+        AssignedInteger y = ctx.bisec_int(cond, a.y, b.y);
+        return AssignedNonZeroPoint{x, y};
+    }
+    // ecc_chip.rs:913-933
+    AssignedNonZeroPoint bisec_candidate_non_zero(const std::vector<AssignedNonZeroPoint>& candidates,
+                                                  const std::vector<AssignedCondition>& group_bits) {
+        std::vector<AssignedNonZeroPoint> curr = candidates;
+        for (auto& bit : group_bits) {
+            std::vector<AssignedNonZeroPoint> next;
+            for (size_t k = 0; k < curr.size(); k += 2) {
+                if (k + 1 >= curr.size()) throw std::runtime_error("bisec_candidate: odd chunk");
+                next.push_back(ecc_bisec_non_zero_point(bit, curr[k + 1], curr[k]));
+            }
+            curr = next;
+        }
+        if (curr.size() != 1) throw std::runtime_error("bisec_candidate: size != 1");
+        return curr[0];
+    }
     AssignedPoint msm_unsafe_from_inputs(uint32_t n, uint32_t first_slot, const MsmInputs& mi, uint32_t gen_x_slot,
                                          uint32_t gen_y_slot) {
         Recorder& c = ctx;
@@ -364,17 +389,17 @@ struct NativeScalarEccContext {
         };
 
         // ---- msm_batch_on_group_non_zero_with_select_chip (ecc_chip.rs:223-371) ----
-        if (!(n <= MSM_PREFIX_OFFSET)) throw std::runtime_error("msm: too many points");
+        if (with_select && !(n <= MSM_PREFIX_OFFSET)) throw std::runtime_error("msm: too many points");
         // ecc_reduce_non_zero(points): bisec_int results have times == 1, so no rows (ecc_chip.rs:233-236)
         AssignedNonZeroPoint rand_acc_point = assign_non_zero_point(mi.r1_x, mi.r1_y);
         AssignedNonZeroPoint rand_line_point = assign_non_zero_point(mi.r2_x, mi.r2_y);
         AssignedNonZeroPoint rand_acc_point_neg = ecc_reduce_non_zero(ecc_neg_non_zero(rand_acc_point));
         AssignedNonZeroPoint rand_line_point_neg = ecc_reduce_non_zero(ecc_neg_non_zero(rand_line_point));
 
-        size_t best_group_size = 5;
+        size_t best_group_size = with_select ? 5 : 2;
         size_t n_group = (n + best_group_size - 1) / best_group_size;
         size_t group_size = (n + n_group - 1) / n_group;
-        size_t group_prefix = get_and_increase_msm_prefix();
+        size_t group_prefix = with_select ? get_and_increase_msm_prefix() : 0;
         size_t n_chunks = (n + group_size - 1) / group_size;
         size_t n_full = n / group_size;  // groups with exactly group_size points
 
@@ -400,13 +425,13 @@ struct NativeScalarEccContext {
             const AssignedNonZeroPoint& init = (group_index % 2 == 0) ? init_even : init_odd;
             cl.clear();
             cl.push_back(init);
-            assign_cache_point_non_zero(init, group_prefix + group_index, 0);
+            if (with_select) assign_cache_point_non_zero(init, group_prefix + group_index, 0);
             for (uint32_t i = 1; i < (1u << pts.size()); i++) {
                 uint32_t pos = __builtin_ctz(i);
                 uint32_t other = i - (1u << pos);
                 AssignedNonZeroPoint p = ecc_add_unsafe(cl[other], pts[pos]);
                 p = ecc_reduce_non_zero(p);
-                assign_cache_point_non_zero(p, group_prefix + group_index, i);
+                if (with_select) assign_cache_point_non_zero(p, group_prefix + group_index, i);
                 cl.push_back(p);
                 ctx.cut();
             }
@@ -521,8 +546,26 @@ struct NativeScalarEccContext {
                 std::vector<AssignedCondition> group_bits;
                 for (size_t j = lo; j < hi; j++)
                     group_bits.push_back(AssignedCondition{c.param(AssignedValue{c.strand_ref(bits0[wi].v.ref, seg_bits, (uint32_t)j)})});
-                AssignedNonZeroPoint ci = pick_and_select(table_aux[group_index], group_bits, group_index + group_prefix,
-                                                          (int64_t)(win_sel + group_index));
+                AssignedNonZeroPoint ci;
+                if (with_select) {
+                    ci = pick_and_select(table_aux[group_index], group_bits, group_index + group_prefix, (int64_t)(win_sel + group_index));
+                } else {
+                    // the candidates as handles (their cells are listed in the group's table); the value chain follows
+                    // the bisection tree itself (BISEC_INT ops), the predictor uses the select pre-kernel's pick
+                    std::vector<AssignedNonZeroPoint> cands;
+                    for (uint32_t i = 0; i < (1u << (hi - lo)); i++) {
+                        const uint32_t* t = &c.aux[table_aux[group_index] + i * NC];
+                        AssignedNonZeroPoint q;
+                        for (int j = 0; j < L; j++) {
+                            q.x.limbs_le[j] = t[j];
+                            q.y.limbs_le[j] = t[L + 1 + j];
+                        }
+                        q.x.native = t[L];
+                        q.y.native = t[2 * L + 1];
+                        cands.push_back(q);
+                    }
+                    ci = bisec_candidate_non_zero(cands, group_bits);
+                }
                 acc = ecc_add_unsafe(ci, acc);
                 c.cut();
             }

@@ -19,6 +19,7 @@ EXPORTED_SYMBOLS = [
     "h2e_program_pairing_check_bls12_381", "h2e_program_destroy", "h2e_program_shape", "h2e_run",
     "h2e_int_mul_batch", "h2e_msm_bn256_tile", "h2e_pairing_check_bn256", "h2e_pairing_check_bls12_381",
     "h2e_last_run_launch_ms", "h2e_set_profiling", "h2e_program_outputs", "h2e_program_launches", "h2e_export_columns",
+    "h2e_program_msm_bn256_tile_no_select",
 ]
 
 
@@ -67,6 +68,7 @@ def lib():
     L.h2e_program_int_mul_batch.argtypes = [i32, u32, i32, C.POINTER(vp)]
     L.h2e_program_integer_chip_st.argtypes = [i32, i32, C.POINTER(vp)]
     L.h2e_program_msm_bn256_tile.argtypes = [u32, i32, C.POINTER(vp)]
+    L.h2e_program_msm_bn256_tile_no_select.argtypes = [u32, i32, C.POINTER(vp)]
     L.h2e_program_pairing_check_bn256.argtypes = [i32, C.POINTER(vp)]
     L.h2e_program_pairing_check_bls12_381.argtypes = [i32, C.POINTER(vp)]
     L.h2e_program_destroy.argtypes = [vp]
@@ -124,8 +126,9 @@ class Program:
         return cls._make(lib().h2e_program_integer_chip_st, field_pair, int(emit_shape))
 
     @classmethod
-    def msm_bn256_tile(cls, n_points, emit_shape=True):
-        return cls._make(lib().h2e_program_msm_bn256_tile, n_points, int(emit_shape))
+    def msm_bn256_tile(cls, n_points, emit_shape=True, with_select=True):
+        f = lib().h2e_program_msm_bn256_tile if with_select else lib().h2e_program_msm_bn256_tile_no_select
+        return cls._make(f, n_points, int(emit_shape))
 
     @classmethod
     def pairing_check_bn256(cls, emit_shape=True):

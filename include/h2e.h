@@ -70,6 +70,10 @@ int h2e_program_integer_chip_st(int field_pair, int emit_shape, h2e_program** ou
  * assign_point(expected), ecc_assert_equal.
  * inputs: 3n slots (x, y, z-flag) per point, n scalars, generator (x,y), r1 (x,y), r2 (x,y), expected (x,y,z). */
 int h2e_program_msm_bn256_tile(uint32_t n_points, int emit_shape, h2e_program** out);
+/* The same test body on a context without the select chip (NativeScalarEccContext::new_without_select_chip,
+ * src/context.rs:190-207): msm_batch_on_group_non_zero_without_select_chip (src/circuit/ecc_chip.rs:91-221), groups of
+ * two points, candidates chosen by bisec_candidate_non_zero (:913-933).  SURVEY.md §8(f)-3.  Same inputs. */
+int h2e_program_msm_bn256_tile_no_select(uint32_t n_points, int emit_shape, h2e_program** out);
 /* check_pairing([(a, b), (-a, b)]) with G2 as constants (PairingChipOps::check_pairing,
  * src/circuit/pairing_chip.rs:173-176; shape of src/tests/native_scalar_pairing_chip.rs:67-97).
  * inputs: b.x.c0, b.x.c1, b.y.c0, b.y.c1, (-a).x, (-a).y, (-a).z, a.x, a.y, a.z. */

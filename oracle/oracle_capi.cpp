@@ -93,11 +93,18 @@ void* oracle_run_integer_chip_st(int fp, const uint64_t* inputs) {
 }
 
 // src/tests/native_scalar_ecc_chip.rs:34-47 for one tile
-void* oracle_run_msm_bn256_tile(uint32_t n, const uint64_t* inputs, int threads) {
+static void* run_msm_bn256_tile(uint32_t n, const uint64_t* inputs, int threads, bool with_select);
+void* oracle_run_msm_bn256_tile(uint32_t n, const uint64_t* inputs, int threads) { return run_msm_bn256_tile(n, inputs, threads, true); }
+// the same body on NativeScalarEccContext::new_without_select_chip (src/context.rs:190-207; ecc_chip.rs:91-221)
+void* oracle_run_msm_bn256_tile_no_select(uint32_t n, const uint64_t* inputs, int threads) {
+    return run_msm_bn256_tile(n, inputs, threads, false);
+}
+static void* run_msm_bn256_tile(uint32_t n, const uint64_t* inputs, int threads, bool with_select) {
     return guarded([&](Run& r) {
         IntegerContext ic(r.ctx, BnFq::modulus());
         Inputs in{inputs, 4};
-        NativeScalarEccContext ecc = NativeScalarEccContext::new_with_select_chip(ic, bn256_g1_params());
+        NativeScalarEccContext ecc = with_select ? NativeScalarEccContext::new_with_select_chip(ic, bn256_g1_params())
+                                                 : NativeScalarEccContext::new_without_select_chip(ic, bn256_g1_params());
         ecc.n_threads = threads;
         // the generator comes in as an input too (slots 4n, 4n+1); it must be C::generator()
         ecc.curve.generator = in.point(4 * n, 4 * n + 1, 4 * n + 8);

@@ -31,11 +31,12 @@ def load():
     L = C.CDLL(LIB)
     vp = C.c_void_p
     for name in ("oracle_run_int_mul_batch", "oracle_run_integer_chip_st", "oracle_run_msm_bn256_tile",
-                 "oracle_run_pairing_check_bn256", "oracle_run_pairing_check_bls12_381"):
+                 "oracle_run_msm_bn256_tile_no_select", "oracle_run_pairing_check_bn256", "oracle_run_pairing_check_bls12_381"):
         getattr(L, name).restype = vp
     L.oracle_run_int_mul_batch.argtypes = [C.c_int, C.c_uint32, vp]
     L.oracle_run_integer_chip_st.argtypes = [C.c_int, vp]
     L.oracle_run_msm_bn256_tile.argtypes = [C.c_uint32, vp, C.c_int]
+    L.oracle_run_msm_bn256_tile_no_select.argtypes = [C.c_uint32, vp, C.c_int]
     L.oracle_run_pairing_check_bn256.argtypes = [vp]
     L.oracle_run_pairing_check_bls12_381.argtypes = [vp]
     L.oracle_info.argtypes = [vp, C.POINTER(Info)]
@@ -120,9 +121,10 @@ def run_integer_chip_st(fp, inputs):
     return Run(load().oracle_run_integer_chip_st(fp, p))
 
 
-def run_msm_bn256_tile(n, inputs, threads=1):
+def run_msm_bn256_tile(n, inputs, threads=1, with_select=True):
     a, p = _ptr(inputs)
-    return Run(load().oracle_run_msm_bn256_tile(n, p, threads))
+    f = load().oracle_run_msm_bn256_tile if with_select else load().oracle_run_msm_bn256_tile_no_select
+    return Run(f(n, p, threads))
 
 
 def run_pairing_check_bn256(inputs):

@@ -21,7 +21,7 @@ def _oracle_run(doc):
     if k == "integer_chip_st":
         return oracle_lib.run_integer_chip_st(p["field_pair"], inp)
     if k == "msm_bn256_tile":
-        return oracle_lib.run_msm_bn256_tile(p["n"], inp)
+        return oracle_lib.run_msm_bn256_tile(p["n"], inp, with_select=p.get("with_select", True))
     raise AssertionError(k)
 
 

@@ -154,6 +154,19 @@ def test_msm_value_chain_does_not_depend_on_expansion(engine, oracle, monkeypatc
     assert np.array_equal(got[tail0:], ovals[tail0:]), "tail differs when the windows' expansion is left out"
 
 
+@pytest.mark.parametrize("n", [1, 5, 12])
+def test_msm_tile_no_select(engine, oracle, n):
+    """MSM without the select chip (ecc_chip.rs:91-221, candidates by bisection trees)"""
+    ins = [synth.msm_bn256_tile_inputs(n, tile=60 + t)[0] for t in range(2)]
+    prog = Program.msm_bn256_tile(n, with_select=False)
+    base, rng, sel, status = _run(engine, prog, ins)
+    assert (status == 0).all(), status
+    for k, inp in enumerate(ins):
+        orun = oracle_lib.run_msm_bn256_tile(n, inp, with_select=False)
+        assert orun.info.status == 0, orun.error
+        compare_advice(prog, orun, base, rng, sel, instance=k)
+
+
 def test_msm_tile_with_identity_inputs(engine, oracle):
     """identity points go through ecc_bisec_to_non_zero_point / ecc_bisec_scalar (quirk Q9)"""
     n = 6
@@ -206,7 +219,7 @@ def test_engine_matches_golden_fixtures(engine, doc):
     k, p = doc["kind"], doc["params"]
     prog = {"int_mul_batch": lambda: Program.int_mul_batch(p["field_pair"], p["n"]),
             "integer_chip_st": lambda: Program.integer_chip_st(p["field_pair"]),
-            "msm_bn256_tile": lambda: Program.msm_bn256_tile(p["n"])}[k]()
+            "msm_bn256_tile": lambda: Program.msm_bn256_tile(p["n"], with_select=p.get("with_select", True))}[k]()
     assert [prog.base_rows, prog.range_rows, prog.select_rows] == doc["rows"]
     assert prog.n_advice_cells == doc["n_advice_cells"] and prog.n_permutations == doc["n_permutations"]
     base, rng, sel, status = _run(engine, prog, [golden_util.inputs_of(doc)])

@@ -42,6 +42,21 @@ def test_msm_tile_shape(oracle, h2e_built, n):
     compare_shape(prog, orun)
 
 
+@pytest.mark.parametrize("n", [1, 3, 6])
+def test_msm_tile_no_select_shape(oracle, h2e_built, n):
+    """the same body on a context without the select chip (msm_batch_on_group_non_zero_without_
+    select_chip, ecc_chip.rs:91-221: groups of two, bisec_candidate_non_zero).  The oracle's witness satisfies the
+    reference's constraints (no select rows); the recorder's shape artefacts equal the oracle's."""
+    inputs, _ = synth.msm_bn256_tile_inputs(n, tile=40 + n)
+    prog = Program.msm_bn256_tile(n, with_select=False)
+    orun = oracle_lib.run_msm_bn256_tile(n, inputs, with_select=False)
+    assert orun.info.status == 0, orun.error
+    ok, msg = orun.check()
+    assert ok, msg
+    assert prog.select_offset == 0
+    compare_shape(prog, orun)
+
+
 def test_pairing_check_bn256_shape(oracle, h2e_built):
     """config 4 unit (2-pair bn256 check_pairing, G2 as per-instance constants -> fixed patches)"""
     inputs = synth.pairing_check_bn256_inputs()
