@@ -1518,7 +1518,7 @@ WI_INLINE Mont<4> mont_n(const H2EFieldConsts* fc) {
 // Fix-up of the is_zero inverse witnesses (base_chip.rs:298-321: b = a^-1 or 0), batched with Montgomery's
 // trick: one lane owns FIXUP_K consecutive cells of one strand's list; the destination cells themselves hold
 // the running prefix products between the forward and the backward pass.
-static constexpr int FIXUP_K = 32;
+static constexpr int FIXUP_K = 64;
 __global__ void __launch_bounds__(64) h2e_fixup_inverses(H2ELaunch L, const InstanceDesc* inst, u32 n_instances,
                                                          const H2EFieldConsts* fc) {
     u32 chunks = (L.n_fixups + FIXUP_K - 1) / FIXUP_K;

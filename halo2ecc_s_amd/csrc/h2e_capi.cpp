@@ -1562,10 +1562,14 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
                 HIP_TRY(hipEventRecord(seg_ev[si], sa));
                 continue;
             }
+            // a small expansion (the MSM tail: 763 waves) does not queue behind a big one on the expansion stream: it runs
+            // beside it on the side stream as soon as its value chain is done
+            hipStream_t sx = ((uint64_t)L.n_sub * L.n_strands * n_instances < (1u << 18) && !getenv("H2E_NO_SMALL_X_ASIDE")) ? sc : sb;
+            if (sx == sc) used_se = true;
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, sa));
-            HIP_TRY(hipStreamWaitEvent(sb, e, 0));
-            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sb));
+            HIP_TRY(hipStreamWaitEvent(sx, e, 0));
+            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sx));
             // test hook: leave out the expansion of cut segment <si> (or, with -1, of every cut segment but the last):
             // whatever the value chain reads must have been stored by the value chain itself (tests/test_parity_gpu.py)
             bool skip_x = false;
@@ -1574,9 +1578,9 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
                 for (size_t sj = si + 1; sj < r.segments.size(); sj++) later_cut = later_cut || p->seg_n_sub[sj] > 1;
                 skip_x = atoi(sx) == (int)si || (atoi(sx) == -1 && later_cut);
             }
-            if (!skip_x && (lrc = launch(2, sb))) return lrc;
-            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sb));
-            if (!skip_x && (lrc = fixup_after(sb))) return lrc;
+            if (!skip_x && (lrc = launch(2, sx))) return lrc;
+            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sx));
+            if (!skip_x && (lrc = fixup_after(sx))) return lrc;
         } else if (p->seg_side_dep[si] != -2 && !getenv("H2E_DEBUG_NO_SIDE")) {
             // runs beside the value chain: after the last segment it reads, before the first segment that reads it
             int32_t depi = p->seg_side_dep[si];
