@@ -5,8 +5,8 @@ import numpy as np, torch
 from halo2ecc_s_amd import Engine, Program, synth
 eng = Engine(0)
 out = {}
-for name, n, mk, gen, cells in (("bn256", 64, Program.pairing_check_bn256, synth.pairing_check_bn256_inputs, 6165013),
-                                ("bls12_381", 16, Program.pairing_check_bls12_381, synth.pairing_check_bls12_381_inputs, 7952811)):
+for name, n, mk, gen, cells in (("bn256", int(os.environ.get("N_BN", "64")), Program.pairing_check_bn256, synth.pairing_check_bn256_inputs, 6165013),
+                                ("bls12_381", int(os.environ.get("N_BLS", "16")), Program.pairing_check_bls12_381, synth.pairing_check_bls12_381_inputs, 7952811)):
     prog = mk(emit_shape=False)
     base_ins = [gen(instance=k) for k in range(4)]
     ins = np.stack([base_ins[k % 4] for k in range(n)])
@@ -17,4 +17,6 @@ for name, n, mk, gen, cells in (("bn256", 64, Program.pairing_check_bn256, synth
         eng.run(prog, d, b, r, s, st); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     assert int(st.abs().max()) == 0
     out[name] = {"instances": n, "ms": dt * 1e3, "cells_per_s": cells * n / dt, "pairing_checks_per_s": n / dt}
+    del d, b, r, s, st
+    torch.cuda.empty_cache()
 print(json.dumps(out))
