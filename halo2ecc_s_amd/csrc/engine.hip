@@ -1420,6 +1420,237 @@ __global__ void __launch_bounds__(64) h2e_replay(H2ELaunch L, const InstanceDesc
 }
 
 // ================================================================================================
+// Level-parallel replay (host: compile_replay in h2e_capi.cpp).  A wave replays ONE (instance, strand); lanes are given
+// to independent ops: step s runs records 64 s .. 64 s + 63, all of one opcode (H2E_V_NOP in unused lanes), values live
+// in LDS slots shared by the wave.  For a pairing check this is ~30 k steps instead of a chain of 175 k ops.
+template <class FP>
+struct LVals {
+    static constexpr int W = 2 * FP::L + 4;
+    u64* v;   // [slot][W]
+};
+template <class FP>
+WI_INLINE IntVal<FP> lv_ld_int(const LVals<FP>& lv, u32 slot) {
+    IntVal<FP> r;
+    const u64* p = lv.v + (size_t)slot * LVals<FP>::W;
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) {
+        r.l[i].v[0] = p[2 * i];
+        r.l[i].v[1] = p[2 * i + 1];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.native.v[i] = p[2 * FP::L + i];
+    return r;
+}
+template <class FP>
+WI_INLINE Fe lv_ld_fe(const LVals<FP>& lv, u32 slot) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.v[i] = lv.v[(size_t)slot * LVals<FP>::W + i];
+    return r;
+}
+// operands that come from cells: written by other kernels, or by an H2E_V_FULL step of this wave (behind a fence)
+template <class FP>
+WI_INLINE IntVal<FP> l_src_int(const LVals<FP>& lv, const LC& c, const VHdr& h, int which, const u32* lrefs) {
+    u32 kind = (h.w[7] >> (3 * which)) & 7u, word = h.w[2 + which];
+    if (kind == H2E_VSRC_INT_SLOT) return lv_ld_int<FP>(lv, word);
+    u32 refs[FP::L + 1];
+#pragma unroll
+    for (int j = 0; j <= FP::L; j++) refs[j] = lrefs[word + j];
+    return ld_int<FP>(c, refs);
+}
+template <class FP>
+WI_INLINE Fe l_src_fe(const LVals<FP>& lv, const LC& c, const VHdr& h, int which) {
+    u32 kind = (h.w[7] >> (3 * which)) & 7u, word = h.w[2 + which];
+    if (kind == H2E_VSRC_FE_SLOT) return lv_ld_fe<FP>(lv, word);
+    return ld_fe(c, word);
+}
+template <class FP>
+WI_INLINE void l_out_int(const LVals<FP>& lv, const LC& c, const VHdr& h, bool mul_like, const Limb* l, const Fe& native) {
+    if ((h.w[0] >> 8) & H2E_VFLAG_STORE) {
+        if (mul_like) {
+#pragma unroll
+            for (int i = 0; i < FP::L; i++) stR(c, h.w[6] + 3 * i, 0, fe_of(l[i]));
+            stB(c, h.w[5], 4, native);
+        } else {
+#pragma unroll
+            for (int i = 0; i < FP::L; i++) stB(c, h.w[5] + i, 4, fe_of(l[i]));
+            stB(c, h.w[5] + FP::L, 4, native);
+        }
+    }
+    u32 dst = h.w[0] >> 16;
+    if (dst != 0xffffu) {
+        u64* p = lv.v + (size_t)dst * LVals<FP>::W;
+#pragma unroll
+        for (int i = 0; i < FP::L; i++) {
+            p[2 * i] = l[i].v[0];
+            p[2 * i + 1] = l[i].v[1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) p[2 * FP::L + i] = native.v[i];
+    }
+}
+template <class FP>
+WI_INLINE void l_out_w(const LVals<FP>& lv, const LC& c, const VHdr& h, const Wd<FP::WW>& x) {
+    Limb l[FP::L];
+    split_limbs<FP>(x, l);
+    l_out_int<FP>(lv, c, h, true, l, native_of_w<FP>(c, x));
+}
+template <class FP>
+WI_INLINE void l_out_fe(const LVals<FP>& lv, const LC& c, const VHdr& h, const Fe& v) {
+    if ((h.w[0] >> 8) & H2E_VFLAG_STORE) stB(c, h.w[5], 4, v);
+    u32 dst = h.w[0] >> 16;
+    if (dst != 0xffffu) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) lv.v[(size_t)dst * LVals<FP>::W + i] = v.v[i];
+    }
+}
+// one lane's op of a step; `opc` is the step's opcode (wave-uniform), everything else is per lane
+template <class FP>
+WI_INLINE void exec_lop(const LVals<FP>& lv, const LC& c, u32 opc, const VHdr& h, const u32* lrefs) {
+    constexpr int L = FP::L;
+    u32 imm = h.w[1];
+    if (opc == H2E_V_MUL) {
+        IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs), b = l_src_int<FP>(lv, c, h, 1, lrefs);
+        Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
+        Wd<FPX<FP>::QW> dq;
+        Wd<FP::WW> rem;
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW>(A, B)), dq, rem);
+        l_out_w<FP>(lv, c, h, rem);
+    } else if (opc == H2E_V_SUB) {
+        IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs), b = l_src_int<FP>(lv, c, h, 1, lrefs);
+        Limb s[L];
+#pragma unroll
+        for (int i = 0; i < L; i++) s[i] = wd_sub<2>(wd_add<2>(a.l[i], wd_load<2>(c.fc->ceil_limbs[imm][i])), b.l[i]);
+        l_out_int<FP>(lv, c, h, false, s, addmod_n(c, submod_n(c, a.native, b.native), wd_load<4>(c.fc->ceil_native[imm])));
+    } else if (opc == H2E_V_ADD) {
+        IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs), b = l_src_int<FP>(lv, c, h, 1, lrefs);
+        Limb s[L];
+#pragma unroll
+        for (int i = 0; i < L; i++) s[i] = wd_add<2>(a.l[i], b.l[i]);
+        l_out_int<FP>(lv, c, h, false, s, addmod_n(c, a.native, b.native));
+    } else if (opc == H2E_V_REDUCE) {
+        IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs);
+        Wd<FP::WW> rem;
+        u64 dsmall;
+        divrem_small<FP>(c, compose<FP, FPX<FP>::AW>(a.l), dsmall, rem);
+        l_out_w<FP>(lv, c, h, rem);
+    } else if (opc == H2E_V_NEG) {
+        IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs);
+        Limb s[L];
+#pragma unroll
+        for (int i = 0; i < L; i++) s[i] = wd_sub<2>(wd_load<2>(c.fc->ceil_limbs[imm][i]), a.l[i]);
+        l_out_int<FP>(lv, c, h, false, s, submod_n(c, wd_load<4>(c.fc->ceil_native[imm]), a.native));
+    } else if (opc == H2E_V_MUL_SMALL) {
+        IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs);
+        Wd<1> k = wd_from_u64<1>(imm);
+        Limb s[L];
+#pragma unroll
+        for (int i = 0; i < L; i++) s[i] = wd_resize<2>(wd_mul<2, 1>(a.l[i], k));
+        l_out_int<FP>(lv, c, h, false, s, mod_n<5>(c, wd_mul<4, 1>(a.native, k)));
+    } else if (opc == H2E_V_DIV) {
+        IntVal<FP> b = l_src_int<FP>(lv, c, h, 0, lrefs), a = l_src_int<FP>(lv, c, h, 1, lrefs);
+        Wd<FPX<FP>::QW> q0;
+        Wd<FP::WW> a_red, b_red, cv;
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(compose<FP, FPX<FP>::AW>(a.l)), q0, a_red);
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(compose<FP, FPX<FP>::AW>(b.l)), q0, b_red);
+        Wd<FP::WW> binv = wd_inv_mod<FP::WW>(b_red, wd_load<FP::WW>(c.fc->w));
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FP::WW, FP::WW>(a_red, binv)), q0, cv);
+        l_out_w<FP>(lv, c, h, cv);
+    } else if (opc == H2E_V_MASK) {
+        IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs);
+        Fe coeff = l_src_fe<FP>(lv, c, h, 1);
+        bool keep = !wd_is_zero<4>(coeff);
+        Limb s[L];
+#pragma unroll
+        for (int i = 0; i < L; i++) s[i] = keep ? a.l[i] : wd_zero<2>();
+        l_out_int<FP>(lv, c, h, false, s, keep ? a.native : wd_zero<4>());
+    } else if (opc == H2E_V_BISEC_INT) {
+        Fe cond = l_src_fe<FP>(lv, c, h, 0);
+        IntVal<FP> a = l_src_int<FP>(lv, c, h, 1, lrefs), b = l_src_int<FP>(lv, c, h, 2, lrefs);
+        bool take_a = !wd_is_zero<4>(cond);
+        Limb s[L];
+#pragma unroll
+        for (int i = 0; i < L; i++) s[i] = take_a ? a.l[i] : b.l[i];
+        l_out_int<FP>(lv, c, h, false, s, take_a ? a.native : b.native);
+    } else if (opc == H2E_V_IS_ZERO) {
+        IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs);
+        bool all_zero = true;
+#pragma unroll
+        for (int i = 0; i < L; i++) all_zero = all_zero && wd_is_zero<2>(a.l[i]);
+        bool is_w = wd_eq<4>(a.native, wd_load<4>(c.fc->w_native));
+#pragma unroll
+        for (int i = 0; i < FP::PW; i++) is_w = is_w && wd_eq<2>(a.l[i], wd_load<2>(c.fc->w_limbs[i]));
+        l_out_fe<FP>(lv, c, h, fe_u64((all_zero || is_w) ? 1 : 0));
+    } else if (opc == H2E_V_NOT) {
+        l_out_fe<FP>(lv, c, h, submod_n(c, fe_u64(1), l_src_fe<FP>(lv, c, h, 0)));
+    } else if (opc == H2E_V_AND || opc == H2E_V_OR || opc == H2E_V_XNOR) {
+        Fe a = l_src_fe<FP>(lv, c, h, 0), b = l_src_fe<FP>(lv, c, h, 1);
+        u64 r = opc == H2E_V_AND ? (a.v[0] & b.v[0]) : opc == H2E_V_OR ? (a.v[0] | b.v[0]) : (1 ^ a.v[0] ^ b.v[0]);
+        l_out_fe<FP>(lv, c, h, fe_u64(r));
+    }
+}
+
+template <class FP>
+__global__ void __launch_bounds__(64) h2e_replay_levels(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
+    u32 instance = blockIdx.x / L.n_strands, strand = blockIdx.x % L.n_strands, lane = threadIdx.x;
+    InstanceDesc d = inst[instance];
+    LC c;
+    c.base = d.base;
+    c.range = d.range;
+    c.select = d.select;
+    c.inputs = d.inputs;
+    c.status = d.status;
+    c.ob = L.strand_base0 + strand * L.delta_base;
+    c.orr = L.strand_range0 + strand * L.delta_range;
+    c.os = L.strand_select0 + strand * L.delta_select;
+    c.params = L.params + (size_t)strand * L.n_params;
+    c.aux = L.aux;
+    c.pool = L.const_pool;
+    c.fc = &g_fc[FP::ID];
+    c.strand = strand;
+    c.input_stride = L.input_stride;
+    c.hints = d.hints;
+    c.hint_stride = L.hint_stride;
+    c.sel = d.sel;
+    c.sel_stride = L.sel_stride;
+    __shared__ Stage stage;
+    extern __shared__ ulonglong2 l_dyn[];
+    LVals<FP> lv;
+    lv.v = (u64*)l_dyn;
+    c.st = &stage;
+    c.active = true;
+    __builtin_amdgcn_s_setprio(3);
+    auto fetch = [&](u32 step, uint4* r) {
+        const uint4* p = (const uint4*)(L.lrecs + (size_t)step * 64 + lane);
+        r[0] = p[0];
+        r[1] = p[1];
+    };
+    uint4 nxt[2];
+    fetch(0, nxt);
+    for (u32 step = 0; step < L.l_steps; step++) {
+        VHdr h;
+        h.w[0] = nxt[0].x; h.w[1] = nxt[0].y; h.w[2] = nxt[0].z; h.w[3] = nxt[0].w;
+        h.w[4] = nxt[1].x; h.w[5] = nxt[1].y; h.w[6] = nxt[1].z; h.w[7] = nxt[1].w;
+        if (step + 1 < L.l_steps) fetch(step + 1, nxt);   // the next step's records are in flight while this one runs
+        u32 opc = __builtin_amdgcn_readfirstlane(h.w[0]) & 0xffu;   // lane 0 always holds an op
+        if (opc == H2E_V_FULL) {
+            // the tape op itself, for the whole wave: its rows are its results.  What it reads may have been stored by
+            // other lanes in earlier steps, and later steps read its rows: fence on both sides.
+            __threadfence();
+            H2EOp op = L.tape[__builtin_amdgcn_readfirstlane(h.w[1])];
+            op.opcode = (uint16_t)__builtin_amdgcn_readfirstlane(op.opcode);
+            c.active = lane == 0;
+            exec_op<FP, false>(c, op);
+            c.active = true;
+            __threadfence();
+        } else if ((h.w[0] & 0xffu) != H2E_V_NOP) {
+            exec_lop<FP>(lv, c, opc, h, L.lrefs);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave's LDS ops complete in order; keep the compiler honest
+    }
+}
+
+// ================================================================================================
 // Montgomery arithmetic (R = 2^(64 N)) — used by the value-predictor kernels (mod w) and the inverse fix-up (mod n)
 template <int N>
 struct Mont {
@@ -2027,6 +2258,11 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
     static const size_t x_pad = getenv("H2E_X_LDS_PAD") ? (size_t)atol(getenv("H2E_X_LDS_PAD")) : 0;
     size_t xlds = grid.x > 4096 ? x_pad : 0;
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
+    if ((mode & 1) && launch->lrecs) {                                                                                         \
+        hipLaunchKernelGGL(h2e_replay_levels<FP>, dim3(n_instances * launch->n_strands), block,                                \
+                           (size_t)launch->l_slots * LVals<FP>::W * 8, stream, *launch, inst, n_instances);                   \
+        mode &= ~1;                                                                                                            \
+    }                                                                                                                          \
     if ((mode & 1) && launch->vtape &&                                                                                         \
         ((size_t)launch->v_units * 2 + ((size_t)launch->v_int_slots * VSlots<FP>::W + VSlots<FP>::NF * 4)) * 64 * 8 +           \
                 sizeof(Stage) + 2 * H2E_VCHUNK * sizeof(H2EVRec) > 160 * 1024)                                                  \

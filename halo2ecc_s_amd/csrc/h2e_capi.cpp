@@ -78,6 +78,12 @@ struct h2e_program {
     std::vector<uint32_t> h_vpieces;
     H2EVRec* d_vtape = nullptr;
     uint32_t* d_vpieces = nullptr;
+    // level-parallel replay (segments whose dependency graph is much shallower than it is long: the pairings)
+    std::vector<H2EVRec> h_lrecs;               // 64 records per step (lane l of a step runs record 64 * step + l)
+    std::vector<uint32_t> h_lrefs;              // cell refs of global integer operands
+    std::vector<uint32_t> seg_l_begin, seg_l_steps, seg_l_slots;
+    H2EVRec* d_lrecs = nullptr;
+    uint32_t* d_lrefs = nullptr;
     InstanceDescHost* d_inst = nullptr;
     uint32_t inst_cap = 0;
     std::vector<InstanceDescHost> h_inst;
@@ -93,6 +99,8 @@ struct h2e_program {
             (void)hipFree(d_subs);
             (void)hipFree(d_vtape);
             (void)hipFree(d_vpieces);
+            (void)hipFree(d_lrecs);
+            (void)hipFree(d_lrefs);
             (void)hipFree(d_inst);
         }
     }
@@ -303,6 +311,9 @@ struct h2e_program {
         seg_n_pieces.assign(r.segments.size(), 0);
         seg_v_slots.assign(r.segments.size(), 1);
         seg_v_units.assign(r.segments.size(), 1);
+        seg_l_begin.assign(r.segments.size(), 0);
+        seg_l_steps.assign(r.segments.size(), 0);
+        seg_l_slots.assign(r.segments.size(), 0);
         for (auto& c : cs) compile_replay(c.sg, c.ops, c.n_ops, c.first, c.last, [&](uint32_t region, uint32_t row) { return producer(c, region, row); });
     }
 
@@ -519,6 +530,178 @@ struct h2e_program {
                     vals[v].dst_slot = sl;
                     vals[v].resident = true;
                     d.dst[w] = sl;
+                }
+            }
+        }
+        // ---- level-parallel replay ---------------------------------------------------------------------------------
+        // A pairing's replay is 175 k ops in one chain, but its dependency graph is only ~8.5 k levels deep (an Fq12
+        // product is 54 independent Fq products).  When a segment is that shape, lanes are given to *ops*: a wave replays
+        // one instance, each step runs up to 64 independent ops of one opcode, values live in LDS slots shared by the
+        // wave (allocated over the step order).  Ops that go through cells (H2E_V_FULL: assign / constants / bisec rows)
+        // are steps of their own behind a fence.
+        {
+            size_t si = (size_t)(sg - r.segments.data());
+            bool eligible = !getenv("H2E_NO_LEVELS") && sg->n_strands == 1 && alive.size() >= 4096;
+            std::vector<uint32_t> level(alive.size(), 0);
+            uint32_t depth = 0;
+            for (uint32_t pos = 0; pos < alive.size() && eligible; pos++) {
+                const H2EOp& op = ops[alive[pos]];
+                int k = kind_of(op);
+                if (k == K_SEL || op.opcode == H2E_OP_PICK_INDEX || ((op.flags & H2E_FLAG_HINTED) && k == K_MUL)) eligible = false;
+                uint32_t lv = 0;
+                for (int q = 0; q < 3; q++)
+                    if (dec[pos].val[q] >= 0) lv = std::max(lv, level[alive_pos[dec[pos].val[q] / 2]] + 1);
+                for (int q = 0; q < H2E_OP_MAX_REFS; q++) {
+                    int wtr = writer_of(op.refs[q]);   // rows an earlier op of this replay writes for real
+                    if (wtr >= 0 && (uint32_t)wtr != alive[pos] && alive_pos[wtr] != 0xffffffffu && alive_pos[wtr] < pos)
+                        lv = std::max(lv, level[alive_pos[wtr]] + 1);
+                }
+                level[pos] = lv;
+                depth = std::max(depth, lv + 1);
+            }
+            if (eligible && (uint64_t)depth * 4 > alive.size()) eligible = false;   // not shallow enough to pay off
+            if (eligible) {
+                // as late as possible: an op runs just before its first consumer (values stay in slots for a short time: a
+                // pairing's G2 line coefficients are then made next to the Miller-loop step that uses them); ops nothing
+                // in the replay depends on run as early as they can, which frees their operands
+                std::vector<uint32_t> late(alive.size(), 0xffffffffu);
+                for (uint32_t pos = (uint32_t)alive.size(); pos-- > 0;) {
+                    uint32_t lv = late[pos] == 0xffffffffu ? level[pos] : late[pos] - 1;
+                    if (lv < level[pos]) throw std::runtime_error("replay compile: level order broken");
+                    level[pos] = lv;
+                    const H2EOp& op = ops[alive[pos]];
+                    for (int q = 0; q < 3; q++)
+                        if (dec[pos].val[q] >= 0) {
+                            uint32_t pp = alive_pos[dec[pos].val[q] / 2];
+                            late[pp] = std::min(late[pp], lv);
+                        }
+                    for (int q = 0; q < H2E_OP_MAX_REFS; q++) {
+                        int wtr = writer_of(op.refs[q]);
+                        if (wtr >= 0 && (uint32_t)wtr != alive[pos] && alive_pos[wtr] != 0xffffffffu && alive_pos[wtr] < pos)
+                            late[alive_pos[wtr]] = std::min(late[alive_pos[wtr]], lv);
+                    }
+                }
+            }
+            if (eligible) {
+                // steps: by level, then by opcode; V_FULL ops one per step
+                std::vector<uint32_t> order(alive.size());
+                for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+                auto vop_of = [&](uint32_t pos) -> uint32_t {
+                    const H2EOp& op = ops[alive[pos]];
+                    switch (op.opcode) {
+                        case H2E_OP_INT_MUL: return H2E_V_MUL;
+                        case H2E_OP_REDUCE: return H2E_V_REDUCE;
+                        case H2E_OP_DIV_CORE: return H2E_V_DIV;
+                        case H2E_OP_INT_ADD: return H2E_V_ADD;
+                        case H2E_OP_INT_SUB: return H2E_V_SUB;
+                        case H2E_OP_INT_NEG: return H2E_V_NEG;
+                        case H2E_OP_INT_MUL_SMALL: return H2E_V_MUL_SMALL;
+                        case H2E_OP_MASK_INT: return H2E_V_MASK;
+                        case H2E_OP_BISEC_INT: return H2E_V_BISEC_INT;
+                        case H2E_OP_IS_INT_ZERO: return H2E_V_IS_ZERO;
+                        case H2E_OP_NOT: return H2E_V_NOT;
+                        case H2E_OP_AND: return H2E_V_AND;
+                        case H2E_OP_OR: return H2E_V_OR;
+                        case H2E_OP_XNOR: return H2E_V_XNOR;
+                        default: return H2E_V_FULL;
+                    }
+                };
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+                    if (level[a] != level[b]) return level[a] < level[b];
+                    return vop_of(a) < vop_of(b);
+                });
+                std::vector<uint32_t> step_of(alive.size(), 0);
+                std::vector<std::vector<uint32_t>> steps;
+                for (size_t i = 0; i < order.size();) {
+                    uint32_t pos = order[i], vop = vop_of(pos);
+                    size_t j = i + 1;
+                    if (vop != H2E_V_FULL)
+                        while (j < order.size() && j - i < 64 && level[order[j]] == level[pos] && vop_of(order[j]) == vop) j++;
+                    steps.emplace_back(order.begin() + i, order.begin() + j);
+                    for (size_t q = i; q < j; q++) step_of[order[q]] = (uint32_t)steps.size() - 1;
+                    i = j;
+                }
+                // value slots over the step order: a slot freed in step s is reusable from step s + 1
+                std::vector<uint32_t> last_step(2 * (size_t)n_ops, 0);
+                for (uint32_t pos = 0; pos < alive.size(); pos++)
+                    for (int q = 0; q < 3; q++)
+                        if (dec[pos].val[q] >= 0) last_step[dec[pos].val[q]] = std::max(last_step[dec[pos].val[q]], step_of[pos]);
+                std::vector<int> lslot(2 * (size_t)n_ops, -1);
+                std::vector<std::vector<int>> free_at(steps.size() + 1);
+                std::vector<int> free_list;
+                int n_slots = 0;
+                const int slot_cap = (int)((160u * 1024 - 30u * 1024) / ((2 * (uint32_t)L + 4) * 8));
+                for (size_t st = 0; st < steps.size() && eligible; st++) {
+                    for (int sl : free_at[st]) free_list.push_back(sl);
+                    for (uint32_t pos : steps[st]) {
+                        uint32_t i = alive[pos];
+                        int k = kind_of(ops[i]);
+                        int nres = (k == K_MUL || k == K_ADD || k == K_FE) ? 1 : 0;
+                        for (int w = 0; w < nres; w++) {
+                            int v = 2 * (int)i + w;
+                            if (vals[v].uses.empty()) continue;
+                            int sl;
+                            if (!free_list.empty()) {
+                                sl = free_list.back();
+                                free_list.pop_back();
+                            } else {
+                                sl = n_slots++;
+                            }
+                            lslot[v] = sl;
+                            free_at[std::min<size_t>(last_step[v] + 1, steps.size())].push_back(sl);
+                        }
+                    }
+                    if (n_slots > slot_cap) eligible = false;
+                }
+                if (!eligible && getenv("H2E_DUMP_TAPE"))
+                    fprintf(stderr, "segment %zu: level-parallel replay needs more than %d value slots (depth %u, %zu steps)\n", si, slot_cap, depth, steps.size());
+                if (eligible) {
+                    seg_l_begin[si] = (uint32_t)h_lrecs.size();
+                    seg_l_steps[si] = (uint32_t)steps.size();
+                    seg_l_slots[si] = (uint32_t)std::max(1, n_slots);
+                    for (auto& stp : steps) {
+                        for (size_t lane = 0; lane < 64; lane++) {
+                            H2EVRec h{{H2E_V_NOP, 0, 0, 0, 0, 0, 0, 0}};
+                            if (lane < stp.size()) {
+                                uint32_t pos = stp[lane], i = alive[pos];
+                                const H2EOp& op = ops[i];
+                                int k = kind_of(op);
+                                uint32_t vop = vop_of(pos), vflags = 0;
+                                bool store = !(op.flags & H2E_FLAG_LOCAL_RESULT) || vals[2 * (size_t)i].force_store;
+                                if (op.opcode == H2E_OP_AND || op.opcode == H2E_OP_OR || op.opcode == H2E_OP_XNOR || op.opcode == H2E_OP_BISEC_INT)
+                                    store = true;
+                                if (store) vflags |= H2E_VFLAG_STORE;
+                                int dsl = lslot[2 * (size_t)i];
+                                h.w[0] = vop | (vflags << 8) | ((uint32_t)(dsl >= 0 ? dsl : 0xffff) << 16);
+                                h.w[1] = vop == H2E_V_FULL ? i : op.imm;   // V_FULL: index of the tape op (segment relative)
+                                h.w[5] = k == K_FE ? fe_row(op) : op.base_row;
+                                h.w[6] = op.range_row;
+                                if (vop != H2E_V_FULL) {
+                                    Opd o[3];
+                                    int n = operands(op, o);
+                                    for (int q = 0; q < n; q++) {
+                                        int v = dec[pos].val[q];
+                                        if (v >= 0) {
+                                            h.w[7] |= (uint32_t)(o[q].is_int ? H2E_VSRC_INT_SLOT : H2E_VSRC_FE_SLOT) << (3 * q);
+                                            h.w[2 + q] = (uint32_t)lslot[v];
+                                        } else {
+                                            h.w[7] |= (uint32_t)H2E_VSRC_GLOBAL << (3 * q);
+                                            if (o[q].is_int) {
+                                                h.w[2 + q] = (uint32_t)h_lrefs.size();
+                                                for (int j = 0; j <= L; j++) h_lrefs.push_back(op.refs[o[q].refpos + j]);
+                                            } else {
+                                                h.w[2 + q] = o[q].ref;
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                            h_lrecs.push_back(h);
+                        }
+                    }
+                    if (getenv("H2E_DUMP_TAPE"))
+                        fprintf(stderr, "segment %zu: level-parallel replay: %zu alive ops, depth %u, %zu steps, %d value slots\n", si, alive.size(),
+                                depth, steps.size(), n_slots);
                 }
             }
         }
@@ -1310,6 +1493,8 @@ static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
     HIP_TRY(up((void**)&p->d_subs, p->h_subs.empty() ? nullptr : p->h_subs.data(), p->h_subs.size() * 4));
     HIP_TRY(up((void**)&p->d_vtape, p->h_vtape.empty() ? nullptr : p->h_vtape.data(), p->h_vtape.size() * sizeof(H2EVRec)));
     HIP_TRY(up((void**)&p->d_vpieces, p->h_vpieces.empty() ? nullptr : p->h_vpieces.data(), p->h_vpieces.size() * 4));
+    HIP_TRY(up((void**)&p->d_lrecs, p->h_lrecs.empty() ? nullptr : p->h_lrecs.data(), p->h_lrecs.size() * sizeof(H2EVRec)));
+    HIP_TRY(up((void**)&p->d_lrefs, p->h_lrefs.empty() ? nullptr : p->h_lrefs.data(), p->h_lrefs.size() * 4));
     p->device = ctx->device;
     return 0;
 }
@@ -1532,6 +1717,11 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         L.v_int_slots = compiled ? p->seg_v_slots[si] : 0;
         L.v_units = compiled ? p->seg_v_units[si] : 0;
         L.sel_stride = s.sel_stride;
+        bool levels = compiled && si < p->seg_l_steps.size() && p->seg_l_steps[si] > 0;
+        L.lrecs = levels ? p->d_lrecs + p->seg_l_begin[si] : nullptr;
+        L.lrefs = p->d_lrefs;
+        L.l_steps = levels ? p->seg_l_steps[si] : 0;
+        L.l_slots = levels ? p->seg_l_slots[si] : 0;
         int lrc;
         auto launch = [&](int mode, hipStream_t st) -> int {
             int rc2 = h2e_engine_launch(fp, mode, &L, p->d_inst, n_instances, ctx->d_fc[fp], st);

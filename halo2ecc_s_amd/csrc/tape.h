@@ -166,6 +166,10 @@ typedef struct H2ELaunch {
     uint32_t n_vpieces;
     uint32_t v_int_slots, v_units; // LDS sizing of the replay kernel: integer slots and 16-byte staging units per lane
     uint32_t sel_stride;          // selection-buffer entries per strand (H2E_FLAG_PRESELECTED)
+    // level-parallel replay (h2e_capi.cpp compile_replay): 64 records per step; lane l of a wave runs record 64 * step + l
+    const struct H2EVRec* lrecs;
+    const uint32_t* lrefs;        // cell refs of global integer operands (L + 1 each)
+    uint32_t l_steps, l_slots;
 } H2ELaunch;
 
 // ---- compiled values-only replay ("V-tape") ----------------------------------------------------
