@@ -1591,8 +1591,9 @@ WI_INLINE void exec_lop(const LVals<FP>& lv, const LC& c, u32 opc, const VHdr& h
 }
 
 template <class FP>
-__global__ void __launch_bounds__(64) h2e_replay_levels(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
-    u32 instance = blockIdx.x / L.n_strands, strand = blockIdx.x % L.n_strands, lane = threadIdx.x;
+__global__ void __launch_bounds__(64 * H2E_LEVEL_WAVES) h2e_replay_levels(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
+    u32 instance = blockIdx.x / L.n_strands, strand = blockIdx.x % L.n_strands;
+    u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     InstanceDesc d = inst[instance];
     LC c;
     c.base = d.base;
@@ -1613,40 +1614,46 @@ __global__ void __launch_bounds__(64) h2e_replay_levels(H2ELaunch L, const Insta
     c.hint_stride = L.hint_stride;
     c.sel = d.sel;
     c.sel_stride = L.sel_stride;
-    __shared__ Stage stage;
+    __shared__ Stage stage;   // only wave 0 (H2E_V_FULL ops) uses it
     extern __shared__ ulonglong2 l_dyn[];
     LVals<FP> lv;
     lv.v = (u64*)l_dyn;
     c.st = &stage;
     c.active = true;
     __builtin_amdgcn_s_setprio(3);
-    auto fetch = [&](u32 step, uint4* r) {
-        const uint4* p = (const uint4*)(L.lrecs + (size_t)step * 64 + lane);
+    // rounds: every wave runs one step (64 records, one opcode) of the current level, then a barrier; the waves share
+    // the instance's value slots
+    auto fetch = [&](u32 round, uint4* r) {
+        const uint4* p = (const uint4*)(L.lrecs + (size_t)round * (64 * H2E_LEVEL_WAVES) + threadIdx.x);
         r[0] = p[0];
         r[1] = p[1];
     };
     uint4 nxt[2];
     fetch(0, nxt);
-    for (u32 step = 0; step < L.l_steps; step++) {
+    for (u32 round = 0; round < L.l_steps; round++) {
         VHdr h;
         h.w[0] = nxt[0].x; h.w[1] = nxt[0].y; h.w[2] = nxt[0].z; h.w[3] = nxt[0].w;
         h.w[4] = nxt[1].x; h.w[5] = nxt[1].y; h.w[6] = nxt[1].z; h.w[7] = nxt[1].w;
-        if (step + 1 < L.l_steps) fetch(step + 1, nxt);   // the next step's records are in flight while this one runs
-        u32 opc = __builtin_amdgcn_readfirstlane(h.w[0]) & 0xffu;   // lane 0 always holds an op
-        if (opc == H2E_V_FULL) {
-            // the tape op itself, for the whole wave: its rows are its results.  What it reads may have been stored by
-            // other lanes in earlier steps, and later steps read its rows: fence on both sides.
+        if (round + 1 < L.l_steps) fetch(round + 1, nxt);   // the next round's records are in flight while this one runs
+        u32 w0 = __builtin_amdgcn_readfirstlane(h.w[0]);     // lane 0 of the wave's step
+        u32 opc = w0 & 0xffu;
+        if (opc == H2E_V_FULL || ((w0 >> 8) & H2E_VFLAG_FENCE)) {
+            // a tape op that goes through cells, run by wave 0 for the instance: its rows are its results.  What it reads
+            // may have been stored by any wave in earlier rounds, and later rounds read its rows: fences on both sides.
             __threadfence();
-            H2EOp op = L.tape[__builtin_amdgcn_readfirstlane(h.w[1])];
-            op.opcode = (uint16_t)__builtin_amdgcn_readfirstlane(op.opcode);
-            c.active = lane == 0;
-            exec_op<FP, false>(c, op);
-            c.active = true;
-            __threadfence();
+            __syncthreads();
+            if (opc == H2E_V_FULL) {
+                H2EOp op = L.tape[__builtin_amdgcn_readfirstlane(h.w[1])];
+                op.opcode = (uint16_t)__builtin_amdgcn_readfirstlane(op.opcode);
+                c.active = lane == 0;
+                exec_op<FP, false>(c, op);
+                c.active = true;
+                __threadfence();
+            }
         } else if ((h.w[0] & 0xffu) != H2E_V_NOP) {
             exec_lop<FP>(lv, c, opc, h, L.lrefs);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave's LDS ops complete in order; keep the compiler honest
+        __syncthreads();   // the round's values are in their slots
     }
 }
 
@@ -2259,7 +2266,7 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
     size_t xlds = grid.x > 4096 ? x_pad : 0;
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
     if ((mode & 1) && launch->lrecs) {                                                                                         \
-        hipLaunchKernelGGL(h2e_replay_levels<FP>, dim3(n_instances * launch->n_strands), block,                                \
+        hipLaunchKernelGGL(h2e_replay_levels<FP>, dim3(n_instances * launch->n_strands), dim3(64 * H2E_LEVEL_WAVES),          \
                            (size_t)launch->l_slots * LVals<FP>::W * 8, stream, *launch, inst, n_instances);                   \
         mode &= ~1;                                                                                                            \
     }                                                                                                                          \

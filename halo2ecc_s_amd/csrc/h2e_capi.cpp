@@ -610,58 +610,91 @@ struct h2e_program {
                     if (level[a] != level[b]) return level[a] < level[b];
                     return vop_of(a) < vop_of(b);
                 });
-                std::vector<uint32_t> step_of(alive.size(), 0);
-                std::vector<std::vector<uint32_t>> steps;
+                std::vector<uint32_t> step_of(alive.size(), 0);   // the *round* an op runs in (see below)
+                std::vector<std::vector<uint32_t>> steps;            // steps[NW * round + wave]: the ops one wave runs in a round
+                // rounds: H2E_LEVEL_WAVES waves share an instance's value slots; in a round each wave runs one step (up to 64
+                // ops of one opcode), all steps of a round come from the same level, a barrier separates rounds.  An op
+                // that goes through cells (V_FULL) is a round of its own.
+                const size_t NW = H2E_LEVEL_WAVES;
                 for (size_t i = 0; i < order.size();) {
-                    uint32_t pos = order[i], vop = vop_of(pos);
-                    size_t j = i + 1;
-                    if (vop != H2E_V_FULL)
-                        while (j < order.size() && j - i < 64 && level[order[j]] == level[pos] && vop_of(order[j]) == vop) j++;
-                    steps.emplace_back(order.begin() + i, order.begin() + j);
-                    for (size_t q = i; q < j; q++) step_of[order[q]] = (uint32_t)steps.size() - 1;
-                    i = j;
+                    uint32_t lv0 = level[order[i]];
+                    std::vector<std::vector<uint32_t>> lvl_steps;
+                    std::vector<uint32_t> lvl_full;
+                    while (i < order.size() && level[order[i]] == lv0) {
+                        uint32_t pos = order[i], vop = vop_of(pos);
+                        if (vop == H2E_V_FULL) {
+                            lvl_full.push_back(pos);
+                            i++;
+                            continue;
+                        }
+                        size_t j = i + 1;
+                        while (j < order.size() && j - i < 64 && level[order[j]] == lv0 && vop_of(order[j]) == vop) j++;
+                        lvl_steps.emplace_back(order.begin() + i, order.begin() + j);
+                        i = j;
+                    }
+                    auto new_round = [&]() {
+                        for (size_t w = 0; w < NW; w++) steps.emplace_back();
+                        return steps.size() / NW - 1;
+                    };
+                    for (uint32_t pos : lvl_full) {
+                        size_t rd = new_round();
+                        steps[rd * NW].push_back(pos);
+                        step_of[pos] = (uint32_t)rd;
+                    }
+                    for (size_t k = 0; k < lvl_steps.size(); k++) {
+                        if (k % NW == 0) new_round();
+                        size_t rd = steps.size() / NW - 1;
+                        steps[rd * NW + k % NW] = lvl_steps[k];
+                        for (uint32_t pos : lvl_steps[k]) step_of[pos] = (uint32_t)rd;
+                    }
                 }
-                // value slots over the step order: a slot freed in step s is reusable from step s + 1
+                const size_t n_rounds = steps.size() / NW;
+                // value slots over the round order: a slot freed in round r is reusable from round r + 1
                 std::vector<uint32_t> last_step(2 * (size_t)n_ops, 0);
                 for (uint32_t pos = 0; pos < alive.size(); pos++)
                     for (int q = 0; q < 3; q++)
                         if (dec[pos].val[q] >= 0) last_step[dec[pos].val[q]] = std::max(last_step[dec[pos].val[q]], step_of[pos]);
                 std::vector<int> lslot(2 * (size_t)n_ops, -1);
-                std::vector<std::vector<int>> free_at(steps.size() + 1);
+                std::vector<std::vector<int>> free_at(n_rounds + 1);
                 std::vector<int> free_list;
                 int n_slots = 0;
                 const int slot_cap = (int)((160u * 1024 - 30u * 1024) / ((2 * (uint32_t)L + 4) * 8));
-                for (size_t st = 0; st < steps.size() && eligible; st++) {
-                    for (int sl : free_at[st]) free_list.push_back(sl);
-                    for (uint32_t pos : steps[st]) {
-                        uint32_t i = alive[pos];
-                        int k = kind_of(ops[i]);
-                        int nres = (k == K_MUL || k == K_ADD || k == K_FE) ? 1 : 0;
-                        for (int w = 0; w < nres; w++) {
-                            int v = 2 * (int)i + w;
-                            if (vals[v].uses.empty()) continue;
-                            int sl;
-                            if (!free_list.empty()) {
-                                sl = free_list.back();
-                                free_list.pop_back();
-                            } else {
-                                sl = n_slots++;
+                for (size_t rd = 0; rd < n_rounds && eligible; rd++) {
+                    for (int sl : free_at[rd]) free_list.push_back(sl);
+                    for (size_t w = 0; w < NW; w++)
+                        for (uint32_t pos : steps[rd * NW + w]) {
+                            uint32_t i = alive[pos];
+                            int k = kind_of(ops[i]);
+                            int nres = (k == K_MUL || k == K_ADD || k == K_FE) ? 1 : 0;
+                            for (int ww = 0; ww < nres; ww++) {
+                                int v = 2 * (int)i + ww;
+                                if (vals[v].uses.empty()) continue;
+                                int sl;
+                                if (!free_list.empty()) {
+                                    sl = free_list.back();
+                                    free_list.pop_back();
+                                } else {
+                                    sl = n_slots++;
+                                }
+                                lslot[v] = sl;
+                                free_at[std::min<size_t>(last_step[v] + 1, n_rounds)].push_back(sl);
                             }
-                            lslot[v] = sl;
-                            free_at[std::min<size_t>(last_step[v] + 1, steps.size())].push_back(sl);
                         }
-                    }
                     if (n_slots > slot_cap) eligible = false;
                 }
                 if (!eligible && getenv("H2E_DUMP_TAPE"))
-                    fprintf(stderr, "segment %zu: level-parallel replay needs more than %d value slots (depth %u, %zu steps)\n", si, slot_cap, depth, steps.size());
+                    fprintf(stderr, "segment %zu: level-parallel replay needs more than %d value slots (depth %u, %zu rounds)\n", si, slot_cap, depth, n_rounds);
                 if (eligible) {
                     seg_l_begin[si] = (uint32_t)h_lrecs.size();
-                    seg_l_steps[si] = (uint32_t)steps.size();
+                    seg_l_steps[si] = (uint32_t)n_rounds;
                     seg_l_slots[si] = (uint32_t)std::max(1, n_slots);
-                    for (auto& stp : steps) {
+                    for (size_t sidx = 0; sidx < steps.size(); sidx++) {
+                        auto& stp = steps[sidx];
+                        // the other waves of a V_FULL round fence their stores before the barrier (lane 0 of their NOP step says so)
+                        const auto& lead = steps[sidx / NW * NW];
+                        bool full_round = !lead.empty() && vop_of(lead[0]) == H2E_V_FULL;
                         for (size_t lane = 0; lane < 64; lane++) {
-                            H2EVRec h{{H2E_V_NOP, 0, 0, 0, 0, 0, 0, 0}};
+                            H2EVRec h{{H2E_V_NOP | ((full_round && lane == 0) ? (H2E_VFLAG_FENCE << 8) : 0u), 0, 0, 0, 0, 0, 0, 0}};
                             if (lane < stp.size()) {
                                 uint32_t pos = stp[lane], i = alive[pos];
                                 const H2EOp& op = ops[i];
@@ -700,8 +733,8 @@ struct h2e_program {
                         }
                     }
                     if (getenv("H2E_DUMP_TAPE"))
-                        fprintf(stderr, "segment %zu: level-parallel replay: %zu alive ops, depth %u, %zu steps, %d value slots\n", si, alive.size(),
-                                depth, steps.size(), n_slots);
+                        fprintf(stderr, "segment %zu: level-parallel replay: %zu alive ops, depth %u, %zu rounds of %zu waves, %d value slots\n", si,
+                                alive.size(), depth, n_rounds, NW, n_slots);
                 }
             }
         }

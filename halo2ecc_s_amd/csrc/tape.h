@@ -166,7 +166,8 @@ typedef struct H2ELaunch {
     uint32_t n_vpieces;
     uint32_t v_int_slots, v_units; // LDS sizing of the replay kernel: integer slots and 16-byte staging units per lane
     uint32_t sel_stride;          // selection-buffer entries per strand (H2E_FLAG_PRESELECTED)
-    // level-parallel replay (h2e_capi.cpp compile_replay): 64 records per step; lane l of a wave runs record 64 * step + l
+    // level-parallel replay (h2e_capi.cpp compile_replay): H2E_LEVEL_WAVES x 64 records per round; thread t of the
+    // workgroup runs record 64 * H2E_LEVEL_WAVES * round + t; l_steps = rounds
     const struct H2EVRec* lrecs;
     const uint32_t* lrefs;        // cell refs of global integer operands (L + 1 each)
     uint32_t l_steps, l_slots;
@@ -207,12 +208,14 @@ enum H2EVOpcode {
 #define H2E_VFLAG_STORE 1u          // the result is also written to its cells
 #define H2E_VFLAG_HINT_STRIDED 2u
 #define H2E_VFLAG_STAGED 4u         // H2E_V_HINT: imm is a staging unit
+#define H2E_VFLAG_FENCE 8u          // level-parallel replay: this round holds an H2E_V_FULL op - fence before the barrier
 #define H2E_VSRC_NONE 0u
 #define H2E_VSRC_INT_SLOT 1u
 #define H2E_VSRC_FE_SLOT 2u
 #define H2E_VSRC_GLOBAL 3u
 #define H2E_VSRC_STAGE 4u
 #define H2E_V_NO_SLOT 0xffu
+#define H2E_LEVEL_WAVES 4u   // waves of a level-parallel replay workgroup (they share one instance's value slots)
 
 // ---- value-predictor ("V") kernels for the MSM ---------------------------------------------------
 // They run native Montgomery / Jacobian arithmetic over the same inputs, write numerator/denominator pairs of
