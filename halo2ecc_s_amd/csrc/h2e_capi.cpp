@@ -703,6 +703,7 @@ struct h2e_program {
                                 bool store = !(op.flags & H2E_FLAG_LOCAL_RESULT) || vals[2 * (size_t)i].force_store;
                                 if (op.opcode == H2E_OP_AND || op.opcode == H2E_OP_OR || op.opcode == H2E_OP_XNOR || op.opcode == H2E_OP_BISEC_INT)
                                     store = true;
+                                if (getenv("H2E_DEBUG_LEVELS_NOSTORE")) store = false;   // timing experiment only: results are wrong
                                 if (store) vflags |= H2E_VFLAG_STORE;
                                 int dsl = lslot[2 * (size_t)i];
                                 h.w[0] = vop | (vflags << 8) | ((uint32_t)(dsl >= 0 ? dsl : 0xffff) << 16);

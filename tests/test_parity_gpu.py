@@ -59,7 +59,7 @@ def test_int_mul_edge_values(engine, oracle):
         compare_advice(prog, orun, base, rng, sel)
 
 
-@pytest.mark.parametrize("n", [1, 6, 12])
+@pytest.mark.parametrize("n", [1, 5, 6, 10, 12, 33])   # 5, 10: no remainder group; 6: even group count; 33: several full groups + remainder
 def test_msm_tile(engine, oracle, n):
     ins = [synth.msm_bn256_tile_inputs(n, tile=t)[0] for t in range(2)]
     prog = Program.msm_bn256_tile(n)
