@@ -1304,6 +1304,20 @@ WI_INLINE void exec_vop(const VSlots<FP>& vs, const LC& c, const VHdr& h, const 
         }
         return;
     }
+    if (opc == H2E_V_CONST) {   // a pool constant: limb i in (base_row + i, col 0), native in (base_row + L, col 0)
+        Wd<FP::WW> x = wd_load<FP::WW>(c.pool + imm);
+        Limb l[L];
+        split_limbs<FP>(x, l);
+        Fe native = mod_n<FP::WW>(c, x);
+        if ((h.w[0] >> 8) & H2E_VFLAG_STORE) {
+#pragma unroll
+            for (int i = 0; i < L; i++) stB(c, h.w[5] + i, 0, fe_of(l[i]));
+            stB(c, h.w[5] + L, 0, native);
+        }
+        u32 dst = (h.w[0] >> 16) & 0xffu;
+        if (dst != H2E_V_NO_SLOT) vs_st_int<FP>(vs, dst, l, native);
+        return;
+    }
     if (opc == H2E_V_LOAD_SEL) {   // a point picked by the select pre-kernel: x, y canonical -> two integer slots
         Wd<FP::WW> xy[2];
         if (((h.w[7]) & 7u) == H2E_VSRC_STAGE) {
@@ -1581,6 +1595,19 @@ WI_INLINE void exec_lop(const LVals<FP>& lv, const LC& c, u32 opc, const VHdr& h
 #pragma unroll
         for (int i = 0; i < FP::PW; i++) is_w = is_w && wd_eq<2>(a.l[i], wd_load<2>(c.fc->w_limbs[i]));
         l_out_fe<FP>(lv, c, h, fe_u64((all_zero || is_w) ? 1 : 0));
+    } else if (opc == H2E_V_CONST) {
+        Wd<FP::WW> x = wd_load<FP::WW>(c.pool + imm);
+        Limb l[L];
+        split_limbs<FP>(x, l);
+        Fe native = mod_n<FP::WW>(c, x);
+        if ((h.w[0] >> 8) & H2E_VFLAG_STORE) {
+#pragma unroll
+            for (int i = 0; i < L; i++) stB(c, h.w[5] + i, 0, fe_of(l[i]));
+            stB(c, h.w[5] + L, 0, native);
+        }
+        VHdr h2 = h;
+        h2.w[0] &= ~(H2E_VFLAG_STORE << 8);
+        l_out_int<FP>(lv, c, h2, false, l, native);
     } else if (opc == H2E_V_NOT) {
         l_out_fe<FP>(lv, c, h, submod_n(c, fe_u64(1), l_src_fe<FP>(lv, c, h, 0)));
     } else if (opc == H2E_V_AND || opc == H2E_V_OR || opc == H2E_V_XNOR) {

@@ -326,7 +326,7 @@ struct h2e_program {
         const int L = r.fp.limbs;
         const uint32_t NS = L == 3 ? 22 : 18, NF = 4;   // VSlots in engine.hip (NF) and the LDS budget (NS)
         const uint32_t rel = sg->is_fork ? 1 : 0;
-        enum { K_NONE, K_MUL, K_ADD, K_FE, K_SEL, K_FULL };
+        enum { K_NONE, K_MUL, K_ADD, K_FE, K_SEL, K_FULL, K_CONST };
         auto kind_of = [](const H2EOp& op) -> int {
             switch (op.opcode) {
                 case H2E_OP_INT_MUL: case H2E_OP_REDUCE: case H2E_OP_DIV_CORE: return K_MUL;
@@ -335,6 +335,7 @@ struct h2e_program {
                 case H2E_OP_IS_INT_ZERO: case H2E_OP_NOT: case H2E_OP_AND: case H2E_OP_OR: case H2E_OP_XNOR: case H2E_OP_PICK_INDEX:
                     return K_FE;
                 case H2E_OP_SELECT_POINT: return K_SEL;
+                case H2E_OP_CONST_INT: return K_CONST;   // a constant of the pool: a value like any other (cells: column 0)
                 case H2E_OP_ASSERT_CONST: case H2E_OP_CACHE_INT: case H2E_OP_SUM_LIMBS: case H2E_OP_NOP: return K_NONE;
                 default: return K_FULL;
             }
@@ -393,6 +394,7 @@ struct h2e_program {
             if (is_int) {
                 if (pk == K_MUL && region == 1 && col == 0 && row == po.range_row) return 2 * p;
                 if (pk == K_ADD && region == 0 && col == 4 && row == po.base_row) return 2 * p;
+                if (pk == K_CONST && region == 0 && col == 0 && row == po.base_row) return 2 * p;
                 if (pk == K_SEL && region == 2 && col == 0 && row == po.select_row) return 2 * p;
                 if (pk == K_SEL && region == 2 && col == 0 && row == po.select_row + (uint32_t)L + 1) return 2 * p + 1;
             } else {
@@ -518,7 +520,7 @@ struct h2e_program {
                     }
                 }
             }
-            int nres = k == K_SEL ? 2 : (k == K_MUL || k == K_ADD || k == K_FE) ? 1 : 0;
+            int nres = k == K_SEL ? 2 : (k == K_MUL || k == K_ADD || k == K_FE || k == K_CONST) ? 1 : 0;
             for (int w = 0; w < nres; w++) {
                 int v = 2 * (int)i + w;
                 if (vals[v].uses.empty()) continue;
@@ -603,6 +605,7 @@ struct h2e_program {
                         case H2E_OP_AND: return H2E_V_AND;
                         case H2E_OP_OR: return H2E_V_OR;
                         case H2E_OP_XNOR: return H2E_V_XNOR;
+                        case H2E_OP_CONST_INT: return H2E_V_CONST;
                         default: return H2E_V_FULL;
                     }
                 };
@@ -665,7 +668,7 @@ struct h2e_program {
                         for (uint32_t pos : steps[rd * NW + w]) {
                             uint32_t i = alive[pos];
                             int k = kind_of(ops[i]);
-                            int nres = (k == K_MUL || k == K_ADD || k == K_FE) ? 1 : 0;
+                            int nres = (k == K_MUL || k == K_ADD || k == K_FE || k == K_CONST) ? 1 : 0;
                             for (int ww = 0; ww < nres; ww++) {
                                 int v = 2 * (int)i + ww;
                                 if (vals[v].uses.empty()) continue;
@@ -752,7 +755,7 @@ struct h2e_program {
         std::vector<int> produced;
         for (uint32_t pos = 0; pos < alive.size(); pos++) {
             int k = kind_of(ops[alive[pos]]);
-            int nres = k == K_SEL ? 2 : (k == K_MUL || k == K_ADD || k == K_FE) ? 1 : 0;
+            int nres = k == K_SEL ? 2 : (k == K_MUL || k == K_ADD || k == K_FE || k == K_CONST) ? 1 : 0;
             for (int w = 0; w < nres; w++) produced.push_back(2 * (int)alive[pos] + w);
         }
         auto is_fe_val = [&](int v) { return kind_of(ops[v / 2]) == K_FE; };
@@ -848,7 +851,7 @@ struct h2e_program {
                 {   // advance the live set from pos - 1 to pos
                     uint32_t i = alive[pos - 1];
                     int k = kind_of(ops[i]);
-                    int nres = k == K_SEL ? 2 : (k == K_MUL || k == K_ADD || k == K_FE) ? 1 : 0;
+                    int nres = k == K_SEL ? 2 : (k == K_MUL || k == K_ADD || k == K_FE || k == K_CONST) ? 1 : 0;
                     for (int w = 0; w < nres; w++)
                         if (!vals[2 * (size_t)i + w].uses.empty() && last_use(2 * (int)i + w) >= pos) live_set.insert(2 * (int)i + w);
                     for (int v : expires[pos - 1]) live_set.erase(v);
@@ -910,6 +913,7 @@ struct h2e_program {
                 case H2E_OP_XNOR: vop = H2E_V_XNOR; break;
                 case H2E_OP_PICK_INDEX: vop = H2E_V_PICK_INDEX; break;
                 case H2E_OP_SELECT_POINT: vop = (op.flags & H2E_FLAG_PRESELECTED) ? H2E_V_LOAD_SEL : H2E_V_SELECT_POINT; break;
+                case H2E_OP_CONST_INT: vop = H2E_V_CONST; break;
                 default: vop = H2E_V_FULL; break;
             }
             if (hinted && (op.flags & H2E_FLAG_HINT_STRIDED)) vflags |= H2E_VFLAG_HINT_STRIDED;

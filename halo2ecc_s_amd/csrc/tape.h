@@ -203,7 +203,8 @@ enum H2EVOpcode {
     H2E_V_SELECT_POINT,
     H2E_V_FULL,          // run the tape op held in the 2 extension records as it is (its rows are its results)
     H2E_V_GATHER, H2E_V_GATHER_WAIT,
-    H2E_V_LOAD_SEL       // both coordinates of a pre-selected point: src0 = staging unit (or selection entry), two dst slots
+    H2E_V_LOAD_SEL,      // both coordinates of a pre-selected point: src0 = staging unit (or selection entry), two dst slots
+    H2E_V_CONST          // assign_int_constant of a pool constant (imm = pool word offset): limbs in column 0 of base_row + i
 };
 #define H2E_VFLAG_STORE 1u          // the result is also written to its cells
 #define H2E_VFLAG_HINT_STRIDED 2u
