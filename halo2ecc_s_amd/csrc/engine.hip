@@ -2192,7 +2192,7 @@ __global__ void __launch_bounds__(64) h2e_finalize_ecc(H2EPreKernel K, const Ins
             u32 k = (u32)(e + 1);
             u32 kind = (K.pattern >> (2 * (k % K.pattern_len))) & 3u;
             Wd<NW> l2 = mm(M, ln, ln);
-            Wd<NW> xa, aux0, aux1 = wd_zero<NW>();
+            Wd<NW> xa, aux0 = wd_zero<NW>(), aux1 = wd_zero<NW>();
             if (kind == H2E_ECC_ADD_EXT_PREV) {
                 xa = mont_sub<NW>(M, mont_sub<NW>(M, l2, xn), xe);      // x_a = lambda^2 - x_c - x_b
                 aux0 = mont_sub<NW>(M, xa, xe);                        // x_a - x_b
@@ -2202,13 +2202,14 @@ __global__ void __launch_bounds__(64) h2e_finalize_ecc(H2EPreKernel K, const Ins
                 aux0 = mont_sub<NW>(M, xa, xb);
             } else {
                 xa = xe;
-                aux0 = mm(M, xa, xa);                                   // x_a^2
+                if ((K.used_slots >> H2E_HINT_AUX0) & 1u) aux0 = mm(M, xa, xa);   // x_a^2
                 aux1 = mont_dbl<NW>(M, ye);                             // 2 y_a
             }
             Wd<NW> t2 = mont_sub<NW>(M, xa, xn);
             Wd<NW> t2l = mm(M, t2, ln);
             Wd<NW> one = wd_from_u64<NW>(1);
             auto put = [&](u32 slot, const Wd<NW>& vm) {
+                if (!((K.used_slots >> slot) & 1u)) return;   // nobody reads it
                 Wd<NW> cv = mm(M, vm, one);   // out of the Montgomery domain: canonical
                 u64* hp = hint((int)k, slot);
 #pragma unroll

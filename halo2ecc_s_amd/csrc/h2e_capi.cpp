@@ -263,6 +263,10 @@ struct h2e_program {
                 if (op.opcode == H2E_OP_PICK_INDEX && (op.flags & H2E_FLAG_PRESELECTED)) needed = false;   // the select pre-kernel did it
                 if (!needed) {
                     op.flags |= H2E_FLAG_VALUES_SKIP;
+                    // a value hint nobody consumes needs neither checking nor producing (the division's quotient is
+                    // consumed by the expansion itself and keeps its hint)
+                    if ((op.flags & H2E_FLAG_HINTED) && (op.opcode == H2E_OP_INT_MUL || op.opcode == H2E_OP_REDUCE))
+                        op.flags &= ~(uint16_t)(H2E_FLAG_HINTED | H2E_FLAG_HINT_STRIDED);
                     continue;
                 }
                 uint32_t reads[H2E_OP_MAX_REFS];
@@ -1221,6 +1225,15 @@ struct h2e_program {
         mark_local_results();
         mark_deferrable();
         mark_side_segments();
+        // which of the 8 value-hint slots per ecc op does anything read?  (finalize_ecc skips the others)
+        for (auto& pk : r.pre_kernels) {
+            if (!pk.k.ecc_ops) continue;
+            uint32_t lo = pk.k.hint_base, per = pk.k.hints_per_lane, mask = 1u << H2E_HINT_LAMBDA;
+            for (const H2EOp& op : r.tape)
+                if ((op.flags & H2E_FLAG_HINTED) && op.imm >= lo && op.imm < lo + per) mask |= 1u << ((op.imm - lo) % H2E_ECC_HINT_SLOTS);
+            pk.k.used_slots = mask;
+            if (getenv("H2E_DUMP_TAPE")) fprintf(stderr, "predictor kind %u: value-hint slots in use: 0x%02x\n", pk.k.kind, mask);
+        }
         if (getenv("H2E_DUMP_TAPE")) {   // debugging aid: per segment, ops by opcode (alive / skipped by the values replay)
             for (size_t si = 0; si < r.segments.size(); si++) {
                 auto& sg = r.segments[si];

@@ -240,4 +240,5 @@ typedef struct H2EPreKernel {
     uint32_t pattern_len;
     uint32_t pattern;
     uint32_t sel_begin;      // first entry of this kernel's strands in the selection buffer (SELECT writes, WINDOWS reads)
+    uint32_t used_slots;     // full value hints: bit k set = slot k of the ecc blocks is read by someone (host, after the DCE pass)
 } H2EPreKernel;
