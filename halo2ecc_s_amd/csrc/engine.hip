@@ -1595,6 +1595,9 @@ WI_INLINE void exec_lop(const LVals<FP>& lv, const LC& c, u32 opc, const VHdr& h
 #pragma unroll
         for (int i = 0; i < FP::PW; i++) is_w = is_w && wd_eq<2>(a.l[i], wd_load<2>(c.fc->w_limbs[i]));
         l_out_fe<FP>(lv, c, h, fe_u64((all_zero || is_w) ? 1 : 0));
+    } else if (opc == H2E_V_HINT) {   // the canonical result comes from the predictors (one load per lane)
+        u32 slot = imm + ((((h.w[0] >> 8) & H2E_VFLAG_HINT_STRIDED) != 0) ? c.strand * c.hint_stride : 0);
+        l_out_w<FP>(lv, c, h, wd_load<FP::WW>(c.hints + (size_t)slot * H2E_W_WORDS_MAX));
     } else if (opc == H2E_V_CONST) {
         Wd<FP::WW> x = wd_load<FP::WW>(c.pool + imm);
         Limb l[L];

@@ -553,6 +553,7 @@ struct h2e_program {
             for (uint32_t pos = 0; pos < alive.size() && eligible; pos++) {
                 const H2EOp& op = ops[alive[pos]];
                 int k = kind_of(op);
+                // (hinted chains are wide, not deep - the MSM tail would need > 1664 value slots - and have pieces instead)
                 if (k == K_SEL || op.opcode == H2E_OP_PICK_INDEX || ((op.flags & H2E_FLAG_HINTED) && k == K_MUL)) eligible = false;
                 uint32_t lv = 0;
                 for (int q = 0; q < 3; q++)
@@ -594,6 +595,7 @@ struct h2e_program {
                 for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
                 auto vop_of = [&](uint32_t pos) -> uint32_t {
                     const H2EOp& op = ops[alive[pos]];
+                    if ((op.flags & H2E_FLAG_HINTED) && kind_of(op) == K_MUL) return H2E_V_HINT;
                     switch (op.opcode) {
                         case H2E_OP_INT_MUL: return H2E_V_MUL;
                         case H2E_OP_REDUCE: return H2E_V_REDUCE;
@@ -712,6 +714,7 @@ struct h2e_program {
                                     store = true;
                                 if (getenv("H2E_DEBUG_LEVELS_NOSTORE")) store = false;   // timing experiment only: results are wrong
                                 if (store) vflags |= H2E_VFLAG_STORE;
+                                if (vop == H2E_V_HINT && (op.flags & H2E_FLAG_HINT_STRIDED)) vflags |= H2E_VFLAG_HINT_STRIDED;
                                 int dsl = lslot[2 * (size_t)i];
                                 h.w[0] = vop | (vflags << 8) | ((uint32_t)(dsl >= 0 ? dsl : 0xffff) << 16);
                                 h.w[1] = vop == H2E_V_FULL ? i : op.imm;   // V_FULL: index of the tape op (segment relative)
