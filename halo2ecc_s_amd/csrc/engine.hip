@@ -76,6 +76,12 @@ struct LC {  // lane context
     u32 sel_stride;
     struct Stage* st;   // LDS row staging (see rowB)
     bool active;        // false for the padding lanes of the last wave: compute, but store nothing
+    // expansion only: the last two integer results of this lane's sub-range, kept in LDS ([2][W][64] words).  An op's
+    // operands are mostly the results of the one or two ops before it; re-reading them from their cells misses the L2
+    // (19.5 KB written per lane and sub-range against 512 B of L2 per lane) - 22 GB of the window launch's traffic.
+    u64* xc = nullptr;
+    u32 rel = 0;
+    mutable u32 xt0 = H2E_NO_REF, xt1 = H2E_NO_REF, xn = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -303,10 +309,37 @@ struct IntVal {  // value of an AssignedInteger
 template <class FP>
 WI_INLINE IntVal<FP> ld_int(const LC& c, const u32* refs) {
     IntVal<FP> r;
+    if (c.xc != nullptr && (refs[0] == c.xt0 || refs[0] == c.xt1)) {   // wave-uniform
+        const u64* p = c.xc + (size_t)(refs[0] == c.xt0 ? 0 : 1) * (2 * FP::L + 4) * 64 + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < FP::L; i++) {
+            r.l[i].v[0] = p[(2 * i) * 64];
+            r.l[i].v[1] = p[(2 * i + 1) * 64];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.native.v[i] = p[(2 * FP::L + i) * 64];
+        return r;
+    }
 #pragma unroll
     for (int i = 0; i < FP::L; i++) r.l[i] = ld_limb(c, refs[i]);
     r.native = ld_fe(c, refs[FP::L]);
     return r;
+}
+// remember an integer result of the expansion (key = the ref later ops quote for it: its first limb cell)
+template <class FP>
+WI_INLINE void xc_put(const LC& c, u32 key, const Limb* l, const Fe& native) {
+    if (c.xc == nullptr) return;
+    u64* p = c.xc + (size_t)c.xn * (2 * FP::L + 4) * 64 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) {
+        p[(2 * i) * 64] = l[i].v[0];
+        p[(2 * i + 1) * 64] = l[i].v[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) p[(2 * FP::L + i) * 64] = native.v[i];
+    if (c.xn == 0) c.xt0 = key;
+    else c.xt1 = key;
+    c.xn ^= 1u;
 }
 // Horner composition of limbs (integer_chip.rs:217-224): sum l_i * 2^(108 i)
 template <class FP, int OW>
@@ -491,7 +524,9 @@ WI_INLINE void op_int_add(const LC& c, const H2EOp& op) {
         s[i] = wd_add<2>(a.l[i], b.l[i]);
         ROW_B2(c, r + i, fe_of(a.l[i]), fe_of(b.l[i]), fe_of(s[i]));
     }
-    row_limbs<FP>(c, r + FP::L, s, addmod_n(c, a.native, b.native));
+    Fe nat = addmod_n(c, a.native, b.native);
+    row_limbs<FP>(c, r + FP::L, s, nat);
+    xc_put<FP>(c, H2E_MAKE_REF(0, 4, c.rel, r), s, nat);
 }
 
 template <class FP>
@@ -506,7 +541,9 @@ WI_INLINE void op_int_sub(const LC& c, const H2EOp& op) {
         ROW_B2(c, r + i, fe_of(a.l[i]), fe_of(b.l[i]), fe_of(s[i]));
     }
     Fe un = wd_load<4>(c.fc->ceil_native[t]);
-    row_limbs<FP>(c, r + FP::L, s, addmod_n(c, submod_n(c, a.native, b.native), un));
+    Fe nat = addmod_n(c, submod_n(c, a.native, b.native), un);
+    row_limbs<FP>(c, r + FP::L, s, nat);
+    xc_put<FP>(c, H2E_MAKE_REF(0, 4, c.rel, r), s, nat);
 }
 
 template <class FP>
@@ -521,7 +558,9 @@ WI_INLINE void op_int_neg(const LC& c, const H2EOp& op) {
         ROW_B1(c, r + i, fe_of(a.l[i]), fe_of(s[i]));
     }
     Fe un = wd_load<4>(c.fc->ceil_native[t]);
-    row_limbs<FP>(c, r + FP::L, s, submod_n(c, un, a.native));
+    Fe nat = submod_n(c, un, a.native);
+    row_limbs<FP>(c, r + FP::L, s, nat);
+    xc_put<FP>(c, H2E_MAKE_REF(0, 4, c.rel, r), s, nat);
 }
 
 template <class FP>
@@ -535,7 +574,9 @@ WI_INLINE void op_int_mul_small(const LC& c, const H2EOp& op) {
         s[i] = wd_resize<2>(wd_mul<2, 1>(a.l[i], k));
         ROW_B1(c, r + i, fe_of(a.l[i]), fe_of(s[i]));
     }
-    row_limbs<FP>(c, r + FP::L, s, mod_n<5>(c, wd_mul<4, 1>(a.native, k)));
+    Fe nat = mod_n<5>(c, wd_mul<4, 1>(a.native, k));
+    row_limbs<FP>(c, r + FP::L, s, nat);
+    xc_put<FP>(c, H2E_MAKE_REF(0, 4, c.rel, r), s, nat);
 }
 
 // A hinted INT_MUL / REDUCE: the values-only replay took the result from the hint slot, so every later op was fed
@@ -566,6 +607,7 @@ WI_INLINE void op_int_mul(const LC& c, const H2EOp& op) {
     split_limbs<FP>(dq, dl);
     Fe rem_native = native_of_w<FP>(c, rem), d_native = mod_n<FPX<FP>::QW>(c, dq);
     u32 rr = op.range_row;
+    xc_put<FP>(c, H2E_MAKE_REF(1, 0, c.rel, op.range_row), rl, rem_native);
     rr += emit_assigned<FP>(c, op.base_row, rr, rl, rem_native);
     rr += emit_assigned<FP>(c, op.base_row + 1, rr, dl, d_native);
     emit_mul_equation<FP>(c, op.base_row + 2, rr, a, b, dl, d_native, rl, rem_native);
@@ -584,6 +626,7 @@ WI_INLINE void op_reduce(const LC& c, const H2EOp& op) {
     split_limbs<FP>(rem, rl);
     Fe rem_native = native_of_w<FP>(c, rem);
     u32 rr = op.range_row, br = op.base_row;
+    xc_put<FP>(c, H2E_MAKE_REF(1, 0, c.rel, op.range_row), rl, rem_native);
     rr += emit_assigned<FP>(c, br, rr, rl, rem_native);
     emit_common(c, rr, d);
     rr += 1;
@@ -702,6 +745,7 @@ WI_INLINE void op_div_core(const LC& c, const H2EOp& op) {
     split_limbs<FP>(dq, dl);
     Fe c_native = native_of_w<FP>(c, cv), d_native = mod_n<FPX<FP>::QW>(c, dq);
     u32 rr = op.range_row;
+    xc_put<FP>(c, H2E_MAKE_REF(1, 0, c.rel, op.range_row), cl, c_native);
     rr += emit_assigned<FP>(c, op.base_row, rr, cl, c_native);
     rr += emit_assigned<FP>(c, op.base_row + 1, rr, dl, d_native);
     IntVal<FP> cvv;
@@ -972,8 +1016,11 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     c.hint_stride = L.hint_stride;
     __shared__ Stage stage;
     __shared__ TapeChunk chunk;
+    __shared__ u64 xcache[2][2 * FP::L + 4][64];
     c.st = &stage;
     c.active = active;
+    c.xc = &xcache[0][0][0];
+    c.rel = L.rel_refs;
     {
         for (u32 i0 = op_lo; i0 < op_hi; i0 += 64) {
             load_chunk(&chunk, L.tape, i0, op_hi);
