@@ -81,7 +81,7 @@ struct LC {  // lane context
     // (19.5 KB written per lane and sub-range against 512 B of L2 per lane) - 22 GB of the window launch's traffic.
     u64* xc = nullptr;
     u32 rel = 0;
-    mutable u32 xt0 = H2E_NO_REF, xt1 = H2E_NO_REF, xn = 0;
+    mutable u32 xt0 = H2E_NO_REF, xt1 = H2E_NO_REF, xt2 = H2E_NO_REF, xn = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -309,8 +309,8 @@ struct IntVal {  // value of an AssignedInteger
 template <class FP>
 WI_INLINE IntVal<FP> ld_int(const LC& c, const u32* refs) {
     IntVal<FP> r;
-    if (c.xc != nullptr && (refs[0] == c.xt0 || refs[0] == c.xt1)) {   // wave-uniform
-        const u64* p = c.xc + (size_t)(refs[0] == c.xt0 ? 0 : 1) * (2 * FP::L + 4) * 64 + threadIdx.x;
+    if (c.xc != nullptr && (refs[0] == c.xt0 || refs[0] == c.xt1 || refs[0] == c.xt2)) {   // wave-uniform
+        const u64* p = c.xc + (size_t)(refs[0] == c.xt0 ? 0 : refs[0] == c.xt1 ? 1 : 2) * (2 * FP::L + 4) * 64 + threadIdx.x;
 #pragma unroll
         for (int i = 0; i < FP::L; i++) {
             r.l[i].v[0] = p[(2 * i) * 64];
@@ -338,8 +338,9 @@ WI_INLINE void xc_put(const LC& c, u32 key, const Limb* l, const Fe& native) {
 #pragma unroll
     for (int i = 0; i < 4; i++) p[(2 * FP::L + i) * 64] = native.v[i];
     if (c.xn == 0) c.xt0 = key;
-    else c.xt1 = key;
-    c.xn ^= 1u;
+    else if (c.xn == 1) c.xt1 = key;
+    else c.xt2 = key;
+    c.xn = c.xn == 2 ? 0 : c.xn + 1;
 }
 // Horner composition of limbs (integer_chip.rs:217-224): sum l_i * 2^(108 i)
 template <class FP, int OW>
@@ -1016,7 +1017,7 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     c.hint_stride = L.hint_stride;
     __shared__ Stage stage;
     __shared__ TapeChunk chunk;
-    __shared__ u64 xcache[2][2 * FP::L + 4][64];
+    __shared__ u64 xcache[3][2 * FP::L + 4][64];
     c.st = &stage;
     c.active = active;
     c.xc = &xcache[0][0][0];
