@@ -53,8 +53,8 @@ def cpu_baseline(points):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tiles", type=int, default=64, help="tiles per GPU (64 x 1024 = 2^16 points)")
     ap.add_argument("--points", type=int, default=1024, help="points per tile")
     ap.add_argument("--cpu-sample-points", type=int, default=1024)
