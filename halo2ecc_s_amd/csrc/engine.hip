@@ -76,12 +76,10 @@ struct LC {  // lane context
     u32 sel_stride;
     struct Stage* st;   // LDS row staging (see rowB)
     bool active;        // false for the padding lanes of the last wave: compute, but store nothing
-    // expansion only: the last two integer results of this lane's sub-range, kept in LDS ([2][W][64] words).  An op's
+    // expansion only: three integer results of this lane's sub-range kept in LDS ([3][W][64] words).  An op's
     // operands are mostly the results of the one or two ops before it; re-reading them from their cells misses the L2
     // (19.5 KB written per lane and sub-range against 512 B of L2 per lane) - 22 GB of the window launch's traffic.
     u64* xc = nullptr;
-    u32 rel = 0;
-    mutable u32 xt0 = H2E_NO_REF, xt1 = H2E_NO_REF, xt2 = H2E_NO_REF, xn = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -309,8 +307,20 @@ struct IntVal {  // value of an AssignedInteger
 template <class FP>
 WI_INLINE IntVal<FP> ld_int(const LC& c, const u32* refs) {
     IntVal<FP> r;
-    if (c.xc != nullptr && (refs[0] == c.xt0 || refs[0] == c.xt1 || refs[0] == c.xt2)) {   // wave-uniform
-        const u64* p = c.xc + (size_t)(refs[0] == c.xt0 ? 0 : refs[0] == c.xt1 ? 1 : 2) * (2 * FP::L + 4) * 64 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < FP::L; i++) r.l[i] = ld_limb(c, refs[i]);
+    r.native = ld_fe(c, refs[FP::L]);
+    return r;
+}
+// The host assigns the cache entries per sub-range (furthest-next-use replacement over the static op sequence,
+// h2e_capi.cpp assign_expansion_slots): op.flags bits 8-9 = entry + 1 for the result, bits 10-15 for the up to three
+// integer operands (0 = cells).
+template <class FP>
+WI_INLINE IntVal<FP> ld_int_x(const LC& c, const H2EOp& op, int refpos, int which) {
+    u32 code = (op.flags >> (10 + 2 * which)) & 3u;
+    if (c.xc != nullptr && code != 0) {
+        IntVal<FP> r;
+        const u64* p = c.xc + (size_t)(code - 1) * (2 * FP::L + 4) * 64 + threadIdx.x;
 #pragma unroll
         for (int i = 0; i < FP::L; i++) {
             r.l[i].v[0] = p[(2 * i) * 64];
@@ -320,16 +330,17 @@ WI_INLINE IntVal<FP> ld_int(const LC& c, const u32* refs) {
         for (int i = 0; i < 4; i++) r.native.v[i] = p[(2 * FP::L + i) * 64];
         return r;
     }
+    IntVal<FP> r;
 #pragma unroll
-    for (int i = 0; i < FP::L; i++) r.l[i] = ld_limb(c, refs[i]);
-    r.native = ld_fe(c, refs[FP::L]);
+    for (int i = 0; i < FP::L; i++) r.l[i] = ld_limb(c, op.refs[refpos + i]);
+    r.native = ld_fe(c, op.refs[refpos + FP::L]);
     return r;
 }
-// remember an integer result of the expansion (key = the ref later ops quote for it: its first limb cell)
 template <class FP>
-WI_INLINE void xc_put(const LC& c, u32 key, const Limb* l, const Fe& native) {
-    if (c.xc == nullptr) return;
-    u64* p = c.xc + (size_t)c.xn * (2 * FP::L + 4) * 64 + threadIdx.x;
+WI_INLINE void xc_put_x(const LC& c, const H2EOp& op, const Limb* l, const Fe& native) {
+    u32 code = (op.flags >> 8) & 3u;
+    if (c.xc == nullptr || code == 0) return;
+    u64* p = c.xc + (size_t)(code - 1) * (2 * FP::L + 4) * 64 + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < FP::L; i++) {
         p[(2 * i) * 64] = l[i].v[0];
@@ -337,10 +348,6 @@ WI_INLINE void xc_put(const LC& c, u32 key, const Limb* l, const Fe& native) {
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) p[(2 * FP::L + i) * 64] = native.v[i];
-    if (c.xn == 0) c.xt0 = key;
-    else if (c.xn == 1) c.xt1 = key;
-    else c.xt2 = key;
-    c.xn = c.xn == 2 ? 0 : c.xn + 1;
 }
 // Horner composition of limbs (integer_chip.rs:217-224): sum l_i * 2^(108 i)
 template <class FP, int OW>
@@ -517,7 +524,7 @@ WI_INLINE void op_const_int(const LC& c, const H2EOp& op, bool from_input) {
 
 template <class FP>
 WI_INLINE void op_int_add(const LC& c, const H2EOp& op) {
-    IntVal<FP> a = ld_int<FP>(c, op.refs), b = ld_int<FP>(c, op.refs + FP::L + 1);
+    IntVal<FP> a = ld_int_x<FP>(c, op, 0, 0), b = ld_int_x<FP>(c, op, FP::L + 1, 1);
     u32 r = op.base_row;
     Limb s[FP::L];
 #pragma unroll
@@ -527,12 +534,12 @@ WI_INLINE void op_int_add(const LC& c, const H2EOp& op) {
     }
     Fe nat = addmod_n(c, a.native, b.native);
     row_limbs<FP>(c, r + FP::L, s, nat);
-    xc_put<FP>(c, H2E_MAKE_REF(0, 4, c.rel, r), s, nat);
+    xc_put_x<FP>(c, op, s, nat);
 }
 
 template <class FP>
 WI_INLINE void op_int_sub(const LC& c, const H2EOp& op) {
-    IntVal<FP> a = ld_int<FP>(c, op.refs), b = ld_int<FP>(c, op.refs + FP::L + 1);
+    IntVal<FP> a = ld_int_x<FP>(c, op, 0, 0), b = ld_int_x<FP>(c, op, FP::L + 1, 1);
     u32 r = op.base_row, t = op.imm;
     Limb s[FP::L];
 #pragma unroll
@@ -544,12 +551,12 @@ WI_INLINE void op_int_sub(const LC& c, const H2EOp& op) {
     Fe un = wd_load<4>(c.fc->ceil_native[t]);
     Fe nat = addmod_n(c, submod_n(c, a.native, b.native), un);
     row_limbs<FP>(c, r + FP::L, s, nat);
-    xc_put<FP>(c, H2E_MAKE_REF(0, 4, c.rel, r), s, nat);
+    xc_put_x<FP>(c, op, s, nat);
 }
 
 template <class FP>
 WI_INLINE void op_int_neg(const LC& c, const H2EOp& op) {
-    IntVal<FP> a = ld_int<FP>(c, op.refs);
+    IntVal<FP> a = ld_int_x<FP>(c, op, 0, 0);
     u32 r = op.base_row, t = op.imm;
     Limb s[FP::L];
 #pragma unroll
@@ -561,12 +568,12 @@ WI_INLINE void op_int_neg(const LC& c, const H2EOp& op) {
     Fe un = wd_load<4>(c.fc->ceil_native[t]);
     Fe nat = submod_n(c, un, a.native);
     row_limbs<FP>(c, r + FP::L, s, nat);
-    xc_put<FP>(c, H2E_MAKE_REF(0, 4, c.rel, r), s, nat);
+    xc_put_x<FP>(c, op, s, nat);
 }
 
 template <class FP>
 WI_INLINE void op_int_mul_small(const LC& c, const H2EOp& op) {
-    IntVal<FP> a = ld_int<FP>(c, op.refs);
+    IntVal<FP> a = ld_int_x<FP>(c, op, 0, 0);
     u32 r = op.base_row;
     Wd<1> k = wd_from_u64<1>(op.imm);
     Limb s[FP::L];
@@ -577,7 +584,7 @@ WI_INLINE void op_int_mul_small(const LC& c, const H2EOp& op) {
     }
     Fe nat = mod_n<5>(c, wd_mul<4, 1>(a.native, k));
     row_limbs<FP>(c, r + FP::L, s, nat);
-    xc_put<FP>(c, H2E_MAKE_REF(0, 4, c.rel, r), s, nat);
+    xc_put_x<FP>(c, op, s, nat);
 }
 
 // A hinted INT_MUL / REDUCE: the values-only replay took the result from the hint slot, so every later op was fed
@@ -596,7 +603,7 @@ WI_INLINE void check_value_hint(const LC& c, const H2EOp& op, const Wd<FP::WW>& 
 template <class FP>
 WI_INLINE void op_int_mul(const LC& c, const H2EOp& op) {
     constexpr int L = FP::L;
-    IntVal<FP> a = ld_int<FP>(c, op.refs), b = ld_int<FP>(c, op.refs + L + 1);
+    IntVal<FP> a = ld_int_x<FP>(c, op, 0, 0), b = ld_int_x<FP>(c, op, L + 1, 1);
     Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
     Wd<FPX<FP>::XW> X = wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW>(A, B));
     Wd<FPX<FP>::QW> dq;
@@ -608,7 +615,7 @@ WI_INLINE void op_int_mul(const LC& c, const H2EOp& op) {
     split_limbs<FP>(dq, dl);
     Fe rem_native = native_of_w<FP>(c, rem), d_native = mod_n<FPX<FP>::QW>(c, dq);
     u32 rr = op.range_row;
-    xc_put<FP>(c, H2E_MAKE_REF(1, 0, c.rel, op.range_row), rl, rem_native);
+    xc_put_x<FP>(c, op, rl, rem_native);
     rr += emit_assigned<FP>(c, op.base_row, rr, rl, rem_native);
     rr += emit_assigned<FP>(c, op.base_row + 1, rr, dl, d_native);
     emit_mul_equation<FP>(c, op.base_row + 2, rr, a, b, dl, d_native, rl, rem_native);
@@ -617,7 +624,7 @@ WI_INLINE void op_int_mul(const LC& c, const H2EOp& op) {
 template <class FP>
 WI_INLINE void op_reduce(const LC& c, const H2EOp& op) {
     constexpr int L = FP::L;
-    IntVal<FP> a = ld_int<FP>(c, op.refs);
+    IntVal<FP> a = ld_int_x<FP>(c, op, 0, 0);
     Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l);
     Wd<FP::WW> rem;
     u64 d;
@@ -627,7 +634,7 @@ WI_INLINE void op_reduce(const LC& c, const H2EOp& op) {
     split_limbs<FP>(rem, rl);
     Fe rem_native = native_of_w<FP>(c, rem);
     u32 rr = op.range_row, br = op.base_row;
-    xc_put<FP>(c, H2E_MAKE_REF(1, 0, c.rel, op.range_row), rl, rem_native);
+    xc_put_x<FP>(c, op, rl, rem_native);
     rr += emit_assigned<FP>(c, br, rr, rl, rem_native);
     emit_common(c, rr, d);
     rr += 1;
@@ -667,7 +674,7 @@ WI_INLINE void emit_invert(const LC& c, u32 row, const Fe& a) {
 template <class FP>
 WI_INLINE void op_is_int_zero(const LC& c, const H2EOp& op) {
     constexpr int L = FP::L;
-    IntVal<FP> a = ld_int<FP>(c, op.refs);
+    IntVal<FP> a = ld_int_x<FP>(c, op, 0, 0);
     Limb sum = a.l[0];
 #pragma unroll
     for (int i = 1; i < L; i++) sum = wd_add<2>(sum, a.l[i]);
@@ -701,7 +708,7 @@ WI_INLINE void op_is_int_zero(const LC& c, const H2EOp& op) {
 template <class FP>
 WI_INLINE void op_mask_int(const LC& c, const H2EOp& op) {
     constexpr int L = FP::L;
-    IntVal<FP> a = ld_int<FP>(c, op.refs);
+    IntVal<FP> a = ld_int_x<FP>(c, op, 0, 0);
     Fe coeff = ld_fe(c, op.refs[L + 1]);
     bool keep = !wd_is_zero<4>(coeff);
     u32 r = op.base_row;
@@ -714,7 +721,7 @@ WI_INLINE void op_mask_int(const LC& c, const H2EOp& op) {
 template <class FP>
 WI_INLINE void op_div_core(const LC& c, const H2EOp& op) {
     constexpr int L = FP::L;
-    IntVal<FP> b = ld_int<FP>(c, op.refs), a = ld_int<FP>(c, op.refs + L + 1);
+    IntVal<FP> b = ld_int_x<FP>(c, op, 0, 0), a = ld_int_x<FP>(c, op, L + 1, 1);
     Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
     Wd<FP::WW> w = wd_load<FP::WW>(c.fc->w);
     // canonical representatives mod w (bn_to_field::<W>)
@@ -746,7 +753,7 @@ WI_INLINE void op_div_core(const LC& c, const H2EOp& op) {
     split_limbs<FP>(dq, dl);
     Fe c_native = native_of_w<FP>(c, cv), d_native = mod_n<FPX<FP>::QW>(c, dq);
     u32 rr = op.range_row;
-    xc_put<FP>(c, H2E_MAKE_REF(1, 0, c.rel, op.range_row), cl, c_native);
+    xc_put_x<FP>(c, op, cl, c_native);
     rr += emit_assigned<FP>(c, op.base_row, rr, cl, c_native);
     rr += emit_assigned<FP>(c, op.base_row + 1, rr, dl, d_native);
     IntVal<FP> cvv;
@@ -1021,7 +1028,6 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     c.st = &stage;
     c.active = active;
     c.xc = &xcache[0][0][0];
-    c.rel = L.rel_refs;
     {
         for (u32 i0 = op_lo; i0 < op_hi; i0 += 64) {
             load_chunk(&chunk, L.tape, i0, op_hi);

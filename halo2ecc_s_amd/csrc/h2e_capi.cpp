@@ -1222,10 +1222,112 @@ struct h2e_program {
         }
     }
 
+    // Expansion result cache (engine.hip ld_int_x / xc_put_x): per sub-range of a cut segment, which of the three LDS
+    // entries an integer result goes to and which operands are read from them - furthest-next-use replacement over the
+    // static op sequence.  Encoded in op.flags bits 8-15.
+    void assign_expansion_slots() {
+        h2e::Recorder& r = *rec;
+        const int L = r.fp.limbs;
+        const int NSLOT = 3;
+        for (auto& sg : r.segments) {
+            uint32_t n_ops = sg.tape_end - sg.tape_begin;
+            if (sg.n_cuts == 0 || n_ops == 0) continue;
+            H2EOp* ops = r.tape.data() + sg.tape_begin;
+            const uint32_t rel = sg.is_fork ? 1 : 0;
+            std::vector<uint32_t> bounds;
+            uint32_t lastb = 0;
+            for (uint32_t k = 0; k < sg.n_cuts; k++) {
+                uint32_t at = r.cuts[sg.cuts_begin + k];
+                if (at > lastb && at < n_ops) {
+                    bounds.push_back(at);
+                    lastb = at;
+                }
+            }
+            bounds.push_back(n_ops);
+            auto result_key = [&](const H2EOp& op) -> uint32_t {
+                switch (op.opcode) {
+                    case H2E_OP_INT_ADD: case H2E_OP_INT_SUB: case H2E_OP_INT_NEG: case H2E_OP_INT_MUL_SMALL:
+                        return H2E_MAKE_REF(0, 4, rel, op.base_row);
+                    case H2E_OP_INT_MUL: case H2E_OP_REDUCE: case H2E_OP_DIV_CORE:
+                        return H2E_MAKE_REF(1, 0, rel, op.range_row);
+                    default: return H2E_NO_REF;
+                }
+            };
+            auto operand_pos = [&](const H2EOp& op, int* pos) -> int {
+                switch (op.opcode) {
+                    case H2E_OP_INT_ADD: case H2E_OP_INT_SUB: case H2E_OP_INT_MUL: case H2E_OP_DIV_CORE:
+                        pos[0] = 0; pos[1] = L + 1; return 2;
+                    case H2E_OP_INT_NEG: case H2E_OP_INT_MUL_SMALL: case H2E_OP_REDUCE: case H2E_OP_IS_INT_ZERO: case H2E_OP_MASK_INT:
+                        pos[0] = 0; return 1;
+                    default: return 0;
+                }
+            };
+            uint32_t lo = 0;
+            for (uint32_t hi : bounds) {
+                std::map<uint32_t, uint32_t> producer_of;          // key -> op index
+                std::map<uint32_t, std::vector<uint32_t>> uses;     // producer op -> consumer op indices (ascending)
+                for (uint32_t i = lo; i < hi; i++) {
+                    ops[i].flags &= 0x00ff;
+                    int pos[2];
+                    int n = operand_pos(ops[i], pos);
+                    for (int q = 0; q < n; q++) {
+                        auto it = producer_of.find(ops[i].refs[pos[q]]);
+                        if (it != producer_of.end()) uses[it->second].push_back(i);
+                    }
+                    uint32_t key = result_key(ops[i]);
+                    if (key != H2E_NO_REF) producer_of[key] = i;
+                }
+                int owner[NSLOT];
+                for (int sl = 0; sl < NSLOT; sl++) owner[sl] = -1;
+                std::map<uint32_t, size_t> next;   // producer -> index of its next unconsumed use
+                auto next_use = [&](uint32_t p) -> uint32_t {
+                    auto& u = uses[p];
+                    size_t k = next[p];
+                    return k < u.size() ? u[k] : 0xffffffffu;
+                };
+                std::map<uint32_t, int> slot_of;
+                for (uint32_t i = lo; i < hi; i++) {
+                    int pos[2];
+                    int n = operand_pos(ops[i], pos);
+                    for (int q = 0; q < n; q++) {
+                        auto it = producer_of.find(ops[i].refs[pos[q]]);
+                        if (it == producer_of.end() || it->second >= i) continue;
+                        uint32_t pr = it->second;
+                        // (a key can be produced twice in a sub-range only if rows repeated, which they do not)
+                        auto st = slot_of.find(pr);
+                        if (st != slot_of.end() && owner[st->second] == (int)pr) ops[i].flags |= (uint16_t)((st->second + 1) << (10 + 2 * q));
+                        auto& u = uses[pr];
+                        while (next[pr] < u.size() && u[next[pr]] <= i) next[pr]++;
+                    }
+                    for (int sl = 0; sl < NSLOT; sl++)
+                        if (owner[sl] >= 0 && next_use((uint32_t)owner[sl]) == 0xffffffffu) owner[sl] = -1;
+                    if (result_key(ops[i]) != H2E_NO_REF && !uses[i].empty()) {
+                        int pick = -1;
+                        for (int sl = 0; sl < NSLOT && pick < 0; sl++)
+                            if (owner[sl] < 0) pick = sl;
+                        if (pick < 0) {
+                            int far = 0;
+                            for (int sl = 1; sl < NSLOT; sl++)
+                                if (next_use((uint32_t)owner[sl]) > next_use((uint32_t)owner[far])) far = sl;
+                            if (next_use((uint32_t)owner[far]) > uses[i][0]) pick = far;
+                        }
+                        if (pick >= 0) {
+                            owner[pick] = (int)i;
+                            slot_of[i] = pick;
+                            ops[i].flags |= (uint16_t)((pick + 1) << 8);
+                        }
+                    }
+                }
+                lo = hi;
+            }
+        }
+    }
+
     void finish() {
         h2e::Recorder& r = *rec;
         r.close_segment();
         mark_local_results();
+        assign_expansion_slots();
         mark_deferrable();
         mark_side_segments();
         // which of the 8 value-hint slots per ecc op does anything read?  (finalize_ecc skips the others)
