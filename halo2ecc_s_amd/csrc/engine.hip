@@ -1852,24 +1852,50 @@ __global__ void __launch_bounds__(64) h2e_fixup_inverses(H2ELaunch L, const Inst
     u32 ob = L.strand_base0 + strand * L.delta_base;
     Mont<4> M = mont_n(fc);
     u32 lo = chunk * FIXUP_K, hi = min(lo + FIXUP_K, L.n_fixups);
+    // The cells of one thread are 160 B apart (every load a miss): both passes fetch FB rows at a time, independent
+    // loads in flight together, before the serial multiplications over them.  (Measured: no change at 1.5 waves per
+    // SIMD - the kernel's 1.3-2.2 ms are the thread's ~570 dependent multiplications, 380 of them the inversion.)
+    constexpr u32 FB = 8;
     Fe acc = M.r1;  // Montgomery one
-    for (u32 i = lo; i < hi; i++) {
-        u64* row = base + (size_t)(L.fixups[i] + ob) * 5 * 4;
-        Fe x = wd_load<4>(row);
-        st_cell(row + 4, acc);  // prefix product of the non-zero values before i
-        if (!wd_is_zero<4>(x)) acc = mont_mul<4>(M, acc, to_mont<4>(M, x));
+    for (u32 i0 = lo; i0 < hi; i0 += FB) {
+        u64* rows[FB];
+        Fe xs[FB];
+#pragma unroll
+        for (u32 j = 0; j < FB; j++) rows[j] = base + (size_t)(L.fixups[min(i0 + j, hi - 1)] + ob) * 5 * 4;
+#pragma unroll
+        for (u32 j = 0; j < FB; j++) xs[j] = wd_load<4>(rows[j]);
+#pragma unroll
+        for (u32 j = 0; j < FB; j++) {
+            if (i0 + j < hi) {
+                st_cell(rows[j] + 4, acc);  // prefix product of the non-zero values before i
+                if (!wd_is_zero<4>(xs[j])) acc = mont_mul<4>(M, acc, to_mont<4>(M, xs[j]));
+            }
+        }
     }
     Fe ainv = mont_inv<4>(M, acc);
-    for (u32 i = hi; i-- > lo;) {
-        u64* row = base + (size_t)(L.fixups[i] + ob) * 5 * 4;
-        Fe x = wd_load<4>(row);
-        Fe pre = wd_load<4>(row + 4);
-        Fe out = wd_zero<4>();
-        if (!wd_is_zero<4>(x)) {
-            out = from_mont<4>(M, mont_mul<4>(M, ainv, pre));
-            ainv = mont_mul<4>(M, ainv, to_mont<4>(M, x));
+    for (u32 i1 = hi; i1 > lo;) {
+        u32 cnt = min(FB, i1 - lo);   // rows i1-1 ... i1-cnt, in that order
+        u64* rows[FB];
+        Fe xs[FB], pre[FB];
+#pragma unroll
+        for (u32 j = 0; j < FB; j++) rows[j] = base + (size_t)(L.fixups[i1 - 1 - min(j, cnt - 1)] + ob) * 5 * 4;
+#pragma unroll
+        for (u32 j = 0; j < FB; j++) {
+            xs[j] = wd_load<4>(rows[j]);
+            pre[j] = wd_load<4>(rows[j] + 4);
         }
-        st_cell(row + 4, out);
+#pragma unroll
+        for (u32 j = 0; j < FB; j++) {
+            if (j < cnt) {
+                Fe out = wd_zero<4>();
+                if (!wd_is_zero<4>(xs[j])) {
+                    out = from_mont<4>(M, mont_mul<4>(M, ainv, pre[j]));
+                    ainv = mont_mul<4>(M, ainv, to_mont<4>(M, xs[j]));
+                }
+                st_cell(rows[j] + 4, out);
+            }
+        }
+        i1 -= cnt;
     }
 }
 

@@ -1393,6 +1393,7 @@ struct h2e_ctx {
     hipStream_t early_stream = nullptr;
     hipStream_t fixup_stream = nullptr;
     uint32_t n_launches = 0;
+    std::vector<uint32_t> x_kernels;   // per launched segment: expansion kernel launches of the last run (2 = split)
     ~h2e_ctx() {
         for (auto& kv : cache) delete kv.second;
         for (int i = 0; i < 3; i++)
@@ -1767,6 +1768,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         HIP_TRY(hipStreamWaitEvent(sb, e, 0));
     }
     ctx->n_launches = 0;
+    ctx->x_kernels.clear();
     // (the runtime maps streams onto 4 hardware queues by default: a fifth stream would share one and serialise behind
     // it, so the side segments use the early-predictor stream)
     hipStream_t se = sc;
@@ -1810,6 +1812,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
                 side_done[sj] = nullptr;
             }
         uint32_t li = ctx->n_launches;
+        if (ctx->x_kernels.size() <= li) ctx->x_kernels.resize(li + 1, 1);
         if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 0), sa));
         // this segment's predictors: chains first, then (after the early starters below) their finalize kernels
         for (size_t pi = 0; pi < r.pre_kernels.size(); pi++) {
@@ -1879,20 +1882,67 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         L.l_steps = levels ? p->seg_l_steps[si] : 0;
         L.l_slots = levels ? p->seg_l_slots[si] : 0;
         int lrc;
-        auto launch = [&](int mode, hipStream_t st) -> int {
-            int rc2 = h2e_engine_launch(fp, mode, &L, p->d_inst, n_instances, ctx->d_fc[fp], st);
+        auto launch_one = [&](int mode, const H2ELaunch& l, hipStream_t st) -> int {
+            int rc2 = h2e_engine_launch(fp, mode, &l, p->d_inst, n_instances, ctx->d_fc[fp], st);
             if (rc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc2));
             return 0;
         };
+        auto launch = [&](int mode, hipStream_t st) -> int { return launch_one(mode, L, st); };
+        // A big expansion (the MSM windows: 52 k workgroups that hold every CU's LDS for 22 ms) goes out as two
+        // back-to-back launches over the first H2E_X_SPLIT percent / the rest of its sub-ranges: while the first one
+        // drains, the value chain that became ready meanwhile (the MSM tail's replay wants most of a CU's LDS per
+        // workgroup) gets its CUs instead of waiting for the whole expansion (13 ms -> 1.9 ms), and the inverse
+        // fix-up of the first part runs under the second.
+        uint32_t split_sub = 0, split_fix = 0;
+        {
+            const char* e1 = getenv("H2E_X_SPLIT");
+            const char* e2 = getenv("H2E_X_SPLIT_MIN_LANES");
+            uint32_t pct = e1 ? (uint32_t)atoi(e1) : 45;
+            uint64_t min_lanes = e2 ? (uint64_t)atoll(e2) : (1ull << 21);
+            if (pct > 0 && pct < 100 && L.n_sub >= 4 && (uint64_t)L.n_sub * L.n_strands * n_instances >= min_lanes) {
+                split_sub = std::min<uint32_t>(std::max<uint32_t>(2, (uint32_t)((uint64_t)L.n_sub * pct / 100)), L.n_sub - 2);
+                uint32_t row = r.tape[s.tape_begin + p->h_subs[p->seg_sub_begin[si] + split_sub]].base_row;
+                auto fb = r.fixups.begin() + s.fixups_begin;
+                // fix-up rows are recorded in tape order: those below the first row of the second part belong to the first
+                split_fix = std::is_sorted(fb, fb + s.n_fixups) ? (uint32_t)(std::lower_bound(fb, fb + s.n_fixups, row) - fb) : 0;
+                if (getenv("H2E_DEBUG_X_SPLIT_REPORT"))
+                    fprintf(stderr, "x-split segment %zu: %u of %u sub-ranges, %u of %u fix-ups\n", si, split_sub, L.n_sub, split_fix, s.n_fixups);
+            }
+        }
         // the inverse fix-up of a segment only touches cells nothing else reads or writes: own stream, after the expansion
-        auto fixup_after = [&](hipStream_t st) -> int {
-            if (!s.n_fixups) return 0;
+        // (a small expansion that runs on the side stream keeps its fix-up there: the fix-up stream may be waiting for
+        // a big expansion)
+        bool fixup_in_stream = false;
+        auto fixup_part = [&](hipStream_t st, uint32_t lo, uint32_t hi) -> int {
+            if (hi <= lo) return 0;
+            H2ELaunch f = L;
+            f.fixups = L.fixups + lo;
+            f.n_fixups = hi - lo;
+            if (fixup_in_stream) return launch_one(4, f, st);
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, st));
             HIP_TRY(hipStreamWaitEvent(sd, e, 0));
             used_sd = true;
-            return launch(4, sd);
+            return launch_one(4, f, sd);
         };
+        auto fixup_after = [&](hipStream_t st) -> int { return fixup_part(st, 0, s.n_fixups); };
+        // full expansion + fix-up of this segment on stream st
+        auto expand = [&](hipStream_t st) -> int {
+            int xrc;
+            if (!split_sub) {
+                if ((xrc = launch(2, st))) return xrc;
+                return 0;
+            }
+            H2ELaunch a = L, b = L;
+            ctx->x_kernels[li] = 2;
+            a.n_sub = split_sub;
+            b.n_sub = L.n_sub - split_sub;
+            b.sub = L.sub + split_sub;
+            if ((xrc = launch_one(2, a, st))) return xrc;
+            if ((xrc = fixup_part(st, 0, split_fix))) return xrc;
+            return launch_one(2, b, st);
+        };
+        auto expand_fixup = [&](hipStream_t st) -> int { return fixup_part(st, split_sub ? split_fix : 0, s.n_fixups); };
         if (L.n_sub > 1) {
             if ((lrc = launch(1, sa))) return lrc;
             if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
@@ -1912,6 +1962,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
             // beside it on the side stream as soon as its value chain is done
             hipStream_t sx = ((uint64_t)L.n_sub * L.n_strands * n_instances < (1u << 18) && !getenv("H2E_NO_SMALL_X_ASIDE")) ? sc : sb;
             if (sx == sc) used_se = true;
+            fixup_in_stream = sx == sc;
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, sa));
             HIP_TRY(hipStreamWaitEvent(sx, e, 0));
@@ -1924,9 +1975,9 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
                 for (size_t sj = si + 1; sj < r.segments.size(); sj++) later_cut = later_cut || p->seg_n_sub[sj] > 1;
                 skip_x = atoi(sx) == (int)si || (atoi(sx) == -1 && later_cut);
             }
-            if (!skip_x && (lrc = launch(2, sx))) return lrc;
+            if (!skip_x && (lrc = expand(sx))) return lrc;
             if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sx));
-            if (!skip_x && (lrc = fixup_after(sx))) return lrc;
+            if (!skip_x && (lrc = expand_fixup(sx))) return lrc;
         } else if (p->seg_side_dep[si] != -2 && !getenv("H2E_DEBUG_NO_SIDE")) {
             // runs beside the value chain: after the last segment it reads, before the first segment that reads it
             int32_t depi = p->seg_side_dep[si];
@@ -2039,6 +2090,12 @@ int h2e_last_run_launch_ms(h2e_ctx* ctx, float* ms, uint32_t cap) {
         ms[2 * i] = t0;
         ms[2 * i + 1] = t1;
     }
+    return (int)ctx->n_launches;
+}
+
+int h2e_last_run_expansion_launches(h2e_ctx* ctx, uint32_t* counts, uint32_t cap) {
+    if (!ctx || !counts) return fail(H2E_ERR_INVALID, "null argument");
+    for (uint32_t i = 0; i < ctx->n_launches && i < cap; i++) counts[i] = i < ctx->x_kernels.size() ? ctx->x_kernels[i] : 1;
     return (int)ctx->n_launches;
 }
 

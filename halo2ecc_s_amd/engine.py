@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "h2e_program_pairing_check_bls12_381", "h2e_program_destroy", "h2e_program_shape", "h2e_run",
     "h2e_int_mul_batch", "h2e_msm_bn256_tile", "h2e_pairing_check_bn256", "h2e_pairing_check_bls12_381",
     "h2e_last_run_launch_ms", "h2e_set_profiling", "h2e_program_outputs", "h2e_program_launches", "h2e_export_columns",
-    "h2e_program_msm_bn256_tile_no_select",
+    "h2e_program_msm_bn256_tile_no_select", "h2e_last_run_expansion_launches",
 ]
 
 
@@ -81,6 +81,7 @@ def lib():
     L.h2e_pairing_check_bls12_381.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     L.h2e_last_run_launch_ms.argtypes = [vp, C.POINTER(C.c_float), u32]
     L.h2e_set_profiling.argtypes = [vp, i32]
+    L.h2e_last_run_expansion_launches.argtypes = [vp, C.POINTER(u32), u32]
     L.h2e_program_outputs.argtypes = [vp, C.POINTER(u32), u32]
     L.h2e_program_launches.argtypes = [vp, C.POINTER(C.c_uint64), u32]
     L.h2e_export_columns.argtypes = [vp, u32, C.c_uint64, u32, vp, vp, vp]
@@ -249,6 +250,14 @@ class Engine:
         if n < 0:
             _check(n)
         return [(buf[2 * i], buf[2 * i + 1]) for i in range(min(n, cap // 2))]
+
+    def last_run_expansion_launches(self, cap=64):
+        """per launched segment: kernel launches its full expansion went out as (2 = split, see h2e.h)"""
+        buf = (C.c_uint32 * cap)()
+        n = lib().h2e_last_run_expansion_launches(self._h, buf, cap)
+        if n < 0:
+            _check(n)
+        return [int(buf[i]) for i in range(min(n, cap))]
 
     def close(self):
         if self._h:

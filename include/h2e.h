@@ -150,6 +150,9 @@ int h2e_export_columns(h2e_ctx* ctx, uint32_t n_instances, uint64_t rows, uint32
  * (predictor kernels + values-only replay), ms[2i+1] = full expansion (the inverse fix-up runs on its own stream and is not included; call after synchronising). */
 int h2e_last_run_launch_ms(h2e_ctx* ctx, float* ms, uint32_t cap);
 int h2e_set_profiling(h2e_ctx* ctx, int enable);
+/* Companion of h2e_last_run_launch_ms: counts[i] = kernel launches the full expansion of segment i went out as in the
+ * last run (1, or 2 when a big expansion was split - ms[2i+1] then brackets both; see h2e_capi.cpp `expand`). */
+int h2e_last_run_expansion_launches(h2e_ctx* ctx, uint32_t* counts, uint32_t cap);
 
 #ifdef __cplusplus
 }

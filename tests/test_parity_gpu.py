@@ -154,6 +154,27 @@ def test_msm_value_chain_does_not_depend_on_expansion(engine, oracle, monkeypatc
     assert np.array_equal(got[tail0:], ovals[tail0:]), "tail differs when the windows' expansion is left out"
 
 
+@pytest.mark.parametrize("pct", [10, 45, 90])
+def test_msm_split_expansion(engine, oracle, monkeypatch, capfd, pct):
+    """A big expansion goes out as two launches over a prefix / the rest of its sub-ranges, with the inverse fix-up of
+    the first part in between (h2e_capi.cpp `expand`; at BASELINE's size: the MSM windows).  Forced here at a small
+    size: every cell, the is_zero inverses of both parts included, must still equal the oracle's."""
+    n, tiles = 96, 2
+    ins = [synth.msm_bn256_tile_inputs(n, tile=40 + t, cheap_points=True)[0] for t in range(tiles)]
+    prog = Program.msm_bn256_tile(n)
+    monkeypatch.setenv("H2E_X_SPLIT_MIN_LANES", "0")
+    monkeypatch.setenv("H2E_X_SPLIT", str(pct))
+    monkeypatch.setenv("H2E_DEBUG_X_SPLIT_REPORT", "1")
+    base, rng, sel, status = _run(engine, prog, ins)
+    err = capfd.readouterr().err
+    assert "x-split segment" in err, "the split path was not taken"
+    assert (status == 0).all(), status
+    for k, inp in enumerate(ins):
+        orun = oracle_lib.run_msm_bn256_tile(n, inp)
+        assert orun.info.status == 0, orun.error
+        compare_advice(prog, orun, base, rng, sel, instance=k)
+
+
 @pytest.mark.parametrize("n", [1, 5, 12])
 def test_msm_tile_no_select(engine, oracle, n):
     """MSM without the select chip (ecc_chip.rs:91-221, candidates by bisection trees)"""
