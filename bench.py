@@ -53,8 +53,8 @@ def cpu_baseline(points):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--tiles", type=int, default=64, help="tiles per GPU (64 x 1024 = 2^16 points)")
     ap.add_argument("--points", type=int, default=1024, help="points per tile")
     ap.add_argument("--cpu-sample-points", type=int, default=1024)
@@ -142,12 +142,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    launch_ms = []
+    launch_ms, step_ms = [], []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
-        if len(launch_ms) == 0 or True:
-            torch.cuda.current_stream().synchronize()
-            launch_ms.append(eng.last_run_launch_ms())
+        torch.cuda.current_stream().synchronize()
+        launch_ms.append(eng.last_run_launch_ms())
+        step_ms.append(1e3 * (time.perf_counter() - ts))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -178,6 +179,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        "step_ms": [round(x, 2) for x in step_ms],   # rank 0's wall time of each timed step (diagnostic)
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
