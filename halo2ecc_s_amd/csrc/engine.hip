@@ -999,6 +999,10 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     bool active = idx < per_sub;
     if (!active) idx = per_sub - 1;
     u32 instance = idx / L.n_strands, strand = idx % L.n_strands;
+    if (L.rel_refs & 2) {   // experiment (H2E_X_INSTANCE_MINOR): a wave = one strand of 64 instances, row streams 1 GB apart
+        instance = idx % n_instances;
+        strand = idx / n_instances;
+    }
     u32 op_lo = 0, op_hi = L.n_ops;
     if (!VALUES_ONLY && L.n_sub > 1) {
         op_lo = L.sub[sub];

@@ -1866,7 +1866,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         L.hint_stride = s.hint_stride;
         L.n_fixups = s.n_fixups;
         L.fixups = p->d_fixups + s.fixups_begin;
-        L.rel_refs = s.is_fork ? 1 : 0;
+        L.rel_refs = (s.is_fork ? 1 : 0) | (getenv("H2E_X_INSTANCE_MINOR") ? 2 : 0);
         L.n_sub = p->seg_n_sub[si];
         L.sub = L.n_sub > 1 ? p->d_subs + p->seg_sub_begin[si] : nullptr;
         bool compiled = si < p->seg_n_pieces.size() && p->seg_n_pieces[si] > 0;
@@ -1910,8 +1910,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
             }
         }
         // the inverse fix-up of a segment only touches cells nothing else reads or writes: own stream, after the expansion
-        // (a small expansion that runs on the side stream keeps its fix-up there: the fix-up stream may be waiting for
-        // a big expansion)
+        // (a small expansion sent to the side stream keeps its fix-up there)
         bool fixup_in_stream = false;
         auto fixup_part = [&](hipStream_t st, uint32_t lo, uint32_t hi) -> int {
             if (hi <= lo) return 0;
@@ -1958,9 +1957,12 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
                 HIP_TRY(hipEventRecord(seg_ev[si], sa));
                 continue;
             }
-            // a small expansion (the MSM tail: 763 waves) does not queue behind a big one on the expansion stream: it runs
-            // beside it on the side stream as soon as its value chain is done
-            hipStream_t sx = ((uint64_t)L.n_sub * L.n_strands * n_instances < (1u << 18) && !getenv("H2E_NO_SMALL_X_ASIDE")) ? sc : sb;
+            // a small expansion (the MSM tail: 763 waves) queues behind the big one on the expansion stream: beside it on
+            // the side stream (H2E_SMALL_X_ASIDE) it and its fix-up slow the big one down by more than they take alone
+            // (in-process A/B, exp/ab_inprocess.py: step +0.6 ... +1.0 ms).  Its fix-up follows the big one's on the fix-up
+            // stream: on the side stream it delays the side segments of the program's end (+1.2 ms)
+            bool small_x = (uint64_t)L.n_sub * L.n_strands * n_instances < (1u << 18);
+            hipStream_t sx = (small_x && getenv("H2E_SMALL_X_ASIDE")) ? sc : sb;
             if (sx == sc) used_se = true;
             fixup_in_stream = sx == sc;
             hipEvent_t e = sync_event();
