@@ -1959,12 +1959,13 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
             }
             // a small expansion (the MSM tail: 763 waves) queues behind the big one on the expansion stream: beside it on
             // the side stream (H2E_SMALL_X_ASIDE) it and its fix-up slow the big one down by more than they take alone
-            // (in-process A/B, exp/ab_inprocess.py: step +0.6 ... +1.0 ms).  Its fix-up follows the big one's on the fix-up
-            // stream: on the side stream it delays the side segments of the program's end (+1.2 ms)
+            // (in-process A/B, exp/ab_inprocess.py: step +0.6 ... +1.0 ms); its fix-up on the side stream delays the side
+            // segments of the program's end (+1.2 ms)
             bool small_x = (uint64_t)L.n_sub * L.n_strands * n_instances < (1u << 18);
             hipStream_t sx = (small_x && getenv("H2E_SMALL_X_ASIDE")) ? sc : sb;
             if (sx == sc) used_se = true;
-            fixup_in_stream = sx == sc;
+            // its fix-up follows it in its stream: the fix-up stream still holds the big expansion's second fix-up
+            fixup_in_stream = sx == sc || (small_x && !getenv("H2E_NO_FIXUP_IN_STREAM"));
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, sa));
             HIP_TRY(hipStreamWaitEvent(sx, e, 0));
