@@ -1735,7 +1735,12 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
                                      : hipErrorNotSupported;
         if (me != hipSuccess) {
             (void)hipGetLastError();
-            HIP_TRY(hipStreamCreateWithFlags(&ctx->expand_stream, hipStreamNonBlocking));
+            // experiment knob H2E_STREAM_PRIORITIES="x,e,f": HIP stream priorities of the expansion / early / fix-up streams
+            int px = 0, pe = 0, pf = 0;
+            if (const char* pr = getenv("H2E_STREAM_PRIORITIES")) sscanf(pr, "%d,%d,%d", &px, &pe, &pf);
+            HIP_TRY(hipStreamCreateWithPriority(&ctx->expand_stream, hipStreamNonBlocking, px));
+            if (!ctx->early_stream) HIP_TRY(hipStreamCreateWithPriority(&ctx->early_stream, hipStreamNonBlocking, pe));
+            if (!ctx->fixup_stream) HIP_TRY(hipStreamCreateWithPriority(&ctx->fixup_stream, hipStreamNonBlocking, pf));
         }
     }
     if (!ctx->early_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->early_stream, hipStreamNonBlocking));
