@@ -25,14 +25,6 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured 
 Q = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
 
 
-def read_cell(base, ref):
-    """value of a base-chip cell reference from the advice tensor of one instance"""
-    region, col, row = ref >> 30, (ref >> 27) & 7, ref & 0x3FFFFFF
-    assert region == 0
-    w = base[row, col].cpu().numpy().view(np.uint64)
-    return sum(int(w[k]) << (64 * k) for k in range(4))
-
-
 def cpu_baseline(points):
     """The oracle (CPU restatement = 'port') timed on this box's host cores on a bounded sample: one tile of
     `points` points, window-parallel like the reference's rayon region (src/circuit/ecc_chip.rs:317-343)."""
@@ -108,9 +100,9 @@ def main():
         torch.cuda.synchronize()
         exp = np.zeros((tiles, 3, 4), dtype=np.uint64)
         for t in range(tiles):
-            xs = [read_cell(base[t], r) for r in out_refs[0:L]]
-            ys = [read_cell(base[t], r) for r in out_refs[L + 1:2 * L + 1]]
-            z = read_cell(base[t], out_refs[2 * L + 2])
+            xs = [eng.read_cell(base, r, t) for r in out_refs[0:L]]
+            ys = [eng.read_cell(base, r, t) for r in out_refs[L + 1:2 * L + 1]]
+            z = eng.read_cell(base, out_refs[2 * L + 2], t)
             x = sum(v << (108 * i) for i, v in enumerate(xs)) % Q
             y = sum(v << (108 * i) for i, v in enumerate(ys)) % Q
             if z:

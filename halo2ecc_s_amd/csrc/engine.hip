@@ -1,11 +1,14 @@
 // gfx950 witness engine: replays a witness tape (tape.h) for many instances / strands at once.
 //
-// Mapping: one lane per (instance, strand).  All lanes of a launch execute the same op at the same
-// time (the tape is wave-uniform, fetched through the scalar cache), so there is no divergence
-// except inside the two modular inversions.  Every lane streams its advice cells row-major into its
-// own row range of the instance's arrays — [row][col][4 x u64], canonical little-endian bn256-Fr —
-// exactly the rows the reference's forked context would have written (src/context.rs:610-632,
-// 803-815, 722-735).  Operands are read back from those arrays through cell references.
+// Mapping: one lane per (strand, instance), instance minor.  All lanes of a launch execute the same op at the
+// same time (the tape is wave-uniform, fetched through the scalar cache), so there is no divergence except inside
+// the two modular inversions.  Advice arrays are *batch-interleaved*: [row][col][half][instance][2 x u64] - the rows
+// and columns are exactly those the reference's (forked) context would have written (src/context.rs:610-632,
+// 803-815, 722-735), a cell is two 16-byte halves (canonical little-endian bn256-Fr), and the instances of the batch
+// are the minor dimension.  The 64 lanes of a wave are 64 instances at the same (row, col): every store instruction
+// of a wave is one contiguous 1 KB run, unassigned cells are never touched (no bytes beyond the 32 B per assigned
+// cell), and a wave walks through memory sequentially row after row.  With one instance the layout is the
+// reference's row-major `[row][col][4 x u64]`.  Operands are read back from those arrays through cell references.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "tape.h"
@@ -47,9 +50,9 @@ typedef Wd<2> Limb;   // <= 114 bit
 typedef Wd<4> Fe;     // canonical bn256-Fr value
 
 struct InstanceDesc {
-    u64* base;          // [base_rows][5][4]
-    u64* range;         // [range_rows][3][4]
-    u64* select;        // [select_rows][2][4]
+    u64* base;          // batch array [base_rows][5][2][n_instances][2] + 2 * instance
+    u64* range;         // [range_rows][3][2][n_instances][2] + 2 * instance
+    u64* select;        // [select_rows][2][2][n_instances][2] + 2 * instance
     const u64* inputs;  // [n_slots][slot_words]
     u32* status;
     u64* hints;         // [n_hint_slots][4]   quotient hints for H2E_OP_DIV_CORE (canonical values)
@@ -65,6 +68,7 @@ struct LC {  // lane context
     const u64* inputs;
     u32* status;
     u32 ob, orr, os;       // strand offsets
+    u32 hs;                // words between the two halves of a cell = 2 * n_instances (2: one instance, row-major)
     const u32* params;     // this strand's parameter refs
     const u32* aux;
     const u64* pool;
@@ -74,7 +78,6 @@ struct LC {  // lane context
     u32 hint_stride;
     const u64* sel;     // selection buffer (H2E_FLAG_PRESELECTED)
     u32 sel_stride;
-    struct Stage* st;   // LDS row staging (see rowB)
     bool active;        // false for the padding lanes of the last wave: compute, but store nothing
     // expansion only: three integer results of this lane's sub-range kept in LDS ([3][W][64] words).  An op's
     // operands are mostly the results of the one or two ops before it; re-reading them from their cells misses the L2
@@ -88,32 +91,34 @@ WI_INLINE u64* cell_ptr(const LC& c, u32 ref) {
     if (H2E_REF_REGION(ref) == H2E_REGION_PARAM) ref = c.params[H2E_REF_ROW(ref)];
     u32 region = H2E_REF_REGION(ref), col = H2E_REF_COL(ref), row = H2E_REF_ROW(ref);
     bool rel = H2E_REF_REL(ref);
-    if (region == 0) return c.base + ((size_t)(row + (rel ? c.ob : 0)) * 5 + col) * 4;
-    if (region == 1) return c.range + ((size_t)(row + (rel ? c.orr : 0)) * 3 + col) * 4;
-    return c.select + ((size_t)(row + (rel ? c.os : 0)) * 2 + col) * 4;
+    if (region == 0) return c.base + ((size_t)(row + (rel ? c.ob : 0)) * 5 + col) * 2 * c.hs;
+    if (region == 1) return c.range + ((size_t)(row + (rel ? c.orr : 0)) * 3 + col) * 2 * c.hs;
+    return c.select + ((size_t)(row + (rel ? c.os : 0)) * 2 + col) * 2 * c.hs;
 }
-WI_INLINE Fe ld_fe(const LC& c, u32 ref) {
-    const ulonglong2* p = (const ulonglong2*)cell_ptr(c, ref);
-    ulonglong2 a = p[0], b = p[1];
+WI_INLINE Fe ld_cell(const u64* p, u32 hs) {
+    ulonglong2 a = *(const ulonglong2*)p, b = *(const ulonglong2*)(p + hs);
     Fe r;
     r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
     return r;
 }
-WI_INLINE Limb ld_limb(const LC& c, u32 ref) {  // values known to be < 2^128
+WI_INLINE Fe ld_fe(const LC& c, u32 ref) { return ld_cell(cell_ptr(c, ref), c.hs); }
+WI_INLINE Limb ld_limb(const LC& c, u32 ref) {  // values known to be < 2^128: the low half only
     const ulonglong2* p = (const ulonglong2*)cell_ptr(c, ref);
     ulonglong2 a = p[0];
     Limb r;
     r.v[0] = a.x; r.v[1] = a.y;
     return r;
 }
-WI_INLINE void st_cell(u64* p, const Fe& v) {
-    ulonglong2* q = (ulonglong2*)p;
-    q[0] = make_ulonglong2(v.v[0], v.v[1]);
-    q[1] = make_ulonglong2(v.v[2], v.v[3]);
+WI_INLINE void st_cell(u64* p, u32 hs, const Fe& v) {
+    *(ulonglong2*)p = make_ulonglong2(v.v[0], v.v[1]);
+    *(ulonglong2*)(p + hs) = make_ulonglong2(v.v[2], v.v[3]);
 }
-WI_INLINE void stB(const LC& c, u32 row, int col, const Fe& v) { st_cell(c.base + ((size_t)(row + c.ob) * 5 + col) * 4, v); }
-WI_INLINE void stR(const LC& c, u32 row, int col, const Fe& v) { st_cell(c.range + ((size_t)(row + c.orr) * 3 + col) * 4, v); }
-WI_INLINE void stS(const LC& c, u32 row, int col, const Fe& v) { st_cell(c.select + ((size_t)(row + c.os) * 2 + col) * 4, v); }
+WI_INLINE u64* rowB_ptr(const LC& c, u32 row) { return c.base + (size_t)(row + c.ob) * 10 * c.hs; }
+WI_INLINE u64* rowR_ptr(const LC& c, u32 row) { return c.range + (size_t)(row + c.orr) * 6 * c.hs; }
+WI_INLINE u64* rowS_ptr(const LC& c, u32 row) { return c.select + (size_t)(row + c.os) * 4 * c.hs; }
+WI_INLINE void stB(const LC& c, u32 row, int col, const Fe& v) { st_cell(rowB_ptr(c, row) + (size_t)col * 2 * c.hs, c.hs, v); }
+WI_INLINE void stR(const LC& c, u32 row, int col, const Fe& v) { st_cell(rowR_ptr(c, row) + (size_t)col * 2 * c.hs, c.hs, v); }
+WI_INLINE void stS(const LC& c, u32 row, int col, const Fe& v) { st_cell(rowS_ptr(c, row) + (size_t)col * 2 * c.hs, c.hs, v); }
 WI_INLINE Fe fe_of(const Limb& l) { return wd_resize<4>(l); }
 WI_INLINE Fe fe_u64(u64 x) { return wd_from_u64<4>(x); }
 WI_INLINE void flag(const LC& c, u32 bits) { atomicOr(c.status, bits); }
@@ -155,84 +160,38 @@ WI_INLINE Fe fe_of_signed(const LC& c, const Wd<4>& x) { return wd_is_neg<4>(x) 
 WI_INLINE Fe inv_n(const LC& c, const Fe& a) { return wd_inv_mod<4>(a, n_of(c)); }
 
 // ------------------------------------------------------------------------------------------------
-// Row emission.  A lane owns whole rows (every row is written by exactly one op), and different lanes of a wave
-// write rows that are far apart, so storing cell by cell makes every 16-byte store its own L1->L2 request
-// (measured: TCP stalled ~100 % of the expansion kernel, 4.05 G write requests for 65 GB).  Instead each lane
-// drops its row into LDS and the wave flushes the 64 rows together: consecutive lanes store consecutive 16-byte
-// pieces of the same row, so one request carries a 64-byte run.  `mask` = assigned columns.  Whole rows are
-// stored (unassigned cells as zero, which is what they hold anyway): rows with holes made ~half of the HBM write
-// requests 32-byte partial lines, and the same kernel ran 25 % faster writing 40 % more bytes without them.
-// (Tried: collecting 2-3 consecutive rows per lane and kind before flushing.  exp/ubench/segwrite.hip says HBM write
-// throughput follows the contiguous segment size - 160 B: 2.9 TB/s, 640 B: 5.8 TB/s - but in this kernel the larger
-// staging buffers cut the waves per CU from 10 to 3 and the expansion got 25 % slower; one row per flush it is.)
-struct Stage {  // one buffer, used for one row kind at a time (12 KB per wave keeps 13 waves per CU resident)
-    union {
-        u64 b[64][22];  // base row: 5 cells x 32 B, lane stride 176 B (conflict-free for 128-bit LDS access)
-        u64 r[64][14];  // range row: 3 cells, lane stride 112 B
-        u64 s[64][10];  // select row: 2 cells, lane stride 80 B
-        u64 r3[64][38]; // the 3 (or 2) range rows of one limb, written as one 288-byte (192-byte) segment: HBM write
-                        // throughput follows the contiguous segment size (exp/ubench/segwrite.hip); lane stride 304 B
-    };
-    u64* ptr[64];
-};
-WI_INLINE void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-WI_INLINE void stage_cell(u64* dst, const Fe& v) {
-    ulonglong2* q = (ulonglong2*)dst;
-    q[0] = make_ulonglong2(v.v[0], v.v[1]);
-    q[1] = make_ulonglong2(v.v[2], v.v[3]);
-}
-template <int CELLS, int STRIDE64>
-WI_INLINE void flush_rows(u64 (*buf)[STRIDE64], u64** ptrs, u32 mask) {
-    constexpr int PIECES = CELLS * 2;  // 16-byte pieces per row
-    u32 lane = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < PIECES; i++) {
-        u32 chunk = i * 64 + lane;
-        u32 r = chunk / PIECES, piece = chunk - r * PIECES;
-        u64* p = ptrs[r];
-        if (p != nullptr && ((mask >> (piece >> 1)) & 1)) {
-            ulonglong2 v = *(const ulonglong2*)&buf[r][piece * 2];
-            *(ulonglong2*)(p + piece * 2) = v;
-        }
-    }
-}
+// Row emission.  A lane owns whole rows (every row is written by exactly one op) and stores the assigned cells of a
+// row straight from registers: the lanes of a wave are consecutive instances at the same (row, col, half), so each
+// 16-byte store instruction of the wave is one contiguous 1 KB run (full 128-byte lines, no read-modify-write, no LDS
+// staging), and cells the shape leaves unassigned cost nothing.  `mask` = assigned columns (compile-time at nearly
+// every call site).  Round 1 kept the reference's per-instance row-major layout: 160 / 96 / 64-byte segments per lane,
+// LDS-staged whole-row flushes, 1.48 x the algorithmic bytes written (zero cells) at 0.35 of the HBM roof.
 WI_INLINE void rowB(const LC& c, u32 row, u32 mask, const Fe& v0, const Fe& v1, const Fe& v2, const Fe& v3, const Fe& v4) {
-    Stage* st = c.st;
-    u32 lane = threadIdx.x;
-    mask = 0x1f;  // always store the whole row (see "pieces of unassigned cells" above)
-    if (mask & 1) stage_cell(&st->b[lane][0], v0);
-    if (mask & 2) stage_cell(&st->b[lane][4], v1);
-    if (mask & 4) stage_cell(&st->b[lane][8], v2);
-    if (mask & 8) stage_cell(&st->b[lane][12], v3);
-    if (mask & 16) stage_cell(&st->b[lane][16], v4);
-    st->ptr[lane] = c.active ? c.base + (size_t)(row + c.ob) * 20 : nullptr;
-    lds_fence();
-    flush_rows<5, 22>(st->b, st->ptr, mask);
-    lds_fence();
+    if (!c.active) return;
+    u64* p = rowB_ptr(c, row);
+    u32 hs = c.hs;
+    if (mask & 1) st_cell(p, hs, v0);
+    if (mask & 2) st_cell(p + (size_t)2 * hs, hs, v1);
+    if (mask & 4) st_cell(p + (size_t)4 * hs, hs, v2);
+    if (mask & 8) st_cell(p + (size_t)6 * hs, hs, v3);
+    if (mask & 16) st_cell(p + (size_t)8 * hs, hs, v4);
 }
 WI_INLINE void rowR(const LC& c, u32 row, u32 mask, const Fe& acc, const Fe& tagged, const Fe& common) {
-    Stage* st = c.st;
-    u32 lane = threadIdx.x;
-    mask = 7;
-    if (mask & 1) stage_cell(&st->r[lane][0], acc);
-    if (mask & 2) stage_cell(&st->r[lane][4], tagged);
-    if (mask & 4) stage_cell(&st->r[lane][8], common);
-    st->ptr[lane] = c.active ? c.range + (size_t)(row + c.orr) * 12 : nullptr;
-    lds_fence();
-    flush_rows<3, 14>(st->r, st->ptr, mask);
-    lds_fence();
+    if (!c.active) return;
+    u64* p = rowR_ptr(c, row);
+    u32 hs = c.hs;
+    if (mask & 1) st_cell(p, hs, acc);
+    if (mask & 2) st_cell(p + (size_t)2 * hs, hs, tagged);
+    if (mask & 4) st_cell(p + (size_t)4 * hs, hs, common);
 }
 WI_INLINE void rowS(const LC& c, u32 row, u32 mask, const Fe& value, const Fe& selector) {
-    Stage* st = c.st;
-    u32 lane = threadIdx.x;
-    mask = 3;
-    if (mask & 1) stage_cell(&st->s[lane][0], value);
-    if (mask & 2) stage_cell(&st->s[lane][4], selector);
-    st->ptr[lane] = c.active ? c.select + (size_t)(row + c.os) * 8 : nullptr;
-    lds_fence();
-    flush_rows<2, 10>(st->s, st->ptr, mask);
-    lds_fence();
+    if (!c.active) return;
+    u64* p = rowS_ptr(c, row);
+    u32 hs = c.hs;
+    if (mask & 1) st_cell(p, hs, value);
+    if (mask & 2) st_cell(p + (size_t)2 * hs, hs, selector);
 }
+WI_INLINE void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 static __device__ const Fe FE0 = {{0, 0, 0, 0}};
 // base row with cols 0..k-1 and/or the last column
 #define ROW_B1(c, row, a, last) rowB(c, row, 0x11, a, FE0, FE0, FE0, last)
@@ -249,55 +208,48 @@ WI_INLINE u64 chunk18(const Limb& x, int i) {  // i-th 18-bit chunk of a <=128-b
     if (sh >= 64) lo = x.v[1] >> (sh - 64);
     return lo & 0x3ffffu;
 }
-// (a rolled loop: these are expanded at ~20 places each, and 18 unrolled pieces in flight cost registers)
-template <int PIECES>
-WI_INLINE void flush_range_group(Stage* st) {
-    lds_fence();
-    u32 lane = threadIdx.x;
-#pragma unroll 1
-    for (int i = 0; i < PIECES; i++) {
-        u32 chunk = i * 64 + lane;
-        u32 r = chunk / PIECES, piece = chunk - r * PIECES;
-        u64* p = st->ptr[r];
-        if (p != nullptr) *(ulonglong2*)(p + piece * 2) = *(const ulonglong2*)&st->r3[r][piece * 2];
-    }
-    lds_fence();
+// small values (18-bit chunks, the <= 18-bit common value): the high half of the cell is zero
+WI_INLINE void st_small(u64* p, u32 hs, u64 x) {
+    *(ulonglong2*)p = make_ulonglong2(x, 0);
+    *(ulonglong2*)(p + hs) = make_ulonglong2(0, 0);
 }
-WI_INLINE void flush_range3(Stage* st) { flush_range_group<18>(st); }
-WI_INLINE void flush_range2(Stage* st) { flush_range_group<12>(st); }
-// assign_nonleading_limb: 3 rows, 7 cells
+WI_INLINE void st_limb(u64* p, u32 hs, const Limb& x) {
+    *(ulonglong2*)p = make_ulonglong2(x.v[0], x.v[1]);
+    *(ulonglong2*)(p + hs) = make_ulonglong2(0, 0);
+}
+// assign_nonleading_limb: 3 rows, 7 cells (row 0: acc, tagged, common; rows 1, 2: tagged, common; context.rs:909-972)
 WI_INLINE void emit_limb3(const LC& c, u32 row, const Limb& x) {
-    Stage* st = c.st;
-    u32 lane = threadIdx.x;
-    u64* d = st->r3[lane];
-    stage_cell(d + 0, fe_of(x));
-    stage_cell(d + 4, fe_u64(chunk18(x, 3)));
-    stage_cell(d + 8, fe_u64(chunk18(x, 0)));
-    stage_cell(d + 12, FE0);
-    stage_cell(d + 16, fe_u64(chunk18(x, 4)));
-    stage_cell(d + 20, fe_u64(chunk18(x, 1)));
-    stage_cell(d + 24, FE0);
-    stage_cell(d + 28, fe_u64(chunk18(x, 5)));
-    stage_cell(d + 32, fe_u64(chunk18(x, 2)));
-    st->ptr[lane] = c.active ? c.range + (size_t)(row + c.orr) * 12 : nullptr;
-    flush_range3(st);
+    if (!c.active) return;
+    u32 hs = c.hs;
+    u64* p = rowR_ptr(c, row);
+    size_t cs = (size_t)2 * hs, rs = (size_t)6 * hs;
+    st_limb(p, hs, x);
+    st_small(p + cs, hs, chunk18(x, 3));
+    st_small(p + 2 * cs, hs, chunk18(x, 0));
+    st_small(p + rs + cs, hs, chunk18(x, 4));
+    st_small(p + rs + 2 * cs, hs, chunk18(x, 1));
+    st_small(p + 2 * rs + cs, hs, chunk18(x, 5));
+    st_small(p + 2 * rs + 2 * cs, hs, chunk18(x, 2));
 }
 // leading limb in a 2-line range value (36..72 bits): 2 rows, 5 cells
 WI_INLINE void emit_lead2(const LC& c, u32 row, const Limb& x) {
-    Stage* st = c.st;
-    u32 lane = threadIdx.x;
-    u64* d = st->r3[lane];
-    stage_cell(d + 0, fe_of(x));
-    stage_cell(d + 4, fe_u64(chunk18(x, 2)));
-    stage_cell(d + 8, fe_u64(chunk18(x, 0)));
-    stage_cell(d + 12, FE0);
-    stage_cell(d + 16, fe_u64(chunk18(x, 3)));
-    stage_cell(d + 20, fe_u64(chunk18(x, 1)));
-    st->ptr[lane] = c.active ? c.range + (size_t)(row + c.orr) * 12 : nullptr;
-    flush_range2(st);
+    if (!c.active) return;
+    u32 hs = c.hs;
+    u64* p = rowR_ptr(c, row);
+    size_t cs = (size_t)2 * hs, rs = (size_t)6 * hs;
+    st_limb(p, hs, x);
+    st_small(p + cs, hs, chunk18(x, 2));
+    st_small(p + 2 * cs, hs, chunk18(x, 0));
+    st_small(p + rs + cs, hs, chunk18(x, 3));
+    st_small(p + rs + 2 * cs, hs, chunk18(x, 1));
 }
 // assign_common: 1 row, 2 cells
-WI_INLINE void emit_common(const LC& c, u32 row, u64 x) { rowR(c, row, 3, fe_u64(x), fe_u64(x), FE0); }
+WI_INLINE void emit_common(const LC& c, u32 row, u64 x) {
+    if (!c.active) return;
+    u64* p = rowR_ptr(c, row);
+    st_small(p, c.hs, x);
+    st_small(p + (size_t)2 * c.hs, c.hs, x);
+}
 
 template <class FP>
 struct IntVal {  // value of an AssignedInteger
@@ -990,19 +942,16 @@ WI_INLINE H2EOp chunk_op(const TapeChunk* tc, u32 k) {
 template <class FP, bool VALUES_ONLY>
 __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDesc* inst, u32 n_instances,
                                                    const H2EFieldConsts* fc) {
-    // lanes: [sub-range][instance][strand], each sub-range padded to whole waves so a wave replays one op range
+    // lanes: [sub-range][strand][instance], each sub-range padded to whole waves so a wave replays one op range; the
+    // instance is the minor index: the lanes of a wave are consecutive instances (the minor dimension of the advice
+    // arrays), so the wave's loads and stores of a cell are contiguous
     u32 per_sub = n_instances * L.n_strands;
     u32 blocks_per_sub = (per_sub + 63) / 64;
     u32 sub = blockIdx.x / blocks_per_sub, idx = (blockIdx.x % blocks_per_sub) * 64 + threadIdx.x;  // sub is wave-uniform
-    // padding lanes of the last wave replay the last valid lane's work but store nothing: every lane must take
-    // part in the cooperative row flushes
+    // padding lanes of the last wave replay the last valid lane's work but store nothing
     bool active = idx < per_sub;
     if (!active) idx = per_sub - 1;
-    u32 instance = idx / L.n_strands, strand = idx % L.n_strands;
-    if (L.rel_refs & 2) {   // experiment (H2E_X_INSTANCE_MINOR): a wave = one strand of 64 instances, row streams 1 GB apart
-        instance = idx % n_instances;
-        strand = idx / n_instances;
-    }
+    u32 instance = idx % n_instances, strand = idx / n_instances;
     u32 op_lo = 0, op_hi = L.n_ops;
     if (!VALUES_ONLY && L.n_sub > 1) {
         op_lo = L.sub[sub];
@@ -1026,10 +975,9 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     c.input_stride = L.input_stride;
     c.hints = d.hints;
     c.hint_stride = L.hint_stride;
-    __shared__ Stage stage;
+    c.hs = 2 * n_instances;
     __shared__ TapeChunk chunk;
     __shared__ u64 xcache[3][2 * FP::L + 4][64];
-    c.st = &stage;
     c.active = active;
     c.xc = &xcache[0][0][0];
     {
@@ -1219,7 +1167,7 @@ WI_INLINE void exec_vop(const VSlots<FP>& vs, const LC& c, const VHdr& h, const 
                     src = c.sel + (size_t)(ref + c.strand * c.sel_stride) * H2E_SEL_WORDS;
                 else
                     src = cell_ptr(c, ref);
-                src += ((meta >> 4) & 0xfu) * 2;
+                src += (size_t)((meta >> 4) & 0xfu) * ((meta & 3u) == 0u ? c.hs : 2u);   // 16-byte piece: a cell's halves are hs words apart
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(vs.stage + (size_t)(h.w[1] + e) * 64), 16, 0, 0);
             }
@@ -1424,7 +1372,7 @@ __global__ void __launch_bounds__(64) h2e_replay(H2ELaunch L, const InstanceDesc
     bool active = idx < per;
     if (!active) idx = per - 1;   // padding lanes repeat the last lane's work (same values to the same cells)
     u32 rec0 = L.vpieces[2 * piece], rec1 = L.vpieces[2 * piece + 1];
-    u32 instance = idx / L.n_strands, strand = idx % L.n_strands;
+    u32 instance = idx % n_instances, strand = idx / n_instances;   // instance minor, like the advice arrays
     InstanceDesc d = inst[instance];
     LC c;
     c.base = d.base;
@@ -1445,14 +1393,13 @@ __global__ void __launch_bounds__(64) h2e_replay(H2ELaunch L, const InstanceDesc
     c.hint_stride = L.hint_stride;
     c.sel = d.sel;
     c.sel_stride = L.sel_stride;
-    __shared__ Stage stage;
+    c.hs = 2 * n_instances;
     __shared__ H2EVRec chunk[2][H2E_VCHUNK];
     extern __shared__ ulonglong2 v_dyn[];
     VSlots<FP> slots;
     slots.stage = v_dyn;
     slots.ints = (u64*)(v_dyn + (size_t)L.v_units * 64);
     slots.fes = slots.ints + (size_t)L.v_int_slots * VSlots<FP>::W * 64;
-    c.st = &stage;
     c.active = active;
     __builtin_amdgcn_s_setprio(3);   // the value chain is the critical path
     HintPrefetch<FP> hp;
@@ -1702,11 +1649,10 @@ __global__ void __launch_bounds__(64 * H2E_LEVEL_WAVES) h2e_replay_levels(H2ELau
     c.hint_stride = L.hint_stride;
     c.sel = d.sel;
     c.sel_stride = L.sel_stride;
-    __shared__ Stage stage;   // only wave 0 (H2E_V_FULL ops) uses it
+    c.hs = 2 * n_instances;
     extern __shared__ ulonglong2 l_dyn[];
     LVals<FP> lv;
     lv.v = (u64*)l_dyn;
-    c.st = &stage;
     c.active = true;
     __builtin_amdgcn_s_setprio(3);
     // rounds: every wave runs one step (64 records, one opcode) of the current level, then a barrier; the waves share
@@ -1851,27 +1797,28 @@ __global__ void __launch_bounds__(64) h2e_fixup_inverses(H2ELaunch L, const Inst
     u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     u32 total = n_instances * L.n_strands * chunks;
     if (gid >= total) return;
-    u32 chunk = gid % chunks, strand = (gid / chunks) % L.n_strands, instance = gid / (chunks * L.n_strands);
+    // instance minor: the lanes of a wave read / write the same cell of consecutive instances (contiguous)
+    u32 instance = gid % n_instances, strand = (gid / n_instances) % L.n_strands, chunk = gid / (n_instances * L.n_strands);
     u64* base = inst[instance].base;
+    u32 hs = 2 * n_instances;
     u32 ob = L.strand_base0 + strand * L.delta_base;
     Mont<4> M = mont_n(fc);
     u32 lo = chunk * FIXUP_K, hi = min(lo + FIXUP_K, L.n_fixups);
-    // The cells of one thread are 160 B apart (every load a miss): both passes fetch FB rows at a time, independent
-    // loads in flight together, before the serial multiplications over them.  (Measured: no change at 1.5 waves per
-    // SIMD - the kernel's 1.3-2.2 ms are the thread's ~570 dependent multiplications, 380 of them the inversion.)
+    // both passes fetch FB rows at a time, independent loads in flight together, before the serial multiplications
+    // over them.  (The kernel's time is the thread's ~570 dependent multiplications, 380 of them the inversion.)
     constexpr u32 FB = 8;
     Fe acc = M.r1;  // Montgomery one
     for (u32 i0 = lo; i0 < hi; i0 += FB) {
         u64* rows[FB];
         Fe xs[FB];
 #pragma unroll
-        for (u32 j = 0; j < FB; j++) rows[j] = base + (size_t)(L.fixups[min(i0 + j, hi - 1)] + ob) * 5 * 4;
+        for (u32 j = 0; j < FB; j++) rows[j] = base + (size_t)(L.fixups[min(i0 + j, hi - 1)] + ob) * 10 * hs;
 #pragma unroll
-        for (u32 j = 0; j < FB; j++) xs[j] = wd_load<4>(rows[j]);
+        for (u32 j = 0; j < FB; j++) xs[j] = ld_cell(rows[j], hs);
 #pragma unroll
         for (u32 j = 0; j < FB; j++) {
             if (i0 + j < hi) {
-                st_cell(rows[j] + 4, acc);  // prefix product of the non-zero values before i
+                st_cell(rows[j] + (size_t)2 * hs, hs, acc);  // prefix product of the non-zero values before i
                 if (!wd_is_zero<4>(xs[j])) acc = mont_mul<4>(M, acc, to_mont<4>(M, xs[j]));
             }
         }
@@ -1882,11 +1829,11 @@ __global__ void __launch_bounds__(64) h2e_fixup_inverses(H2ELaunch L, const Inst
         u64* rows[FB];
         Fe xs[FB], pre[FB];
 #pragma unroll
-        for (u32 j = 0; j < FB; j++) rows[j] = base + (size_t)(L.fixups[i1 - 1 - min(j, cnt - 1)] + ob) * 5 * 4;
+        for (u32 j = 0; j < FB; j++) rows[j] = base + (size_t)(L.fixups[i1 - 1 - min(j, cnt - 1)] + ob) * 10 * hs;
 #pragma unroll
         for (u32 j = 0; j < FB; j++) {
-            xs[j] = wd_load<4>(rows[j]);
-            pre[j] = wd_load<4>(rows[j] + 4);
+            xs[j] = ld_cell(rows[j], hs);
+            pre[j] = ld_cell(rows[j] + (size_t)2 * hs, hs);
         }
 #pragma unroll
         for (u32 j = 0; j < FB; j++) {
@@ -1896,7 +1843,7 @@ __global__ void __launch_bounds__(64) h2e_fixup_inverses(H2ELaunch L, const Inst
                     out = from_mont<4>(M, mont_mul<4>(M, ainv, pre[j]));
                     ainv = mont_mul<4>(M, ainv, to_mont<4>(M, xs[j]));
                 }
-                st_cell(rows[j] + 4, out);
+                st_cell(rows[j] + (size_t)2 * hs, hs, out);
             }
         }
         i1 -= cnt;
@@ -2047,6 +1994,7 @@ __global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* arg
     v.c.inputs = d.inputs;
     v.c.status = d.status;
     v.c.ob = v.c.orr = v.c.os = 0;
+    v.c.hs = 2 * n_instances;
     v.c.params = params_all + K.params_begin + (size_t)lane * K.n_params;
     v.c.aux = aux;
     v.c.pool = nullptr;
@@ -2175,6 +2123,7 @@ __global__ void __launch_bounds__(64) h2e_select(H2EPreKernel K, const u32* args
     c.range = d.range;
     c.select = d.select;
     c.ob = c.orr = c.os = 0;
+    c.hs = 2 * n_instances;
     c.params = params_all + K.params_begin + (size_t)w * K.n_params;
     u32 lo = g * group_size, hi = min(n_points, lo + group_size), idx = 0;
     for (u32 j = lo; j < hi; j++) idx |= (u32)(ld_limb(c, H2E_MAKE_REF(H2E_REGION_PARAM, 0, 0, j)).v[0] & 1) << (j - lo);
@@ -2318,44 +2267,65 @@ __global__ void __launch_bounds__(64) h2e_finalize_ecc(H2EPreKernel K, const Ins
 }
 
 // ------------------------------------------------------------------------------------------------
-// Row-major advice rows -> one array per column (what halo2's advice columns are; context.rs:310-541 does this cell by
-// cell on the host).  A wave takes 64 rows: the 64 x COLS x 32 bytes are contiguous on the way in, each column's
-// 64 x 32 bytes contiguous on the way out; LDS in between.  HBM bound, 2 x 32 B per cell.
-template <int COLS>
-__global__ void __launch_bounds__(64) h2e_columns(const ulonglong2* __restrict__ in, ulonglong2* __restrict__ out, u64 rows,
-                                                  u64 tiles_per_instance) {
-    __shared__ ulonglong2 tile[64][COLS * 2 + 1];
-    u64 instance = blockIdx.x / tiles_per_instance, t = blockIdx.x % tiles_per_instance;
-    u64 row0 = t * 64;
-    u32 n = (u32)min((u64)64, rows - row0), lane = threadIdx.x;
-    const ulonglong2* src = in + (instance * rows + row0) * (COLS * 2);
-#pragma unroll
-    for (int k = 0; k < COLS * 2; k++) {
-        u32 piece = k * 64 + lane;
-        if (piece < n * COLS * 2) tile[piece / (COLS * 2)][piece % (COLS * 2)] = src[piece];
+// Hand-off (device half).  The batch-interleaved advice array [row][COLS][half][instance] of a run ->
+// one array per instance in the consumer's layout: row-major [instance][row][COLS][4 words] (the reference's
+// `Vec<[(Option<N>, bool); COLS]>`, src/context.rs:243-251) or column-major [instance][COLS][row][4 words] (halo2's
+// advice columns; context.rs:310-541 builds them cell by cell on the host).  Cells the shape leaves unassigned come
+// out as zero (`flags` = the program's assigned / permute bytes; without flags the input is copied as it is), and
+// `mont` = 1 emits Montgomery-form cells (x * 2^256 mod n: the in-memory form of halo2's Fr, so the host side needs no
+// per-cell `Fr::from_repr`, src/utils.rs:10-17).  A block moves TR rows x TI instances through LDS: contiguous
+// TI x 16 bytes on the way in, TR x COLS x 32 (rows) or TR x 32 (columns) bytes on the way out.  HBM bound.
+template <int COLS, bool COLUMNS>
+__global__ void __launch_bounds__(256) h2e_export(const ulonglong2* __restrict__ in, ulonglong2* __restrict__ out,
+                                                  const uint8_t* __restrict__ flags, u64 rows, u32 n_inst, u32 mont,
+                                                  const H2EFieldConsts* fc) {
+    constexpr int TR = 8, TI = 32, PER_I = TR * COLS * 2, PITCH = PER_I + 1;
+    __shared__ ulonglong2 tile[TI * PITCH];
+    u64 row0 = (u64)blockIdx.x * TR;
+    u32 inst0 = blockIdx.y * TI;
+    u32 nr = (u32)min((u64)TR, rows - row0), ni = min((u32)TI, n_inst - inst0);
+    for (u32 p = threadIdx.x; p < (u32)PER_I * TI; p += 256) {
+        u32 i = p % TI, q = p / TI;   // q = (r * COLS + col) * 2 + half: memory order of the batch array
+        if (i < ni && q < nr * COLS * 2) tile[i * PITCH + q] = in[(row0 * COLS * 2 + q) * n_inst + inst0 + i];
     }
     __syncthreads();
-#pragma unroll
-    for (int col = 0; col < COLS; col++) {
-        ulonglong2* dst = out + ((instance * COLS + col) * rows + row0) * 2;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            u32 piece = k * 64 + lane;
-            if (piece < n * 2) dst[piece] = tile[piece / 2][col * 2 + (piece & 1)];
+    Mont<4> M = mont_n(fc);
+    for (u32 p = threadIdx.x; p < (u32)TR * COLS * TI; p += 256) {
+        u32 i = p / (TR * COLS), k = p % (TR * COLS);
+        u32 r, col;
+        if (COLUMNS) { col = k / TR; r = k % TR; } else { r = k / COLS; col = k % COLS; }
+        if (i >= ni || r >= nr) continue;
+        u32 q = (r * COLS + col) * 2;
+        ulonglong2 lo = tile[i * PITCH + q], hi = tile[i * PITCH + q + 1];
+        if (flags != nullptr && !(flags[(row0 + r) * COLS + col] & 1)) lo = hi = make_ulonglong2(0, 0);
+        if (mont) {
+            Fe x;
+            x.v[0] = lo.x; x.v[1] = lo.y; x.v[2] = hi.x; x.v[3] = hi.y;
+            x = mont_mul<4>(M, x, M.r2);
+            lo = make_ulonglong2(x.v[0], x.v[1]);
+            hi = make_ulonglong2(x.v[2], x.v[3]);
         }
+        u64 cell = COLUMNS ? ((u64)(inst0 + i) * COLS + col) * rows + row0 + r : ((u64)(inst0 + i) * rows + row0 + r) * COLS + col;
+        out[cell * 2] = lo;
+        out[cell * 2 + 1] = hi;
     }
 }
-extern "C" int h2e_engine_columns(uint32_t cols, const void* in, void* out, uint64_t rows, uint32_t n_instances, hipStream_t stream) {
+extern "C" int h2e_engine_export(uint32_t cols, int columns, int mont, const void* in, void* out, const uint8_t* flags, uint64_t rows,
+                                 uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream) {
     if (rows == 0 || n_instances == 0) return 0;
-    u64 tiles = (rows + 63) / 64;
-    if (tiles * n_instances > 0x7fffffffull) return -1;
-    dim3 grid((u32)(tiles * n_instances)), block(64);
+    u64 tiles = (rows + 7) / 8;
+    if (tiles > 0x7fffffffull) return -1;
+    dim3 grid((u32)tiles, (n_instances + 31) / 32), block(256);
+#define H2E_EXPORT(C, COLMAJ)                                                                                                  \
+    hipLaunchKernelGGL((h2e_export<C, COLMAJ>), grid, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, flags, rows, \
+                       n_instances, (u32)mont, fc_dev)
     switch (cols) {
-        case 5: hipLaunchKernelGGL(h2e_columns<5>, grid, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, rows, tiles); break;
-        case 3: hipLaunchKernelGGL(h2e_columns<3>, grid, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, rows, tiles); break;
-        case 2: hipLaunchKernelGGL(h2e_columns<2>, grid, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, rows, tiles); break;
+        case 5: if (columns) H2E_EXPORT(5, true); else H2E_EXPORT(5, false); break;
+        case 3: if (columns) H2E_EXPORT(3, true); else H2E_EXPORT(3, false); break;
+        case 2: if (columns) H2E_EXPORT(2, true); else H2E_EXPORT(2, false); break;
         default: return -1;
     }
+#undef H2E_EXPORT
     return (int)hipGetLastError();
 }
 
@@ -2367,6 +2337,16 @@ extern "C" int h2e_engine_set_consts(int field_pair, const H2EFieldConsts* host)
                                   hipMemcpyHostToDevice);
 }
 
+__global__ void h2e_or_status(const InstanceDesc* inst, u32 n_instances, u32 bits) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_instances) atomicOr(inst[i].status, bits);
+}
+extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances, uint32_t bits, hipStream_t stream) {
+    if (n_instances == 0) return 0;
+    hipLaunchKernelGGL(h2e_or_status, dim3((n_instances + 63) / 64), dim3(64), 0, stream, (const InstanceDesc*)instances, n_instances, bits);
+    return (int)hipGetLastError();
+}
+
 // mode: 1 = values-only replay (whole tape per lane), 2 = full expansion (sub-ranges if any), 4 = inverse fix-up
 extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
                                  uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream) {
@@ -2376,9 +2356,7 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
     u32 n_sub = launch->n_sub > 1 ? launch->n_sub : 1;
     dim3 block(64), grid1(blocks_per_sub), grid(blocks_per_sub * n_sub);
     const InstanceDesc* inst = (const InstanceDesc*)instances;
-    // experiment knob: cap the expansion's waves per CU by padding its LDS footprint (H2E_X_LDS_PAD bytes)
-    static const size_t x_pad = getenv("H2E_X_LDS_PAD") ? (size_t)atol(getenv("H2E_X_LDS_PAD")) : 0;
-    size_t xlds = grid.x > 4096 ? x_pad : 0;
+    size_t xlds = 0;
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
     if ((mode & 1) && launch->lrecs) {                                                                                         \
         hipLaunchKernelGGL(h2e_replay_levels<FP>, dim3(n_instances * launch->n_strands), dim3(64 * H2E_LEVEL_WAVES),          \
@@ -2387,7 +2365,7 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
     }                                                                                                                          \
     if ((mode & 1) && launch->vtape &&                                                                                         \
         ((size_t)launch->v_units * 2 + ((size_t)launch->v_int_slots * VSlots<FP>::W + VSlots<FP>::NF * 4)) * 64 * 8 +           \
-                sizeof(Stage) + 2 * H2E_VCHUNK * sizeof(H2EVRec) > 160 * 1024)                                                  \
+                2 * H2E_VCHUNK * sizeof(H2EVRec) > 160 * 1024)                                                  \
         return -3;   /* the host compiler's LDS budget and the kernel's static LDS disagree */                                 \
     if ((mode & 1) && launch->vtape)                                                                                           \
         hipLaunchKernelGGL(h2e_replay<FP>, dim3(blocks_per_sub * launch->n_vpieces), block,                                    \
@@ -2402,7 +2380,10 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
         default: return -1;
     }
 #undef H2E_LAUNCH_FP
-    if ((int)hipGetLastError() != 0) return (int)hipGetLastError();
+    {
+        hipError_t le = hipGetLastError();   // (reading it resets it: read once)
+        if (le != hipSuccess) return (int)le;
+    }
     if ((mode & 4) && launch->n_fixups) {
         u32 chunks = (launch->n_fixups + FIXUP_K - 1) / FIXUP_K;
         u32 lanes = n_instances * launch->n_strands * chunks;

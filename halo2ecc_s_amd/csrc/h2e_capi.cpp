@@ -11,7 +11,9 @@
 #include "recorder_pairing.hpp"
 
 extern "C" int h2e_engine_set_consts(int field_pair, const H2EFieldConsts* host);
-extern "C" int h2e_engine_columns(uint32_t cols, const void* in, void* out, uint64_t rows, uint32_t n_instances, hipStream_t stream);
+extern "C" int h2e_engine_export(uint32_t cols, int columns, int mont, const void* in, void* out, const uint8_t* flags, uint64_t rows,
+                                 uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream);
+extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances, uint32_t bits, hipStream_t stream);
 extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
                                  uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream);
 extern "C" int h2e_engine_predict(int field_pair, int phase, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,
@@ -30,6 +32,14 @@ int fail(int code, const std::string& msg) {
         hipError_t _e = (expr);                                                               \
         if (_e != hipSuccess) return fail(H2E_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
+
+// Debugging aids of the program compiler (tape dumps, switching compiler passes off).  Compiled out of the shipped
+// library: build with -DH2E_DEBUG_HOOKS to get them back; the default build never reads the environment here.
+#ifdef H2E_DEBUG_HOOKS
+inline const char* dbg_env(const char* name) { return getenv(name); }
+#else
+inline const char* dbg_env(const char*) { return nullptr; }
+#endif
 
 const h2e::FieldPair& field_pair(int id) {
     static std::mutex mu;
@@ -84,9 +94,7 @@ struct h2e_program {
     std::vector<uint32_t> seg_l_begin, seg_l_steps, seg_l_slots;
     H2EVRec* d_lrecs = nullptr;
     uint32_t* d_lrefs = nullptr;
-    InstanceDescHost* d_inst = nullptr;
-    uint32_t inst_cap = 0;
-    std::vector<InstanceDescHost> h_inst;
+    uint8_t* d_flags[3] = {nullptr, nullptr, nullptr};   // assigned / permute bytes on the device (h2e_export masks with them)
 
     ~h2e_program() {
         if (device >= 0) {
@@ -101,7 +109,7 @@ struct h2e_program {
             (void)hipFree(d_vpieces);
             (void)hipFree(d_lrecs);
             (void)hipFree(d_lrefs);
-            (void)hipFree(d_inst);
+            for (int i = 0; i < 3; i++) (void)hipFree(d_flags[i]);
         }
     }
     // Liveness over sub-ranges: an arithmetic op whose result cells are only read by ops of its own sub-range gets
@@ -547,7 +555,7 @@ struct h2e_program {
         // are steps of their own behind a fence.
         {
             size_t si = (size_t)(sg - r.segments.data());
-            bool eligible = !getenv("H2E_NO_LEVELS") && sg->n_strands == 1 && alive.size() >= 4096;
+            bool eligible = !dbg_env("H2E_NO_LEVELS") && sg->n_strands == 1 && alive.size() >= 4096;
             std::vector<uint32_t> level(alive.size(), 0);
             uint32_t depth = 0;
             for (uint32_t pos = 0; pos < alive.size() && eligible; pos++) {
@@ -691,7 +699,7 @@ struct h2e_program {
                         }
                     if (n_slots > slot_cap) eligible = false;
                 }
-                if (!eligible && getenv("H2E_DUMP_TAPE"))
+                if (!eligible && dbg_env("H2E_DUMP_TAPE"))
                     fprintf(stderr, "segment %zu: level-parallel replay needs more than %d value slots (depth %u, %zu rounds)\n", si, slot_cap, depth, n_rounds);
                 if (eligible) {
                     seg_l_begin[si] = (uint32_t)h_lrecs.size();
@@ -712,7 +720,6 @@ struct h2e_program {
                                 bool store = !(op.flags & H2E_FLAG_LOCAL_RESULT) || vals[2 * (size_t)i].force_store;
                                 if (op.opcode == H2E_OP_AND || op.opcode == H2E_OP_OR || op.opcode == H2E_OP_XNOR || op.opcode == H2E_OP_BISEC_INT)
                                     store = true;
-                                if (getenv("H2E_DEBUG_LEVELS_NOSTORE")) store = false;   // timing experiment only: results are wrong
                                 if (store) vflags |= H2E_VFLAG_STORE;
                                 if (vop == H2E_V_HINT && (op.flags & H2E_FLAG_HINT_STRIDED)) vflags |= H2E_VFLAG_HINT_STRIDED;
                                 int dsl = lslot[2 * (size_t)i];
@@ -743,7 +750,7 @@ struct h2e_program {
                             h_lrecs.push_back(h);
                         }
                     }
-                    if (getenv("H2E_DUMP_TAPE"))
+                    if (dbg_env("H2E_DUMP_TAPE"))
                         fprintf(stderr, "segment %zu: level-parallel replay: %zu alive ops, depth %u, %zu rounds of %zu waves, %d value slots\n", si,
                                 alive.size(), depth, n_rounds, NW, n_slots);
                 }
@@ -772,8 +779,8 @@ struct h2e_program {
             std::map<int, int> slot_of;                // value -> slot during the prologue
         };
         const uint32_t PIECE_TARGET = 96, PIECE_BUDGET = 40;
-        static const bool pieces_on = !getenv("H2E_NO_PIECES");
-        static const bool stage_on = !getenv("H2E_NO_STAGE");
+        static const bool pieces_on = !dbg_env("H2E_NO_PIECES");
+        static const bool stage_on = !dbg_env("H2E_NO_STAGE");
         // positions that can never be cut: an op at or after p reads a *cell* written before p (rows of a V_FULL op, or
         // a value that lost / never had its slot) - difference arrays over (writer, last reader]
         std::vector<int32_t> blocked(alive.size() + 2, 0);
@@ -1097,7 +1104,7 @@ struct h2e_program {
         seg_v_slots[si] = used_slots;
         seg_v_units[si] = std::max(1u, max_units);
         h_vtape.insert(h_vtape.end(), out.begin(), out.end());
-        if (getenv("H2E_DUMP_TAPE"))
+        if (dbg_env("H2E_DUMP_TAPE"))
             fprintf(stderr, "segment %zu: replay %zu alive ops, %zu records, %u pieces, %u int slots, %u staging units\n", si, alive.size(),
                     out.size(), seg_n_pieces[si], seg_v_slots[si], seg_v_units[si]);
     }
@@ -1125,14 +1132,14 @@ struct h2e_program {
                 for (uint32_t i = r.segments[sj].tape_begin; i < r.segments[sj].tape_end && !referenced; i++)
                     for (int k = 0; k < H2E_OP_MAX_REFS; k++) referenced = referenced || hits(r.tape[i].refs[k]);
             }
-            bool dbg = getenv("H2E_DUMP_TAPE") != nullptr;
+            bool dbg = dbg_env("H2E_DUMP_TAPE") != nullptr;
             if (dbg && referenced) fprintf(stderr, "segment %zu referenced by ops\n", si);
             for (uint32_t ref : r.aux) if (hits(ref)) { if (dbg && !referenced) fprintf(stderr, "segment %zu referenced by aux %08x\n", si, ref); referenced = true; }
             for (uint32_t ref : r.params) if (hits(ref)) { if (dbg && !referenced) fprintf(stderr, "segment %zu referenced by params %08x\n", si, ref); referenced = true; }
             for (uint32_t ref : r.outputs) referenced = referenced || hits(ref);
             for (uint32_t ref : r.pre_args) if (hits(ref)) { if (dbg && !referenced) fprintf(stderr, "segment %zu referenced by pre_args %08x\n", si, ref); referenced = true; }
             seg_deferrable[si] = referenced ? 0 : 1;
-            if (getenv("H2E_DUMP_TAPE")) fprintf(stderr, "segment %zu deferrable %d\n", si, (int)seg_deferrable[si]);
+            if (dbg_env("H2E_DUMP_TAPE")) fprintf(stderr, "segment %zu deferrable %d\n", si, (int)seg_deferrable[si]);
         }
     }
 
@@ -1218,7 +1225,7 @@ struct h2e_program {
             if (first_reader <= si + 1) continue;   // nothing to overlap with
             seg_side_dep[si] = last_dep;
             seg_first_reader[si] = first_reader;
-            if (getenv("H2E_DUMP_TAPE")) fprintf(stderr, "segment %zu: side stream after segment %d, first reader %u\n", si, last_dep, first_reader);
+            if (dbg_env("H2E_DUMP_TAPE")) fprintf(stderr, "segment %zu: side stream after segment %d, first reader %u\n", si, last_dep, first_reader);
         }
     }
 
@@ -1337,9 +1344,9 @@ struct h2e_program {
             for (const H2EOp& op : r.tape)
                 if ((op.flags & H2E_FLAG_HINTED) && op.imm >= lo && op.imm < lo + per) mask |= 1u << ((op.imm - lo) % H2E_ECC_HINT_SLOTS);
             pk.k.used_slots = mask;
-            if (getenv("H2E_DUMP_TAPE")) fprintf(stderr, "predictor kind %u: value-hint slots in use: 0x%02x\n", pk.k.kind, mask);
+            if (dbg_env("H2E_DUMP_TAPE")) fprintf(stderr, "predictor kind %u: value-hint slots in use: 0x%02x\n", pk.k.kind, mask);
         }
-        if (getenv("H2E_DUMP_TAPE")) {   // debugging aid: per segment, ops by opcode (alive / skipped by the values replay)
+        if (dbg_env("H2E_DUMP_TAPE")) {   // debugging aid: per segment, ops by opcode (alive / skipped by the values replay)
             for (size_t si = 0; si < r.segments.size(); si++) {
                 auto& sg = r.segments[si];
                 std::map<int, std::array<uint32_t, 4>> h;
@@ -1379,41 +1386,68 @@ struct h2e_program {
     }
 };
 
+// Everything one run owns while it is in flight: engine workspace, instance table, events.  A context keeps a small
+// ring of these, so that h2e_submit can queue the value chain of run k + 1 (caller's stream) while run k's expansion is
+// still streaming on the expansion stream; h2e_run uses the same slots and joins before it returns.
+struct JobSlot {
+    // engine workspace (grow-only): quotient hints, numerator/denominator pairs, Jacobian scratch, selected points
+    uint64_t *ws_hints = nullptr, *ws_nd = nullptr, *ws_jac = nullptr, *ws_sel = nullptr;
+    size_t ws_hints_words = 0, ws_nd_words = 0, ws_jac_words = 0, ws_sel_words = 0;
+    InstanceDescHost* d_inst = nullptr;
+    uint32_t inst_cap = 0;
+    std::vector<InstanceDescHost> h_inst;
+    std::vector<hipEvent_t> ev;       // profiling: 4 per launched segment (value-chain begin/end, expansion begin/end)
+    std::vector<hipEvent_t> sync_ev;  // cross-stream dependencies
+    hipEvent_t done = nullptr;        // recorded when every stream of the slot's last run has finished
+    bool used = false;
+    bool profiled = false;            // the last run on this slot recorded `ev`
+    uint32_t n_launches = 0;
+    std::vector<uint32_t> x_kernels;  // per launched segment: expansion kernel launches of the last run (2 = split)
+    void release() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+        for (auto e : sync_ev) (void)hipEventDestroy(e);
+        if (done) (void)hipEventDestroy(done);
+        (void)hipFree(ws_hints);
+        (void)hipFree(ws_nd);
+        (void)hipFree(ws_jac);
+        (void)hipFree(ws_sel);
+        (void)hipFree(d_inst);
+    }
+};
+
 struct h2e_ctx {
     int device;
     H2EFieldConsts* d_fc[3] = {nullptr, nullptr, nullptr};
     std::map<std::string, h2e_program*> cache;
     bool profiling = false;
-    // engine workspace (grow-only): quotient hints, numerator/denominator pairs, Jacobian scratch
-    uint64_t *ws_hints = nullptr, *ws_nd = nullptr, *ws_jac = nullptr, *ws_sel = nullptr;
-    size_t ws_hints_words = 0, ws_nd_words = 0, ws_jac_words = 0, ws_sel_words = 0;
-    std::vector<hipEvent_t> ev;       // profiling: 4 per launched segment (value-chain begin/end, expansion begin/end)
-    std::vector<hipEvent_t> sync_ev;  // cross-stream dependencies
+    static constexpr int N_SLOTS = 2;
+    JobSlot slots[N_SLOTS];
+    uint64_t n_runs = 0;     // runs submitted so far: run k uses slot k % N_SLOTS
+    int last_slot = -1;
     hipStream_t expand_stream = nullptr;
     hipStream_t early_stream = nullptr;
     hipStream_t fixup_stream = nullptr;
-    uint32_t n_launches = 0;
-    std::vector<uint32_t> x_kernels;   // per launched segment: expansion kernel launches of the last run (2 = split)
+    // tuning knobs, read once at h2e_ctx_create (H2E_X_SPLIT, H2E_X_SPLIT_MIN_LANES); h2e_ctx_set_option overrides
+    uint32_t x_split_pct = 45;
+    uint64_t x_split_min_lanes = 1ull << 21;
+    int64_t test_skip_expansion = INT64_MIN;   // test hook (h2e_ctx_set_option): see H2E_OPT_TEST_SKIP_EXPANSION
+    uint32_t last_split_segments = 0;          // segments of the last run whose expansion was split (h2e_ctx_get_stat)
+    std::mutex mu;                             // h2e_run / h2e_submit on one context are serialised on the host
     ~h2e_ctx() {
         for (auto& kv : cache) delete kv.second;
         for (int i = 0; i < 3; i++)
             if (d_fc[i]) (void)hipFree(d_fc[i]);
-        for (auto e : ev) (void)hipEventDestroy(e);
-        for (auto e : sync_ev) (void)hipEventDestroy(e);
+        for (auto& sl : slots) sl.release();
         if (expand_stream) (void)hipStreamDestroy(expand_stream);
         if (early_stream) (void)hipStreamDestroy(early_stream);
         if (fixup_stream) (void)hipStreamDestroy(fixup_stream);
-        (void)hipFree(ws_hints);
-        (void)hipFree(ws_nd);
-        (void)hipFree(ws_jac);
-        (void)hipFree(ws_sel);
     }
 };
 
 extern "C" {
 
 const char* h2e_last_error(void) { return g_last_error.c_str(); }
-const char* h2e_version(void) { return "h2e 0.1 (gfx950)"; }
+const char* h2e_version(void) { return "h2e 0.2 (gfx950, batch-interleaved advice)"; }
 
 int h2e_ctx_create(int device, h2e_ctx** out) {
     if (!out) return fail(H2E_ERR_INVALID, "out is null");
@@ -1423,6 +1457,9 @@ int h2e_ctx_create(int device, h2e_ctx** out) {
     if (device < 0 || device >= count) return fail(H2E_ERR_INVALID, "bad device index");
     h2e_ctx* c = new h2e_ctx();
     c->device = device;
+    // tuning knobs are read once, here (nothing reads the environment while a run is being queued)
+    if (const char* e1 = getenv("H2E_X_SPLIT")) c->x_split_pct = (uint32_t)std::max(0, std::min(100, atoi(e1)));
+    if (const char* e2 = getenv("H2E_X_SPLIT_MIN_LANES")) c->x_split_min_lanes = (uint64_t)atoll(e2);
     *out = c;
     return 0;
 }
@@ -1656,11 +1693,14 @@ static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
     return 0;
 }
 
-int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
-            void* d_select, void* d_status, void* stream_) {
+// One run.  `join` = true: the caller's stream completes when every stream of the run has (h2e_run); false: the
+// caller's stream only carries the value chain and `slot.done` is recorded on the fix-up stream when the run is
+// complete (h2e_submit / h2e_wait).
+static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
+                    void* d_select, void* d_status, hipStream_t stream, bool join, int* slot_out) {
     if (!ctx || !p) return fail(H2E_ERR_INVALID, "null ctx/program");
-    if (n_instances == 0) return 0;
-    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_inputs || !d_base || !d_range || !d_select || !d_status) return fail(H2E_ERR_INVALID, "null device pointer");
+    std::lock_guard<std::mutex> guard(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_device_program(ctx, p);
     if (rc) return rc;
@@ -1671,19 +1711,42 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         HIP_TRY((hipError_t)h2e_engine_set_consts(fp, &field_pair(fp).fc));
     }
     h2e::Recorder& r = *p->rec;
+    if (!ctx->expand_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->expand_stream, hipStreamNonBlocking));
+    if (!ctx->early_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->early_stream, hipStreamNonBlocking));
+    if (!ctx->fixup_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->fixup_stream, hipStreamNonBlocking));
+    // Streams.  The *value chain* (predictor kernels + values-only replay, or the plain tape for segments without cuts)
+    // runs on the caller's stream: it is what later segments depend on.  The full expansion of a cut segment only needs
+    // the value chain up to that segment, so it runs on a second stream and overlaps the value chain of the following
+    // segments (and, with h2e_submit, of the following run); predictors that only depend on earlier predictors and fork
+    // segments outside the chain on a third; inverse fix-ups on a fourth.  (The runtime maps streams onto 4 hardware
+    // queues by default: a fifth stream would share one and serialise behind it.)
+    hipStream_t sa = stream, sb = ctx->expand_stream, sc = ctx->early_stream, sd = ctx->fixup_stream;
+    int slot_index = (int)(ctx->n_runs % h2e_ctx::N_SLOTS);
+    JobSlot& J = ctx->slots[slot_index];
+    ctx->n_runs++;
+    ctx->last_slot = slot_index;
+    if (slot_out) *slot_out = slot_index;
+    if (!J.done) HIP_TRY(hipEventCreateWithFlags(&J.done, hipEventDisableTiming));
+    // the slot's previous run (two submissions ago) must be complete before its workspace is overwritten
+    if (J.used) HIP_TRY(hipStreamWaitEvent(sa, J.done, 0));
+    J.used = true;
     // instance descriptors
-    if (p->inst_cap < n_instances) {
-        if (p->d_inst) HIP_TRY(hipFree(p->d_inst));
-        HIP_TRY(hipMalloc((void**)&p->d_inst, (size_t)n_instances * sizeof(InstanceDescHost)));
-        p->inst_cap = n_instances;
+    if (J.inst_cap < n_instances) {
+        if (J.d_inst) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(J.d_inst));
+            J.d_inst = nullptr;
+        }
+        HIP_TRY(hipMalloc((void**)&J.d_inst, (size_t)n_instances * sizeof(InstanceDescHost)));
+        J.inst_cap = n_instances;
     }
-    p->h_inst.resize(n_instances);
+    J.h_inst.resize(n_instances);
     size_t slot_words = r.fp.w_words;
     // workspace
     auto grow = [&](uint64_t** buf, size_t* have, size_t need) -> hipError_t {
         if (need <= *have) return hipSuccess;
         if (*buf) {
-            hipError_t e = hipStreamSynchronize(stream);
+            hipError_t e = hipDeviceSynchronize();
             if (e != hipSuccess) return e;
             (void)hipFree(*buf);
             *buf = nullptr;
@@ -1696,86 +1759,54 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
            nd_words = hint_words * 2,
            jac_words = (size_t)r.n_jac_slots * 3 * H2E_W_WORDS_MAX,
            sel_words = (size_t)r.n_sel_slots * H2E_SEL_WORDS;
-    HIP_TRY(grow(&ctx->ws_hints, &ctx->ws_hints_words, std::max<size_t>(1, hint_words * n_instances)));
-    HIP_TRY(grow(&ctx->ws_nd, &ctx->ws_nd_words, std::max<size_t>(1, nd_words * n_instances)));
-    HIP_TRY(grow(&ctx->ws_jac, &ctx->ws_jac_words, std::max<size_t>(1, jac_words * n_instances)));
-    HIP_TRY(grow(&ctx->ws_sel, &ctx->ws_sel_words, std::max<size_t>(1, sel_words * n_instances)));
+    HIP_TRY(grow(&J.ws_hints, &J.ws_hints_words, std::max<size_t>(1, hint_words * n_instances)));
+    HIP_TRY(grow(&J.ws_nd, &J.ws_nd_words, std::max<size_t>(1, nd_words * n_instances)));
+    HIP_TRY(grow(&J.ws_jac, &J.ws_jac_words, std::max<size_t>(1, jac_words * n_instances)));
+    HIP_TRY(grow(&J.ws_sel, &J.ws_sel_words, std::max<size_t>(1, sel_words * n_instances)));
     for (uint32_t i = 0; i < n_instances; i++) {
-        InstanceDescHost& d = p->h_inst[i];
-        d.base = (uint64_t*)d_base + (size_t)i * p->base_rows * 5 * 4;
-        d.range = (uint64_t*)d_range + (size_t)i * p->range_rows * 3 * 4;
-        d.select = (uint64_t*)d_select + (size_t)i * p->select_rows * 2 * 4;
+        InstanceDescHost& d = J.h_inst[i];
+        // batch-interleaved advice arrays [row][col][half][instance][2 words]: instance i starts 2 words in
+        d.base = (uint64_t*)d_base + (size_t)i * 2;
+        d.range = (uint64_t*)d_range + (size_t)i * 2;
+        d.select = (uint64_t*)d_select + (size_t)i * 2;
         d.inputs = (const uint64_t*)d_inputs + (size_t)i * r.n_input_slots * slot_words;
         d.status = (uint32_t*)d_status + i;
-        d.hints = ctx->ws_hints + (size_t)i * hint_words;
-        d.nd = ctx->ws_nd + (size_t)i * nd_words;
-        d.jac = ctx->ws_jac + (size_t)i * jac_words;
-        d.sel = ctx->ws_sel + (size_t)i * sel_words;
+        d.hints = J.ws_hints + (size_t)i * hint_words;
+        d.nd = J.ws_nd + (size_t)i * nd_words;
+        d.jac = J.ws_jac + (size_t)i * jac_words;
+        d.sel = J.ws_sel + (size_t)i * sel_words;
     }
-    HIP_TRY(hipMemcpyAsync(p->d_inst, p->h_inst.data(), (size_t)n_instances * sizeof(InstanceDescHost),
+    HIP_TRY(hipMemcpyAsync(J.d_inst, J.h_inst.data(), (size_t)n_instances * sizeof(InstanceDescHost),
                            hipMemcpyHostToDevice, stream));
-    // Two streams.  The *value chain* (predictor kernels + values-only replay, or the plain tape for segments
-    // without cuts) runs on the caller's stream: it is what later segments depend on.  The full expansion of a
-    // cut segment only needs the value chain up to that segment, so it runs on a second stream and overlaps the
-    // value chain of the following segments (e.g. the MSM windows' expansion hides the serial tail's replay).
-    if (!ctx->expand_stream) {
-        // Keep a few CUs out of the expansion stream's mask so the (latency-bound, few-wave) value chain on the
-        // caller's stream always finds an idle CU instead of queueing behind millions of expansion lanes.
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
-        int cus = prop.multiProcessorCount;
-        const char* env = getenv("H2E_RESERVED_CUS");
-        int reserved = env ? atoi(env) : 0;  // measured: a CU-masked stream serialises against the other stream on this stack
-        std::vector<uint32_t> mask((cus + 31) / 32, 0);
-        for (int i = 0; i < cus; i++) {
-            // CU ids are dealt round-robin over the 8 XCDs; reserve the last `reserved` ids (2 per XCD for 16)
-            if (i < cus - reserved) mask[i / 32] |= 1u << (i % 32);
-        }
-        hipError_t me = reserved > 0 ? hipExtStreamCreateWithCUMask(&ctx->expand_stream, (uint32_t)mask.size(), mask.data())
-                                     : hipErrorNotSupported;
-        if (me != hipSuccess) {
-            (void)hipGetLastError();
-            // experiment knob H2E_STREAM_PRIORITIES="x,e,f": HIP stream priorities of the expansion / early / fix-up streams
-            int px = 0, pe = 0, pf = 0;
-            if (const char* pr = getenv("H2E_STREAM_PRIORITIES")) sscanf(pr, "%d,%d,%d", &px, &pe, &pf);
-            HIP_TRY(hipStreamCreateWithPriority(&ctx->expand_stream, hipStreamNonBlocking, px));
-            if (!ctx->early_stream) HIP_TRY(hipStreamCreateWithPriority(&ctx->early_stream, hipStreamNonBlocking, pe));
-            if (!ctx->fixup_stream) HIP_TRY(hipStreamCreateWithPriority(&ctx->fixup_stream, hipStreamNonBlocking, pf));
-        }
-    }
-    if (!ctx->early_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->early_stream, hipStreamNonBlocking));
-    if (!ctx->fixup_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->fixup_stream, hipStreamNonBlocking));
-    hipStream_t sa = stream, sb = ctx->expand_stream, sc = ctx->early_stream, sd = ctx->fixup_stream;
-    if (getenv("H2E_DEBUG_ONE_STREAM")) sb = sc = sd = sa;   // debugging aid: everything in program order
-    if (getenv("H2E_DEBUG_NO_FIXUP_STREAM")) sd = sb;
     bool used_sd = false;
     std::vector<hipEvent_t> early_done(r.pre_kernels.size(), nullptr);
     size_t n_sync = 0;
     auto sync_event = [&]() -> hipEvent_t {
-        if (n_sync == ctx->sync_ev.size()) {
+        if (n_sync == J.sync_ev.size()) {
             hipEvent_t e = nullptr;
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-            ctx->sync_ev.push_back(e);
+            J.sync_ev.push_back(e);
         }
-        return ctx->sync_ev[n_sync++];
+        return J.sync_ev[n_sync++];
     };
     auto prof_event = [&](uint32_t k) -> hipEvent_t {
-        while (ctx->ev.size() <= k) {
+        while (J.ev.size() <= k) {
             hipEvent_t e = nullptr;
             if (hipEventCreate(&e) != hipSuccess) return nullptr;
-            ctx->ev.push_back(e);
+            J.ev.push_back(e);
         }
-        return ctx->ev[k];
+        return J.ev[k];
     };
-    {   // the expansion stream starts after everything already queued on the caller's stream
+    const bool profiling = ctx->profiling;
+    J.profiled = profiling;
+    {   // the engine's streams start after everything already queued on the caller's stream
         hipEvent_t e = sync_event();
         HIP_TRY(hipEventRecord(e, sa));
         HIP_TRY(hipStreamWaitEvent(sb, e, 0));
     }
-    ctx->n_launches = 0;
-    ctx->x_kernels.clear();
-    // (the runtime maps streams onto 4 hardware queues by default: a fifth stream would share one and serialise behind
-    // it, so the side segments use the early-predictor stream)
+    J.n_launches = 0;
+    J.x_kernels.clear();
+    ctx->last_split_segments = 0;
     hipStream_t se = sc;
     std::vector<hipEvent_t> seg_ev(r.segments.size(), nullptr), side_done(r.segments.size(), nullptr);
     hipEvent_t run_begin = sync_event();
@@ -1792,16 +1823,16 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         hipEvent_t e0 = sync_event();
         HIP_TRY(hipEventRecord(e0, sa));
         HIP_TRY(hipStreamWaitEvent(sb, e0, 0));
-        if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 2), sb));
-        int prc2 = h2e_engine_launch(fp, 2, &pending_L, p->d_inst, n_instances, ctx->d_fc[fp], sb);
+        if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 2), sb));
+        int prc2 = h2e_engine_launch(fp, 2, &pending_L, J.d_inst, n_instances, ctx->d_fc[fp], sb);
         if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
-        if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 3), sb));
+        if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 3), sb));
         if (pending_L.n_fixups) {
             hipEvent_t e1 = sync_event();
             HIP_TRY(hipEventRecord(e1, sb));
             HIP_TRY(hipStreamWaitEvent(sd, e1, 0));
             used_sd = true;
-            prc2 = h2e_engine_launch(fp, 4, &pending_L, p->d_inst, n_instances, ctx->d_fc[fp], sd);
+            prc2 = h2e_engine_launch(fp, 4, &pending_L, J.d_inst, n_instances, ctx->d_fc[fp], sd);
             if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
         }
         have_pending = false;
@@ -1816,9 +1847,9 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
                 HIP_TRY(hipStreamWaitEvent(sa, side_done[sj], 0));
                 side_done[sj] = nullptr;
             }
-        uint32_t li = ctx->n_launches;
-        if (ctx->x_kernels.size() <= li) ctx->x_kernels.resize(li + 1, 1);
-        if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 0), sa));
+        uint32_t li = J.n_launches;
+        if (J.x_kernels.size() <= li) J.x_kernels.resize(li + 1, 1);
+        if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 0), sa));
         // this segment's predictors: chains first, then (after the early starters below) their finalize kernels
         for (size_t pi = 0; pi < r.pre_kernels.size(); pi++) {
             const h2e::PreKernel& pk = r.pre_kernels[pi];
@@ -1827,7 +1858,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
                 HIP_TRY(hipStreamWaitEvent(sa, early_done[pi], 0));
                 continue;
             }
-            int prc = h2e_engine_predict(fp, 1, &pk.k, p->d_pre_args, p->d_params, p->d_aux, p->d_inst, n_instances, ctx->d_fc[fp], sa);
+            int prc = h2e_engine_predict(fp, 1, &pk.k, p->d_pre_args, p->d_params, p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sa);
             if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
         }
         if (have_pending && hold_longer && s.sel_stride) {
@@ -1837,20 +1868,21 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         // predictors of later segments that only depend on this segment's predictor chains start now, on the side stream
         for (size_t pi = 0; pi < r.pre_kernels.size(); pi++) {
             const h2e::PreKernel& pk = r.pre_kernels[pi];
-            if (pk.early_after_segment != (int32_t)si || pk.before_segment <= si || getenv("H2E_DEBUG_NO_EARLY")) continue;
+            if (pk.early_after_segment != (int32_t)si || pk.before_segment <= si) continue;
             hipEvent_t e0 = sync_event();
             HIP_TRY(hipEventRecord(e0, sa));
             HIP_TRY(hipStreamWaitEvent(sc, e0, 0));
-            int prc = h2e_engine_predict(fp, 3, &pk.k, p->d_pre_args, p->d_params, p->d_aux, p->d_inst, n_instances, ctx->d_fc[fp], sc);
+            int prc = h2e_engine_predict(fp, 3, &pk.k, p->d_pre_args, p->d_params, p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sc);
             if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
             hipEvent_t e1 = sync_event();
             HIP_TRY(hipEventRecord(e1, sc));
             early_done[pi] = e1;
+            used_se = true;
         }
         for (size_t pi = 0; pi < r.pre_kernels.size(); pi++) {
             const h2e::PreKernel& pk = r.pre_kernels[pi];
             if (pk.before_segment != si || early_done[pi]) continue;
-            int prc = h2e_engine_predict(fp, 2, &pk.k, p->d_pre_args, p->d_params, p->d_aux, p->d_inst, n_instances, ctx->d_fc[fp], sa);
+            int prc = h2e_engine_predict(fp, 2, &pk.k, p->d_pre_args, p->d_params, p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sa);
             if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
         }
         H2ELaunch L;
@@ -1871,7 +1903,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         L.hint_stride = s.hint_stride;
         L.n_fixups = s.n_fixups;
         L.fixups = p->d_fixups + s.fixups_begin;
-        L.rel_refs = (s.is_fork ? 1 : 0) | (getenv("H2E_X_INSTANCE_MINOR") ? 2 : 0);
+        L.rel_refs = s.is_fork ? 1 : 0;
         L.n_sub = p->seg_n_sub[si];
         L.sub = L.n_sub > 1 ? p->d_subs + p->seg_sub_begin[si] : nullptr;
         bool compiled = si < p->seg_n_pieces.size() && p->seg_n_pieces[si] > 0;
@@ -1888,34 +1920,29 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         L.l_slots = levels ? p->seg_l_slots[si] : 0;
         int lrc;
         auto launch_one = [&](int mode, const H2ELaunch& l, hipStream_t st) -> int {
-            int rc2 = h2e_engine_launch(fp, mode, &l, p->d_inst, n_instances, ctx->d_fc[fp], st);
+            int rc2 = h2e_engine_launch(fp, mode, &l, J.d_inst, n_instances, ctx->d_fc[fp], st);
             if (rc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc2));
             return 0;
         };
         auto launch = [&](int mode, hipStream_t st) -> int { return launch_one(mode, L, st); };
-        // A big expansion (the MSM windows: 52 k workgroups that hold every CU's LDS for 22 ms) goes out as two
-        // back-to-back launches over the first H2E_X_SPLIT percent / the rest of its sub-ranges: while the first one
-        // drains, the value chain that became ready meanwhile (the MSM tail's replay wants most of a CU's LDS per
-        // workgroup) gets its CUs instead of waiting for the whole expansion (13 ms -> 1.9 ms), and the inverse
-        // fix-up of the first part runs under the second.
+        // A big expansion (the MSM windows) goes out as two back-to-back launches over the first x_split_pct percent / the
+        // rest of its sub-ranges: while the first one drains, the value chain that became ready meanwhile (the MSM tail's
+        // replay wants most of a CU's LDS per workgroup) gets its CUs instead of waiting for the whole expansion, and the
+        // inverse fix-up of the first part runs under the second.
         uint32_t split_sub = 0, split_fix = 0;
         {
-            const char* e1 = getenv("H2E_X_SPLIT");
-            const char* e2 = getenv("H2E_X_SPLIT_MIN_LANES");
-            uint32_t pct = e1 ? (uint32_t)atoi(e1) : 45;
-            uint64_t min_lanes = e2 ? (uint64_t)atoll(e2) : (1ull << 21);
-            if (pct > 0 && pct < 100 && L.n_sub >= 4 && (uint64_t)L.n_sub * L.n_strands * n_instances >= min_lanes) {
+            uint32_t pct = ctx->x_split_pct;
+            if (pct > 0 && pct < 100 && L.n_sub >= 4 && (uint64_t)L.n_sub * L.n_strands * n_instances >= ctx->x_split_min_lanes) {
                 split_sub = std::min<uint32_t>(std::max<uint32_t>(2, (uint32_t)((uint64_t)L.n_sub * pct / 100)), L.n_sub - 2);
                 uint32_t row = r.tape[s.tape_begin + p->h_subs[p->seg_sub_begin[si] + split_sub]].base_row;
                 auto fb = r.fixups.begin() + s.fixups_begin;
                 // fix-up rows are recorded in tape order: those below the first row of the second part belong to the first
                 split_fix = std::is_sorted(fb, fb + s.n_fixups) ? (uint32_t)(std::lower_bound(fb, fb + s.n_fixups, row) - fb) : 0;
-                if (getenv("H2E_DEBUG_X_SPLIT_REPORT"))
-                    fprintf(stderr, "x-split segment %zu: %u of %u sub-ranges, %u of %u fix-ups\n", si, split_sub, L.n_sub, split_fix, s.n_fixups);
+                ctx->last_split_segments++;
             }
         }
         // the inverse fix-up of a segment only touches cells nothing else reads or writes: own stream, after the expansion
-        // (a small expansion sent to the side stream keeps its fix-up there)
+        // (a small expansion keeps its fix-up in its own stream)
         bool fixup_in_stream = false;
         auto fixup_part = [&](hipStream_t st, uint32_t lo, uint32_t hi) -> int {
             if (hi <= lo) return 0;
@@ -1938,7 +1965,7 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
                 return 0;
             }
             H2ELaunch a = L, b = L;
-            ctx->x_kernels[li] = 2;
+            J.x_kernels[li] = 2;
             a.n_sub = split_sub;
             b.n_sub = L.n_sub - split_sub;
             b.sub = L.sub + split_sub;
@@ -1949,98 +1976,144 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
         auto expand_fixup = [&](hipStream_t st) -> int { return fixup_part(st, split_sub ? split_fix : 0, s.n_fixups); };
         if (L.n_sub > 1) {
             if ((lrc = launch(1, sa))) return lrc;
-            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
             if (have_pending && !hold_longer && (lrc = flush_pending())) return lrc;
-            if (s.expand_after_next && si + 1 < r.segments.size() && p->seg_n_sub[si + 1] > 1 && !getenv("H2E_DEBUG_NO_HOLD")) {
+            if (s.expand_after_next && si + 1 < r.segments.size() && p->seg_n_sub[si + 1] > 1) {
+                if (have_pending && (lrc = flush_pending())) return lrc;   // single slot: never overwrite a held expansion
                 pending_L = L;
                 pending_li = li;
                 have_pending = true;
                 hold_longer = false;
-                for (size_t sj = si + 1; sj < r.segments.size() && !getenv("H2E_NO_HOLD_LONGER"); sj++) hold_longer = hold_longer || r.segments[sj].sel_stride != 0;
-                ctx->n_launches++;
+                for (size_t sj = si + 1; sj < r.segments.size(); sj++) hold_longer = hold_longer || r.segments[sj].sel_stride != 0;
+                J.n_launches++;
                 seg_ev[si] = sync_event();
                 HIP_TRY(hipEventRecord(seg_ev[si], sa));
                 continue;
             }
             // a small expansion (the MSM tail: 763 waves) queues behind the big one on the expansion stream: beside it on
-            // the side stream (H2E_SMALL_X_ASIDE) it and its fix-up slow the big one down by more than they take alone
-            // (in-process A/B, exp/ab_inprocess.py: step +0.6 ... +1.0 ms); its fix-up on the side stream delays the side
-            // segments of the program's end (+1.2 ms)
+            // the side stream it and its fix-up slow the big one down by more than they take alone; its fix-up follows it
+            // in its stream: the fix-up stream still holds the big expansion's second fix-up
             bool small_x = (uint64_t)L.n_sub * L.n_strands * n_instances < (1u << 18);
-            hipStream_t sx = (small_x && getenv("H2E_SMALL_X_ASIDE")) ? sc : sb;
-            if (sx == sc) used_se = true;
-            // its fix-up follows it in its stream: the fix-up stream still holds the big expansion's second fix-up
-            fixup_in_stream = sx == sc || (small_x && !getenv("H2E_NO_FIXUP_IN_STREAM"));
+            hipStream_t sx = sb;
+            fixup_in_stream = small_x;
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, sa));
             HIP_TRY(hipStreamWaitEvent(sx, e, 0));
-            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sx));
-            // test hook: leave out the expansion of cut segment <si> (or, with -1, of every cut segment but the last):
-            // whatever the value chain reads must have been stored by the value chain itself (tests/test_parity_gpu.py)
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sx));
+            // test hook (H2E_OPT_TEST_SKIP_EXPANSION): leave out the expansion of cut segment <si> (or, with -1, of every cut
+            // segment but the last): whatever the value chain reads must have been stored by the value chain itself.  The
+            // run's status words get H2E_ST_TEST_HOOK, so its arrays cannot be mistaken for a witness.
             bool skip_x = false;
-            if (const char* sx = getenv("H2E_DEBUG_SKIP_X")) {
+            if (ctx->test_skip_expansion != INT64_MIN) {
                 bool later_cut = false;
                 for (size_t sj = si + 1; sj < r.segments.size(); sj++) later_cut = later_cut || p->seg_n_sub[sj] > 1;
-                skip_x = atoi(sx) == (int)si || (atoi(sx) == -1 && later_cut);
+                skip_x = ctx->test_skip_expansion == (int64_t)si || (ctx->test_skip_expansion == -1 && later_cut);
             }
             if (!skip_x && (lrc = expand(sx))) return lrc;
-            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sx));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sx));
             if (!skip_x && (lrc = expand_fixup(sx))) return lrc;
-        } else if (p->seg_side_dep[si] != -2 && !getenv("H2E_DEBUG_NO_SIDE")) {
+        } else if (p->seg_side_dep[si] != -2) {
             // runs beside the value chain: after the last segment it reads, before the first segment that reads it
             int32_t depi = p->seg_side_dep[si];
             HIP_TRY(hipStreamWaitEvent(se, depi >= 0 && seg_ev[depi] ? seg_ev[depi] : run_begin, 0));
             used_se = true;
-            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
-            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), se));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), se));
             if ((lrc = launch(2, se))) return lrc;
-            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), se));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), se));
             if ((lrc = fixup_after(se))) return lrc;
             side_done[si] = sync_event();
             HIP_TRY(hipEventRecord(side_done[si], se));
         } else if (p->seg_deferrable[si]) {
             // nothing later reads this segment's cells: off the critical stream
-            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, sa));
             HIP_TRY(hipStreamWaitEvent(sb, e, 0));
-            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sb));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sb));
             if ((lrc = launch(2, sb))) return lrc;
-            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sb));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sb));
             if ((lrc = fixup_after(sb))) return lrc;
         } else {
-            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
-            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sa));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sa));
             if ((lrc = launch(2, sa))) return lrc;
-            if (ctx->profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sa));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sa));
             if ((lrc = fixup_after(sa))) return lrc;
         }
         seg_ev[si] = sync_event();
         HIP_TRY(hipEventRecord(seg_ev[si], sa));
-        if (getenv("H2E_DEBUG_JOIN_AFTER") && (int)si == atoi(getenv("H2E_DEBUG_JOIN_AFTER"))) {   // debugging aid
-            hipEvent_t e = sync_event();
-            HIP_TRY(hipEventRecord(e, sb));
-            HIP_TRY(hipStreamWaitEvent(sa, e, 0));
-        }
-        ctx->n_launches++;
+        J.n_launches++;
     }
-    if (have_pending) return fail(H2E_ERR_INVALID, "internal: a held-back expansion was never launched");
-    {   // join: the caller's stream completes when the expansion and fix-up streams do
-        hipEvent_t e = sync_event();
-        HIP_TRY(hipEventRecord(e, sb));
-        HIP_TRY(hipStreamWaitEvent(sa, e, 0));
-        if (used_sd) {
-            hipEvent_t e2 = sync_event();
-            HIP_TRY(hipEventRecord(e2, sd));
-            HIP_TRY(hipStreamWaitEvent(sa, e2, 0));
-        }
+    if (have_pending) {   // (no later segment took it with it)
+        int frc = flush_pending();
+        if (frc) return frc;
+    }
+    if (ctx->test_skip_expansion != INT64_MIN) {
+        int orc = h2e_engine_or_status(J.d_inst, n_instances, H2E_ST_TEST_HOOK, sa);
+        if (orc != 0) return fail(H2E_ERR_HIP, std::string("status kernel launch failed: ") + hipGetErrorString((hipError_t)orc));
+    }
+    // completion: the fix-up stream collects the other streams and records the slot's `done` event; h2e_run then makes
+    // the caller's stream wait for it, h2e_submit leaves that to h2e_wait
+    {
+        hipEvent_t ea = sync_event();
+        HIP_TRY(hipEventRecord(ea, sa));
+        HIP_TRY(hipStreamWaitEvent(sd, ea, 0));
+        hipEvent_t eb = sync_event();
+        HIP_TRY(hipEventRecord(eb, sb));
+        HIP_TRY(hipStreamWaitEvent(sd, eb, 0));
         if (used_se) {
             hipEvent_t e3 = sync_event();
             HIP_TRY(hipEventRecord(e3, se));
-            HIP_TRY(hipStreamWaitEvent(sa, e3, 0));
+            HIP_TRY(hipStreamWaitEvent(sd, e3, 0));
         }
+        (void)used_sd;
+        HIP_TRY(hipEventRecord(J.done, sd));
+        if (join) HIP_TRY(hipStreamWaitEvent(sa, J.done, 0));
     }
     return 0;
+}
+
+int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
+            void* d_select, void* d_status, void* stream_) {
+    if (n_instances == 0) return 0;
+    return run_impl(ctx, p, n_instances, d_inputs, d_base, d_range, d_select, d_status, (hipStream_t)stream_, true, nullptr);
+}
+
+int h2e_submit(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
+               void* d_select, void* d_status, void* stream_, int* job) {
+    if (!job) return fail(H2E_ERR_INVALID, "job is null");
+    *job = -1;
+    if (n_instances == 0) return fail(H2E_ERR_INVALID, "n_instances must be > 0");
+    return run_impl(ctx, p, n_instances, d_inputs, d_base, d_range, d_select, d_status, (hipStream_t)stream_, false, job);
+}
+
+int h2e_wait(h2e_ctx* ctx, int job, void* stream_) {
+    if (!ctx || job < 0 || job >= h2e_ctx::N_SLOTS || !ctx->slots[job].done) return fail(H2E_ERR_INVALID, "bad job");
+    std::lock_guard<std::mutex> guard(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream_, ctx->slots[job].done, 0));
+    return 0;
+}
+
+int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value) {
+    if (!ctx) return fail(H2E_ERR_INVALID, "null ctx");
+    std::lock_guard<std::mutex> guard(ctx->mu);
+    switch (option) {
+        case H2E_OPT_X_SPLIT_PCT: ctx->x_split_pct = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(100, value)); return 0;
+        case H2E_OPT_X_SPLIT_MIN_LANES: ctx->x_split_min_lanes = (uint64_t)std::max<int64_t>(0, value); return 0;
+        case H2E_OPT_TEST_SKIP_EXPANSION: ctx->test_skip_expansion = value; return 0;
+        default: return fail(H2E_ERR_INVALID, "unknown option");
+    }
+}
+int64_t h2e_ctx_get_stat(h2e_ctx* ctx, int stat) {
+    if (!ctx) return -1;
+    switch (stat) {
+        case H2E_STAT_LAST_SPLIT_SEGMENTS: return ctx->last_split_segments;
+        case H2E_STAT_RUNS: return (int64_t)ctx->n_runs;
+        case H2E_STAT_PIPELINE_DEPTH: return h2e_ctx::N_SLOTS;
+        default: return -1;
+    }
 }
 
 int h2e_program_outputs(const h2e_program* p, uint32_t* refs, uint32_t cap) {
@@ -2071,40 +2144,73 @@ int h2e_program_launches(const h2e_program* p, uint64_t* out, uint32_t cap) {
     return (int)k;
 }
 
-int h2e_export_columns(h2e_ctx* ctx, uint32_t n_instances, uint64_t rows, uint32_t cols, const void* d_rows, void* d_columns,
-                       void* stream) {
-    if (!ctx || !d_rows || !d_columns) return fail(H2E_ERR_INVALID, "null argument");
-    if (cols != 5 && cols != 3 && cols != 2) return fail(H2E_ERR_INVALID, "cols must be 5 (base), 3 (range) or 2 (select)");
+int h2e_export(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, int layout, int form, const void* d_batch,
+               void* d_out, void* stream) {
+    if (!ctx || !p || !d_batch || !d_out) return fail(H2E_ERR_INVALID, "null argument");
+    if (region < 0 || region > 2) return fail(H2E_ERR_INVALID, "region must be 0 (base), 1 (range) or 2 (select)");
+    if (layout != H2E_LAYOUT_ROWS && layout != H2E_LAYOUT_COLUMNS) return fail(H2E_ERR_INVALID, "bad layout");
+    if (form != H2E_FORM_CANONICAL && form != H2E_FORM_MONTGOMERY) return fail(H2E_ERR_INVALID, "bad number form");
+    if (n_instances == 0) return 0;
+    std::lock_guard<std::mutex> guard(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
-    int rc = h2e_engine_columns(cols, d_rows, d_columns, rows, n_instances, (hipStream_t)stream);
+    if (p->device >= 0 && p->device != ctx->device) return fail(H2E_ERR_INVALID, "program bound to another device");
+    const h2e::Recorder& r = *p->rec;
+    const uint32_t cols = region == 0 ? 5 : region == 1 ? 3 : 2;
+    const uint64_t rows = region == 0 ? p->base_rows : region == 1 ? p->range_rows : p->select_rows;
+    const std::vector<uint8_t>& hf = region == 0 ? r.base_flags : region == 1 ? r.range_flags : r.select_flags;
+    const uint8_t* d_flags = nullptr;
+    if (r.emit_shape) {
+        if (hf.size() < rows * cols) return fail(H2E_ERR_SHAPE, "internal: flag array shorter than the advice array");
+        if (!p->d_flags[region]) {
+            HIP_TRY(hipMalloc((void**)&p->d_flags[region], std::max<size_t>(16, rows * cols)));
+            HIP_TRY(hipMemcpy(p->d_flags[region], hf.data(), rows * cols, hipMemcpyHostToDevice));
+        }
+        d_flags = p->d_flags[region];
+    }
+    int fp = p->field_pair;
+    if (!ctx->d_fc[fp]) {
+        HIP_TRY(hipMalloc((void**)&ctx->d_fc[fp], sizeof(H2EFieldConsts)));
+        HIP_TRY(hipMemcpy(ctx->d_fc[fp], &field_pair(fp).fc, sizeof(H2EFieldConsts), hipMemcpyHostToDevice));
+        HIP_TRY((hipError_t)h2e_engine_set_consts(fp, &field_pair(fp).fc));
+    }
+    int rc = h2e_engine_export(cols, layout == H2E_LAYOUT_COLUMNS, form == H2E_FORM_MONTGOMERY, d_batch, d_out, d_flags, rows,
+                               n_instances, ctx->d_fc[fp], (hipStream_t)stream);
     if (rc != 0) return fail(H2E_ERR_HIP, rc < 0 ? "export: bad geometry" : std::string("export launch failed: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }
 
 int h2e_set_profiling(h2e_ctx* ctx, int enable) {
     if (!ctx) return fail(H2E_ERR_INVALID, "null ctx");
+    std::lock_guard<std::mutex> guard(ctx->mu);
     ctx->profiling = enable != 0;
     return 0;
 }
 int h2e_last_run_launch_ms(h2e_ctx* ctx, float* ms, uint32_t cap) {
-    if (!ctx) return fail(H2E_ERR_INVALID, "null ctx");
-    if (!ctx->profiling) return 0;
+    if (!ctx || !ms) return fail(H2E_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(ctx->mu);
+    if (ctx->last_slot < 0) return 0;
+    JobSlot& J = ctx->slots[ctx->last_slot];
+    if (!J.profiled) return 0;   // the last run recorded no events (profiling was off when it was queued)
     // two numbers per launched segment: value chain (predictors + values-only replay), expansion (+ fix-up)
-    for (uint32_t i = 0; i < ctx->n_launches && 2 * i + 1 < cap; i++) {
+    uint32_t n = std::min<uint32_t>(J.n_launches, (uint32_t)(J.ev.size() / 4));
+    for (uint32_t i = 0; i < n && 2 * i + 1 < cap; i++) {
         float t0 = 0, t1 = 0;
-        hipError_t e = hipEventElapsedTime(&t0, ctx->ev[4 * i], ctx->ev[4 * i + 1]);
-        if (e == hipSuccess) e = hipEventElapsedTime(&t1, ctx->ev[4 * i + 2], ctx->ev[4 * i + 3]);
+        hipError_t e = hipEventElapsedTime(&t0, J.ev[4 * i], J.ev[4 * i + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t1, J.ev[4 * i + 2], J.ev[4 * i + 3]);
         if (e != hipSuccess) return fail(H2E_ERR_HIP, hipGetErrorString(e));
         ms[2 * i] = t0;
         ms[2 * i + 1] = t1;
     }
-    return (int)ctx->n_launches;
+    return (int)n;
 }
 
 int h2e_last_run_expansion_launches(h2e_ctx* ctx, uint32_t* counts, uint32_t cap) {
     if (!ctx || !counts) return fail(H2E_ERR_INVALID, "null argument");
-    for (uint32_t i = 0; i < ctx->n_launches && i < cap; i++) counts[i] = i < ctx->x_kernels.size() ? ctx->x_kernels[i] : 1;
-    return (int)ctx->n_launches;
+    std::lock_guard<std::mutex> guard(ctx->mu);
+    if (ctx->last_slot < 0) return 0;
+    JobSlot& J = ctx->slots[ctx->last_slot];
+    for (uint32_t i = 0; i < J.n_launches && i < cap; i++) counts[i] = i < J.x_kernels.size() ? J.x_kernels[i] : 1;
+    return (int)J.n_launches;
 }
 
 static int cached_run(h2e_ctx* ctx, const std::string& key, std::function<int(h2e_program**)> make, uint32_t n_instances,

@@ -638,8 +638,6 @@ struct NativeScalarEccContext {
         }
 
         // accumulate windows (ecc_chip.rs:354-362)
-        // experiment knob H2E_TAIL_CUT_EVERY: cut the tail's expansion inside its EC ops as well (shorter sub-ranges)
-        if (const char* e = getenv("H2E_TAIL_CUT_EVERY")) c.auto_cut_every = (uint32_t)atoi(e);
         AssignedNonZeroPoint acc = rand_acc_point;
         for (size_t wi = 0; wi < windows; wi++) {
             acc = ecc_double_unsafe(acc);

@@ -12,13 +12,21 @@ import numpy as np
 
 FIELD_BN256_FQ, FIELD_BLS12_381_FQ, FIELD_BLS12_381_FR = 0, 1, 2
 ST_OK, ST_ASSERT_FAILED, ST_RETRY_ADD_SAME_OR_NEG_POINT, ST_RETRY_ADD_IDENTITY, ST_ARITH = 0, 1, 2, 4, 8
+ST_TEST_HOOK = 0x80
+LAYOUT_ROWS, LAYOUT_COLUMNS = 0, 1
+FORM_CANONICAL, FORM_MONTGOMERY = 0, 1
+OPT_X_SPLIT_PCT, OPT_X_SPLIT_MIN_LANES, OPT_TEST_SKIP_EXPANSION = 1, 2, 3
+STAT_LAST_SPLIT_SEGMENTS, STAT_RUNS, STAT_PIPELINE_DEPTH = 1, 2, 3
+OPT_OFF = -(1 << 63)
+COLS = (5, 3, 2)
 
 EXPORTED_SYMBOLS = [
     "h2e_last_error", "h2e_version", "h2e_ctx_create", "h2e_ctx_destroy", "h2e_program_int_mul_batch",
     "h2e_program_integer_chip_st", "h2e_program_msm_bn256_tile", "h2e_program_pairing_check_bn256",
     "h2e_program_pairing_check_bls12_381", "h2e_program_destroy", "h2e_program_shape", "h2e_run",
     "h2e_int_mul_batch", "h2e_msm_bn256_tile", "h2e_pairing_check_bn256", "h2e_pairing_check_bls12_381",
-    "h2e_last_run_launch_ms", "h2e_set_profiling", "h2e_program_outputs", "h2e_program_launches", "h2e_export_columns",
+    "h2e_last_run_launch_ms", "h2e_set_profiling", "h2e_program_outputs", "h2e_program_launches", "h2e_export",
+    "h2e_submit", "h2e_wait", "h2e_ctx_set_option", "h2e_ctx_get_stat",
     "h2e_program_msm_bn256_tile_no_select", "h2e_last_run_expansion_launches",
 ]
 
@@ -84,7 +92,12 @@ def lib():
     L.h2e_last_run_expansion_launches.argtypes = [vp, C.POINTER(u32), u32]
     L.h2e_program_outputs.argtypes = [vp, C.POINTER(u32), u32]
     L.h2e_program_launches.argtypes = [vp, C.POINTER(C.c_uint64), u32]
-    L.h2e_export_columns.argtypes = [vp, u32, C.c_uint64, u32, vp, vp, vp]
+    L.h2e_export.argtypes = [vp, vp, u32, i32, i32, i32, vp, vp, vp]
+    L.h2e_submit.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
+    L.h2e_wait.argtypes = [vp, i32, vp]
+    L.h2e_ctx_set_option.argtypes = [vp, i32, C.c_int64]
+    L.h2e_ctx_get_stat.argtypes = [vp, i32]
+    L.h2e_ctx_get_stat.restype = C.c_int64
     _lib = L
     return L
 
@@ -205,15 +218,19 @@ class Engine:
         _check(lib().h2e_ctx_create(device, C.byref(h)))
         self._h = h
 
-    def alloc(self, program, n_instances):
+    def alloc(self, program, n_instances, fill=0):
+        """Batch-interleaved advice arrays [rows][cols][half][instance][2 words] (include/h2e.h) + status words.
+        `fill`: byte the arrays are initialised with (the engine only writes assigned cells; 0xFF poisons the rest)."""
         t = self.torch
         dev = f"cuda:{self.device}"
         kw = dict(dtype=t.int64, device=dev)
-        base = t.zeros((n_instances, program.base_rows, 5, 4), **kw)
-        rng = t.zeros((n_instances, program.range_rows, 3, 4), **kw)
-        sel = t.zeros((n_instances, program.select_rows, 2, 4), **kw)
+        arrs = []
+        for rows, cols in zip((program.base_rows, program.range_rows, program.select_rows), COLS):
+            shape = (rows, cols, 2, n_instances, 2)
+            assert fill in (0, 0xFF)
+            arrs.append(t.zeros(shape, **kw) if fill == 0 else t.full(shape, -1, **kw))
         status = t.zeros((n_instances,), dtype=t.int32, device=dev)
-        return base, rng, sel, status
+        return arrs[0], arrs[1], arrs[2], status
 
     def upload_inputs(self, program, inputs):
         """inputs: numpy uint64 [n_instances][n_input_slots][slot_words]"""
@@ -222,23 +239,55 @@ class Engine:
         assert a.shape[1:] == (program.n_input_slots, program.slot_words), (a.shape, program.n_input_slots)
         return t.from_numpy(a.view(np.int64)).to(f"cuda:{self.device}")
 
-    def run(self, program, d_inputs, base, rng, sel, status, stream=None):
-        t = self.torch
-        n = d_inputs.shape[0]
-        s = stream if stream is not None else t.cuda.current_stream(self.device)
-        _check(lib().h2e_run(self._h, program._h, n, d_inputs.data_ptr(), base.data_ptr(), rng.data_ptr(),
-                             sel.data_ptr(), status.data_ptr(), s.cuda_stream))
+    def _stream(self, stream):
+        return stream if stream is not None else self.torch.cuda.current_stream(self.device)
 
-    def export_columns(self, rows_major, stream=None):
-        """row-major advice tensor [instances][rows][cols][4] -> column-major [instances][cols][rows][4] on the device
-        (h2e_export_columns: the halo2 side keeps one array per advice column)"""
+    def run(self, program, d_inputs, base, rng, sel, status, stream=None):
+        n = d_inputs.shape[0]
+        assert base.shape[3] == n and rng.shape[3] == n and sel.shape[3] == n, "advice arrays are batch-interleaved for n instances"
+        _check(lib().h2e_run(self._h, program._h, n, d_inputs.data_ptr(), base.data_ptr(), rng.data_ptr(),
+                             sel.data_ptr(), status.data_ptr(), self._stream(stream).cuda_stream))
+
+    def submit(self, program, d_inputs, base, rng, sel, status, stream=None):
+        """pipelined submission (h2e_submit): returns the job id to pass to wait()"""
+        n = d_inputs.shape[0]
+        assert base.shape[3] == n and rng.shape[3] == n and sel.shape[3] == n
+        job = C.c_int(-1)
+        _check(lib().h2e_submit(self._h, program._h, n, d_inputs.data_ptr(), base.data_ptr(), rng.data_ptr(),
+                                sel.data_ptr(), status.data_ptr(), self._stream(stream).cuda_stream, C.byref(job)))
+        return job.value
+
+    def wait(self, job, stream=None):
+        _check(lib().h2e_wait(self._h, job, self._stream(stream).cuda_stream))
+
+    def export(self, program, region, batch, layout=LAYOUT_ROWS, form=FORM_CANONICAL, stream=None, out=None):
+        """h2e_export: batch-interleaved array of one region -> per-instance arrays on the device,
+        [instances][rows][cols][4] (LAYOUT_ROWS, the reference's Records layout) or [instances][cols][rows][4]
+        (LAYOUT_COLUMNS, halo2's advice columns); unassigned cells zero; canonical or Montgomery-form cells."""
         t = self.torch
-        n, rows, cols, w = rows_major.shape
-        assert w == 4 and rows_major.is_contiguous()
-        out = t.empty((n, cols, rows, 4), dtype=rows_major.dtype, device=rows_major.device)
-        s = stream if stream is not None else t.cuda.current_stream(self.device)
-        _check(lib().h2e_export_columns(self._h, n, rows, cols, rows_major.data_ptr(), out.data_ptr(), s.cuda_stream))
+        rows, cols, two, n, w = batch.shape
+        assert two == 2 and w == 2 and cols == COLS[region] and batch.is_contiguous()
+        assert rows == (program.base_rows, program.range_rows, program.select_rows)[region]
+        shape = (n, rows, cols, 4) if layout == LAYOUT_ROWS else (n, cols, rows, 4)
+        if out is None:
+            out = t.empty(shape, dtype=batch.dtype, device=batch.device)
+        assert tuple(out.shape) == shape and out.is_contiguous()
+        _check(lib().h2e_export(self._h, program._h, n, region, layout, form, batch.data_ptr(), out.data_ptr(),
+                                self._stream(stream).cuda_stream))
         return out
+
+    def read_cell(self, base, ref, instance):
+        """value of a base-chip cell reference (region << 30 | col << 27 | row) of one instance, as a Python int"""
+        region, col, row = ref >> 30, (ref >> 27) & 7, ref & 0x3FFFFFF
+        assert region == 0
+        w = base[row, col, :, instance, :].reshape(4).cpu().numpy().view(np.uint64)
+        return sum(int(w[k]) << (64 * k) for k in range(4))
+
+    def set_option(self, option, value):
+        _check(lib().h2e_ctx_set_option(self._h, option, value))
+
+    def get_stat(self, stat):
+        return int(lib().h2e_ctx_get_stat(self._h, stat))
 
     def set_profiling(self, on):
         _check(lib().h2e_set_profiling(self._h, int(on)))

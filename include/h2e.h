@@ -11,10 +11,19 @@
  * Conventions
  *  - all multi-word integers are little-endian arrays of uint64_t; advice cells are canonical bn256-Fr
  *    values (what `field_to_bn` sees, src/utils.rs:4-8), 4 words each;
- *  - advice arrays are row-major like the reference's `Vec<[(Option<N>, bool); COLS]>`
- *    (src/context.rs:243-251): base [rows][5][4], range [rows][3][4], select [rows][2][4] words; cells the
- *    shape leaves unassigned are written as zero (the engine stores whole rows: rows with holes cost HBM
- *    bandwidth), so the arrays need no initialisation;
+ *  - advice arrays are *batch-interleaved*: rows and columns are the reference's
+ *    (`Vec<[(Option<N>, bool); COLS]>`, src/context.rs:243-251; COLS = 5 base, 3 range, 2 select), a cell is two
+ *    16-byte halves, and the n_instances instances of a run are the minor dimension:
+ *        array[row][col][half][instance][2 words]      (n_instances * rows * COLS * 4 words in all)
+ *    i.e. word k of cell (row, col) of instance i is at
+ *        ((row * COLS + col) * 2 + k / 2) * 2 * n_instances + 2 * i + k % 2.
+ *    With n_instances == 1 this is exactly the reference's row-major [rows][COLS][4].  Why: the 64 lanes of a
+ *    wavefront are 64 instances at the same cell, so every store the engine issues is a contiguous 1 KB run and
+ *    only assigned cells cost HBM bandwidth.  The engine writes assigned cells only (the assigned / permute
+ *    flags are shape artefacts, h2e_program_shape): cells the shape leaves unassigned keep whatever the caller's
+ *    buffer held - zero-fill the arrays, or read them through h2e_export, which masks with the flags;
+ *  - h2e_export turns a batch-interleaved array into one array per instance, row-major (Records) or
+ *    column-major (halo2 advice columns), canonical or Montgomery-form cells;
  *  - inputs: [n_instances][n_input_slots][slot_words] words; a slot holds one W value (canonical) or one
  *    Fr value / flag in its first 4 words;
  *  - device pointers are plain `void*` from any allocator (hipMalloc, torch); the engine never frees
@@ -45,6 +54,7 @@ extern "C" {
 #define H2E_ST_RETRY_ADD_SAME_OR_NEG_POINT 2u
 #define H2E_ST_RETRY_ADD_IDENTITY 4u
 #define H2E_ST_ARITH 8u
+#define H2E_ST_TEST_HOOK 0x80u   /* the run was made with a test hook that leaves rows out (h2e_ctx_set_option) */
 
 typedef struct h2e_ctx h2e_ctx;          /* device + constant tables; one per GPU, re-entrant per ctx */
 typedef struct h2e_program h2e_program;  /* recorded shape of one workload */
@@ -118,13 +128,39 @@ int h2e_program_outputs(const h2e_program* p, uint32_t* refs, uint32_t cap);
 int h2e_program_launches(const h2e_program* p, uint64_t* out, uint32_t cap);
 
 /* ---- execution --------------------------------------------------------------------------------- */
-/* Fill the advice values of n_instances instances.  d_base/d_range/d_select: device arrays of
- * n_instances * rows * cols * 4 words (instance-major); d_inputs as described above; d_status:
+/* Fill the advice values of n_instances instances.  d_base/d_range/d_select: batch-interleaved device arrays of
+ * rows * cols * 4 * n_instances words (see Conventions); d_inputs as described above; d_status:
  * n_instances uint32 (or-ed, zero it first).  Asynchronous on `stream`: the engine fans the work out over
  * three internal streams of the context (expansion, early predictors / side segments, inverse fix-up), all of them
- * ordered after what is already queued on `stream`, and `stream` completes only when all of them have. */
+ * ordered after what is already queued on `stream`, and `stream` completes only when all of them have.
+ * Re-entrancy: calls on one context are serialised on the host by the context's lock; every run owns its instance
+ * table, workspace and events (a ring of H2E_STAT_PIPELINE_DEPTH job slots per context), so runs of the same or of
+ * different programs may be queued back to back from any thread.  Different contexts share nothing. */
 int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
             void* d_select, void* d_status, void* stream);
+
+/* Pipelined submission for streaming jobs (a 2^20-point MSM is 1024 tiles through a ring of output buffers,
+ * SURVEY.md 8d cfg 3).  Like h2e_run, but `stream` only carries the run's value chain and is NOT joined with the
+ * engine's expansion streams: the value chain of the next h2e_submit overlaps this run's expansion.  *job identifies
+ * the run; h2e_wait(job, s) makes stream `s` wait until every array of that run is complete.  At most
+ * H2E_STAT_PIPELINE_DEPTH runs are in flight: a further submit first waits (on `stream`, not on the host) for the run
+ * that used the same slot.  Runs in flight must use different advice arrays and status words. */
+int h2e_submit(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
+               void* d_select, void* d_status, void* stream, int* job);
+int h2e_wait(h2e_ctx* ctx, int job, void* stream);
+
+/* Options / statistics of a context.  Tuning knobs are read from the environment once, at h2e_ctx_create
+ * (H2E_X_SPLIT, H2E_X_SPLIT_MIN_LANES); nothing reads the environment while a run is queued. */
+#define H2E_OPT_X_SPLIT_PCT 1          /* a big expansion goes out as two launches: percent of sub-ranges in the first (0 = off) */
+#define H2E_OPT_X_SPLIT_MIN_LANES 2    /* ... if it has at least this many lanes */
+#define H2E_OPT_TEST_SKIP_EXPANSION 3  /* TEST HOOK: leave out the full expansion of cut segment <value> (-1: of every cut
+                                          segment but the last; INT64_MIN: off).  Rows are missing from such a run: every
+                                          status word gets H2E_ST_TEST_HOOK. */
+int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value);
+#define H2E_STAT_LAST_SPLIT_SEGMENTS 1 /* segments of the last run whose expansion went out as two launches */
+#define H2E_STAT_RUNS 2
+#define H2E_STAT_PIPELINE_DEPTH 3
+int64_t h2e_ctx_get_stat(h2e_ctx* ctx, int stat);
 
 /* Named entry points of SURVEY.md §8(b): build-or-reuse the program for the shape, then run it. */
 int h2e_int_mul_batch(h2e_ctx* ctx, int field_pair, uint32_t n, uint32_t n_instances, const void* d_inputs, void* d_base,
@@ -136,18 +172,28 @@ int h2e_pairing_check_bn256(h2e_ctx* ctx, uint32_t n_instances, const void* d_in
 int h2e_pairing_check_bls12_381(h2e_ctx* ctx, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
                                 void* d_select, void* d_status, void* stream);
 
-/* ---- hand-off to the halo2 side (device half) --------------------------------
- * halo2 keeps one array per advice column; the reference's Records::_assign_to_{base,range,select}_chip
- * (src/context.rs:310-541) copy the row-major `[(Option<N>, bool); COLS]` cells into them one by one.
- * Transposes row-major advice arrays [instance][row][cols][4 words] into column-major
- * [instance][cols][row][4 words] on the device (cols = 5 base, 3 range, 2 select); the assigned / permute flags and
- * the fixed columns are shape artefacts (h2e_program_shape).  Asynchronous on `stream`. */
-int h2e_export_columns(h2e_ctx* ctx, uint32_t n_instances, uint64_t rows, uint32_t cols, const void* d_rows, void* d_columns,
-                       void* stream);
+/* ---- hand-off to the consumer (device half) ------------------------------------
+ * halo2 keeps one array per advice column and its field elements are Montgomery-form [u64; 4]; the reference's
+ * Records::_assign_to_{base,range,select}_chip (src/context.rs:310-541) copy row-major `[(Option<N>, bool); COLS]`
+ * cells into them one by one, and every value crosses utils.rs:10-17 (`bn_to_field`).  h2e_export turns the
+ * batch-interleaved array of one region (0 base, 1 range, 2 select) of a run into one array per instance,
+ *   H2E_LAYOUT_ROWS     [instance][row][COLS][4 words]   (the reference's Records layout), or
+ *   H2E_LAYOUT_COLUMNS  [instance][COLS][row][4 words]   (halo2's advice columns),
+ * with cells the shape leaves unassigned as zero (programs recorded with emit_shape = 0 have no flags: their cells are
+ * copied as they are), as canonical little-endian values (H2E_FORM_CANONICAL, what field_to_bn sees, utils.rs:4-8) or
+ * as Montgomery-form words (H2E_FORM_MONTGOMERY: x * 2^256 mod n, the in-memory form of halo2's Fr).
+ * Asynchronous on `stream`. */
+#define H2E_LAYOUT_ROWS 0
+#define H2E_LAYOUT_COLUMNS 1
+#define H2E_FORM_CANONICAL 0
+#define H2E_FORM_MONTGOMERY 1
+int h2e_export(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, int layout, int form, const void* d_batch,
+               void* d_out, void* stream);
 
 /* Timing hook used by bench.py: HIP events recorded by the engine on the stream each kernel group is launched
  * on.  Returns the number of launched segments and fills two numbers per segment: ms[2i] = value chain
- * (predictor kernels + values-only replay), ms[2i+1] = full expansion (the inverse fix-up runs on its own stream and is not included; call after synchronising). */
+ * (predictor kernels + values-only replay), ms[2i+1] = full expansion (the inverse fix-up runs on its own stream and is not included; call after synchronising).
+ * Refers to the most recently queued run; returns 0 when that run was queued with profiling off. */
 int h2e_last_run_launch_ms(h2e_ctx* ctx, float* ms, uint32_t cap);
 int h2e_set_profiling(h2e_ctx* ctx, int enable);
 /* Companion of h2e_last_run_launch_ms: counts[i] = kernel launches the full expansion of segment i went out as in the

@@ -10,12 +10,21 @@ from parity import compare_advice, compare_shape
 pytestmark = pytest.mark.gpu
 
 
-def _run(engine, prog, inputs_list):
+def _rows(engine, prog, arrs):
+    """batch-interleaved advice arrays -> per-instance row-major [inst][rows][cols][4] (the reference's Records layout);
+    programs recorded with their shape export unassigned cells as zero whatever the buffer held"""
+    out = tuple(engine.export(prog, region, a) for region, a in enumerate(arrs))
+    engine.torch.cuda.synchronize()
+    return out
+
+
+def _run(engine, prog, inputs_list, fill=0):
     inputs = np.stack(inputs_list)
     d_in = engine.upload_inputs(prog, inputs)
-    base, rng, sel, status = engine.alloc(prog, len(inputs_list))
+    base, rng, sel, status = engine.alloc(prog, len(inputs_list), fill=fill)
     engine.run(prog, d_in, base, rng, sel, status)
     engine.torch.cuda.synchronize()
+    base, rng, sel = _rows(engine, prog, (base, rng, sel))
     return base, rng, sel, status.cpu().numpy()
 
 
@@ -101,39 +110,64 @@ def test_msm_alternating_inputs_reuse_buffers(engine, oracle):
         assert (status.cpu().numpy() == 0).all(), (rep, status.cpu().numpy())
     orun = oracle_lib.run_msm_bn256_tile(n, sets[1][tiles - 1])
     assert orun.info.status == 0, orun.error
+    base, rng, sel = _rows(engine, prog, (base, rng, sel))
     compare_advice(prog, orun, base, rng, sel, instance=tiles - 1)
 
 
-@pytest.mark.parametrize("cols", [5, 3, 2])
-def test_export_columns(engine, cols):
-    """h2e_export_columns (SURVEY §8f-1, device half): row-major advice rows -> one array per column, bit exact;
-    row counts that are not a multiple of the 64-row tile, several instances"""
+BN_R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+def _to_ints(a):
+    """[..., 4] uint64 words -> flat list of Python ints"""
+    a = a.reshape(-1, 4)
+    return [sum(int(a[i, k]) << (64 * k) for k in range(4)) for i in range(a.shape[0])]
+
+
+@pytest.mark.parametrize("n_inst", [1, 3, 33, 70])
+def test_export_layouts(engine, n_inst):
+    """h2e_export (device half) on random cells: batch-interleaved [rows][cols][half][inst][2] ->
+    per-instance rows / columns, bit exact against a torch permute; instance counts around the 32-instance tile,
+    row counts around the 8-row tile (emit_shape = 0: no flags, cells copied as they are)"""
     t = engine.torch
-    for rows in (1, 63, 64, 1000, 4099):
-        g = t.Generator(device="cuda").manual_seed(rows + cols)
-        x = t.randint(-2**62, 2**62, (3, rows, cols, 4), dtype=t.int64, device="cuda", generator=g)
-        y = engine.export_columns(x)
+    prog = Program.int_mul_batch(0, 5, emit_shape=False)
+    for region, (rows, cols) in enumerate(((prog.base_rows, 5), (prog.range_rows, 3), (prog.select_rows, 2))):
+        g = t.Generator(device="cuda").manual_seed(rows + cols + n_inst)
+        x = t.randint(-2**62, 2**62, (rows, cols, 2, n_inst, 2), dtype=t.int64, device="cuda", generator=g)
+        want_rows = x.permute(3, 0, 1, 2, 4).reshape(n_inst, rows, cols, 4)
+        got = engine.export(prog, region, x, layout=0)
+        got_c = engine.export(prog, region, x, layout=1)
         t.cuda.synchronize()
-        assert t.equal(y, x.permute(0, 2, 1, 3).contiguous())
+        assert t.equal(got, want_rows)
+        assert t.equal(got_c, want_rows.permute(0, 2, 1, 3).contiguous())
 
 
-def test_export_columns_of_a_witness(engine, oracle):
-    """the exported columns of an MSM tile equal the oracle's Records columns"""
+def test_export_columns_and_montgomery_of_a_witness(engine, oracle):
+    """the exported columns of an MSM tile equal the oracle's Records columns (unassigned cells zero although the run
+    wrote into 0xFF-poisoned arrays), and the Montgomery-form export is x * 2^256 mod n of the canonical one
+    (the in-memory form of halo2's Fr: src/utils.rs:10-17 costs one such conversion per cell on the host)"""
     n = 6
     inp, _ = synth.msm_bn256_tile_inputs(n, tile=5)
     prog = Program.msm_bn256_tile(n)
-    base, rng, sel, status = _run(engine, prog, [inp])
-    assert (status == 0).all()
+    d_in = engine.upload_inputs(prog, np.stack([inp, inp]))
+    arrs = engine.alloc(prog, 2, fill=0xFF)
+    engine.run(prog, d_in, *arrs)
+    engine.torch.cuda.synchronize()
+    assert (arrs[3].cpu().numpy() == 0).all()
     orun = oracle_lib.run_msm_bn256_tile(n, inp)
-    for region, arr in enumerate((base, rng, sel)):
-        cols = engine.export_columns(arr)
+    for region in range(3):
+        cols = engine.export(prog, region, arrs[region], layout=1)
+        mont = engine.export(prog, region, arrs[region], layout=0, form=1)
         engine.torch.cuda.synchronize()
-        ovals, _ = orun.adv(region, arr.shape[1])
-        got = cols[0].cpu().numpy().view(np.uint64)
-        assert np.array_equal(got, np.ascontiguousarray(ovals.transpose(1, 0, 2)))
+        ovals, _ = orun.adv(region, arrs[region].shape[0])
+        for inst in range(2):
+            got = cols[inst].cpu().numpy().view(np.uint64)
+            assert np.array_equal(got, np.ascontiguousarray(ovals.transpose(1, 0, 2)))
+        rows = min(ovals.shape[0], 300)   # Python-int check of the Montgomery form on the first rows
+        want = [(v << 256) % BN_R for v in _to_ints(ovals[:rows])]
+        assert _to_ints(mont[1].cpu().numpy().view(np.uint64)[:rows]) == want
 
 
-def test_msm_value_chain_does_not_depend_on_expansion(engine, oracle, monkeypatch):
+def test_msm_value_chain_does_not_depend_on_expansion(engine, oracle):
     """The expansion of a cut segment runs on its own stream, concurrently with the value chain of the following
     segments, so the value chain may only read cells the value chain itself stored.  With the expansion of every
     cut segment but the last left out (test hook), the last segment - the MSM tail, which reads the windows' sums -
@@ -141,10 +175,13 @@ def test_msm_value_chain_does_not_depend_on_expansion(engine, oracle, monkeypatc
     n = 24
     inp, _ = synth.msm_bn256_tile_inputs(n, tile=3)
     prog = Program.msm_bn256_tile(n)
-    monkeypatch.setenv("H2E_DEBUG_SKIP_X", "-1")
-    base, rng, sel, status = _run(engine, prog, [inp])
-    monkeypatch.delenv("H2E_DEBUG_SKIP_X")
-    assert (status == 0).all(), status
+    from halo2ecc_s_amd import engine as E
+    engine.set_option(E.OPT_TEST_SKIP_EXPANSION, -1)
+    try:
+        base, rng, sel, status = _run(engine, prog, [inp])
+    finally:
+        engine.set_option(E.OPT_TEST_SKIP_EXPANSION, E.OPT_OFF)
+    assert (status == E.ST_TEST_HOOK).all(), status   # the hook marks the run: its arrays are not a witness
     orun = oracle_lib.run_msm_bn256_tile(n, inp)
     assert orun.info.status == 0, orun.error
     win = prog.launches()[-2]
@@ -152,22 +189,26 @@ def test_msm_value_chain_does_not_depend_on_expansion(engine, oracle, monkeypatc
     ovals, _ = orun.adv(0, prog.base_rows)
     got = base[0].cpu().numpy().view(np.uint64)
     assert np.array_equal(got[tail0:], ovals[tail0:]), "tail differs when the windows' expansion is left out"
+    assert not np.array_equal(got[:tail0], ovals[:tail0]), "the hook left nothing out"
 
 
 @pytest.mark.parametrize("pct", [10, 45, 90])
-def test_msm_split_expansion(engine, oracle, monkeypatch, capfd, pct):
+def test_msm_split_expansion(engine, oracle, pct):
     """A big expansion goes out as two launches over a prefix / the rest of its sub-ranges, with the inverse fix-up of
     the first part in between (h2e_capi.cpp `expand`; at BASELINE's size: the MSM windows).  Forced here at a small
     size: every cell, the is_zero inverses of both parts included, must still equal the oracle's."""
     n, tiles = 96, 2
     ins = [synth.msm_bn256_tile_inputs(n, tile=40 + t, cheap_points=True)[0] for t in range(tiles)]
     prog = Program.msm_bn256_tile(n)
-    monkeypatch.setenv("H2E_X_SPLIT_MIN_LANES", "0")
-    monkeypatch.setenv("H2E_X_SPLIT", str(pct))
-    monkeypatch.setenv("H2E_DEBUG_X_SPLIT_REPORT", "1")
-    base, rng, sel, status = _run(engine, prog, ins)
-    err = capfd.readouterr().err
-    assert "x-split segment" in err, "the split path was not taken"
+    from halo2ecc_s_amd import engine as E
+    engine.set_option(E.OPT_X_SPLIT_MIN_LANES, 0)
+    engine.set_option(E.OPT_X_SPLIT_PCT, pct)
+    try:
+        base, rng, sel, status = _run(engine, prog, ins)
+        assert engine.get_stat(E.STAT_LAST_SPLIT_SEGMENTS) >= 1, "the split path was not taken"
+    finally:
+        engine.set_option(E.OPT_X_SPLIT_MIN_LANES, 1 << 21)
+        engine.set_option(E.OPT_X_SPLIT_PCT, 45)
     assert (status == 0).all(), status
     for k, inp in enumerate(ins):
         orun = oracle_lib.run_msm_bn256_tile(n, inp)
