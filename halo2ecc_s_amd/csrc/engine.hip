@@ -11,6 +11,7 @@
 // reference's row-major `[row][col][4 x u64]`.  Operands are read back from those arrays through cell references.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <algorithm>
 #include "tape.h"
 #include "wide_int.h"
 
@@ -977,9 +978,9 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     c.hint_stride = L.hint_stride;
     c.hs = 2 * n_instances;
     __shared__ TapeChunk chunk;
-    __shared__ u64 xcache[3][2 * FP::L + 4][64];
+    extern __shared__ u64 xcache_dyn[];   // [3][2 L + 4][64] words when the result cache is on (H2ELaunch.rel_refs bit 2)
     c.active = active;
-    c.xc = &xcache[0][0][0];
+    c.xc = (L.rel_refs & 4) ? xcache_dyn : nullptr;
     {
         for (u32 i0 = op_lo; i0 < op_hi; i0 += 64) {
             load_chunk(&chunk, L.tape, i0, op_hi);
@@ -2337,6 +2338,71 @@ extern "C" int h2e_engine_set_consts(int field_pair, const H2EFieldConsts* host)
                                   hipMemcpyHostToDevice);
 }
 
+// ------------------------------------------------------------------------------------------------
+// On-device consumer of a streaming job (SURVEY.md 8d cfg 3 / 8e): a 32-byte digest per instance of one region's
+// batch-interleaved advice array, so that tiles can be checked / gathered without their 1.2 GB leaving the GPU.
+//   digest[j] = sum over assigned cells (row, col) of  sm(w_j ^ sm(row * COLS + col) ^ j * 0xA24BAED4963EE407)   (mod 2^64)
+// with sm = the SplitMix64 finaliser and w_0..w_3 the cell's words: a sum, so the order cells are visited in does not
+// matter (oracle/digest.hpp computes the same over its Records).  HBM bound: every cell is read once; a wave reads one
+// (row, col, half) of 64 instances per load (1 KB contiguous).
+WI_INLINE u64 h2e_sm64(u64 z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+template <int COLS>
+__global__ void __launch_bounds__(256) h2e_digest(const ulonglong2* __restrict__ in, const uint8_t* __restrict__ flags, u64 rows,
+                                                  u32 n_inst, u64* __restrict__ out) {
+    constexpr u32 TR = 64;   // rows per tile; the 4 waves of a block take every 4th row of a tile
+    u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    u64 tiles = (rows + TR - 1) / TR;
+    for (u32 i0 = 0; i0 < n_inst; i0 += 64) {
+        u32 inst = i0 + lane;
+        bool live = inst < n_inst;
+        u64 d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        for (u64 t = blockIdx.x; t < tiles; t += gridDim.x) {
+            u64 r1 = min(rows, (t + 1) * TR);
+            for (u64 row = t * TR + wave; row < r1; row += 4) {
+#pragma unroll
+                for (int col = 0; col < COLS; col++) {
+                    u64 cell = row * COLS + col;
+                    if (flags != nullptr && !(flags[cell] & 1)) continue;   // wave-uniform
+                    if (!live) continue;
+                    ulonglong2 lo = in[(cell * 2) * n_inst + inst], hi = in[(cell * 2 + 1) * n_inst + inst];
+                    u64 tt = h2e_sm64(cell);
+                    d0 += h2e_sm64(lo.x ^ tt);
+                    d1 += h2e_sm64(lo.y ^ tt ^ 0xA24BAED4963EE407ull);
+                    d2 += h2e_sm64(hi.x ^ tt ^ (2 * 0xA24BAED4963EE407ull));
+                    d3 += h2e_sm64(hi.y ^ tt ^ (3 * 0xA24BAED4963EE407ull));
+                }
+            }
+        }
+        if (live) {
+            atomicAdd((unsigned long long*)&out[(size_t)inst * 4 + 0], (unsigned long long)d0);
+            atomicAdd((unsigned long long*)&out[(size_t)inst * 4 + 1], (unsigned long long)d1);
+            atomicAdd((unsigned long long*)&out[(size_t)inst * 4 + 2], (unsigned long long)d2);
+            atomicAdd((unsigned long long*)&out[(size_t)inst * 4 + 3], (unsigned long long)d3);
+        }
+    }
+}
+extern "C" int h2e_engine_digest(uint32_t cols, const void* in, const uint8_t* flags, uint64_t rows, uint32_t n_instances, void* out,
+                                 hipStream_t stream) {
+    if (n_instances == 0) return 0;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)n_instances * 32, stream);
+    if (e != hipSuccess) return (int)e;
+    if (rows == 0) return 0;
+    u64 tiles = (rows + 63) / 64;
+    dim3 grid((u32)std::min<u64>(tiles, 2048)), block(256);
+    switch (cols) {
+        case 5: hipLaunchKernelGGL(h2e_digest<5>, grid, block, 0, stream, (const ulonglong2*)in, flags, rows, n_instances, (u64*)out); break;
+        case 3: hipLaunchKernelGGL(h2e_digest<3>, grid, block, 0, stream, (const ulonglong2*)in, flags, rows, n_instances, (u64*)out); break;
+        case 2: hipLaunchKernelGGL(h2e_digest<2>, grid, block, 0, stream, (const ulonglong2*)in, flags, rows, n_instances, (u64*)out); break;
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+
 __global__ void h2e_or_status(const InstanceDesc* inst, u32 n_instances, u32 bits) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_instances) atomicOr(inst[i].status, bits);
@@ -2345,6 +2411,17 @@ extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances,
     if (n_instances == 0) return 0;
     hipLaunchKernelGGL(h2e_or_status, dim3((n_instances + 63) / 64), dim3(64), 0, stream, (const InstanceDesc*)instances, n_instances, bits);
     return (int)hipGetLastError();
+}
+
+// Tuning knobs (h2e_capi.cpp reads H2E_TUNE once, at h2e_ctx_create): [0] LDS bytes a small predictor grid reserves so
+// that no expansion wave shares its CU, [1] expansion result cache in LDS on / off, [2] extra dynamic LDS per expansion
+// workgroup (caps its waves per CU).  Defaults (profiles/r2_tune_sweep.txt): nothing reserved and no result cache -
+// with the batch-interleaved layout an operand re-read is a coalesced 1 KB load and the cache buys the expansion
+// nothing (11.6 vs 11.7 ms), while the 15 KB of LDS per workgroup it held kept the value chain's replay workgroups
+// (95-135 KB of LDS each) of the next run from sharing CUs with the expansion: pipelined step 24.0 -> 20.9 ms.
+static int g_tune[3] = {0, 0, 0};
+extern "C" void h2e_engine_set_tuning(int key, int value) {
+    if (key >= 0 && key < 3) g_tune[key] = value;
 }
 
 // mode: 1 = values-only replay (whole tape per lane), 2 = full expansion (sub-ranges if any), 4 = inverse fix-up
@@ -2356,7 +2433,9 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
     u32 n_sub = launch->n_sub > 1 ? launch->n_sub : 1;
     dim3 block(64), grid1(blocks_per_sub), grid(blocks_per_sub * n_sub);
     const InstanceDesc* inst = (const InstanceDesc*)instances;
-    size_t xlds = 0;
+    const bool xcache_on = g_tune[1] != 0;
+    H2ELaunch launch_x = *launch;
+    if (xcache_on) launch_x.rel_refs |= 4u;
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
     if ((mode & 1) && launch->lrecs) {                                                                                         \
         hipLaunchKernelGGL(h2e_replay_levels<FP>, dim3(n_instances * launch->n_strands), dim3(64 * H2E_LEVEL_WAVES),          \
@@ -2372,7 +2451,10 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
                            ((size_t)launch->v_units * 2 + ((size_t)launch->v_int_slots * VSlots<FP>::W + VSlots<FP>::NF * 4)) * 64 * 8, \
                            stream, *launch, inst, n_instances);                                                                \
     if ((mode & 1) && !launch->vtape) return -2;   /* a values-only replay always runs from the compiled V-tape */          \
-    if (mode & 2) hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid, block, xlds, stream, *launch, inst, n_instances, fc_dev);
+    if (mode & 2)                                                                                                              \
+        hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid, block,                                                             \
+                           (xcache_on ? (size_t)3 * (2 * FP::L + 4) * 64 * 8 : 0) + (grid.x > 4096 ? (size_t)g_tune[2] : 0),   \
+                           stream, launch_x, inst, n_instances, fc_dev);
     switch (field_pair) {
         case 0: { H2E_LAUNCH_FP(FP_BN256_FQ) } break;
         case 1: { H2E_LAUNCH_FP(FP_BLS_FQ) } break;
@@ -2402,7 +2484,7 @@ extern "C" int h2e_engine_predict(int field_pair, int phase, const H2EPreKernel*
     dim3 block(64), grid((lanes + 63) / 64);
     // A latency-bound predictor (few waves) must not share its CU with expansion waves of another stream: ask
     // for most of the CU's LDS so that nothing else fits next to it.
-    size_t lds_reserve = grid.x <= 512 ? 140 * 1024 : 0;
+    size_t lds_reserve = grid.x <= 512 ? (size_t)g_tune[0] : 0;
     u32 n_hints = k->n_lanes * k->hints_per_lane;
     u32 chunks = (n_hints + HINT_K - 1) / HINT_K;
     dim3 grid2((n_instances * chunks + 63) / 64);

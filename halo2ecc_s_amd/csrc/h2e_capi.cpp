@@ -13,6 +13,9 @@
 extern "C" int h2e_engine_set_consts(int field_pair, const H2EFieldConsts* host);
 extern "C" int h2e_engine_export(uint32_t cols, int columns, int mont, const void* in, void* out, const uint8_t* flags, uint64_t rows,
                                  uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream);
+extern "C" int h2e_engine_digest(uint32_t cols, const void* in, const uint8_t* flags, uint64_t rows, uint32_t n_instances, void* out,
+                                 hipStream_t stream);
+extern "C" void h2e_engine_set_tuning(int key, int value);
 extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances, uint32_t bits, hipStream_t stream);
 extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
                                  uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream);
@@ -94,6 +97,7 @@ struct h2e_program {
     std::vector<uint32_t> seg_l_begin, seg_l_steps, seg_l_slots;
     H2EVRec* d_lrecs = nullptr;
     uint32_t* d_lrefs = nullptr;
+    int64_t tail_from = -1;   // first segment of the program's serial tail (runs on the job slot's side stream), -1: none
     uint8_t* d_flags[3] = {nullptr, nullptr, nullptr};   // assigned / permute bytes on the device (h2e_export masks with them)
 
     ~h2e_program() {
@@ -1337,6 +1341,23 @@ struct h2e_program {
         assign_expansion_slots();
         mark_deferrable();
         mark_side_segments();
+        // The serial tail of the program: the last cut single-strand segment whose predictor chain already starts early
+        // on the side stream (it only needs an earlier segment's predictors - the MSM tail), provided nothing after it
+        // forks again.  Its whole value chain, and whatever follows it, runs on the job slot's side stream (run_impl).
+        tail_from = -1;
+        for (size_t si = 0; si < r.segments.size(); si++) {
+            const h2e::Segment& sg = r.segments[si];
+            if (sg.tape_end <= sg.tape_begin || sg.n_strands != 1 || sg.n_cuts == 0) continue;
+            bool early_chain = false;
+            for (auto& pk : r.pre_kernels) early_chain = early_chain || (pk.before_segment == si && pk.early_after_segment >= 0);
+            bool forks_later = false;
+            for (size_t sj = si + 1; sj < r.segments.size(); sj++)
+                forks_later = forks_later || (r.segments[sj].tape_end > r.segments[sj].tape_begin && r.segments[sj].n_strands > 1);
+            if (early_chain && !forks_later) {
+                tail_from = (int64_t)si;
+                break;
+            }
+        }
         // which of the 8 value-hint slots per ecc op does anything read?  (finalize_ecc skips the others)
         for (auto& pk : r.pre_kernels) {
             if (!pk.k.ecc_ops) continue;
@@ -1399,6 +1420,15 @@ struct JobSlot {
     std::vector<hipEvent_t> ev;       // profiling: 4 per launched segment (value-chain begin/end, expansion begin/end)
     std::vector<hipEvent_t> sync_ev;  // cross-stream dependencies
     hipEvent_t done = nullptr;        // recorded when every stream of the slot's last run has finished
+    hipEvent_t order_ev = nullptr;    // the caller's stream at submission (h2e_submit)
+    // Side stream of the slot: early predictors, fork segments outside the chain, and the *serial tail* of a program
+    // (the MSM tail: a single-wave 13 ms predictor chain + its replay).  Per slot, so that the tail of run k and the
+    // value chain of run k + 1 (caller's stream) run side by side - the tail chain is latency-, not throughput-bound.
+    hipStream_t side_stream = nullptr;
+    // Chain stream of the slot (h2e_submit only): the run's value chain is queued here, ordered after what the caller's
+    // stream held at submission, so that the value chains of consecutive runs overlap each other as well - each of their
+    // kernels is latency-bound and leaves most of the GPU idle.
+    hipStream_t chain_stream = nullptr;
     bool used = false;
     bool profiled = false;            // the last run on this slot recorded `ev`
     uint32_t n_launches = 0;
@@ -1407,6 +1437,9 @@ struct JobSlot {
         for (auto e : ev) (void)hipEventDestroy(e);
         for (auto e : sync_ev) (void)hipEventDestroy(e);
         if (done) (void)hipEventDestroy(done);
+        if (order_ev) (void)hipEventDestroy(order_ev);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
+        if (chain_stream) (void)hipStreamDestroy(chain_stream);
         (void)hipFree(ws_hints);
         (void)hipFree(ws_nd);
         (void)hipFree(ws_jac);
@@ -1425,11 +1458,11 @@ struct h2e_ctx {
     uint64_t n_runs = 0;     // runs submitted so far: run k uses slot k % N_SLOTS
     int last_slot = -1;
     hipStream_t expand_stream = nullptr;
-    hipStream_t early_stream = nullptr;
     hipStream_t fixup_stream = nullptr;
     // tuning knobs, read once at h2e_ctx_create (H2E_X_SPLIT, H2E_X_SPLIT_MIN_LANES); h2e_ctx_set_option overrides
     uint32_t x_split_pct = 45;
     uint64_t x_split_min_lanes = 1ull << 21;
+    int prio_expand = 0, prio_side = 0, prio_fixup = 0;   // HIP stream priorities (H2E_STREAM_PRIORITIES="x,s,f"; lower = higher priority)
     int64_t test_skip_expansion = INT64_MIN;   // test hook (h2e_ctx_set_option): see H2E_OPT_TEST_SKIP_EXPANSION
     uint32_t last_split_segments = 0;          // segments of the last run whose expansion was split (h2e_ctx_get_stat)
     std::mutex mu;                             // h2e_run / h2e_submit on one context are serialised on the host
@@ -1439,7 +1472,6 @@ struct h2e_ctx {
             if (d_fc[i]) (void)hipFree(d_fc[i]);
         for (auto& sl : slots) sl.release();
         if (expand_stream) (void)hipStreamDestroy(expand_stream);
-        if (early_stream) (void)hipStreamDestroy(early_stream);
         if (fixup_stream) (void)hipStreamDestroy(fixup_stream);
     }
 };
@@ -1460,6 +1492,14 @@ int h2e_ctx_create(int device, h2e_ctx** out) {
     // tuning knobs are read once, here (nothing reads the environment while a run is being queued)
     if (const char* e1 = getenv("H2E_X_SPLIT")) c->x_split_pct = (uint32_t)std::max(0, std::min(100, atoi(e1)));
     if (const char* e2 = getenv("H2E_X_SPLIT_MIN_LANES")) c->x_split_min_lanes = (uint64_t)atoll(e2);
+    if (const char* e4 = getenv("H2E_TUNE")) {   // "reserve,xcache,xpad" (engine.hip g_tune)
+        int a = 0, b = 0, d = 0;
+        sscanf(e4, "%d,%d,%d", &a, &b, &d);
+        h2e_engine_set_tuning(0, a);
+        h2e_engine_set_tuning(1, b);
+        h2e_engine_set_tuning(2, d);
+    }
+    if (const char* e3 = getenv("H2E_STREAM_PRIORITIES")) sscanf(e3, "%d,%d,%d", &c->prio_expand, &c->prio_side, &c->prio_fixup);
     *out = c;
     return 0;
 }
@@ -1607,6 +1647,55 @@ int h2e_program_pairing_check_bls12_381(int emit_shape, h2e_program** out) {
     return 0;
 }
 
+// pairing(terms) [== expected]: the first block of the reference's pairing tests
+// (src/tests/native_scalar_pairing_chip.rs:20-65 with one pair, general_scalar_pairing_chip.rs:20-72 with two)
+int h2e_program_pairing(int curve, uint32_t n_pairs, int with_expected, int emit_shape, h2e_program** out) {
+    h2e_program* p = nullptr;
+    if (curve != 0 && curve != 1) return fail(H2E_ERR_INVALID, "curve must be 0 (bn256) or 1 (bls12_381)");
+    if (n_pairs == 0 || n_pairs > 8) return fail(H2E_ERR_INVALID, "n_pairs must be 1..8");
+    int rc = new_program(curve == 0 ? H2E_FIELD_BN256_FQ : H2E_FIELD_BLS12_381_FQ, emit_shape, out, p);
+    if (rc) return rc;
+    GUARDED({
+        h2e::Recorder& r = *p->rec;
+        r.auto_cut_every = 16;
+        uint32_t s = r.alloc_inputs(7 * n_pairs + (with_expected ? 12 : 0));
+        h2e::NativeScalarEccContext ecc(r, curve == 0 ? h2e::bn256_g1_params() : h2e::bls12_381_g1_params(), 0);
+        std::unique_ptr<h2e::PairingOps> po;
+        if (curve == 0) po.reset(new h2e::Bn256PairingOps(r));
+        else po.reset(new h2e::Bls12381PairingOps(r));
+        std::vector<h2e::AssignedG2Affine> g2;
+        for (uint32_t k = 0; k < n_pairs; k++) {
+            h2e::AssignedFq2 x{r.assign_int_constant_input(s + 4 * k + 0), r.assign_int_constant_input(s + 4 * k + 1)};
+            h2e::AssignedFq2 y{r.assign_int_constant_input(s + 4 * k + 2), r.assign_int_constant_input(s + 4 * k + 3)};
+            g2.push_back(h2e::AssignedG2Affine{x, y, h2e::AssignedCondition{r.assign_constant_u64(0)}});
+        }
+        uint32_t e0 = s + 4 * n_pairs;
+        h2e::AssignedFq12 expected;
+        if (with_expected) {   // fq12_assign_constant: c0.c0.c0, c0.c0.c1, c0.c1.c0, ... (fq12.rs:453-458)
+            h2e::AssignedInteger v[12];
+            for (int i = 0; i < 12; i++) v[i] = r.assign_int_constant_input(e0 + i);
+            expected = h2e::AssignedFq12{h2e::AssignedFq6{{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}},
+                                         h2e::AssignedFq6{{v[6], v[7]}, {v[8], v[9]}, {v[10], v[11]}}};
+        }
+        uint32_t p0 = e0 + (with_expected ? 12 : 0);
+        std::vector<h2e::AssignedPoint> g1;
+        for (uint32_t k = 0; k < n_pairs; k++) g1.push_back(ecc.assign_point(h2e::PointInput{p0 + 3 * k, p0 + 3 * k + 1, p0 + 3 * k + 2, false}));
+        std::vector<h2e::PairingOps::Term> terms;
+        for (uint32_t k = 0; k < n_pairs; k++) terms.push_back(h2e::PairingOps::Term(&g1[k], &g2[k]));
+        h2e::AssignedFq12 res = po->pairing(terms);
+        if (with_expected) po->fq12_assert_eq(expected, res);
+        const h2e::AssignedFq2* parts[6] = {&res.c0.c0, &res.c0.c1, &res.c0.c2, &res.c1.c0, &res.c1.c1, &res.c1.c2};
+        for (auto* f2 : parts)
+            for (const h2e::AssignedInteger* a : {&f2->c0, &f2->c1}) {
+                for (int i = 0; i < r.fp.limbs; i++) r.outputs.push_back(a->limbs_le[i]);
+                r.outputs.push_back(a->native);
+            }
+        p->finish();
+    })
+    *out = p;
+    return 0;
+}
+
 int h2e_program_shape(const h2e_program* p, h2e_shape* out) {
     if (!p || !out) return fail(H2E_ERR_INVALID, "null argument");
     const h2e::Recorder& r = *p->rec;
@@ -1711,18 +1800,26 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         HIP_TRY((hipError_t)h2e_engine_set_consts(fp, &field_pair(fp).fc));
     }
     h2e::Recorder& r = *p->rec;
-    if (!ctx->expand_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->expand_stream, hipStreamNonBlocking));
-    if (!ctx->early_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->early_stream, hipStreamNonBlocking));
-    if (!ctx->fixup_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->fixup_stream, hipStreamNonBlocking));
+    if (!ctx->expand_stream) HIP_TRY(hipStreamCreateWithPriority(&ctx->expand_stream, hipStreamNonBlocking, ctx->prio_expand));
+    if (!ctx->fixup_stream) HIP_TRY(hipStreamCreateWithPriority(&ctx->fixup_stream, hipStreamNonBlocking, ctx->prio_fixup));
     // Streams.  The *value chain* (predictor kernels + values-only replay, or the plain tape for segments without cuts)
     // runs on the caller's stream: it is what later segments depend on.  The full expansion of a cut segment only needs
     // the value chain up to that segment, so it runs on a second stream and overlaps the value chain of the following
-    // segments (and, with h2e_submit, of the following run); predictors that only depend on earlier predictors and fork
-    // segments outside the chain on a third; inverse fix-ups on a fourth.  (The runtime maps streams onto 4 hardware
-    // queues by default: a fifth stream would share one and serialise behind it.)
-    hipStream_t sa = stream, sb = ctx->expand_stream, sc = ctx->early_stream, sd = ctx->fixup_stream;
+    // segments (and, with h2e_submit, of the following run); predictors that only depend on earlier predictors, fork
+    // segments outside the chain and the program's serial tail on the slot's side stream; inverse fix-ups on a fourth.
+    // (The runtime maps a process's streams onto GPU_MAX_HW_QUEUES = 4 hardware queues by default; streams that share a
+    // queue serialise.  A host that pipelines runs should raise it to 8 before HIP initialises - bench.py does.)
     int slot_index = (int)(ctx->n_runs % h2e_ctx::N_SLOTS);
     JobSlot& J = ctx->slots[slot_index];
+    if (!J.side_stream) HIP_TRY(hipStreamCreateWithPriority(&J.side_stream, hipStreamNonBlocking, ctx->prio_side));
+    if (!join && !J.chain_stream) HIP_TRY(hipStreamCreateWithPriority(&J.chain_stream, hipStreamNonBlocking, ctx->prio_side));
+    if (!join) {   // the chain stream takes over from the caller's stream at this point
+        if (!J.order_ev) HIP_TRY(hipEventCreateWithFlags(&J.order_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(J.order_ev, stream));
+        HIP_TRY(hipStreamWaitEvent(J.chain_stream, J.order_ev, 0));
+    }
+    const hipStream_t sa_main = join ? stream : J.chain_stream;
+    hipStream_t sa = sa_main, sb = ctx->expand_stream, sc = J.side_stream, sd = ctx->fixup_stream;
     ctx->n_runs++;
     ctx->last_slot = slot_index;
     if (slot_out) *slot_out = slot_index;
@@ -1777,7 +1874,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         d.sel = J.ws_sel + (size_t)i * sel_words;
     }
     HIP_TRY(hipMemcpyAsync(J.d_inst, J.h_inst.data(), (size_t)n_instances * sizeof(InstanceDescHost),
-                           hipMemcpyHostToDevice, stream));
+                           hipMemcpyHostToDevice, sa));
     bool used_sd = false;
     std::vector<hipEvent_t> early_done(r.pre_kernels.size(), nullptr);
     size_t n_sync = 0;
@@ -1841,6 +1938,15 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     for (size_t si = 0; si < r.segments.size(); si++) {
         const h2e::Segment& s = r.segments[si];
         if (s.tape_end <= s.tape_begin) continue;
+        if ((int64_t)si == p->tail_from && sa == sa_main) {
+            // the serial tail of the program: from here on the value chain continues on the slot's side stream, and the
+            // caller's stream is free for the next run's value chain
+            hipEvent_t e = sync_event();
+            HIP_TRY(hipEventRecord(e, sa));
+            HIP_TRY(hipStreamWaitEvent(sc, e, 0));
+            sa = sc;
+            used_se = true;
+        }
         // side segments this one reads must be done
         for (size_t sj = 0; sj < si; sj++)
             if (side_done[sj] && p->seg_first_reader[sj] <= si) {
@@ -2057,7 +2163,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     // the caller's stream wait for it, h2e_submit leaves that to h2e_wait
     {
         hipEvent_t ea = sync_event();
-        HIP_TRY(hipEventRecord(ea, sa));
+        HIP_TRY(hipEventRecord(ea, sa_main));
         HIP_TRY(hipStreamWaitEvent(sd, ea, 0));
         hipEvent_t eb = sync_event();
         HIP_TRY(hipEventRecord(eb, sb));
@@ -2069,7 +2175,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         }
         (void)used_sd;
         HIP_TRY(hipEventRecord(J.done, sd));
-        if (join) HIP_TRY(hipStreamWaitEvent(sa, J.done, 0));
+        if (join) HIP_TRY(hipStreamWaitEvent(sa_main, J.done, 0));
     }
     return 0;
 }
@@ -2144,6 +2250,40 @@ int h2e_program_launches(const h2e_program* p, uint64_t* out, uint32_t cap) {
     return (int)k;
 }
 
+// the program's assigned / permute bytes of one region on the device (nullptr for programs recorded without their shape)
+static int device_flags(h2e_program* p, int region, const uint8_t** out) {
+    const h2e::Recorder& r = *p->rec;
+    *out = nullptr;
+    if (!r.emit_shape) return 0;
+    const uint32_t cols = region == 0 ? 5 : region == 1 ? 3 : 2;
+    const uint64_t rows = region == 0 ? p->base_rows : region == 1 ? p->range_rows : p->select_rows;
+    const std::vector<uint8_t>& hf = region == 0 ? r.base_flags : region == 1 ? r.range_flags : r.select_flags;
+    if (hf.size() < rows * cols) return fail(H2E_ERR_SHAPE, "internal: flag array shorter than the advice array");
+    if (!p->d_flags[region]) {
+        HIP_TRY(hipMalloc((void**)&p->d_flags[region], std::max<size_t>(16, rows * cols)));
+        HIP_TRY(hipMemcpy(p->d_flags[region], hf.data(), rows * cols, hipMemcpyHostToDevice));
+    }
+    *out = p->d_flags[region];
+    return 0;
+}
+
+int h2e_digest(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, const void* d_batch, void* d_digests, void* stream) {
+    if (!ctx || !p || !d_batch || !d_digests) return fail(H2E_ERR_INVALID, "null argument");
+    if (region < 0 || region > 2) return fail(H2E_ERR_INVALID, "region must be 0 (base), 1 (range) or 2 (select)");
+    if (n_instances == 0) return 0;
+    std::lock_guard<std::mutex> guard(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (p->device >= 0 && p->device != ctx->device) return fail(H2E_ERR_INVALID, "program bound to another device");
+    const uint8_t* d_flags = nullptr;
+    int rc = device_flags(p, region, &d_flags);
+    if (rc) return rc;
+    const uint32_t cols = region == 0 ? 5 : region == 1 ? 3 : 2;
+    const uint64_t rows = region == 0 ? p->base_rows : region == 1 ? p->range_rows : p->select_rows;
+    rc = h2e_engine_digest(cols, d_batch, d_flags, rows, n_instances, d_digests, (hipStream_t)stream);
+    if (rc != 0) return fail(H2E_ERR_HIP, rc < 0 ? "digest: bad geometry" : std::string("digest launch failed: ") + hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
 int h2e_export(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, int layout, int form, const void* d_batch,
                void* d_out, void* stream) {
     if (!ctx || !p || !d_batch || !d_out) return fail(H2E_ERR_INVALID, "null argument");
@@ -2154,18 +2294,12 @@ int h2e_export(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, i
     std::lock_guard<std::mutex> guard(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     if (p->device >= 0 && p->device != ctx->device) return fail(H2E_ERR_INVALID, "program bound to another device");
-    const h2e::Recorder& r = *p->rec;
     const uint32_t cols = region == 0 ? 5 : region == 1 ? 3 : 2;
     const uint64_t rows = region == 0 ? p->base_rows : region == 1 ? p->range_rows : p->select_rows;
-    const std::vector<uint8_t>& hf = region == 0 ? r.base_flags : region == 1 ? r.range_flags : r.select_flags;
     const uint8_t* d_flags = nullptr;
-    if (r.emit_shape) {
-        if (hf.size() < rows * cols) return fail(H2E_ERR_SHAPE, "internal: flag array shorter than the advice array");
-        if (!p->d_flags[region]) {
-            HIP_TRY(hipMalloc((void**)&p->d_flags[region], std::max<size_t>(16, rows * cols)));
-            HIP_TRY(hipMemcpy(p->d_flags[region], hf.data(), rows * cols, hipMemcpyHostToDevice));
-        }
-        d_flags = p->d_flags[region];
+    {
+        int frc = device_flags(p, region, &d_flags);
+        if (frc) return frc;
     }
     int fp = p->field_pair;
     if (!ctx->d_fc[fp]) {
@@ -2185,12 +2319,10 @@ int h2e_set_profiling(h2e_ctx* ctx, int enable) {
     ctx->profiling = enable != 0;
     return 0;
 }
-int h2e_last_run_launch_ms(h2e_ctx* ctx, float* ms, uint32_t cap) {
-    if (!ctx || !ms) return fail(H2E_ERR_INVALID, "null argument");
-    std::lock_guard<std::mutex> guard(ctx->mu);
-    if (ctx->last_slot < 0) return 0;
-    JobSlot& J = ctx->slots[ctx->last_slot];
-    if (!J.profiled) return 0;   // the last run recorded no events (profiling was off when it was queued)
+static int job_launch_ms(h2e_ctx* ctx, int job, float* ms, uint32_t cap) {
+    JobSlot& J = ctx->slots[job];
+    if (!J.profiled || !J.done) return 0;   // that run recorded no events (profiling was off when it was queued)
+    HIP_TRY(hipEventSynchronize(J.done));
     // two numbers per launched segment: value chain (predictors + values-only replay), expansion (+ fix-up)
     uint32_t n = std::min<uint32_t>(J.n_launches, (uint32_t)(J.ev.size() / 4));
     for (uint32_t i = 0; i < n && 2 * i + 1 < cap; i++) {
@@ -2202,6 +2334,17 @@ int h2e_last_run_launch_ms(h2e_ctx* ctx, float* ms, uint32_t cap) {
         ms[2 * i + 1] = t1;
     }
     return (int)n;
+}
+int h2e_last_run_launch_ms(h2e_ctx* ctx, float* ms, uint32_t cap) {
+    if (!ctx || !ms) return fail(H2E_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(ctx->mu);
+    if (ctx->last_slot < 0) return 0;
+    return job_launch_ms(ctx, ctx->last_slot, ms, cap);
+}
+int h2e_job_launch_ms(h2e_ctx* ctx, int job, float* ms, uint32_t cap) {
+    if (!ctx || !ms || job < 0 || job >= h2e_ctx::N_SLOTS) return fail(H2E_ERR_INVALID, "bad argument");
+    std::lock_guard<std::mutex> guard(ctx->mu);
+    return job_launch_ms(ctx, job, ms, cap);
 }
 
 int h2e_last_run_expansion_launches(h2e_ctx* ctx, uint32_t* counts, uint32_t cap) {

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "h2e_program_pairing_check_bls12_381", "h2e_program_destroy", "h2e_program_shape", "h2e_run",
     "h2e_int_mul_batch", "h2e_msm_bn256_tile", "h2e_pairing_check_bn256", "h2e_pairing_check_bls12_381",
     "h2e_last_run_launch_ms", "h2e_set_profiling", "h2e_program_outputs", "h2e_program_launches", "h2e_export",
-    "h2e_submit", "h2e_wait", "h2e_ctx_set_option", "h2e_ctx_get_stat",
+    "h2e_submit", "h2e_wait", "h2e_job_launch_ms", "h2e_digest", "h2e_program_pairing", "h2e_ctx_set_option", "h2e_ctx_get_stat",
     "h2e_program_msm_bn256_tile_no_select", "h2e_last_run_expansion_launches",
 ]
 
@@ -79,6 +79,7 @@ def lib():
     L.h2e_program_msm_bn256_tile_no_select.argtypes = [u32, i32, C.POINTER(vp)]
     L.h2e_program_pairing_check_bn256.argtypes = [i32, C.POINTER(vp)]
     L.h2e_program_pairing_check_bls12_381.argtypes = [i32, C.POINTER(vp)]
+    L.h2e_program_pairing.argtypes = [i32, u32, i32, i32, C.POINTER(vp)]
     L.h2e_program_destroy.argtypes = [vp]
     L.h2e_program_destroy.restype = None
     L.h2e_program_shape.argtypes = [vp, C.POINTER(_Shape)]
@@ -89,10 +90,12 @@ def lib():
     L.h2e_pairing_check_bls12_381.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     L.h2e_last_run_launch_ms.argtypes = [vp, C.POINTER(C.c_float), u32]
     L.h2e_set_profiling.argtypes = [vp, i32]
+    L.h2e_job_launch_ms.argtypes = [vp, i32, C.POINTER(C.c_float), u32]
     L.h2e_last_run_expansion_launches.argtypes = [vp, C.POINTER(u32), u32]
     L.h2e_program_outputs.argtypes = [vp, C.POINTER(u32), u32]
     L.h2e_program_launches.argtypes = [vp, C.POINTER(C.c_uint64), u32]
     L.h2e_export.argtypes = [vp, vp, u32, i32, i32, i32, vp, vp, vp]
+    L.h2e_digest.argtypes = [vp, vp, u32, i32, vp, vp, vp]
     L.h2e_submit.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
     L.h2e_wait.argtypes = [vp, i32, vp]
     L.h2e_ctx_set_option.argtypes = [vp, i32, C.c_int64]
@@ -152,6 +155,11 @@ class Program:
     def pairing_check_bls12_381(cls, emit_shape=True):
         return cls._make(lib().h2e_program_pairing_check_bls12_381, int(emit_shape))
 
+    @classmethod
+    def pairing(cls, curve, n_pairs, with_expected, emit_shape=True):
+        """pairing(terms) [+ fq12_assert_eq(expected, result)]; curve 0 = bn256, 1 = bls12_381"""
+        return cls._make(lib().h2e_program_pairing, curve, n_pairs, int(with_expected), int(emit_shape))
+
     # ---- shape artefacts (numpy views; valid while the program is alive) ----
     def fixed_dict(self):
         return _view(self.shape.dict, self.n_dict * 4, np.uint64).reshape(-1, 4)
@@ -181,8 +189,8 @@ class Program:
         return _view(self.shape.fixed_patches, self.n_fixed_patches * 4, np.uint32).reshape(-1, 4)
 
     def outputs(self):
-        buf = (C.c_uint32 * 64)()
-        n = lib().h2e_program_outputs(self._h, buf, 64)
+        buf = (C.c_uint32 * 256)()
+        n = lib().h2e_program_outputs(self._h, buf, 256)
         return [int(buf[i]) for i in range(n)]
 
     def launches(self):
@@ -276,6 +284,16 @@ class Engine:
                                 self._stream(stream).cuda_stream))
         return out
 
+    def digest(self, program, region, batch, stream=None, out=None):
+        """h2e_digest: 32-byte digest per instance of one region's batch-interleaved array -> int64 tensor [instances][4]"""
+        t = self.torch
+        rows, cols, two, n, w = batch.shape
+        assert two == 2 and w == 2 and cols == COLS[region] and batch.is_contiguous()
+        if out is None:
+            out = t.empty((n, 4), dtype=t.int64, device=batch.device)
+        _check(lib().h2e_digest(self._h, program._h, n, region, batch.data_ptr(), out.data_ptr(), self._stream(stream).cuda_stream))
+        return out
+
     def read_cell(self, base, ref, instance):
         """value of a base-chip cell reference (region << 30 | col << 27 | row) of one instance, as a Python int"""
         region, col, row = ref >> 30, (ref >> 27) & 7, ref & 0x3FFFFFF
@@ -296,6 +314,14 @@ class Engine:
         """per launched segment: (value-chain ms, expansion ms), from HIP events on the launching streams"""
         buf = (C.c_float * cap)()
         n = lib().h2e_last_run_launch_ms(self._h, buf, cap)
+        if n < 0:
+            _check(n)
+        return [(buf[2 * i], buf[2 * i + 1]) for i in range(min(n, cap // 2))]
+
+    def job_launch_ms(self, job, cap=128):
+        """the same for the last run queued on job slot `job` (waits on the host until that run is complete)"""
+        buf = (C.c_float * cap)()
+        n = lib().h2e_job_launch_ms(self._h, job, buf, cap)
         if n < 0:
             _check(n)
         return [(buf[2 * i], buf[2 * i + 1]) for i in range(min(n, cap // 2))]

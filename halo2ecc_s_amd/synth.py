@@ -248,3 +248,22 @@ def pairing_check_bls12_381_inputs(seed_index=5, instance=0):
     na = ec_neg(a)
     vals = [b[0].a, b[0].b, b[1].a, b[1].b, bc[0].a, bc[0].b, bc[1].a, bc[1].b, na[0].a, na[1].a, 0, ac[0].a, ac[1].a, 0]
     return pack(vals, 6)
+
+
+def pairing_inputs(curve, n_pairs, seed_index=6, instance=0, expected=None):
+    """inputs of h2e_program_pairing: per pair the G2 point (constants), [the expected Fq12 value: 12 W values], per pair the
+    G1 point.  curve 0 = bn256, 1 = bls12_381.  `expected` = list of 12 ints (the native pairing value, in the
+    reference's tests computed by the curve library: src/tests/native_scalar_pairing_chip.rs:29, general_...:30-33)"""
+    rng = SplitMix64(SEED0 + seed_index + 1000003 * instance + 7919 * curve)
+    g1, g2, r, sw = (bn_g1_gen(), bn_g2_gen(), BN_R, 4) if curve == 0 else (bls_g1_gen(), bls_g2_gen(), BLS_R, 6)
+    a = [ec_mul(g1, rng.below(r)) for _ in range(n_pairs)]
+    b = [ec_mul(g2, rng.below(r)) for _ in range(n_pairs)]
+    vals = []
+    for q in b:
+        vals += [q[0].a, q[0].b, q[1].a, q[1].b]
+    if expected is not None:
+        assert len(expected) == 12
+        vals += list(expected)
+    for p in a:
+        vals += [p[0].a, p[1].a, 0]
+    return pack(vals, sw)

@@ -91,6 +91,13 @@ int h2e_program_pairing_check_bn256(int emit_shape, h2e_program** out);
 /* check_pairing([(ac, b), (-a, bc)]) (shape of src/tests/general_scalar_pairing_chip.rs:74-105).
  * inputs: b.x.c0,b.x.c1,b.y.c0,b.y.c1, bc.x.c0,bc.x.c1,bc.y.c0,bc.y.c1, (-a).x,(-a).y,(-a).z, ac.x,ac.y,ac.z. */
 int h2e_program_pairing_check_bls12_381(int emit_shape, h2e_program** out);
+/* pairing(terms) with n_pairs (G1 assigned, G2 constant) pairs, and - with_expected - fq12_assert_eq against an Fq12
+ * constant: the first block of the reference's pairing tests (PairingChipOps::pairing, src/circuit/pairing_chip.rs:157-171;
+ * src/tests/native_scalar_pairing_chip.rs:20-65: 1 pair == native pairing(); general_scalar_pairing_chip.rs:20-72: the
+ * product of 2 pairs == native).  curve: 0 = bn256, 1 = bls12_381.
+ * inputs: per pair b.x.c0, b.x.c1, b.y.c0, b.y.c1; [expected: 12 W values c0.c0.c0, c0.c0.c1, c0.c1.c0, ... c1.c2.c1];
+ * per pair a.x, a.y, a.z.  outputs (h2e_program_outputs): the 12 result integers' cells (limbs, native each). */
+int h2e_program_pairing(int curve, uint32_t n_pairs, int with_expected, int emit_shape, h2e_program** out);
 void h2e_program_destroy(h2e_program* p);
 
 /* ---- shape artefacts: what Records holds besides advice values -------------------------------- */
@@ -190,12 +197,22 @@ int h2e_pairing_check_bls12_381(h2e_ctx* ctx, uint32_t n_instances, const void* 
 int h2e_export(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, int layout, int form, const void* d_batch,
                void* d_out, void* stream);
 
+/* On-device consumer for streaming jobs (SURVEY.md 8d cfg 3, 8e): a 32-byte digest per instance of one region's
+ * batch-interleaved array, d_digests = [n_instances][4] words:
+ *   digest[j] = sum over assigned cells (row, col) of sm(w_j ^ sm(row * COLS + col) ^ j * 0xA24BAED4963EE407)  mod 2^64,
+ * sm = the SplitMix64 finaliser (z += 0x9E3779B97F4A7C15; z = (z ^ z >> 30) * 0xBF58476D1CE4E5B9;
+ * z = (z ^ z >> 27) * 0x94D049BB133111EB; z ^ z >> 31), w_0..w_3 the cell's canonical words.  Programs recorded
+ * without their shape digest every cell of the array.  Asynchronous on `stream`. */
+int h2e_digest(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, const void* d_batch, void* d_digests, void* stream);
+
 /* Timing hook used by bench.py: HIP events recorded by the engine on the stream each kernel group is launched
  * on.  Returns the number of launched segments and fills two numbers per segment: ms[2i] = value chain
  * (predictor kernels + values-only replay), ms[2i+1] = full expansion (the inverse fix-up runs on its own stream and is not included; call after synchronising).
  * Refers to the most recently queued run; returns 0 when that run was queued with profiling off. */
 int h2e_last_run_launch_ms(h2e_ctx* ctx, float* ms, uint32_t cap);
 int h2e_set_profiling(h2e_ctx* ctx, int enable);
+/* the same for the last run queued on job slot `job` (h2e_submit); waits on the host for that run to complete */
+int h2e_job_launch_ms(h2e_ctx* ctx, int job, float* ms, uint32_t cap);
 /* Companion of h2e_last_run_launch_ms: counts[i] = kernel launches the full expansion of segment i went out as in the
  * last run (1, or 2 when a big expansion was split - ms[2i+1] then brackets both; see h2e_capi.cpp `expand`). */
 int h2e_last_run_expansion_launches(h2e_ctx* ctx, uint32_t* counts, uint32_t cap);

@@ -5,6 +5,7 @@
 // vector, with the CPU restatement, and keeps the resulting Records for export / checking.
 #include <chrono>
 #include <cstring>
+#include <memory>
 #include "checker.hpp"
 #include "pairing.hpp"
 #include "testutil.hpp"
@@ -137,6 +138,39 @@ void* oracle_run_pairing_check_bn256(const uint64_t* inputs) {
     });
 }
 
+// first block of the pairing tests: pairing(terms) [== expected]
+// (src/tests/native_scalar_pairing_chip.rs:20-65, general_scalar_pairing_chip.rs:20-72); same inputs as h2e_program_pairing
+void* oracle_run_pairing(int curve, uint32_t n_pairs, int with_expected, const uint64_t* inputs) {
+    return guarded([&](Run& r) {
+        IntegerContext ic(r.ctx, curve == 0 ? BnFq::modulus() : BlsFq::modulus());
+        Inputs in{inputs, curve == 0 ? 4 : 6};
+        NativeScalarEccContext ecc(ic, curve == 0 ? bn256_g1_params() : bls12_381_g1_params(), 0);
+        std::unique_ptr<PairingOps> po;
+        if (curve == 0) po.reset(new Bn256PairingOps(ecc.base));
+        else po.reset(new Bls12381PairingOps(ecc.base));
+        std::vector<AssignedG2Affine> g2;
+        for (uint32_t k = 0; k < n_pairs; k++) {
+            AssignedFq2 x = po->fq2_assign_constant(Fq2Const{in.w(4 * k), in.w(4 * k + 1)});
+            AssignedFq2 y = po->fq2_assign_constant(Fq2Const{in.w(4 * k + 2), in.w(4 * k + 3)});
+            g2.push_back(AssignedG2Affine{x, y, AssignedCondition(r.ctx->assign_constant(Fr::zero()))});
+        }
+        uint32_t e0 = 4 * n_pairs;
+        AssignedFq12 expected;
+        if (with_expected) {
+            AssignedFq2 v[6];
+            for (int i = 0; i < 6; i++) v[i] = po->fq2_assign_constant(Fq2Const{in.w(e0 + 2 * i), in.w(e0 + 2 * i + 1)});
+            expected = AssignedFq12{AssignedFq6{v[0], v[1], v[2]}, AssignedFq6{v[3], v[4], v[5]}};
+        }
+        uint32_t p0 = e0 + (with_expected ? 12 : 0);
+        std::vector<AssignedPoint> g1;
+        for (uint32_t k = 0; k < n_pairs; k++) g1.push_back(ecc.assign_point(in.point(p0 + 3 * k, p0 + 3 * k + 1, p0 + 3 * k + 2)));
+        std::vector<PairingOps::Term> terms;
+        for (uint32_t k = 0; k < n_pairs; k++) terms.push_back(PairingOps::Term(&g1[k], &g2[k]));
+        AssignedFq12 res = po->pairing(terms);
+        if (with_expected) po->fq12_assert_eq(expected, res);
+    });
+}
+
 // second block of src/tests/general_scalar_pairing_chip.rs:74-105
 void* oracle_run_pairing_check_bls12_381(const uint64_t* inputs) {
     return guarded([&](Run& r) {
@@ -203,6 +237,27 @@ void oracle_export_adv(void* h, int region, uint64_t* out, uint8_t* flags, uint6
             }
             flags[row * cols + c] = row < have ? (uint8_t)(v[row * cols + c].present | (v[row * cols + c].permute << 1)) : 0;
         }
+}
+// The streaming-job digest of one advice array (definition: include/h2e.h, h2e_digest): sum over assigned cells of
+// sm(w_j ^ sm(row * COLS + col) ^ j * 0xA24BAED4963EE407) mod 2^64, sm = SplitMix64 finaliser, w = canonical words.
+static uint64_t digest_sm64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+void oracle_digest(void* h, int region, uint64_t* out4) {
+    Run* r = (Run*)h;
+    RecordsInner& in = *r->ctx->records.inner;
+    const std::vector<AdvCell>& v = region == 0 ? in.base_adv : region == 1 ? in.range_adv : in.select_adv;
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    for (size_t cell = 0; cell < v.size(); cell++) {
+        if (!v[cell].present) continue;
+        uint64_t w[4];
+        v[cell].val.to_canonical(w);
+        uint64_t t = digest_sm64((uint64_t)cell);
+        for (int j = 0; j < 4; j++) out4[j] += digest_sm64(w[j] ^ t ^ ((uint64_t)j * 0xA24BAED4963EE407ull));
+    }
 }
 void oracle_export_fix(void* h, int region, uint64_t* out, uint8_t* present, uint64_t rows) {
     Run* r = (Run*)h;

@@ -31,18 +31,21 @@ def load():
     L = C.CDLL(LIB)
     vp = C.c_void_p
     for name in ("oracle_run_int_mul_batch", "oracle_run_integer_chip_st", "oracle_run_msm_bn256_tile",
-                 "oracle_run_msm_bn256_tile_no_select", "oracle_run_pairing_check_bn256", "oracle_run_pairing_check_bls12_381"):
+                 "oracle_run_msm_bn256_tile_no_select", "oracle_run_pairing_check_bn256", "oracle_run_pairing_check_bls12_381", "oracle_run_pairing"):
         getattr(L, name).restype = vp
     L.oracle_run_int_mul_batch.argtypes = [C.c_int, C.c_uint32, vp]
     L.oracle_run_integer_chip_st.argtypes = [C.c_int, vp]
     L.oracle_run_msm_bn256_tile.argtypes = [C.c_uint32, vp, C.c_int]
     L.oracle_run_msm_bn256_tile_no_select.argtypes = [C.c_uint32, vp, C.c_int]
+    L.oracle_run_pairing.argtypes = [C.c_int, C.c_uint32, C.c_int, vp]
     L.oracle_run_pairing_check_bn256.argtypes = [vp]
     L.oracle_run_pairing_check_bls12_381.argtypes = [vp]
     L.oracle_info.argtypes = [vp, C.POINTER(Info)]
     L.oracle_error.argtypes = [vp]
     L.oracle_error.restype = C.c_char_p
     L.oracle_export_adv.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
+    L.oracle_digest.argtypes = [vp, C.c_int, vp]
+    L.oracle_digest.restype = None
     L.oracle_export_fix.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
     L.oracle_export_permutations.argtypes = [vp, vp]
     L.oracle_check.argtypes = [vp, C.c_char_p, C.c_int]
@@ -79,6 +82,12 @@ class Run:
         present = np.zeros((rows, cols), dtype=np.uint8)
         self.L.oracle_export_fix(self.h, region, out.ctypes.data, present.ctypes.data, rows)
         return out, present
+
+    def digest(self, region):
+        """32-byte streaming-job digest of one advice array (definition: include/h2e.h, h2e_digest)"""
+        out = np.zeros(4, dtype=np.uint64)
+        self.L.oracle_digest(self.h, region, out.ctypes.data)
+        return out
 
     def permutations(self):
         out = np.zeros((self.info.n_permutations, 2), dtype=np.uint32)
@@ -135,3 +144,8 @@ def run_pairing_check_bn256(inputs):
 def run_pairing_check_bls12_381(inputs):
     a, p = _ptr(inputs)
     return Run(load().oracle_run_pairing_check_bls12_381(p))
+
+
+def run_pairing(curve, n_pairs, with_expected, inputs):
+    a, p = _ptr(inputs)
+    return Run(load().oracle_run_pairing(curve, n_pairs, int(with_expected), p))

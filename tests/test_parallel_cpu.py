@@ -1,5 +1,7 @@
-"""world_size-2 gloo test of the N>1 path: units shard round-robin, each rank produces its units (here with
-the oracle standing in for the GPU worker), one all_gather of per-unit records, every rank sees all units."""
+"""world_size-2 gloo test of the N>1 path, through the same two functions bench.py's step uses
+(parallel.unit_records + parallel.gather_unit_records): units shard round-robin, each rank produces its units' arrays
+(here the oracle stands in for the GPU worker and its rows are laid out batch-interleaved like the engine's), builds the
+per-unit records {status, Offset, result point cells, digests}, one all_gather, every rank sees all units."""
 import os
 import sys
 
@@ -21,15 +23,30 @@ def _worker(rank, world, port, n_units, q):
     import oracle_lib
     from halo2ecc_s_amd import synth
     from halo2ecc_s_amd.parallel import gather_unit_records, shard_units
+    from halo2ecc_s_amd.parallel import unit_records, RECORD_WORDS
+    from halo2ecc_s_amd import Program
     units = shard_units(n_units, world, rank)
-    recs = []
+    n = 2
+    prog = Program.msm_bn256_tile(n)
+    runs = []
     for u in units:
-        inp, _ = synth.msm_bn256_tile_inputs(2, tile=u)
-        run = oracle_lib.run_msm_bn256_tile(2, inp)
-        recs.append([run.info.status, run.info.base_offset, run.info.n_advice_cells])
-        run.close()
-    local = torch.tensor(recs, dtype=torch.int64).reshape(len(units), 3)
+        inp, _ = synth.msm_bn256_tile_inputs(n, tile=u)
+        runs.append(oracle_lib.run_msm_bn256_tile(n, inp))
+    # this rank's base array, batch-interleaved [rows][5][half][unit][2] like the engine's output
+    rows = np.stack([r.adv(0, prog.base_rows)[0] for r in runs], axis=0)                  # [unit][row][5][4]
+    base = torch.from_numpy(np.ascontiguousarray(rows.reshape(len(units), prog.base_rows, 5, 2, 2).transpose(1, 2, 3, 0, 4)).view(np.int64))
+    status = torch.tensor([r.info.status for r in runs], dtype=torch.int32)
+    offsets = torch.tensor([prog.base_offset, prog.range_offset, prog.select_offset], dtype=torch.int64)
+    dig = torch.from_numpy(np.stack([[r.digest(region) for r in runs] for region in range(3)]).view(np.int64))   # [3][unit][4]
+    local = unit_records(status, offsets, base, prog.outputs(), dig)
+    assert local.shape == (len(units), RECORD_WORDS)
+    # the record's result point is the MSM result the oracle asserted equal to the expected input
+    for i, r in enumerate(runs):
+        x = sum((int(local[i, 4 + 2 * k]) & (2**64 - 1) | (int(local[i, 5 + 2 * k]) & (2**64 - 1)) << 64) << (108 * k) for k in range(3))
+        assert x % synth.BN_Q == sum(int(w) << (64 * j) for j, w in enumerate(synth.msm_bn256_tile_inputs(n, tile=units[i])[0][4 * n + 6]))
     allrec = gather_unit_records(units, local, n_units, world)
+    for r in runs:
+        r.close()
     q.put((rank, units, allrec.numpy().tolist()))
     dist.barrier()
     dist.destroy_process_group()
@@ -61,6 +78,7 @@ def test_gather_world2_gloo(oracle):
     assert by_rank[0][0] == [0, 2, 4] and by_rank[1][0] == [1, 3]
     assert by_rank[0][1] == by_rank[1][1]  # every rank sees the same gathered table
     table = np.array(by_rank[0][1])
-    assert table.shape == (n_units, 3)
+    assert table.shape == (n_units, 29)
     assert (table[:, 0] == 0).all()          # every unit OK
     assert len(set(table[:, 1])) == 1        # same shape -> same offsets
+    assert len(set(map(tuple, table[:, 17:29]))) == n_units   # different inputs -> different digests

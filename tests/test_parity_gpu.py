@@ -272,6 +272,212 @@ def test_pairing_check_bls12_381(engine, oracle):
     compare_advice(prog, orun, base, rng, sel, instance=0)
 
 
+def test_poisoned_buffers_only_assigned_cells_are_written(engine, oracle):
+    """The engine writes assigned cells only (include/h2e.h): after a run into 0xFF-filled arrays every assigned cell
+    equals the oracle's and every other word is still 0xFF - rows after the last op, holes inside rows and the
+    unused select array of an integer-only program included (trailing rows are owned by no op)."""
+    cases = [(Program.integer_chip_st(0), [synth.integer_chip_st_inputs(0, seed_index=77 + k) for k in range(3)],
+              lambda inp: oracle_lib.run_integer_chip_st(0, inp)),
+             (Program.msm_bn256_tile(5), [synth.msm_bn256_tile_inputs(5, tile=70 + k)[0] for k in range(3)],
+              lambda inp: oracle_lib.run_msm_bn256_tile(5, inp))]
+    for prog, ins, orun_of in cases:
+        d_in = engine.upload_inputs(prog, np.stack(ins))
+        base, rng, sel, status = engine.alloc(prog, len(ins), fill=0xFF)
+        engine.run(prog, d_in, base, rng, sel, status)
+        engine.torch.cuda.synchronize()
+        assert (status.cpu().numpy() == 0).all()
+        flags = (prog.base_flags(), prog.range_flags(), prog.select_flags())
+        for k, inp in enumerate(ins):
+            orun = orun_of(inp)
+            for region, arr in enumerate((base, rng, sel)):
+                rows, cols = arr.shape[0], arr.shape[1]
+                got = arr[:, :, :, k, :].cpu().numpy().view(np.uint64).reshape(rows, cols, 4)   # raw, not exported
+                ovals, oflags = orun.adv(region, rows)
+                assigned = (flags[region] & 1).astype(bool)
+                assert np.array_equal(assigned, (oflags & 1).astype(bool))
+                assert np.array_equal(got[assigned], ovals[assigned])
+                assert (got[~assigned] == np.uint64(0xFFFFFFFFFFFFFFFF)).all(), f"region {region}: an unassigned cell was written"
+
+
+def test_digest_matches_oracle(engine, oracle):
+    """h2e_digest (the on-device consumer of a streaming job) of every array of every instance == the oracle's digest of
+    its Records (same definition, include/h2e.h), also when the run went into poisoned arrays"""
+    n = 12
+    ins = [synth.msm_bn256_tile_inputs(n, tile=80 + k)[0] for k in range(5)]
+    prog = Program.msm_bn256_tile(n)
+    d_in = engine.upload_inputs(prog, np.stack(ins))
+    arrs = engine.alloc(prog, len(ins), fill=0xFF)
+    engine.run(prog, d_in, *arrs)
+    dg = [engine.digest(prog, region, arrs[region]) for region in range(3)]
+    engine.torch.cuda.synchronize()
+    assert (arrs[3].cpu().numpy() == 0).all()
+    for k, inp in enumerate(ins):
+        orun = oracle_lib.run_msm_bn256_tile(n, inp)
+        for region in range(3):
+            assert np.array_equal(dg[region][k].cpu().numpy().view(np.uint64), orun.digest(region)), (k, region)
+
+
+def test_pipelined_submit_matches_run(engine, oracle):
+    """h2e_submit / h2e_wait: runs queued back to back into a ring of two output-buffer sets (the value chain of run
+    k + 1 overlaps the expansion of run k; each run owns its workspace and instance table) give exactly the arrays of
+    one-after-the-other h2e_run calls.  Six runs over three different input batches, digests compared per run, the last
+    run of each ring slot compared cell for cell with the oracle."""
+    t = engine.torch
+    n, tiles = 96, 3
+    prog = Program.msm_bn256_tile(n)
+    sets = [[synth.msm_bn256_tile_inputs(n, tile=200 + 10 * k + i, cheap_points=True)[0] for i in range(tiles)] for k in range(3)]
+    d_in = [engine.upload_inputs(prog, np.stack(s_)) for s_ in sets]
+    ring = [engine.alloc(prog, tiles) for _ in range(2)]
+    want = []
+    for k in range(3):   # reference digests from plain h2e_run
+        ring[0][3].zero_()
+        engine.run(prog, d_in[k], *ring[0])
+        want.append(t.stack([engine.digest(prog, region, ring[0][region]) for region in range(3)]).clone())
+    t.cuda.synchronize()
+    got, jobs = [], []
+    for step in range(6):
+        slot = step % 2
+        if len(jobs) == 2:   # the slot's previous run must be consumed before its arrays are overwritten
+            j, s_, k_ = jobs.pop(0)
+            engine.wait(j)
+            got.append((k_, t.stack([engine.digest(prog, region, ring[s_][region]) for region in range(3)]).clone(), ring[s_][3].clone()))
+        ring[slot][3].zero_()
+        jobs.append((engine.submit(prog, d_in[step % 3], *ring[slot]), slot, step % 3))
+    for j, s_, k_ in jobs:
+        engine.wait(j)
+        got.append((k_, t.stack([engine.digest(prog, region, ring[s_][region]) for region in range(3)]).clone(), ring[s_][3].clone()))
+    t.cuda.synchronize()
+    assert len(got) == 6
+    for k_, dg, st in got:
+        assert (st.cpu().numpy() == 0).all()
+        assert t.equal(dg, want[k_]), f"pipelined run of batch {k_} differs from h2e_run"
+    for slot, k_ in ((0, 4 % 3), (1, 5 % 3)):
+        base, rng, sel = _rows(engine, prog, ring[slot][:3])
+        orun = oracle_lib.run_msm_bn256_tile(n, sets[k_][tiles - 1])
+        compare_advice(prog, orun, base, rng, sel, instance=tiles - 1)
+
+
+def _named_call(engine, fn, *args):
+    from halo2ecc_s_amd.engine import _check, lib
+    _check(getattr(lib(), fn)(engine._h, *args, engine.torch.cuda.current_stream().cuda_stream))
+
+
+def test_named_entry_points(engine, oracle):
+    """the named C entry points of SURVEY 8(b) (build-or-reuse the program for the shape, then run it) produce the same
+    cells as the oracle: h2e_int_mul_batch, h2e_msm_bn256_tile, h2e_pairing_check_bn256 / _bls12_381"""
+    t = engine.torch
+    # int_mul batch
+    fp, n = 0, 9
+    prog = Program.int_mul_batch(fp, n)
+    ins = [synth.int_mul_batch_inputs(fp, n, seed_index=300 + k) for k in range(2)]
+    d_in = engine.upload_inputs(prog, np.stack(ins))
+    arrs = engine.alloc(prog, 2)
+    _named_call(engine, "h2e_int_mul_batch", fp, n, 2, d_in.data_ptr(), *(a.data_ptr() for a in arrs))
+    t.cuda.synchronize()
+    assert (arrs[3].cpu().numpy() == 0).all()
+    compare_advice(prog, oracle_lib.run_int_mul_batch(fp, n, ins[1]), *_rows(engine, prog, arrs[:3]), instance=1)
+    # MSM tile
+    n = 7
+    prog = Program.msm_bn256_tile(n)
+    ins = [synth.msm_bn256_tile_inputs(n, tile=310 + k)[0] for k in range(2)]
+    d_in = engine.upload_inputs(prog, np.stack(ins))
+    arrs = engine.alloc(prog, 2)
+    _named_call(engine, "h2e_msm_bn256_tile", n, 2, d_in.data_ptr(), *(a.data_ptr() for a in arrs))
+    t.cuda.synchronize()
+    assert (arrs[3].cpu().numpy() == 0).all()
+    compare_advice(prog, oracle_lib.run_msm_bn256_tile(n, ins[0]), *_rows(engine, prog, arrs[:3]), instance=0)
+    # pairing checks
+    for name, mk, gen, orun_of in (("h2e_pairing_check_bn256", Program.pairing_check_bn256, synth.pairing_check_bn256_inputs, oracle_lib.run_pairing_check_bn256),
+                                   ("h2e_pairing_check_bls12_381", Program.pairing_check_bls12_381, synth.pairing_check_bls12_381_inputs, oracle_lib.run_pairing_check_bls12_381)):
+        prog = mk(emit_shape=False)
+        ins = [gen(instance=320 + k) for k in range(2)]
+        d_in = engine.upload_inputs(prog, np.stack(ins))
+        arrs = engine.alloc(prog, 2)
+        _named_call(engine, name, 2, d_in.data_ptr(), *(a.data_ptr() for a in arrs))
+        t.cuda.synchronize()
+        assert (arrs[3].cpu().numpy() == 0).all()
+        compare_advice(prog, orun_of(ins[1]), *_rows(engine, prog, arrs[:3]), instance=1)
+
+
+def test_pairing_bn256_batch_64(engine, oracle):
+    """BASELINE configs[3] at its batch size: 64 x bn256 check_pairing with distinct inputs in one run (the grid of the
+    level-parallel replay and the multi-wave expansion paths differ from the 2-instance unit test): every status word 0,
+    first / a middle / last instance cell for cell against the oracle, digests of all 64 pairwise distinct"""
+    n_inst = 64
+    ins = [synth.pairing_check_bn256_inputs(instance=400 + k) for k in range(n_inst)]
+    prog = Program.pairing_check_bn256(emit_shape=False)
+    d_in = engine.upload_inputs(prog, np.stack(ins))
+    arrs = engine.alloc(prog, n_inst)
+    engine.run(prog, d_in, *arrs)
+    dg = engine.digest(prog, 0, arrs[0])
+    engine.torch.cuda.synchronize()
+    assert (arrs[3].cpu().numpy() == 0).all(), arrs[3].cpu().numpy()
+    assert len({tuple(r) for r in dg.cpu().numpy().tolist()}) == n_inst
+    for k in (0, 37, n_inst - 1):
+        orun = oracle_lib.run_pairing_check_bn256(ins[k])
+        assert orun.info.status == 0, orun.error
+        rows = [engine.export(prog, region, arrs[region])[k:k + 1] for region in range(3)]
+        engine.torch.cuda.synchronize()
+        compare_advice(prog, orun, *rows, instance=0)
+        del rows
+
+
+def test_pairing_bls12_381_batch_16(engine, oracle):
+    """BASELINE configs[4] at its batch size: 16 x bls12_381 check_pairing, distinct inputs, one run"""
+    n_inst = 16
+    ins = [synth.pairing_check_bls12_381_inputs(instance=500 + k) for k in range(n_inst)]
+    prog = Program.pairing_check_bls12_381(emit_shape=False)
+    d_in = engine.upload_inputs(prog, np.stack(ins))
+    arrs = engine.alloc(prog, n_inst)
+    engine.run(prog, d_in, *arrs)
+    engine.torch.cuda.synchronize()
+    assert (arrs[3].cpu().numpy() == 0).all(), arrs[3].cpu().numpy()
+    rows = _rows(engine, prog, arrs[:3])
+    for k in (0, 9, n_inst - 1):
+        orun = oracle_lib.run_pairing_check_bls12_381(ins[k])
+        assert orun.info.status == 0, orun.error
+        compare_advice(prog, orun, *rows, instance=k)
+
+
+def test_msm_batch_64_tiles_full_size(engine, oracle):
+    """BASELINE configs[1] at its batch size: 64 tiles x 1024 points in one run (110 GB of advice arrays): every status
+    word 0 once each tile's expected result is fed back, and the last tile cell for cell against the oracle"""
+    import os
+    t = engine.torch
+    n, tiles = 1024, 64
+    prog = Program.msm_bn256_tile(n, emit_shape=False)
+    ins = np.stack([synth.msm_bn256_tile_inputs(n, tile=600 + k, cheap_points=True, with_expected=False)[0] for k in range(tiles)])
+    d_in = engine.upload_inputs(prog, ins)
+    arrs = engine.alloc(prog, tiles)
+    engine.run(prog, d_in, *arrs)
+    t.cuda.synchronize()
+    refs = prog.outputs()
+    Qm = synth.BN_Q
+    exp = np.zeros((tiles, 3, 4), dtype=np.uint64)
+    for k in range(tiles):
+        xs = [engine.read_cell(arrs[0], r, k) for r in refs[0:3]]
+        ys = [engine.read_cell(arrs[0], r, k) for r in refs[4:7]]
+        z = engine.read_cell(arrs[0], refs[8], k)
+        assert z == 0
+        exp[k] = synth.pack([sum(v << (108 * i) for i, v in enumerate(xs)) % Qm, sum(v << (108 * i) for i, v in enumerate(ys)) % Qm, 0], 4)
+    d_in[:, 4 * n + 6:4 * n + 9, :] = t.from_numpy(exp.view(np.int64)).to(d_in.device)
+    arrs[3].zero_()
+    engine.run(prog, d_in, *arrs)
+    t.cuda.synchronize()
+    assert (arrs[3].cpu().numpy() == 0).all(), arrs[3].cpu().numpy()
+    k = tiles - 1
+    final_in = d_in[k].cpu().numpy().view(np.uint64)
+    orun = oracle_lib.run_msm_bn256_tile(n, final_in, threads=os.cpu_count())
+    assert orun.info.status == 0, orun.error
+    for region in range(3):
+        rows = arrs[region].shape[0]
+        got = arrs[region][:, :, :, k, :].cpu().numpy().view(np.uint64).reshape(rows, arrs[region].shape[1], 4)
+        ovals, _ = orun.adv(region, rows)
+        assert np.array_equal(got, ovals), f"region {region} differs"
+    del arrs
+    t.cuda.empty_cache()
+
+
 import golden_util  # noqa: E402
 
 
