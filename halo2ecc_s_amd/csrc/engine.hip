@@ -75,6 +75,7 @@ struct LC {  // lane context
     const u64* pool;
     const H2EFieldConsts* fc;
     u32 strand, input_stride;
+    u32 sw;                // words per input slot
     const u64* hints;
     u32 hint_stride;
     const u64* sel;     // selection buffer (H2E_FLAG_PRESELECTED)
@@ -453,7 +454,7 @@ WI_INLINE void emit_mul_equation(const LC& c, u32 brow, u32 rrow, const IntVal<F
 template <class FP>
 WI_INLINE void op_assign_w(const LC& c, const H2EOp& op) {
     u32 slot = op.imm + ((op.flags & H2E_FLAG_INPUT_STRIDED) ? c.strand * c.input_stride : 0);
-    Wd<FP::WW> x = wd_load<FP::WW>(c.inputs + (size_t)slot * FP::WW);
+    Wd<FP::WW> x = wd_load<FP::WW>(c.inputs + (size_t)slot * c.sw);
     Limb l[FP::L];
     split_limbs<FP>(x, l);
     emit_assigned<FP>(c, op.base_row, op.range_row, l, native_of_w<FP>(c, x));
@@ -464,7 +465,7 @@ WI_INLINE void op_const_int(const LC& c, const H2EOp& op, bool from_input) {
     Wd<FP::WW> x;
     if (from_input) {
         u32 slot = op.imm + ((op.flags & H2E_FLAG_INPUT_STRIDED) ? c.strand * c.input_stride : 0);
-        x = wd_load<FP::WW>(c.inputs + (size_t)slot * FP::WW);
+        x = wd_load<FP::WW>(c.inputs + (size_t)slot * c.sw);
     } else {
         x = wd_load<FP::WW>(c.pool + op.imm);
     }
@@ -718,15 +719,35 @@ WI_INLINE void op_div_core(const LC& c, const H2EOp& op) {
 
 template <class FP>
 WI_INLINE void op_bisec_int(const LC& c, const H2EOp& op) {
-    constexpr int L = FP::L;
+    // imm = limbs of the integers (0: this kernel's field).  A GeneralScalarEccContext bisects scalars of its other
+    // integer context (3 limbs) inside a fork of the base field (4 limbs): the rows are base-chip rows only.
+    const int L = op.imm ? (int)op.imm : FP::L;
     Fe cond = ld_fe(c, op.refs[0]);
     bool take_a = !wd_is_zero<4>(cond);
     u32 r = op.base_row;
 #pragma unroll
-    for (int i = 0; i <= L; i++) {
-        Fe av = ld_fe(c, op.refs[1 + i]), bv = ld_fe(c, op.refs[1 + L + 1 + i]);
-        ROW_B4(c, r + i, cond, av, cond, bv, take_a ? av : bv);
+    for (int i = 0; i <= H2E_MAX_L; i++) {
+        if (i <= L) {
+            Fe av = ld_fe(c, op.refs[1 + i]), bv = ld_fe(c, op.refs[1 + L + 1 + i]);
+            ROW_B4(c, r + i, cond, av, cond, bv, take_a ? av : bv);
+        }
     }
+}
+
+// one limb of GeneralScalarEccContext::decompose_scalar::<1> (general_scalar_ecc_chip.rs:107-130): imm = limb bits
+WI_INLINE void op_decompose_limb(const LC& c, const H2EOp& op) {
+    Limb rest = ld_limb(c, op.refs[0]);
+    u32 r = op.base_row, nbits = op.imm;
+    for (u32 j = 0; j < nbits; j++) {
+        u64 b = rest.v[0] & 1;
+        Limb v = wd_shr1<2>(rest);
+        rowB(c, r, 3, fe_u64(b), fe_u64(b), FE0, FE0, FE0);                 // assign_bit: two copies (quirk Q2)
+        ROW_B2(c, r + 1, fe_of(rest), fe_u64(b), fe_of(v));                 // [rest * -1, b * 1 | v * 2]
+        r += 2;
+        rest = v;
+    }
+    rowB(c, r, 1, fe_of(rest), FE0, FE0, FE0, FE0);                         // assert_constant(rest, 0)
+    if (c.active && !wd_is_zero<2>(rest)) flag(c, H2E_STATUS_ASSERT_FAILED);
 }
 
 template <class FP>
@@ -852,11 +873,11 @@ WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
         case H2E_OP_ASSIGN_W: op_assign_w<FP>(c, op); break;
         case H2E_OP_ASSIGN: {
             u32 slot = op.imm + ((op.flags & H2E_FLAG_INPUT_STRIDED) ? c.strand * c.input_stride : 0);
-            rowB(c, op.base_row, 1, wd_load<4>(c.inputs + (size_t)slot * FP::WW), FE0, FE0, FE0, FE0);
+            rowB(c, op.base_row, 1, wd_load<4>(c.inputs + (size_t)slot * c.sw), FE0, FE0, FE0, FE0);
         } break;
         case H2E_OP_ASSIGN_BIT: {
             u32 slot = op.imm + ((op.flags & H2E_FLAG_INPUT_STRIDED) ? c.strand * c.input_stride : 0);
-            Fe v = wd_load<4>(c.inputs + (size_t)slot * FP::WW);
+            Fe v = wd_load<4>(c.inputs + (size_t)slot * c.sw);
             rowB(c, op.base_row, 3, v, v, FE0, FE0, FE0);
         } break;
         case H2E_OP_CONST_INT: op_const_int<FP>(c, op, false); break;
@@ -898,6 +919,7 @@ WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
         case H2E_OP_PICK_INDEX: op_pick_index(c, op); break;
         case H2E_OP_CACHE_INT: op_cache_int<FP>(c, op); break;
         case H2E_OP_SELECT_POINT: op_select_point<FP>(c, op); break;
+        case H2E_OP_DECOMPOSE_LIMB: op_decompose_limb(c, op); break;
         default: break;
     }
 }
@@ -974,6 +996,7 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     c.fc = &g_fc[FP::ID];   // constant address space -> scalar loads (the `fc` argument serves the other kernels)
     c.strand = strand;
     c.input_stride = L.input_stride;
+    c.sw = L.slot_words;
     c.hints = d.hints;
     c.hint_stride = L.hint_stride;
     c.hs = 2 * n_instances;
@@ -1390,6 +1413,7 @@ __global__ void __launch_bounds__(64) h2e_replay(H2ELaunch L, const InstanceDesc
     c.fc = &g_fc[FP::ID];
     c.strand = strand;
     c.input_stride = L.input_stride;
+    c.sw = L.slot_words;
     c.hints = d.hints;
     c.hint_stride = L.hint_stride;
     c.sel = d.sel;
@@ -1646,6 +1670,7 @@ __global__ void __launch_bounds__(64 * H2E_LEVEL_WAVES) h2e_replay_levels(H2ELau
     c.fc = &g_fc[FP::ID];
     c.strand = strand;
     c.input_stride = L.input_stride;
+    c.sw = L.slot_words;
     c.hints = d.hints;
     c.hint_stride = L.hint_stride;
     c.sel = d.sel;

@@ -7,6 +7,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include "../../include/h2e.h"
 #include "recorder_pairing.hpp"
 
@@ -44,13 +45,7 @@ inline const char* dbg_env(const char* name) { return getenv(name); }
 inline const char* dbg_env(const char*) { return nullptr; }
 #endif
 
-const h2e::FieldPair& field_pair(int id) {
-    static std::mutex mu;
-    static std::unique_ptr<h2e::FieldPair> fps[3];
-    std::lock_guard<std::mutex> g(mu);
-    if (!fps[id]) fps[id].reset(new h2e::FieldPair(id));
-    return *fps[id];
-}
+const h2e::FieldPair& field_pair(int id) { return h2e::field_pair_of(id); }
 
 struct InstanceDescHost {  // must match engine.hip InstanceDesc
     uint64_t* base;
@@ -1336,6 +1331,7 @@ struct h2e_program {
 
     void finish() {
         h2e::Recorder& r = *rec;
+        if (r.fp.id != r.primary_field) r.use_field(r.primary_field);   // the analyses below decode cut segments in the program's field
         r.close_segment();
         mark_local_results();
         assign_expansion_slots();
@@ -1600,6 +1596,34 @@ static int program_msm_bn256_tile(uint32_t n, int emit_shape, bool with_select, 
     return 0;
 }
 
+// body of test_bls12_381_ecc_chip_over_bn256_fr (src/tests/general_scalar_ecc_chip.rs:14-49) for one tile of n points:
+// GeneralScalarEccContext<bls12_381::G1Affine, bn256::Fr> - points over the 4-limb bls12_381 Fq, scalars as integers of
+// the other integer context (3-limb bls12_381 Fr), 3 x 108 = 324 one-bit windows (general_scalar_ecc_chip.rs:96-147)
+int h2e_program_msm_bls12_381_tile(uint32_t n, int emit_shape, h2e_program** out) {
+    h2e_program* p = nullptr;
+    if (n == 0) return fail(H2E_ERR_INVALID, "n_points must be > 0");
+    int rc = new_program(H2E_FIELD_BLS12_381_FQ, emit_shape, out, p);
+    if (rc) return rc;
+    GUARDED({
+        h2e::Recorder& r = *p->rec;
+        uint32_t s = r.alloc_inputs(4 * n + 9);
+        h2e::NativeScalarEccContext ecc(r, h2e::bls12_381_g1_params(), 0);
+        ecc.scalar_field = H2E_FIELD_BLS12_381_FR;
+        h2e::NativeScalarEccContext::MsmInputs mi{s + 4 * n + 2, s + 4 * n + 3, s + 4 * n + 4, s + 4 * n + 5};
+        h2e::AssignedPoint res = ecc.msm_unsafe_from_inputs(n, s, mi, s + 4 * n, s + 4 * n + 1);
+        h2e::AssignedPoint res_expect = ecc.assign_point(h2e::PointInput{s + 4 * n + 6, s + 4 * n + 7, s + 4 * n + 8, false});
+        ecc.ecc_assert_equal(res, res_expect);
+        for (int i = 0; i < r.fp.limbs; i++) r.outputs.push_back(res.x.limbs_le[i]);
+        r.outputs.push_back(res.x.native);
+        for (int i = 0; i < r.fp.limbs; i++) r.outputs.push_back(res.y.limbs_le[i]);
+        r.outputs.push_back(res.y.native);
+        r.outputs.push_back(res.z.v.ref);
+        p->finish();
+    })
+    *out = p;
+    return 0;
+}
+
 int h2e_program_pairing_check_bn256(int emit_shape, h2e_program** out) {
     h2e_program* p = nullptr;
     int rc = new_program(H2E_FIELD_BN256_FQ, emit_shape, out, p);
@@ -1794,12 +1818,18 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     int rc = ensure_device_program(ctx, p);
     if (rc) return rc;
     int fp = p->field_pair;
-    if (!ctx->d_fc[fp]) {
-        HIP_TRY(hipMalloc((void**)&ctx->d_fc[fp], sizeof(H2EFieldConsts)));
-        HIP_TRY(hipMemcpy(ctx->d_fc[fp], &field_pair(fp).fc, sizeof(H2EFieldConsts), hipMemcpyHostToDevice));
-        HIP_TRY((hipError_t)h2e_engine_set_consts(fp, &field_pair(fp).fc));
-    }
     h2e::Recorder& r = *p->rec;
+    {   // constants of every W field the program's segments work in (a GeneralScalarEccContext has two)
+        bool need[3] = {false, false, false};
+        need[fp] = true;
+        for (auto& sg : r.segments) need[sg.field_pair] = true;
+        for (int f = 0; f < 3; f++)
+            if (need[f] && !ctx->d_fc[f]) {
+                HIP_TRY(hipMalloc((void**)&ctx->d_fc[f], sizeof(H2EFieldConsts)));
+                HIP_TRY(hipMemcpy(ctx->d_fc[f], &field_pair(f).fc, sizeof(H2EFieldConsts), hipMemcpyHostToDevice));
+                HIP_TRY((hipError_t)h2e_engine_set_consts(f, &field_pair(f).fc));
+            }
+    }
     if (!ctx->expand_stream) HIP_TRY(hipStreamCreateWithPriority(&ctx->expand_stream, hipStreamNonBlocking, ctx->prio_expand));
     if (!ctx->fixup_stream) HIP_TRY(hipStreamCreateWithPriority(&ctx->fixup_stream, hipStreamNonBlocking, ctx->prio_fixup));
     // Streams.  The *value chain* (predictor kernels + values-only replay, or the plain tape for segments without cuts)
@@ -1921,7 +1951,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         HIP_TRY(hipEventRecord(e0, sa));
         HIP_TRY(hipStreamWaitEvent(sb, e0, 0));
         if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 2), sb));
-        int prc2 = h2e_engine_launch(fp, 2, &pending_L, J.d_inst, n_instances, ctx->d_fc[fp], sb);
+        int prc2 = h2e_engine_launch((int)pending_L.field_pair, 2, &pending_L, J.d_inst, n_instances, ctx->d_fc[pending_L.field_pair], sb);
         if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
         if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 3), sb));
         if (pending_L.n_fixups) {
@@ -1929,7 +1959,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             HIP_TRY(hipEventRecord(e1, sb));
             HIP_TRY(hipStreamWaitEvent(sd, e1, 0));
             used_sd = true;
-            prc2 = h2e_engine_launch(fp, 4, &pending_L, J.d_inst, n_instances, ctx->d_fc[fp], sd);
+            prc2 = h2e_engine_launch((int)pending_L.field_pair, 4, &pending_L, J.d_inst, n_instances, ctx->d_fc[pending_L.field_pair], sd);
             if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
         }
         have_pending = false;
@@ -2010,6 +2040,8 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         L.n_fixups = s.n_fixups;
         L.fixups = p->d_fixups + s.fixups_begin;
         L.rel_refs = s.is_fork ? 1 : 0;
+        L.field_pair = (uint32_t)s.field_pair;
+        L.slot_words = (uint32_t)slot_words;
         L.n_sub = p->seg_n_sub[si];
         L.sub = L.n_sub > 1 ? p->d_subs + p->seg_sub_begin[si] : nullptr;
         bool compiled = si < p->seg_n_pieces.size() && p->seg_n_pieces[si] > 0;
@@ -2026,7 +2058,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         L.l_slots = levels ? p->seg_l_slots[si] : 0;
         int lrc;
         auto launch_one = [&](int mode, const H2ELaunch& l, hipStream_t st) -> int {
-            int rc2 = h2e_engine_launch(fp, mode, &l, J.d_inst, n_instances, ctx->d_fc[fp], st);
+            int rc2 = h2e_engine_launch((int)l.field_pair, mode, &l, J.d_inst, n_instances, ctx->d_fc[l.field_pair], st);
             if (rc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc2));
             return 0;
         };
@@ -2391,6 +2423,355 @@ int h2e_pairing_check_bls12_381(h2e_ctx* ctx, uint32_t n_instances, const void* 
     return cached_run(ctx, "pairing_check_bls12_381",
                       [&](h2e_program** p) { return h2e_program_pairing_check_bls12_381(0, p); }, n_instances, d_inputs,
                       d_base, d_range, d_select, d_status, stream);
+}
+
+// =================================================================================================================
+// Operator API: a device-resident Context (include/h2e.h "operator API").  The reference's operator surface is a
+// Context you call chip ops on; its own seam for running part of the work elsewhere is fork-at-offset / merge
+// (ParallelClone, src/circuit/ecc_chip.rs:64-77).  h2e_records is that Context for a batch of instances: advice arrays
+// in HBM, cursors / heights / msm prefix / shape artefacts on the host.  Every op records one program that starts at the
+// current offsets with its operands as handles to earlier rows, runs it on the shared arrays and advances the cursors.
+struct h2e_records {
+    h2e_ctx* ctx = nullptr;
+    int field_pair = 0, scalar_field = -1;
+    uint32_t n_instances = 0;
+    bool emit_shape = true, own_arrays = false;
+    uint64_t cap[3] = {0, 0, 0};
+    void* d_arr[3] = {nullptr, nullptr, nullptr};
+    uint32_t* d_status = nullptr;
+    // Context (src/context.rs:40-46) + Records heights (:297-299) + NativeScalarEccContext.1 / msm_prefix
+    uint64_t off[3] = {0, 0, 0}, height[3] = {0, 0, 0};
+    size_t msm_prefix = 0;
+    uint64_t n_advice_cells = 0, n_ops = 0;
+    // accumulated shape artefacts
+    std::vector<h2e::FrVal> dict;
+    std::unordered_map<h2e::FrVal, uint32_t, h2e::FrValHash> dict_map;
+    std::vector<uint32_t> fix[3];
+    std::vector<uint8_t> flags[3];
+    std::vector<uint32_t> perm_flat;
+    std::vector<uint32_t> patch_flat;   // [row, fixed col, op index << 16 | input slot, limb]
+    std::vector<h2e_program*> programs; // the ops' programs (their device tapes are in use until the stream has drained)
+    h2e_records() { dict.push_back(h2e::FrVal{0, 0, 0, 0}); }
+    ~h2e_records() {
+        if (ctx) {
+            (void)hipSetDevice(ctx->device);
+            (void)hipDeviceSynchronize();
+        }
+        for (auto* p : programs) delete p;
+        if (own_arrays) {
+            for (int i = 0; i < 3; i++) (void)hipFree(d_arr[i]);
+            (void)hipFree(d_status);
+        }
+    }
+    uint32_t intern(const h2e::FrVal& v) {
+        auto it = dict_map.find(v);
+        if (it != dict_map.end()) return it->second;
+        uint32_t id = (uint32_t)dict.size();
+        dict.push_back(v);
+        dict_map.emplace(v, id);
+        return id;
+    }
+};
+
+namespace {
+const int FIXC[3] = {9, 2, 2}, ADVC[3] = {5, 3, 2};
+h2e::AssignedInteger to_int(const h2e_int& a) {
+    h2e::AssignedInteger r;
+    for (int i = 0; i < H2E_MAX_L; i++) r.limbs_le[i] = a.limbs[i];
+    r.native = a.native;
+    r.times = a.times;
+    return r;
+}
+h2e_int from_int(const h2e::AssignedInteger& a) {
+    h2e_int r;
+    for (int i = 0; i < H2E_MAX_L; i++) r.limbs[i] = a.limbs_le[i];
+    r.native = a.native;
+    r.times = (uint32_t)a.times;
+    return r;
+}
+h2e::AssignedPoint to_point(const h2e_point& p) { return h2e::AssignedPoint{to_int(p.x), to_int(p.y), h2e::AssignedCondition{h2e::AssignedValue{p.z}}}; }
+h2e_point from_point(const h2e::AssignedPoint& p) {
+    h2e_point r;
+    r.x = from_int(p.x);
+    r.y = from_int(p.y);
+    r.z = p.z.v.ref;
+    return r;
+}
+
+// Record one op at the records' current state, run it, merge its shape artefacts and advance the Context.
+int records_op(h2e_records* R, uint32_t n_slots, const void* d_inputs, void* stream,
+               const std::function<void(h2e::Recorder&, h2e::NativeScalarEccContext&, uint32_t)>& body) {
+    if (!R) return fail(H2E_ERR_INVALID, "null records");
+    if (n_slots && !d_inputs) return fail(H2E_ERR_INVALID, "the op takes inputs: d_inputs is null");
+    h2e_program* p = new h2e_program();
+    p->field_pair = R->field_pair;
+    try {
+        p->rec.reset(new h2e::Recorder(field_pair(R->field_pair)));
+        h2e::Recorder& r = *p->rec;
+        r.emit_shape = R->emit_shape;
+        // clone_with_offset of the caller's context (context.rs:145-158): cursors and heights carry over
+        r.base_offset = R->off[0];
+        r.range_offset = R->off[1];
+        r.select_offset = R->off[2];
+        r.base_height = R->height[0];
+        r.range_height = R->height[1];
+        r.select_height = R->height[2];
+        h2e::NativeScalarEccContext ecc(r, R->field_pair == H2E_FIELD_BN256_FQ ? h2e::bn256_g1_params() : h2e::bls12_381_g1_params(), R->msm_prefix);
+        ecc.scalar_field = R->scalar_field;
+        uint32_t s0 = r.alloc_inputs(std::max<uint32_t>(1, n_slots));
+        body(r, ecc, s0);
+        p->finish();
+        if (p->base_rows > R->cap[0] || p->range_rows > R->cap[1] || p->select_rows > R->cap[2]) {
+            delete p;
+            return fail(H2E_ERR_SHAPE, "records: the op does not fit the arrays' capacity (like HALO2ECC_S_MAX_ROWS, src/context.rs:36)");
+        }
+        R->msm_prefix = ecc.msm_prefix;
+    } catch (std::exception& e) {
+        delete p;
+        return fail(H2E_ERR_SHAPE, e.what());
+    }
+    h2e::Recorder& r = *p->rec;
+    static const uint64_t dummy_zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)dummy_zero;
+    int rc = 0;
+    if (!r.tape.empty()) {
+        const void* in = d_inputs;
+        void* scratch = nullptr;
+        if (!in) {   // ops without inputs still get a valid (unused) pointer
+            HIP_TRY(hipSetDevice(R->ctx->device));
+            HIP_TRY(hipMalloc(&scratch, (size_t)R->n_instances * 64));
+            in = scratch;
+        }
+        rc = h2e_run(R->ctx, p, R->n_instances, in, R->d_arr[0], R->d_arr[1], R->d_arr[2], R->d_status, stream);
+        if (scratch) {
+            (void)hipStreamSynchronize((hipStream_t)stream);
+            (void)hipFree(scratch);
+        }
+    }
+    if (rc) {
+        delete p;
+        return rc;
+    }
+    // merge (ParallelClone::merge + apply_offset_diff)
+    uint64_t before[3] = {R->off[0], R->off[1], R->off[2]};
+    R->off[0] = r.base_offset;
+    R->off[1] = r.range_offset;
+    R->off[2] = r.select_offset;
+    R->height[0] = r.base_height;
+    R->height[1] = r.range_height;
+    R->height[2] = r.select_height;
+    if (R->emit_shape) {
+        const std::vector<uint32_t>* pfix[3] = {&r.base_fix, &r.range_fix, &r.select_fix};
+        const std::vector<uint8_t>* pfl[3] = {&r.base_flags, &r.range_flags, &r.select_flags};
+        uint64_t rows[3] = {p->base_rows, p->range_rows, p->select_rows};
+        std::vector<uint32_t> idmap(r.dict.size(), 0);
+        for (size_t i = 1; i < r.dict.size(); i++) idmap[i] = R->intern(r.dict[i]);
+        for (int reg = 0; reg < 3; reg++) {
+            if (R->fix[reg].size() < rows[reg] * FIXC[reg]) R->fix[reg].resize(rows[reg] * FIXC[reg], 0);
+            if (R->flags[reg].size() < rows[reg] * ADVC[reg]) R->flags[reg].resize(rows[reg] * ADVC[reg], 0);
+            for (uint64_t row = before[reg]; row < rows[reg]; row++) {
+                for (int c = 0; c < FIXC[reg]; c++) {
+                    size_t k = row * FIXC[reg] + c;
+                    if (k < pfix[reg]->size() && (*pfix[reg])[k]) R->fix[reg][k] = idmap[(*pfix[reg])[k]];
+                }
+                for (int c = 0; c < ADVC[reg]; c++) {
+                    size_t k = row * ADVC[reg] + c;
+                    if (k < pfl[reg]->size()) R->flags[reg][k] |= (*pfl[reg])[k];
+                }
+            }
+        }
+        auto set_perm = [&](uint32_t cell) {
+            uint32_t reg = H2E_REF_REGION(cell);
+            size_t k = (size_t)H2E_REF_ROW(cell) * ADVC[reg] + H2E_REF_COL(cell);
+            if (R->flags[reg].size() <= k) R->flags[reg].resize(k + 1, 0);
+            R->flags[reg][k] |= 2;
+        };
+        for (auto& pr : r.permutations) {
+            R->perm_flat.push_back(pr.first);
+            R->perm_flat.push_back(pr.second);
+            set_perm(pr.first);
+            set_perm(pr.second);
+        }
+        for (auto& fpch : r.fixed_patches) {
+            R->patch_flat.push_back(fpch.row);
+            R->patch_flat.push_back(fpch.col);
+            R->patch_flat.push_back((uint32_t)(R->n_ops << 16) | fpch.input_slot);
+            R->patch_flat.push_back((uint32_t)fpch.limb);
+        }
+        R->n_advice_cells += r.n_advice_cells;
+    }
+    R->n_ops++;
+    R->programs.push_back(p);
+    return 0;
+}
+}  // namespace
+
+int h2e_records_create(h2e_ctx* ctx, int field_pair_id, int scalar_field, uint32_t n_instances, uint64_t base_rows, uint64_t range_rows,
+                       uint64_t select_rows, int emit_shape, h2e_records** out) {
+    if (!ctx || !out) return fail(H2E_ERR_INVALID, "null argument");
+    if (field_pair_id < 0 || field_pair_id > 2 || scalar_field < -1 || scalar_field > 2) return fail(H2E_ERR_INVALID, "bad field pair");
+    if (n_instances == 0 || base_rows == 0 || range_rows == 0 || select_rows == 0) return fail(H2E_ERR_INVALID, "empty records");
+    h2e_records* R = new h2e_records();
+    R->ctx = ctx;
+    R->field_pair = field_pair_id;
+    R->scalar_field = scalar_field;
+    R->n_instances = n_instances;
+    R->emit_shape = emit_shape != 0;
+    R->cap[0] = base_rows;
+    R->cap[1] = range_rows;
+    R->cap[2] = select_rows;
+    R->own_arrays = true;
+    hipError_t e = hipSetDevice(ctx->device);
+    for (int i = 0; i < 3 && e == hipSuccess; i++) {
+        size_t bytes = (size_t)R->cap[i] * ADVC[i] * 32 * n_instances;
+        e = hipMalloc(&R->d_arr[i], bytes);
+        if (e == hipSuccess) e = hipMemset(R->d_arr[i], 0, bytes);
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&R->d_status, (size_t)n_instances * 4);
+    if (e == hipSuccess) e = hipMemset(R->d_status, 0, (size_t)n_instances * 4);
+    if (e != hipSuccess) {
+        delete R;
+        return fail(H2E_ERR_HIP, std::string("records: ") + hipGetErrorString(e));
+    }
+    *out = R;
+    return 0;
+}
+void h2e_records_destroy(h2e_records* R) { delete R; }
+int h2e_records_arrays(h2e_records* R, void** d_base, void** d_range, void** d_select, void** d_status) {
+    if (!R) return fail(H2E_ERR_INVALID, "null records");
+    if (d_base) *d_base = R->d_arr[0];
+    if (d_range) *d_range = R->d_arr[1];
+    if (d_select) *d_select = R->d_arr[2];
+    if (d_status) *d_status = R->d_status;
+    return 0;
+}
+int h2e_records_shape(const h2e_records* R, h2e_shape* out) {
+    if (!R || !out) return fail(H2E_ERR_INVALID, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    out->field_pair = R->field_pair;
+    out->slot_words = field_pair(R->field_pair).w_words;
+    out->base_offset = R->off[0];
+    out->range_offset = R->off[1];
+    out->select_offset = R->off[2];
+    out->base_height = R->height[0];
+    out->range_height = R->height[1];
+    out->select_height = R->height[2];
+    out->base_rows = R->cap[0];
+    out->range_rows = R->cap[1];
+    out->select_rows = R->cap[2];
+    out->n_advice_cells = R->n_advice_cells;
+    out->n_permutations = R->perm_flat.size() / 2;
+    out->n_dict = R->dict.size();
+    out->n_fixed_patches = R->patch_flat.size() / 4;
+    out->n_segments = 0;
+    out->n_ops = R->n_ops;
+    if (R->emit_shape) {
+        h2e_records* W = const_cast<h2e_records*>(R);
+        for (int reg = 0; reg < 3; reg++) {   // the views cover the arrays' whole capacity
+            W->fix[reg].resize(R->cap[reg] * FIXC[reg], 0);
+            W->flags[reg].resize(R->cap[reg] * ADVC[reg], 0);
+        }
+        out->dict = (const uint64_t*)R->dict.data();
+        out->base_fix = R->fix[0].data();
+        out->range_fix = R->fix[1].data();
+        out->select_fix = R->fix[2].data();
+        out->base_flags = R->flags[0].data();
+        out->range_flags = R->flags[1].data();
+        out->select_flags = R->flags[2].data();
+        out->permutations = R->perm_flat.data();
+        out->fixed_patches = R->patch_flat.data();
+    }
+    return 0;
+}
+
+// ---- ops: same names and argument meaning as the reference's traits -------------------------------------------------
+int h2e_op_assign_w(h2e_records* R, const void* d_inputs, h2e_int* out, void* stream) {   // IntegerChipOps::assign_w (integer_chip.rs:236-258)
+    if (!out) return fail(H2E_ERR_INVALID, "out is null");
+    return records_op(R, 1, d_inputs, stream, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t s) { *out = from_int(r.assign_w(s)); });
+}
+int h2e_op_assign(h2e_records* R, const void* d_inputs, uint32_t* out_cell, void* stream) {   // BaseChipOps::assign (base_chip.rs:351-355)
+    if (!out_cell) return fail(H2E_ERR_INVALID, "out is null");
+    return records_op(R, 1, d_inputs, stream, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t s) { *out_cell = r.assign(s).ref; });
+}
+int h2e_op_int(h2e_records* R, int which, const h2e_int* a, const h2e_int* b, h2e_int* out, uint32_t* out_cond, void* stream) {
+    if (!a || !out || (which != H2E_INT_REDUCE && !b)) return fail(H2E_ERR_INVALID, "null operand");
+    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
+        h2e::AssignedInteger x = to_int(*a), y = b ? to_int(*b) : h2e::AssignedInteger();
+        switch (which) {
+            case H2E_INT_ADD: *out = from_int(r.int_add(x, y)); break;
+            case H2E_INT_SUB: *out = from_int(r.int_sub(x, y)); break;
+            case H2E_INT_MUL: *out = from_int(r.int_mul(x, y)); break;
+            case H2E_INT_REDUCE: *out = from_int(r.reduce(x)); break;
+            case H2E_INT_DIV: {
+                auto d = r.int_div(x, y);
+                *out = from_int(d.second);
+                if (out_cond) *out_cond = d.first.v.ref;
+            } break;
+            default: throw std::runtime_error("h2e_op_int: unknown op");
+        }
+    });
+}
+int h2e_op_assign_points(h2e_records* R, uint32_t n, const void* d_inputs, h2e_point* out, void* stream) {   // EccChipBaseOps::assign_point x n
+    if (!out || n == 0) return fail(H2E_ERR_INVALID, "bad argument");
+    return records_op(R, 3 * n, d_inputs, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& ecc, uint32_t s) {
+        std::vector<h2e::AssignedPoint> pts = ecc.assign_points_from_inputs(n, s);
+        for (uint32_t k = 0; k < n; k++) out[k] = from_point(pts[k]);
+    });
+}
+int h2e_op_assign_scalars(h2e_records* R, uint32_t n, const void* d_inputs, h2e_int* out, void* stream) {   // ctx.assign / scalar_integer_ctx.assign_w x n
+    if (!out || n == 0) return fail(H2E_ERR_INVALID, "bad argument");
+    return records_op(R, n, d_inputs, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& ecc, uint32_t s) {
+        std::vector<h2e::AssignedInteger> sc = ecc.assign_scalars_from_inputs(n, s);
+        for (uint32_t k = 0; k < n; k++) out[k] = from_int(sc[k]);
+    });
+}
+int h2e_op_msm_unsafe(h2e_records* R, uint32_t n, const h2e_point* points, const h2e_int* scalars, const void* d_inputs, h2e_point* out,
+                      void* stream) {   // EccChipScalarOps::msm_unsafe (ecc_chip.rs:373-408); inputs: generator (x, y), r1 (x, y), r2 (x, y)
+    if (!points || !scalars || !out || n == 0) return fail(H2E_ERR_INVALID, "bad argument");
+    return records_op(R, 6, d_inputs, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& ecc, uint32_t s) {
+        std::vector<h2e::AssignedPoint> pts;
+        std::vector<h2e::AssignedInteger> sc;
+        for (uint32_t k = 0; k < n; k++) {
+            pts.push_back(to_point(points[k]));
+            sc.push_back(to_int(scalars[k]));
+        }
+        h2e::NativeScalarEccContext::MsmInputs mi{s + 2, s + 3, s + 4, s + 5};
+        *out = from_point(ecc.msm_unsafe(pts, sc, mi, s, s + 1));
+    });
+}
+int h2e_op_ecc_assert_equal(h2e_records* R, const h2e_point* a, const h2e_point* b, void* stream) {   // ecc_chip.rs:644-658
+    if (!a || !b) return fail(H2E_ERR_INVALID, "null operand");
+    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& ecc, uint32_t) { ecc.ecc_assert_equal(to_point(*a), to_point(*b)); });
+}
+int h2e_op_assign_g2_constant(h2e_records* R, const void* d_inputs, h2e_g2* out, void* stream) {   // fq2_assign_constant x 2 + assign_constant(0)
+    if (!out) return fail(H2E_ERR_INVALID, "out is null");
+    return records_op(R, 4, d_inputs, stream, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t s) {
+        out->x0 = from_int(r.assign_int_constant_input(s + 0));
+        out->x1 = from_int(r.assign_int_constant_input(s + 1));
+        out->y0 = from_int(r.assign_int_constant_input(s + 2));
+        out->y1 = from_int(r.assign_int_constant_input(s + 3));
+        out->z = r.assign_constant_u64(0).ref;
+    });
+}
+int h2e_op_check_pairing(h2e_records* R, uint32_t n_pairs, const h2e_point* g1, const h2e_g2* g2, void* stream) {   // pairing_chip.rs:173-176
+    if (!g1 || !g2 || n_pairs == 0) return fail(H2E_ERR_INVALID, "bad argument");
+    if (R && R->field_pair == H2E_FIELD_BLS12_381_FR) return fail(H2E_ERR_INVALID, "no pairing over this field");
+    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
+        r.auto_cut_every = 16;
+        std::unique_ptr<h2e::PairingOps> po;
+        if (r.fp.id == H2E_FIELD_BN256_FQ) po.reset(new h2e::Bn256PairingOps(r));
+        else po.reset(new h2e::Bls12381PairingOps(r));
+        std::vector<h2e::AssignedPoint> a;
+        std::vector<h2e::AssignedG2Affine> b;
+        for (uint32_t k = 0; k < n_pairs; k++) {
+            a.push_back(to_point(g1[k]));
+            b.push_back(h2e::AssignedG2Affine{h2e::AssignedFq2{to_int(g2[k].x0), to_int(g2[k].x1)}, h2e::AssignedFq2{to_int(g2[k].y0), to_int(g2[k].y1)},
+                                              h2e::AssignedCondition{h2e::AssignedValue{g2[k].z}}});
+        }
+        std::vector<h2e::PairingOps::Term> terms;
+        for (uint32_t k = 0; k < n_pairs; k++) terms.push_back(h2e::PairingOps::Term(&a[k], &b[k]));
+        po->check_pairing(terms);
+    });
 }
 
 }  // extern "C"

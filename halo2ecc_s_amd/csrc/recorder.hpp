@@ -17,6 +17,8 @@
 #include <array>
 #include <cstring>
 #include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -154,6 +156,15 @@ struct FieldPair {
     }
 };
 
+inline const FieldPair& field_pair_of(int id) {
+    static std::mutex mu;
+    static std::unique_ptr<FieldPair> fps[3];
+    if (id < 0 || id > 2) throw std::runtime_error("bad field pair");
+    std::lock_guard<std::mutex> g(mu);
+    if (!fps[id]) fps[id].reset(new FieldPair(id));
+    return *fps[id];
+}
+
 // ---- handles (src/assign.rs) --------------------------------------------------------------------
 struct AssignedValue {   // assign.rs:25-29 (cell only; the value lives on the device)
     uint32_t ref = H2E_NO_REF;
@@ -186,6 +197,7 @@ struct Segment {  // one engine launch
     uint32_t fixups_begin = 0, n_fixups = 0;
     uint32_t cuts_begin = 0, n_cuts = 0;  // op indices (relative to tape_begin) where the expansion may be split
     bool is_fork = false;
+    int field_pair = 0;   // the W field the segment's integer ops work in (GeneralScalarEccContext has two, context.rs:215-239)
     // scheduling hint: the next segment's value chain is tiny (a handful of waves that need most of a CU's LDS); this
     // segment's bandwidth-bound expansion would starve it, so the expansion is launched behind that chain
     bool expand_after_next = false;
@@ -217,7 +229,8 @@ struct Offset {  // ecc_chip.rs:36-41
 
 // Context + Records (shape part) + BaseChipOps/RangeChipOps/SelectChipOps/IntegerChipOps, recording.
 struct Recorder {
-    const FieldPair& fp;
+    FieldPair fp;          // the integer chip's current W field (a copy: use_field switches it)
+    int primary_field;
     // ---- program ----
     std::vector<H2EOp> tape;
     std::vector<uint32_t> aux;
@@ -268,7 +281,7 @@ struct Recorder {
     uint32_t id_ceil[OVERFLOW_LIMIT][H2E_MAX_L];
     uint32_t id_neg_limb_modulus, id_K0, id_K1, id_reduce_k[2], id_small[16], id_pow2[8], id_tag[19];
 
-    explicit Recorder(const FieldPair& f) : fp(f) {
+    explicit Recorder(const FieldPair& f) : fp(f), primary_field(f.id) {
         dict.push_back(FrVal{0, 0, 0, 0});
         id_zero = intern(fp.fr(HBig(0)));
         id_one = intern(fp.fr(HBig(1)));
@@ -277,8 +290,21 @@ struct Recorder {
         id_three = intern(fp.fr(HBig(3)));
         id_four = intern(fp.fr(HBig(4)));
         HBig limb_modulus = HBig(1).shl(LIMB_BITS);
+        for (int i = 0; i < H2E_MAX_L; i++) id_limb_coeff[i] = intern(fp.fr(HBig(1).shl(i * LIMB_BITS)));
+        id_neg_limb_modulus = intern(fp.fr_neg(limb_modulus));
+        id_reduce_k[0] = intern(fp.fr(limb_modulus * HBig(OVERFLOW_LIMIT)));                         // :362-365
+        id_reduce_k[1] = intern(fp.fr(limb_modulus * HBig(OVERFLOW_LIMIT) - HBig(OVERFLOW_LIMIT)));
+        for (int k = 0; k < 16; k++) id_small[k] = intern(fp.fr(HBig((uint64_t)k)));
+        for (int k = 0; k < 8; k++) id_pow2[k] = intern(fp.fr(HBig(1ull << k)));
+        for (int k = 0; k <= 18; k++) id_tag[k] = intern(fp.fr(HBig((uint64_t)k)));
+        field_ids();
+        begin_segment();
+    }
+
+    // dictionary ids of the fixed values that depend on W
+    void field_ids() {
+        HBig limb_modulus = HBig(1).shl(LIMB_BITS);
         for (int i = 0; i < fp.limbs; i++) {
-            id_limb_coeff[i] = intern(fp.fr(HBig(1).shl(i * LIMB_BITS)));
             id_w_limb[i] = intern(fp.fr(fp.w_limbs[i]));
             id_neg_w_limb[i] = intern(fp.fr_neg(fp.w_limbs[i]));
         }
@@ -286,15 +312,19 @@ struct Recorder {
         id_neg_w_native = intern(fp.fr_neg(fp.w));
         for (int t = 1; t < OVERFLOW_LIMIT; t++)
             for (int i = 0; i < fp.limbs; i++) id_ceil[t][i] = intern(fp.fr(fp.ceil_limbs[t][i]));
-        id_neg_limb_modulus = intern(fp.fr_neg(limb_modulus));
         HBig borrow = HBig((uint64_t)fp.limbs) * limb_modulus + HBig(2);     // integer_chip.rs:112
         id_K0 = intern(fp.fr(limb_modulus * borrow));                       // :117
         id_K1 = intern(fp.fr(limb_modulus * borrow - borrow));              // :144
-        id_reduce_k[0] = intern(fp.fr(limb_modulus * HBig(OVERFLOW_LIMIT)));                         // :362-365
-        id_reduce_k[1] = intern(fp.fr(limb_modulus * HBig(OVERFLOW_LIMIT) - HBig(OVERFLOW_LIMIT)));
-        for (int k = 0; k < 16; k++) id_small[k] = intern(fp.fr(HBig((uint64_t)k)));
-        for (int k = 0; k < 8; k++) id_pow2[k] = intern(fp.fr(HBig(1ull << k)));
-        for (int k = 0; k <= 18; k++) id_tag[k] = intern(fp.fr(HBig((uint64_t)k)));
+    }
+    // Switch the integer chip to another W field (the scalar_integer_ctx / base_integer_ctx of a
+    // GeneralScalarEccContext share one Context, context.rs:215-239).  Main context only: a segment (= one engine
+    // launch = one kernel instantiation) works in one field.
+    void use_field(int id) {
+        if (id == fp.id) return;
+        if (in_strand) throw std::runtime_error("use_field inside a fork");
+        fp = field_pair_of(id);
+        field_ids();
+        close_segment();
         begin_segment();
     }
 
@@ -310,6 +340,7 @@ struct Recorder {
     // ---- segments / strands --------------------------------------------------------------------
     void begin_segment() {
         Segment s;
+        s.field_pair = fp.id;
         s.tape_begin = s.tape_end = (uint32_t)tape.size();
         s.fixups_begin = (uint32_t)fixups.size();
         s.cuts_begin = (uint32_t)cuts.size();
@@ -370,7 +401,10 @@ struct Recorder {
 
     // Run `body(strand)` for n strands as a forked region.  Every strand must consume the same Offset
     // (the reference asserts this for MSM windows, ecc_chip.rs:339).  Returns the per-strand Offset.
-    Offset fork(uint32_t n_strands, uint32_t input_stride, const std::function<void(uint32_t)>& body) {
+    // `merged` = the strands are the reference's cloned contexts that are merge()d back (the MSM windows,
+    // ecc_chip.rs:289-352): merge sets range_height = max(select_height, other.range_height) with the parent's select
+    // height *before* that clone's select rows are merged (quirk Q3, native_scalar_ecc_chip.rs:80-89)
+    Offset fork(uint32_t n_strands, uint32_t input_stride, const std::function<void(uint32_t)>& body, bool merged = false) {
         if (in_strand) throw std::runtime_error("nested fork");
         Offset delta;
         if (n_strands == 0) return delta;
@@ -378,6 +412,7 @@ struct Recorder {
         Segment seg;
         seg.tape_begin = (uint32_t)tape.size();
         seg.is_fork = true;
+        seg.field_pair = fp.id;
         seg.n_strands = n_strands;
         seg.base0 = (uint32_t)base_offset;
         seg.range0 = (uint32_t)range_offset;
@@ -388,6 +423,7 @@ struct Recorder {
         seg.cuts_begin = fork_cuts_begin = (uint32_t)cuts.size();
         cur_tape_begin = seg.tape_begin;
         size_t b0 = base_offset, r0 = range_offset, s0 = select_offset;
+        const size_t select_height_at_fork = select_height;
         seg_cells_start = n_advice_cells;
         in_strand = true;
         strand_params_begin = seg.params_begin;
@@ -437,6 +473,12 @@ struct Recorder {
             if (delta.base_offset_diff) base_height = std::max(base_height, base_offset);
             if (delta.range_offset_diff) range_height = std::max(range_height, range_offset + 1);
             if (delta.select_offset_diff) select_height = std::max(select_height, select_offset);
+        }
+        if (merged) {
+            // select height of the parent when the last clone is merged = after the clones before it
+            size_t sel_before_last = delta.select_offset_diff ? std::max<size_t>(select_height_at_fork, s0 + (n_strands - 1) * delta.select_offset_diff)
+                                                              : select_height_at_fork;
+            range_height = std::max(range_height, sel_before_last);
         }
         strand_n_params = 0;
         begin_segment();
@@ -1078,16 +1120,45 @@ struct Recorder {
     }
     // bisec_int (integer_chip.rs:660-681)
     AssignedInteger bisec_int(const AssignedCondition& cond, const AssignedInteger& a, const AssignedInteger& b) {
-        H2EOp op = new_op(H2E_OP_BISEC_INT);
+        return bisec_int_limbs(cond, a, b, fp.limbs);
+    }
+    // bisec_int of integers of `limbs` limbs, whatever the current field is: the rows are base-chip rows only, so the
+    // other integer context of a GeneralScalarEccContext can call it from inside a fork of this one (ecc_bisec_scalar next
+    // to ecc_bisec_to_non_zero_point in msm_unsafe's loop, ecc_chip.rs:386-391).  op.imm = limbs.
+    AssignedInteger bisec_int_limbs(const AssignedCondition& cond, const AssignedInteger& a, const AssignedInteger& b, int limbs) {
+        H2EOp op = new_op(H2E_OP_BISEC_INT, (uint32_t)limbs);
         op.refs[0] = cond.v.ref;
-        put_int(op, 1, a);
-        put_int(op, fp.limbs + 2, b);
+        for (int i = 0; i < limbs; i++) {
+            op.refs[1 + i] = a.limbs_le[i];
+            op.refs[limbs + 2 + i] = b.limbs_le[i];
+        }
+        op.refs[1 + limbs] = a.native;
+        op.refs[2 * limbs + 2] = b.native;
         push(op);
         AssignedInteger r;
-        for (int i = 0; i < fp.limbs; i++) r.limbs_le[i] = mk(0, 4, bisec_row(cond.v.ref, a.limbs_le[i], b.limbs_le[i]));
+        for (int i = 0; i < limbs; i++) r.limbs_le[i] = mk(0, 4, bisec_row(cond.v.ref, a.limbs_le[i], b.limbs_le[i]));
         r.native = mk(0, 4, bisec_row(cond.v.ref, a.native, b.native));
         r.times = std::max(a.times, b.times);
         return r;
+    }
+    // One limb of GeneralScalarEccContext::decompose_scalar::<1> (general_scalar_ecc_chip.rs:107-130): per bit j of the
+    // limb (LSB first) assign_bit(b_j), then [rest * -1, b_j * 1 | v * 2] with v = (rest - b_j) / 2 becoming the next
+    // `rest`; finally assert_constant(rest, 0).  Returns the bit cells in the order they are pushed (LSB first).
+    std::vector<AssignedCondition> decompose_limb(uint32_t limb_ref, int bits) {
+        H2EOp op = new_op(H2E_OP_DECOMPOSE_LIMB, (uint32_t)bits);
+        op.refs[0] = limb_ref;
+        push(op);
+        std::vector<AssignedCondition> out;
+        uint32_t rest = limb_ref;
+        for (int j = 0; j < bits; j++) {
+            size_t brow = base_line({U(id_one), U(id_zero)}, none(), id_neg_one);      // assign_bit (base_chip.rs:357-367)
+            uint32_t b = mk(0, 0, brow);
+            size_t row = base_line({A(rest, id_neg_one), A(b, id_one)}, U(id_two));
+            rest = mk(0, 4, row);
+            out.push_back(AssignedCondition{AssignedValue{b}});
+        }
+        base_line({A(rest, id_neg_one)}, none(), 0, 0, 0, id_zero);                      // assert_constant(rest, 0)
+        return out;
     }
 };
 

@@ -309,6 +309,50 @@ struct NativeScalarEccContext {
     }
     AssignedValue ecc_assign_constant_zero_scalar() { return ctx.assign_constant_u64(0); }
 
+    // ---- EccChipScalarOps for a non-native scalar field (GeneralScalarEccContext, general_scalar_ecc_chip.rs:93-168) ----
+    // scalar_field >= 0: AssignedScalar = AssignedInteger<C::Scalar, N> of the *other* integer context (context.rs:215-239);
+    // -1: AssignedValue (NativeScalarEccContext), carried in AssignedInteger::native so that one MSM body serves both.
+    int scalar_field = -1;
+    int scalar_limbs() const { return scalar_field < 0 ? 0 : field_pair_of(scalar_field).limbs; }
+    AssignedInteger scalar_param(const AssignedInteger& s) {
+        AssignedInteger r = s;
+        for (int i = 0; i < scalar_limbs(); i++) r.limbs_le[i] = ctx.param(s.limbs_le[i]);
+        r.native = ctx.param(s.native);
+        return r;
+    }
+    AssignedInteger scalar_zero() {   // ecc_assign_constant_zero_scalar (native :188-192, general :163-167)
+        AssignedInteger r;
+        if (scalar_field < 0) {
+            r.native = ecc_assign_constant_zero_scalar().ref;
+            return r;
+        }
+        int base_field = ctx.fp.id;
+        ctx.use_field(scalar_field);
+        r = ctx.assign_int_constant(HBig(0));
+        ctx.use_field(base_field);
+        return r;
+    }
+    AssignedInteger scalar_bisec(const AssignedCondition& cond, const AssignedInteger& a, const AssignedInteger& b) {
+        AssignedInteger r;
+        if (scalar_field < 0) {
+            r.native = ecc_bisec_scalar(cond, AssignedValue{a.native}, AssignedValue{b.native}).ref;
+            return r;
+        }
+        return ctx.bisec_int_limbs(cond, a, b, scalar_limbs());   // scalar_integer_ctx.bisec_int (general :154-161)
+    }
+    // decompose_scalar::<1>: bit cells, MSB (window 0) first
+    std::vector<AssignedCondition> scalar_decompose(const AssignedInteger& s) {
+        if (scalar_field < 0) return decompose_scalar(AssignedValue{s.native});
+        // general_scalar_ecc_chip.rs:96-147: reduce (a no-op for the bisected scalars: times == 1), then limb by limb
+        if (s.times != 1) throw std::runtime_error("decompose_scalar: scalar not reduced (times != 1)");
+        std::vector<AssignedCondition> bits;
+        for (int l = 0; l < scalar_limbs(); l++) {
+            std::vector<AssignedCondition> b = ctx.decompose_limb(s.limbs_le[l], LIMB_BITS);
+            bits.insert(bits.end(), b.begin(), b.end());
+        }
+        return std::vector<AssignedCondition>(bits.rbegin(), bits.rend());
+    }
+
     void push_point_refs(std::vector<uint32_t>& v, const AssignedNonZeroPoint& p) const {
         for (int j = 0; j < ctx.fp.limbs; j++) v.push_back(p.x.limbs_le[j]);
         v.push_back(p.x.native);
@@ -348,35 +392,67 @@ struct NativeScalarEccContext {
         if (curr.size() != 1) throw std::runtime_error("bisec_candidate: size != 1");
         return curr[0];
     }
-    AssignedPoint msm_unsafe_from_inputs(uint32_t n, uint32_t first_slot, const MsmInputs& mi, uint32_t gen_x_slot,
-                                         uint32_t gen_y_slot) {
+    // points.iter().map(|x| ctx.assign_point(x)) as a fork over the points: slots (x, y, z) per point from first_slot
+    std::vector<AssignedPoint> assign_points_from_inputs(uint32_t n, uint32_t first_slot) {
         Recorder& c = ctx;
-        int L = c.fp.limbs;
-        // points.iter().map(|x| ctx.assign_point(x))
         AssignedPoint p0;
         c.fork(n, 3, [&](uint32_t k) {
             AssignedPoint p = assign_point(PointInput{first_slot + 0, first_slot + 1, first_slot + 2, true});
             if (k == 0) p0 = p;
         });
-        Segment seg_points = c.segments[c.segments.size() - 2];
-        // scalars.iter().map(|x| ctx.assign(*x))
-        AssignedValue s0;
+        Segment seg = c.segments[c.segments.size() - 2];
+        std::vector<AssignedPoint> out;
+        for (uint32_t k = 0; k < n; k++)
+            out.push_back(AssignedPoint{c.strand_int(p0.x, seg, k), c.strand_int(p0.y, seg, k),
+                                        AssignedCondition{AssignedValue{c.strand_ref(p0.z.v.ref, seg, k)}}});
+        return out;
+    }
+    // the scalars of the test bodies: native `ctx.assign(x)` (tests/native_scalar_ecc_chip.rs:40-43) or
+    // `scalar_integer_ctx.assign_w(x)` (tests/general_scalar_ecc_chip.rs:38-41), one input slot each from first_slot
+    std::vector<AssignedInteger> assign_scalars_from_inputs(uint32_t n, uint32_t first_slot) {
+        Recorder& c = ctx;
+        AssignedInteger s0;
+        int base_field = c.fp.id;
+        if (scalar_field >= 0) c.use_field(scalar_field);
         c.fork(n, 1, [&](uint32_t k) {
-            AssignedValue s = c.assign(first_slot + 3 * n, true);
+            AssignedInteger s;
+            if (scalar_field < 0) s.native = c.assign(first_slot, true).ref;
+            else s = c.assign_w(first_slot, true);
             if (k == 0) s0 = s;
         });
-        Segment seg_scalars = c.segments[c.segments.size() - 2];
-
-        // ---- msm_unsafe (ecc_chip.rs:373-408) ----
+        Segment seg = c.segments[c.segments.size() - 2];
+        if (scalar_field >= 0) c.use_field(base_field);
+        std::vector<AssignedInteger> out;
+        for (uint32_t k = 0; k < n; k++) {
+            AssignedInteger s = s0;
+            for (int i = 0; i < scalar_limbs(); i++) s.limbs_le[i] = c.strand_ref(s0.limbs_le[i], seg, k);
+            s.native = c.strand_ref(s0.native, seg, k);
+            out.push_back(s);
+        }
+        return out;
+    }
+    AssignedPoint msm_unsafe_from_inputs(uint32_t n, uint32_t first_slot, const MsmInputs& mi, uint32_t gen_x_slot,
+                                         uint32_t gen_y_slot) {
+        std::vector<AssignedPoint> points = assign_points_from_inputs(n, first_slot);
+        std::vector<AssignedInteger> scalars = assign_scalars_from_inputs(n, first_slot + 3 * n);
+        return msm_unsafe(points, scalars, mi, gen_x_slot, gen_y_slot);
+    }
+    // EccChipScalarOps::msm_unsafe (ecc_chip.rs:373-408) on assigned points / scalars (handles = absolute cell refs).
+    // The blinding points r1, r2 the reference draws inside (quirk Q1) and the generator are instance inputs.
+    AssignedPoint msm_unsafe(const std::vector<AssignedPoint>& points, const std::vector<AssignedInteger>& scalars,
+                             const MsmInputs& mi, uint32_t gen_x_slot, uint32_t gen_y_slot) {
+        Recorder& c = ctx;
+        int L = c.fp.limbs;
+        uint32_t n = (uint32_t)points.size();
+        if (n == 0 || scalars.size() != n) throw std::runtime_error("msm_unsafe: points / scalars mismatch");
         AssignedNonZeroPoint non_zero_p = assign_non_zero_point(gen_x_slot, gen_y_slot);
-        AssignedValue s_zero = ecc_assign_constant_zero_scalar();
-        AssignedValue ns0;
+        AssignedInteger s_zero = scalar_zero();
+        AssignedInteger ns0;
         AssignedNonZeroPoint np0;
         c.fork(n, 0, [&](uint32_t k) {
-            AssignedPoint pk{c.param(c.strand_int(p0.x, seg_points, k)), c.param(c.strand_int(p0.y, seg_points, k)),
-                             AssignedCondition{c.param(AssignedValue{c.strand_ref(p0.z.v.ref, seg_points, k)})}};
-            AssignedValue sk = c.param(AssignedValue{c.strand_ref(s0.ref, seg_scalars, k)});
-            AssignedValue s = ecc_bisec_scalar(pk.z, s_zero, sk);
+            AssignedPoint pk{c.param(points[k].x), c.param(points[k].y), AssignedCondition{c.param(points[k].z.v)}};
+            AssignedInteger sk = scalar_param(scalars[k]);
+            AssignedInteger s = scalar_bisec(pk.z, s_zero, sk);
             AssignedNonZeroPoint p = ecc_bisec_to_non_zero_point(pk, non_zero_p);
             if (k == 0) {
                 ns0 = s;
@@ -386,6 +462,12 @@ struct NativeScalarEccContext {
         Segment seg_norm = c.segments[c.segments.size() - 2];
         auto point_k = [&](uint32_t k) {
             return AssignedNonZeroPoint{c.strand_int(np0.x, seg_norm, k), c.strand_int(np0.y, seg_norm, k)};
+        };
+        auto scalar_k = [&](uint32_t k) {
+            AssignedInteger r = ns0;
+            for (int i = 0; i < scalar_limbs(); i++) r.limbs_le[i] = c.strand_ref(ns0.limbs_le[i], seg_norm, k);
+            r.native = c.strand_ref(ns0.native, seg_norm, k);
+            return r;
         };
 
         // ---- msm_batch_on_group_non_zero_with_select_chip (ecc_chip.rs:223-371) ----
@@ -518,8 +600,8 @@ struct NativeScalarEccContext {
         // decompose_scalar per scalar (ecc_chip.rs:277-280)
         std::vector<AssignedCondition> bits0;
         c.fork(n, 0, [&](uint32_t k) {
-            AssignedValue sk = c.param(AssignedValue{c.strand_ref(ns0.ref, seg_norm, k)});
-            std::vector<AssignedCondition> b = decompose_scalar(sk);
+            AssignedInteger sk = scalar_param(scalar_k(k));
+            std::vector<AssignedCondition> b = scalar_decompose(sk);
             if (k == 0) bits0 = b;
         });
         Segment seg_bits = c.segments[c.segments.size() - 2];
@@ -570,7 +652,7 @@ struct NativeScalarEccContext {
                 c.cut();
             }
             if (wi == 0) line_acc0 = acc;
-        });
+        }, true);
         c.end_hints();
         c.segments[c.segments.size() - 2].sel_stride = (uint32_t)n_groups;
         Segment seg_windows = c.segments[c.segments.size() - 2];

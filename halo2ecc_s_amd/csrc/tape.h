@@ -43,7 +43,8 @@ enum H2EOpcode {
     H2E_OP_NOT,               // base_chip.rs:398-403
     H2E_OP_MASK_INT,          // int_div's a' = a * not(is_b_zero), limb-wise + native   :511-520
     H2E_OP_DIV_CORE,          // int_div's c,d hints + assign_w/assign_d + mul equation  :522-535
-    H2E_OP_BISEC_INT,         // :660-681
+    H2E_OP_BISEC_INT,         // :660-681   imm = limbs (0: the kernel's field; a GeneralScalarEccContext bisects scalars
+                              //            of its other integer context inside a fork of the base field)
     H2E_OP_SUM_LIMBS,         // sum_with_constant(limbs, 1) of assert_int_equal  :607-610
     // base chip rows
     H2E_OP_ASSERT_CONST,      // assert_constant(x, imm in {0,1})    base_chip.rs:375-379 ; flags a status on mismatch
@@ -56,6 +57,8 @@ enum H2EOpcode {
     // select chip
     H2E_OP_CACHE_INT,         // assign_cache_integer      ecc_chip.rs:734-751
     H2E_OP_SELECT_POINT,      // assign_selected_point_non_zero  ecc_chip.rs:955-967 (value picked by index cell)
+    // general (non-native) scalars
+    H2E_OP_DECOMPOSE_LIMB,    // one limb of decompose_scalar::<1>  general_scalar_ecc_chip.rs:107-130, imm = limb bits
     H2E_OP_COUNT
 };
 
@@ -171,6 +174,8 @@ typedef struct H2ELaunch {
     const struct H2EVRec* lrecs;
     const uint32_t* lrefs;        // cell refs of global integer operands (L + 1 each)
     uint32_t l_steps, l_slots;
+    uint32_t field_pair;          // the W field of this segment's integer ops (host side: which kernel instantiation)
+    uint32_t slot_words;          // words per input slot (the program's: 6 for a bls12_381 Fq program even in its Fr segments)
 } H2ELaunch;
 
 // ---- compiled values-only replay ("V-tape") ----------------------------------------------------

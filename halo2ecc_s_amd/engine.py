@@ -26,7 +26,10 @@ EXPORTED_SYMBOLS = [
     "h2e_program_pairing_check_bls12_381", "h2e_program_destroy", "h2e_program_shape", "h2e_run",
     "h2e_int_mul_batch", "h2e_msm_bn256_tile", "h2e_pairing_check_bn256", "h2e_pairing_check_bls12_381",
     "h2e_last_run_launch_ms", "h2e_set_profiling", "h2e_program_outputs", "h2e_program_launches", "h2e_export",
-    "h2e_submit", "h2e_wait", "h2e_job_launch_ms", "h2e_digest", "h2e_program_pairing", "h2e_ctx_set_option", "h2e_ctx_get_stat",
+    "h2e_submit", "h2e_wait", "h2e_job_launch_ms", "h2e_digest", "h2e_program_pairing", "h2e_program_msm_bls12_381_tile",
+    "h2e_records_create", "h2e_records_destroy", "h2e_records_arrays", "h2e_records_shape", "h2e_op_assign_w", "h2e_op_assign",
+    "h2e_op_int", "h2e_op_assign_points", "h2e_op_assign_scalars", "h2e_op_msm_unsafe", "h2e_op_ecc_assert_equal",
+    "h2e_op_assign_g2_constant", "h2e_op_check_pairing", "h2e_ctx_set_option", "h2e_ctx_get_stat",
     "h2e_program_msm_bn256_tile_no_select", "h2e_last_run_expansion_launches",
 ]
 
@@ -54,6 +57,20 @@ class _Shape(C.Structure):
     ]
 
 
+class HInt(C.Structure):      # h2e_int: AssignedInteger (src/assign.rs:31-37) as cell references + times
+    _fields_ = [("limbs", C.c_uint32 * 4), ("native", C.c_uint32), ("times", C.c_uint32)]
+
+
+class HPoint(C.Structure):    # h2e_point: AssignedPoint
+    _fields_ = [("x", HInt), ("y", HInt), ("z", C.c_uint32)]
+
+
+class HG2(C.Structure):       # h2e_g2: AssignedG2Affine
+    _fields_ = [("x0", HInt), ("x1", HInt), ("y0", HInt), ("y1", HInt), ("z", C.c_uint32)]
+
+
+INT_ADD, INT_SUB, INT_MUL, INT_DIV, INT_REDUCE = 0, 1, 2, 3, 4
+
 _lib = None
 
 
@@ -79,6 +96,21 @@ def lib():
     L.h2e_program_msm_bn256_tile_no_select.argtypes = [u32, i32, C.POINTER(vp)]
     L.h2e_program_pairing_check_bn256.argtypes = [i32, C.POINTER(vp)]
     L.h2e_program_pairing_check_bls12_381.argtypes = [i32, C.POINTER(vp)]
+    L.h2e_program_msm_bls12_381_tile.argtypes = [u32, i32, C.POINTER(vp)]
+    L.h2e_records_create.argtypes = [vp, i32, i32, u32, C.c_uint64, C.c_uint64, C.c_uint64, i32, C.POINTER(vp)]
+    L.h2e_records_destroy.argtypes = [vp]
+    L.h2e_records_destroy.restype = None
+    L.h2e_records_arrays.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.h2e_records_shape.argtypes = [vp, C.POINTER(_Shape)]
+    L.h2e_op_assign_w.argtypes = [vp, vp, C.POINTER(HInt), vp]
+    L.h2e_op_assign.argtypes = [vp, vp, C.POINTER(u32), vp]
+    L.h2e_op_int.argtypes = [vp, i32, C.POINTER(HInt), C.POINTER(HInt), C.POINTER(HInt), C.POINTER(u32), vp]
+    L.h2e_op_assign_points.argtypes = [vp, u32, vp, C.POINTER(HPoint), vp]
+    L.h2e_op_assign_scalars.argtypes = [vp, u32, vp, C.POINTER(HInt), vp]
+    L.h2e_op_msm_unsafe.argtypes = [vp, u32, C.POINTER(HPoint), C.POINTER(HInt), vp, C.POINTER(HPoint), vp]
+    L.h2e_op_ecc_assert_equal.argtypes = [vp, C.POINTER(HPoint), C.POINTER(HPoint), vp]
+    L.h2e_op_assign_g2_constant.argtypes = [vp, vp, C.POINTER(HG2), vp]
+    L.h2e_op_check_pairing.argtypes = [vp, u32, C.POINTER(HPoint), C.POINTER(HG2), vp]
     L.h2e_program_pairing.argtypes = [i32, u32, i32, i32, C.POINTER(vp)]
     L.h2e_program_destroy.argtypes = [vp]
     L.h2e_program_destroy.restype = None
@@ -156,6 +188,11 @@ class Program:
         return cls._make(lib().h2e_program_pairing_check_bls12_381, int(emit_shape))
 
     @classmethod
+    def msm_bls12_381_tile(cls, n_points, emit_shape=True):
+        """general-scalar MSM tile: bls12_381 G1 points, bls12_381 Fr scalars as 3-limb integers"""
+        return cls._make(lib().h2e_program_msm_bls12_381_tile, n_points, int(emit_shape))
+
+    @classmethod
     def pairing(cls, curve, n_pairs, with_expected, emit_shape=True):
         """pairing(terms) [+ fq12_assert_eq(expected, result)]; curve 0 = bn256, 1 = bls12_381"""
         return cls._make(lib().h2e_program_pairing, curve, n_pairs, int(with_expected), int(emit_shape))
@@ -211,6 +248,114 @@ class Program:
             self.close()
         except Exception:
             pass
+
+
+class Records:
+    """Operator API (include/h2e.h): a device-resident Context for a batch of instances.  Mirrors the reference's usage:
+    create a context, call chip ops on it with handles, read `Records` at the end."""
+
+    def __init__(self, engine, field_pair, n_instances, rows, scalar_field=-1, emit_shape=True):
+        self.engine, self.n, self.field_pair = engine, n_instances, field_pair
+        self.rows = tuple(rows)
+        self.slot_words = 6 if field_pair == FIELD_BLS12_381_FQ else 4
+        h = C.c_void_p()
+        _check(lib().h2e_records_create(engine._h, field_pair, scalar_field, n_instances, rows[0], rows[1], rows[2], int(emit_shape), C.byref(h)))
+        self._h = h
+        self._keep = []   # input tensors stay alive while kernels may read them
+
+    def _in(self, values):
+        """numpy uint64 [n_instances][slots][slot_words] -> device pointer"""
+        t = self.engine.torch
+        a = np.ascontiguousarray(values, dtype=np.uint64)
+        assert a.shape[0] == self.n and a.shape[2] == self.slot_words, a.shape
+        d = t.from_numpy(a.view(np.int64)).to(f"cuda:{self.engine.device}")
+        self._keep.append(d)
+        return d.data_ptr()
+
+    def _s(self):
+        return self.engine._stream(None).cuda_stream
+
+    def assign_w(self, values):
+        out = HInt()
+        _check(lib().h2e_op_assign_w(self._h, self._in(values), C.byref(out), self._s()))
+        return out
+
+    def assign(self, values):
+        out = C.c_uint32()
+        _check(lib().h2e_op_assign(self._h, self._in(values), C.byref(out), self._s()))
+        return out.value
+
+    def int_op(self, which, a, b=None):
+        out, cond = HInt(), C.c_uint32()
+        _check(lib().h2e_op_int(self._h, which, C.byref(a), C.byref(b) if b is not None else None, C.byref(out), C.byref(cond), self._s()))
+        return (out, cond.value) if which == INT_DIV else out
+
+    def assign_points(self, n, values):
+        out = (HPoint * n)()
+        _check(lib().h2e_op_assign_points(self._h, n, self._in(values), out, self._s()))
+        return out
+
+    def assign_scalars(self, n, values):
+        out = (HInt * n)()
+        _check(lib().h2e_op_assign_scalars(self._h, n, self._in(values), out, self._s()))
+        return out
+
+    def msm_unsafe(self, points, scalars, values):
+        out = HPoint()
+        _check(lib().h2e_op_msm_unsafe(self._h, len(points), points, scalars, self._in(values), C.byref(out), self._s()))
+        return out
+
+    def ecc_assert_equal(self, a, b):
+        _check(lib().h2e_op_ecc_assert_equal(self._h, C.byref(a), C.byref(b), self._s()))
+
+    def assign_g2_constant(self, values):
+        out = HG2()
+        _check(lib().h2e_op_assign_g2_constant(self._h, self._in(values), C.byref(out), self._s()))
+        return out
+
+    def check_pairing(self, g1, g2):
+        a = (HPoint * len(g1))(*g1)
+        b = (HG2 * len(g2))(*g2)
+        _check(lib().h2e_op_check_pairing(self._h, len(g1), a, b, self._s()))
+
+    def shape(self):
+        s = _Shape()
+        _check(lib().h2e_records_shape(self._h, C.byref(s)))
+        return s
+
+    def arrays(self):
+        """the batch-interleaved advice arrays as torch tensors [rows][cols][2][n][2] + status words (views of the
+        records' device memory: valid while the records are alive)"""
+        t = self.engine.torch
+        p = [C.c_void_p() for _ in range(4)]
+        _check(lib().h2e_records_arrays(self._h, *(C.byref(x) for x in p)))
+        out = []
+        for k, (rows, cols) in enumerate(zip(self.rows, COLS)):
+            out.append(_device_view(t, p[k].value, (rows, cols, 2, self.n, 2), t.int64, self.engine.device))
+        out.append(_device_view(t, p[3].value, (self.n,), t.int32, self.engine.device))
+        return out
+
+    def close(self):
+        if self._h:
+            self.engine.torch.cuda.synchronize()
+            lib().h2e_records_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _device_view(t, ptr, shape, dtype, device):
+    """torch tensor over foreign device memory (through __cuda_array_interface__)"""
+    n = int(np.prod(shape))
+    itemsize = 8 if dtype == t.int64 else 4
+
+    class _Mem:
+        __cuda_array_interface__ = {"shape": (n,), "typestr": "<i8" if itemsize == 8 else "<i4", "data": (ptr, False), "version": 2}
+    return t.as_tensor(_Mem(), device=f"cuda:{device}").view(shape)
 
 
 class Engine:

@@ -192,23 +192,31 @@ def msm_bn256_tile_inputs(n, seed_index=2, tile=0, cheap_points=False, with_expe
     cheap_points: P_i = P_0 + i*D instead of n independent scalar multiplications (bench-sized tiles).
     identity_at: indices whose point is the identity (z = 1, x = y = 0).
     Returns (inputs[4n+9][4], expected_point or None)."""
+    return _msm_tile_inputs(bn_g1_gen(), BN_R, 4, n, seed_index, tile, cheap_points, with_expected, identity_at)
+
+
+def msm_bls12_381_tile_inputs(n, seed_index=8, tile=0, cheap_points=False, with_expected=True, identity_at=()):
+    """the same for h2e_program_msm_bls12_381_tile (general-scalar MSM: bls12_381 G1 points, scalars < bls12_381 r; 6-word slots)"""
+    return _msm_tile_inputs(bls_g1_gen(), BLS_R, 6, n, seed_index, tile, cheap_points, with_expected, identity_at)
+
+
+def _msm_tile_inputs(G, R, slot_words, n, seed_index, tile, cheap_points, with_expected, identity_at):
     rng = SplitMix64(SEED0 + seed_index + 1000003 * tile)
-    G = bn_g1_gen()
     pts = []
     if cheap_points:
-        P = ec_mul(G, rng.below(BN_R))
-        D = ec_mul(G, rng.below(BN_R))
+        P = ec_mul(G, rng.below(R))
+        D = ec_mul(G, rng.below(R))
         for _ in range(n):
             pts.append(P)
             P = ec_add(P, D)
     else:
         for _ in range(n):
-            pts.append(ec_mul(G, rng.below(BN_R)))
+            pts.append(ec_mul(G, rng.below(R)))
     for i in identity_at:
         pts[i] = None
-    scalars = [rng.below(BN_R) for _ in range(n)]
-    r1 = ec_mul(G, rng.below(BN_R))
-    r2 = ec_mul(G, rng.below(BN_R))
+    scalars = [rng.below(R) for _ in range(n)]
+    r1 = ec_mul(G, rng.below(R))
+    r2 = ec_mul(G, rng.below(R))
     vals = []
     for P in pts:
         vals += [0, 0, 1] if P is None else [P[0].a, P[1].a, 0]
@@ -224,7 +232,7 @@ def msm_bn256_tile_inputs(n, seed_index=2, tile=0, cheap_points=False, with_expe
         vals += [0, 0, 1] if acc is None else [acc[0].a, acc[1].a, 0]
     else:
         vals += [G[0].a, G[1].a, 0]  # placeholder: the final ecc_assert_equal will flag ASSERT_FAILED
-    return pack(vals, 4), expected
+    return pack(vals, slot_words), expected
 
 
 def pairing_check_bn256_inputs(seed_index=4, instance=0):

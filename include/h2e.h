@@ -84,6 +84,12 @@ int h2e_program_msm_bn256_tile(uint32_t n_points, int emit_shape, h2e_program** 
  * src/context.rs:190-207): msm_batch_on_group_non_zero_without_select_chip (src/circuit/ecc_chip.rs:91-221), groups of
  * two points, candidates chosen by bisec_candidate_non_zero (:913-933).  SURVEY.md §8(f)-3.  Same inputs. */
 int h2e_program_msm_bn256_tile_no_select(uint32_t n_points, int emit_shape, h2e_program** out);
+/* body of test_bls12_381_ecc_chip_over_bn256_fr (src/tests/general_scalar_ecc_chip.rs:14-49) for one tile of n points
+ * (SURVEY.md 8(f)-2): GeneralScalarEccContext<bls12_381::G1Affine, bn256::Fr> - assign_point x n, scalar_integer_ctx.assign_w x n,
+ * msm (general_scalar_ecc_chip.rs:93-168: scalars are 3-limb integers of the second integer context, decomposed limb by
+ * limb into 324 one-bit windows), assign_point(expected), ecc_assert_equal.  Same input layout as h2e_program_msm_bn256_tile
+ * with 6-word slots (points over bls12_381 Fq, scalars < bls12_381 r). */
+int h2e_program_msm_bls12_381_tile(uint32_t n_points, int emit_shape, h2e_program** out);
 /* check_pairing([(a, b), (-a, b)]) with G2 as constants (PairingChipOps::check_pairing,
  * src/circuit/pairing_chip.rs:173-176; shape of src/tests/native_scalar_pairing_chip.rs:67-97).
  * inputs: b.x.c0, b.x.c1, b.y.c0, b.y.c1, (-a).x, (-a).y, (-a).z, a.x, a.y, a.z. */
@@ -196,6 +202,48 @@ int h2e_pairing_check_bls12_381(h2e_ctx* ctx, uint32_t n_instances, const void* 
 #define H2E_FORM_MONTGOMERY 1
 int h2e_export(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, int layout, int form, const void* d_batch,
                void* d_out, void* stream);
+
+/* ---- operator API: a device-resident Context -----------------------------------------------------
+ * The reference's operator surface is a Context you call chip ops on (`IntegerChipOps` src/circuit/integer_chip.rs:15-70,
+ * `EccChipBaseOps` / `EccChipScalarOps` src/circuit/ecc_chip.rs:79-430, `PairingChipOps` src/circuit/pairing_chip.rs:157-176); its own
+ * seam for doing part of the work elsewhere is fork-at-offset / merge (`ParallelClone`, ecc_chip.rs:64-77).  h2e_records is that
+ * Context for a batch of n_instances instances which run the same ops on different values: the advice arrays live in HBM
+ * (batch-interleaved, `rows` = the capacity, like HALO2ECC_S_MAX_ROWS of src/context.rs:36), cursors, heights, the msm prefix
+ * (`NativeScalarEccContext.1`, native_scalar_ecc_chip.rs:173-178) and the shape artefacts on the host.  Every op appends its rows
+ * at the current offsets - exactly the rows the reference's op writes when called at that point of a Context - takes its operands
+ * as handles (cell references to rows written earlier, plus the static `times`), and returns handles.  Values never cross the
+ * boundary except as inputs: d_inputs = device [n_instances][slots of the op][slot_words] canonical words.
+ * field_pair = the W field of the integer chip / the base field of the curve; scalar_field = -1 for a NativeScalarEccContext,
+ * H2E_FIELD_BLS12_381_FR for GeneralScalarEccContext<bls12_381::G1Affine, bn256::Fr> (scalars are h2e_int of that field then;
+ * native scalars use h2e_int.native only).  Ops are asynchronous on `stream` like h2e_run; status words accumulate (or). */
+typedef struct h2e_records h2e_records;
+typedef struct h2e_int { uint32_t limbs[4]; uint32_t native; uint32_t times; } h2e_int;      /* AssignedInteger (src/assign.rs:31-37) */
+typedef struct h2e_point { h2e_int x, y; uint32_t z; } h2e_point;                            /* AssignedPoint (src/assign.rs:46-51) */
+typedef struct h2e_g2 { h2e_int x0, x1, y0, y1; uint32_t z; } h2e_g2;                         /* AssignedG2Affine (src/assign.rs:171-192) */
+int h2e_records_create(h2e_ctx* ctx, int field_pair, int scalar_field, uint32_t n_instances, uint64_t base_rows, uint64_t range_rows,
+                       uint64_t select_rows, int emit_shape, h2e_records** out);
+void h2e_records_destroy(h2e_records* rec);
+int h2e_records_arrays(h2e_records* rec, void** d_base, void** d_range, void** d_select, void** d_status);
+/* offsets, heights, accumulated fixed cells / flags / permutations over rows [0, capacity); *_rows = the capacity;
+ * fixed_patches[k] = [row, fixed col, op index << 16 | input slot, limb] */
+int h2e_records_shape(const h2e_records* rec, h2e_shape* out);
+int h2e_op_assign_w(h2e_records* rec, const void* d_inputs /* 1 slot */, h2e_int* out, void* stream);
+int h2e_op_assign(h2e_records* rec, const void* d_inputs /* 1 slot */, uint32_t* out_cell, void* stream);
+#define H2E_INT_ADD 0
+#define H2E_INT_SUB 1
+#define H2E_INT_MUL 2
+#define H2E_INT_DIV 3      /* out_cond = the is_b_zero condition cell */
+#define H2E_INT_REDUCE 4   /* b unused */
+int h2e_op_int(h2e_records* rec, int which, const h2e_int* a, const h2e_int* b, h2e_int* out, uint32_t* out_cond, void* stream);
+int h2e_op_assign_points(h2e_records* rec, uint32_t n, const void* d_inputs /* (x, y, z) x n */, h2e_point* out, void* stream);
+int h2e_op_assign_scalars(h2e_records* rec, uint32_t n, const void* d_inputs /* n slots */, h2e_int* out, void* stream);
+/* EccChipScalarOps::msm_unsafe on assigned points / scalars (ecc_chip.rs:373-408).  d_inputs: generator x, y, then the blinding
+ * points r1 (x, y), r2 (x, y) the reference draws inside (quirk Q1).  A failing instance reports H2E_ST_RETRY_* like UnsafeError. */
+int h2e_op_msm_unsafe(h2e_records* rec, uint32_t n, const h2e_point* points, const h2e_int* scalars, const void* d_inputs, h2e_point* out,
+                      void* stream);
+int h2e_op_ecc_assert_equal(h2e_records* rec, const h2e_point* a, const h2e_point* b, void* stream);
+int h2e_op_assign_g2_constant(h2e_records* rec, const void* d_inputs /* x.c0, x.c1, y.c0, y.c1 */, h2e_g2* out, void* stream);
+int h2e_op_check_pairing(h2e_records* rec, uint32_t n_pairs, const h2e_point* g1, const h2e_g2* g2, void* stream);
 
 /* On-device consumer for streaming jobs (SURVEY.md 8d cfg 3, 8e): a 32-byte digest per instance of one region's
  * batch-interleaved array, d_digests = [n_instances][4] words:

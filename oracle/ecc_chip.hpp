@@ -620,6 +620,84 @@ struct NativeScalarEccContext : EccScalarOps<NativeScalarEccContext, AssignedVal
     AssignedValue ecc_assign_constant_zero_scalar() { return base.ctx->assign_constant(Fr::zero()); }
 };
 
+// GeneralScalarEccContext<C, N> (context.rs:215-239, circuit/general_scalar_ecc_chip.rs): two integer contexts - base
+// field and scalar field of C - over one shared Context; AssignedScalar = AssignedInteger<C::Scalar, N>
+struct GeneralScalarEccContext : EccScalarOps<GeneralScalarEccContext, AssignedInteger> {
+    typedef EccScalarOps<GeneralScalarEccContext, AssignedInteger> Base;
+    IntegerContext scalar;   // scalar_integer_ctx
+    GeneralScalarEccContext(const IntegerContext& base_ic, const IntegerContext& scalar_ic, const CurveParams& cp, size_t prefix = 0)
+        : Base(base_ic, cp, prefix), scalar(scalar_ic) {}
+
+    // ParallelClone (general_scalar_ecc_chip.rs:43-91)
+    void apply_offset_diff(const Offset& d) {
+        base.ctx->base_offset += d.base_offset_diff;
+        base.ctx->range_offset += d.range_offset_diff;
+        base.ctx->select_offset += d.select_offset_diff;
+    }
+    GeneralScalarEccContext clone_with_offset(const Offset& d) const {
+        auto c = std::make_shared<Context>(base.ctx->clone_without_permutation());
+        c->base_offset += d.base_offset_diff;
+        c->range_offset += d.range_offset_diff;
+        c->select_offset += d.select_offset_diff;
+        GeneralScalarEccContext r(IntegerContext(c, base.info), IntegerContext(c, scalar.info), curve, msm_prefix);
+        r.n_threads = n_threads;
+        return r;
+    }
+    GeneralScalarEccContext clone_without_offset() const { return clone_with_offset(Offset()); }
+    Offset offset() const {
+        Offset o;
+        o.base_offset_diff = base.ctx->base_offset;
+        o.range_offset_diff = base.ctx->range_offset;
+        o.select_offset_diff = base.ctx->select_offset;
+        return o;
+    }
+    void merge(GeneralScalarEccContext& other) {
+        Records& record = base.ctx->records;
+        Records& record_other = other.base.ctx->records;
+        record.permutations.insert(record.permutations.end(), record_other.permutations.begin(), record_other.permutations.end());
+        record_other.permutations.clear();
+        record.base_height = std::max(record.base_height, record_other.base_height);
+        record.range_height = std::max(record.select_height, record_other.range_height);  // sic (quirk Q3), general_scalar_ecc_chip.rs:88
+        record.select_height = std::max(record.select_height, record_other.select_height);
+    }
+    template <class Fn>
+    void run_windows(std::vector<GeneralScalarEccContext>& ops, Fn fn) {
+        for (size_t k = 0; k < ops.size(); k++) fn(k);   // (the oracle keeps this context single-threaded)
+    }
+
+    // general_scalar_ecc_chip.rs:96-147 with WINDOW_SIZE = 1
+    std::vector<AssignedCondition> decompose_scalar(const AssignedInteger& s_in) {
+        Fr zero = Fr::zero(), one = Fr::one();
+        Fr two = one + one;
+        Fr two_inv = two.inv_or_zero();   // two.invert().unwrap()
+        AssignedInteger s = scalar.reduce(s_in);
+        std::vector<AssignedCondition> bits;
+        for (auto& l : s.limbs_le) {
+            BigUint v = l.val.to_bn();
+            AssignedValue rest = l;
+            for (uint64_t j = 0; j < scalar.info->limb_bits; j++) {
+                AssignedCondition b = base.ctx->assign_bit(v.bit(j) ? Fr::one() : Fr::zero());
+                Fr nv = (rest.val - b.v.val) * two_inv;
+                rest = base.ctx->one_line_with_last({pr(rest, -one), pr(b.v, one)}, pr(nv, two), nullptr, {}, nullptr).second;
+                bits.push_back(b);
+            }
+            base.ctx->assert_constant(rest, zero);
+        }
+        // WINDOW_SIZE == 1: no padding
+        return std::vector<AssignedCondition>(bits.rbegin(), bits.rend());
+    }
+    size_t get_and_increase_msm_prefix() {  // :149-154
+        size_t ret = msm_prefix;
+        if (!(ret < MSM_LIMIT)) throw PanicError("msm prefix limit");
+        msm_prefix += MSM_PREFIX_OFFSET;
+        return ret;
+    }
+    AssignedInteger ecc_bisec_scalar(const AssignedCondition& cond, const AssignedInteger& a, const AssignedInteger& b) {
+        return scalar.bisec_int(cond, a, b);   // :156-163
+    }
+    AssignedInteger ecc_assign_constant_zero_scalar() { return scalar.assign_int_constant(BigUint(0)); }   // :165-168
+};
+
 }  // namespace h2o
 
 #include <thread>

@@ -138,6 +138,55 @@ void* oracle_run_pairing_check_bn256(const uint64_t* inputs) {
     });
 }
 
+// Operator-API scenario (tests/test_ops_gpu.py): chip ops called one after the other on ONE context that already holds rows -
+// assign_point x n, assign x n, five integer ops, msm_unsafe twice (second call: msm prefix 2^20, quirk Q9; swapped blinding
+// points), ecc_assert_equal(res1, res2).  Inputs as for the MSM tile (the expected-result slots are unused).
+void* oracle_run_ops_msm_twice(uint32_t n, const uint64_t* inputs) {
+    return guarded([&](Run& r) {
+        IntegerContext ic(r.ctx, BnFq::modulus());
+        Inputs in{inputs, 4};
+        NativeScalarEccContext ecc = NativeScalarEccContext::new_with_select_chip(ic, bn256_g1_params());
+        ecc.curve.generator = in.point(4 * n, 4 * n + 1, 4 * n + 8);
+        ecc.curve.generator.is_identity = false;
+        std::vector<AssignedPoint> ap;
+        std::vector<AssignedValue> as;
+        for (uint32_t k = 0; k < n; k++) ap.push_back(ecc.assign_point(in.point(3 * k, 3 * k + 1, 3 * k + 2)));
+        for (uint32_t k = 0; k < n; k++) as.push_back(r.ctx->assign(in.fr(3 * n + k)));
+        AssignedInteger m = ic.int_mul(ap[0].x, ap[0].y);
+        AssignedInteger s = ic.int_add(m, m);
+        AssignedInteger s2 = ic.int_sub(s, ap[0].x);
+        AssignedInteger rd = ic.reduce(s2);
+        ic.int_div(rd, ap[0].y);
+        NativePoint r1 = in.point(4 * n + 2, 4 * n + 3, 4 * n + 8), r2 = in.point(4 * n + 4, 4 * n + 5, 4 * n + 8);
+        r1.is_identity = r2.is_identity = false;
+        AssignedPoint res1 = ecc.msm_unsafe(ap, as, r1, r2);
+        AssignedPoint res2 = ecc.msm_unsafe(ap, as, r2, r1);
+        ecc.ecc_assert_equal(res1, res2);
+    });
+}
+
+// src/tests/general_scalar_ecc_chip.rs:14-49 for one tile of n points (GeneralScalarEccContext<bls12_381::G1Affine, bn256::Fr>);
+// same input layout as h2e_program_msm_bls12_381_tile (6-word slots)
+void* oracle_run_msm_bls12_381_tile(uint32_t n, const uint64_t* inputs) {
+    return guarded([&](Run& r) {
+        IntegerContext ic(r.ctx, BlsFq::modulus());
+        IntegerContext sc(r.ctx, BlsFr::modulus());
+        Inputs in{inputs, 6};
+        GeneralScalarEccContext ecc(ic, sc, bls12_381_g1_params(), 0);
+        ecc.curve.generator = in.point(4 * n, 4 * n + 1, 4 * n + 8);
+        ecc.curve.generator.is_identity = false;
+        std::vector<AssignedPoint> ap;
+        std::vector<AssignedInteger> as;
+        for (uint32_t k = 0; k < n; k++) ap.push_back(ecc.assign_point(in.point(3 * k, 3 * k + 1, 3 * k + 2)));
+        for (uint32_t k = 0; k < n; k++) as.push_back(ecc.scalar.assign_w(in.w(3 * n + k)));
+        NativePoint r1 = in.point(4 * n + 2, 4 * n + 3, 4 * n + 8), r2 = in.point(4 * n + 4, 4 * n + 5, 4 * n + 8);
+        r1.is_identity = r2.is_identity = false;
+        AssignedPoint res = ecc.msm_unsafe(ap, as, r1, r2);
+        AssignedPoint res_expect = ecc.assign_point(in.point(4 * n + 6, 4 * n + 7, 4 * n + 8));
+        ecc.ecc_assert_equal(res, res_expect);
+    });
+}
+
 // first block of the pairing tests: pairing(terms) [== expected]
 // (src/tests/native_scalar_pairing_chip.rs:20-65, general_scalar_pairing_chip.rs:20-72); same inputs as h2e_program_pairing
 void* oracle_run_pairing(int curve, uint32_t n_pairs, int with_expected, const uint64_t* inputs) {

@@ -935,16 +935,57 @@ class NativeScalarEccContext:
         carry = self.ecc_non_zero_point_downgrade(rand_acc_point_neg)
         return self.ecc_add(acc, curv, carry)
 
+    def ecc_bisec_scalar(self, cond, a, b):                               # native_scalar_ecc_chip.rs:180-187
+        return self.ctx.bisec(cond, a, b)
+
+    def ecc_assign_constant_zero_scalar(self):                            # :188-192
+        return self.ctx.assign_constant(0)
+
     def msm_unsafe(self, points, scalars, r1, r2):                        # ecc_chip.rs:373-408 (quirk Q1: r1, r2 are inputs here)
         non_zero_p = self.assign_non_zero_point(self.generator)
-        s_zero = self.ctx.assign_constant(0)
+        s_zero = self.ecc_assign_constant_zero_scalar()
         nz_points, nz_scalars = [], []
         for p, s in zip(points, scalars):                                 # quirk Q9: every input goes through both bisecs
-            s2 = self.ctx.bisec(p.z, s_zero, s)
+            s2 = self.ecc_bisec_scalar(p.z, s_zero, s)
             p2 = self.ecc_bisec_to_non_zero_point(p, non_zero_p)
             nz_points.append(p2)
             nz_scalars.append(s2)
         return self._msm_batch(nz_points, nz_scalars, r1, r2, self.has_select_chip())
+
+
+class GeneralScalarEccContext(NativeScalarEccContext):
+    """GeneralScalarEccContext<C, N> (context.rs:215-239, circuit/general_scalar_ecc_chip.rs): a second integer context over
+    the curve's scalar field on the same Context; scalars are AssignedIntegers of that context"""
+
+    def __init__(self, ic, sc, curve_b, generator, msm_prefix=0):
+        super().__init__(ic, curve_b, generator, 0, msm_prefix)
+        self.sc = sc
+
+    def clone_with_offset(self, d):                                       # general_scalar_ecc_chip.rs:50-72
+        c = self.ctx.clone_with_offset(d)
+        return GeneralScalarEccContext(self.ic.fork(c), self.sc.fork(c), self.curve_b, self.generator, self.prefix)
+
+    def decompose_scalar(self, s):                                        # :96-147, WINDOW_SIZE = 1
+        ctx = self.ctx
+        two_inv = pow(2, -1, N_MOD)
+        s = self.sc.reduce(s)
+        bits = []
+        for l in s.limbs_le:
+            v = l.val
+            rest = l
+            for j in range(self.sc.info.limb_bits):
+                b = ctx.assign_bit((v >> j) & 1)
+                nv = (rest.val - b.val) * two_inv % N_MOD
+                rest = ctx.one_line_with_last([(rest, -1), (b, 1)], (nv, 2))[1]
+                bits.append(b)
+            ctx.assert_constant(rest, 0)
+        return [[b] for b in reversed(bits)]
+
+    def ecc_bisec_scalar(self, cond, a, b):                               # :156-163
+        return self.sc.bisec_int(cond, a, b)
+
+    def ecc_assign_constant_zero_scalar(self):                            # :165-168
+        return self.sc.assign_int_constant(0)
 
 
 # ===================================================================================================
@@ -1681,6 +1722,48 @@ def run_msm_bn256_tile(n, inputs, with_select=True):                      # test
     ecc = NativeScalarEccContext(ic, 3, gen, 254, 0 if with_select else None)
     points = [ecc.assign_point(_pt(inputs, 3 * k, 3 * k + 1, 3 * k + 2)) for k in range(n)]
     scalars = [ctx.assign(_w(inputs, 3 * n + k)) for k in range(n)]
+    r1 = (_w(inputs, 4 * n + 2), _w(inputs, 4 * n + 3))
+    r2 = (_w(inputs, 4 * n + 4), _w(inputs, 4 * n + 5))
+    before = (ctx.offset(), Counter(ctx.s.counts))
+    res = ecc.msm_unsafe(points, scalars, r1, r2)
+    ctx.s.marks = {"msm_unsafe_rows": [a - b for a, b in zip(ctx.offset(), before[0])],
+                   "msm_unsafe_counts": dict(sorted((ctx.s.counts - before[1]).items()))}
+    res_expect = ecc.assign_point(_pt(inputs, 4 * n + 6, 4 * n + 7, 4 * n + 8))
+    ecc.ecc_assert_equal(res, res_expect)
+    return ctx
+
+
+def run_ops_msm_twice(n, inputs):
+    """operator-API scenario (tests/test_ops_gpu.py): ops one after the other on one context - assign_point x n, assign x n,
+    int_mul / int_add / int_sub / reduce / int_div, msm_unsafe twice (the second with msm prefix 2^20 and swapped blinding
+    points), ecc_assert_equal(res1, res2)"""
+    ctx = Context()
+    ic = IntegerContext(ctx, BN_Q)
+    gen = (_w(inputs, 4 * n), _w(inputs, 4 * n + 1))
+    ecc = NativeScalarEccContext(ic, 3, gen, 254, 0)
+    points = [ecc.assign_point(_pt(inputs, 3 * k, 3 * k + 1, 3 * k + 2)) for k in range(n)]
+    scalars = [ctx.assign(_w(inputs, 3 * n + k)) for k in range(n)]
+    m = ic.int_mul(points[0].x, points[0].y)
+    s = ic.int_add(m, m)
+    s2 = ic.int_sub(s, points[0].x)
+    rd = ic.reduce(s2)
+    ic.int_div(rd, points[0].y)
+    r1 = (_w(inputs, 4 * n + 2), _w(inputs, 4 * n + 3))
+    r2 = (_w(inputs, 4 * n + 4), _w(inputs, 4 * n + 5))
+    res1 = ecc.msm_unsafe(points, scalars, r1, r2)
+    res2 = ecc.msm_unsafe(points, scalars, r2, r1)
+    ecc.ecc_assert_equal(res1, res2)
+    return ctx
+
+
+def run_msm_bls12_381_tile(n, inputs):                                    # tests/general_scalar_ecc_chip.rs:14-49
+    ctx = Context()
+    ic = IntegerContext(ctx, BLS_Q)
+    sc = IntegerContext(ctx, BLS_R)
+    gen = (_w(inputs, 4 * n), _w(inputs, 4 * n + 1))
+    ecc = GeneralScalarEccContext(ic, sc, 4, gen, 0)
+    points = [ecc.assign_point(_pt(inputs, 3 * k, 3 * k + 1, 3 * k + 2)) for k in range(n)]
+    scalars = [sc.assign_w(_w(inputs, 3 * n + k)) for k in range(n)]
     r1 = (_w(inputs, 4 * n + 2), _w(inputs, 4 * n + 3))
     r2 = (_w(inputs, 4 * n + 4), _w(inputs, 4 * n + 5))
     before = (ctx.offset(), Counter(ctx.s.counts))

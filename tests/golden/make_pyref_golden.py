@@ -9,7 +9,7 @@ nothing but the reference's text agree cell for cell.  When /root/reference is p
 constants oracle/pyref.py derives mathematically (Frobenius coefficients, xi^((q-1)/2)) against the reference's tables
 (src/circuit/bn256_constants.rs, src/circuit/bls12_381_pairing_chip.rs:58-107).
 
-Run from the repo root:  python tests/golden/make_pyref_golden.py [--big]     (--big adds the 1024-point tile: ~15 min)
+Run from the repo root:  python tests/golden/make_pyref_golden.py [--big | --only-next]   (--big adds the 1024-point tile: ~25 min)
 """
 import hashlib
 import json
@@ -81,8 +81,7 @@ def write(name, kind, params, inputs, ctx, secs, inline_inputs=True):
     print(f"{name}: {secs:.0f} s, offsets {s['offsets']}, heights {s['heights']}, {s['n_advice_cells']} cells, counts {s['counts']}", flush=True)
 
 
-def main():
-    check_constants_against_reference()
+def base_blocks():
     t = time.time()
     inp = synth.pairing_check_bn256_inputs(instance=1)
     write("pairing_check_bn256_i1", "pairing_check_bn256", {"instance": 1}, inp, pyref.run_pairing_check_bn256(inp), time.time() - t)
@@ -98,12 +97,40 @@ def main():
         t = time.time()
         inp = synth.integer_chip_st_inputs(fp, seed_index=21)
         write(f"integer_chip_st_fp{fp}", "integer_chip_st", {"field_pair": fp, "seed_index": 21}, inp, pyref.run_integer_chip_st(fp, inp), time.time() - t)
+
+
+def next_rows_blocks():
+    # general-scalar MSM (tests/general_scalar_ecc_chip.rs:14-49 at 7 points: one full group of 4 + a remainder group)
+    t = time.time()
+    n = 7
+    inp, _ = synth.msm_bls12_381_tile_inputs(n, tile=3)
+    write(f"msm_bls12_381_tile_n{n}", "msm_bls12_381_tile", {"n": n, "tile": 3}, inp, pyref.run_msm_bls12_381_tile(n, inp), time.time() - t)
+    # pairing(terms) == native (tests/native_scalar_pairing_chip.rs:20-65): the expected Fq12 constant is what pyref's
+    # own pairing computes (the reference takes it from the curve library); fq12_assert_eq must then hold
+    t = time.time()
+    inp = synth.pairing_inputs(0, 1, instance=2)
+    res = pyref.run_pairing(0, 1, False, inp).s.marks["result"]
+    inp = synth.pairing_inputs(0, 1, instance=2, expected=res)
+    write("pairing_bn256_1pair_expected", "pairing", {"curve": 0, "n_pairs": 1, "with_expected": True, "instance": 2}, inp,
+          pyref.run_pairing(0, 1, True, inp), time.time() - t)
+
+
+def big_blocks():
+    t = time.time()
+    n = 1024
+    inp, _ = synth.msm_bn256_tile_inputs(n, tile=100, cheap_points=True)
+    write("msm_bn256_tile_n1024", "msm_bn256_tile", {"n": n, "tile": 100, "with_select": True, "cheap_points": True}, inp,
+          pyref.run_msm_bn256_tile(n, inp), time.time() - t, inline_inputs=False)
+
+
+def main():
+    """no flag: everything but the 1024-point tile; --big: that tile too; --only-next: just the fixtures of the 8(f) rows"""
+    check_constants_against_reference()
+    if "--only-next" not in sys.argv:
+        base_blocks()
+    next_rows_blocks()
     if "--big" in sys.argv:
-        t = time.time()
-        n = 1024
-        inp, _ = synth.msm_bn256_tile_inputs(n, tile=100, cheap_points=True)
-        write("msm_bn256_tile_n1024", "msm_bn256_tile", {"n": n, "tile": 100, "with_select": True, "cheap_points": True}, inp,
-              pyref.run_msm_bn256_tile(n, inp), time.time() - t, inline_inputs=False)
+        big_blocks()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,104 @@
+"""Operator API (include/h2e.h): chip ops called one after the other on a device-resident Context - operands are
+handles to rows written earlier, every op starts at the Context's current offsets (and msm prefix) - against the oracle running
+the same op sequence in one context of its own.  All calls go through the C ABI."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from halo2ecc_s_amd import Records, synth
+from halo2ecc_s_amd import engine as E
+from parity import expand_fixed
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows_of(engine, rec, orun, n_inst):
+    """compare every advice cell (exported to the reference's row-major layout, masked by the accumulated flags), the flags,
+    offsets / heights, the permutation list in order and the fixed cells of a finished records object with an oracle run"""
+    t = engine.torch
+    t.cuda.synchronize()
+    arrs = rec.arrays()
+    sh = rec.shape()
+    i = orun.info
+    assert i.status == 0, orun.error
+    assert (sh.base_offset, sh.range_offset, sh.select_offset) == (i.base_offset, i.range_offset, i.select_offset)
+    assert (sh.base_height, sh.range_height, sh.select_height) == (i.base_height, i.range_height, i.select_height)
+    assert sh.n_permutations == i.n_permutations
+    perms = E._view(sh.permutations, sh.n_permutations * 2, np.uint32).reshape(-1, 2)
+    assert np.array_equal(perms, orun.permutations()), "permutation list differs"
+    d = E._view(sh.dict, sh.n_dict * 4, np.uint64).reshape(-1, 4)
+    fixp = (sh.base_fix, sh.range_fix, sh.select_fix)
+    flp = (sh.base_flags, sh.range_flags, sh.select_flags)
+    for region in range(3):
+        rows, cols, fcols = rec.rows[region], E.COLS[region], (9, 2, 2)[region]
+        flags = E._view(flp[region], rows * cols, np.uint8).reshape(rows, cols)
+        ovals, oflags = orun.adv(region, rows)
+        assert np.array_equal(flags, oflags), f"flags differ in region {region}"
+        ids = E._view(fixp[region], rows * fcols, np.uint32).reshape(rows, fcols)
+        ofix, opresent = orun.fix(region, rows)
+        assert np.array_equal((ids != 0).astype(np.uint8), opresent), f"fixed presence differs in region {region}"
+        assert np.array_equal(d[ids], ofix), f"fixed values differ in region {region}"
+        got = arrs[region].permute(3, 0, 1, 2, 4).reshape(n_inst, rows, cols, 4)
+        assigned = t.from_numpy((flags & 1).astype(bool)).to(got.device)
+        return_vals = (got * assigned[None, :, :, None]).cpu().numpy().view(np.uint64)
+        yield region, return_vals, ovals
+
+
+def test_ops_msm_twice_in_one_context(engine, oracle):
+    """assign_point x n, assign x n, int_mul / int_add / int_sub / reduce / int_div on assigned integers, msm_unsafe, a second
+    msm_unsafe on the same handles (offsets deep inside the arrays, msm prefix 2^20: its select rows encode group + 2^20,
+    src/circuit/native_scalar_ecc_chip.rs:173-178), ecc_assert_equal of the two results - nine separate ops on the GPU equal
+    the oracle calling the same ops on one context, cell for cell"""
+    n, n_inst = 6, 3
+    ins = [synth.msm_bn256_tile_inputs(n, tile=800 + k)[0] for k in range(n_inst)]
+    oruns = [oracle_lib.run_ops_msm_twice(n, inp) for inp in ins]
+    i = oruns[0].info
+    rows = (max(i.base_height, i.base_offset) + 1, max(i.range_height, i.range_offset) + 1, max(i.select_height, i.select_offset) + 1)
+    rec = Records(engine, E.FIELD_BN256_FQ, n_inst, rows)
+    a = np.stack(ins)                                            # [inst][4n+9][4]
+    pts = rec.assign_points(n, a[:, 0:3 * n])
+    scs = rec.assign_scalars(n, a[:, 3 * n:4 * n])
+    m = rec.int_op(E.INT_MUL, pts[0].x, pts[0].y)
+    s = rec.int_op(E.INT_ADD, m, m)
+    s2 = rec.int_op(E.INT_SUB, s, pts[0].x)
+    assert (m.times, s.times, s2.times) == (1, 2, 4)
+    rd = rec.int_op(E.INT_REDUCE, s2)
+    q, cond = rec.int_op(E.INT_DIV, rd, pts[0].y)
+    g, r1, r2 = a[:, 4 * n:4 * n + 2], a[:, 4 * n + 2:4 * n + 4], a[:, 4 * n + 4:4 * n + 6]
+    res1 = rec.msm_unsafe(pts, scs, np.concatenate([g, r1, r2], axis=1))
+    res2 = rec.msm_unsafe(pts, scs, np.concatenate([g, r2, r1], axis=1))
+    rec.ecc_assert_equal(res1, res2)
+    engine.torch.cuda.synchronize()
+    assert (rec.arrays()[3].cpu().numpy() == 0).all()
+    for k, orun in enumerate(oruns):
+        for region, got, ovals in _rows_of(engine, rec, orun, n_inst):
+            assert np.array_equal(got[k], ovals), f"instance {k}: advice differs in region {region}"
+    rec.close()
+
+
+def test_ops_check_pairing_on_assigned_terms(engine, oracle):
+    """PairingChipOps::check_pairing (src/circuit/pairing_chip.rs:173-176) as an op on terms assigned by earlier ops: the G2
+    constants, two assign_point ops, then the check - the same rows as the reference's test body
+    (src/tests/native_scalar_pairing_chip.rs:67-97)"""
+    n_inst = 2
+    ins = [synth.pairing_check_bn256_inputs(instance=810 + k) for k in range(n_inst)]
+    oruns = [oracle_lib.run_pairing_check_bn256(inp) for inp in ins]
+    i = oruns[0].info
+    rows = (max(i.base_height, i.base_offset) + 1, max(i.range_height, i.range_offset) + 1, 1)
+    rec = Records(engine, E.FIELD_BN256_FQ, n_inst, rows, emit_shape=False)
+    a = np.stack(ins)
+    b = rec.assign_g2_constant(a[:, 0:4])
+    neg_a = rec.assign_points(1, a[:, 4:7])[0]
+    pa = rec.assign_points(1, a[:, 7:10])[0]
+    rec.check_pairing([pa, neg_a], [b, b])
+    engine.torch.cuda.synchronize()
+    arrs = rec.arrays()
+    assert (arrs[3].cpu().numpy() == 0).all()
+    sh = rec.shape()
+    assert (sh.base_offset, sh.range_offset) == (i.base_offset, i.range_offset)
+    for k, orun in enumerate(oruns):
+        for region in range(2):
+            ovals, _ = orun.adv(region, rows[region])
+            got = arrs[region][:, :, :, k, :].cpu().numpy().view(np.uint64).reshape(rows[region], E.COLS[region], 4)
+            assert np.array_equal(got, ovals), f"instance {k}: advice differs in region {region}"
+    rec.close()

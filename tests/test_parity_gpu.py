@@ -82,16 +82,26 @@ def test_msm_tile(engine, oracle, n):
 
 def test_msm_tile_full_size(engine, oracle):
     """BASELINE configs[1]'s tile - 1024 points, 38.1 M advice cells - cell for cell against the oracle (which takes a
-    few seconds over all host cores), on the last of several tiles so that the multi-wave paths are exercised"""
+    few seconds over all host cores), on the last of several tiles so that the multi-wave paths are exercised.  That last tile
+    is the one tests/golden/pyref/msm_bn256_tile_n1024.json was traced on by the independent Python restatement: the oracle's
+    digests of its three advice arrays must equal the fixture's (three texts, one witness - at BASELINE's size)"""
+    import json
     import os
     n, tiles = 1024, 3
-    ins = [synth.msm_bn256_tile_inputs(n, tile=100 + t, cheap_points=True)[0] for t in range(tiles)]
+    ins = [synth.msm_bn256_tile_inputs(n, tile=100 + t, cheap_points=True)[0] for t in (2, 1, 0)]
     prog = Program.msm_bn256_tile(n)
     base, rng, sel, status = _run(engine, prog, ins)
     assert (status == 0).all(), status
     orun = oracle_lib.run_msm_bn256_tile(n, ins[tiles - 1], threads=os.cpu_count())
     assert orun.info.status == 0, orun.error
     compare_advice(prog, orun, base, rng, sel, instance=tiles - 1)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pyref", "msm_bn256_tile_n1024.json")) as f:
+        fx = json.load(f)["pyref"]
+    i = orun.info
+    assert fx["offsets"] == [i.base_offset, i.range_offset, i.select_offset] and fx["heights"] == [i.base_height, i.range_height, i.select_height]
+    assert fx["n_permutations"] == i.n_permutations and fx["n_advice_cells"] == i.n_advice_cells
+    for region in range(3):
+        assert fx["adv_digest"][region] == [int(x) for x in orun.digest(region)], f"oracle != pyref fixture in region {region}"
 
 
 def test_msm_alternating_inputs_reuse_buffers(engine, oracle):
@@ -227,6 +237,59 @@ def test_msm_tile_no_select(engine, oracle, n):
         orun = oracle_lib.run_msm_bn256_tile(n, inp, with_select=False)
         assert orun.info.status == 0, orun.error
         compare_advice(prog, orun, base, rng, sel, instance=k)
+
+
+@pytest.mark.parametrize("n", [2, 7, 50])   # 50 = the reference's test size (src/tests/general_scalar_ecc_chip.rs:22): 10 groups of 5
+def test_msm_bls12_381_tile_general_scalars(engine, oracle, n):
+    """SURVEY 8(f)-2: general-scalar MSM (GeneralScalarEccContext<bls12_381::G1Affine, bn256::Fr>,
+    src/circuit/general_scalar_ecc_chip.rs:93-168): points over the 4-limb bls12_381 Fq, scalars as 3-limb integers of the
+    second integer context decomposed limb by limb into 324 windows - two W fields in one program"""
+    tiles = 2 if n < 50 else 1
+    ins = [synth.msm_bls12_381_tile_inputs(n, tile=700 + t, cheap_points=n >= 50)[0] for t in range(tiles)]
+    prog = Program.msm_bls12_381_tile(n)
+    base, rng, sel, status = _run(engine, prog, ins)
+    assert (status == 0).all(), status
+    for k, inp in enumerate(ins):
+        orun = oracle_lib.run_msm_bls12_381_tile(n, inp)
+        assert orun.info.status == 0, orun.error
+        compare_advice(prog, orun, base, rng, sel, instance=k)
+
+
+def test_pairing_result_paths(engine, oracle):
+    """pairing(terms) == expected (first block of the reference's pairing tests: src/tests/native_scalar_pairing_chip.rs:20-65
+    with one bn256 pair, general_scalar_pairing_chip.rs:20-72 with the product of two bls12_381 pairs): run without the
+    expected constant, read the Fq12 result from the program's output cells, feed it back as the constant the in-circuit
+    fq12_assert_eq compares with - status 0 - and compare every cell with the oracle"""
+    t = engine.torch
+    for curve, n_pairs, Q in ((0, 1, synth.BN_Q), (1, 2, synth.BLS_Q)):
+        L = 3 if curve == 0 else 4
+        inp = synth.pairing_inputs(curve, n_pairs, instance=1)
+        prog = Program.pairing(curve, n_pairs, False, emit_shape=False)
+        d_in = engine.upload_inputs(prog, np.stack([inp]))
+        arrs = engine.alloc(prog, 1)
+        engine.run(prog, d_in, *arrs)
+        t.cuda.synchronize()
+        assert int(arrs[3][0]) == 0
+        refs = prog.outputs()
+        assert len(refs) == 12 * (L + 1)
+
+        def cell(ref):
+            region, col, row = ref >> 30, (ref >> 27) & 7, ref & 0x3FFFFFF
+            w = arrs[region][row, col, :, 0, :].reshape(4).cpu().numpy().view(np.uint64)
+            return sum(int(w[k]) << (64 * k) for k in range(4))
+        exp = [sum(cell(r) << (108 * j) for j, r in enumerate(refs[i * (L + 1):i * (L + 1) + L])) % Q for i in range(12)]
+        inp2 = synth.pairing_inputs(curve, n_pairs, instance=1, expected=exp)
+        prog2 = Program.pairing(curve, n_pairs, True, emit_shape=False)
+        base, rng, sel, status = _run(engine, prog2, [inp2])
+        assert (status == 0).all(), status
+        orun = oracle_lib.run_pairing(curve, n_pairs, True, inp2)
+        assert orun.info.status == 0, orun.error
+        compare_advice(prog2, orun, base, rng, sel)
+        # a wrong expected value must fail the in-circuit assert
+        bad = list(exp)
+        bad[5] = (bad[5] + 1) % Q
+        _, _, _, st_bad = _run(engine, prog2, [synth.pairing_inputs(curve, n_pairs, instance=1, expected=bad)])
+        assert st_bad[0] & 1
 
 
 def test_msm_tile_with_identity_inputs(engine, oracle):
