@@ -2428,6 +2428,124 @@ extern "C" int h2e_engine_digest(uint32_t cols, const void* in, const uint8_t* f
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Shape artefacts in the prover's layout, generated on the device.
+// (a) fixed columns: the program's fixed cells are dictionary ids (h2e_shape); expanded to [instance][COLS][row][4 words]
+//     (column-major, what halo2's fixed columns are) or [instance][row][COLS][4], None -> 0, canonical or Montgomery form.
+template <bool COLUMNS>
+__global__ void __launch_bounds__(256) h2e_fixed_columns(const u32* __restrict__ ids, const u64* __restrict__ dict, u64 rows, u32 cols,
+                                                         u32 n_inst, u32 mont, const H2EFieldConsts* fc, ulonglong2* __restrict__ out) {
+    u64 cell = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (cell >= rows * cols) return;
+    u64 row = cell / cols;
+    u32 col = (u32)(cell % cols);
+    u32 id = ids[cell];
+    Fe v = wd_load<4>(dict + (size_t)id * 4);   // entry 0 = None = zero
+    if (mont) {
+        Mont<4> M = mont_n(fc);
+        v = mont_mul<4>(M, v, M.r2);
+    }
+    u64 o = COLUMNS ? (u64)col * rows + row : cell;
+    for (u32 i = 0; i < n_inst; i++) {
+        ulonglong2* q = out + ((u64)i * rows * cols + o) * 2;
+        q[0] = make_ulonglong2(v.v[0], v.v[1]);
+        q[1] = make_ulonglong2(v.v[2], v.v[3]);
+    }
+}
+// constants made from instance inputs (the G2 points of a pairing check): [row, fixed col, input slot, limb (-1: value mod n)]
+template <class FP>
+__global__ void h2e_fixed_patches(const u32* __restrict__ patches, u32 n_patches, const u64* __restrict__ inputs, u32 n_slots, u32 slot_words,
+                                  u64 rows, u32 cols, u32 columns, u32 n_inst, u32 mont, const H2EFieldConsts* fc, ulonglong2* __restrict__ out) {
+    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_patches * n_inst) return;
+    u32 k = gid % n_patches, i = gid / n_patches;
+    u32 row = patches[4 * k], col = patches[4 * k + 1], slot = patches[4 * k + 2];
+    int limb = (int)patches[4 * k + 3];
+    Wd<FP::WW> x = wd_load<FP::WW>(inputs + ((size_t)i * n_slots + slot) * slot_words);
+    LC c;
+    c.fc = fc;
+    Fe v;
+    if (limb < 0) {
+        v = mod_n<FP::WW>(c, x);
+    } else {
+        Limb l[FP::L];
+        split_limbs<FP>(x, l);
+        Limb pick = l[0];
+#pragma unroll
+        for (int j = 1; j < FP::L; j++)
+            if (j == limb) pick = l[j];
+        v = fe_of(pick);
+    }
+    if (mont) {
+        Mont<4> M = mont_n(fc);
+        v = mont_mul<4>(M, v, M.r2);
+    }
+    u64 o = columns ? (u64)col * rows + row : (u64)row * cols + col;
+    ulonglong2* q = out + ((u64)i * rows * cols + o) * 2;
+    q[0] = make_ulonglong2(v.v[0], v.v[1]);
+    q[1] = make_ulonglong2(v.v[2], v.v[3]);
+}
+// (b) the 18-bit tagged range lookup table (RangeChip::init_table, src/circuit/range_chip.rs:230-258): for tag in 0..=18,
+//     value in 0..2^tag: row (tag, value); 2^19 - 1 rows, two columns, column-major [2][rows][4 words]
+__global__ void h2e_range_table(u32 mont, const H2EFieldConsts* fc, ulonglong2* __restrict__ out) {
+    const u32 rows = (1u << 19) - 1;
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    u32 tag = 31 - __clz(r + 1), value = r + 1 - (1u << tag);
+    Fe t = fe_u64(tag), v = fe_u64(value);
+    if (mont) {
+        Mont<4> M = mont_n(fc);
+        t = mont_mul<4>(M, t, M.r2);
+        v = mont_mul<4>(M, v, M.r2);
+    }
+    out[(size_t)r * 2] = make_ulonglong2(t.v[0], t.v[1]);
+    out[(size_t)r * 2 + 1] = make_ulonglong2(t.v[2], t.v[3]);
+    out[((size_t)rows + r) * 2] = make_ulonglong2(v.v[0], v.v[1]);
+    out[((size_t)rows + r) * 2 + 1] = make_ulonglong2(v.v[2], v.v[3]);
+}
+// (c) the permutation list as copy constraints between (advice column, row) pairs: global advice column = 0-4 base, 5-7 range,
+//     8-9 select; out[k] = [column_a, row_a, column_b, row_b]
+__global__ void h2e_copy_constraints(const u32* __restrict__ perms, u64 n, uint4* __restrict__ out) {
+    u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    u32 a = perms[2 * k], b = perms[2 * k + 1];
+    const u32 base_col[3] = {0, 5, 8};
+    out[k] = make_uint4(base_col[H2E_REF_REGION(a)] + H2E_REF_COL(a), H2E_REF_ROW(a), base_col[H2E_REF_REGION(b)] + H2E_REF_COL(b), H2E_REF_ROW(b));
+}
+extern "C" int h2e_engine_fixed(int field_pair, const uint32_t* ids, const uint64_t* dict, uint64_t rows, uint32_t cols, int columns, int mont,
+                                const uint32_t* patches, uint32_t n_patches, const uint64_t* inputs, uint32_t n_slots, uint32_t slot_words,
+                                uint32_t n_instances, const H2EFieldConsts* fc_dev, void* out, hipStream_t stream) {
+    if (rows == 0 || n_instances == 0) return 0;
+    u64 cells = rows * cols;
+    if ((cells + 255) / 256 > 0x7fffffffull) return -1;
+    dim3 grid((u32)((cells + 255) / 256)), block(256);
+    if (columns) hipLaunchKernelGGL((h2e_fixed_columns<true>), grid, block, 0, stream, ids, dict, rows, cols, n_instances, (u32)mont, fc_dev, (ulonglong2*)out);
+    else hipLaunchKernelGGL((h2e_fixed_columns<false>), grid, block, 0, stream, ids, dict, rows, cols, n_instances, (u32)mont, fc_dev, (ulonglong2*)out);
+    if (n_patches && inputs) {
+        dim3 g2((n_patches * n_instances + 63) / 64), b2(64);
+#define H2E_PATCH(FP)                                                                                                               \
+    hipLaunchKernelGGL(h2e_fixed_patches<FP>, g2, b2, 0, stream, patches, n_patches, inputs, n_slots, slot_words, rows, cols, (u32)columns, \
+                       n_instances, (u32)mont, fc_dev, (ulonglong2*)out)
+        switch (field_pair) {
+            case 0: H2E_PATCH(FP_BN256_FQ); break;
+            case 1: H2E_PATCH(FP_BLS_FQ); break;
+            case 2: H2E_PATCH(FP_BLS_FR); break;
+            default: return -1;
+        }
+#undef H2E_PATCH
+    }
+    return (int)hipGetLastError();
+}
+extern "C" int h2e_engine_range_table(int mont, const H2EFieldConsts* fc_dev, void* out, hipStream_t stream) {
+    hipLaunchKernelGGL(h2e_range_table, dim3(((1u << 19) - 1 + 255) / 256), dim3(256), 0, stream, (u32)mont, fc_dev, (ulonglong2*)out);
+    return (int)hipGetLastError();
+}
+extern "C" int h2e_engine_copy_constraints(const uint32_t* perms, uint64_t n, void* out, hipStream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(h2e_copy_constraints, dim3((u32)((n + 255) / 256)), dim3(256), 0, stream, perms, n, (uint4*)out);
+    return (int)hipGetLastError();
+}
+
 __global__ void h2e_or_status(const InstanceDesc* inst, u32 n_instances, u32 bits) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_instances) atomicOr(inst[i].status, bits);

@@ -17,6 +17,11 @@ extern "C" int h2e_engine_export(uint32_t cols, int columns, int mont, const voi
 extern "C" int h2e_engine_digest(uint32_t cols, const void* in, const uint8_t* flags, uint64_t rows, uint32_t n_instances, void* out,
                                  hipStream_t stream);
 extern "C" void h2e_engine_set_tuning(int key, int value);
+extern "C" int h2e_engine_fixed(int field_pair, const uint32_t* ids, const uint64_t* dict, uint64_t rows, uint32_t cols, int columns, int mont,
+                                const uint32_t* patches, uint32_t n_patches, const uint64_t* inputs, uint32_t n_slots, uint32_t slot_words,
+                                uint32_t n_instances, const H2EFieldConsts* fc_dev, void* out, hipStream_t stream);
+extern "C" int h2e_engine_range_table(int mont, const H2EFieldConsts* fc_dev, void* out, hipStream_t stream);
+extern "C" int h2e_engine_copy_constraints(const uint32_t* perms, uint64_t n, void* out, hipStream_t stream);
 extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances, uint32_t bits, hipStream_t stream);
 extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
                                  uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream);
@@ -94,6 +99,11 @@ struct h2e_program {
     uint32_t* d_lrefs = nullptr;
     int64_t tail_from = -1;   // first segment of the program's serial tail (runs on the job slot's side stream), -1: none
     uint8_t* d_flags[3] = {nullptr, nullptr, nullptr};   // assigned / permute bytes on the device (h2e_export masks with them)
+    // shape artefacts on the device (h2e_export_fixed / h2e_export_copy_constraints), uploaded on first use
+    uint32_t* d_fix[3] = {nullptr, nullptr, nullptr};
+    uint64_t* d_dict = nullptr;
+    uint32_t* d_patches = nullptr;
+    uint32_t* d_perms = nullptr;
 
     ~h2e_program() {
         if (device >= 0) {
@@ -110,6 +120,10 @@ struct h2e_program {
             (void)hipFree(d_lrefs);
             for (int i = 0; i < 3; i++) (void)hipFree(d_flags[i]);
         }
+        for (int i = 0; i < 3; i++) (void)hipFree(d_fix[i]);
+        (void)hipFree(d_dict);
+        (void)hipFree(d_patches);
+        (void)hipFree(d_perms);
     }
     // Liveness over sub-ranges: an arithmetic op whose result cells are only read by ops of its own sub-range gets
     // H2E_FLAG_LOCAL_RESULT, so the values-only replay keeps that result in LDS and does not store it (the full
@@ -2342,6 +2356,82 @@ int h2e_export(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, i
     int rc = h2e_engine_export(cols, layout == H2E_LAYOUT_COLUMNS, form == H2E_FORM_MONTGOMERY, d_batch, d_out, d_flags, rows,
                                n_instances, ctx->d_fc[fp], (hipStream_t)stream);
     if (rc != 0) return fail(H2E_ERR_HIP, rc < 0 ? "export: bad geometry" : std::string("export launch failed: ") + hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
+static int ensure_fc(h2e_ctx* ctx, int fp) {
+    if (!ctx->d_fc[fp]) {
+        HIP_TRY(hipMalloc((void**)&ctx->d_fc[fp], sizeof(H2EFieldConsts)));
+        HIP_TRY(hipMemcpy(ctx->d_fc[fp], &field_pair(fp).fc, sizeof(H2EFieldConsts), hipMemcpyHostToDevice));
+        HIP_TRY((hipError_t)h2e_engine_set_consts(fp, &field_pair(fp).fc));
+    }
+    return 0;
+}
+
+int h2e_export_fixed(h2e_ctx* ctx, h2e_program* p, int region, int layout, int form, uint32_t n_instances, const void* d_inputs, void* d_out,
+                     void* stream) {
+    if (!ctx || !p || !d_out) return fail(H2E_ERR_INVALID, "null argument");
+    if (region < 0 || region > 2) return fail(H2E_ERR_INVALID, "region must be 0 (base), 1 (range) or 2 (select)");
+    if (layout != H2E_LAYOUT_ROWS && layout != H2E_LAYOUT_COLUMNS) return fail(H2E_ERR_INVALID, "bad layout");
+    if (form != H2E_FORM_CANONICAL && form != H2E_FORM_MONTGOMERY) return fail(H2E_ERR_INVALID, "bad number form");
+    h2e::Recorder& r = *p->rec;
+    if (!r.emit_shape) return fail(H2E_ERR_INVALID, "the program was recorded without its shape (emit_shape = 0)");
+    if (n_instances == 0) return fail(H2E_ERR_INVALID, "n_instances must be > 0");
+    if (region == 0 && !r.fixed_patches.empty() && !d_inputs)
+        return fail(H2E_ERR_INVALID, "this program has fixed cells made from instance inputs: d_inputs is needed");
+    std::lock_guard<std::mutex> guard(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_fc(ctx, p->field_pair);
+    if (rc) return rc;
+    const uint32_t cols = region == 0 ? 9 : 2;
+    const uint64_t rows = region == 0 ? p->base_rows : region == 1 ? p->range_rows : p->select_rows;
+    const std::vector<uint32_t>& ids = region == 0 ? r.base_fix : region == 1 ? r.range_fix : r.select_fix;
+    if (ids.size() < rows * cols) return fail(H2E_ERR_SHAPE, "internal: fixed array shorter than the region");
+    if (!p->d_fix[region]) {
+        HIP_TRY(hipMalloc((void**)&p->d_fix[region], std::max<size_t>(16, rows * cols * 4)));
+        HIP_TRY(hipMemcpy(p->d_fix[region], ids.data(), rows * cols * 4, hipMemcpyHostToDevice));
+    }
+    if (!p->d_dict) {
+        HIP_TRY(hipMalloc((void**)&p->d_dict, r.dict.size() * 32));
+        HIP_TRY(hipMemcpy(p->d_dict, r.dict.data(), r.dict.size() * 32, hipMemcpyHostToDevice));
+    }
+    uint32_t n_patches = region == 0 ? (uint32_t)r.fixed_patches.size() : 0;
+    if (n_patches && !p->d_patches) {
+        HIP_TRY(hipMalloc((void**)&p->d_patches, (size_t)n_patches * 16));
+        HIP_TRY(hipMemcpy(p->d_patches, p->patch_flat.data(), (size_t)n_patches * 16, hipMemcpyHostToDevice));
+    }
+    rc = h2e_engine_fixed(p->field_pair, p->d_fix[region], p->d_dict, rows, cols, layout == H2E_LAYOUT_COLUMNS, form == H2E_FORM_MONTGOMERY,
+                          p->d_patches, n_patches, (const uint64_t*)d_inputs, r.n_input_slots, (uint32_t)r.fp.w_words, n_instances,
+                          ctx->d_fc[p->field_pair], d_out, (hipStream_t)stream);
+    if (rc != 0) return fail(H2E_ERR_HIP, rc < 0 ? "export_fixed: bad geometry" : std::string("export_fixed launch failed: ") + hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
+int h2e_range_table(h2e_ctx* ctx, int form, void* d_out, void* stream) {
+    if (!ctx || !d_out) return fail(H2E_ERR_INVALID, "null argument");
+    if (form != H2E_FORM_CANONICAL && form != H2E_FORM_MONTGOMERY) return fail(H2E_ERR_INVALID, "bad number form");
+    std::lock_guard<std::mutex> guard(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_fc(ctx, 0);
+    if (rc) return rc;
+    rc = h2e_engine_range_table(form == H2E_FORM_MONTGOMERY, ctx->d_fc[0], d_out, (hipStream_t)stream);
+    if (rc != 0) return fail(H2E_ERR_HIP, std::string("range table launch failed: ") + hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
+int h2e_export_copy_constraints(h2e_ctx* ctx, h2e_program* p, void* d_out, void* stream) {
+    if (!ctx || !p || !d_out) return fail(H2E_ERR_INVALID, "null argument");
+    h2e::Recorder& r = *p->rec;
+    if (!r.emit_shape) return fail(H2E_ERR_INVALID, "the program was recorded without its shape (emit_shape = 0)");
+    std::lock_guard<std::mutex> guard(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t n = r.permutations.size();
+    if (n && !p->d_perms) {
+        HIP_TRY(hipMalloc((void**)&p->d_perms, n * 8));
+        HIP_TRY(hipMemcpy(p->d_perms, p->perm_flat.data(), n * 8, hipMemcpyHostToDevice));
+    }
+    int rc = h2e_engine_copy_constraints(p->d_perms, n, d_out, (hipStream_t)stream);
+    if (rc != 0) return fail(H2E_ERR_HIP, std::string("copy-constraint launch failed: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }
 

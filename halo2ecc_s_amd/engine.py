@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "h2e_submit", "h2e_wait", "h2e_job_launch_ms", "h2e_digest", "h2e_program_pairing", "h2e_program_msm_bls12_381_tile",
     "h2e_records_create", "h2e_records_destroy", "h2e_records_arrays", "h2e_records_shape", "h2e_op_assign_w", "h2e_op_assign",
     "h2e_op_int", "h2e_op_assign_points", "h2e_op_assign_scalars", "h2e_op_msm_unsafe", "h2e_op_ecc_assert_equal",
-    "h2e_op_assign_g2_constant", "h2e_op_check_pairing", "h2e_ctx_set_option", "h2e_ctx_get_stat",
+    "h2e_op_assign_g2_constant", "h2e_op_check_pairing", "h2e_export_fixed", "h2e_range_table", "h2e_export_copy_constraints", "h2e_ctx_set_option", "h2e_ctx_get_stat",
     "h2e_program_msm_bn256_tile_no_select", "h2e_last_run_expansion_launches",
 ]
 
@@ -97,6 +97,9 @@ def lib():
     L.h2e_program_pairing_check_bn256.argtypes = [i32, C.POINTER(vp)]
     L.h2e_program_pairing_check_bls12_381.argtypes = [i32, C.POINTER(vp)]
     L.h2e_program_msm_bls12_381_tile.argtypes = [u32, i32, C.POINTER(vp)]
+    L.h2e_export_fixed.argtypes = [vp, vp, i32, i32, i32, u32, vp, vp, vp]
+    L.h2e_range_table.argtypes = [vp, i32, vp, vp]
+    L.h2e_export_copy_constraints.argtypes = [vp, vp, vp, vp]
     L.h2e_records_create.argtypes = [vp, i32, i32, u32, C.c_uint64, C.c_uint64, C.c_uint64, i32, C.POINTER(vp)]
     L.h2e_records_destroy.argtypes = [vp]
     L.h2e_records_destroy.restype = None
@@ -438,6 +441,31 @@ class Engine:
             out = t.empty((n, 4), dtype=t.int64, device=batch.device)
         _check(lib().h2e_digest(self._h, program._h, n, region, batch.data_ptr(), out.data_ptr(), self._stream(stream).cuda_stream))
         return out
+
+    def export_fixed(self, program, region, n_instances=1, d_inputs=None, layout=LAYOUT_COLUMNS, form=FORM_CANONICAL, stream=None):
+        """h2e_export_fixed: fixed cells of one region on the device, [inst][cols][rows][4] (columns) or [inst][rows][cols][4]"""
+        t = self.torch
+        rows = (program.base_rows, program.range_rows, program.select_rows)[region]
+        cols = (9, 2, 2)[region]
+        shape = (n_instances, cols, rows, 4) if layout == LAYOUT_COLUMNS else (n_instances, rows, cols, 4)
+        out = t.empty(shape, dtype=t.int64, device=f"cuda:{self.device}")
+        _check(lib().h2e_export_fixed(self._h, program._h, region, layout, form, n_instances, d_inputs.data_ptr() if d_inputs is not None else None,
+                                      out.data_ptr(), self._stream(stream).cuda_stream))
+        return out
+
+    def range_table(self, form=FORM_CANONICAL, stream=None):
+        """h2e_range_table: [2][524287][4] (tag column, value column)"""
+        t = self.torch
+        out = t.empty((2, 524287, 4), dtype=t.int64, device=f"cuda:{self.device}")
+        _check(lib().h2e_range_table(self._h, form, out.data_ptr(), self._stream(stream).cuda_stream))
+        return out
+
+    def export_copy_constraints(self, program, stream=None):
+        """h2e_export_copy_constraints: int32 [n_permutations][4] = (column a, row a, column b, row b)"""
+        t = self.torch
+        out = t.empty((max(1, program.n_permutations), 4), dtype=t.int32, device=f"cuda:{self.device}")
+        _check(lib().h2e_export_copy_constraints(self._h, program._h, out.data_ptr(), self._stream(stream).cuda_stream))
+        return out[:program.n_permutations]
 
     def read_cell(self, base, ref, instance):
         """value of a base-chip cell reference (region << 30 | col << 27 | row) of one instance, as a Python int"""

@@ -203,6 +203,24 @@ int h2e_pairing_check_bls12_381(h2e_ctx* ctx, uint32_t n_instances, const void* 
 int h2e_export(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, int layout, int form, const void* d_batch,
                void* d_out, void* stream);
 
+/* ---- shape artefacts in the prover's layout, made on the device -----------------
+ * What Records holds besides advice values is shape-only (h2e_program_shape keeps it as dictionary ids / flag bytes / cell
+ * pairs on the host); these three put it into HBM in the form halo2 consumes:
+ *  h2e_export_fixed: the fixed cells of one region (base 9, range 2, select 2 columns: src/context.rs:367-375,
+ *    src/circuit/range_chip.rs:88-92, select_chip.rs:48-52) as [instance][COLS][row][4 words] (H2E_LAYOUT_COLUMNS) or
+ *    [instance][row][COLS][4] (H2E_LAYOUT_ROWS), None -> 0, canonical or Montgomery form.  Fixed cells are the same for every
+ *    instance except those made from instance inputs (the G2 constants of a pairing check): pass the run's d_inputs for them.
+ *  h2e_range_table: the 18-bit tagged range lookup table of RangeChip::init_table (src/circuit/range_chip.rs:230-258) -
+ *    row (tag, value) for tag in 0..=18, value in 0..2^tag - as [2][H2E_RANGE_TABLE_ROWS][4 words] (tag column, value column).
+ *  h2e_export_copy_constraints: the permutation list (src/context.rs:300, _assign_permutation :523-541) as
+ *    [n_permutations][4] uint32 = (advice column a, row a, advice column b, row b), advice columns numbered 0-4 base,
+ *    5-7 range, 8-9 select. */
+#define H2E_RANGE_TABLE_ROWS 524287u
+int h2e_export_fixed(h2e_ctx* ctx, h2e_program* p, int region, int layout, int form, uint32_t n_instances, const void* d_inputs, void* d_out,
+                     void* stream);
+int h2e_range_table(h2e_ctx* ctx, int form, void* d_out, void* stream);
+int h2e_export_copy_constraints(h2e_ctx* ctx, h2e_program* p, void* d_out, void* stream);
+
 /* ---- operator API: a device-resident Context -----------------------------------------------------
  * The reference's operator surface is a Context you call chip ops on (`IntegerChipOps` src/circuit/integer_chip.rs:15-70,
  * `EccChipBaseOps` / `EccChipScalarOps` src/circuit/ecc_chip.rs:79-430, `PairingChipOps` src/circuit/pairing_chip.rs:157-176); its own
