@@ -814,8 +814,17 @@ WI_INLINE void op_pick_index(const LC& c, const H2EOp& op) {
 
 template <class FP>
 WI_INLINE void op_cache_int(const LC& c, const H2EOp& op) {
+    const int n = op.imm ? (int)op.imm : FP::L + 1;   // imm: cells to cache (single cells of assign_cache_point, ecc_chip.rs:779-788)
 #pragma unroll
-    for (int i = 0; i <= FP::L; i++) rowS(c, op.select_row + i, 1, ld_fe(c, op.refs[i]), FE0);
+    for (int i = 0; i <= H2E_MAX_L; i++)
+        if (i < n) rowS(c, op.select_row + i, 1, ld_fe(c, op.refs[i]), FE0);
+}
+
+// sum_with_constant([(a, 1), (b, 2^108)], None) of ecc_encode (ecc_chip.rs:718-731): [a, b | a + b * 2^108]
+WI_INLINE void op_shift_add(const LC& c, const H2EOp& op) {
+    Fe a = ld_fe(c, op.refs[0]), b = ld_fe(c, op.refs[1]);
+    Fe s = mod_n<6>(c, wd_add<6>(wd_resize<6>(a), wd_shl<6, 108>(b)));
+    ROW_B2(c, op.base_row, a, b, s);
 }
 
 // assign_selected_point_non_zero: refs[0] = index cell, imm = aux offset of the candidate ref table
@@ -825,6 +834,12 @@ WI_INLINE void op_select_point(const LC& c, const H2EOp& op) {
     constexpr int NC = 2 * (FP::L + 1);
     Fe index = ld_fe(c, op.refs[0]);
     u32 idx = (u32)(index.v[0] & 0xff);
+    u32 nc_dyn = (op.flags >> 8) & 0xffu;
+    if (nc_dyn) {   // candidates of another width (points with curvature, ecc_chip.rs:790-812): one cell at a time
+        const u32* tab = c.aux + op.imm + idx * nc_dyn;
+        for (u32 j = 0; j < nc_dyn; j++) rowS(c, op.select_row + j, 3, ld_fe(c, tab[j]), index);
+        return;
+    }
     const u32* tab = c.aux + op.imm + idx * NC;
     Fe v[NC];
 #pragma unroll
@@ -920,6 +935,7 @@ WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
         case H2E_OP_CACHE_INT: op_cache_int<FP>(c, op); break;
         case H2E_OP_SELECT_POINT: op_select_point<FP>(c, op); break;
         case H2E_OP_DECOMPOSE_LIMB: op_decompose_limb(c, op); break;
+        case H2E_OP_SHIFT_ADD: op_shift_add(c, op); break;
         default: break;
     }
 }

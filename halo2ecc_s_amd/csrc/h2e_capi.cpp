@@ -2833,6 +2833,81 @@ int h2e_op_ecc_assert_equal(h2e_records* R, const h2e_point* a, const h2e_point*
     if (!a || !b) return fail(H2E_ERR_INVALID, "null operand");
     return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& ecc, uint32_t) { ecc.ecc_assert_equal(to_point(*a), to_point(*b)); });
 }
+// ---- the complete-addition / curvature surface of EccChipBaseOps ----
+namespace {
+h2e::AssignedPointWithCurvature to_pc(const h2e_point_c& a) {
+    return h2e::AssignedPointWithCurvature{to_int(a.p.x), to_int(a.p.y), h2e::AssignedCondition{h2e::AssignedValue{a.p.z}},
+                                           h2e::AssignedCurvature{to_int(a.cv), h2e::AssignedCondition{h2e::AssignedValue{a.cz}}}};
+}
+h2e_point_c from_pc(const h2e::AssignedPointWithCurvature& a) {
+    h2e_point_c r;
+    r.p = from_point(a.to_point());
+    r.cv = from_int(a.curvature.v);
+    r.cz = a.curvature.z.v.ref;
+    return r;
+}
+}  // namespace
+int h2e_op_to_point_with_curvature(h2e_records* R, const h2e_point* a, h2e_point_c* out, void* stream) {   // ecc_chip.rs:695-708
+    if (!a || !out) return fail(H2E_ERR_INVALID, "null operand");
+    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { *out = from_pc(e.to_point_with_curvature(to_point(*a))); });
+}
+int h2e_op_ecc_reduce_with_curvature(h2e_records* R, const h2e_point* a, h2e_point_c* out, void* stream) {   // :677-693 (ecc_reduce :668-675, assign_identity :514-529)
+    if (!a || !out) return fail(H2E_ERR_INVALID, "null operand");
+    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { *out = from_pc(e.ecc_reduce_with_curvature(to_point(*a))); });
+}
+int h2e_op_ecc_double(h2e_records* R, const h2e_point_c* a, h2e_point* out, void* stream) {   // :630-642
+    if (!a || !out) return fail(H2E_ERR_INVALID, "null operand");
+    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { *out = from_point(e.ecc_double(to_pc(*a))); });
+}
+int h2e_op_ecc_add(h2e_records* R, const h2e_point_c* a, const h2e_point* b, h2e_point* out, void* stream) {   // :606-628
+    if (!a || !b || !out) return fail(H2E_ERR_INVALID, "null operand");
+    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { *out = from_point(e.ecc_add(to_pc(*a), to_point(*b))); });
+}
+int h2e_op_ecc_neg(h2e_records* R, const h2e_point* a, h2e_point* out, void* stream) {   // :660-666
+    if (!a || !out) return fail(H2E_ERR_INVALID, "null operand");
+    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { *out = from_point(e.ecc_neg(to_point(*a))); });
+}
+int h2e_op_ecc_encode(h2e_records* R, const h2e_point* a, uint32_t* out_cells3, void* stream) {   // :710-732
+    if (!a || !out_cells3) return fail(H2E_ERR_INVALID, "null operand");
+    if (R && field_pair(R->field_pair).limbs != 3) return fail(H2E_ERR_INVALID, "ecc_encode packs two 3-limb coordinates");
+    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) {
+        std::vector<h2e::AssignedValue> v = e.ecc_encode(to_point(*a));
+        for (int i = 0; i < 3; i++) out_cells3[i] = v[i].ref;
+    });
+}
+int h2e_op_ecc_mul(h2e_records* R, const h2e_point* a, const h2e_int* scalar, const void* d_inputs, h2e_point* out, void* stream) {   // :418-420
+    return h2e_op_msm_unsafe(R, 1, a, scalar, d_inputs, out, stream);
+}
+int h2e_op_assign_constant_point(h2e_records* R, const uint64_t* x_words, const uint64_t* y_words, int is_identity, h2e_point* out, void* stream) {   // :441-456
+    if (!out || (!is_identity && (!x_words || !y_words))) return fail(H2E_ERR_INVALID, "null operand");
+    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder& r, h2e::NativeScalarEccContext& e, uint32_t) {
+        h2e::HBig x, y;
+        if (!is_identity) {
+            x = h2e::HBig::from_words(x_words, r.fp.w_words);
+            y = h2e::HBig::from_words(y_words, r.fp.w_words);
+        }
+        *out = from_point(e.assign_constant_point(x, y, is_identity != 0));
+    });
+}
+int h2e_op_bisec_point_with_curvature(h2e_records* R, uint32_t cond_cell, const h2e_point_c* a, const h2e_point_c* b, h2e_point_c* out, void* stream) {   // :562-578
+    if (!a || !b || !out) return fail(H2E_ERR_INVALID, "null operand");
+    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) {
+        *out = from_pc(e.bisec_point_with_curvature(h2e::AssignedCondition{h2e::AssignedValue{cond_cell}}, to_pc(*a), to_pc(*b)));
+    });
+}
+int h2e_op_assign_cache_point(h2e_records* R, const h2e_point_c* p, uint64_t group, uint64_t selector, void* stream) {   // :779-788
+    if (!p) return fail(H2E_ERR_INVALID, "null operand");
+    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { e.assign_cache_point(to_pc(*p), (size_t)group, (size_t)selector); });
+}
+int h2e_op_assign_selected_point(h2e_records* R, uint32_t n, const h2e_point_c* candidates, uint32_t index_cell, uint64_t group, h2e_point_c* out,
+                                 void* stream) {   // :790-812, the candidate picked on the device by the value of the index cell
+    if (!candidates || !out || n == 0) return fail(H2E_ERR_INVALID, "bad argument");
+    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) {
+        std::vector<h2e::AssignedPointWithCurvature> c;
+        for (uint32_t k = 0; k < n; k++) c.push_back(to_pc(candidates[k]));
+        *out = from_pc(e.assign_selected_point(c, h2e::AssignedValue{index_cell}, (size_t)group));
+    });
+}
 int h2e_op_assign_g2_constant(h2e_records* R, const void* d_inputs, h2e_g2* out, void* stream) {   // fq2_assign_constant x 2 + assign_constant(0)
     if (!out) return fail(H2E_ERR_INVALID, "out is null");
     return records_op(R, 4, d_inputs, stream, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t s) {

@@ -157,6 +157,127 @@ struct NativeScalarEccContext {
         auto zv = ctx.int_div(numerator, denominator);
         return AssignedPointWithCurvature{a.x, a.y, a.z, AssignedCurvature{zv.second, zv.first}};
     }
+    // ---- the rest of the public EccChipBaseOps surface (not reached by the BASELINE configs) ----
+    // ecc_chip.rs:441-456: a point known when the circuit is built (x, y canonical; identity -> (0, 0, z = 1))
+    AssignedPoint assign_constant_point(const HBig& x, const HBig& y, bool is_identity) {
+        AssignedInteger ax = ctx.assign_int_constant(is_identity ? HBig(0) : x);
+        AssignedInteger ay = ctx.assign_int_constant(is_identity ? HBig(0) : y);
+        AssignedValue z = ctx.assign_constant_u64(is_identity ? 1 : 0);
+        return AssignedPoint{ax, ay, AssignedCondition{z}};
+    }
+    // ecc_chip.rs:514-529
+    AssignedPointWithCurvature assign_identity() {
+        AssignedInteger zero = ctx.assign_int_constant(HBig(0));
+        AssignedValue one = ctx.assign_constant_u64(1);
+        return AssignedPointWithCurvature{zero, zero, AssignedCondition{one}, AssignedCurvature{zero, AssignedCondition{one}}};
+    }
+    // ecc_chip.rs:562-578
+    AssignedPointWithCurvature bisec_point_with_curvature(const AssignedCondition& cond, const AssignedPointWithCurvature& a,
+                                                          const AssignedPointWithCurvature& b) {
+        AssignedInteger x = ctx.bisec_int(cond, a.x, b.x);
+        AssignedInteger y = ctx.bisec_int(cond, a.y, b.y);
+        AssignedCondition z = ctx.bisec_cond(cond, a.z, b.z);
+        AssignedCurvature c = bisec_curvature(cond, a.curvature, b.curvature);
+        return AssignedPointWithCurvature{x, y, z, c};
+    }
+    // ecc_chip.rs:630-642
+    AssignedPoint ecc_double(const AssignedPointWithCurvature& a) {
+        AssignedPoint a_p = a.to_point();
+        AssignedPoint p = lambda_to_point(a.curvature, a_p, a_p);
+        p.z = ctx.bisec_cond(a.z, a.z, p.z);
+        return p;
+    }
+    // ecc_chip.rs:660-666
+    AssignedPoint ecc_neg(const AssignedPoint& a) { return AssignedPoint{a.x, ctx.int_neg(a.y), a.z}; }
+    // ecc_chip.rs:668-675
+    AssignedPoint ecc_reduce(const AssignedPoint& a) {
+        AssignedInteger x = ctx.reduce(a.x);
+        AssignedInteger y = ctx.reduce(a.y);
+        AssignedPointWithCurvature identity = assign_identity();
+        return bisec_point(a.z, identity.to_point(), AssignedPoint{x, y, a.z});
+    }
+    // ecc_chip.rs:677-693
+    AssignedPointWithCurvature ecc_reduce_with_curvature(const AssignedPoint& a_in) {
+        AssignedPoint a = ecc_reduce(a_in);
+        AssignedInteger x_square = ctx.int_square(a.x);
+        AssignedInteger numerator = ctx.int_mul_small_constant(x_square, 3);
+        AssignedInteger denominator = ctx.int_mul_small_constant(a.y, 2);
+        auto zv = ctx.int_div(numerator, denominator);
+        AssignedInteger v = ctx.reduce(zv.second);
+        return AssignedPointWithCurvature{a.x, a.y, a.z, AssignedCurvature{v, zv.first}};
+    }
+    // ecc_chip.rs:710-732: [x0 + x1 B, x2 + y0 B, y1 + y2 B] with B = 2^108 (3-limb fields)
+    std::vector<AssignedValue> ecc_encode(const AssignedPoint& p_in) {
+        AssignedPoint p = ecc_reduce(p_in);
+        auto shift_add = [&](uint32_t a, uint32_t b) {
+            H2EOp op = ctx.new_op(H2E_OP_SHIFT_ADD);
+            op.refs[0] = a;
+            op.refs[1] = b;
+            ctx.push(op);
+            size_t row = ctx.base_line({Recorder::A(a, ctx.id_one), Recorder::A(b, ctx.id_limb_coeff[1])}, Recorder::U(ctx.id_neg_one));
+            return AssignedValue{ctx.mk(0, 4, row)};
+        };
+        AssignedValue s0 = shift_add(p.x.limbs_le[0], p.x.limbs_le[1]);
+        AssignedValue s1 = shift_add(p.x.limbs_le[2], p.y.limbs_le[0]);
+        AssignedValue s2 = shift_add(p.y.limbs_le[1], p.y.limbs_le[2]);
+        return {s0, s1, s2};
+    }
+    void cache_cell(uint32_t ref, size_t offset, size_t g, size_t sc) {
+        H2EOp op = ctx.new_op(H2E_OP_CACHE_INT, 1);
+        op.refs[0] = ref;
+        ctx.push(op);
+        ctx.assign_cache_value(ref, offset, g, sc);
+    }
+    // ecc_chip.rs:779-788
+    void assign_cache_point(const AssignedPointWithCurvature& p, size_t g, size_t sc) {
+        size_t i = 0;
+        assign_cache_integer(p.x, sc, g, i);
+        assign_cache_integer(p.y, sc, g, i);
+        cache_cell(p.z.v.ref, i, g, sc);
+        i += 1;
+        assign_cache_integer(p.curvature.v, sc, g, i);
+        cache_cell(p.curvature.z.v.ref, i, g, sc);
+    }
+    // ecc_chip.rs:790-812.  The reference is handed the already chosen candidate (a value copy); here the candidate is
+    // picked on the device by the value of the index cell `sc` from the candidates' cells.
+    AssignedPointWithCurvature assign_selected_point(const std::vector<AssignedPointWithCurvature>& candidates, const AssignedValue& sc, size_t g) {
+        const int L = ctx.fp.limbs;
+        const uint32_t nc = 3 * (L + 1) + 2;
+        if (nc > 255 || candidates.empty() || candidates.size() > 256) throw std::runtime_error("assign_selected_point: bad candidate table");
+        uint32_t table = (uint32_t)ctx.aux.size();
+        for (auto& q : candidates) {
+            for (const AssignedInteger* a : {&q.x, &q.y}) {
+                for (int j = 0; j < L; j++) ctx.aux.push_back(a->limbs_le[j]);
+                ctx.aux.push_back(a->native);
+            }
+            ctx.aux.push_back(q.z.v.ref);
+            for (int j = 0; j < L; j++) ctx.aux.push_back(q.curvature.v.limbs_le[j]);
+            ctx.aux.push_back(q.curvature.v.native);
+            ctx.aux.push_back(q.curvature.z.v.ref);
+        }
+        H2EOp op = ctx.new_op(H2E_OP_SELECT_POINT, table, (uint16_t)(nc << 8));
+        op.refs[0] = sc.ref;
+        ctx.push(op);
+        size_t i = 0;
+        auto sel_int = [&]() {
+            AssignedInteger t;
+            for (int j = 0; j < L; j++) t.limbs_le[j] = ctx.assign_selected_value(i++, g, sc.ref);
+            t.native = ctx.assign_selected_value(i++, g, sc.ref);
+            t.times = 1;
+            return t;
+        };
+        AssignedInteger x = sel_int(), y = sel_int();
+        AssignedValue z{ctx.assign_selected_value(i++, g, sc.ref)};
+        AssignedInteger cv = sel_int();
+        AssignedValue cz{ctx.assign_selected_value(i++, g, sc.ref)};
+        return AssignedPointWithCurvature{x, y, AssignedCondition{z}, AssignedCurvature{cv, AssignedCondition{cz}}};
+    }
+    // ecc_chip.rs:975-982
+    void ecc_assert_equal_non_zero(const AssignedNonZeroPoint& a, const AssignedNonZeroPoint& b) {
+        ctx.assert_int_equal(a.x, b.x);
+        ctx.assert_int_equal(a.y, b.y);
+    }
+
     // ecc_chip.rs:734-751
     void assign_cache_integer(const AssignedInteger& p, size_t sc, size_t g, size_t& offset) {
         if (p.times != 1) throw std::runtime_error("assign_cache_integer: times != 1");

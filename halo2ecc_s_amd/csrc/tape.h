@@ -55,10 +55,13 @@ enum H2EOpcode {
     H2E_OP_DECOMPOSE_NATIVE,  // native_scalar_ecc_chip.rs:97-171 (WINDOW_SIZE = 1), imm = NUM_BITS
     H2E_OP_PICK_INDEX,        // pick_candidate_non_zero's index row(s)  ecc_chip.rs:941-948
     // select chip
-    H2E_OP_CACHE_INT,         // assign_cache_integer      ecc_chip.rs:734-751
-    H2E_OP_SELECT_POINT,      // assign_selected_point_non_zero  ecc_chip.rs:955-967 (value picked by index cell)
+    H2E_OP_CACHE_INT,         // assign_cache_integer      ecc_chip.rs:734-751; imm = cells to cache (0: L + 1, an integer)
+    H2E_OP_SELECT_POINT,      // assign_selected_point_non_zero  ecc_chip.rs:955-967 (value picked by index cell);
+                              // flags bits 8-15 = cells per candidate (0: 2 (L + 1)): assign_selected_point :790-812 selects
+                              // x, y, z, curvature (3 L + 5 cells; at most 16)
     // general (non-native) scalars
     H2E_OP_DECOMPOSE_LIMB,    // one limb of decompose_scalar::<1>  general_scalar_ecc_chip.rs:107-130, imm = limb bits
+    H2E_OP_SHIFT_ADD,         // sum_with_constant([(a, 1), (b, 2^108)])  of ecc_encode  ecc_chip.rs:718-731
     H2E_OP_COUNT
 };
 

@@ -29,7 +29,9 @@ EXPORTED_SYMBOLS = [
     "h2e_submit", "h2e_wait", "h2e_job_launch_ms", "h2e_digest", "h2e_program_pairing", "h2e_program_msm_bls12_381_tile",
     "h2e_records_create", "h2e_records_destroy", "h2e_records_arrays", "h2e_records_shape", "h2e_op_assign_w", "h2e_op_assign",
     "h2e_op_int", "h2e_op_assign_points", "h2e_op_assign_scalars", "h2e_op_msm_unsafe", "h2e_op_ecc_assert_equal",
-    "h2e_op_assign_g2_constant", "h2e_op_check_pairing", "h2e_export_fixed", "h2e_range_table", "h2e_export_copy_constraints", "h2e_ctx_set_option", "h2e_ctx_get_stat",
+    "h2e_op_assign_g2_constant", "h2e_op_check_pairing", "h2e_op_to_point_with_curvature", "h2e_op_ecc_reduce_with_curvature",
+    "h2e_op_ecc_double", "h2e_op_ecc_add", "h2e_op_ecc_neg", "h2e_op_ecc_encode", "h2e_op_ecc_mul", "h2e_op_assign_constant_point",
+    "h2e_op_bisec_point_with_curvature", "h2e_op_assign_cache_point", "h2e_op_assign_selected_point", "h2e_export_fixed", "h2e_range_table", "h2e_export_copy_constraints", "h2e_ctx_set_option", "h2e_ctx_get_stat",
     "h2e_program_msm_bn256_tile_no_select", "h2e_last_run_expansion_launches",
 ]
 
@@ -63,6 +65,10 @@ class HInt(C.Structure):      # h2e_int: AssignedInteger (src/assign.rs:31-37) a
 
 class HPoint(C.Structure):    # h2e_point: AssignedPoint
     _fields_ = [("x", HInt), ("y", HInt), ("z", C.c_uint32)]
+
+
+class HPointC(C.Structure):   # h2e_point_c: AssignedPointWithCurvature
+    _fields_ = [("p", HPoint), ("cv", HInt), ("cz", C.c_uint32)]
 
 
 class HG2(C.Structure):       # h2e_g2: AssignedG2Affine
@@ -114,6 +120,18 @@ def lib():
     L.h2e_op_ecc_assert_equal.argtypes = [vp, C.POINTER(HPoint), C.POINTER(HPoint), vp]
     L.h2e_op_assign_g2_constant.argtypes = [vp, vp, C.POINTER(HG2), vp]
     L.h2e_op_check_pairing.argtypes = [vp, u32, C.POINTER(HPoint), C.POINTER(HG2), vp]
+    u64 = C.c_uint64
+    L.h2e_op_to_point_with_curvature.argtypes = [vp, C.POINTER(HPoint), C.POINTER(HPointC), vp]
+    L.h2e_op_ecc_reduce_with_curvature.argtypes = [vp, C.POINTER(HPoint), C.POINTER(HPointC), vp]
+    L.h2e_op_ecc_double.argtypes = [vp, C.POINTER(HPointC), C.POINTER(HPoint), vp]
+    L.h2e_op_ecc_add.argtypes = [vp, C.POINTER(HPointC), C.POINTER(HPoint), C.POINTER(HPoint), vp]
+    L.h2e_op_ecc_neg.argtypes = [vp, C.POINTER(HPoint), C.POINTER(HPoint), vp]
+    L.h2e_op_ecc_encode.argtypes = [vp, C.POINTER(HPoint), C.POINTER(u32), vp]
+    L.h2e_op_ecc_mul.argtypes = [vp, C.POINTER(HPoint), C.POINTER(HInt), vp, C.POINTER(HPoint), vp]
+    L.h2e_op_assign_constant_point.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), i32, C.POINTER(HPoint), vp]
+    L.h2e_op_bisec_point_with_curvature.argtypes = [vp, u32, C.POINTER(HPointC), C.POINTER(HPointC), C.POINTER(HPointC), vp]
+    L.h2e_op_assign_cache_point.argtypes = [vp, C.POINTER(HPointC), u64, u64, vp]
+    L.h2e_op_assign_selected_point.argtypes = [vp, u32, C.POINTER(HPointC), u32, u64, C.POINTER(HPointC), vp]
     L.h2e_program_pairing.argtypes = [i32, u32, i32, i32, C.POINTER(vp)]
     L.h2e_program_destroy.argtypes = [vp]
     L.h2e_program_destroy.restype = None
@@ -310,6 +328,64 @@ class Records:
 
     def ecc_assert_equal(self, a, b):
         _check(lib().h2e_op_ecc_assert_equal(self._h, C.byref(a), C.byref(b), self._s()))
+
+    # ---- the complete-addition / curvature surface of EccChipBaseOps ----
+    def to_point_with_curvature(self, a):
+        out = HPointC()
+        _check(lib().h2e_op_to_point_with_curvature(self._h, C.byref(a), C.byref(out), self._s()))
+        return out
+
+    def ecc_reduce_with_curvature(self, a):
+        out = HPointC()
+        _check(lib().h2e_op_ecc_reduce_with_curvature(self._h, C.byref(a), C.byref(out), self._s()))
+        return out
+
+    def ecc_double(self, a):
+        out = HPoint()
+        _check(lib().h2e_op_ecc_double(self._h, C.byref(a), C.byref(out), self._s()))
+        return out
+
+    def ecc_add(self, a, b):
+        out = HPoint()
+        _check(lib().h2e_op_ecc_add(self._h, C.byref(a), C.byref(b), C.byref(out), self._s()))
+        return out
+
+    def ecc_neg(self, a):
+        out = HPoint()
+        _check(lib().h2e_op_ecc_neg(self._h, C.byref(a), C.byref(out), self._s()))
+        return out
+
+    def ecc_encode(self, a):
+        out = (C.c_uint32 * 3)()
+        _check(lib().h2e_op_ecc_encode(self._h, C.byref(a), out, self._s()))
+        return list(out)
+
+    def ecc_mul(self, a, scalar, values):
+        out = HPoint()
+        _check(lib().h2e_op_ecc_mul(self._h, C.byref(a), C.byref(scalar), self._in(values), C.byref(out), self._s()))
+        return out
+
+    def assign_constant_point(self, x, y, is_identity=False):
+        n = self.slot_words
+        xs = (C.c_uint64 * n)(*[(x >> (64 * k)) & (2**64 - 1) for k in range(n)])
+        ys = (C.c_uint64 * n)(*[(y >> (64 * k)) & (2**64 - 1) for k in range(n)])
+        out = HPoint()
+        _check(lib().h2e_op_assign_constant_point(self._h, xs, ys, int(is_identity), C.byref(out), self._s()))
+        return out
+
+    def bisec_point_with_curvature(self, cond_cell, a, b):
+        out = HPointC()
+        _check(lib().h2e_op_bisec_point_with_curvature(self._h, cond_cell, C.byref(a), C.byref(b), C.byref(out), self._s()))
+        return out
+
+    def assign_cache_point(self, p, group, selector):
+        _check(lib().h2e_op_assign_cache_point(self._h, C.byref(p), group, selector, self._s()))
+
+    def assign_selected_point(self, candidates, index_cell, group):
+        arr = (HPointC * len(candidates))(*candidates)
+        out = HPointC()
+        _check(lib().h2e_op_assign_selected_point(self._h, len(candidates), arr, index_cell, group, C.byref(out), self._s()))
+        return out
 
     def assign_g2_constant(self, values):
         out = HG2()

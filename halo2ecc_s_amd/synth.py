@@ -275,3 +275,14 @@ def pairing_inputs(curve, n_pairs, seed_index=6, instance=0, expected=None):
     for p in a:
         vals += [p[0].a, p[1].a, 0]
     return pack(vals, sw)
+
+
+def ops_ecc_surface_inputs(seed_index=9, instance=0):
+    """inputs of the operator-API scenario over the complete-addition surface (tests/test_ops_gpu.py, oracle_run_ops_ecc_surface):
+    P (x, y, z), Q (x, y, z), scalar, index (= 1), generator (x, y), r1 (x, y), r2 (x, y)"""
+    rng = SplitMix64(SEED0 + seed_index + 1000003 * instance)
+    G = bn_g1_gen()
+    P, Q = ec_mul(G, rng.below(BN_R)), ec_mul(G, rng.below(BN_R))
+    s = rng.below(BN_R)
+    r1, r2 = ec_mul(G, rng.below(BN_R)), ec_mul(G, rng.below(BN_R))
+    return pack([P[0].a, P[1].a, 0, Q[0].a, Q[1].a, 0, s, 1, G[0].a, G[1].a, r1[0].a, r1[1].a, r2[0].a, r2[1].a], 4)

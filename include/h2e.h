@@ -260,6 +260,24 @@ int h2e_op_assign_scalars(h2e_records* rec, uint32_t n, const void* d_inputs /* 
 int h2e_op_msm_unsafe(h2e_records* rec, uint32_t n, const h2e_point* points, const h2e_int* scalars, const void* d_inputs, h2e_point* out,
                       void* stream);
 int h2e_op_ecc_assert_equal(h2e_records* rec, const h2e_point* a, const h2e_point* b, void* stream);
+/* the complete-addition / curvature surface of EccChipBaseOps (src/circuit/ecc_chip.rs:441-812): */
+typedef struct h2e_point_c { h2e_point p; h2e_int cv; uint32_t cz; } h2e_point_c;              /* AssignedPointWithCurvature (src/assign.rs:59-65) */
+int h2e_op_to_point_with_curvature(h2e_records* rec, const h2e_point* a, h2e_point_c* out, void* stream);        /* :695-708 */
+int h2e_op_ecc_reduce_with_curvature(h2e_records* rec, const h2e_point* a, h2e_point_c* out, void* stream);      /* :677-693 (ecc_reduce, assign_identity) */
+int h2e_op_ecc_double(h2e_records* rec, const h2e_point_c* a, h2e_point* out, void* stream);                      /* :630-642 */
+int h2e_op_ecc_add(h2e_records* rec, const h2e_point_c* a, const h2e_point* b, h2e_point* out, void* stream);     /* :606-628 */
+int h2e_op_ecc_neg(h2e_records* rec, const h2e_point* a, h2e_point* out, void* stream);                           /* :660-666 */
+int h2e_op_ecc_encode(h2e_records* rec, const h2e_point* a, uint32_t* out_cells3, void* stream);                  /* :710-732 */
+int h2e_op_ecc_mul(h2e_records* rec, const h2e_point* a, const h2e_int* scalar, const void* d_inputs /* as msm_unsafe */, h2e_point* out,
+                   void* stream);                                                                                 /* :418-420 */
+int h2e_op_assign_constant_point(h2e_records* rec, const uint64_t* x_words, const uint64_t* y_words, int is_identity, h2e_point* out,
+                                 void* stream);                                                                   /* :441-456 */
+int h2e_op_bisec_point_with_curvature(h2e_records* rec, uint32_t cond_cell, const h2e_point_c* a, const h2e_point_c* b, h2e_point_c* out,
+                                      void* stream);                                                              /* :562-578 */
+int h2e_op_assign_cache_point(h2e_records* rec, const h2e_point_c* p, uint64_t group, uint64_t selector, void* stream);   /* :779-788 */
+/* :790-812; the reference is handed the chosen candidate, here it is picked on the device by the value of the index cell */
+int h2e_op_assign_selected_point(h2e_records* rec, uint32_t n, const h2e_point_c* candidates, uint32_t index_cell, uint64_t group,
+                                 h2e_point_c* out, void* stream);
 int h2e_op_assign_g2_constant(h2e_records* rec, const void* d_inputs /* x.c0, x.c1, y.c0, y.c1 */, h2e_g2* out, void* stream);
 int h2e_op_check_pairing(h2e_records* rec, uint32_t n_pairs, const h2e_point* g1, const h2e_g2* g2, void* stream);
 

@@ -165,6 +165,41 @@ void* oracle_run_ops_msm_twice(uint32_t n, const uint64_t* inputs) {
     });
 }
 
+// Operator-API scenario over the complete-addition / curvature surface of EccChipBaseOps (tests/test_ops_gpu.py).
+// inputs (4-word slots): P (x, y, z), Q (x, y, z), scalar, index (= 1), generator (x, y), r1 (x, y), r2 (x, y)
+void* oracle_run_ops_ecc_surface(const uint64_t* inputs) {
+    return guarded([&](Run& r) {
+        IntegerContext ic(r.ctx, BnFq::modulus());
+        Inputs in{inputs, 4};
+        NativeScalarEccContext ecc = NativeScalarEccContext::new_with_select_chip(ic, bn256_g1_params());
+        ecc.curve.generator = in.point(8, 9, 2);
+        ecc.curve.generator.is_identity = false;
+        AssignedPoint P = ecc.assign_point(in.point(0, 1, 2));
+        AssignedPoint Q = ecc.assign_point(in.point(3, 4, 5));
+        AssignedValue s = r.ctx->assign(in.fr(6));
+        AssignedValue idx = r.ctx->assign(in.fr(7));
+        AssignedPointWithCurvature Pc = ecc.ecc_reduce_with_curvature(P);
+        AssignedPoint D = ecc.ecc_double(Pc);
+        AssignedPointWithCurvature Qc = ecc.to_point_with_curvature(Q);
+        AssignedPoint S = ecc.ecc_add(Qc, D);
+        AssignedPoint N = ecc.ecc_neg(S);
+        ecc.ecc_encode(N);
+        NativePoint r1 = in.point(10, 11, 2), r2 = in.point(12, 13, 2);
+        r1.is_identity = r2.is_identity = false;
+        ecc.msm_unsafe({P}, {s}, r1, r2);                                  // ecc_mul (ecc_chip.rs:418-420)
+        AssignedPoint C = ecc.assign_constant_point(ecc.curve.generator);
+        AssignedPointWithCurvature Cc = ecc.to_point_with_curvature(C);
+        ecc.bisec_point_with_curvature(P.z, Pc, Cc);
+        ecc.assign_cache_point(Pc, 7, 0);
+        ecc.assign_cache_point(Cc, 7, 1);
+        std::vector<AssignedPointWithCurvature> cands{Pc, Cc};
+        uint64_t w[4];
+        idx.val.to_canonical(w);
+        AssignedPointWithCurvature Sel = ecc.assign_selected_point(cands[w[0] & 0xff], idx, 7);
+        ecc.ecc_assert_equal(Sel.to_point(), C);
+    });
+}
+
 // src/tests/general_scalar_ecc_chip.rs:14-49 for one tile of n points (GeneralScalarEccContext<bls12_381::G1Affine, bn256::Fr>);
 // same input layout as h2e_program_msm_bls12_381_tile (6-word slots)
 void* oracle_run_msm_bls12_381_tile(uint32_t n, const uint64_t* inputs) {

@@ -756,6 +756,66 @@ class NativeScalarEccContext:
         both = ctx.and_(a.z, b.z)
         ctx.assert_true(ctx.or_(eq_xyz, both))
 
+    def assign_constant_point(self, p):                                   # :441-456
+        x, y = p if p is not None else (0, 0)
+        ax, ay = self.ic.assign_int_constant(x), self.ic.assign_int_constant(y)
+        return Pt(ax, ay, self.ctx.assign_constant(1 if p is None else 0))
+
+    def assign_identity(self):                                            # :514-529
+        zero = self.ic.assign_int_constant(0)
+        one = self.ctx.assign_constant(1)
+        return Pt(zero, zero, one), (zero, one)
+
+    def bisec_point_with_curvature(self, cond, a, a_curv, b, b_curv):     # :562-578
+        x = self.ic.bisec_int(cond, a.x, b.x)
+        y = self.ic.bisec_int(cond, a.y, b.y)
+        z = self.ctx.bisec(cond, a.z, b.z)
+        return Pt(x, y, z), self.bisec_curvature(cond, a_curv, b_curv)
+
+    def ecc_double(self, a, a_curv):                                      # :630-642
+        p = self.lambda_to_point(a_curv, a, a)
+        p.z = self.ctx.bisec(a.z, a.z, p.z)
+        return p
+
+    def ecc_neg(self, a):                                                 # :660-666
+        return Pt(a.x, self.ic.int_neg(a.y), a.z)
+
+    def ecc_reduce(self, a):                                              # :668-675
+        x, y = self.ic.reduce(a.x), self.ic.reduce(a.y)
+        identity, _ = self.assign_identity()
+        return self.bisec_point(a.z, identity, Pt(x, y, a.z))
+
+    def ecc_reduce_with_curvature(self, a):                               # :677-693
+        a = self.ecc_reduce(a)
+        x_square = self.ic.int_square(a.x)
+        num = self.ic.int_mul_small_constant(x_square, 3)
+        den = self.ic.int_mul_small_constant(a.y, 2)
+        z, v = self.ic.int_div(num, den)
+        return a, (self.ic.reduce(v), z)
+
+    def ecc_encode(self, p):                                              # :710-732
+        p = self.ecc_reduce(p)
+        shift = (1 << self.ic.info.limb_bits) % N_MOD
+        c = self.ctx
+        return [c.sum_with_constant([(p.x.limbs_le[0], 1), (p.x.limbs_le[1], shift)], None),
+                c.sum_with_constant([(p.x.limbs_le[2], 1), (p.y.limbs_le[0], shift)], None),
+                c.sum_with_constant([(p.y.limbs_le[1], 1), (p.y.limbs_le[2], shift)], None)]
+
+    def assign_cache_point(self, p, curv, g, sc):                         # :779-788
+        i = self.assign_cache_integer(p.x, sc, g, 0)
+        i = self.assign_cache_integer(p.y, sc, g, i)
+        self.ic.assign_cache_value(p.z, i, g, sc)
+        i = self.assign_cache_integer(curv[0], sc, g, i + 1)
+        self.ic.assign_cache_value(curv[1], i, g, sc)
+
+    def assign_selected_point(self, p, curv, sc, g):                      # :790-812
+        x, i = self.assign_selected_integer(p.x, sc, g, 0)
+        y, i = self.assign_selected_integer(p.y, sc, g, i)
+        z = self.ic.assign_selected_value(p.z, i, g, sc)
+        cv, i = self.assign_selected_integer(curv[0], sc, g, i + 1)
+        cz = self.ic.assign_selected_value(curv[1], i, g, sc)
+        return Pt(x, y, z), (cv, cz)
+
     def to_point_with_curvature(self, a):                                 # :695-708
         ic = self.ic
         x_square = ic.int_square(a.x)
@@ -1753,6 +1813,38 @@ def run_ops_msm_twice(n, inputs):
     res1 = ecc.msm_unsafe(points, scalars, r1, r2)
     res2 = ecc.msm_unsafe(points, scalars, r2, r1)
     ecc.ecc_assert_equal(res1, res2)
+    return ctx
+
+
+def run_ops_ecc_surface(inputs):
+    """operator-API scenario over the complete-addition / curvature surface (tests/test_ops_gpu.py): inputs = P, Q (x, y, z each),
+    scalar, index (= 1), generator (x, y), r1 (x, y), r2 (x, y)"""
+    ctx = Context()
+    ic = IntegerContext(ctx, BN_Q)
+    gen = (_w(inputs, 8), _w(inputs, 9))
+    ecc = NativeScalarEccContext(ic, 3, gen, 254, 0)
+    P = ecc.assign_point(_pt(inputs, 0, 1, 2))
+    Q = ecc.assign_point(_pt(inputs, 3, 4, 5))
+    s = ctx.assign(_w(inputs, 6))
+    idx = ctx.assign(_w(inputs, 7))
+    Pr, Pc = ecc.ecc_reduce_with_curvature(P)
+    D = ecc.ecc_double(Pr, Pc)
+    Qp, Qc = ecc.to_point_with_curvature(Q)
+    S = ecc.ecc_add(Qp, Qc, D)
+    N = ecc.ecc_neg(S)
+    ecc.ecc_encode(N)
+    r1 = (_w(inputs, 10), _w(inputs, 11))
+    r2 = (_w(inputs, 12), _w(inputs, 13))
+    ecc.msm_unsafe([P], [s], r1, r2)                                      # ecc_mul (ecc_chip.rs:418-420)
+    C = ecc.assign_constant_point(gen)
+    Cp, Cc = ecc.to_point_with_curvature(C)
+    ecc.bisec_point_with_curvature(P.z, Pr, Pc, Cp, Cc)
+    ecc.assign_cache_point(Pr, Pc, 7, 0)
+    ecc.assign_cache_point(Cp, Cc, 7, 1)
+    cands = [(Pr, Pc), (Cp, Cc)]
+    pick = cands[idx.val & 0xFF]
+    Sel, _ = ecc.assign_selected_point(pick[0], pick[1], idx, 7)
+    ecc.ecc_assert_equal(Sel, C)
     return ctx
 
 

@@ -102,3 +102,44 @@ def test_ops_check_pairing_on_assigned_terms(engine, oracle):
             got = arrs[region][:, :, :, k, :].cpu().numpy().view(np.uint64).reshape(rows[region], E.COLS[region], 4)
             assert np.array_equal(got, ovals), f"instance {k}: advice differs in region {region}"
     rec.close()
+
+
+def test_ops_complete_addition_surface(engine, oracle):
+    """the public EccChipBaseOps surface no BASELINE config reaches, as ops on assigned handles -
+    ecc_reduce_with_curvature (ecc_reduce, assign_identity, bisec_point), ecc_double, to_point_with_curvature, the complete
+    ecc_add, ecc_neg, ecc_encode, ecc_mul, assign_constant_point, bisec_point_with_curvature, assign_cache_point /
+    assign_selected_point on points with curvature (picked on the device by the index cell's value), ecc_assert_equal -
+    sixteen ops equal the oracle calling the same methods (src/circuit/ecc_chip.rs:441-812) on one context"""
+    n_inst = 3
+    ins = [synth.ops_ecc_surface_inputs(instance=k) for k in range(n_inst)]
+    oruns = [oracle_lib.run_ops_ecc_surface(inp) for inp in ins]
+    i = oruns[0].info
+    rows = (max(i.base_height, i.base_offset) + 1, max(i.range_height, i.range_offset) + 1, max(i.select_height, i.select_offset) + 1)
+    rec = Records(engine, E.FIELD_BN256_FQ, n_inst, rows)
+    a = np.stack(ins)
+    P = rec.assign_points(1, a[:, 0:3])[0]
+    Q = rec.assign_points(1, a[:, 3:6])[0]
+    s = rec.assign_scalars(1, a[:, 6:7])[0]
+    idx = rec.assign(a[:, 7:8])
+    Pc = rec.ecc_reduce_with_curvature(P)
+    D = rec.ecc_double(Pc)
+    Qc = rec.to_point_with_curvature(Q)
+    S = rec.ecc_add(Qc, D)
+    N = rec.ecc_neg(S)
+    enc = rec.ecc_encode(N)
+    assert len(enc) == 3
+    rec.ecc_mul(P, s, a[:, 8:14])
+    g = synth.bn_g1_gen()
+    Cp = rec.assign_constant_point(g[0].a, g[1].a)
+    Cc = rec.to_point_with_curvature(Cp)
+    rec.bisec_point_with_curvature(P.z, Pc, Cc)
+    rec.assign_cache_point(Pc, 7, 0)
+    rec.assign_cache_point(Cc, 7, 1)
+    Sel = rec.assign_selected_point([Pc, Cc], idx, 7)
+    rec.ecc_assert_equal(Sel.p, Cp)
+    engine.torch.cuda.synchronize()
+    assert (rec.arrays()[3].cpu().numpy() == 0).all()
+    for k, orun in enumerate(oruns):
+        for region, got, ovals in _rows_of(engine, rec, orun, n_inst):
+            assert np.array_equal(got[k], ovals), f"instance {k}: advice differs in region {region}"
+    rec.close()

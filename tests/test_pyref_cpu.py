@@ -182,3 +182,13 @@ def test_pyref_ops_scenario_matches_oracle(oracle):
     assert_oracle_matches(pyref.summary(pyref.run_ops_msm_twice(n, inp)), orun)
     ok, msg = orun.check()
     assert ok, msg
+
+
+def test_pyref_ecc_surface_scenario_matches_oracle(oracle):
+    """the complete-addition / curvature surface of EccChipBaseOps (ecc_chip.rs:441-812), the scenario of
+    tests/test_ops_gpu.py::test_ops_complete_addition_surface: oracle == pyref, constraint checker green"""
+    inp = synth.ops_ecc_surface_inputs(instance=5)
+    orun = oracle_lib.run_ops_ecc_surface(inp)
+    assert_oracle_matches(pyref.summary(pyref.run_ops_ecc_surface(inp)), orun)
+    ok, msg = orun.check()
+    assert ok, msg
