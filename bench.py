@@ -144,7 +144,8 @@ def main():
     ap.add_argument("--workload", default="msm", choices=sorted(DEFAULT_UNITS))
     ap.add_argument("--units", "--tiles", type=int, default=None, help="units per GPU: MSM tiles (64 x 1024 = 2^16 points) / pairing instances")
     ap.add_argument("--points", type=int, default=1024, help="points per MSM tile")
-    ap.add_argument("--ring", type=int, default=2, help="output-buffer sets steps rotate through (2: step k+1's value chain runs under step k's expansion; 1: h2e_run, no overlap)")
+    ap.add_argument("--ring", type=int, default=None, help="output-buffer sets steps rotate through = runs in flight (default: 2 for the MSM - step k+1's value chain runs under "
+                    "step k's expansion, 2 x 110 GB of arrays; 8 for the pairing checks, whose 35 ms level-parallel value chains only occupy one CU per instance; 1: h2e_run, no overlap)")
     ap.add_argument("--digest", action="store_true", help="consume every step's arrays with the on-device digest kernel (streaming-job mode, configs[2])")
     ap.add_argument("--job-tiles", type=int, default=None, help="run one MSM job of this many tiles over all ranks (2^20 points = 1024): steps = job_tiles / (units x gpus), digest on")
     ap.add_argument("--cpu-sample-points", type=int, default=1024)
@@ -158,6 +159,8 @@ def main():
     args = ap.parse_args()
     if args.units is None:
         args.units = DEFAULT_UNITS[args.workload]
+    if args.ring is None:
+        args.ring = 2 if args.workload == "msm" else 8
     if args.job_tiles:
         args.digest = True
         args.steps = max(1, args.job_tiles // (args.units * max(1, args.gpus)))
@@ -169,9 +172,9 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(29500 + os.getpid() % 1000), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd).returncode)
-    # pipelined runs use five HIP streams (caller's, expansion, fix-up, one side stream per job slot): more than the 4
-    # hardware queues a process gets by default, and streams that share a queue serialise
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # pipelined runs use several HIP streams (caller's, expansion, fix-up, a chain and a side stream per job slot): more than
+    # the 4 hardware queues a process gets by default, and streams that share a queue serialise
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     if world > 1 and args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -212,7 +215,17 @@ def main():
         traffic, traffic_err = measure_traffic(args)
 
     eng = Engine(local_rank)
-    ring = max(1, min(args.ring, eng.get_stat(3)))
+    ring = max(1, min(args.ring, eng.get_stat(4)))
+    eng.set_option(4, ring)          # H2E_OPT_PIPELINE_DEPTH: as many job slots (workspaces, streams) as runs in flight
+    # The first process that touches the HBM of a freshly booted box pays for it: without this throw-away allocate / fill / free
+    # of (almost) the whole memory the steps of that process run 2 x slower than those of any later one (47 vs 24 ms, measured
+    # with two bench runs in one gpurun call; exp/first_touch.py).  0.3 s, untimed, no effect on later processes.
+    free_b, _total = torch.cuda.mem_get_info(local_rank)
+    scratch = torch.empty((int(free_b * 0.92) // 8,), dtype=torch.int64, device=dev)
+    scratch.fill_(-1)
+    torch.cuda.synchronize()
+    del scratch
+    torch.cuda.empty_cache()
     bufs = [eng.alloc(prog, units) for _ in range(ring)]   # (base, range, select, status) per ring slot
     out_refs = prog.outputs()
     L = 3

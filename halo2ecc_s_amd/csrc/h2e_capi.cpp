@@ -1463,7 +1463,9 @@ struct h2e_ctx {
     H2EFieldConsts* d_fc[3] = {nullptr, nullptr, nullptr};
     std::map<std::string, h2e_program*> cache;
     bool profiling = false;
-    static constexpr int N_SLOTS = 2;
+    static constexpr int N_SLOTS = 8;
+    uint32_t depth = 2;      // job slots in use = runs in flight (H2E_OPT_PIPELINE_DEPTH); each slot brings its own streams   // runs in flight (h2e_submit): 2 hide an MSM step's value chain; the pairing checks' 34 ms
+                                        // level-parallel chains (one workgroup per instance) want 4
     JobSlot slots[N_SLOTS];
     uint64_t n_runs = 0;     // runs submitted so far: run k uses slot k % N_SLOTS
     int last_slot = -1;
@@ -1853,9 +1855,14 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     // segments outside the chain and the program's serial tail on the slot's side stream; inverse fix-ups on a fourth.
     // (The runtime maps a process's streams onto GPU_MAX_HW_QUEUES = 4 hardware queues by default; streams that share a
     // queue serialise.  A host that pipelines runs should raise it to 8 before HIP initialises - bench.py does.)
-    int slot_index = (int)(ctx->n_runs % h2e_ctx::N_SLOTS);
+    int slot_index = (int)(ctx->n_runs % ctx->depth);
     JobSlot& J = ctx->slots[slot_index];
-    if (!J.side_stream) HIP_TRY(hipStreamCreateWithPriority(&J.side_stream, hipStreamNonBlocking, ctx->prio_side));
+    {   // the side stream only exists for programs that use it (every stream takes one of the process's hardware queues)
+        bool need_side = p->tail_from >= 0;
+        for (auto& pk : r.pre_kernels) need_side = need_side || pk.early_after_segment >= 0;
+        for (size_t si = 0; si < r.segments.size() && si < p->seg_side_dep.size(); si++) need_side = need_side || p->seg_side_dep[si] != -2;
+        if (need_side && !J.side_stream) HIP_TRY(hipStreamCreateWithPriority(&J.side_stream, hipStreamNonBlocking, ctx->prio_side));
+    }
     if (!join && !J.chain_stream) HIP_TRY(hipStreamCreateWithPriority(&J.chain_stream, hipStreamNonBlocking, ctx->prio_side));
     if (!join) {   // the chain stream takes over from the caller's stream at this point
         if (!J.order_ev) HIP_TRY(hipEventCreateWithFlags(&J.order_ev, hipEventDisableTiming));
@@ -2255,6 +2262,13 @@ int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value) {
         case H2E_OPT_X_SPLIT_PCT: ctx->x_split_pct = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(100, value)); return 0;
         case H2E_OPT_X_SPLIT_MIN_LANES: ctx->x_split_min_lanes = (uint64_t)std::max<int64_t>(0, value); return 0;
         case H2E_OPT_TEST_SKIP_EXPANSION: ctx->test_skip_expansion = value; return 0;
+        case H2E_OPT_PIPELINE_DEPTH:
+            if (value < 1 || value > h2e_ctx::N_SLOTS) return fail(H2E_ERR_INVALID, "pipeline depth out of range");
+            HIP_TRY(hipSetDevice(ctx->device));
+            HIP_TRY(hipDeviceSynchronize());   // no run may be in flight while the slots are renumbered
+            ctx->depth = (uint32_t)value;
+            ctx->n_runs = 0;
+            return 0;
         default: return fail(H2E_ERR_INVALID, "unknown option");
     }
 }
@@ -2263,7 +2277,8 @@ int64_t h2e_ctx_get_stat(h2e_ctx* ctx, int stat) {
     switch (stat) {
         case H2E_STAT_LAST_SPLIT_SEGMENTS: return ctx->last_split_segments;
         case H2E_STAT_RUNS: return (int64_t)ctx->n_runs;
-        case H2E_STAT_PIPELINE_DEPTH: return h2e_ctx::N_SLOTS;
+        case H2E_STAT_PIPELINE_DEPTH: return ctx->depth;
+        case H2E_STAT_MAX_PIPELINE_DEPTH: return h2e_ctx::N_SLOTS;
         default: return -1;
     }
 }

@@ -169,10 +169,13 @@ int h2e_wait(h2e_ctx* ctx, int job, void* stream);
 #define H2E_OPT_TEST_SKIP_EXPANSION 3  /* TEST HOOK: leave out the full expansion of cut segment <value> (-1: of every cut
                                           segment but the last; INT64_MIN: off).  Rows are missing from such a run: every
                                           status word gets H2E_ST_TEST_HOOK. */
+#define H2E_OPT_PIPELINE_DEPTH 4       /* job slots in use = runs h2e_submit keeps in flight (1 .. H2E_STAT_MAX_PIPELINE_DEPTH, default 2).
+                                          Every slot has its own workspace and streams; call with no run in flight. */
 int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value);
 #define H2E_STAT_LAST_SPLIT_SEGMENTS 1 /* segments of the last run whose expansion went out as two launches */
 #define H2E_STAT_RUNS 2
 #define H2E_STAT_PIPELINE_DEPTH 3
+#define H2E_STAT_MAX_PIPELINE_DEPTH 4
 int64_t h2e_ctx_get_stat(h2e_ctx* ctx, int stat);
 
 /* Named entry points of SURVEY.md §8(b): build-or-reuse the program for the shape, then run it. */
