@@ -2405,17 +2405,26 @@ __global__ void __launch_bounds__(256) h2e_digest(const ulonglong2* __restrict__
         for (u64 t = blockIdx.x; t < tiles; t += gridDim.x) {
             u64 r1 = min(rows, (t + 1) * TR);
             for (u64 row = t * TR + wave; row < r1; row += 4) {
+                // all of the row's loads first (up to 2 x COLS independent 1 KB wave loads in flight), then the hashing
+                ulonglong2 lo[COLS], hi[COLS];
+                bool on[COLS];
 #pragma unroll
                 for (int col = 0; col < COLS; col++) {
                     u64 cell = row * COLS + col;
-                    if (flags != nullptr && !(flags[cell] & 1)) continue;   // wave-uniform
-                    if (!live) continue;
-                    ulonglong2 lo = in[(cell * 2) * n_inst + inst], hi = in[(cell * 2 + 1) * n_inst + inst];
-                    u64 tt = h2e_sm64(cell);
-                    d0 += h2e_sm64(lo.x ^ tt);
-                    d1 += h2e_sm64(lo.y ^ tt ^ 0xA24BAED4963EE407ull);
-                    d2 += h2e_sm64(hi.x ^ tt ^ (2 * 0xA24BAED4963EE407ull));
-                    d3 += h2e_sm64(hi.y ^ tt ^ (3 * 0xA24BAED4963EE407ull));
+                    on[col] = live && (flags == nullptr || (flags[cell] & 1));   // the flag is wave-uniform
+                    if (on[col]) {
+                        lo[col] = in[(cell * 2) * n_inst + inst];
+                        hi[col] = in[(cell * 2 + 1) * n_inst + inst];
+                    }
+                }
+#pragma unroll
+                for (int col = 0; col < COLS; col++) {
+                    if (!on[col]) continue;
+                    u64 tt = h2e_sm64(row * COLS + col);
+                    d0 += h2e_sm64(lo[col].x ^ tt);
+                    d1 += h2e_sm64(lo[col].y ^ tt ^ 0xA24BAED4963EE407ull);
+                    d2 += h2e_sm64(hi[col].x ^ tt ^ (2 * 0xA24BAED4963EE407ull));
+                    d3 += h2e_sm64(hi[col].y ^ tt ^ (3 * 0xA24BAED4963EE407ull));
                 }
             }
         }
