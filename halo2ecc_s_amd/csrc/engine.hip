@@ -56,11 +56,33 @@ struct InstanceDesc {
     u64* select;        // [select_rows][2][2][n_instances][2] + 2 * instance
     const u64* inputs;  // [n_slots][slot_words]
     u32* status;
-    u64* hints;         // [n_hint_slots][4]   quotient hints for H2E_OP_DIV_CORE (canonical values)
-    u64* nd;            // [n_hint_slots][2][4] numerator / denominator pairs (Montgomery form) of the V kernels
-    u64* jac;           // [n_jac_slots][3][WW] Jacobian scratch of the V kernels
-    u64* sel;           // [n_sel_slots][H2E_SEL_WORDS] points picked by the select pre-kernel
+    // Workspace of the value chain, instance-minor like the advice arrays: value slot v of this instance sits at
+    // ptr + v * ws (ws = n_instances * words per slot; ptr already points at this instance's words of slot 0), so the
+    // lanes of a wave - the same slot of consecutive instances - read and write one contiguous run.
+    u64* hints;         // [n_hint_slots] quotient / value hints (canonical values)
+    u64* nd;            // [n_hint_slots][2] numerator / denominator pairs (Montgomery form) of the V kernels
+    u64* jac;           // [n_jac_slots][3] Jacobian scratch of the V kernels
+    u64* sel;           // [n_sel_slots][2] points picked by the select pre-kernel (x, y canonical)
+    u32 ws;             // words between consecutive value slots
+    u32 pad_;
 };
+// a W value in a 16-byte aligned workspace slot
+template <int N>
+WI_INLINE Wd<N> ws_load(const u64* p) {
+    Wd<N> r;
+#pragma unroll
+    for (int i = 0; i < N / 2; i++) {
+        ulonglong2 t = ((const ulonglong2*)p)[i];
+        r.v[2 * i] = t.x;
+        r.v[2 * i + 1] = t.y;
+    }
+    return r;
+}
+template <int N>
+WI_INLINE void ws_store(u64* p, const Wd<N>& v) {
+#pragma unroll
+    for (int i = 0; i < N / 2; i++) ((ulonglong2*)p)[i] = make_ulonglong2(v.v[2 * i], v.v[2 * i + 1]);
+}
 
 struct LC {  // lane context
     u64* base;
@@ -78,6 +100,7 @@ struct LC {  // lane context
     u32 sw;                // words per input slot
     const u64* hints;
     u32 hint_stride;
+    u32 ws;             // words between consecutive workspace value slots (InstanceDesc)
     const u64* sel;     // selection buffer (H2E_FLAG_PRESELECTED)
     u32 sel_stride;
     bool active;        // false for the padding lanes of the last wave: compute, but store nothing
@@ -550,7 +573,7 @@ WI_INLINE u32 hint_slot_of(const LC& c, const H2EOp& op) {
 template <class FP>
 WI_INLINE void check_value_hint(const LC& c, const H2EOp& op, const Wd<FP::WW>& rem) {
     if (op.flags & H2E_FLAG_HINTED) {
-        Wd<FP::WW> h = wd_load<FP::WW>(c.hints + (size_t)hint_slot_of<FP>(c, op) * H2E_W_WORDS_MAX);
+        Wd<FP::WW> h = ws_load<FP::WW>(c.hints + (size_t)hint_slot_of<FP>(c, op) * c.ws);
         if (!wd_eq<FP::WW>(h, rem)) flag(c, H2E_STATUS_ARITH);
     }
 }
@@ -689,7 +712,7 @@ WI_INLINE void op_div_core(const LC& c, const H2EOp& op) {
         // c = a * b^-1 mod w was predicted by the V kernels (native Montgomery arithmetic + batch inversion);
         // a wrong hint cannot go unnoticed: (b*c - a) must be an exact multiple of w below.
         u32 slot = op.imm + ((op.flags & H2E_FLAG_HINT_STRIDED) ? c.strand * c.hint_stride : 0);
-        cv = wd_load<FP::WW>(c.hints + (size_t)slot * H2E_W_WORDS_MAX);
+        cv = ws_load<FP::WW>(c.hints + (size_t)slot * c.ws);
         if (wd_is_zero<FP::WW>(b_red)) cv = wd_zero<FP::WW>();
     } else {
         Wd<FP::WW> binv = wd_inv_mod<FP::WW>(b_red, w);
@@ -873,12 +896,12 @@ WI_INLINE Wd<FP::WW> hint_value(const LC& c, HintPrefetch<FP>& hp, u32 slot) {
             r = hp.v[i];
             hit = true;
         }
-    if (!hit) r = wd_load<FP::WW>(c.hints + (size_t)slot * H2E_W_WORDS_MAX);
+    if (!hit) r = ws_load<FP::WW>(c.hints + (size_t)slot * c.ws);
 #pragma unroll
     for (int i = 0; i < HintPrefetch<FP>::E; i++)
         if (i == e) {
             hp.slot[i] = slot + H2E_ECC_HINT_SLOTS;
-            hp.v[i] = wd_load<FP::WW>(c.hints + (size_t)(slot + H2E_ECC_HINT_SLOTS) * H2E_W_WORDS_MAX);  // workspace has spare slots
+            hp.v[i] = ws_load<FP::WW>(c.hints + (size_t)(slot + H2E_ECC_HINT_SLOTS) * c.ws);  // workspace has spare slots
         }
     return r;
 }
@@ -1014,6 +1037,7 @@ __global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDe
     c.input_stride = L.input_stride;
     c.sw = L.slot_words;
     c.hints = d.hints;
+    c.ws = d.ws;
     c.hint_stride = L.hint_stride;
     c.hs = 2 * n_instances;
     __shared__ TapeChunk chunk;
@@ -1201,13 +1225,13 @@ WI_INLINE void exec_vop(const VSlots<FP>& vs, const LC& c, const VHdr& h, const 
             if (e < n) {
                 u32 meta = h.w[2 + 2 * e], ref = h.w[3 + 2 * e];
                 const u64* src;
+                u32 piece = (meta >> 4) & 0xfu;   // 16-byte piece of the value
                 if ((meta & 3u) == 1u)
-                    src = c.hints + (size_t)(ref + ((meta & 0x100u) ? c.strand * c.hint_stride : 0)) * H2E_W_WORDS_MAX;
-                else if ((meta & 3u) == 2u)
-                    src = c.sel + (size_t)(ref + c.strand * c.sel_stride) * H2E_SEL_WORDS;
+                    src = c.hints + (size_t)(ref + ((meta & 0x100u) ? c.strand * c.hint_stride : 0)) * c.ws + piece * 2u;
+                else if ((meta & 3u) == 2u)   // x then y: two value slots, H2E_W_WORDS_MAX / 2 piece numbers each
+                    src = c.sel + (size_t)(2u * (ref + c.strand * c.sel_stride) + piece / (H2E_W_WORDS_MAX / 2)) * c.ws + (piece % (H2E_W_WORDS_MAX / 2)) * 2u;
                 else
-                    src = cell_ptr(c, ref);
-                src += (size_t)((meta >> 4) & 0xfu) * ((meta & 3u) == 0u ? c.hs : 2u);   // 16-byte piece: a cell's halves are hs words apart
+                    src = cell_ptr(c, ref) + (size_t)piece * c.hs;   // a cell's halves are hs words apart
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(vs.stage + (size_t)(h.w[1] + e) * 64), 16, 0, 0);
             }
@@ -1370,9 +1394,9 @@ WI_INLINE void exec_vop(const VSlots<FP>& vs, const LC& c, const VHdr& h, const 
             xy[0] = vs_stage_w<FP>(vs, h.w[2]);
             xy[1] = vs_stage_w<FP>(vs, h.w[2] + VSlots<FP>::HINT_UNITS);
         } else {
-            const u64* p = c.sel + (size_t)(h.w[2] + c.strand * c.sel_stride) * H2E_SEL_WORDS;
-            xy[0] = wd_load<FP::WW>(p);
-            xy[1] = wd_load<FP::WW>(p + H2E_W_WORDS_MAX);
+            const u64* p = c.sel + (size_t)2 * (h.w[2] + c.strand * c.sel_stride) * c.ws;
+            xy[0] = ws_load<FP::WW>(p);
+            xy[1] = ws_load<FP::WW>(p + c.ws);
         }
         u32 dst[2] = {(h.w[0] >> 16) & 0xffu, (h.w[7] >> 16) & 0xffu};
 #pragma unroll
@@ -1431,6 +1455,7 @@ __global__ void __launch_bounds__(64) h2e_replay(H2ELaunch L, const InstanceDesc
     c.input_stride = L.input_stride;
     c.sw = L.slot_words;
     c.hints = d.hints;
+    c.ws = d.ws;
     c.hint_stride = L.hint_stride;
     c.sel = d.sel;
     c.sel_stride = L.sel_stride;
@@ -1643,7 +1668,7 @@ WI_INLINE void exec_lop(const LVals<FP>& lv, const LC& c, u32 opc, const VHdr& h
         l_out_fe<FP>(lv, c, h, fe_u64((all_zero || is_w) ? 1 : 0));
     } else if (opc == H2E_V_HINT) {   // the canonical result comes from the predictors (one load per lane)
         u32 slot = imm + ((((h.w[0] >> 8) & H2E_VFLAG_HINT_STRIDED) != 0) ? c.strand * c.hint_stride : 0);
-        l_out_w<FP>(lv, c, h, wd_load<FP::WW>(c.hints + (size_t)slot * H2E_W_WORDS_MAX));
+        l_out_w<FP>(lv, c, h, ws_load<FP::WW>(c.hints + (size_t)slot * c.ws));
     } else if (opc == H2E_V_CONST) {
         Wd<FP::WW> x = wd_load<FP::WW>(c.pool + imm);
         Limb l[L];
@@ -1688,6 +1713,7 @@ __global__ void __launch_bounds__(64 * H2E_LEVEL_WAVES) h2e_replay_levels(H2ELau
     c.input_stride = L.input_stride;
     c.sw = L.slot_words;
     c.hints = d.hints;
+    c.ws = d.ws;
     c.hint_stride = L.hint_stride;
     c.sel = d.sel;
     c.sel_stride = L.sel_stride;
@@ -1847,9 +1873,12 @@ __global__ void __launch_bounds__(64) h2e_fixup_inverses(H2ELaunch L, const Inst
     Mont<4> M = mont_n(fc);
     u32 lo = chunk * FIXUP_K, hi = min(lo + FIXUP_K, L.n_fixups);
     // both passes fetch FB rows at a time, independent loads in flight together, before the serial multiplications
-    // over them.  (The kernel's time is the thread's ~570 dependent multiplications, 380 of them the inversion.)
+    // over them.
     constexpr u32 FB = 8;
-    Fe acc = M.r1;  // Montgomery one
+    // No Montgomery conversions: with mm(a, b) = a b / R on the canonical values themselves, the prefixes are
+    // p_i = p_(i-1) x_i / R (p_0 = 1); from u_k = 1 / p_k (a plain inverse) the backward pass gets
+    // 1 / x_i = mm(p_(i-1), u_i) and u_(i-1) = mm(x_i, u_i): three multiplications per cell.
+    Fe acc = wd_from_u64<4>(1);
     for (u32 i0 = lo; i0 < hi; i0 += FB) {
         u64* rows[FB];
         Fe xs[FB];
@@ -1861,11 +1890,11 @@ __global__ void __launch_bounds__(64) h2e_fixup_inverses(H2ELaunch L, const Inst
         for (u32 j = 0; j < FB; j++) {
             if (i0 + j < hi) {
                 st_cell(rows[j] + (size_t)2 * hs, hs, acc);  // prefix product of the non-zero values before i
-                if (!wd_is_zero<4>(xs[j])) acc = mont_mul<4>(M, acc, to_mont<4>(M, xs[j]));
+                if (!wd_is_zero<4>(xs[j])) acc = mont_mul<4>(M, acc, xs[j]);
             }
         }
     }
-    Fe ainv = mont_inv<4>(M, acc);
+    Fe ainv = wd_inv_mod<4>(acc, M.p);
     for (u32 i1 = hi; i1 > lo;) {
         u32 cnt = min(FB, i1 - lo);   // rows i1-1 ... i1-cnt, in that order
         u64* rows[FB];
@@ -1882,8 +1911,8 @@ __global__ void __launch_bounds__(64) h2e_fixup_inverses(H2ELaunch L, const Inst
             if (j < cnt) {
                 Fe out = wd_zero<4>();
                 if (!wd_is_zero<4>(xs[j])) {
-                    out = from_mont<4>(M, mont_mul<4>(M, ainv, pre[j]));
-                    ainv = mont_mul<4>(M, ainv, to_mont<4>(M, xs[j]));
+                    out = mont_mul<4>(M, ainv, pre[j]);
+                    ainv = mont_mul<4>(M, ainv, xs[j]);
                 }
                 st_cell(rows[j] + (size_t)2 * hs, hs, out);
             }
@@ -1976,12 +2005,9 @@ WI_INLINE Wd<FP::WW> ld_w_mont(const LC& c, const Mont<FP::WW>& M, const u32* li
 }
 template <class FP>
 WI_INLINE void st_nd(const VC& v, u32 slot, const Wd<FP::WW>& num, const Wd<FP::WW>& den) {
-    u64* p = v.nd + (size_t)slot * 2 * H2E_W_WORDS_MAX;
-#pragma unroll
-    for (int i = 0; i < FP::WW; i++) {
-        p[i] = num.v[i];
-        p[H2E_W_WORDS_MAX + i] = den.v[i];
-    }
+    u64* p = v.nd + (size_t)slot * 2 * v.c.ws;
+    ws_store<FP::WW>(p, num);
+    ws_store<FP::WW>(p + v.c.ws, den);
 }
 // record of one ecc op of a fully hinted chain, kept in the nd area of the op's hint block: (numerator, z of the
 // result = denominator, Jacobian x, y of the result), Montgomery form
@@ -1993,21 +2019,18 @@ WI_INLINE void st_rec(const VC& v, u32 block_slot, const Wd<FP::WW>& num, const 
 }
 template <class FP>
 WI_INLINE void st_jac(const VC& v, u32 slot, const Jac<FP::WW>& p) {
-    u64* q = v.jac + (size_t)slot * 3 * H2E_W_WORDS_MAX;
-#pragma unroll
-    for (int i = 0; i < FP::WW; i++) {
-        q[i] = p.x.v[i];
-        q[H2E_W_WORDS_MAX + i] = p.y.v[i];
-        q[2 * H2E_W_WORDS_MAX + i] = p.z.v[i];
-    }
+    u64* q = v.jac + (size_t)slot * 3 * v.c.ws;
+    ws_store<FP::WW>(q, p.x);
+    ws_store<FP::WW>(q + v.c.ws, p.y);
+    ws_store<FP::WW>(q + 2 * (size_t)v.c.ws, p.z);
 }
 template <class FP>
 WI_INLINE Jac<FP::WW> ld_jac(const VC& v, u32 slot) {
-    const u64* q = v.jac + (size_t)slot * 3 * H2E_W_WORDS_MAX;
+    const u64* q = v.jac + (size_t)slot * 3 * v.c.ws;
     Jac<FP::WW> p;
-    p.x = wd_load<FP::WW>(q);
-    p.y = wd_load<FP::WW>(q + H2E_W_WORDS_MAX);
-    p.z = wd_load<FP::WW>(q + 2 * H2E_W_WORDS_MAX);
+    p.x = ws_load<FP::WW>(q);
+    p.y = ws_load<FP::WW>(q + v.c.ws);
+    p.z = ws_load<FP::WW>(q + 2 * (size_t)v.c.ws);
     return p;
 }
 
@@ -2027,7 +2050,7 @@ __global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* arg
     __builtin_amdgcn_s_setprio(3);  // value chain: critical path (see h2e_run_tape<.., true>)
     u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_instances * K.n_lanes) return;
-    u32 instance = gid / K.n_lanes, lane = gid % K.n_lanes;
+    u32 instance = gid % n_instances, lane = gid / n_instances;   // instance-minor: the workspace slots of a wave are contiguous
     InstanceDesc d = inst[instance];
     VC v;
     v.c.base = d.base;
@@ -2044,6 +2067,7 @@ __global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* arg
     v.c.strand = lane;
     v.c.input_stride = 0;
     v.c.hints = nullptr;
+    v.c.ws = d.ws;
     v.c.hint_stride = 0;
     v.nd = d.nd;
     v.jac = d.jac;
@@ -2081,66 +2105,233 @@ __global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* arg
             st_nd<FP>(v, hint0 + i - 1, num, r.z);
             st_jac<FP>(v, j0 + i, r);
         }
-    } else if (K.kind == H2E_PRE_MSM_WINDOWS) {
-        // acc = -r1; acc = C_g[idx] + acc for every group   (ecc_chip.rs:320-336), a = candidate affine, b = acc Jacobian
-        u32 n_groups = a[0], group_size = a[1], n_points = a[2];
-        const u32* neg_r1 = a + 3;
-        const u32* tables = a + 3 + NR;
-        Jac<NW> acc;
-        acc.x = ld_w_mont<FP>(v.c, M, neg_r1);
-        acc.y = ld_w_mont<FP>(v.c, M, neg_r1 + L + 1);
-        acc.z = M.r1;
-        st_rec<FP>(v, hint0 + H2E_ECC_HINT_SLOTS * n_groups, acc.x, acc.z, acc.x, acc.y);   // the chain's initial point
-        // the candidates were picked by the select pre-kernel (one lane per window and group): no data-dependent
-        // addresses in this chain, and the next group's point is fetched one iteration ahead
-        (void)group_size; (void)n_points; (void)tables;
-        const u64* selp = d.sel + (size_t)(K.sel_begin + lane * n_groups) * H2E_SEL_WORDS;
-        Wd<NW> nx = wd_load<NW>(selp), ny = wd_load<NW>(selp + H2E_W_WORDS_MAX);
-        for (u32 g = 0; g < n_groups; g++) {
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scan predictors.  The two long chains of msm_unsafe - a window's sum over its groups (ecc_chip.rs:320-336) and the
+// accumulation over the windows (ecc_chip.rs:355-362) - are sums / a Horner recurrence in the group, so a lane does
+// not have to walk them from the start: chunk sums first, a short serial pass over the chunks, then every chunk's
+// *real* operations (the ones whose lambda = num / den and Jacobian result the hints are made from) in parallel from
+// the chunk's start value.  The start value only has to be *some* Jacobian representation of the right point: the
+// records stay self-consistent (finalize_ecc divides by each record's own Z), and the hints are canonical affine
+// values.  A scan-only addition can hit equal / opposite points although the real chain does not (result Z = 0,
+// which every later formula propagates); the lanes that find a start value with Z = 0 walk the real chain instead.
+static __device__ unsigned long long g_scan_fallbacks;   // lanes that walked the real chain (h2e_engine_scan_fallbacks)
+static __device__ u32 g_scan_test;   // test knob (h2e_engine_set_tuning(3, mask)): 1 = treat odd window chunks' offsets as degenerate,
+                                     // 2 = odd tail chunks' sums, 4 = the tail's in-chunk start values of odd windows
+template <class FP>
+WI_INLINE void vc_init(VC& v, const InstanceDesc& d, u32 n_instances, const u32* params, const u32* aux, const H2EFieldConsts* fc, u32 lane) {
+    v.c.base = d.base;
+    v.c.range = d.range;
+    v.c.select = d.select;
+    v.c.inputs = d.inputs;
+    v.c.status = d.status;
+    v.c.ob = v.c.orr = v.c.os = 0;
+    v.c.hs = 2 * n_instances;
+    v.c.params = params;
+    v.c.aux = aux;
+    v.c.pool = nullptr;
+    v.c.fc = fc;
+    v.c.strand = lane;
+    v.c.input_stride = 0;
+    v.c.hints = nullptr;
+    v.c.ws = d.ws;
+    v.c.hint_stride = 0;
+    v.c.ws = d.ws;
+    v.nd = d.nd;
+    v.jac = d.jac;
+}
+// phase 0: chunk sums S_c (lane = window x chunk); 1: offsets O_0 = -r1, O_(c+1) = S_c + O_c (lane = window);
+// 2: the chunk's additions acc = C_g[idx] + acc from O_c, with their records (lane = window x chunk)
+template <class FP>
+__global__ void __launch_bounds__(64) h2e_predict_windows(H2EPreKernel K, u32 phase, const u32* args, const InstanceDesc* inst, u32 n_instances,
+                                                          const H2EFieldConsts* fc) {
+    constexpr int L = FP::L, NW = FP::WW, NR = 2 * (L + 1);
+    constexpr u32 G = H2E_WIN_CHUNKS;
+    __builtin_amdgcn_s_setprio(3);
+    const u32* a = args + K.args_begin;
+    u32 n_groups = a[0];
+    const u32* neg_r1 = a + 3;
+    u32 len = (n_groups + G - 1) / G, nch = (n_groups + len - 1) / len;
+    u32 per_instance = phase == 1 ? K.n_lanes : K.n_lanes * nch;
+    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_instances * per_instance) return;
+    u32 instance = gid % n_instances, rest = gid / n_instances;
+    u32 window = phase == 1 ? rest : rest / nch, ch = phase == 1 ? 0 : rest % nch;
+    InstanceDesc d = inst[instance];
+    VC v;
+    vc_init<FP>(v, d, n_instances, nullptr, nullptr, fc, window);
+    MontW<FP> M;
+    (Mont<NW>&)M = mont_w<FP>(fc);
+    u32 s0 = K.scan_begin + window * 2 * G;   // S_c at s0 + c, O_c at s0 + G + c
+    const u64* selp = d.sel + (size_t)2 * (K.sel_begin + window * n_groups) * d.ws;   // (x, y) of group g at selp + 2 g ws
+    const size_t sel_step = (size_t)2 * d.ws;
+    auto neg_r1_point = [&]() {
+        Jac<NW> p;
+        p.x = ld_w_mont<FP>(v.c, M, neg_r1);
+        p.y = ld_w_mont<FP>(v.c, M, neg_r1 + L + 1);
+        p.z = M.r1;
+        return p;
+    };
+    // acc = C_g + acc over groups [g0, g1), the candidate fetched one iteration ahead; REC: leave the ops' records
+    auto walk = [&](Jac<NW> acc, u32 g0, u32 g1, bool rec, u32 hint0) {
+        if (g0 >= g1) return acc;
+        const u64* np = selp + g0 * sel_step;
+        Wd<NW> nx = ws_load<NW>(np), ny = ws_load<NW>(np + d.ws);
+        for (u32 g = g0; g < g1; g++) {
             Wd<NW> sx = nx, sy = ny;
-            const u64* np = selp + (size_t)min(g + 1, n_groups - 1) * H2E_SEL_WORDS;
-            nx = wd_load<NW>(np);
-            ny = wd_load<NW>(np + H2E_W_WORDS_MAX);
+            np = selp + min(g + 1, g1 - 1) * sel_step;
+            nx = ws_load<NW>(np);
+            ny = ws_load<NW>(np + d.ws);
             asm volatile("" ::: "memory");
             Wd<NW> cx = to_mont<NW>(M, sx), cy = to_mont<NW>(M, sy);
             Wd<NW> num;
             acc = jac_madd(M, acc, cx, cy, num);
-            st_rec<FP>(v, hint0 + H2E_ECC_HINT_SLOTS * g, num, acc.z, acc.x, acc.y);
+            if (rec) st_rec<FP>(v, hint0 + H2E_ECC_HINT_SLOTS * g, num, acc.z, acc.x, acc.y);
         }
-        st_jac<FP>(v, K.scratch_begin + lane, acc);
-    } else if (K.kind == H2E_PRE_MSM_TAIL) {
-        // acc = r1; per window: acc = 2 acc; acc = line_w + acc; [acc = acc + (-r2)]   (ecc_chip.rs:355-362)
-        u32 windows = a[0], odd = a[1];
-        const u32* r1 = a + 2;
-        const u32* neg_r2 = a + 2 + NR;
-        u32 line0 = a[2 + 2 * NR];
+        return acc;
+    };
+    u32 g0 = ch * len, g1 = min(g0 + len, n_groups);
+    // The candidates of consecutive groups carry opposite blinding points (+-r2) and a group whose bits are all zero
+    // contributes nothing else: a bare sum of candidates runs into P + (-P) all the time (two all-zero groups in a row:
+    // 2^-10 per pair).  The chunk sums therefore start from -2 r1 - as safe as the real chain, which starts from -r1 -
+    // and the serial pass takes the 2 r1 out again: S'_c = -2 r1 + sum, O_(c+1) = (O_c + S'_c) + 2 r1.
+    if (phase == 0) {
+        Wd<NW> num;
+        Jac<NW> s = jac_dbl(M, neg_r1_point(), num);
+        s = walk(s, g0, g1, false, 0);
+        st_jac<FP>(v, s0 + ch, s);
+    } else if (phase == 1) {
+        Wd<NW> num;
+        Jac<NW> o = neg_r1_point();
+        Jac<NW> two_r1 = jac_dbl(M, o, num);
+        two_r1.y = mont_sub<NW>(M, wd_zero<NW>(), two_r1.y);
+        for (u32 c = 0; c + 1 < nch; c++) {
+            o = jac_add(M, ld_jac<FP>(v, s0 + c), o, num);
+            o = jac_add(M, two_r1, o, num);
+            st_jac<FP>(v, s0 + G + c + 1, o);
+        }
+    } else {
+        u32 hint0 = K.hint_base + window * K.hints_per_lane;
         Jac<NW> acc;
-        acc.x = ld_w_mont<FP>(v.c, M, r1);
-        acc.y = ld_w_mont<FP>(v.c, M, r1 + L + 1);
-        acc.z = M.r1;
-        Wd<NW> bx = ld_w_mont<FP>(v.c, M, neg_r2), by = ld_w_mont<FP>(v.c, M, neg_r2 + L + 1);
-        u32 h = hint0;
-        // the next window's sum is fetched one iteration ahead (a dependent load on gfx9 also waits for every older
-        // store of the wave); the loop is kept rolled so that its code stays inside the instruction cache
-        st_rec<FP>(v, hint0 + H2E_ECC_HINT_SLOTS * K.ecc_ops, acc.x, acc.z, acc.x, acc.y);   // the chain's initial point
-        Jac<NW> next = ld_jac<FP>(v, line0);
-        for (u32 w = 0; w < windows; w++) {
+        if (ch == 0) {
+            acc = neg_r1_point();
+            st_rec<FP>(v, hint0 + H2E_ECC_HINT_SLOTS * n_groups, acc.x, acc.z, acc.x, acc.y);   // the chain's initial point
+        } else {
+            acc = ld_jac<FP>(v, s0 + G + ch);
+            if (wd_is_zero<NW>(acc.z) || ((g_scan_test & 1u) && (ch & 1u))) {
+                atomicAdd(&g_scan_fallbacks, 1ull);
+                acc = walk(neg_r1_point(), 0, g0, false, 0);
+            }
+        }
+        acc = walk(acc, g0, g1, !(g_scan_test & 8u), hint0);   // (8: timing experiment without the records)
+        if (ch == nch - 1) st_jac<FP>(v, K.scratch_begin + window, acc);
+    }
+}
+
+// The tail: acc = r1; per window w: acc = 2 acc; acc = line_w + acc; [acc = acc + (-r2)], i.e. acc_w = 2 acc_(w-1) + T_w.
+// phase 0: local Horner sums B_w of a chunk (lane = chunk); 1: per chunk the doubling chain D_w = 2^(j+1) A_(c-1) and
+// A_c = D + B at the chunk's end (lane = instance; the only serial part: one doubling per window);
+// 2: window w starts from acc_(w-1) = D_(w-1) + B_(w-1) and does its real operations, with their records (lane = window)
+template <class FP>
+__global__ void __launch_bounds__(64) h2e_predict_tail(H2EPreKernel K, u32 phase, const u32* args, const InstanceDesc* inst, u32 n_instances,
+                                                       const H2EFieldConsts* fc) {
+    constexpr int L = FP::L, NW = FP::WW, NR = 2 * (L + 1);
+    constexpr u32 CH = H2E_TAIL_CHUNK;
+    __builtin_amdgcn_s_setprio(3);
+    const u32* a = args + K.args_begin;
+    u32 windows = a[0], odd = a[1];
+    const u32* r1 = a + 2;
+    const u32* neg_r2 = a + 2 + NR;
+    u32 line0 = a[2 + 2 * NR];
+    u32 nch = (windows + CH - 1) / CH;
+    u32 per_instance = phase == 0 ? nch : phase == 1 ? 1 : windows;
+    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_instances * per_instance) return;
+    u32 instance = gid % n_instances, rest = gid / n_instances;
+    InstanceDesc d = inst[instance];
+    VC v;
+    vc_init<FP>(v, d, n_instances, nullptr, nullptr, fc, 0);
+    MontW<FP> M;
+    (Mont<NW>&)M = mont_w<FP>(fc);
+    u32 sB = K.scan_begin, sD = sB + windows, sA = sD + windows;
+    Wd<NW> bx = ld_w_mont<FP>(v.c, M, neg_r2), by = ld_w_mont<FP>(v.c, M, neg_r2 + L + 1);
+    auto r1_point = [&]() {
+        Jac<NW> p;
+        p.x = ld_w_mont<FP>(v.c, M, r1);
+        p.y = ld_w_mont<FP>(v.c, M, r1 + L + 1);
+        p.z = M.r1;
+        return p;
+    };
+    // the real operations of windows [w0, w1) from acc; REC: leave their records
+    auto walk = [&](Jac<NW> acc, u32 w0, u32 w1, bool rec) {
+        if (w0 >= w1) return acc;
+        u32 h = K.hint_base + H2E_ECC_HINT_SLOTS * (2 + odd) * w0;
+        Jac<NW> next = ld_jac<FP>(v, line0 + w0);
+        for (u32 w = w0; w < w1; w++) {
             Jac<NW> line = next;
-            next = ld_jac<FP>(v, line0 + min(w + 1, windows - 1));
+            next = ld_jac<FP>(v, line0 + min(w + 1, w1 - 1));
             asm volatile("" ::: "memory");
             Wd<NW> num;
             acc = jac_dbl(M, acc, num);
-            st_rec<FP>(v, h, num, acc.z, acc.x, acc.y);
+            if (rec) st_rec<FP>(v, h, num, acc.z, acc.x, acc.y);
             h += H2E_ECC_HINT_SLOTS;
             acc = jac_add(M, line, acc, num);
-            st_rec<FP>(v, h, num, acc.z, acc.x, acc.y);
+            if (rec) st_rec<FP>(v, h, num, acc.z, acc.x, acc.y);
             h += H2E_ECC_HINT_SLOTS;
             if (odd) {
                 acc = jac_madd(M, acc, bx, by, num);
-                st_rec<FP>(v, h, num, acc.z, acc.x, acc.y);
+                if (rec) st_rec<FP>(v, h, num, acc.z, acc.x, acc.y);
                 h += H2E_ECC_HINT_SLOTS;
             }
         }
+        return acc;
+    };
+    auto chunk_start = [&](u32 c) { return c == 0 ? r1_point() : ld_jac<FP>(v, sA + c - 1); };
+    if (phase == 0) {
+        u32 w0 = rest * CH, w1 = min(w0 + CH, windows);
+        Jac<NW> b;
+        for (u32 w = w0; w < w1; w++) {
+            Wd<NW> num;
+            Jac<NW> t = ld_jac<FP>(v, line0 + w);
+            if (odd) t = jac_madd(M, t, bx, by, num);
+            b = w == w0 ? t : jac_add(M, t, jac_dbl(M, b, num), num);
+            st_jac<FP>(v, sB + w, b);
+        }
+    } else if (phase == 1) {
+        Jac<NW> acc = r1_point();
+        for (u32 c = 0; c < nch; c++) {
+            u32 w0 = c * CH, w1 = min(w0 + CH, windows);
+            Jac<NW> dd = acc;
+            Wd<NW> num;
+            for (u32 w = w0; w < w1; w++) {
+                dd = jac_dbl(M, dd, num);
+                st_jac<FP>(v, sD + w, dd);
+            }
+            Jac<NW> nx = jac_add(M, ld_jac<FP>(v, sB + w1 - 1), dd, num);
+            if (wd_is_zero<NW>(nx.z) || ((g_scan_test & 2u) && (c & 1u))) {
+                atomicAdd(&g_scan_fallbacks, 1ull);
+                nx = walk(acc, w0, w1, false);
+            }
+            acc = nx;
+            st_jac<FP>(v, sA + c, acc);
+        }
+    } else {
+        u32 w = rest, c = w / CH, w0 = c * CH;
+        Jac<NW> acc;
+        if (w == w0) {
+            acc = chunk_start(c);
+        } else {
+            Wd<NW> num;
+            acc = jac_add(M, ld_jac<FP>(v, sB + w - 1), ld_jac<FP>(v, sD + w - 1), num);
+            if (wd_is_zero<NW>(acc.z) || ((g_scan_test & 4u) && (w & 1u))) {
+                atomicAdd(&g_scan_fallbacks, 1ull);
+                acc = walk(chunk_start(c), w0, w, false);
+            }
+        }
+        if (w == 0) st_rec<FP>(v, K.hint_base + H2E_ECC_HINT_SLOTS * K.ecc_ops, acc.x, acc.z, acc.x, acc.y);   // the chain's initial point
+        walk(acc, w, w + 1, true);
     }
 }
 
@@ -2154,7 +2345,7 @@ __global__ void __launch_bounds__(64) h2e_select(H2EPreKernel K, const u32* args
     constexpr int L = FP::L, NW = FP::WW, NR = 2 * (L + 1);
     u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_instances * K.n_lanes) return;
-    u32 instance = gid / K.n_lanes, lane = gid % K.n_lanes;
+    u32 instance = gid % n_instances, lane = gid / n_instances;
     const u32* a = args + K.args_begin;
     u32 n_groups = a[0], group_size = a[1], n_points = a[2];
     const u32* tables = a + 3 + NR;
@@ -2170,15 +2361,14 @@ __global__ void __launch_bounds__(64) h2e_select(H2EPreKernel K, const u32* args
     u32 lo = g * group_size, hi = min(n_points, lo + group_size), idx = 0;
     for (u32 j = lo; j < hi; j++) idx |= (u32)(ld_limb(c, H2E_MAKE_REF(H2E_REGION_PARAM, 0, 0, j)).v[0] & 1) << (j - lo);
     const u32* tab = aux + tables[g] + idx * NR;
-    u64* out = d.sel + (size_t)(K.sel_begin + w * n_groups + g) * H2E_SEL_WORDS;
+    u64* out = d.sel + (size_t)2 * (K.sel_begin + w * n_groups + g) * d.ws;
 #pragma unroll
     for (int which = 0; which < 2; which++) {
         Limb l[L];
 #pragma unroll
         for (int i = 0; i < L; i++) l[i] = ld_limb(c, tab[which * (L + 1) + i]);
         Wd<NW> v = wd_resize<NW>(compose<FP, FPX<FP>::AW>(l));
-#pragma unroll
-        for (int i = 0; i < NW; i++) out[which * H2E_W_WORDS_MAX + i] = v.v[i];
+        ws_store<NW>(out + (size_t)which * d.ws, v);
     }
 }
 
@@ -2192,31 +2382,30 @@ __global__ void __launch_bounds__(64) h2e_finalize_hints(u32 hint_base, u32 n_hi
     u32 chunks = (n_hints + HINT_K - 1) / HINT_K;
     u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_instances * chunks) return;
-    u32 instance = gid / chunks, chunk = gid % chunks;
+    u32 instance = gid % n_instances, chunk = gid / n_instances;
     InstanceDesc d = inst[instance];
     Mont<NW> M = mont_w<FP>(fc);
     u32 lo = hint_base + chunk * HINT_K, hi = min(lo + HINT_K, hint_base + n_hints);
     Wd<NW> acc = M.r1;
     for (u32 s = lo; s < hi; s++) {
-        Wd<NW> den = wd_load<NW>(d.nd + (size_t)s * 2 * H2E_W_WORDS_MAX + H2E_W_WORDS_MAX);
-        u64* hp = d.hints + (size_t)s * H2E_W_WORDS_MAX;
-#pragma unroll
-        for (int i = 0; i < NW; i++) hp[i] = acc.v[i];
+        Wd<NW> den = ws_load<NW>(d.nd + ((size_t)s * 2 + 1) * d.ws);
+        ws_store<NW>(d.hints + (size_t)s * d.ws, acc);
         if (!wd_is_zero<NW>(den)) acc = mont_mul<NW>(M, acc, den);
     }
-    Wd<NW> ainv = mont_inv<NW>(M, acc);
+    // the running inverse is kept as a plain value (not in Montgomery form): multiplied with Montgomery-form prefixes /
+    // denominators / numerators it stays plain, and num * (1 / den) comes out canonical without a conversion
+    Wd<NW> ainv = wd_inv_mod<NW>(from_mont<NW>(M, acc), M.p);
     for (u32 s = hi; s-- > lo;) {
-        const u64* np = d.nd + (size_t)s * 2 * H2E_W_WORDS_MAX;
-        Wd<NW> num = wd_load<NW>(np), den = wd_load<NW>(np + H2E_W_WORDS_MAX);
-        u64* hp = d.hints + (size_t)s * H2E_W_WORDS_MAX;
+        const u64* np = d.nd + (size_t)s * 2 * d.ws;
+        Wd<NW> num = ws_load<NW>(np), den = ws_load<NW>(np + d.ws);
+        u64* hp = d.hints + (size_t)s * d.ws;
         Wd<NW> out = wd_zero<NW>();
         if (!wd_is_zero<NW>(den)) {
-            Wd<NW> dinv = mont_mul<NW>(M, ainv, wd_load<NW>(hp));
+            Wd<NW> dinv = mont_mul<NW>(M, ainv, ws_load<NW>(hp));
             ainv = mont_mul<NW>(M, ainv, den);
-            out = from_mont<NW>(M, mont_mul<NW>(M, num, dinv));
+            out = mont_mul<NW>(M, num, dinv);
         }
-#pragma unroll
-        for (int i = 0; i < NW; i++) hp[i] = out.v[i];
+        ws_store<NW>(hp, out);
     }
 }
 
@@ -2232,35 +2421,34 @@ __global__ void __launch_bounds__(64) h2e_finalize_ecc(H2EPreKernel K, const Ins
     u32 chunks = (K.ecc_ops + ECC_CH - 1) / ECC_CH;
     u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_instances * K.n_lanes * chunks) return;
-    u32 chunk = gid % chunks, lane = (gid / chunks) % K.n_lanes, instance = gid / (chunks * K.n_lanes);
+    u32 instance = gid % n_instances, chunk = (gid / n_instances) % chunks, lane = gid / (n_instances * chunks);
     InstanceDesc d = inst[instance];
     MontW<FP> M;
     (Mont<NW>&)M = mont_w<FP>(fc);
     u32 hint0 = K.hint_base + lane * K.hints_per_lane;
     int lo = (int)(chunk * ECC_CH), hi = min(lo + ECC_CH, (int)K.ecc_ops);
     // element e in [lo - 1, hi): e = -1 is the chain's initial point (block ecc_ops)
-    auto rec = [&](int e) -> u64* { return d.nd + (size_t)(hint0 + H2E_ECC_HINT_SLOTS * (e < 0 ? K.ecc_ops : (u32)e)) * 2 * H2E_W_WORDS_MAX; };
-    auto hint = [&](int e, u32 k) -> u64* { return d.hints + (size_t)(hint0 + H2E_ECC_HINT_SLOTS * (u32)e + k) * H2E_W_WORDS_MAX; };
+    const size_t ws = d.ws;
+    auto rec = [&](int e) -> u64* { return d.nd + (size_t)(hint0 + H2E_ECC_HINT_SLOTS * (e < 0 ? K.ecc_ops : (u32)e)) * 2 * ws; };
+    auto hint = [&](int e, u32 k) -> u64* { return d.hints + (size_t)(hint0 + H2E_ECC_HINT_SLOTS * (u32)e + k) * ws; };
     Wd<NW> acc = M.r1;
     for (int e = lo - 1; e < hi; e++) {
         u64* r = rec(e);
-        Wd<NW> den = wd_load<NW>(r + H2E_W_WORDS_MAX);
+        Wd<NW> den = ws_load<NW>(r + ws);
         // prefix product -> third pair of the block's nd area (element lo - 1 also belongs to the previous chunk's
         // lane, which keeps its own prefix in the first half of that pair)
-        u64* pp = r + (e == lo - 1 ? 5 : 4) * H2E_W_WORDS_MAX;
-#pragma unroll
-        for (int i = 0; i < NW; i++) pp[i] = acc.v[i];
+        ws_store<NW>(r + (e == lo - 1 ? 5 : 4) * ws, acc);
         if (!wd_is_zero<NW>(den)) acc = mm(M, acc, den);
     }
     Wd<NW> ainv = mont_inv<NW>(M, acc);
     Wd<NW> xn = wd_zero<NW>(), yn = xn, ln = xn;   // op e + 1: affine result and lambda
     for (int e = hi - 1; e >= lo - 1; e--) {
         const u64* r = rec(e);
-        Wd<NW> num = wd_load<NW>(r), den = wd_load<NW>(r + H2E_W_WORDS_MAX);
-        Wd<NW> X = wd_load<NW>(r + 2 * H2E_W_WORDS_MAX), Y = wd_load<NW>(r + 3 * H2E_W_WORDS_MAX);
+        Wd<NW> num = ws_load<NW>(r), den = ws_load<NW>(r + ws);
+        Wd<NW> X = ws_load<NW>(r + 2 * ws), Y = ws_load<NW>(r + 3 * ws);
         Wd<NW> dinv = wd_zero<NW>();
         if (!wd_is_zero<NW>(den)) {
-            dinv = mm(M, ainv, wd_load<NW>(r + (e == lo - 1 ? 5 : 4) * H2E_W_WORDS_MAX));
+            dinv = mm(M, ainv, ws_load<NW>(r + (e == lo - 1 ? 5 : 4) * ws));
             ainv = mm(M, ainv, den);
         }
         Wd<NW> zi2 = mm(M, dinv, dinv);
@@ -2289,9 +2477,7 @@ __global__ void __launch_bounds__(64) h2e_finalize_ecc(H2EPreKernel K, const Ins
             auto put = [&](u32 slot, const Wd<NW>& vm) {
                 if (!((K.used_slots >> slot) & 1u)) return;   // nobody reads it
                 Wd<NW> cv = mm(M, vm, one);   // out of the Montgomery domain: canonical
-                u64* hp = hint((int)k, slot);
-#pragma unroll
-                for (int i = 0; i < NW; i++) hp[i] = cv.v[i];
+                ws_store<NW>(hint((int)k, slot), cv);
             };
             put(H2E_HINT_LAMBDA, ln);
             put(H2E_HINT_LAMBDA2, l2);
@@ -2588,8 +2774,17 @@ extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances,
 // nothing (11.6 vs 11.7 ms), while the 15 KB of LDS per workgroup it held kept the value chain's replay workgroups
 // (95-135 KB of LDS each) of the next run from sharing CUs with the expansion: pipelined step 24.0 -> 20.9 ms.
 static int g_tune[3] = {0, 0, 0};
+extern "C" long long h2e_engine_scan_fallbacks(void) {
+    unsigned long long n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_scan_fallbacks), sizeof(n)) != hipSuccess) return -1;
+    return (long long)n;
+}
 extern "C" void h2e_engine_set_tuning(int key, int value) {
     if (key >= 0 && key < 3) g_tune[key] = value;
+    if (key == 3) {
+        u32 m = (u32)value;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_test), &m, sizeof(m));
+    }
 }
 
 // mode: 1 = values-only replay (whole tape per lane), 2 = full expansion (sub-ranges if any), 4 = inverse fix-up
@@ -2663,7 +2858,19 @@ extern "C" int h2e_engine_predict(int field_pair, int phase, const H2EPreKernel*
         if (phase & 1) hipLaunchKernelGGL(h2e_select<FP>, grid, block, 0, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances); \
         break;                                                                                                                      \
     }                                                                                                                               \
-    if (phase & 1)                                                                                                                  \
+    if ((phase & 1) && k->kind == H2E_PRE_MSM_WINDOWS) {                                                                            \
+        u32 ng = k->ecc_ops, len = (ng + H2E_WIN_CHUNKS - 1) / H2E_WIN_CHUNKS, nch = (ng + len - 1) / len;                          \
+        dim3 gc((lanes * nch + 63) / 64);                                                                                           \
+        hipLaunchKernelGGL(h2e_predict_windows<FP>, gc, block, 0, stream, *k, 0u, args_dev, inst, n_instances, fc_dev);             \
+        hipLaunchKernelGGL(h2e_predict_windows<FP>, grid, block, 0, stream, *k, 1u, args_dev, inst, n_instances, fc_dev);           \
+        hipLaunchKernelGGL(h2e_predict_windows<FP>, gc, block, 0, stream, *k, 2u, args_dev, inst, n_instances, fc_dev);             \
+    } else if ((phase & 1) && k->kind == H2E_PRE_MSM_TAIL) {                                                                        \
+        u32 windows = k->ecc_ops / k->pattern_len, nch = (windows + H2E_TAIL_CHUNK - 1) / H2E_TAIL_CHUNK;                           \
+        dim3 g0((n_instances * nch + 63) / 64), g2((n_instances * windows + 63) / 64);                                              \
+        hipLaunchKernelGGL(h2e_predict_tail<FP>, g0, block, 0, stream, *k, 0u, args_dev, inst, n_instances, fc_dev);                \
+        hipLaunchKernelGGL(h2e_predict_tail<FP>, grid, block, lds_reserve, stream, *k, 1u, args_dev, inst, n_instances, fc_dev);    \
+        hipLaunchKernelGGL(h2e_predict_tail<FP>, g2, block, 0, stream, *k, 2u, args_dev, inst, n_instances, fc_dev);                \
+    } else if (phase & 1)                                                                                                           \
         hipLaunchKernelGGL(h2e_predict<FP>, grid, block, lds_reserve, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev); \
     if ((phase & 2) && k->ecc_ops)                                                                                                  \
         hipLaunchKernelGGL(h2e_finalize_ecc<FP>, grid3, block, 0, stream, *k, inst, n_instances, fc_dev);                           \

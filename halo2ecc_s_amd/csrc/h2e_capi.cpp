@@ -17,6 +17,7 @@ extern "C" int h2e_engine_export(uint32_t cols, int columns, int mont, const voi
 extern "C" int h2e_engine_digest(uint32_t cols, const void* in, const uint8_t* flags, uint64_t rows, uint32_t n_instances, void* out,
                                  hipStream_t stream);
 extern "C" void h2e_engine_set_tuning(int key, int value);
+extern "C" long long h2e_engine_scan_fallbacks(void);
 extern "C" int h2e_engine_fixed(int field_pair, const uint32_t* ids, const uint64_t* dict, uint64_t rows, uint32_t cols, int columns, int mont,
                                 const uint32_t* patches, uint32_t n_patches, const uint64_t* inputs, uint32_t n_slots, uint32_t slot_words,
                                 uint32_t n_instances, const H2EFieldConsts* fc_dev, void* out, hipStream_t stream);
@@ -50,6 +51,36 @@ inline const char* dbg_env(const char* name) { return getenv(name); }
 inline const char* dbg_env(const char*) { return nullptr; }
 #endif
 
+// Ablation hooks of the scheduler (H2E_DEBUG_HOOKS builds only; exp/ablate.sh): H2E_DEBUG_SKIP is a bit mask of kernel
+// classes run_impl leaves out - 1 inverse fix-ups, 2 finalize kernels, 4 MSM tail predictor, 8 MSM windows predictor,
+// 16 select, 32 value replay of cut segments, 64 expansions.  The arrays of such a run are garbage: what it measures is
+// what the class costs the step (its own time and what it takes from the kernels it runs beside).
+#ifdef H2E_DEBUG_HOOKS
+static uint32_t dbg_skip_mask() {
+    static const uint32_t m = getenv("H2E_DEBUG_SKIP") ? (uint32_t)atoi(getenv("H2E_DEBUG_SKIP")) : 0u;
+    return m;
+}
+static int dbg_engine_launch(int fpair, int mode, const H2ELaunch* l, const void* inst, uint32_t n, const H2EFieldConsts* fc, hipStream_t st) {
+    uint32_t m = dbg_skip_mask();
+    if ((mode == 4 && (m & 1u)) || (mode == 1 && (m & 32u)) || (mode == 2 && l->n_sub > 1 && (m & 64u))) return 0;
+    return h2e_engine_launch(fpair, mode, l, inst, n, fc, st);
+}
+static int dbg_engine_predict(int fpair, int phase, const H2EPreKernel* k, const uint32_t* a, const uint32_t* prm, const uint32_t* aux,
+                              const void* inst, uint32_t n, const H2EFieldConsts* fc, hipStream_t st) {
+    uint32_t m = dbg_skip_mask();
+    if (m & 2u) phase &= ~2;
+    if ((k->kind == H2E_PRE_MSM_TAIL && (m & 4u)) || (k->kind == H2E_PRE_MSM_WINDOWS && (m & 8u)) || (k->kind == H2E_PRE_MSM_SELECT && (m & 16u)))
+        phase &= ~1;
+    if (!phase) return 0;
+    return h2e_engine_predict(fpair, phase, k, a, prm, aux, inst, n, fc, st);
+}
+#define H2E_LAUNCH dbg_engine_launch
+#define H2E_PREDICT dbg_engine_predict
+#else
+#define H2E_LAUNCH h2e_engine_launch
+#define H2E_PREDICT h2e_engine_predict
+#endif
+
 const h2e::FieldPair& field_pair(int id) { return h2e::field_pair_of(id); }
 
 struct InstanceDescHost {  // must match engine.hip InstanceDesc
@@ -62,6 +93,8 @@ struct InstanceDescHost {  // must match engine.hip InstanceDesc
     uint64_t* nd;
     uint64_t* jac;
     uint64_t* sel;
+    uint32_t ws;     // words between consecutive workspace value slots = n_instances * words per slot (instance-minor)
+    uint32_t pad_;
 };
 
 }  // namespace
@@ -1083,7 +1116,10 @@ struct h2e_program {
             if (rs)
                 for (uint32_t q : rs->prologue) consider(q, true);
             for (uint32_t pos = pos_begin; pos < pos_end; pos++) consider(pos, false);
-            if (!stage_on) {
+            // Staging (asynchronous gathers into LDS ahead of the serial chain) pays for segments with few lanes, whose
+            // time is load latency; a segment with thousands of workgroups (the MSM windows: 254 strands x 38 pieces) is
+            // bound by how many of them fit on a CU, and the staging area is half of its LDS (1.85 -> 0.85 ms).
+            if (!stage_on || (uint64_t)sg->n_strands * (restarts.size() + 1) >= 2048) {
                 sm = StageMap();
                 gl.clear();
             }
@@ -1474,6 +1510,11 @@ struct h2e_ctx {
     // tuning knobs, read once at h2e_ctx_create (H2E_X_SPLIT, H2E_X_SPLIT_MIN_LANES); h2e_ctx_set_option overrides
     uint32_t x_split_pct = 45;
     uint64_t x_split_min_lanes = 1ull << 21;
+    uint32_t sched = 0;      // scheduling experiments (H2E_SCHED bit mask): 1 = a pipelined run's small fix-ups go to the slot's side
+                             // stream, 2 = its small expansions too (instead of queueing on the shared expansion stream)
+    // CU partition (H2E_CU_RESERVE="n[,fixup_side]"): the value-chain streams of pipelined runs get the device's last n CUs for
+    // themselves, the expansion stream the others (fix-up stream: the expansion's CUs, or with fixup_side = 1 the chain's, 2 all)
+    uint32_t cu_reserve = 0, cu_fixup_side = 0, cu_pattern = 0;   // pattern 1: every (n_cu / n)-th CU instead of the last n
     int prio_expand = 0, prio_side = 0, prio_fixup = 0;   // HIP stream priorities (H2E_STREAM_PRIORITIES="x,s,f"; lower = higher priority)
     int64_t test_skip_expansion = INT64_MIN;   // test hook (h2e_ctx_set_option): see H2E_OPT_TEST_SKIP_EXPANSION
     uint32_t last_split_segments = 0;          // segments of the last run whose expansion was split (h2e_ctx_get_stat)
@@ -1505,12 +1546,18 @@ int h2e_ctx_create(int device, h2e_ctx** out) {
     if (const char* e1 = getenv("H2E_X_SPLIT")) c->x_split_pct = (uint32_t)std::max(0, std::min(100, atoi(e1)));
     if (const char* e2 = getenv("H2E_X_SPLIT_MIN_LANES")) c->x_split_min_lanes = (uint64_t)atoll(e2);
     if (const char* e4 = getenv("H2E_TUNE")) {   // "reserve,xcache,xpad" (engine.hip g_tune)
-        int a = 0, b = 0, d = 0;
-        sscanf(e4, "%d,%d,%d", &a, &b, &d);
+        int a = 0, b = 0, d = 0, t = 0;
+        sscanf(e4, "%d,%d,%d,%d", &a, &b, &d, &t);
         h2e_engine_set_tuning(0, a);
         h2e_engine_set_tuning(1, b);
         h2e_engine_set_tuning(2, d);
+        if (t) {
+            (void)hipSetDevice(device);
+            h2e_engine_set_tuning(3, t);   // scan predictor test mask (H2E_OPT_TEST_SCAN_FALLBACK)
+        }
     }
+    if (const char* e5 = getenv("H2E_SCHED")) c->sched = (uint32_t)atoi(e5);
+    if (const char* e6 = getenv("H2E_CU_RESERVE")) sscanf(e6, "%u,%u,%u", &c->cu_reserve, &c->cu_fixup_side, &c->cu_pattern);
     if (const char* e3 = getenv("H2E_STREAM_PRIORITIES")) sscanf(e3, "%d,%d,%d", &c->prio_expand, &c->prio_side, &c->prio_fixup);
     *out = c;
     return 0;
@@ -1825,6 +1872,22 @@ static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
 // One run.  `join` = true: the caller's stream completes when every stream of the run has (h2e_run); false: the
 // caller's stream only carries the value chain and `slot.done` is recorded on the fix-up stream when the run is
 // complete (h2e_submit / h2e_wait).
+// kind: 0 expansion, 1 value chain / side, 2 fix-up
+static hipError_t make_stream(h2e_ctx* ctx, hipStream_t* out, int prio, int kind) {
+    if (!ctx->cu_reserve) return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
+    if (e != hipSuccess) return e;
+    uint32_t n_cu = (uint32_t)prop.multiProcessorCount, res = std::min(ctx->cu_reserve, n_cu - 1);
+    int side = kind == 2 ? (ctx->cu_fixup_side == 1 ? 1 : ctx->cu_fixup_side == 2 ? 2 : 0) : kind;
+    std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
+    for (uint32_t i = 0; i < n_cu; i++) {
+        bool chain_cu = ctx->cu_pattern == 1 ? (i % (n_cu / res) == 0 && i / (n_cu / res) < res) : i >= n_cu - res;
+        if (side == 2 || (side == 1) == chain_cu) mask[i / 32] |= 1u << (i % 32);
+    }
+    return hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
+}
+
 static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
                     void* d_select, void* d_status, hipStream_t stream, bool join, int* slot_out) {
     if (!ctx || !p) return fail(H2E_ERR_INVALID, "null ctx/program");
@@ -1846,8 +1909,8 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
                 HIP_TRY((hipError_t)h2e_engine_set_consts(f, &field_pair(f).fc));
             }
     }
-    if (!ctx->expand_stream) HIP_TRY(hipStreamCreateWithPriority(&ctx->expand_stream, hipStreamNonBlocking, ctx->prio_expand));
-    if (!ctx->fixup_stream) HIP_TRY(hipStreamCreateWithPriority(&ctx->fixup_stream, hipStreamNonBlocking, ctx->prio_fixup));
+    if (!ctx->expand_stream) HIP_TRY(make_stream(ctx, &ctx->expand_stream, ctx->prio_expand, 0));
+    if (!ctx->fixup_stream) HIP_TRY(make_stream(ctx, &ctx->fixup_stream, ctx->prio_fixup, 2));
     // Streams.  The *value chain* (predictor kernels + values-only replay, or the plain tape for segments without cuts)
     // runs on the caller's stream: it is what later segments depend on.  The full expansion of a cut segment only needs
     // the value chain up to that segment, so it runs on a second stream and overlaps the value chain of the following
@@ -1861,9 +1924,9 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         bool need_side = p->tail_from >= 0;
         for (auto& pk : r.pre_kernels) need_side = need_side || pk.early_after_segment >= 0;
         for (size_t si = 0; si < r.segments.size() && si < p->seg_side_dep.size(); si++) need_side = need_side || p->seg_side_dep[si] != -2;
-        if (need_side && !J.side_stream) HIP_TRY(hipStreamCreateWithPriority(&J.side_stream, hipStreamNonBlocking, ctx->prio_side));
+        if (need_side && !J.side_stream) HIP_TRY(make_stream(ctx, &J.side_stream, ctx->prio_side, 1));
     }
-    if (!join && !J.chain_stream) HIP_TRY(hipStreamCreateWithPriority(&J.chain_stream, hipStreamNonBlocking, ctx->prio_side));
+    if (!join && !J.chain_stream) HIP_TRY(make_stream(ctx, &J.chain_stream, ctx->prio_side, 1));
     if (!join) {   // the chain stream takes over from the caller's stream at this point
         if (!J.order_ev) HIP_TRY(hipEventCreateWithFlags(&J.order_ev, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(J.order_ev, stream));
@@ -1903,10 +1966,14 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         if (e == hipSuccess) *have = need;
         return e;
     };
-    size_t hint_words = ((size_t)r.n_hint_slots + H2E_ECC_HINT_SLOTS) * H2E_W_WORDS_MAX,  // spare: the replay prefetches slot + 8
+    // the value chain's workspace is instance-minor ([slot][instance][w words], engine.hip InstanceDesc); a slot holds a
+    // value of the widest W field the program works in
+    size_t wsw = slot_words;
+    for (auto& sg : r.segments) wsw = std::max<size_t>(wsw, (size_t)field_pair(sg.field_pair).w_words);
+    size_t hint_words = ((size_t)r.n_hint_slots + H2E_ECC_HINT_SLOTS) * wsw,  // spare: the replay prefetches slot + 8
            nd_words = hint_words * 2,
-           jac_words = (size_t)r.n_jac_slots * 3 * H2E_W_WORDS_MAX,
-           sel_words = (size_t)r.n_sel_slots * H2E_SEL_WORDS;
+           jac_words = (size_t)r.n_jac_slots * 3 * wsw,
+           sel_words = (size_t)r.n_sel_slots * 2 * wsw;
     HIP_TRY(grow(&J.ws_hints, &J.ws_hints_words, std::max<size_t>(1, hint_words * n_instances)));
     HIP_TRY(grow(&J.ws_nd, &J.ws_nd_words, std::max<size_t>(1, nd_words * n_instances)));
     HIP_TRY(grow(&J.ws_jac, &J.ws_jac_words, std::max<size_t>(1, jac_words * n_instances)));
@@ -1919,10 +1986,12 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         d.select = (uint64_t*)d_select + (size_t)i * 2;
         d.inputs = (const uint64_t*)d_inputs + (size_t)i * r.n_input_slots * slot_words;
         d.status = (uint32_t*)d_status + i;
-        d.hints = J.ws_hints + (size_t)i * hint_words;
-        d.nd = J.ws_nd + (size_t)i * nd_words;
-        d.jac = J.ws_jac + (size_t)i * jac_words;
-        d.sel = J.ws_sel + (size_t)i * sel_words;
+        d.hints = J.ws_hints + (size_t)i * wsw;
+        d.nd = J.ws_nd + (size_t)i * wsw;
+        d.jac = J.ws_jac + (size_t)i * wsw;
+        d.sel = J.ws_sel + (size_t)i * wsw;
+        d.ws = (uint32_t)(n_instances * wsw);
+        d.pad_ = 0;
     }
     HIP_TRY(hipMemcpyAsync(J.d_inst, J.h_inst.data(), (size_t)n_instances * sizeof(InstanceDescHost),
                            hipMemcpyHostToDevice, sa));
@@ -1972,7 +2041,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         HIP_TRY(hipEventRecord(e0, sa));
         HIP_TRY(hipStreamWaitEvent(sb, e0, 0));
         if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 2), sb));
-        int prc2 = h2e_engine_launch((int)pending_L.field_pair, 2, &pending_L, J.d_inst, n_instances, ctx->d_fc[pending_L.field_pair], sb);
+        int prc2 = H2E_LAUNCH((int)pending_L.field_pair, 2, &pending_L, J.d_inst, n_instances, ctx->d_fc[pending_L.field_pair], sb);
         if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
         if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 3), sb));
         if (pending_L.n_fixups) {
@@ -1980,7 +2049,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             HIP_TRY(hipEventRecord(e1, sb));
             HIP_TRY(hipStreamWaitEvent(sd, e1, 0));
             used_sd = true;
-            prc2 = h2e_engine_launch((int)pending_L.field_pair, 4, &pending_L, J.d_inst, n_instances, ctx->d_fc[pending_L.field_pair], sd);
+            prc2 = H2E_LAUNCH((int)pending_L.field_pair, 4, &pending_L, J.d_inst, n_instances, ctx->d_fc[pending_L.field_pair], sd);
             if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
         }
         have_pending = false;
@@ -2015,7 +2084,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
                 HIP_TRY(hipStreamWaitEvent(sa, early_done[pi], 0));
                 continue;
             }
-            int prc = h2e_engine_predict(fp, 1, &pk.k, p->d_pre_args, p->d_params, p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sa);
+            int prc = H2E_PREDICT(fp, 1, &pk.k, p->d_pre_args, p->d_params, p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sa);
             if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
         }
         if (have_pending && hold_longer && s.sel_stride) {
@@ -2029,7 +2098,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             hipEvent_t e0 = sync_event();
             HIP_TRY(hipEventRecord(e0, sa));
             HIP_TRY(hipStreamWaitEvent(sc, e0, 0));
-            int prc = h2e_engine_predict(fp, 3, &pk.k, p->d_pre_args, p->d_params, p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sc);
+            int prc = H2E_PREDICT(fp, 3, &pk.k, p->d_pre_args, p->d_params, p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sc);
             if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
             hipEvent_t e1 = sync_event();
             HIP_TRY(hipEventRecord(e1, sc));
@@ -2039,7 +2108,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         for (size_t pi = 0; pi < r.pre_kernels.size(); pi++) {
             const h2e::PreKernel& pk = r.pre_kernels[pi];
             if (pk.before_segment != si || early_done[pi]) continue;
-            int prc = h2e_engine_predict(fp, 2, &pk.k, p->d_pre_args, p->d_params, p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sa);
+            int prc = H2E_PREDICT(fp, 2, &pk.k, p->d_pre_args, p->d_params, p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sa);
             if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
         }
         H2ELaunch L;
@@ -2079,7 +2148,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         L.l_slots = levels ? p->seg_l_slots[si] : 0;
         int lrc;
         auto launch_one = [&](int mode, const H2ELaunch& l, hipStream_t st) -> int {
-            int rc2 = h2e_engine_launch((int)l.field_pair, mode, &l, J.d_inst, n_instances, ctx->d_fc[l.field_pair], st);
+            int rc2 = H2E_LAUNCH((int)l.field_pair, mode, &l, J.d_inst, n_instances, ctx->d_fc[l.field_pair], st);
             if (rc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc2));
             return 0;
         };
@@ -2108,6 +2177,13 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             H2ELaunch f = L;
             f.fixups = L.fixups + lo;
             f.n_fixups = hi - lo;
+            if (fixup_in_stream && !join && sc && (ctx->sched & 1u) && st != sc) {   // pipelined: keep the shared expansion stream free
+                hipEvent_t e = sync_event();
+                HIP_TRY(hipEventRecord(e, st));
+                HIP_TRY(hipStreamWaitEvent(sc, e, 0));
+                used_se = true;
+                return launch_one(4, f, sc);
+            }
             if (fixup_in_stream) return launch_one(4, f, st);
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, st));
@@ -2153,7 +2229,8 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             // the side stream it and its fix-up slow the big one down by more than they take alone; its fix-up follows it
             // in its stream: the fix-up stream still holds the big expansion's second fix-up
             bool small_x = (uint64_t)L.n_sub * L.n_strands * n_instances < (1u << 18);
-            hipStream_t sx = sb;
+            hipStream_t sx = (small_x && !join && sc && (ctx->sched & 2u)) ? sc : sb;
+            if (sx == sc) used_se = true;
             fixup_in_stream = small_x;
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, sa));
@@ -2269,6 +2346,11 @@ int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value) {
             ctx->depth = (uint32_t)value;
             ctx->n_runs = 0;
             return 0;
+        case H2E_OPT_TEST_SCAN_FALLBACK:
+            HIP_TRY(hipSetDevice(ctx->device));
+            HIP_TRY(hipDeviceSynchronize());
+            h2e_engine_set_tuning(3, (int)value);
+            return 0;
         default: return fail(H2E_ERR_INVALID, "unknown option");
     }
 }
@@ -2277,6 +2359,9 @@ int64_t h2e_ctx_get_stat(h2e_ctx* ctx, int stat) {
     switch (stat) {
         case H2E_STAT_LAST_SPLIT_SEGMENTS: return ctx->last_split_segments;
         case H2E_STAT_RUNS: return (int64_t)ctx->n_runs;
+        case H2E_STAT_SCAN_FALLBACKS:
+            if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+            return (int64_t)h2e_engine_scan_fallbacks();
         case H2E_STAT_PIPELINE_DEPTH: return ctx->depth;
         case H2E_STAT_MAX_PIPELINE_DEPTH: return h2e_ctx::N_SLOTS;
         default: return -1;

@@ -813,6 +813,8 @@ struct NativeScalarEccContext {
             pk.k.n_params = seg_windows.n_params;
             pk.k.params_begin = seg_windows.params_begin;
             pk.k.scratch_begin = win_jac;
+            pk.k.scan_begin = c.n_jac_slots;
+            c.n_jac_slots += H2E_WIN_SCAN_SLOTS((uint32_t)windows);
             pk.before_segment = win_seg_index;
             c.pre_kernels.push_back(pk);
         }
@@ -833,6 +835,8 @@ struct NativeScalarEccContext {
             push_point_refs(c.pre_args, rand_acc_point);
             push_point_refs(c.pre_args, rand_line_point_neg);
             c.pre_args.push_back(win_jac);
+            pk.k.scan_begin = c.n_jac_slots;
+            c.n_jac_slots += H2E_TAIL_SCAN_SLOTS((uint32_t)windows);
             pk.before_segment = (uint32_t)c.segments.size() - 1;
             pk.early_after_segment = (int32_t)win_seg_index;
             c.pre_kernels.push_back(pk);

@@ -249,4 +249,13 @@ typedef struct H2EPreKernel {
     uint32_t pattern;
     uint32_t sel_begin;      // first entry of this kernel's strands in the selection buffer (SELECT writes, WINDOWS reads)
     uint32_t used_slots;     // full value hints: bit k set = slot k of the ecc blocks is read by someone (host, after the DCE pass)
+    uint32_t scan_begin;     // WINDOWS / TAIL: first Jacobian scratch slot of the chain's scan (sizes: H2E_WIN_SCAN_SLOTS / H2E_TAIL_SCAN_SLOTS)
 } H2EPreKernel;
+// The MSM chains are walked as scans (engine.hip "scan predictors"): a window's sum over its groups in H2E_WIN_CHUNKS
+// chunks (chunk sums -> offsets -> the real additions of every chunk in parallel), the tail's accumulation
+// acc <- 2 acc + line_w [- r2] in chunks of H2E_TAIL_CHUNK windows (local Horner sums B, the doubling chain D of the
+// chunk's start value A, acc_w = D_w + B_w).  Scratch slots per instance:
+#define H2E_WIN_CHUNKS 8u
+#define H2E_TAIL_CHUNK 16u
+#define H2E_WIN_SCAN_SLOTS(windows) ((windows) * 2u * H2E_WIN_CHUNKS)                                   /* S_c, O_c per window */
+#define H2E_TAIL_SCAN_SLOTS(windows) (2u * (windows) + ((windows) + H2E_TAIL_CHUNK - 1u) / H2E_TAIL_CHUNK)  /* B_w, D_w, A_c */

@@ -15,8 +15,8 @@ ST_OK, ST_ASSERT_FAILED, ST_RETRY_ADD_SAME_OR_NEG_POINT, ST_RETRY_ADD_IDENTITY, 
 ST_TEST_HOOK = 0x80
 LAYOUT_ROWS, LAYOUT_COLUMNS = 0, 1
 FORM_CANONICAL, FORM_MONTGOMERY = 0, 1
-OPT_X_SPLIT_PCT, OPT_X_SPLIT_MIN_LANES, OPT_TEST_SKIP_EXPANSION, OPT_PIPELINE_DEPTH = 1, 2, 3, 4
-STAT_LAST_SPLIT_SEGMENTS, STAT_RUNS, STAT_PIPELINE_DEPTH, STAT_MAX_PIPELINE_DEPTH = 1, 2, 3, 4
+OPT_X_SPLIT_PCT, OPT_X_SPLIT_MIN_LANES, OPT_TEST_SKIP_EXPANSION, OPT_PIPELINE_DEPTH, OPT_TEST_SCAN_FALLBACK = 1, 2, 3, 4, 5
+STAT_LAST_SPLIT_SEGMENTS, STAT_RUNS, STAT_PIPELINE_DEPTH, STAT_MAX_PIPELINE_DEPTH, STAT_SCAN_FALLBACKS = 1, 2, 3, 4, 5
 OPT_OFF = -(1 << 63)
 COLS = (5, 3, 2)
 

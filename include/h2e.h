@@ -171,11 +171,15 @@ int h2e_wait(h2e_ctx* ctx, int job, void* stream);
                                           status word gets H2E_ST_TEST_HOOK. */
 #define H2E_OPT_PIPELINE_DEPTH 4       /* job slots in use = runs h2e_submit keeps in flight (1 .. H2E_STAT_MAX_PIPELINE_DEPTH, default 2).
                                           Every slot has its own workspace and streams; call with no run in flight. */
+#define H2E_OPT_TEST_SCAN_FALLBACK 5    /* TEST HOOK: bit mask - the MSM scan predictors treat some of their (valid) start values as degenerate
+                                          and walk the real chain instead (1 window chunks, 2 tail chunk sums, 4 tail in-chunk starts).
+                                          The results are the same; what it covers is the fallback path.  Process-wide; 0 = off. */
 int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value);
 #define H2E_STAT_LAST_SPLIT_SEGMENTS 1 /* segments of the last run whose expansion went out as two launches */
 #define H2E_STAT_RUNS 2
 #define H2E_STAT_PIPELINE_DEPTH 3
 #define H2E_STAT_MAX_PIPELINE_DEPTH 4
+#define H2E_STAT_SCAN_FALLBACKS 5      /* lanes of the MSM scan predictors that had to walk the real chain so far (process-wide; synchronises) */
 int64_t h2e_ctx_get_stat(h2e_ctx* ctx, int stat);
 
 /* Named entry points of SURVEY.md §8(b): build-or-reuse the program for the shape, then run it. */

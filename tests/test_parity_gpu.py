@@ -226,6 +226,32 @@ def test_msm_split_expansion(engine, oracle, pct):
         compare_advice(prog, orun, base, rng, sel, instance=k)
 
 
+@pytest.mark.parametrize("mask", [1, 2, 4, 7])
+def test_msm_scan_predictor_fallback(engine, oracle, mask):
+    """The MSM chains are predicted as scans (engine.hip "scan predictors"): chunk sums, a short serial pass, then every
+    chunk's real operations from the chunk's start value.  A start value the scan could not make (a scan-only addition of
+    equal / opposite points: Z = 0) is replaced by walking the real chain.  Forced here on every other chunk / window
+    (H2E_OPT_TEST_SCAN_FALLBACK): same witness.  n = 96: 20 groups -> 7 window chunks; 254 windows -> 16 tail chunks."""
+    n, tiles = 96, 2
+    ins = [synth.msm_bn256_tile_inputs(n, tile=70 + t, cheap_points=True)[0] for t in range(tiles)]
+    prog = Program.msm_bn256_tile(n)
+    from halo2ecc_s_amd import engine as E
+    before = engine.get_stat(E.STAT_SCAN_FALLBACKS)
+    base0, rng0, sel0, status0 = _run(engine, prog, ins)
+    assert engine.get_stat(E.STAT_SCAN_FALLBACKS) == before, "the scan fell back although nothing was degenerate"
+    engine.set_option(E.OPT_TEST_SCAN_FALLBACK, mask)
+    try:
+        base, rng, sel, status = _run(engine, prog, ins)
+    finally:
+        engine.set_option(E.OPT_TEST_SCAN_FALLBACK, 0)
+    assert engine.get_stat(E.STAT_SCAN_FALLBACKS) > before, "the fallback path was not taken"
+    assert (status == 0).all() and (status0 == 0).all(), status
+    for k, inp in enumerate(ins):
+        orun = oracle_lib.run_msm_bn256_tile(n, inp)
+        assert orun.info.status == 0, orun.error
+        compare_advice(prog, orun, base, rng, sel, instance=k)
+
+
 @pytest.mark.parametrize("n", [1, 5, 12])
 def test_msm_tile_no_select(engine, oracle, n):
     """MSM without the select chip (ecc_chip.rs:91-221, candidates by bisection trees)"""
