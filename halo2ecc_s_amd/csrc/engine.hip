@@ -1001,8 +1001,18 @@ WI_INLINE H2EOp chunk_op(const TapeChunk* tc, u32 k) {
     return op;
 }
 
+// Register budgets.  A wave is only dispatched to a SIMD that has its whole register allocation free (512 per lane and
+// SIMD).  The expansion keeps every SIMD filled with its own waves; a value-chain kernel of another stream gets a wave in
+// when an expansion wave retires *and* what that frees is enough for it - a replay wave with 284 registers never fitted next
+// to a remaining 231-register expansion wave and waited for a SIMD to drain completely (6 ms for a 0.5 ms kernel).
+#ifndef H2E_X_WAVES
+#define H2E_X_WAVES 1
+#endif
+#ifndef H2E_REPLAY_WAVES
+#define H2E_REPLAY_WAVES 2
+#endif
 template <class FP, bool VALUES_ONLY>
-__global__ void __launch_bounds__(64) h2e_run_tape(H2ELaunch L, const InstanceDesc* inst, u32 n_instances,
+__global__ void __launch_bounds__(64, H2E_X_WAVES) h2e_run_tape(H2ELaunch L, const InstanceDesc* inst, u32 n_instances,
                                                    const H2EFieldConsts* fc) {
     // lanes: [sub-range][strand][instance], each sub-range padded to whole waves so a wave replays one op range; the
     // instance is the minor index: the lanes of a wave are consecutive instances (the minor dimension of the advice
@@ -1427,7 +1437,7 @@ WI_INLINE void exec_vop(const VSlots<FP>& vs, const LC& c, const VHdr& h, const 
 }
 
 template <class FP>
-__global__ void __launch_bounds__(64) h2e_replay(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
+__global__ void __launch_bounds__(64, H2E_REPLAY_WAVES) h2e_replay(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
     // lanes: [piece][instance][strand]; pieces are independent stretches of the replay (host: compile_replay)
     u32 per = n_instances * L.n_strands;
     u32 blocks_per = (per + 63) / 64;

@@ -1507,10 +1507,12 @@ struct h2e_ctx {
     int last_slot = -1;
     hipStream_t expand_stream = nullptr;
     hipStream_t fixup_stream = nullptr;
+    hipStream_t small_stream = nullptr;   // small expansions of pipelined runs (H2E_SCHED & 4)
     // tuning knobs, read once at h2e_ctx_create (H2E_X_SPLIT, H2E_X_SPLIT_MIN_LANES); h2e_ctx_set_option overrides
     uint32_t x_split_pct = 45;
     uint64_t x_split_min_lanes = 1ull << 21;
-    uint32_t sched = 0;      // scheduling experiments (H2E_SCHED bit mask): 1 = a pipelined run's small fix-ups go to the slot's side
+    uint64_t small_x_lanes = 1u << 18;   // an expansion with fewer lanes is "small" (H2E_SMALL_X_LANES)
+    uint32_t sched = 4;      // scheduling experiments (H2E_SCHED bit mask): 1 = a pipelined run's small fix-ups go to the slot's side
                              // stream, 2 = its small expansions too (instead of queueing on the shared expansion stream)
     // CU partition (H2E_CU_RESERVE="n[,fixup_side]"): the value-chain streams of pipelined runs get the device's last n CUs for
     // themselves, the expansion stream the others (fix-up stream: the expansion's CUs, or with fixup_side = 1 the chain's, 2 all)
@@ -1526,6 +1528,7 @@ struct h2e_ctx {
         for (auto& sl : slots) sl.release();
         if (expand_stream) (void)hipStreamDestroy(expand_stream);
         if (fixup_stream) (void)hipStreamDestroy(fixup_stream);
+        if (small_stream) (void)hipStreamDestroy(small_stream);
     }
 };
 
@@ -1557,6 +1560,7 @@ int h2e_ctx_create(int device, h2e_ctx** out) {
         }
     }
     if (const char* e5 = getenv("H2E_SCHED")) c->sched = (uint32_t)atoi(e5);
+    if (const char* e7 = getenv("H2E_SMALL_X_LANES")) c->small_x_lanes = (uint64_t)atoll(e7);
     if (const char* e6 = getenv("H2E_CU_RESERVE")) sscanf(e6, "%u,%u,%u", &c->cu_reserve, &c->cu_fixup_side, &c->cu_pattern);
     if (const char* e3 = getenv("H2E_STREAM_PRIORITIES")) sscanf(e3, "%d,%d,%d", &c->prio_expand, &c->prio_side, &c->prio_fixup);
     *out = c;
@@ -2028,7 +2032,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     std::vector<hipEvent_t> seg_ev(r.segments.size(), nullptr), side_done(r.segments.size(), nullptr);
     hipEvent_t run_begin = sync_event();
     HIP_TRY(hipEventRecord(run_begin, sa));
-    bool used_se = false;
+    bool used_se = false, used_small = false;
     H2ELaunch pending_L;
     uint32_t pending_li = 0;
     bool have_pending = false;
@@ -2037,16 +2041,22 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     // is no such segment, right behind the next value chain
     bool hold_longer = false;
     auto flush_pending = [&]() -> int {   // launch an expansion that was held back behind a later value chain
+        hipStream_t sp = sb;
+        if (!join && (ctx->sched & 8u)) {   // pipelined: beside the previous run's big expansions, not between them
+            if (!ctx->small_stream) HIP_TRY(make_stream(ctx, &ctx->small_stream, ctx->prio_expand, 0));
+            sp = ctx->small_stream;
+            used_small = true;
+        }
         hipEvent_t e0 = sync_event();
         HIP_TRY(hipEventRecord(e0, sa));
-        HIP_TRY(hipStreamWaitEvent(sb, e0, 0));
-        if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 2), sb));
-        int prc2 = H2E_LAUNCH((int)pending_L.field_pair, 2, &pending_L, J.d_inst, n_instances, ctx->d_fc[pending_L.field_pair], sb);
+        HIP_TRY(hipStreamWaitEvent(sp, e0, 0));
+        if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 2), sp));
+        int prc2 = H2E_LAUNCH((int)pending_L.field_pair, 2, &pending_L, J.d_inst, n_instances, ctx->d_fc[pending_L.field_pair], sp);
         if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
-        if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 3), sb));
+        if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 3), sp));
         if (pending_L.n_fixups) {
             hipEvent_t e1 = sync_event();
-            HIP_TRY(hipEventRecord(e1, sb));
+            HIP_TRY(hipEventRecord(e1, sp));
             HIP_TRY(hipStreamWaitEvent(sd, e1, 0));
             used_sd = true;
             prc2 = H2E_LAUNCH((int)pending_L.field_pair, 4, &pending_L, J.d_inst, n_instances, ctx->d_fc[pending_L.field_pair], sd);
@@ -2228,9 +2238,16 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             // a small expansion (the MSM tail: 763 waves) queues behind the big one on the expansion stream: beside it on
             // the side stream it and its fix-up slow the big one down by more than they take alone; its fix-up follows it
             // in its stream: the fix-up stream still holds the big expansion's second fix-up
-            bool small_x = (uint64_t)L.n_sub * L.n_strands * n_instances < (1u << 18);
+            bool small_x = (uint64_t)L.n_sub * L.n_strands * n_instances < ctx->small_x_lanes;
             hipStream_t sx = (small_x && !join && sc && (ctx->sched & 2u)) ? sc : sb;
             if (sx == sc) used_se = true;
+            if (small_x && !join && (ctx->sched & 4u)) {
+                // pipelined: the shared expansion stream only carries the big expansions - the small ones (latency-bound: a few
+                // hundred waves and their inverse fix-ups) run beside them on their own stream instead of between them
+                if (!ctx->small_stream) HIP_TRY(make_stream(ctx, &ctx->small_stream, ctx->prio_expand, 0));
+                sx = ctx->small_stream;
+                used_small = true;
+            }
             fixup_in_stream = small_x;
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, sa));
@@ -2302,6 +2319,11 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             hipEvent_t e3 = sync_event();
             HIP_TRY(hipEventRecord(e3, se));
             HIP_TRY(hipStreamWaitEvent(sd, e3, 0));
+        }
+        if (used_small) {
+            hipEvent_t e4 = sync_event();
+            HIP_TRY(hipEventRecord(e4, ctx->small_stream));
+            HIP_TRY(hipStreamWaitEvent(sd, e4, 0));
         }
         (void)used_sd;
         HIP_TRY(hipEventRecord(J.done, sd));

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "modinv62.h"
 
 typedef uint64_t u64;
 typedef uint32_t u32;
@@ -281,10 +282,26 @@ WI_INLINE void wd_barrett_divrem(const Wd<XW>& X, const Wd<MW>& m, const Wd<QW>&
 // Returns 0 for a == 0 (Field::invert() -> None, mapped to zero by the callers exactly as the
 // reference does: base_chip.rs:301, integer_chip.rs:524-527).
 template <int N>
+WI_INLINE Wd<N> wd_inv_mod_euclid(const Wd<N>& a, const Wd<N>& p);
+// Division steps in 62-bit batches (modinv62.h): the same instruction sequence in every lane, ~10 x cheaper than the
+// binary extended Euclid below (which stays for widths modinv62 is not instantiated for).  A called function: its
+// ~25 k instructions exist once per kernel, not once per call site.
+template <int N>
+__device__ __attribute__((noinline)) Wd<N> wd_inv_mod_divsteps(Wd<N> a, Wd<N> p) {
+    Wd<N> r;
+    modinv62::inv<N>(a.v, p.v, r.v);
+    return r;
+}
+template <int N>
 WI_INLINE Wd<N> wd_inv_mod(const Wd<N>& a, const Wd<N>& p) {
 #ifdef H2E_EXPERIMENT_NO_INV
     return a;
 #endif
+    if constexpr (N == 4 || N == 6) return wd_inv_mod_divsteps<N>(a, p);
+    else return wd_inv_mod_euclid<N>(a, p);
+}
+template <int N>
+WI_INLINE Wd<N> wd_inv_mod_euclid(const Wd<N>& a, const Wd<N>& p) {
     if (wd_is_zero<N>(a)) return wd_zero<N>();
     Wd<N> u = a, v = p;
     Wd<N> x1 = wd_from_u64<N>(1), x2 = wd_zero<N>();
