@@ -145,25 +145,37 @@ template <int N>
 WI_INLINE u32 limb32(const Wd<N>& a, int k) {
     return (k & 1) ? (u32)(a.v[k >> 1] >> 32) : (u32)a.v[k >> 1];
 }
-// full product: schoolbook over 32-bit limbs; every step `(u64)a*b + acc` is one v_mad_u64_u32
+// Column accumulator of the product-scanning multiplications: 96 bits (lo64 + a carry word); one partial product is
+// one v_mad_u64_u32 into the low 64 bits + one add-with-carry into the third word.  (The operand-scanning form
+// `s = a * b + t[j] + c` costs the compiler as many instructions again for zero-extending and re-pairing its 32-bit
+// carries.)
+struct WdAcc {
+    u64 lo;
+    u32 hi;
+};
+WI_INLINE void wd_mac(WdAcc& A, u32 a, u32 b) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(A.lo), "+v"(A.hi) : "v"(a), "v"(b) : "vcc");
+}
+WI_INLINE u32 wd_acc_shift(WdAcc& A) {   // take the column's 32 bits, move on to the next column
+    u32 r = (u32)A.lo;
+    A.lo = (A.lo >> 32) | ((u64)A.hi << 32);
+    A.hi = 0;
+    return r;
+}
+// full product: product scanning over 32-bit limbs
 template <int NA, int NB>
 WI_INLINE Wd<NA + NB> wd_mul(const Wd<NA>& a, const Wd<NB>& b) {
     constexpr int LA = 2 * NA, LB = 2 * NB;
     u32 t[LA + LB];
+    WdAcc A{0, 0};
 #pragma unroll
-    for (int i = 0; i < LA + LB; i++) t[i] = 0;
+    for (int k = 0; k < LA + LB - 1; k++) {
 #pragma unroll
-    for (int i = 0; i < LA; i++) {
-        u32 ai = limb32<NA>(a, i);
-        u64 c = 0;
-#pragma unroll
-        for (int j = 0; j < LB; j++) {
-            u64 s = (u64)ai * limb32<NB>(b, j) + t[i + j] + c;
-            t[i + j] = (u32)s;
-            c = s >> 32;
-        }
-        t[i + LB] = (u32)c;
+        for (int i = 0; i < LA; i++)
+            if (i <= k && k - i < LB) wd_mac(A, limb32<NA>(a, i), limb32<NB>(b, k - i));
+        t[k] = wd_acc_shift(A);
     }
+    t[LA + LB - 1] = (u32)A.lo;
     Wd<NA + NB> r;
 #pragma unroll
     for (int i = 0; i < NA + NB; i++) r.v[i] = (u64)t[2 * i] | ((u64)t[2 * i + 1] << 32);
@@ -174,23 +186,13 @@ template <int NR, int NA, int NB>
 WI_INLINE Wd<NR> wd_mul_lo(const Wd<NA>& a, const Wd<NB>& b) {
     constexpr int LA = 2 * NA, LB = 2 * NB, LR = 2 * NR;
     u32 t[LR];
+    WdAcc A{0, 0};
 #pragma unroll
-    for (int i = 0; i < LR; i++) t[i] = 0;
+    for (int k = 0; k < LR; k++) {
 #pragma unroll
-    for (int i = 0; i < LA; i++) {
-        if (i < LR) {
-            u32 ai = limb32<NA>(a, i);
-            u64 c = 0;
-#pragma unroll
-            for (int j = 0; j < LB; j++) {
-                if (i + j < LR) {
-                    u64 s = (u64)ai * limb32<NB>(b, j) + t[i + j] + c;
-                    t[i + j] = (u32)s;
-                    c = s >> 32;
-                }
-            }
-            if (i + LB < LR) t[i + LB] = (u32)c;
-        }
+        for (int i = 0; i < LA; i++)
+            if (i <= k && k - i < LB) wd_mac(A, limb32<NA>(a, i), limb32<NB>(b, k - i));
+        t[k] = wd_acc_shift(A);
     }
     Wd<NR> r;
 #pragma unroll
