@@ -707,7 +707,10 @@ struct h2e_program {
                     for (size_t k = 0; k < lvl_steps.size(); k++) {
                         if (k % NW == 0) new_round();
                         size_t rd = steps.size() / NW - 1;
-                        steps[rd * NW + k % NW] = lvl_steps[k];
+                        // Most rounds hold a single step.  Wave w of a workgroup sits on SIMD w of its CU: if that step always
+                        // went to wave 0, SIMD 0 would carry the chains of every instance on the CU and the others idle -
+                        // the steps rotate over the waves from round to round.
+                        steps[rd * NW + (k % NW + rd) % NW] = lvl_steps[k];
                         for (uint32_t pos : lvl_steps[k]) step_of[pos] = (uint32_t)rd;
                     }
                 }
