@@ -220,12 +220,18 @@ def main():
     # The first process that touches the HBM of a freshly booted box pays for it: without this throw-away allocate / fill / free
     # of (almost) the whole memory the steps of that process run 2 x slower than those of any later one (47 vs 24 ms, measured
     # with two bench runs in one gpurun call; exp/first_touch.py).  0.3 s, untimed, no effect on later processes.
-    free_b, _total = torch.cuda.mem_get_info(local_rank)
-    scratch = torch.empty((int(free_b * 0.92) // 8,), dtype=torch.int64, device=dev)
-    scratch.fill_(-1)
-    torch.cuda.synchronize()
-    del scratch
-    torch.cuda.empty_cache()
+    # (Skipped when ranks share a device - `--device`, the one-GPU test of the N > 1 path - where two ranks asking for "all free
+    # memory" at the same moment would race; a failed attempt is not an error either.)
+    if args.device is None or world == 1:
+        try:
+            free_b, _total = torch.cuda.mem_get_info(local_rank)
+            scratch = torch.empty((int(free_b * 0.92) // 8,), dtype=torch.int64, device=dev)
+            scratch.fill_(-1)
+            torch.cuda.synchronize()
+            del scratch
+        except RuntimeError as e:   # out of memory: somebody else is using the device
+            print(f"bench.py: first-touch pass skipped ({str(e).splitlines()[0]})", file=sys.stderr)
+        torch.cuda.empty_cache()
     bufs = [eng.alloc(prog, units) for _ in range(ring)]   # (base, range, select, status) per ring slot
     out_refs = prog.outputs()
     L = 3

@@ -1064,6 +1064,7 @@ __global__ void __launch_bounds__(64, H2E_X_WAVES) h2e_run_tape(H2ELaunch L, con
     extern __shared__ u64 xcache_dyn[];   // [3][2 L + 4][64] words when the result cache is on (H2ELaunch.rel_refs bit 2)
     c.active = active;
     c.xc = (L.rel_refs & 4) ? xcache_dyn : nullptr;
+    if (L.rel_refs & 8) __builtin_amdgcn_s_setprio(3);   // the expansion's waves at the chain kernels' priority (g_tune[1] bit 1)
     {
         for (u32 i0 = op_lo; i0 < op_hi; i0 += 64) {
             load_chunk(&chunk, L.tape, i0, op_hi);
@@ -1773,7 +1774,9 @@ __global__ void __launch_bounds__(64 * H2E_LEVEL_WAVES) h2e_replay_levels(H2ELau
                 __threadfence();
             }
         } else if ((h.w[0] & 0xffu) != H2E_V_NOP) {
+#ifndef H2E_EXP_LEVEL_NOP   // (timing experiment: rounds without their ops)
             exec_lop<FP>(lv, c, opc, h, L.lrefs);
+#endif
         }
         __syncthreads();   // the round's values are in their slots
     }
@@ -2789,7 +2792,9 @@ extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances,
 // with the batch-interleaved layout an operand re-read is a coalesced 1 KB load and the cache buys the expansion
 // nothing (11.6 vs 11.7 ms), while the 15 KB of LDS per workgroup it held kept the value chain's replay workgroups
 // (95-135 KB of LDS each) of the next run from sharing CUs with the expansion: pipelined step 24.0 -> 20.9 ms.
-static int g_tune[3] = {0, 0, 0};
+// [1] bit 1: the expansion's waves run at the chain kernels' priority (s_setprio 3) - the shared expansion stream is the
+// pipelined step's busiest resource: 16.17 -> 16.02 ms, window expansion 11.85 -> 11.4 ms; on by default.
+static int g_tune[3] = {0, 2, 0};
 extern "C" long long h2e_engine_scan_fallbacks(void) {
     unsigned long long n = 0;
     if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_scan_fallbacks), sizeof(n)) != hipSuccess) return -1;
@@ -2812,9 +2817,10 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
     u32 n_sub = launch->n_sub > 1 ? launch->n_sub : 1;
     dim3 block(64), grid1(blocks_per_sub), grid(blocks_per_sub * n_sub);
     const InstanceDesc* inst = (const InstanceDesc*)instances;
-    const bool xcache_on = g_tune[1] != 0;
+    const bool xcache_on = (g_tune[1] & 1) != 0;
     H2ELaunch launch_x = *launch;
     if (xcache_on) launch_x.rel_refs |= 4u;
+    if (g_tune[1] & 2) launch_x.rel_refs |= 8u;
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
     if ((mode & 1) && launch->lrecs) {                                                                                         \
         hipLaunchKernelGGL(h2e_replay_levels<FP>, dim3(n_instances * launch->n_strands), dim3(64 * H2E_LEVEL_WAVES),          \

@@ -799,9 +799,37 @@ struct h2e_program {
                             h_lrecs.push_back(h);
                         }
                     }
-                    if (dbg_env("H2E_DUMP_TAPE"))
+                    if (dbg_env("H2E_DUMP_TAPE")) {
                         fprintf(stderr, "segment %zu: level-parallel replay: %zu alive ops, depth %u, %zu rounds of %zu waves, %d value slots\n", si,
                                 alive.size(), depth, n_rounds, NW, n_slots);
+                        // rounds by their most expensive op kind, and how many of them read an operand from global cells
+                        std::map<uint32_t, std::pair<size_t, size_t>> by_vop;
+                        size_t global_rounds = 0, global_operands = 0;
+                        for (size_t rd = 0; rd < n_rounds; rd++) {
+                            uint32_t worst = 0;
+                            bool g = false;
+                            for (size_t w = 0; w < NW; w++)
+                                for (uint32_t pos : steps[rd * NW + w]) {
+                                    uint32_t vop = vop_of(pos);
+                                    auto rank = [](uint32_t v) { return v == H2E_V_FULL ? 100u : v == H2E_V_DIV ? 90u : v == H2E_V_MUL ? 80u : v == H2E_V_REDUCE ? 70u : 10u; };
+                                    if (rank(vop) > rank(worst) || worst == 0) worst = vop;
+                                    Opd o[3];
+                                    int n = vop == H2E_V_FULL ? 0 : operands(ops[alive[pos]], o);
+                                    for (int q = 0; q < n; q++)
+                                        if (dec[pos].val[q] < 0) {
+                                            g = true;
+                                            global_operands++;
+                                        }
+                                }
+                            by_vop[worst].first++;
+                            if (g) {
+                                by_vop[worst].second++;
+                                global_rounds++;
+                            }
+                        }
+                        for (auto& kv : by_vop) fprintf(stderr, "   rounds led by vop %u: %zu (%zu with a global operand)\n", kv.first, kv.second.first, kv.second.second);
+                        fprintf(stderr, "   %zu rounds with global operands, %zu global operands in all\n", global_rounds, global_operands);
+                    }
                 }
             }
         }
