@@ -1877,7 +1877,10 @@ WI_INLINE Mont<4> mont_n(const H2EFieldConsts* fc) {
 // Fix-up of the is_zero inverse witnesses (base_chip.rs:298-321: b = a^-1 or 0), batched with Montgomery's
 // trick: one lane owns FIXUP_K consecutive cells of one strand's list; the destination cells themselves hold
 // the running prefix products between the forward and the backward pass.
-static constexpr int FIXUP_K = 64;
+#ifndef H2E_FIXUP_K
+#define H2E_FIXUP_K 64
+#endif
+static constexpr int FIXUP_K = H2E_FIXUP_K;
 __global__ void __launch_bounds__(64) h2e_fixup_inverses(H2ELaunch L, const InstanceDesc* inst, u32 n_instances,
                                                          const H2EFieldConsts* fc) {
     u32 chunks = (L.n_fixups + FIXUP_K - 1) / FIXUP_K;
@@ -2393,7 +2396,10 @@ __global__ void __launch_bounds__(64) h2e_select(H2EPreKernel K, const u32* args
 
 // lambda = num / den for a run of hint slots: Montgomery's trick over HINT_K consecutive slots per lane, the
 // hint cells hold the prefix products between the two passes; output canonical (what assign_w(c) expects).
-static constexpr int HINT_K = 32;
+#ifndef H2E_HINT_K
+#define H2E_HINT_K 32
+#endif
+static constexpr int HINT_K = H2E_HINT_K;
 template <class FP>
 __global__ void __launch_bounds__(64) h2e_finalize_hints(u32 hint_base, u32 n_hints, const InstanceDesc* inst,
                                                          u32 n_instances, const H2EFieldConsts* fc) {
@@ -2432,7 +2438,10 @@ __global__ void __launch_bounds__(64) h2e_finalize_hints(u32 hint_base, u32 n_hi
 // and the Jacobian result (X, Y, Z), Z being lambda's denominator - one batch inversion per ECC_CH ops gives every
 // affine intermediate point, and from those the canonical value of every mul-like result of the op.  Parallel over
 // (instance, chain, chunk): the chain itself was only walked by the predictor.
-static constexpr int ECC_CH = 32;
+#ifndef H2E_ECC_CH
+#define H2E_ECC_CH 32
+#endif
+static constexpr int ECC_CH = H2E_ECC_CH;
 template <class FP>
 __global__ void __launch_bounds__(64) h2e_finalize_ecc(H2EPreKernel K, const InstanceDesc* inst, u32 n_instances,
                                                        const H2EFieldConsts* fc) {
