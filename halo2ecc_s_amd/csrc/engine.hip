@@ -2468,24 +2468,31 @@ __global__ void __launch_bounds__(64) h2e_finalize_ecc(H2EPreKernel K, const Ins
         ws_store<NW>(r + (e == lo - 1 ? 5 : 4) * ws, acc);
         if (!wd_is_zero<NW>(den)) acc = mm(M, acc, den);
     }
-    Wd<NW> ainv = mont_inv<NW>(M, acc);
-    Wd<NW> xn = wd_zero<NW>(), yn = xn, ln = xn;   // op e + 1: affine result and lambda
+    // Backward pass in the *plain* domain: the running inverse is a plain value (not in Montgomery form), and a product
+    // of a plain and a Montgomery-form factor is plain - so the affine coordinates, lambda and the derived values come
+    // out canonical as they are, without one conversion per stored hint.  Only lambda and 1 / Z are also needed in
+    // Montgomery form (as the second factor of lambda^2, (x_a - x_c) lambda, 1 / Z^2).  10 multiplications per op (was 14).
+    Wd<NW> ainv = wd_inv_mod<NW>(from_mont<NW>(M, acc), M.p);
+    const bool need_y = ((K.used_slots >> H2E_HINT_YC) | (K.used_slots >> H2E_HINT_AUX1)) & 1u;
+    Wd<NW> xn = wd_zero<NW>(), yn = xn, ln = xn, ln_m = xn;   // op e + 1: affine result and lambda (plain; lambda also Montgomery)
     for (int e = hi - 1; e >= lo - 1; e--) {
         const u64* r = rec(e);
         Wd<NW> num = ws_load<NW>(r), den = ws_load<NW>(r + ws);
-        Wd<NW> X = ws_load<NW>(r + 2 * ws), Y = ws_load<NW>(r + 3 * ws);
+        Wd<NW> X = ws_load<NW>(r + 2 * ws), Y = need_y ? ws_load<NW>(r + 3 * ws) : wd_zero<NW>();
         Wd<NW> dinv = wd_zero<NW>();
         if (!wd_is_zero<NW>(den)) {
             dinv = mm(M, ainv, ws_load<NW>(r + (e == lo - 1 ? 5 : 4) * ws));
             ainv = mm(M, ainv, den);
         }
-        Wd<NW> zi2 = mm(M, dinv, dinv);
-        Wd<NW> xe = mm(M, X, zi2), ye = mm(M, Y, mm(M, zi2, dinv)), le = mm(M, num, dinv);
+        Wd<NW> dinv_m = mm(M, dinv, M.r2);
+        Wd<NW> zi2 = mm(M, dinv, dinv_m);
+        Wd<NW> xe = mm(M, X, zi2), ye = need_y ? mm(M, Y, mm(M, zi2, dinv_m)) : wd_zero<NW>();
+        Wd<NW> le = mm(M, num, dinv), le_m = mm(M, num, dinv_m);
         if (e < hi - 1) {
             // op k = e + 1: c = (xn, yn), lambda = ln, prev = (xe, ye)
             u32 k = (u32)(e + 1);
             u32 kind = (K.pattern >> (2 * (k % K.pattern_len))) & 3u;
-            Wd<NW> l2 = mm(M, ln, ln);
+            Wd<NW> l2 = mm(M, ln, ln_m);
             Wd<NW> xa, aux0 = wd_zero<NW>(), aux1 = wd_zero<NW>();
             if (kind == H2E_ECC_ADD_EXT_PREV) {
                 xa = mont_sub<NW>(M, mont_sub<NW>(M, l2, xn), xe);      // x_a = lambda^2 - x_c - x_b
@@ -2496,16 +2503,13 @@ __global__ void __launch_bounds__(64) h2e_finalize_ecc(H2EPreKernel K, const Ins
                 aux0 = mont_sub<NW>(M, xa, xb);
             } else {
                 xa = xe;
-                if ((K.used_slots >> H2E_HINT_AUX0) & 1u) aux0 = mm(M, xa, xa);   // x_a^2
+                if ((K.used_slots >> H2E_HINT_AUX0) & 1u) aux0 = mm(M, xa, mm(M, xa, M.r2));   // x_a^2
                 aux1 = mont_dbl<NW>(M, ye);                             // 2 y_a
             }
             Wd<NW> t2 = mont_sub<NW>(M, xa, xn);
-            Wd<NW> t2l = mm(M, t2, ln);
-            Wd<NW> one = wd_from_u64<NW>(1);
-            auto put = [&](u32 slot, const Wd<NW>& vm) {
-                if (!((K.used_slots >> slot) & 1u)) return;   // nobody reads it
-                Wd<NW> cv = mm(M, vm, one);   // out of the Montgomery domain: canonical
-                ws_store<NW>(hint((int)k, slot), cv);
+            Wd<NW> t2l = mm(M, t2, ln_m);
+            auto put = [&](u32 slot, const Wd<NW>& v) {
+                if ((K.used_slots >> slot) & 1u) ws_store<NW>(hint((int)k, slot), v);   // (a slot nobody reads is not written)
             };
             put(H2E_HINT_LAMBDA, ln);
             put(H2E_HINT_LAMBDA2, l2);
@@ -2519,6 +2523,7 @@ __global__ void __launch_bounds__(64) h2e_finalize_ecc(H2EPreKernel K, const Ins
         xn = xe;
         yn = ye;
         ln = le;
+        ln_m = le_m;
     }
 }
 
