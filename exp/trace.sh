@@ -5,8 +5,8 @@ shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 bench.py --no-cpu-baseline --traffic off --steps 6 --warmup 2 "$@" > $OUT/stats.log 2>&1
-python exp/timeline.py $OUT/stats/run_kernel_trace.csv 4 > $OUT/timeline.txt
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 bench.py --no-cpu-baseline --traffic off --steps ${STEPS:-6} --warmup ${WARM:-2} "$@" > $OUT/stats.log 2>&1
+python exp/timeline.py $OUT/stats/run_kernel_trace.csv $(( (${STEPS:-6} + ${WARM:-2}) / 2 )) > $OUT/timeline.txt
 grep '"metric"' $OUT/stats.log | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
