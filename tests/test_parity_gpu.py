@@ -538,8 +538,12 @@ def test_msm_batch_64_tiles_full_size(engine, oracle):
     ins = np.stack([synth.msm_bn256_tile_inputs(n, tile=600 + k, cheap_points=True, with_expected=False)[0] for k in range(tiles)])
     d_in = engine.upload_inputs(prog, ins)
     arrs = engine.alloc(prog, tiles)
+    from halo2ecc_s_amd import engine as E
+    fallbacks = engine.get_stat(E.STAT_SCAN_FALLBACKS)
     engine.run(prog, d_in, *arrs)
     t.cuda.synchronize()
+    # 64 x 254 windows x 8 chunks + 64 x 254 tail windows with random blinding: the scan predictors never need their fallback
+    assert engine.get_stat(E.STAT_SCAN_FALLBACKS) == fallbacks, "scan predictor fell back on random inputs (a performance bug, not a correctness one)"
     refs = prog.outputs()
     Qm = synth.BN_Q
     exp = np.zeros((tiles, 3, 4), dtype=np.uint64)
