@@ -6,7 +6,6 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libh2e.so")
-SOURCES = ["engine.hip", "h2e_capi.cpp"]
 DEPS = ["tape.h", "wide_int.h", "modinv62.h", "hbig.hpp", "recorder.hpp", "recorder_ecc.hpp", "recorder_pairing.hpp",
         "pairing_constants.hpp", os.path.join("..", "..", "include", "h2e.h")]
 
@@ -19,15 +18,17 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
+    """engine.hip is compiled once per field pair (-DH2E_FP_ONLY=k: ~2 minutes each, side by side) + the C-ABI layer"""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     deps = [os.path.join(CSRC, d) for d in DEPS]
     objs = []
-    running = []   # the two translation units compile side by side (engine.hip alone takes ~2.5 min)
-    for src in SOURCES:
+    running = []
+    units = [("engine.hip", f"engine_fp{k}.o", [f"-DH2E_FP_ONLY={k}"]) for k in range(3)] + [("h2e_capi.cpp", "h2e_capi.o", [])]
+    for src, obj, defs in units:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        o = os.path.join(CSRC, obj)
         if force or _stale(o, [s] + deps):
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + defs + ["-c", s, "-o", o]
             if src.endswith(".cpp"):
                 cmd.insert(1, "-x")
                 cmd.insert(2, "hip")

@@ -16,6 +16,27 @@
 #include "wide_int.h"
 
 // ------------------------------------------------------------------------------------------------
+// Translation units.  The build compiles this file once per field pair (-DH2E_FP_ONLY=0|1|2, side by side: the
+// kernels of one pair are ~1.5 minutes of compile time, all three in one unit 5): unit k holds the templated kernels
+// of pair k behind h2e_engine_launch_fpK / h2e_engine_predict_fpK / ..., unit 0 also the kernels that do not depend on
+// the pair and the dispatchers under the plain names the C-ABI layer calls.  Without H2E_FP_ONLY everything is one unit.
+#ifndef H2E_FP_ONLY
+#define H2E_FP_ONLY -1
+#endif
+#define H2E_HAS_FP(id) (H2E_FP_ONLY < 0 || H2E_FP_ONLY == (id))
+#define H2E_COMMON_UNIT (H2E_FP_ONLY <= 0)
+#define H2E_CAT2(a, b) a##b
+#define H2E_CAT(a, b) H2E_CAT2(a, b)
+#if H2E_FP_ONLY >= 0
+#define H2E_UNIT(name) H2E_CAT(name##_fp, H2E_FP_ONLY)
+#else
+#define H2E_UNIT(name) name
+#endif
+// symbols with external linkage that every unit has its own copy of
+#define g_fc H2E_UNIT(g_fc)
+#define h2e_fixup_inverses H2E_UNIT(h2e_fixup_inverses)
+
+// ------------------------------------------------------------------------------------------------
 // field-pair traits (compile-time sizes; values come from H2EFieldConsts)
 struct FP_BN256_FQ {   // bn256 Fq over bn256 Fr
     static constexpr int ID = 0;
@@ -134,16 +155,9 @@ WI_INLINE Limb ld_limb(const LC& c, u32 ref) {  // values known to be < 2^128: t
     r.v[0] = a.x; r.v[1] = a.y;
     return r;
 }
-// one 16-byte half of a cell (H2E_NT_STORES: experiment - non-temporal stores for the advice cells)
-typedef unsigned long long h2e_ull2 __attribute__((ext_vector_type(2)));
-WI_INLINE void st16(u64* p, u64 x, u64 y) {
-#ifdef H2E_NT_STORES
-    h2e_ull2 v = {x, y};
-    __builtin_nontemporal_store(v, (h2e_ull2*)p);
-#else
-    *(ulonglong2*)p = make_ulonglong2(x, y);
-#endif
-}
+// one 16-byte half of a cell.  (Plain stores: non-temporal ones made the window expansion 9 % slower - its operand
+// re-reads then miss the L2.)
+WI_INLINE void st16(u64* p, u64 x, u64 y) { *(ulonglong2*)p = make_ulonglong2(x, y); }
 WI_INLINE void st_cell(u64* p, u32 hs, const Fe& v) {
     st16(p, v.v[0], v.v[1]);
     st16(p + hs, v.v[2], v.v[3]);
@@ -1774,9 +1788,7 @@ __global__ void __launch_bounds__(64 * H2E_LEVEL_WAVES) h2e_replay_levels(H2ELau
                 __threadfence();
             }
         } else if ((h.w[0] & 0xffu) != H2E_V_NOP) {
-#ifndef H2E_EXP_LEVEL_NOP   // (timing experiment: rounds without their ops)
-            exec_lop<FP>(lv, c, opc, h, L.lrefs);
-#endif
+            exec_lop<FP>(lv, c, opc, h, L.lrefs);   // (a round without its op costs 0.44 us; with it 3.0 us on average)
         }
         __syncthreads();   // the round's values are in their slots
     }
@@ -2527,6 +2539,7 @@ __global__ void __launch_bounds__(64) h2e_finalize_ecc(H2EPreKernel K, const Ins
     }
 }
 
+#if H2E_COMMON_UNIT   // kernels that do not depend on the field pair: unit 0 only
 // ------------------------------------------------------------------------------------------------
 // Hand-off (device half).  The batch-interleaved advice array [row][COLS][half][instance] of a run ->
 // one array per instance in the consumer's layout: row-major [instance][row][COLS][4 words] (the reference's
@@ -2590,14 +2603,16 @@ extern "C" int h2e_engine_export(uint32_t cols, int columns, int mont, const voi
     return (int)hipGetLastError();
 }
 
+#endif   // H2E_COMMON_UNIT
 // ------------------------------------------------------------------------------------------------
 // host-callable launcher (C linkage, used by the C-ABI layer in h2e_capi.cpp)
-extern "C" int h2e_engine_set_consts(int field_pair, const H2EFieldConsts* host) {
+extern "C" int H2E_UNIT(h2e_engine_set_consts)(int field_pair, const H2EFieldConsts* host) {
     if (field_pair < 0 || field_pair > 2) return -1;
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fc), host, sizeof(H2EFieldConsts), (size_t)field_pair * sizeof(H2EFieldConsts),
                                   hipMemcpyHostToDevice);
 }
 
+#if H2E_COMMON_UNIT
 // ------------------------------------------------------------------------------------------------
 // On-device consumer of a streaming job (SURVEY.md 8d cfg 3 / 8e): a 32-byte digest per instance of one region's
 // batch-interleaved advice array, so that tiles can be checked / gathered without their 1.2 GB leaving the GPU.
@@ -2800,6 +2815,7 @@ extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances,
     return (int)hipGetLastError();
 }
 
+#endif   // H2E_COMMON_UNIT
 // Tuning knobs (h2e_capi.cpp reads H2E_TUNE once, at h2e_ctx_create): [0] LDS bytes a small predictor grid reserves so
 // that no expansion wave shares its CU, [1] expansion result cache in LDS on / off, [2] extra dynamic LDS per expansion
 // workgroup (caps its waves per CU).  Defaults (profiles/r2_tune_sweep.txt): nothing reserved and no result cache -
@@ -2809,12 +2825,12 @@ extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances,
 // [1] bit 1: the expansion's waves run at the chain kernels' priority (s_setprio 3) - the shared expansion stream is the
 // pipelined step's busiest resource: 16.17 -> 16.02 ms, window expansion 11.85 -> 11.4 ms; on by default.
 static int g_tune[3] = {0, 2, 0};
-extern "C" long long h2e_engine_scan_fallbacks(void) {
+extern "C" long long H2E_UNIT(h2e_engine_scan_fallbacks)(void) {
     unsigned long long n = 0;
     if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_scan_fallbacks), sizeof(n)) != hipSuccess) return -1;
     return (long long)n;
 }
-extern "C" void h2e_engine_set_tuning(int key, int value) {
+extern "C" void H2E_UNIT(h2e_engine_set_tuning)(int key, int value) {
     if (key >= 0 && key < 3) g_tune[key] = value;
     if (key == 3) {
         u32 m = (u32)value;
@@ -2823,7 +2839,7 @@ extern "C" void h2e_engine_set_tuning(int key, int value) {
 }
 
 // mode: 1 = values-only replay (whole tape per lane), 2 = full expansion (sub-ranges if any), 4 = inverse fix-up
-extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
+extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
                                  uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream) {
     u32 per_sub = n_instances * launch->n_strands;
     if (per_sub == 0 || launch->n_ops == 0) return 0;
@@ -2855,9 +2871,15 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
                            (xcache_on ? (size_t)3 * (2 * FP::L + 4) * 64 * 8 : 0) + (grid.x > 4096 ? (size_t)g_tune[2] : 0),   \
                            stream, launch_x, inst, n_instances, fc_dev);
     switch (field_pair) {
+#if H2E_HAS_FP(0)
         case 0: { H2E_LAUNCH_FP(FP_BN256_FQ) } break;
+#endif
+#if H2E_HAS_FP(1)
         case 1: { H2E_LAUNCH_FP(FP_BLS_FQ) } break;
+#endif
+#if H2E_HAS_FP(2)
         case 2: { H2E_LAUNCH_FP(FP_BLS_FR) } break;
+#endif
         default: return -1;
     }
 #undef H2E_LAUNCH_FP
@@ -2874,7 +2896,7 @@ extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* laun
 }
 
 // phase: 1 = the predictor chain, 2 = its finalize (batch inversion -> hints), 3 = both
-extern "C" int h2e_engine_predict(int field_pair, int phase, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,
+extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,
                                   const uint32_t* aux_dev, const void* instances, uint32_t n_instances,
                                   const H2EFieldConsts* fc_dev, hipStream_t stream) {
     const InstanceDesc* inst = (const InstanceDesc*)instances;
@@ -2913,11 +2935,70 @@ extern "C" int h2e_engine_predict(int field_pair, int phase, const H2EPreKernel*
     if ((phase & 2) && !k->ecc_ops)                                                                                                 \
         hipLaunchKernelGGL(h2e_finalize_hints<FP>, grid2, block, 0, stream, k->hint_base, n_hints, inst, n_instances, fc_dev);
     switch (field_pair) {
+#if H2E_HAS_FP(0)
         case 0: { H2E_PREDICT_FP(FP_BN256_FQ) } break;
+#endif
+#if H2E_HAS_FP(1)
         case 1: { H2E_PREDICT_FP(FP_BLS_FQ) } break;
+#endif
+#if H2E_HAS_FP(2)
         case 2: { H2E_PREDICT_FP(FP_BLS_FR) } break;
+#endif
         default: return -1;
     }
 #undef H2E_PREDICT_FP
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Dispatchers of a split build (unit 0): the plain names the C-ABI layer calls -> the unit of the field pair
+#if H2E_FP_ONLY == 0
+extern "C" int h2e_engine_set_consts_fp1(int, const H2EFieldConsts*);
+extern "C" int h2e_engine_set_consts_fp2(int, const H2EFieldConsts*);
+extern "C" long long h2e_engine_scan_fallbacks_fp1(void);
+extern "C" long long h2e_engine_scan_fallbacks_fp2(void);
+extern "C" void h2e_engine_set_tuning_fp1(int, int);
+extern "C" void h2e_engine_set_tuning_fp2(int, int);
+extern "C" int h2e_engine_launch_fp1(int, int, const H2ELaunch*, const void*, uint32_t, const H2EFieldConsts*, hipStream_t);
+extern "C" int h2e_engine_launch_fp2(int, int, const H2ELaunch*, const void*, uint32_t, const H2EFieldConsts*, hipStream_t);
+extern "C" int h2e_engine_predict_fp1(int, int, const H2EPreKernel*, const uint32_t*, const uint32_t*, const uint32_t*, const void*, uint32_t,
+                                      const H2EFieldConsts*, hipStream_t);
+extern "C" int h2e_engine_predict_fp2(int, int, const H2EPreKernel*, const uint32_t*, const uint32_t*, const uint32_t*, const void*, uint32_t,
+                                      const H2EFieldConsts*, hipStream_t);
+extern "C" int h2e_engine_set_consts(int field_pair, const H2EFieldConsts* host) {
+    switch (field_pair) {   // a unit's kernels only read their own pair's constants
+        case 0: return h2e_engine_set_consts_fp0(field_pair, host);
+        case 1: return h2e_engine_set_consts_fp1(field_pair, host);
+        case 2: return h2e_engine_set_consts_fp2(field_pair, host);
+        default: return -1;
+    }
+}
+extern "C" long long h2e_engine_scan_fallbacks(void) {
+    long long a = h2e_engine_scan_fallbacks_fp0(), b = h2e_engine_scan_fallbacks_fp1(), c = h2e_engine_scan_fallbacks_fp2();
+    return (a < 0 || b < 0 || c < 0) ? -1 : a + b + c;
+}
+extern "C" void h2e_engine_set_tuning(int key, int value) {
+    h2e_engine_set_tuning_fp0(key, value);
+    h2e_engine_set_tuning_fp1(key, value);
+    h2e_engine_set_tuning_fp2(key, value);
+}
+extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances, uint32_t n_instances,
+                                 const H2EFieldConsts* fc_dev, hipStream_t stream) {
+    switch (field_pair) {
+        case 0: return h2e_engine_launch_fp0(field_pair, mode, launch, instances, n_instances, fc_dev, stream);
+        case 1: return h2e_engine_launch_fp1(field_pair, mode, launch, instances, n_instances, fc_dev, stream);
+        case 2: return h2e_engine_launch_fp2(field_pair, mode, launch, instances, n_instances, fc_dev, stream);
+        default: return -1;
+    }
+}
+extern "C" int h2e_engine_predict(int field_pair, int phase, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,
+                                  const uint32_t* aux_dev, const void* instances, uint32_t n_instances, const H2EFieldConsts* fc_dev,
+                                  hipStream_t stream) {
+    switch (field_pair) {
+        case 0: return h2e_engine_predict_fp0(field_pair, phase, k, args_dev, params_dev, aux_dev, instances, n_instances, fc_dev, stream);
+        case 1: return h2e_engine_predict_fp1(field_pair, phase, k, args_dev, params_dev, aux_dev, instances, n_instances, fc_dev, stream);
+        case 2: return h2e_engine_predict_fp2(field_pair, phase, k, args_dev, params_dev, aux_dev, instances, n_instances, fc_dev, stream);
+        default: return -1;
+    }
+}
+#endif
