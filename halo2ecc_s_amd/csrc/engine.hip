@@ -1728,8 +1728,13 @@ WI_INLINE void exec_lop(const LVals<FP>& lv, const LC& c, u32 opc, const VHdr& h
 
 template <class FP>
 __global__ void __launch_bounds__(64 * H2E_LEVEL_WAVES) h2e_replay_levels(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
-    u32 instance = blockIdx.x / L.n_strands, strand = blockIdx.x % L.n_strands;
-    u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // l_pair: the workgroup replays two (instance, strand) units - lanes 0-31 of every wave the first, lanes 32-63 the
+    // second, each with its own value slots; a unit past the end repeats the last one (same values to the same cells)
+    u32 lane = threadIdx.x & 63u;
+    u32 half = L.l_pair ? (lane >> 5) : 0u;
+    u32 unit = min(blockIdx.x * (L.l_pair ? 2u : 1u) + half, n_instances * L.n_strands - 1u);
+    u32 instance = unit / L.n_strands, strand = unit % L.n_strands;
+    const u32 lead_mask = L.l_pair ? 31u : 63u;   // the lane that runs a tape op (V_FULL) for its unit
     InstanceDesc d = inst[instance];
     LC c;
     c.base = d.base;
@@ -1755,7 +1760,7 @@ __global__ void __launch_bounds__(64 * H2E_LEVEL_WAVES) h2e_replay_levels(H2ELau
     c.hs = 2 * n_instances;
     extern __shared__ ulonglong2 l_dyn[];
     LVals<FP> lv;
-    lv.v = (u64*)l_dyn;
+    lv.v = (u64*)l_dyn + (size_t)half * L.l_slots * LVals<FP>::W;
     c.active = true;
     __builtin_amdgcn_s_setprio(3);
     // rounds: every wave runs one step (64 records, one opcode) of the current level, then a barrier; the waves share
@@ -1782,7 +1787,7 @@ __global__ void __launch_bounds__(64 * H2E_LEVEL_WAVES) h2e_replay_levels(H2ELau
             if (opc == H2E_V_FULL) {
                 H2EOp op = L.tape[__builtin_amdgcn_readfirstlane(h.w[1])];
                 op.opcode = (uint16_t)__builtin_amdgcn_readfirstlane(op.opcode);
-                c.active = lane == 0;
+                c.active = (lane & lead_mask) == 0;
                 exec_op<FP, false>(c, op);
                 c.active = true;
                 __threadfence();
@@ -2853,8 +2858,9 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
     if (g_tune[1] & 2) launch_x.rel_refs |= 8u;
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
     if ((mode & 1) && launch->lrecs) {                                                                                         \
-        hipLaunchKernelGGL(h2e_replay_levels<FP>, dim3(n_instances * launch->n_strands), dim3(64 * H2E_LEVEL_WAVES),          \
-                           (size_t)launch->l_slots * LVals<FP>::W * 8, stream, *launch, inst, n_instances);                   \
+        hipLaunchKernelGGL(h2e_replay_levels<FP>, dim3((n_instances * launch->n_strands + (launch->l_pair ? 1 : 0)) / (launch->l_pair ? 2 : 1)), \
+                           dim3(64 * H2E_LEVEL_WAVES), (size_t)launch->l_slots * LVals<FP>::W * 8 * (launch->l_pair ? 2 : 1), stream, \
+                           *launch, inst, n_instances);                                                                       \
         mode &= ~1;                                                                                                            \
     }                                                                                                                          \
     if ((mode & 1) && launch->vtape &&                                                                                         \

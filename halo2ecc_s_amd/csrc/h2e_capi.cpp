@@ -127,7 +127,7 @@ struct h2e_program {
     // level-parallel replay (segments whose dependency graph is much shallower than it is long: the pairings)
     std::vector<H2EVRec> h_lrecs;               // 64 records per step (lane l of a step runs record 64 * step + l)
     std::vector<uint32_t> h_lrefs;              // cell refs of global integer operands
-    std::vector<uint32_t> seg_l_begin, seg_l_steps, seg_l_slots;
+    std::vector<uint32_t> seg_l_begin, seg_l_steps, seg_l_slots, seg_l_pair;
     H2EVRec* d_lrecs = nullptr;
     uint32_t* d_lrefs = nullptr;
     int64_t tail_from = -1;   // first segment of the program's serial tail (runs on the job slot's side stream), -1: none
@@ -372,6 +372,7 @@ struct h2e_program {
         seg_l_begin.assign(r.segments.size(), 0);
         seg_l_steps.assign(r.segments.size(), 0);
         seg_l_slots.assign(r.segments.size(), 0);
+        seg_l_pair.assign(r.segments.size(), 0);
         for (auto& c : cs) compile_replay(c.sg, c.ops, c.n_ops, c.first, c.last, [&](uint32_t region, uint32_t row) { return producer(c, region, row); });
     }
 
@@ -673,12 +674,25 @@ struct h2e_program {
                     if (level[a] != level[b]) return level[a] < level[b];
                     return vop_of(a) < vop_of(b);
                 });
+                const size_t NW = H2E_LEVEL_WAVES;
                 std::vector<uint32_t> step_of(alive.size(), 0);   // the *round* an op runs in (see below)
                 std::vector<std::vector<uint32_t>> steps;            // steps[NW * round + wave]: the ops one wave runs in a round
+                std::vector<int> lslot;
+                int n_slots = 0;
+                size_t n_rounds = 0;
+                int slot_cap = 0;
+                // Two instances per workgroup when their value slots fit side by side in a CU's LDS: a step then holds up to
+                // 32 ops, lanes 0-31 run them for one instance and lanes 32-63 for the other (levels are ~20 ops wide on
+                // average: one instance leaves two thirds of every wave instruction idle).  Otherwise one instance per
+                // workgroup and steps of 64.
+                bool paired = false;
+                auto schedule = [&](size_t step_ops, int cap) -> bool {
+                steps.clear();
+                std::fill(step_of.begin(), step_of.end(), 0u);
+                slot_cap = cap;
                 // rounds: H2E_LEVEL_WAVES waves share an instance's value slots; in a round each wave runs one step (up to 64
                 // ops of one opcode), all steps of a round come from the same level, a barrier separates rounds.  An op
                 // that goes through cells (V_FULL) is a round of its own.
-                const size_t NW = H2E_LEVEL_WAVES;
                 for (size_t i = 0; i < order.size();) {
                     uint32_t lv0 = level[order[i]];
                     std::vector<std::vector<uint32_t>> lvl_steps;
@@ -691,7 +705,7 @@ struct h2e_program {
                             continue;
                         }
                         size_t j = i + 1;
-                        while (j < order.size() && j - i < 64 && level[order[j]] == lv0 && vop_of(order[j]) == vop) j++;
+                        while (j < order.size() && j - i < step_ops && level[order[j]] == lv0 && vop_of(order[j]) == vop) j++;
                         lvl_steps.emplace_back(order.begin() + i, order.begin() + j);
                         i = j;
                     }
@@ -714,18 +728,18 @@ struct h2e_program {
                         for (uint32_t pos : lvl_steps[k]) step_of[pos] = (uint32_t)rd;
                     }
                 }
-                const size_t n_rounds = steps.size() / NW;
+                n_rounds = steps.size() / NW;
                 // value slots over the round order: a slot freed in round r is reusable from round r + 1
                 std::vector<uint32_t> last_step(2 * (size_t)n_ops, 0);
                 for (uint32_t pos = 0; pos < alive.size(); pos++)
                     for (int q = 0; q < 3; q++)
                         if (dec[pos].val[q] >= 0) last_step[dec[pos].val[q]] = std::max(last_step[dec[pos].val[q]], step_of[pos]);
-                std::vector<int> lslot(2 * (size_t)n_ops, -1);
+                lslot.assign(2 * (size_t)n_ops, -1);
                 std::vector<std::vector<int>> free_at(n_rounds + 1);
                 std::vector<int> free_list;
-                int n_slots = 0;
-                const int slot_cap = (int)((160u * 1024 - 30u * 1024) / ((2 * (uint32_t)L + 4) * 8));
-                for (size_t rd = 0; rd < n_rounds && eligible; rd++) {
+                n_slots = 0;
+                bool fits = true;
+                for (size_t rd = 0; rd < n_rounds && fits; rd++) {
                     for (int sl : free_at[rd]) free_list.push_back(sl);
                     for (size_t w = 0; w < NW; w++)
                         for (uint32_t pos : steps[rd * NW + w]) {
@@ -746,7 +760,14 @@ struct h2e_program {
                                 free_at[std::min<size_t>(last_step[v] + 1, n_rounds)].push_back(sl);
                             }
                         }
-                    if (n_slots > slot_cap) eligible = false;
+                    if (n_slots > slot_cap) fits = false;
+                }
+                return fits;
+                };   // schedule
+                {
+                    const uint32_t slot_bytes = (2 * (uint32_t)L + 4) * 8;
+                    paired = schedule(32, (int)((160u * 1024 - 4u * 1024) / 2 / slot_bytes));
+                    if (!paired) eligible = schedule(64, (int)((160u * 1024 - 30u * 1024) / slot_bytes));
                 }
                 if (!eligible && dbg_env("H2E_DUMP_TAPE"))
                     fprintf(stderr, "segment %zu: level-parallel replay needs more than %d value slots (depth %u, %zu rounds)\n", si, slot_cap, depth, n_rounds);
@@ -754,12 +775,15 @@ struct h2e_program {
                     seg_l_begin[si] = (uint32_t)h_lrecs.size();
                     seg_l_steps[si] = (uint32_t)n_rounds;
                     seg_l_slots[si] = (uint32_t)std::max(1, n_slots);
+                    seg_l_pair[si] = paired ? 1u : 0u;
                     for (size_t sidx = 0; sidx < steps.size(); sidx++) {
                         auto& stp = steps[sidx];
                         // the other waves of a V_FULL round fence their stores before the barrier (lane 0 of their NOP step says so)
                         const auto& lead = steps[sidx / NW * NW];
                         bool full_round = !lead.empty() && vop_of(lead[0]) == H2E_V_FULL;
-                        for (size_t lane = 0; lane < 64; lane++) {
+                        const size_t step_lanes = paired ? 32 : 64;
+                        std::vector<H2EVRec> step_recs;
+                        for (size_t lane = 0; lane < step_lanes; lane++) {
                             H2EVRec h{{H2E_V_NOP | ((full_round && lane == 0) ? (H2E_VFLAG_FENCE << 8) : 0u), 0, 0, 0, 0, 0, 0, 0}};
                             if (lane < stp.size()) {
                                 uint32_t pos = stp[lane], i = alive[pos];
@@ -796,12 +820,14 @@ struct h2e_program {
                                     }
                                 }
                             }
-                            h_lrecs.push_back(h);
+                            step_recs.push_back(h);
                         }
+                        // (paired: the second half of the wave runs the same records for the workgroup's other instance)
+                        for (size_t rep2 = 0; rep2 < 64 / step_lanes; rep2++) h_lrecs.insert(h_lrecs.end(), step_recs.begin(), step_recs.end());
                     }
                     if (dbg_env("H2E_DUMP_TAPE")) {
-                        fprintf(stderr, "segment %zu: level-parallel replay: %zu alive ops, depth %u, %zu rounds of %zu waves, %d value slots\n", si,
-                                alive.size(), depth, n_rounds, NW, n_slots);
+                        fprintf(stderr, "segment %zu: level-parallel replay: %zu alive ops, depth %u, %zu rounds of %zu waves, %d value slots, %s\n", si,
+                                alive.size(), depth, n_rounds, NW, n_slots, paired ? "two instances per workgroup" : "one instance per workgroup");
                         // rounds by their most expensive op kind, and how many of them read an operand from global cells
                         std::map<uint32_t, std::pair<size_t, size_t>> by_vop;
                         size_t global_rounds = 0, global_operands = 0;
@@ -2187,6 +2213,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         L.lrefs = p->d_lrefs;
         L.l_steps = levels ? p->seg_l_steps[si] : 0;
         L.l_slots = levels ? p->seg_l_slots[si] : 0;
+        L.l_pair = levels ? p->seg_l_pair[si] : 0;
         int lrc;
         auto launch_one = [&](int mode, const H2ELaunch& l, hipStream_t st) -> int {
             int rc2 = H2E_LAUNCH((int)l.field_pair, mode, &l, J.d_inst, n_instances, ctx->d_fc[l.field_pair], st);

@@ -179,6 +179,7 @@ typedef struct H2ELaunch {
     uint32_t l_steps, l_slots;
     uint32_t field_pair;          // the W field of this segment's integer ops (host side: which kernel instantiation)
     uint32_t slot_words;          // words per input slot (the program's: 6 for a bls12_381 Fq program even in its Fr segments)
+    uint32_t l_pair;              // level-parallel replay: 1 = two instances per workgroup (lanes 0-31 / 32-63), steps of 32 ops
 } H2ELaunch;
 
 // ---- compiled values-only replay ("V-tape") ----------------------------------------------------
