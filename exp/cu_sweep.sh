@@ -3,7 +3,7 @@
 show='import json,sys
 d=json.loads(sys.stdin.read()); r=d["roofline"]
 print(round(d["ms_per_step"],2), "chain", [round(x,1) for x in r["value_chain_ms"] if x>0.3], "x", [round(x,1) for x in r["expansion_ms"] if x>0.5])'
-for cfg in "0" "16,0,0" "32,0,0" "32,1,0" "32,2,0" "32,0,1" "48,0,0" "64,0,0" "64,1,0" "64,0,1" "96,1,0"; do
+for cfg in ${CFGS:-"0" "64,0,0" "64,1,0" "96,0,0" "96,1,0" "128,1,0" "0"}; do
   echo -n "cu $cfg: "
   H2E_CU_RESERVE=$cfg python bench.py --steps 12 --warmup 4 --no-cpu-baseline --traffic off ${EXTRA} 2>/dev/null | python -c "$show"
 done
