@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--units", "--tiles", type=int, default=None, help="units per GPU: MSM tiles (64 x 1024 = 2^16 points) / pairing instances")
     ap.add_argument("--points", type=int, default=1024, help="points per MSM tile")
     ap.add_argument("--ring", type=int, default=None, help="output-buffer sets steps rotate through = runs in flight (default: 2 for the MSM - step k+1's value chain runs under "
-                    "step k's expansion, 2 x 110 GB of arrays; 8 for the pairing checks, whose 35 ms level-parallel value chains only occupy one CU per instance; 1: h2e_run, no overlap)")
+                    "step k's expansion, 2 x 110 GB of arrays; 8 / 16 for the bn256 / bls12_381 pairing checks, whose 28-41 ms level-parallel value chains are latency; 1: h2e_run, no overlap)")
     ap.add_argument("--digest", action="store_true", help="consume every step's arrays with the on-device digest kernel (streaming-job mode, configs[2])")
     ap.add_argument("--job-tiles", type=int, default=None, help="run one MSM job of this many tiles over all ranks (2^20 points = 1024): steps = job_tiles / (units x gpus), digest on")
     ap.add_argument("--cpu-sample-points", type=int, default=1024)
@@ -160,7 +160,9 @@ def main():
     if args.units is None:
         args.units = DEFAULT_UNITS[args.workload]
     if args.ring is None:
-        args.ring = 2 if args.workload == "msm" else 8
+        # MSM: two 110 GB buffer sets; 64 bn256 checks: 8 runs fill every CU (two instances per workgroup, one workgroup's value
+        # slots per CU); 16 bls12_381 checks are 8 workgroups per run - latency: more runs in flight (6.9 -> 6.3 ms per step)
+        args.ring = {"msm": 2, "pairing_bn256": 8, "pairing_bls12_381": 16}[args.workload]
     if args.job_tiles:
         args.digest = True
         args.steps = max(1, args.job_tiles // (args.units * max(1, args.gpus)))
@@ -174,7 +176,7 @@ def main():
         sys.exit(subprocess.run(cmd).returncode)
     # pipelined runs use several HIP streams (caller's, expansion, fix-up, a chain and a side stream per job slot): more than
     # the 4 hardware queues a process gets by default, and streams that share a queue serialise
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32" if args.ring > 8 else "16")
     if world > 1 and args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 

@@ -60,6 +60,18 @@ for region, name in ((0, "base"), (1, "range")):
             exp[f"{name}_{lname}_{fname}"] = {"ms": round(dt * 1e3, 2), "GB_moved": round(gb, 2), "TB_per_s": round(gb / dt / 1e3, 2)}
     del buf
 out[f"export_{tiles}_tiles"] = exp
+dg = {}
+total = 0.0
+for region, name in ((0, "base"), (1, "range"), (2, "select")):
+    dout = torch.zeros((tiles, 4), dtype=torch.int64, device=dev)
+    dt = timed(lambda: eng.digest(prog, region, arrs[region], out=dout), reps=3, warm=1)
+    flags = (prog.base_flags, prog.range_flags, prog.select_flags)[region]()
+    assigned = int((np.asarray(flags) & 1).sum())
+    gb = assigned * tiles * 32 / 1e9
+    total += dt
+    dg[name] = {"ms": round(dt * 1e3, 2), "GB_read": round(gb, 2), "TB_per_s": round(gb / dt / 1e3, 2)}
+dg["all_ms"] = round(total * 1e3, 2)
+out[f"digest_{tiles}_tiles"] = dg
 cc = timed(lambda: eng.export_copy_constraints(prog), reps=5)
 out["copy_constraints"] = {"n": prog.n_permutations, "ms": round(cc * 1e3, 3), "G_pairs_per_s": round(prog.n_permutations / cc / 1e9, 2)}
 fx = {}

@@ -1556,7 +1556,7 @@ struct h2e_ctx {
     H2EFieldConsts* d_fc[3] = {nullptr, nullptr, nullptr};
     std::map<std::string, h2e_program*> cache;
     bool profiling = false;
-    static constexpr int N_SLOTS = 8;
+    static constexpr int N_SLOTS = 16;
     uint32_t depth = 2;      // job slots in use = runs in flight (H2E_OPT_PIPELINE_DEPTH); each slot brings its own streams   // runs in flight (h2e_submit): 2 hide an MSM step's value chain; the pairing checks' 34 ms
                                         // level-parallel chains (one workgroup per instance) want 4
     JobSlot slots[N_SLOTS];
