@@ -59,6 +59,7 @@ struct FPX {
     static constexpr int XW = (S + 63) / 64;
     static constexpr int QW = (S - FP::K + 1 + 63) / 64;  // words of a quotient d
     static constexpr int AW = (FP::CEIL + 6 + 63) / 64;   // words of a composed operand (< 2^(CEIL+6))
+    static constexpr int AL = (FP::CEIL + 6 + 31) / 32;   // ... and its significant 32-bit limbs
 };
 static constexpr int NK = 254;  // bit length of bn256 Fr modulus
 
@@ -606,7 +607,7 @@ WI_INLINE void op_int_mul(const LC& c, const H2EOp& op) {
     constexpr int L = FP::L;
     IntVal<FP> a = ld_int_x<FP>(c, op, 0, 0), b = ld_int_x<FP>(c, op, L + 1, 1);
     Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
-    Wd<FPX<FP>::XW> X = wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW>(A, B));
+    Wd<FPX<FP>::XW> X = wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW, FPX<FP>::AL, FPX<FP>::AL>(A, B));
     Wd<FPX<FP>::QW> dq;
     Wd<FP::WW> rem;
     divrem_w<FP>(c, X, dq, rem);
@@ -1297,7 +1298,7 @@ WI_INLINE void exec_vop(const VSlots<FP>& vs, const LC& c, const VHdr& h, const 
         Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
         Wd<FPX<FP>::QW> dq;
         Wd<FP::WW> rem;
-        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW>(A, B)), dq, rem);
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW, FPX<FP>::AL, FPX<FP>::AL>(A, B)), dq, rem);
         v_out_w<FP>(vs, c, h, rem);
         return;
     }
@@ -1634,7 +1635,7 @@ WI_INLINE void exec_lop(const LVals<FP>& lv, const LC& c, u32 opc, const VHdr& h
         Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
         Wd<FPX<FP>::QW> dq;
         Wd<FP::WW> rem;
-        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW>(A, B)), dq, rem);
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW, FPX<FP>::AL, FPX<FP>::AL>(A, B)), dq, rem);
         l_out_w<FP>(lv, c, h, rem);
     } else if (opc == H2E_V_SUB) {
         IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs), b = l_src_int<FP>(lv, c, h, 1, lrefs);

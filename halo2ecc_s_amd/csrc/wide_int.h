@@ -162,17 +162,20 @@ WI_INLINE u32 wd_acc_shift(WdAcc& A) {   // take the column's 32 bits, move on t
     A.hi = 0;
     return r;
 }
-// full product: product scanning over 32-bit limbs
-template <int NA, int NB>
+// full product: product scanning over 32-bit limbs.  LAE / LBE: the operands' significant 32-bit limbs when their bit
+// bounds are tighter than the word counts (a 260-bit composed operand lives in 5 words but has 9 limbs: 81 partial
+// products instead of 100) - limbs at and above them must be zero.
+template <int NA, int NB, int LAE = 2 * NA, int LBE = 2 * NB>
 WI_INLINE Wd<NA + NB> wd_mul(const Wd<NA>& a, const Wd<NB>& b) {
     constexpr int LA = 2 * NA, LB = 2 * NB;
+    static_assert(LAE <= LA && LBE <= LB, "effective limbs exceed the operand");
     u32 t[LA + LB];
     WdAcc A{0, 0};
 #pragma unroll
     for (int k = 0; k < LA + LB - 1; k++) {
 #pragma unroll
-        for (int i = 0; i < LA; i++)
-            if (i <= k && k - i < LB) wd_mac(A, limb32<NA>(a, i), limb32<NB>(b, k - i));
+        for (int i = 0; i < LAE; i++)
+            if (i <= k && k - i < LBE) wd_mac(A, limb32<NA>(a, i), limb32<NB>(b, k - i));
         t[k] = wd_acc_shift(A);
     }
     t[LA + LB - 1] = (u32)A.lo;
@@ -182,16 +185,17 @@ WI_INLINE Wd<NA + NB> wd_mul(const Wd<NA>& a, const Wd<NB>& b) {
     return r;
 }
 // low NR words of the product
-template <int NR, int NA, int NB>
+template <int NR, int NA, int NB, int LAE = 2 * NA, int LBE = 2 * NB>
 WI_INLINE Wd<NR> wd_mul_lo(const Wd<NA>& a, const Wd<NB>& b) {
     constexpr int LA = 2 * NA, LB = 2 * NB, LR = 2 * NR;
+    static_assert(LAE <= LA && LBE <= LB, "effective limbs exceed the operand");
     u32 t[LR];
     WdAcc A{0, 0};
 #pragma unroll
     for (int k = 0; k < LR; k++) {
 #pragma unroll
-        for (int i = 0; i < LA; i++)
-            if (i <= k && k - i < LB) wd_mac(A, limb32<NA>(a, i), limb32<NB>(b, k - i));
+        for (int i = 0; i < LAE; i++)
+            if (i <= k && k - i < LBE) wd_mac(A, limb32<NA>(a, i), limb32<NB>(b, k - i));
         t[k] = wd_acc_shift(A);
     }
     Wd<NR> r;
@@ -263,10 +267,13 @@ WI_INLINE Wd<N> wd_select(bool c, const Wd<N>& a, const Wd<N>& b) {
 template <int S, int K, int XW, int MW, int QW>
 WI_INLINE void wd_barrett_divrem(const Wd<XW>& X, const Wd<MW>& m, const Wd<QW>& mu, Wd<QW>& q, Wd<MW>& r) {
     Wd<QW> q1 = wd_shr<QW, K - 1>(X);
-    Wd<2 * QW> q2 = wd_mul<QW, QW>(q1, mu);
+    // q1, mu and q3 are below 2^(S-K+1), m below 2^K: their significant limbs, not their word counts, size the products
+    constexpr int QL = (S - K + 1 + 31) / 32 < 2 * QW ? (S - K + 1 + 31) / 32 : 2 * QW;
+    constexpr int ML = (K + 31) / 32 < 2 * MW ? (K + 31) / 32 : 2 * MW;
+    Wd<2 * QW> q2 = wd_mul<QW, QW, QL, QL>(q1, mu);
     Wd<QW> q3 = wd_shr<QW, S - K + 1>(q2);
     // r = X - q3*m on MW+1 words (true value < 3m)
-    Wd<MW + 1> qm = wd_mul_lo<MW + 1, QW, MW>(q3, m);
+    Wd<MW + 1> qm = wd_mul_lo<MW + 1, QW, MW, QL, ML>(q3, m);
     Wd<MW + 1> rr = wd_sub<MW + 1>(wd_resize<MW + 1>(X), qm);
     Wd<MW + 1> me = wd_resize<MW + 1>(m);
     Wd<QW> one = wd_from_u64<QW>(1);
