@@ -446,6 +446,43 @@ def test_pipelined_submit_matches_run(engine, oracle):
         compare_advice(prog, orun, base, rng, sel, instance=tiles - 1)
 
 
+def test_pipelined_submit_of_different_programs(engine, oracle):
+    """Runs of *different* programs in flight at the same time on one context (an MSM tile batch over bn256 Fq, a bls12_381
+    pairing check over the 4-limb field, a general-scalar MSM with two W fields): every job slot has its own workspace
+    with its own slot width, instance table and streams - each run must come out as if it had run alone."""
+    from halo2ecc_s_amd import engine as E
+    t = engine.torch
+    engine.set_option(E.OPT_PIPELINE_DEPTH, 3)
+    try:
+        n = 33
+        progs = [Program.msm_bn256_tile(n), Program.pairing_check_bls12_381(), Program.msm_bls12_381_tile(7)]
+        ins = [[synth.msm_bn256_tile_inputs(n, tile=300 + k)[0] for k in range(3)],
+               [synth.pairing_check_bls12_381_inputs(instance=300 + k) for k in range(2)],
+               [synth.msm_bls12_381_tile_inputs(7, tile=300 + k)[0] for k in range(3)]]
+        d_in = [engine.upload_inputs(pg, np.stack(i_)) for pg, i_ in zip(progs, ins)]
+        arrs = [engine.alloc(pg, len(i_), fill=0xFF) for pg, i_ in zip(progs, ins)]
+        for rnd in range(2):   # second round: the slots' workspaces are reused by a different program than before
+            order = (0, 1, 2) if rnd == 0 else (1, 2, 0)
+            for a in arrs:
+                a[3].zero_()
+            jobs = [engine.submit(progs[k], d_in[k], *arrs[k]) for k in order]
+            for j in jobs:
+                engine.wait(j)
+            t.cuda.synchronize()
+            for k in range(3):
+                assert (arrs[k][3].cpu().numpy() == 0).all(), (rnd, k, arrs[k][3].cpu().numpy())
+        oracles = [lambda inp: oracle_lib.run_msm_bn256_tile(n, inp), oracle_lib.run_pairing_check_bls12_381,
+                   lambda inp: oracle_lib.run_msm_bls12_381_tile(7, inp)]
+        for k in range(3):
+            base, rng, sel = _rows(engine, progs[k], arrs[k][:3])
+            inst = len(ins[k]) - 1
+            orun = oracles[k](ins[k][inst])
+            assert orun.info.status == 0, orun.error
+            compare_advice(progs[k], orun, base, rng, sel, instance=inst)
+    finally:
+        engine.set_option(E.OPT_PIPELINE_DEPTH, 2)
+
+
 def _named_call(engine, fn, *args):
     from halo2ecc_s_amd.engine import _check, lib
     _check(getattr(lib(), fn)(engine._h, *args, engine.torch.cuda.current_stream().cuda_stream))
