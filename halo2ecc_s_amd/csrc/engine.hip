@@ -1265,7 +1265,7 @@ WI_INLINE void exec_vop(const VSlots<FP>& vs, const LC& c, const VHdr& h, const 
                 if ((meta & 3u) == 1u)
                     src = c.hints + (size_t)(ref + ((meta & 0x100u) ? c.strand * c.hint_stride : 0)) * c.ws + piece * 2u;
                 else if ((meta & 3u) == 2u)   // x then y: two value slots, H2E_W_WORDS_MAX / 2 piece numbers each
-                    src = c.sel + (size_t)(2u * (ref + c.strand * c.sel_stride) + piece / (H2E_W_WORDS_MAX / 2)) * c.ws + (piece % (H2E_W_WORDS_MAX / 2)) * 2u;
+                    src = c.sel + (size_t)(H2E_SEL_SLOTS * (ref + c.strand * c.sel_stride) + piece / (H2E_W_WORDS_MAX / 2)) * c.ws + (piece % (H2E_W_WORDS_MAX / 2)) * 2u;
                 else
                     src = cell_ptr(c, ref) + (size_t)piece * c.hs;   // a cell's halves are hs words apart
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -1430,7 +1430,7 @@ WI_INLINE void exec_vop(const VSlots<FP>& vs, const LC& c, const VHdr& h, const 
             xy[0] = vs_stage_w<FP>(vs, h.w[2]);
             xy[1] = vs_stage_w<FP>(vs, h.w[2] + VSlots<FP>::HINT_UNITS);
         } else {
-            const u64* p = c.sel + (size_t)2 * (h.w[2] + c.strand * c.sel_stride) * c.ws;
+            const u64* p = c.sel + (size_t)H2E_SEL_SLOTS * (h.w[2] + c.strand * c.sel_stride) * c.ws;
             xy[0] = ws_load<FP::WW>(p);
             xy[1] = ws_load<FP::WW>(p + c.ws);
         }
@@ -2205,8 +2205,9 @@ __global__ void __launch_bounds__(64) h2e_predict_windows(H2EPreKernel K, u32 ph
     MontW<FP> M;
     (Mont<NW>&)M = mont_w<FP>(fc);
     u32 s0 = K.scan_begin + window * 2 * G;   // S_c at s0 + c, O_c at s0 + G + c
-    const u64* selp = d.sel + (size_t)2 * (K.sel_begin + window * n_groups) * d.ws;   // (x, y) of group g at selp + 2 g ws
-    const size_t sel_step = (size_t)2 * d.ws;
+    // the candidate of group g in Montgomery form (x, y): value slots 2, 3 of its selection-buffer entry
+    const size_t sel_step = (size_t)H2E_SEL_SLOTS * d.ws;
+    const u64* selp = d.sel + (K.sel_begin + window * n_groups) * sel_step + 2 * (size_t)d.ws;
     auto neg_r1_point = [&]() {
         Jac<NW> p;
         p.x = ld_w_mont<FP>(v.c, M, neg_r1);
@@ -2225,9 +2226,8 @@ __global__ void __launch_bounds__(64) h2e_predict_windows(H2EPreKernel K, u32 ph
             nx = ws_load<NW>(np);
             ny = ws_load<NW>(np + d.ws);
             asm volatile("" ::: "memory");
-            Wd<NW> cx = to_mont<NW>(M, sx), cy = to_mont<NW>(M, sy);
             Wd<NW> num;
-            acc = jac_madd(M, acc, cx, cy, num);
+            acc = jac_madd(M, acc, sx, sy, num);
             if (rec) st_rec<FP>(v, hint0 + H2E_ECC_HINT_SLOTS * g, num, acc.z, acc.x, acc.y);
         }
         return acc;
@@ -2238,6 +2238,7 @@ __global__ void __launch_bounds__(64) h2e_predict_windows(H2EPreKernel K, u32 ph
     // 2^-10 per pair).  The chunk sums therefore start from -2 r1 - as safe as the real chain, which starts from -r1 -
     // and the serial pass takes the 2 r1 out again: S'_c = -2 r1 + sum, O_(c+1) = (O_c + S'_c) + 2 r1.
     if (phase == 0) {
+        if (ch + 1 == nch) return;   // nothing reads the last chunk's sum
         Wd<NW> num;
         Jac<NW> s = jac_dbl(M, neg_r1_point(), num);
         s = walk(s, g0, g1, false, 0);
@@ -2381,7 +2382,7 @@ __global__ void __launch_bounds__(64) h2e_predict_tail(H2EPreKernel K, u32 phase
 // replay) then only read static addresses.  Arguments as for H2E_PRE_MSM_WINDOWS.
 template <class FP>
 __global__ void __launch_bounds__(64) h2e_select(H2EPreKernel K, const u32* args, const u32* params_all, const u32* aux,
-                                                 const InstanceDesc* inst, u32 n_instances) {
+                                                 const InstanceDesc* inst, u32 n_instances, const H2EFieldConsts* fc) {
     constexpr int L = FP::L, NW = FP::WW, NR = 2 * (L + 1);
     u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_instances * K.n_lanes) return;
@@ -2401,14 +2402,16 @@ __global__ void __launch_bounds__(64) h2e_select(H2EPreKernel K, const u32* args
     u32 lo = g * group_size, hi = min(n_points, lo + group_size), idx = 0;
     for (u32 j = lo; j < hi; j++) idx |= (u32)(ld_limb(c, H2E_MAKE_REF(H2E_REGION_PARAM, 0, 0, j)).v[0] & 1) << (j - lo);
     const u32* tab = aux + tables[g] + idx * NR;
-    u64* out = d.sel + (size_t)2 * (K.sel_begin + w * n_groups + g) * d.ws;
+    u64* out = d.sel + (size_t)H2E_SEL_SLOTS * (K.sel_begin + w * n_groups + g) * d.ws;
+    Mont<NW> M = mont_w<FP>(fc);
 #pragma unroll
     for (int which = 0; which < 2; which++) {
         Limb l[L];
 #pragma unroll
         for (int i = 0; i < L; i++) l[i] = ld_limb(c, tab[which * (L + 1) + i]);
         Wd<NW> v = wd_resize<NW>(compose<FP, FPX<FP>::AW>(l));
-        ws_store<NW>(out + (size_t)which * d.ws, v);
+        ws_store<NW>(out + (size_t)which * d.ws, v);                          // canonical: the replay's / expansion's copy
+        ws_store<NW>(out + (size_t)(2 + which) * d.ws, to_mont<NW>(M, v));    // Montgomery form: the scan predictor's
     }
 }
 
@@ -2965,7 +2968,7 @@ extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2E
     dim3 grid3((n_instances * k->n_lanes * ecc_chunks + 63) / 64);
 #define H2E_PREDICT_FP(FP)                                                                                                          \
     if (k->kind == H2E_PRE_MSM_SELECT) {                                                                                            \
-        if (phase & 1) hipLaunchKernelGGL(h2e_select<FP>, grid, block, 0, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances); \
+        if (phase & 1) hipLaunchKernelGGL(h2e_select<FP>, grid, block, 0, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev); \
         break;                                                                                                                      \
     }                                                                                                                               \
     if ((phase & 1) && k->kind == H2E_PRE_MSM_WINDOWS) {                                                                            \

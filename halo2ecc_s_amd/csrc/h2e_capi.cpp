@@ -2034,7 +2034,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     size_t hint_words = ((size_t)r.n_hint_slots + H2E_ECC_HINT_SLOTS) * wsw,  // spare: the replay prefetches slot + 8
            nd_words = hint_words * 2,
            jac_words = (size_t)r.n_jac_slots * 3 * wsw,
-           sel_words = (size_t)r.n_sel_slots * 2 * wsw;
+           sel_words = (size_t)r.n_sel_slots * H2E_SEL_SLOTS * wsw;
     HIP_TRY(grow(&J.ws_hints, &J.ws_hints_words, std::max<size_t>(1, hint_words * n_instances)));
     HIP_TRY(grow(&J.ws_nd, &J.ws_nd_words, std::max<size_t>(1, nd_words * n_instances)));
     HIP_TRY(grow(&J.ws_jac, &J.ws_jac_words, std::max<size_t>(1, jac_words * n_instances)));

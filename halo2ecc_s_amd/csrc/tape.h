@@ -234,6 +234,9 @@ enum H2EVOpcode {
 enum H2EPreKind { H2E_PRE_MSM_CANDIDATES = 1, H2E_PRE_MSM_WINDOWS = 2, H2E_PRE_MSM_TAIL = 3, H2E_PRE_MSM_SELECT = 4 };
 // selection buffer: per (strand, group) the picked candidate, x then y, canonical, H2E_W_WORDS_MAX words each
 #define H2E_SEL_WORDS (2 * H2E_W_WORDS_MAX)
+// selection buffer entry = 4 value slots: x, y canonical (what the replay / expansion read), x, y in Montgomery form (what the
+// windows' scan predictor multiplies: it walks every candidate twice and would convert it both times)
+#define H2E_SEL_SLOTS 4u
 typedef struct H2EPreKernel {
     uint32_t kind;
     uint32_t n_lanes;        // lanes per instance (groups / windows / 1)
