@@ -1036,6 +1036,9 @@ WI_INLINE H2EOp chunk_op(const TapeChunk* tc, u32 k) {
 #ifndef H2E_REPLAY_WAVES
 #define H2E_REPLAY_WAVES 2
 #endif
+#ifndef H2E_CHAIN_WAVES
+#define H2E_CHAIN_WAVES 1   // predictors / finalize / fix-up kernels: waves per SIMD their register budget must allow (experiments)
+#endif
 template <class FP, bool VALUES_ONLY>
 __global__ void __launch_bounds__(64, H2E_X_WAVES) h2e_run_tape(H2ELaunch L, const InstanceDesc* inst, u32 n_instances,
                                                    const H2EFieldConsts* fc) {
@@ -1899,7 +1902,7 @@ WI_INLINE Mont<4> mont_n(const H2EFieldConsts* fc) {
 #define H2E_FIXUP_K 64
 #endif
 static constexpr int FIXUP_K = H2E_FIXUP_K;
-__global__ void __launch_bounds__(64) h2e_fixup_inverses(H2ELaunch L, const InstanceDesc* inst, u32 n_instances,
+__global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_fixup_inverses(H2ELaunch L, const InstanceDesc* inst, u32 n_instances,
                                                          const H2EFieldConsts* fc) {
     u32 chunks = (L.n_fixups + FIXUP_K - 1) / FIXUP_K;
     u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2084,7 +2087,7 @@ WI_INLINE Jac<FP::WW> ld_jac(const VC& v, u32 slot) {
 //  TAIL:       [0] windows, [1] odd-groups flag, [2..) refs of r1, then refs of -r2 (2(L+1) each),
 //              [last] jac scratch slot of window 0's sum.  hints: windows * (2 + odd).
 template <class FP>
-__global__ void __launch_bounds__(64) h2e_predict(H2EPreKernel K, const u32* args, const u32* params_all, const u32* aux,
+__global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_predict(H2EPreKernel K, const u32* args, const u32* params_all, const u32* aux,
                                                   const InstanceDesc* inst, u32 n_instances, const H2EFieldConsts* fc) {
     constexpr int L = FP::L, NW = FP::WW, NR = 2 * (L + 1);
     __builtin_amdgcn_s_setprio(3);  // value chain: critical path (see h2e_run_tape<.., true>)
@@ -2185,7 +2188,7 @@ WI_INLINE void vc_init(VC& v, const InstanceDesc& d, u32 n_instances, const u32*
 // phase 0: chunk sums S_c (lane = window x chunk); 1: offsets O_0 = -r1, O_(c+1) = S_c + O_c (lane = window);
 // 2: the chunk's additions acc = C_g[idx] + acc from O_c, with their records (lane = window x chunk)
 template <class FP>
-__global__ void __launch_bounds__(64) h2e_predict_windows(H2EPreKernel K, u32 phase, const u32* args, const InstanceDesc* inst, u32 n_instances,
+__global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_predict_windows(H2EPreKernel K, u32 phase, const u32* args, const InstanceDesc* inst, u32 n_instances,
                                                           const H2EFieldConsts* fc) {
     constexpr int L = FP::L, NW = FP::WW, NR = 2 * (L + 1);
     constexpr u32 G = H2E_WIN_CHUNKS;
@@ -2276,7 +2279,7 @@ __global__ void __launch_bounds__(64) h2e_predict_windows(H2EPreKernel K, u32 ph
 // A_c = D + B at the chunk's end (lane = instance; the only serial part: one doubling per window);
 // 2: window w starts from acc_(w-1) = D_(w-1) + B_(w-1) and does its real operations, with their records (lane = window)
 template <class FP>
-__global__ void __launch_bounds__(64) h2e_predict_tail(H2EPreKernel K, u32 phase, const u32* args, const InstanceDesc* inst, u32 n_instances,
+__global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_predict_tail(H2EPreKernel K, u32 phase, const u32* args, const InstanceDesc* inst, u32 n_instances,
                                                        const H2EFieldConsts* fc) {
     constexpr int L = FP::L, NW = FP::WW, NR = 2 * (L + 1);
     constexpr u32 CH = H2E_TAIL_CHUNK;
@@ -2422,7 +2425,7 @@ __global__ void __launch_bounds__(64) h2e_select(H2EPreKernel K, const u32* args
 #endif
 static constexpr int HINT_K = H2E_HINT_K;
 template <class FP>
-__global__ void __launch_bounds__(64) h2e_finalize_hints(u32 hint_base, u32 n_hints, const InstanceDesc* inst,
+__global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_finalize_hints(u32 hint_base, u32 n_hints, const InstanceDesc* inst,
                                                          u32 n_instances, const H2EFieldConsts* fc) {
     constexpr int NW = FP::WW;
     u32 chunks = (n_hints + HINT_K - 1) / HINT_K;
@@ -2464,7 +2467,7 @@ __global__ void __launch_bounds__(64) h2e_finalize_hints(u32 hint_base, u32 n_hi
 #endif
 static constexpr int ECC_CH = H2E_ECC_CH;
 template <class FP>
-__global__ void __launch_bounds__(64) h2e_finalize_ecc(H2EPreKernel K, const InstanceDesc* inst, u32 n_instances,
+__global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_finalize_ecc(H2EPreKernel K, const InstanceDesc* inst, u32 n_instances,
                                                        const H2EFieldConsts* fc) {
     constexpr int NW = FP::WW;
     u32 chunks = (K.ecc_ops + ECC_CH - 1) / ECC_CH;
