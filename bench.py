@@ -17,8 +17,16 @@ Steps are pipelined the way a streaming job runs them (a 2^20-point MSM is 1024 
 buffers): step k+1 is submitted (h2e_submit) into the other buffer of a ring of `--ring` (default 2) output-buffer
 sets while step k's expansion is still streaming, so the value chain of one step runs under the expansion of the
 previous one.  The timed region is bracketed by barrier + synchronize on both sides; `--ring 1` runs the steps
-strictly one after the other (h2e_run).  Steps alternate between two input batches and the OR of every step's status
-words must be 0.  Prints ONE JSON line on rank 0.
+strictly one after the other (h2e_run).  Steps alternate between two input batches (a streaming job - `--job-tiles` -
+has distinct inputs for every tile) and the OR of every step's status words must be 0.  Prints ONE JSON line on rank 0.
+
+The default invocation (`python bench.py`, N = 1) reports the whole BASELINE metric in that one line: the top level is
+configs[1] (2^16-point MSM, the largest config whose outputs fit one GPU), and under "also" the same measurement of the
+other configs, each run by a child process of this script before this process touches the GPU: "pairing_bn256" (64 checks),
+"pairing_bls12_381" (16 checks) and "msm_job_2e20" (configs[2] as one streaming job of 1024 tiles with the digest
+consumer).  Every block has ms_per_step, single_batch_ms (one batch alone through h2e_run: the latency), whole_step, a
+roofline whose `kernel` is the time-dominant one, and - for the pairings - its own cpu_baseline.  `--suite main` skips the
+children.
 """
 import argparse
 import concurrent.futures
@@ -47,7 +55,9 @@ DEFAULT_UNITS = {"msm": 64, "pairing_bn256": 64, "pairing_bls12_381": 16}
 # structure: MSM - window-parallel inside a tile like the rayon region
 # (src/circuit/ecc_chip.rs:317-343), tiles in parallel up to memory; pairing - single-threaded per instance (as in
 # the reference), instances in parallel across cores.  Bounded sample of the same workload.
-def cpu_baseline(workload, points):
+def cpu_baseline(workload, points, msm_inputs=None):
+    """msm_inputs: input vectors of tiles whose `expected` slots hold the true MSM result (bench.py learns it on the GPU in an
+    untimed pass 0), so that every baseline unit runs to the end of the test body: its status must be 0."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     import psutil
@@ -58,8 +68,12 @@ def cpu_baseline(workload, points):
     if workload == "msm":
         per_unit_gb = 9.0 * points / 1024            # Records of a 1024-point tile: 7 GB resident
         in_flight = int(max(1, min(cores // 4 if cores >= 8 else 1, avail_gb * 0.8 // per_unit_gb, 32)))
+        if msm_inputs is not None:
+            in_flight = min(in_flight, len(msm_inputs))
+            inputs = [np.ascontiguousarray(msm_inputs[t]) for t in range(in_flight)]
+        else:   # the expected point by the host's own scalar multiplications (small tiles only: pure Python)
+            inputs = [synth.msm_bn256_tile_inputs(points, tile=900 + t, cheap_points=True, with_expected=True)[0] for t in range(in_flight)]
         threads = max(1, cores // in_flight)
-        inputs = [synth.msm_bn256_tile_inputs(points, tile=900 + t, cheap_points=True, with_expected=False)[0] for t in range(in_flight)]
         fn = lambda inp: oracle_lib.run_msm_bn256_tile(points, inp, threads=threads)   # noqa: E731
         what = f"{in_flight} x {points}-point bn256 MSM tiles (test body incl. assign_point) in parallel, {threads} threads each over the MSM windows"
     else:
@@ -75,17 +89,19 @@ def cpu_baseline(workload, points):
 
     def one(inp):
         r = fn(inp)
-        cells, st = r.info.n_advice_cells, r.info.status
+        cells, st, err = r.info.n_advice_cells, r.info.status, r.error
         r.close()
-        return cells, st
+        return cells, st, err
 
     t0 = time.perf_counter()
     with concurrent.futures.ThreadPoolExecutor(in_flight) as ex:   # ctypes calls release the GIL
         res = list(ex.map(one, inputs))
     secs = time.perf_counter() - t0
-    cells = sum(c for c, _ in res)
+    bad = [(k, st, err) for k, (_, st, err) in enumerate(res) if st != 0]
+    assert not bad, f"cpu_baseline: oracle units did not run to the end: {bad[:3]}"
+    cells = sum(c for c, _, _ in res)
     out = {"value": cells / secs, "unit": "cells/s", "cores": min(cores, in_flight * threads), "kind": "port",
-           "sample": f"{what}; {cells} advice cells in {secs:.1f} s wall; oracle C++ restatement; host has {cores} logical cores, "
+           "sample": f"{what}; {cells} advice cells in {secs:.1f} s wall, every unit's status 0; oracle C++ restatement; host has {cores} logical cores, "
                      f"{avail_gb:.0f} GiB free memory ({per_unit_gb:.0f} GiB per unit in flight)",
            "units_in_flight": in_flight, "threads_per_unit": threads, "units_per_s": in_flight / secs}
     if workload == "msm":
@@ -136,6 +152,35 @@ def dominant_traffic(got, dom_n):
     return {"bytes_per_launch": per_launch, "launches": dom_n, "WRITE_SIZE_KB": wr, "FETCH_SIZE_KB_raw": rd}
 
 
+def _tile_inputs(job):
+    """worker of the input pool (module level: picklable)"""
+    from halo2ecc_s_amd import synth
+    n, tile = job
+    return synth.msm_bn256_tile_inputs(n, tile=tile, cheap_points=True, with_expected=False)[0]
+
+
+def run_children(args):
+    """the other configs of BASELINE's metric, one child process of this script each, before this process touches the GPU"""
+    also = {}
+    base = [sys.executable, os.path.abspath(__file__), "--sub", "--suite", "main", "--traffic", "off", "--gpus", "1"]
+    jobs = [("pairing_bn256", ["--workload", "pairing_bn256"]),
+            ("pairing_bls12_381", ["--workload", "pairing_bls12_381"]),
+            ("msm_job_2e20", ["--workload", "msm", "--job-tiles", "1024", "--no-cpu-baseline"])]
+    for name, extra in jobs:
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=args.child_timeout, cwd=ROOT)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+            if r.returncode != 0 or not lines:
+                also[name] = {"error": f"rc {r.returncode}: {r.stderr[-400:]}"}
+            else:
+                also[name] = json.loads(lines[-1])
+        except Exception as e:   # noqa: BLE001  (a failed side measurement must not cost the headline line)
+            also[name] = {"error": f"{type(e).__name__}: {e}"}
+        also[name]["wall_s"] = time.perf_counter() - t0
+    return also
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,23 +190,34 @@ def main():
     ap.add_argument("--units", "--tiles", type=int, default=None, help="units per GPU: MSM tiles (64 x 1024 = 2^16 points) / pairing instances")
     ap.add_argument("--points", type=int, default=1024, help="points per MSM tile")
     ap.add_argument("--ring", type=int, default=None, help="output-buffer sets steps rotate through = runs in flight (default: 2 for the MSM - step k+1's value chain runs under "
-                    "step k's expansion, 2 x 110 GB of arrays; 8 / 16 for the bn256 / bls12_381 pairing checks, whose 28-41 ms level-parallel value chains are latency; 1: h2e_run, no overlap)")
+                    "step k's expansion, 2 x 110 GB of arrays; 8 / 16 for the bn256 / bls12_381 pairing checks, whose value chains are latency-bound; 1: h2e_run, no overlap)")
     ap.add_argument("--digest", action="store_true", help="consume every step's arrays with the on-device digest kernel (streaming-job mode, configs[2])")
-    ap.add_argument("--job-tiles", type=int, default=None, help="run one MSM job of this many tiles over all ranks (2^20 points = 1024): steps = job_tiles / (units x gpus), digest on")
+    ap.add_argument("--job-tiles", type=int, default=None, help="run one MSM job of this many tiles over all ranks (2^20 points = 1024; `--job-tiles 1024 --gpus 8` is configs[2]): "
+                    "steps = job_tiles / (units x gpus), every tile with its own inputs, digest on, one gather of the job's records at the end")
+    ap.add_argument("--suite", default=None, choices=["all", "main"], help="all (default for the plain N = 1 MSM invocation): also measure the pairing configs and the 2^20-point job "
+                    "in child processes and nest them under \"also\"; main: this workload only")
+    ap.add_argument("--latency-steps", type=int, default=3, help="single-batch latency: that many h2e_run steps one after the other, after the timed region (0: off)")
+    ap.add_argument("--dump-records", default=None, help="write the gathered per-unit records of the job (+ the input vectors of --dump-tiles) to this .npz (tests)")
+    ap.add_argument("--dump-tiles", default="", help="comma-separated global tile indices whose input vectors go into --dump-records")
     ap.add_argument("--cpu-sample-points", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic", default="auto", choices=["auto", "off"], help="auto: measure the dominant kernel's HBM bytes with two rocprofv3 --pmc child passes (N=1 only)")
     ap.add_argument("--traffic-timeout", type=int, default=240)
+    ap.add_argument("--child-timeout", type=int, default=900)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--sub", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-check", action="store_true", help="A/B experiments with deliberately broken arithmetic")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on GPUs; gloo only to exercise the N>1 path on one GPU")
     ap.add_argument("--device", type=int, default=None, help="override the CUDA device index (default: LOCAL_RANK)")
     args = ap.parse_args()
+    plain = (args.workload == "msm" and args.units is None and args.job_tiles is None and args.points == 1024 and args.ring is None
+             and not args.digest and not args.pmc_child and not args.sub)
+    if args.suite is None:
+        args.suite = "all" if plain else "main"
     if args.units is None:
         args.units = DEFAULT_UNITS[args.workload]
     if args.ring is None:
-        # MSM: two 110 GB buffer sets; 64 bn256 checks: 8 runs fill every CU (two instances per workgroup, one workgroup's value
-        # slots per CU); 16 bls12_381 checks are 8 workgroups per run - latency: more runs in flight (6.9 -> 6.3 ms per step)
+        # MSM: two 110 GB buffer sets; pairing checks: their value chains are latency (a few dozen workgroups): 8 / 16 runs in flight
         args.ring = {"msm": 2, "pairing_bn256": 8, "pairing_bls12_381": 16}[args.workload]
     if args.job_tiles:
         args.digest = True
@@ -180,6 +236,28 @@ def main():
     if world > 1 and args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
+    also = None
+    if args.suite == "all" and rank == 0 and world == 1 and not args.pmc_child and not args.sub:
+        also = run_children(args)
+
+    n, units = args.points, args.units
+    # synthetic inputs: different per unit and per rank.  Repetition steps alternate between two batches, so that a step can
+    # never pass on data a previous step left behind; a streaming job has one batch per step: tile (step * world + rank) * units + t.
+    # MSM tiles are generated by a process pool *before* this process initialises HIP (fork is only safe until then).
+    job_mode = bool(args.job_tiles)
+    n_batches = args.steps if job_mode else 2
+    first_of = lambda bi: (bi * world + rank) * units   # noqa: E731
+    host_batches = None
+    if args.workload == "msm":
+        jobs = [(n, first_of(bi) + t) for bi in range(n_batches) for t in range(units)]
+        workers = max(1, min(64, (os.cpu_count() or 1) // max(1, world), len(jobs)))
+        if workers > 1 and len(jobs) >= 16:
+            with concurrent.futures.ProcessPoolExecutor(workers) as ex:
+                tiles = list(ex.map(_tile_inputs, jobs, chunksize=max(1, len(jobs) // (4 * workers))))
+        else:
+            tiles = [_tile_inputs(j) for j in jobs]
+        host_batches = [np.stack(tiles[bi * units:(bi + 1) * units]) for bi in range(n_batches)]
+
     import torch
     import torch.distributed as dist
     from halo2ecc_s_amd import Engine, Program, parallel, synth
@@ -196,7 +274,6 @@ def main():
     dev = f"cuda:{local_rank}"
     coll_dev = dev if args.dist_backend == "nccl" else "cpu"
 
-    n, units = args.points, args.units
     if args.workload == "msm":
         make = lambda shape: Program.msm_bn256_tile(n, emit_shape=shape)   # noqa: E731
     elif args.workload == "pairing_bn256":
@@ -208,10 +285,10 @@ def main():
     cells_per_unit = shape_prog.n_advice_cells
     launches = shape_prog.launches()
     shape_prog.close()
-    # dominant kernel = the launch with the most cells (MSM: the window strands; pairing: the whole check)
+    # the launch with the most cells (MSM: the window strands; pairing: the whole check)
     dom = max(range(len(launches)), key=lambda i: launches[i]["cells"])
 
-    # HBM traffic of the dominant kernel: child passes under rocprofv3, before this process allocates its arrays
+    # HBM traffic of the dominant expansion: child passes under rocprofv3, before this process allocates its arrays
     traffic, traffic_err = None, "not measured"
     if args.traffic == "auto" and rank == 0 and world == 1 and not args.pmc_child:
         traffic, traffic_err = measure_traffic(args)
@@ -219,33 +296,24 @@ def main():
     eng = Engine(local_rank)
     ring = max(1, min(args.ring, eng.get_stat(4)))
     eng.set_option(4, ring)          # H2E_OPT_PIPELINE_DEPTH: as many job slots (workspaces, streams) as runs in flight
-    # The first process that touches the HBM of a freshly booted box pays for it: without this throw-away allocate / fill / free
-    # of (almost) the whole memory the steps of that process run 2 x slower than those of any later one (47 vs 24 ms, measured
-    # with two bench runs in one gpurun call; exp/first_touch.py).  0.3 s, untimed, no effect on later processes.
-    # (Skipped when ranks share a device - `--device`, the one-GPU test of the N > 1 path - where two ranks asking for "all free
-    # memory" at the same moment would race; a failed attempt is not an error either.)
+    # The first process that touches the HBM of a freshly booted box pays for it: without a throw-away fill of (almost) the
+    # whole memory the steps of that process run 2 x slower than those of any later one (47 vs 24 ms; exp/first_touch.py).
+    # The engine owns it: H2E_OPT_PREFAULT_HBM (percent of the free memory; 0.3 s, untimed, no effect on later processes).
+    # Skipped when ranks share a device (`--device`, the one-GPU test of the N > 1 path).
     if args.device is None or world == 1:
         try:
-            free_b, _total = torch.cuda.mem_get_info(local_rank)
-            scratch = torch.empty((int(free_b * 0.92) // 8,), dtype=torch.int64, device=dev)
-            scratch.fill_(-1)
-            torch.cuda.synchronize()
-            del scratch
-        except RuntimeError as e:   # out of memory: somebody else is using the device
+            eng.set_option(6, 92)
+        except Exception as e:   # noqa: BLE001  (somebody else is using the device: not an error)
             print(f"bench.py: first-touch pass skipped ({str(e).splitlines()[0]})", file=sys.stderr)
-        torch.cuda.empty_cache()
     bufs = [eng.alloc(prog, units) for _ in range(ring)]   # (base, range, select, status) per ring slot
     out_refs = prog.outputs()
     L = 3
 
-    # synthetic inputs, different per unit and per rank; two batches that the steps alternate between, so that a step
-    # can never pass on data a previous step left behind (same inputs every step would hide a missing dependency)
-    n_batches = 2
     batches = []
     for bi in range(n_batches):
-        first = (bi * world + rank) * units
+        first = first_of(bi)
         if args.workload == "msm":
-            ins = np.stack([synth.msm_bn256_tile_inputs(n, tile=first + t, cheap_points=True, with_expected=False)[0] for t in range(units)])
+            ins = host_batches[bi]
         elif args.workload == "pairing_bn256":
             ins = np.stack([synth.pairing_check_bn256_inputs(instance=first + t) for t in range(units)])
         else:
@@ -271,38 +339,50 @@ def main():
                 exp[t] = synth.pack([x, y, z], 4)
             d_in[:, 4 * n + 6:4 * n + 9, :] = torch.from_numpy(exp.view(np.int64)).to(dev)
         batches.append(d_in)
+    host_batches = None
     status_any = torch.zeros_like(bufs[0][3])   # OR of every step's status words
     step_no = [0]
     timing = [False]
-    pending = []   # (job, ring slot) submitted and not yet waited for
-    gathered_last = [None]
-    my_units = parallel.shard_units(units * world, world, rank)   # global unit indices of this rank (round-robin)
+    pending = []   # (job, ring slot, step index) submitted and not yet waited for
     offsets = torch.tensor([prog.base_offset, prog.range_offset, prog.select_offset], dtype=torch.int64, device=dev)
     digests = [torch.zeros((3, units, 4), dtype=torch.int64, device=dev) for _ in range(ring)]
     digest_any = [None]
+    # Per-unit records {status, Offset, result point cells, 32-byte digest per advice array} of every timed step, built on the
+    # device as the steps retire (no host synchronisation), gathered ONCE at the end of the timed region: the one collective
+    # of the path (RCCL all_gather over xGMI).  Global unit index of step k's unit t on this rank:
+    # (k * world + rank) * units + t.
+    want_records = world > 1 or args.digest or args.dump_records
+    R = parallel.record_words(3)
+    job_rec = torch.zeros((max(1, args.steps), units, R), dtype=torch.int64, device=dev) if want_records else None
+    plan = None
+    if want_records:
+        mine = [(k * world + rank) * units + t for k in range(args.steps) for t in range(units)]
+        plan = parallel.GatherPlan(mine, args.steps * world * units, world, coll_dev)
 
-    def consume(slot):
-        """what happens to a finished step's arrays: status check, optional on-device digest (the consumer of a streaming
-        job: SURVEY 8d cfg 3), and for N > 1 the one collective of the path - an all_gather of the per-unit records
-        {status, Offset, result point cells, 32-byte digest per advice array}"""
+    def consume(slot, k):
+        """what happens to a finished step's arrays: status OR, optional on-device digest (the consumer of a streaming
+        job: SURVEY 8d cfg 3), and its rows of the job's record table"""
         base, rng, sel, status = bufs[slot]
         status_any.bitwise_or_(status)
         if args.digest:
             for region, arr in enumerate((base, rng, sel)):
                 eng.digest(prog, region, arr, out=digests[slot][region])
             digest_any[0] = digests[slot]
-        if world > 1 or args.digest:
-            rec = parallel.unit_records(status, offsets, base, out_refs, digests[slot] if args.digest else None)
-            gathered_last[0] = parallel.gather_unit_records(my_units, rec.to(coll_dev), units * world, world)
+        if want_records and timing[0]:
+            parallel.unit_records(status, offsets, base, out_refs, digests[slot] if args.digest else None, out=job_rec[k - timed_from[0]])
 
     launch_ms = []      # per timed step: (value chain ms, expansion ms) per launched segment, from the engine's HIP events
+    timed_from = [0]
 
-    def retire(job, slot):
+    def retire(job, slot, k):
         eng.wait(job)                                   # the current stream waits for every array of that step
-        consume(slot)
+        consume(slot, k)
         if timing[0]:
             # (waits on the host for that step only: the next one is already queued, the GPU stays busy)
             launch_ms.append(eng.job_launch_ms(job))
+
+    def batch_of(k):
+        return batches[(k - timed_from[0]) % n_batches] if (job_mode and timing[0]) else batches[k % n_batches]
 
     def step():
         k = step_no[0]
@@ -311,8 +391,8 @@ def main():
         base, rng, sel, status = bufs[slot]
         if ring == 1:
             status.zero_()
-            eng.run(prog, batches[k % n_batches], base, rng, sel, status)
-            consume(slot)
+            eng.run(prog, batch_of(k), base, rng, sel, status)
+            consume(slot, k)
             if timing[0]:
                 torch.cuda.current_stream().synchronize()
                 launch_ms.append(eng.last_run_launch_ms())
@@ -320,8 +400,8 @@ def main():
         while len(pending) >= ring:                     # the slot's previous step must have been consumed
             retire(*pending.pop(0))
         status.zero_()
-        job = eng.submit(prog, batches[k % n_batches], base, rng, sel, status)
-        pending.append((job, slot))
+        job = eng.submit(prog, batch_of(k), base, rng, sel, status)
+        pending.append((job, slot, k))
         while len(pending) > ring - 1:                  # consume the step before this one (its expansion overlaps our chain)
             retire(*pending.pop(0))
         return job
@@ -339,6 +419,8 @@ def main():
 
     eng.set_profiling(True)
     timing[0] = True
+    timed_from[0] = step_no[0]
+    gathered, seen = None, None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -346,6 +428,8 @@ def main():
     for _ in range(args.steps):
         step()
     drain()
+    if want_records:   # the final gather: one collective per job, inside the timed region
+        gathered, seen = parallel.gather_records(plan, job_rec.reshape(-1, R).to(coll_dev))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -354,10 +438,33 @@ def main():
         return
     if not args.no_check:
         assert int(status_any.abs().max()) == 0, f"unit status {status_any.cpu().numpy()}"
+        if seen is not None:
+            assert bool(seen.all()), "some units were not produced by any rank"
+    rank_ms = 1e3 * elapsed / args.steps
+    per_rank_ms = [rank_ms]
     if world > 1:
-        tmax = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        allms = torch.zeros((world,), device=coll_dev, dtype=torch.float64)
+        allms[rank] = rank_ms
+        dist.all_reduce(allms, op=dist.ReduceOp.SUM)
+        per_rank_ms = [float(x) for x in allms.tolist()]
+        elapsed = max(per_rank_ms) * args.steps / 1e3
+
+    # single-batch latency: one batch alone through h2e_run (nothing else in flight), inputs resident -> arrays complete
+    single_ms = None
+    timing[0] = False
+    if args.latency_steps > 0:
+        lat = []
+        base, rng, sel, status = bufs[0]
+        for i in range(args.latency_steps):
+            status.zero_()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            eng.run(prog, batches[i % n_batches], base, rng, sel, status)
+            torch.cuda.synchronize()
+            lat.append(1e3 * (time.perf_counter() - t1))
+            if not args.no_check:
+                assert int(status.abs().max()) == 0
+        single_ms = float(np.median(lat))
 
     # per-launch times of every timed step (HIP events recorded by the engine on the launching streams)
     launch_ms = [ms for ms in launch_ms if len(ms) > dom]
@@ -370,15 +477,34 @@ def main():
     dom_ms = float(np.mean([ms[dom][1] for ms in launch_ms])) / dom_n
     dom_bytes = 32.0 * launches[dom]["cells"] * units / dom_n
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    chain_ms = float(np.mean([ms[dom][0] for ms in launch_ms]))
     ms_per_step = 1e3 * elapsed / args.steps
     step_bytes = 32.0 * cells_per_unit * units
+    fpname = "FP_BN256_FQ" if args.workload != "pairing_bls12_381" else "FP_BLS_FQ"
     if args.workload == "msm":
         desc = (f"bn256 G1 select-chip MSM witness, {units} tiles x {n} points per GPU "
                 f"(2^{int(np.log2(max(1, units * n)))} points/GPU), reference test body per tile")
-        kernel = "h2e_run_tape<FP_BN256_FQ, false> (full expansion of the MSM window strands)"
+        if job_mode:
+            desc = (f"bn256 G1 select-chip MSM witness as ONE streaming job of {args.job_tiles} tiles x {n} points "
+                    f"(2^{int(np.log2(max(1, args.job_tiles * n)))} points) over {world} GPU(s): {units} tiles per step and GPU, every tile its own inputs")
     else:
         desc = f"{units} x {args.workload} check_pairing (2 pairs, G2 constant) per GPU, reference test shape"
-        kernel = ("h2e_run_tape<FP_BN256_FQ, false>" if args.workload == "pairing_bn256" else "h2e_run_tape<FP_BLS_FQ, false>") + " (full expansion of the pairing check)"
+    x_kernel = f"h2e_run_tape<{fpname}, false> (full expansion of " + ("the MSM window strands)" if args.workload == "msm" else "the pairing check)")
+    x_roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes_per_launch"] if traffic else None,
+              "kernel": x_kernel, "launch_ms": dom_ms, "algorithmic_bytes_per_launch": dom_bytes, "launches_per_step": dom_n}
+    if chain_ms > dom_ms * dom_n:
+        # the value chain of this launch takes longer than its expansion (the pairing checks: one latency-bound level-parallel
+        # replay): that kernel is the time-dominant one, priced against the bytes of the cells it is the critical path of
+        c_ach = dom_bytes * dom_n / (chain_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": c_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c_ach / HBM_PEAK_GBS, "traffic": None,
+                "kernel": f"h2e_replay_levels<{fpname}> (values-only level-parallel replay: the value chain the expansion waits for; latency-bound - "
+                          "priced against the algorithmic bytes of the cells it is the critical path of)",
+                "launch_ms": chain_ms, "algorithmic_bytes_per_launch": dom_bytes * dom_n, "launches_per_step": 1, "expansion": x_roof}
+    else:
+        roof = x_roof
+    roof["value_chain_ms"] = [float(x) for x in np.mean(np.array([[a for a, _ in ms] for ms in launch_ms]), axis=0)]
+    roof["expansion_ms"] = [float(x) for x in np.mean(np.array([[b for _, b in ms] for ms in launch_ms]), axis=0)]
     out = {
         "metric": "witness_cells_per_sec",
         "value": total_cells / elapsed,
@@ -394,14 +520,12 @@ def main():
         "data": "synthetic",
         "config": {"workload": desc, "units_per_gpu": units, "cells_per_unit": cells_per_unit,
                    "pipeline": f"ring of {ring} output-buffer sets, steps submitted with h2e_submit" if ring > 1 else "h2e_run, one step after the other",
-                   "sharding": f"units round-robin over {world} GPU(s), all_gather of the per-unit records"},
+                   "sharding": f"units round-robin over {world} GPU(s); one all_gather of the job's per-unit records at the end of the timed region"},
+        "single_batch_ms": single_ms,
+        "per_rank_ms_per_step": per_rank_ms,
         "whole_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                        "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes_per_launch"] if traffic else None,
-                     "kernel": kernel, "launch_ms": dom_ms, "algorithmic_bytes_per_launch": dom_bytes, "launches_per_step": dom_n,
-                     "value_chain_ms": [float(x) for x in np.mean(np.array([[a for a, _ in ms] for ms in launch_ms]), axis=0)],
-                     "expansion_ms": [float(x) for x in np.mean(np.array([[b for _, b in ms] for ms in launch_ms]), axis=0)]},
+        "roofline": roof,
     }
     if args.workload == "msm":
         out["msm_points_per_sec"] = n * units * world * args.steps / elapsed
@@ -410,16 +534,30 @@ def main():
     if args.digest:
         out["config"]["consumer"] = "h2e_digest over the three advice arrays of every step (32 B per array and unit), inside the timed region"
         out["digest_sample"] = [int(x) & 0xFFFFFFFFFFFFFFFF for x in digest_any[0][0, 0].cpu().tolist()] if digest_any[0] is not None else None
-    if gathered_last[0] is not None:
-        g = gathered_last[0]
-        out["gathered_records"] = {"shape": list(g.shape), "status_or": int(g[:, 0].abs().max())}
+    if gathered is not None:
+        out["gathered_records"] = {"shape": list(gathered.shape), "status_or": int(gathered[:, 0].abs().max())}
+        if args.dump_records and rank == 0:
+            tiles = [int(x) for x in args.dump_tiles.split(",") if x != ""]
+            keep = {}
+            for t in tiles:   # inputs of global tile t, if this rank ran it (single-GPU tests: always)
+                k, rem = divmod(t, world * units)
+                if rem // units == rank and k < n_batches:
+                    keep[f"inputs_{t}"] = batches[k][rem % units].cpu().numpy().view(np.uint64)
+            np.savez(args.dump_records, records=gathered.cpu().numpy(), **keep)
     if traffic:
-        out["roofline"]["traffic_detail"] = traffic
-        out["roofline"]["traffic_source"] = "two rocprofv3 --pmc child passes of this command (WRITE_SIZE + 2 x FETCH_SIZE, KB -> bytes), this run"
+        x_roof["traffic_detail"] = traffic
+        x_roof["traffic_source"] = "two rocprofv3 --pmc child passes of this command (WRITE_SIZE + 2 x FETCH_SIZE, KB -> bytes), this run"
     else:
-        out["roofline"]["traffic_note"] = traffic_err
+        x_roof["traffic_note"] = traffic_err
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_points)
+        del bufs, digests   # (the oracle needs host memory only; drop the device arrays first)
+        torch.cuda.empty_cache()
+        msm_inputs = None
+        if args.workload == "msm" and n == args.cpu_sample_points:
+            msm_inputs = batches[0].cpu().numpy().view(np.uint64)   # tiles with their GPU-learnt `expected` point
+        out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_points, msm_inputs)
+    if also is not None:
+        out["also"] = also
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -88,13 +88,36 @@ struct InstanceDesc {
     u32 ws;             // words between consecutive value slots
     u32 pad_;
 };
+// Address spaces.  Pointers that come out of InstanceDesc / H2ELaunch are generic to the compiler, and an access through a
+// generic pointer is a FLAT instruction: it counts in the vector-memory AND the LDS counter and completes out of order, so
+// every use of an LDS value slot (or of a loaded cell) waited for *all* outstanding global stores of the wave - the
+// level-parallel replays paid a store round trip to HBM (~3 k cycles) per round for that.  Every access to cells /
+// workspace / inputs therefore goes through g_* (global_load / global_store) and every access to LDS value slots through
+// l_* (ds_read / ds_write).
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+#define H2E_AS_GLOBAL __attribute__((address_space(1)))
+#define H2E_AS_LDS __attribute__((address_space(3)))
+WI_INLINE u64x2 g_ld16(const u64* p) { return *(const H2E_AS_GLOBAL u64x2*)p; }
+WI_INLINE u64 g_ld8(const u64* p) { return *(const H2E_AS_GLOBAL u64*)p; }
+WI_INLINE void g_st16(u64* p, u64 x, u64 y) {
+    u64x2 v = {x, y};
+    *(H2E_AS_GLOBAL u64x2*)p = v;
+}
+WI_INLINE u64 l_ld8(const u64* p) { return *(const H2E_AS_LDS u64*)p; }
+WI_INLINE u64x2 l_ld16(const u64* p) { return *(const H2E_AS_LDS u64x2*)p; }
+WI_INLINE void l_st8(u64* p, u64 v) { *(H2E_AS_LDS u64*)p = v; }
+WI_INLINE void l_st16(u64* p, u64 x, u64 y) {
+    u64x2 v = {x, y};
+    *(H2E_AS_LDS u64x2*)p = v;
+}
 // a W value in a 16-byte aligned workspace slot
 template <int N>
 WI_INLINE Wd<N> ws_load(const u64* p) {
     Wd<N> r;
 #pragma unroll
     for (int i = 0; i < N / 2; i++) {
-        ulonglong2 t = ((const ulonglong2*)p)[i];
+        u64x2 t = g_ld16(p + 2 * i);
         r.v[2 * i] = t.x;
         r.v[2 * i + 1] = t.y;
     }
@@ -103,7 +126,15 @@ WI_INLINE Wd<N> ws_load(const u64* p) {
 template <int N>
 WI_INLINE void ws_store(u64* p, const Wd<N>& v) {
 #pragma unroll
-    for (int i = 0; i < N / 2; i++) ((ulonglong2*)p)[i] = make_ulonglong2(v.v[2 * i], v.v[2 * i + 1]);
+    for (int i = 0; i < N / 2; i++) g_st16(p + 2 * i, v.v[2 * i], v.v[2 * i + 1]);
+}
+// words of the instance inputs / the constant pool (global memory)
+template <int N>
+WI_INLINE Wd<N> g_load(const u64* p) {
+    Wd<N> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = g_ld8(p + i);
+    return r;
 }
 
 struct LC {  // lane context
@@ -130,7 +161,31 @@ struct LC {  // lane context
     // operands are mostly the results of the one or two ops before it; re-reading them from their cells misses the L2
     // (19.5 KB written per lane and sub-range against 512 B of L2 per lane) - 22 GB of the window launch's traffic.
     u64* xc = nullptr;
+    // wave-mode replay: the find_w_modulus_of_ceil_times tables in LDS ([64][H2E_MAX_L][2] limb words, then [64][4] native
+    // words).  Their index is per lane, so from constant memory they are vector loads - and a vector load waits for every
+    // older store of the wave (one counter, in order).
+    const u64* ceil_lds = nullptr;
 };
+WI_INLINE Limb ceil_limb(const LC& c, u32 t, int i) {
+    if (c.ceil_lds) {
+        u64x2 q = l_ld16(c.ceil_lds + ((size_t)t * H2E_MAX_L + i) * 2);
+        Limb r;
+        r.v[0] = q.x;
+        r.v[1] = q.y;
+        return r;
+    }
+    return wd_load<2>(c.fc->ceil_limbs[t][i]);
+}
+WI_INLINE Wd<4> ceil_native(const LC& c, u32 t) {
+    if (c.ceil_lds) {
+        const u64* p = c.ceil_lds + 64 * H2E_MAX_L * 2 + (size_t)t * 4;
+        u64x2 a = l_ld16(p), b = l_ld16(p + 2);
+        Wd<4> r;
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
+        return r;
+    }
+    return wd_load<4>(c.fc->ceil_native[t]);
+}
 
 // ------------------------------------------------------------------------------------------------
 // cell I/O
@@ -143,22 +198,21 @@ WI_INLINE u64* cell_ptr(const LC& c, u32 ref) {
     return c.select + ((size_t)(row + (rel ? c.os : 0)) * 2 + col) * 2 * c.hs;
 }
 WI_INLINE Fe ld_cell(const u64* p, u32 hs) {
-    ulonglong2 a = *(const ulonglong2*)p, b = *(const ulonglong2*)(p + hs);
+    u64x2 a = g_ld16(p), b = g_ld16(p + hs);
     Fe r;
     r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
     return r;
 }
 WI_INLINE Fe ld_fe(const LC& c, u32 ref) { return ld_cell(cell_ptr(c, ref), c.hs); }
 WI_INLINE Limb ld_limb(const LC& c, u32 ref) {  // values known to be < 2^128: the low half only
-    const ulonglong2* p = (const ulonglong2*)cell_ptr(c, ref);
-    ulonglong2 a = p[0];
+    u64x2 a = g_ld16(cell_ptr(c, ref));
     Limb r;
     r.v[0] = a.x; r.v[1] = a.y;
     return r;
 }
 // one 16-byte half of a cell.  (Plain stores: non-temporal ones made the window expansion 9 % slower - its operand
 // re-reads then miss the L2.)
-WI_INLINE void st16(u64* p, u64 x, u64 y) { *(ulonglong2*)p = make_ulonglong2(x, y); }
+WI_INLINE void st16(u64* p, u64 x, u64 y) { g_st16(p, x, y); }
 WI_INLINE void st_cell(u64* p, u32 hs, const Fe& v) {
     st16(p, v.v[0], v.v[1]);
     st16(p + hs, v.v[2], v.v[3]);
@@ -325,11 +379,11 @@ WI_INLINE IntVal<FP> ld_int_x(const LC& c, const H2EOp& op, int refpos, int whic
         const u64* p = c.xc + (size_t)(code - 1) * (2 * FP::L + 4) * 64 + threadIdx.x;
 #pragma unroll
         for (int i = 0; i < FP::L; i++) {
-            r.l[i].v[0] = p[(2 * i) * 64];
-            r.l[i].v[1] = p[(2 * i + 1) * 64];
+            r.l[i].v[0] = l_ld8(p + (2 * i) * 64);
+            r.l[i].v[1] = l_ld8(p + (2 * i + 1) * 64);
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) r.native.v[i] = p[(2 * FP::L + i) * 64];
+        for (int i = 0; i < 4; i++) r.native.v[i] = l_ld8(p + (2 * FP::L + i) * 64);
         return r;
     }
     IntVal<FP> r;
@@ -345,11 +399,11 @@ WI_INLINE void xc_put_x(const LC& c, const H2EOp& op, const Limb* l, const Fe& n
     u64* p = c.xc + (size_t)(code - 1) * (2 * FP::L + 4) * 64 + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < FP::L; i++) {
-        p[(2 * i) * 64] = l[i].v[0];
-        p[(2 * i + 1) * 64] = l[i].v[1];
+        l_st8(p + (2 * i) * 64, l[i].v[0]);
+        l_st8(p + (2 * i + 1) * 64, l[i].v[1]);
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) p[(2 * FP::L + i) * 64] = native.v[i];
+    for (int i = 0; i < 4; i++) l_st8(p + (2 * FP::L + i) * 64, native.v[i]);
 }
 // Horner composition of limbs (integer_chip.rs:217-224): sum l_i * 2^(108 i)
 template <class FP, int OW>
@@ -502,7 +556,7 @@ WI_INLINE void emit_mul_equation(const LC& c, u32 brow, u32 rrow, const IntVal<F
 template <class FP>
 WI_INLINE void op_assign_w(const LC& c, const H2EOp& op) {
     u32 slot = op.imm + ((op.flags & H2E_FLAG_INPUT_STRIDED) ? c.strand * c.input_stride : 0);
-    Wd<FP::WW> x = wd_load<FP::WW>(c.inputs + (size_t)slot * c.sw);
+    Wd<FP::WW> x = g_load<FP::WW>(c.inputs + (size_t)slot * c.sw);
     Limb l[FP::L];
     split_limbs<FP>(x, l);
     emit_assigned<FP>(c, op.base_row, op.range_row, l, native_of_w<FP>(c, x));
@@ -513,9 +567,9 @@ WI_INLINE void op_const_int(const LC& c, const H2EOp& op, bool from_input) {
     Wd<FP::WW> x;
     if (from_input) {
         u32 slot = op.imm + ((op.flags & H2E_FLAG_INPUT_STRIDED) ? c.strand * c.input_stride : 0);
-        x = wd_load<FP::WW>(c.inputs + (size_t)slot * c.sw);
+        x = g_load<FP::WW>(c.inputs + (size_t)slot * c.sw);
     } else {
-        x = wd_load<FP::WW>(c.pool + op.imm);
+        x = g_load<FP::WW>(c.pool + op.imm);
     }
     Limb l[FP::L];
     split_limbs<FP>(x, l);
@@ -936,16 +990,16 @@ WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
         case H2E_OP_ASSIGN_W: op_assign_w<FP>(c, op); break;
         case H2E_OP_ASSIGN: {
             u32 slot = op.imm + ((op.flags & H2E_FLAG_INPUT_STRIDED) ? c.strand * c.input_stride : 0);
-            rowB(c, op.base_row, 1, wd_load<4>(c.inputs + (size_t)slot * c.sw), FE0, FE0, FE0, FE0);
+            rowB(c, op.base_row, 1, g_load<4>(c.inputs + (size_t)slot * c.sw), FE0, FE0, FE0, FE0);
         } break;
         case H2E_OP_ASSIGN_BIT: {
             u32 slot = op.imm + ((op.flags & H2E_FLAG_INPUT_STRIDED) ? c.strand * c.input_stride : 0);
-            Fe v = wd_load<4>(c.inputs + (size_t)slot * c.sw);
+            Fe v = g_load<4>(c.inputs + (size_t)slot * c.sw);
             rowB(c, op.base_row, 3, v, v, FE0, FE0, FE0);
         } break;
         case H2E_OP_CONST_INT: op_const_int<FP>(c, op, false); break;
         case H2E_OP_CONST_INT_INPUT: op_const_int<FP>(c, op, true); break;
-        case H2E_OP_CONST: rowB(c, op.base_row, 1, wd_load<4>(c.pool + op.imm), FE0, FE0, FE0, FE0); break;
+        case H2E_OP_CONST: rowB(c, op.base_row, 1, g_load<4>(c.pool + op.imm), FE0, FE0, FE0, FE0); break;
         case H2E_OP_INT_ADD: op_int_add<FP>(c, op); break;
         case H2E_OP_INT_SUB: op_int_sub<FP>(c, op); break;
         case H2E_OP_INT_NEG: op_int_neg<FP>(c, op); break;
@@ -1114,11 +1168,11 @@ WI_INLINE IntVal<FP> vs_ld_int(const VSlots<FP>& vs, u32 slot) {
     const u64* p = vs.ints + (size_t)slot * VSlots<FP>::W * 64 + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < FP::L; i++) {
-        r.l[i].v[0] = p[(2 * i) * 64];
-        r.l[i].v[1] = p[(2 * i + 1) * 64];
+        r.l[i].v[0] = l_ld8(p + (2 * i) * 64);
+        r.l[i].v[1] = l_ld8(p + (2 * i + 1) * 64);
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) r.native.v[i] = p[(2 * FP::L + i) * 64];
+    for (int i = 0; i < 4; i++) r.native.v[i] = l_ld8(p + (2 * FP::L + i) * 64);
     return r;
 }
 template <class FP>
@@ -1126,40 +1180,40 @@ WI_INLINE void vs_st_int(const VSlots<FP>& vs, u32 slot, const Limb* l, const Fe
     u64* p = vs.ints + (size_t)slot * VSlots<FP>::W * 64 + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < FP::L; i++) {
-        p[(2 * i) * 64] = l[i].v[0];
-        p[(2 * i + 1) * 64] = l[i].v[1];
+        l_st8(p + (2 * i) * 64, l[i].v[0]);
+        l_st8(p + (2 * i + 1) * 64, l[i].v[1]);
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) p[(2 * FP::L + i) * 64] = native.v[i];
+    for (int i = 0; i < 4; i++) l_st8(p + (2 * FP::L + i) * 64, native.v[i]);
 }
 template <class FP>
 WI_INLINE Fe vs_ld_fe(const VSlots<FP>& vs, u32 slot) {
     Fe r;
 #pragma unroll
-    for (int i = 0; i < 4; i++) r.v[i] = vs.fes[(slot * 4 + i) * 64 + threadIdx.x];
+    for (int i = 0; i < 4; i++) r.v[i] = l_ld8(vs.fes + (slot * 4 + i) * 64 + threadIdx.x);
     return r;
 }
 template <class FP>
 WI_INLINE void vs_st_fe(const VSlots<FP>& vs, u32 slot, const Fe& v) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) vs.fes[(slot * 4 + i) * 64 + threadIdx.x] = v.v[i];
+    for (int i = 0; i < 4; i++) l_st8(vs.fes + (slot * 4 + i) * 64 + threadIdx.x, v.v[i]);
 }
 template <class FP>
 WI_INLINE IntVal<FP> vs_stage_int(const VSlots<FP>& vs, u32 unit) {   // L limb units + 2 native units
     IntVal<FP> r;
 #pragma unroll
     for (int i = 0; i < FP::L; i++) {
-        ulonglong2 q = vs.stage[(unit + i) * 64 + threadIdx.x];
+        u64x2 q = l_ld16((const u64*)(vs.stage + (unit + i) * 64 + threadIdx.x));
         r.l[i].v[0] = q.x;
         r.l[i].v[1] = q.y;
     }
-    ulonglong2 a = vs.stage[(unit + FP::L) * 64 + threadIdx.x], b = vs.stage[(unit + FP::L + 1) * 64 + threadIdx.x];
+    u64x2 a = l_ld16((const u64*)(vs.stage + (unit + FP::L) * 64 + threadIdx.x)), b = l_ld16((const u64*)(vs.stage + (unit + FP::L + 1) * 64 + threadIdx.x));
     r.native.v[0] = a.x; r.native.v[1] = a.y; r.native.v[2] = b.x; r.native.v[3] = b.y;
     return r;
 }
 template <class FP>
 WI_INLINE Fe vs_stage_fe(const VSlots<FP>& vs, u32 unit) {
-    ulonglong2 a = vs.stage[unit * 64 + threadIdx.x], b = vs.stage[(unit + 1) * 64 + threadIdx.x];
+    u64x2 a = l_ld16((const u64*)(vs.stage + unit * 64 + threadIdx.x)), b = l_ld16((const u64*)(vs.stage + (unit + 1) * 64 + threadIdx.x));
     Fe r;
     r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
     return r;
@@ -1169,7 +1223,7 @@ WI_INLINE Wd<FP::WW> vs_stage_w(const VSlots<FP>& vs, u32 unit) {
     Wd<FP::WW> r;
 #pragma unroll
     for (int i = 0; i < FP::WW / 2; i++) {
-        ulonglong2 q = vs.stage[(unit + i) * 64 + threadIdx.x];
+        u64x2 q = l_ld16((const u64*)(vs.stage + (unit + i) * 64 + threadIdx.x));
         r.v[2 * i] = q.x;
         r.v[2 * i + 1] = q.y;
     }
@@ -1414,7 +1468,7 @@ WI_INLINE void exec_vop(const VSlots<FP>& vs, const LC& c, const VHdr& h, const 
         return;
     }
     if (opc == H2E_V_CONST) {   // a pool constant: limb i in (base_row + i, col 0), native in (base_row + L, col 0)
-        Wd<FP::WW> x = wd_load<FP::WW>(c.pool + imm);
+        Wd<FP::WW> x = g_load<FP::WW>(c.pool + imm);
         Limb l[L];
         split_limbs<FP>(x, l);
         Fe native = mod_n<FP::WW>(c, x);
@@ -1555,21 +1609,25 @@ struct LVals {
 template <class FP>
 WI_INLINE IntVal<FP> lv_ld_int(const LVals<FP>& lv, u32 slot) {
     IntVal<FP> r;
-    const u64* p = lv.v + (size_t)slot * LVals<FP>::W;
+    const u64* p = lv.v + (size_t)slot * LVals<FP>::W;   // 16-byte aligned: W is even
 #pragma unroll
     for (int i = 0; i < FP::L; i++) {
-        r.l[i].v[0] = p[2 * i];
-        r.l[i].v[1] = p[2 * i + 1];
+        u64x2 q = l_ld16(p + 2 * i);
+        r.l[i].v[0] = q.x;
+        r.l[i].v[1] = q.y;
     }
-#pragma unroll
-    for (int i = 0; i < 4; i++) r.native.v[i] = p[2 * FP::L + i];
+    u64x2 a = l_ld16(p + 2 * FP::L), b = l_ld16(p + 2 * FP::L + 2);
+    r.native.v[0] = a.x; r.native.v[1] = a.y; r.native.v[2] = b.x; r.native.v[3] = b.y;
     return r;
 }
 template <class FP>
 WI_INLINE Fe lv_ld_fe(const LVals<FP>& lv, u32 slot) {
     Fe r;
-#pragma unroll
-    for (int i = 0; i < 4; i++) r.v[i] = lv.v[(size_t)slot * LVals<FP>::W + i];
+    {
+        const u64* p = lv.v + (size_t)slot * LVals<FP>::W;
+        u64x2 a = l_ld16(p), b = l_ld16(p + 2);
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
+    }
     return r;
 }
 // operands that come from cells: written by other kernels, or by an H2E_V_FULL step of this wave (behind a fence)
@@ -1605,12 +1663,9 @@ WI_INLINE void l_out_int(const LVals<FP>& lv, const LC& c, const VHdr& h, bool m
     if (dst != 0xffffu) {
         u64* p = lv.v + (size_t)dst * LVals<FP>::W;
 #pragma unroll
-        for (int i = 0; i < FP::L; i++) {
-            p[2 * i] = l[i].v[0];
-            p[2 * i + 1] = l[i].v[1];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) p[2 * FP::L + i] = native.v[i];
+        for (int i = 0; i < FP::L; i++) l_st16(p + 2 * i, l[i].v[0], l[i].v[1]);
+        l_st16(p + 2 * FP::L, native.v[0], native.v[1]);
+        l_st16(p + 2 * FP::L + 2, native.v[2], native.v[3]);
     }
 }
 template <class FP>
@@ -1624,62 +1679,34 @@ WI_INLINE void l_out_fe(const LVals<FP>& lv, const LC& c, const VHdr& h, const F
     if ((h.w[0] >> 8) & H2E_VFLAG_STORE) stB(c, h.w[5], 4, v);
     u32 dst = h.w[0] >> 16;
     if (dst != 0xffffu) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) lv.v[(size_t)dst * LVals<FP>::W + i] = v.v[i];
+        u64* p = lv.v + (size_t)dst * LVals<FP>::W;
+        l_st16(p, v.v[0], v.v[1]);
+        l_st16(p + 2, v.v[2], v.v[3]);
     }
 }
-// one lane's op of a step; `opc` is the step's opcode (wave-uniform), everything else is per lane
+// the light ops of a step (additions, selections, conditions); `opc` may differ from lane to lane (H2E_VFLAG_MIXED steps)
 template <class FP>
-WI_INLINE void exec_lop(const LVals<FP>& lv, const LC& c, u32 opc, const VHdr& h, const u32* lrefs) {
+WI_INLINE void exec_lop_light(const LVals<FP>& lv, const LC& c, u32 opc, const VHdr& h, const u32* lrefs) {
     constexpr int L = FP::L;
     u32 imm = h.w[1];
-    if (opc == H2E_V_MUL) {
-        IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs), b = l_src_int<FP>(lv, c, h, 1, lrefs);
-        Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
-        Wd<FPX<FP>::QW> dq;
-        Wd<FP::WW> rem;
-        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW, FPX<FP>::AL, FPX<FP>::AL>(A, B)), dq, rem);
-        l_out_w<FP>(lv, c, h, rem);
-    } else if (opc == H2E_V_SUB) {
+    if (opc == H2E_V_SUB) {
         IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs), b = l_src_int<FP>(lv, c, h, 1, lrefs);
         Limb s[L];
 #pragma unroll
-        for (int i = 0; i < L; i++) s[i] = wd_sub<2>(wd_add<2>(a.l[i], wd_load<2>(c.fc->ceil_limbs[imm][i])), b.l[i]);
-        l_out_int<FP>(lv, c, h, false, s, addmod_n(c, submod_n(c, a.native, b.native), wd_load<4>(c.fc->ceil_native[imm])));
+        for (int i = 0; i < L; i++) s[i] = wd_sub<2>(wd_add<2>(a.l[i], ceil_limb(c, imm, i)), b.l[i]);
+        l_out_int<FP>(lv, c, h, false, s, addmod_n(c, submod_n(c, a.native, b.native), ceil_native(c, imm)));
     } else if (opc == H2E_V_ADD) {
         IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs), b = l_src_int<FP>(lv, c, h, 1, lrefs);
         Limb s[L];
 #pragma unroll
         for (int i = 0; i < L; i++) s[i] = wd_add<2>(a.l[i], b.l[i]);
         l_out_int<FP>(lv, c, h, false, s, addmod_n(c, a.native, b.native));
-    } else if (opc == H2E_V_REDUCE) {
-        IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs);
-        Wd<FP::WW> rem;
-        u64 dsmall;
-        divrem_small<FP>(c, compose<FP, FPX<FP>::AW>(a.l), dsmall, rem);
-        l_out_w<FP>(lv, c, h, rem);
     } else if (opc == H2E_V_NEG) {
         IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs);
         Limb s[L];
 #pragma unroll
-        for (int i = 0; i < L; i++) s[i] = wd_sub<2>(wd_load<2>(c.fc->ceil_limbs[imm][i]), a.l[i]);
-        l_out_int<FP>(lv, c, h, false, s, submod_n(c, wd_load<4>(c.fc->ceil_native[imm]), a.native));
-    } else if (opc == H2E_V_MUL_SMALL) {
-        IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs);
-        Wd<1> k = wd_from_u64<1>(imm);
-        Limb s[L];
-#pragma unroll
-        for (int i = 0; i < L; i++) s[i] = wd_resize<2>(wd_mul<2, 1>(a.l[i], k));
-        l_out_int<FP>(lv, c, h, false, s, mod_n<5>(c, wd_mul<4, 1>(a.native, k)));
-    } else if (opc == H2E_V_DIV) {
-        IntVal<FP> b = l_src_int<FP>(lv, c, h, 0, lrefs), a = l_src_int<FP>(lv, c, h, 1, lrefs);
-        Wd<FPX<FP>::QW> q0;
-        Wd<FP::WW> a_red, b_red, cv;
-        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(compose<FP, FPX<FP>::AW>(a.l)), q0, a_red);
-        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(compose<FP, FPX<FP>::AW>(b.l)), q0, b_red);
-        Wd<FP::WW> binv = wd_inv_mod<FP::WW>(b_red, wd_load<FP::WW>(c.fc->w));
-        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FP::WW, FP::WW>(a_red, binv)), q0, cv);
-        l_out_w<FP>(lv, c, h, cv);
+        for (int i = 0; i < L; i++) s[i] = wd_sub<2>(ceil_limb(c, imm, i), a.l[i]);
+        l_out_int<FP>(lv, c, h, false, s, submod_n(c, ceil_native(c, imm), a.native));
     } else if (opc == H2E_V_MASK) {
         IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs);
         Fe coeff = l_src_fe<FP>(lv, c, h, 1);
@@ -1705,11 +1732,53 @@ WI_INLINE void exec_lop(const LVals<FP>& lv, const LC& c, u32 opc, const VHdr& h
 #pragma unroll
         for (int i = 0; i < FP::PW; i++) is_w = is_w && wd_eq<2>(a.l[i], wd_load<2>(c.fc->w_limbs[i]));
         l_out_fe<FP>(lv, c, h, fe_u64((all_zero || is_w) ? 1 : 0));
+    } else if (opc == H2E_V_NOT) {
+        l_out_fe<FP>(lv, c, h, submod_n(c, fe_u64(1), l_src_fe<FP>(lv, c, h, 0)));
+    } else if (opc == H2E_V_AND || opc == H2E_V_OR || opc == H2E_V_XNOR) {
+        Fe a = l_src_fe<FP>(lv, c, h, 0), b = l_src_fe<FP>(lv, c, h, 1);
+        u64 r = opc == H2E_V_AND ? (a.v[0] & b.v[0]) : opc == H2E_V_OR ? (a.v[0] | b.v[0]) : (1 ^ a.v[0] ^ b.v[0]);
+        l_out_fe<FP>(lv, c, h, fe_u64(r));
+    }
+}
+// one lane's op of a step; `opc` is the step's opcode (wave-uniform), everything else is per lane
+template <class FP>
+WI_INLINE void exec_lop(const LVals<FP>& lv, const LC& c, u32 opc, const VHdr& h, const u32* lrefs) {
+    constexpr int L = FP::L;
+    u32 imm = h.w[1];
+    if (opc == H2E_V_MUL) {
+        IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs), b = l_src_int<FP>(lv, c, h, 1, lrefs);
+        Wd<FPX<FP>::AW> A = compose<FP, FPX<FP>::AW>(a.l), B = compose<FP, FPX<FP>::AW>(b.l);
+        Wd<FPX<FP>::QW> dq;
+        Wd<FP::WW> rem;
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FPX<FP>::AW, FPX<FP>::AW, FPX<FP>::AL, FPX<FP>::AL>(A, B)), dq, rem);
+        l_out_w<FP>(lv, c, h, rem);
+    } else if (opc == H2E_V_REDUCE) {
+        IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs);
+        Wd<FP::WW> rem;
+        u64 dsmall;
+        divrem_small<FP>(c, compose<FP, FPX<FP>::AW>(a.l), dsmall, rem);
+        l_out_w<FP>(lv, c, h, rem);
+    } else if (opc == H2E_V_MUL_SMALL) {
+        IntVal<FP> a = l_src_int<FP>(lv, c, h, 0, lrefs);
+        Wd<1> k = wd_from_u64<1>(imm);
+        Limb s[L];
+#pragma unroll
+        for (int i = 0; i < L; i++) s[i] = wd_resize<2>(wd_mul<2, 1>(a.l[i], k));
+        l_out_int<FP>(lv, c, h, false, s, mod_n<5>(c, wd_mul<4, 1>(a.native, k)));
+    } else if (opc == H2E_V_DIV) {
+        IntVal<FP> b = l_src_int<FP>(lv, c, h, 0, lrefs), a = l_src_int<FP>(lv, c, h, 1, lrefs);
+        Wd<FPX<FP>::QW> q0;
+        Wd<FP::WW> a_red, b_red, cv;
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(compose<FP, FPX<FP>::AW>(a.l)), q0, a_red);
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(compose<FP, FPX<FP>::AW>(b.l)), q0, b_red);
+        Wd<FP::WW> binv = wd_inv_mod<FP::WW>(b_red, wd_load<FP::WW>(c.fc->w));
+        divrem_w<FP>(c, wd_resize<FPX<FP>::XW>(wd_mul<FP::WW, FP::WW>(a_red, binv)), q0, cv);
+        l_out_w<FP>(lv, c, h, cv);
     } else if (opc == H2E_V_HINT) {   // the canonical result comes from the predictors (one load per lane)
         u32 slot = imm + ((((h.w[0] >> 8) & H2E_VFLAG_HINT_STRIDED) != 0) ? c.strand * c.hint_stride : 0);
         l_out_w<FP>(lv, c, h, ws_load<FP::WW>(c.hints + (size_t)slot * c.ws));
     } else if (opc == H2E_V_CONST) {
-        Wd<FP::WW> x = wd_load<FP::WW>(c.pool + imm);
+        Wd<FP::WW> x = g_load<FP::WW>(c.pool + imm);
         Limb l[L];
         split_limbs<FP>(x, l);
         Fe native = mod_n<FP::WW>(c, x);
@@ -1721,12 +1790,8 @@ WI_INLINE void exec_lop(const LVals<FP>& lv, const LC& c, u32 opc, const VHdr& h
         VHdr h2 = h;
         h2.w[0] &= ~(H2E_VFLAG_STORE << 8);
         l_out_int<FP>(lv, c, h2, false, l, native);
-    } else if (opc == H2E_V_NOT) {
-        l_out_fe<FP>(lv, c, h, submod_n(c, fe_u64(1), l_src_fe<FP>(lv, c, h, 0)));
-    } else if (opc == H2E_V_AND || opc == H2E_V_OR || opc == H2E_V_XNOR) {
-        Fe a = l_src_fe<FP>(lv, c, h, 0), b = l_src_fe<FP>(lv, c, h, 1);
-        u64 r = opc == H2E_V_AND ? (a.v[0] & b.v[0]) : opc == H2E_V_OR ? (a.v[0] | b.v[0]) : (1 ^ a.v[0] ^ b.v[0]);
-        l_out_fe<FP>(lv, c, h, fe_u64(r));
+    } else {
+        exec_lop_light<FP>(lv, c, opc, h, lrefs);
     }
 }
 
@@ -1796,11 +1861,165 @@ __global__ void __launch_bounds__(64 * H2E_LEVEL_WAVES) h2e_replay_levels(H2ELau
                 c.active = true;
                 __threadfence();
             }
+        } else if ((w0 >> 8) & H2E_VFLAG_MIXED) {
+            exec_lop_light<FP>(lv, c, h.w[0] & 0xffu, h, L.lrefs);   // light ops of any mix: every lane its own opcode
         } else if ((h.w[0] & 0xffu) != H2E_V_NOP) {
             exec_lop<FP>(lv, c, opc, h, L.lrefs);   // (a round without its op costs 0.44 us; with it 3.0 us on average)
         }
         __syncthreads();   // the round's values are in their slots
     }
+}
+
+// Wave-mode level replay: ONE wave replays one (instance, strand); a round is up to 64 independent ops of one cost class
+// (host: schedule_classes in h2e_capi.cpp), values live in the wave's LDS slots.  What the four-wave kernel above paid
+// per round - a workgroup barrier, and a wait for every global store of the round before the next round's records (and
+// the per-lane ceil-table constants) could be read: loads and stores share one in-order counter - is gone:
+//  * the compact record stream goes through two LDS chunk buffers, filled by LDS-DMA one chunk ahead; the wave waits
+//    for memory once per chunk (H2E_WCHUNK records, some 20 rounds), not once per round;
+//  * the ceil tables sit in LDS; nothing in a round's body loads from global memory (a few hundred ops of a pairing
+//    check read cells of other kernels - they do wait);
+//  * result cells that later kernels need are stored and never waited for.
+#ifdef H2E_WAVE_STAMPS
+// diagnostic build only (exp/wave_stamps.sh): cycles and rounds per round kind of workgroup 0, read back by h2e_engine_wave_stamps
+__device__ unsigned long long g_wave_stamps[32];
+extern "C" int H2E_UNIT(h2e_engine_wave_stamps)(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_stamps), sizeof(g_wave_stamps));
+}
+#define WAVE_STAMP() __builtin_amdgcn_s_memtime()
+#endif
+template <class FP>
+__global__ void __launch_bounds__(64) h2e_replay_wave(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
+    const u32 lane = threadIdx.x;
+    u32 unit = blockIdx.x;
+    u32 instance = unit / L.n_strands, strand = unit % L.n_strands;
+    InstanceDesc d = inst[instance];
+    LC c;
+    c.base = d.base;
+    c.range = d.range;
+    c.select = d.select;
+    c.inputs = d.inputs;
+    c.status = d.status;
+    c.ob = L.strand_base0 + strand * L.delta_base;
+    c.orr = L.strand_range0 + strand * L.delta_range;
+    c.os = L.strand_select0 + strand * L.delta_select;
+    c.params = L.params + (size_t)strand * L.n_params;
+    c.aux = L.aux;
+    c.pool = L.const_pool;
+    c.fc = &g_fc[FP::ID];
+    c.strand = strand;
+    c.input_stride = L.input_stride;
+    c.sw = L.slot_words;
+    c.hints = d.hints;
+    c.ws = d.ws;
+    c.hint_stride = L.hint_stride;
+    c.sel = d.sel;
+    c.sel_stride = L.sel_stride;
+    c.hs = 2 * n_instances;
+    c.active = true;
+    extern __shared__ ulonglong2 w_dyn[];
+    H2EVRec* rbuf = (H2EVRec*)w_dyn;                                   // [2][H2E_WCHUNK]
+    u64* ceil_tab = (u64*)(rbuf + 2 * H2E_WCHUNK);                      // [64][H2E_MAX_L][2] + [64][4]
+    constexpr u32 CEIL_WORDS = 64 * H2E_MAX_L * 2 + 64 * 4;
+    LVals<FP> lv;
+    lv.v = ceil_tab + CEIL_WORDS;
+    for (u32 i = lane; i < 64 * H2E_MAX_L * 2; i += 64) l_st8(ceil_tab + i, ((const u64*)c.fc->ceil_limbs)[i]);
+    for (u32 i = lane; i < 64 * 4; i += 64) l_st8(ceil_tab + 64 * H2E_MAX_L * 2 + i, ((const u64*)c.fc->ceil_native)[i]);
+    c.ceil_lds = ceil_tab;
+    __builtin_amdgcn_s_setprio(3);
+    const u32 n_chunks = L.l_recs / H2E_WCHUNK;
+    auto load_chunk = [&](u32 chunk) {   // H2E_WCHUNK records = 8 KB: 8 LDS-DMA pieces of 16 bytes per lane
+        const char* src = (const char*)(L.lrecs + (size_t)chunk * H2E_WCHUNK);
+        char* dst = (char*)(rbuf + (size_t)(chunk & 1u) * H2E_WCHUNK);
+#pragma unroll
+        for (u32 k = 0; k < H2E_WCHUNK * 32u / 1024u; k++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * 1024u + lane * 16u),
+                                             (__attribute__((address_space(3))) void*)(dst + k * 1024u), 16, 0, 0);
+    };
+    load_chunk(0);
+    if (n_chunks > 1) load_chunk(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    u32 cur_chunk = 0;
+    const uint2* rounds = (const uint2*)L.lrounds;
+#ifdef H2E_WAVE_STAMPS
+    unsigned long long st_cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_n[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_light[4] = {0, 0, 0, 0};
+#endif
+    for (u32 round = 0; round < L.l_steps; round++) {
+#ifdef H2E_WAVE_STAMPS
+        unsigned long long t_begin = WAVE_STAMP();
+#endif
+        uint2 rd = rounds[round];                      // wave-uniform: scalar loads
+        u32 first = __builtin_amdgcn_readfirstlane(rd.x), meta = __builtin_amdgcn_readfirstlane(rd.y);
+        u32 cnt = meta & 0xffu, kind = meta >> 8;
+        u32 chunk = first / H2E_WCHUNK;
+        if (chunk != cur_chunk) {
+            // this chunk was requested a chunk ago: the wait is for it and for the stores still under way
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur_chunk = chunk;
+            if (chunk + 1 < n_chunks) load_chunk(chunk + 1);   // into the buffer the wave has just left
+#ifdef H2E_WAVE_STAMPS
+            unsigned long long t_sw = WAVE_STAMP();
+            st_cyc[5] += t_sw - t_begin;
+            st_n[5]++;
+            t_begin = t_sw;
+#endif
+        }
+#ifdef H2E_WAVE_STAMPS
+        unsigned long long t_hdr = WAVE_STAMP(), t_rec = t_hdr, t_exec = t_hdr;
+#endif
+        if (kind == H2E_V_FULL) {
+            // a tape op that goes through cells, run by lane 0: what it reads may have been stored in earlier rounds, and
+            // later rounds read its rows
+            const H2E_AS_LDS u32* rp = (const H2E_AS_LDS u32*)(rbuf + (size_t)(chunk & 1u) * H2E_WCHUNK + first % H2E_WCHUNK);
+            u32 op_index = __builtin_amdgcn_readfirstlane(rp[1]);
+            __threadfence();
+            H2EOp op = L.tape[op_index];
+            op.opcode = (uint16_t)__builtin_amdgcn_readfirstlane(op.opcode);
+            c.active = lane == 0;
+            exec_op<FP, false>(c, op);
+            c.active = true;
+            __threadfence();
+        } else if (lane < cnt) {
+            const H2E_AS_LDS u32x4* rp = (const H2E_AS_LDS u32x4*)(rbuf + (size_t)(chunk & 1u) * H2E_WCHUNK + first % H2E_WCHUNK + lane);
+            u32x4 a = rp[0], b = rp[1];
+            VHdr h;
+            h.w[0] = a.x; h.w[1] = a.y; h.w[2] = a.z; h.w[3] = a.w;
+            h.w[4] = b.x; h.w[5] = b.y; h.w[6] = b.z; h.w[7] = b.w;
+#ifdef H2E_WAVE_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            t_rec = WAVE_STAMP();
+#endif
+            if (kind == 0) exec_lop_light<FP>(lv, c, h.w[0] & 0xffu, h, L.lrefs);
+            else exec_lop<FP>(lv, c, kind, h, L.lrefs);
+#ifdef H2E_WAVE_STAMPS
+            t_exec = WAVE_STAMP();
+#endif
+        }
+        __syncthreads();   // (one wave: no barrier instruction, only the LDS accesses of the round are ordered)
+#ifdef H2E_WAVE_STAMPS
+        {
+            u32 k = kind == 0 ? 0u : kind == H2E_V_MUL ? 2u : kind == H2E_V_DIV ? 3u : kind == H2E_V_FULL ? 4u : 1u;
+            unsigned long long t_end = WAVE_STAMP();
+            st_cyc[k] += t_end - t_begin;
+            st_n[k]++;
+            if (kind == 0 && lane == 0) {   // light rounds, lane 0's view: header, record, op, barrier
+                st_light[0] += t_hdr - t_begin;
+                st_light[1] += t_rec - t_hdr;
+                st_light[2] += t_exec - t_rec;
+                st_light[3] += t_end - t_exec;
+            }
+        }
+#endif
+    }
+#ifdef H2E_WAVE_STAMPS
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 8; k++) {
+            g_wave_stamps[k] = st_cyc[k];
+            g_wave_stamps[8 + k] = st_n[k];
+            if (k < 4) g_wave_stamps[16 + k] = st_light[k];
+        }
+#endif
 }
 
 // ================================================================================================
@@ -2909,6 +3128,12 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
     if (xcache_on) launch_x.rel_refs |= 4u;
     if (g_tune[1] & 2) launch_x.rel_refs |= 8u;
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
+    if ((mode & 1) && launch->lrecs && launch->l_pair == 2) {                                                                   \
+        hipLaunchKernelGGL(h2e_replay_wave<FP>, dim3(n_instances * launch->n_strands), dim3(64),                                \
+                           (size_t)2 * H2E_WCHUNK * 32 + (64 * H2E_MAX_L * 2 + 64 * 4) * 8 + (size_t)launch->l_slots * LVals<FP>::W * 8, \
+                           stream, *launch, inst, n_instances);                                                                \
+        mode &= ~1;                                                                                                            \
+    }                                                                                                                          \
     if ((mode & 1) && launch->lrecs) {                                                                                         \
         hipLaunchKernelGGL(h2e_replay_levels<FP>, dim3((n_instances * launch->n_strands + (launch->l_pair ? 1 : 0)) / (launch->l_pair ? 2 : 1)), \
                            dim3(64 * H2E_LEVEL_WAVES), (size_t)launch->l_slots * LVals<FP>::W * 8 * (launch->l_pair ? 2 : 1), stream, \

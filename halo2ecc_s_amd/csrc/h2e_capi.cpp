@@ -8,6 +8,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <cstring>
 #include "../../include/h2e.h"
 #include "recorder_pairing.hpp"
 
@@ -128,8 +129,11 @@ struct h2e_program {
     std::vector<H2EVRec> h_lrecs;               // 64 records per step (lane l of a step runs record 64 * step + l)
     std::vector<uint32_t> h_lrefs;              // cell refs of global integer operands
     std::vector<uint32_t> seg_l_begin, seg_l_steps, seg_l_slots, seg_l_pair;
+    std::vector<uint32_t> h_lrounds;            // wave mode: per round (first record, count | kind << 8)
+    std::vector<uint32_t> seg_lr_begin, seg_l_recs;
     H2EVRec* d_lrecs = nullptr;
     uint32_t* d_lrefs = nullptr;
+    uint32_t* d_lrounds = nullptr;
     int64_t tail_from = -1;   // first segment of the program's serial tail (runs on the job slot's side stream), -1: none
     uint8_t* d_flags[3] = {nullptr, nullptr, nullptr};   // assigned / permute bytes on the device (h2e_export masks with them)
     // shape artefacts on the device (h2e_export_fixed / h2e_export_copy_constraints), uploaded on first use
@@ -151,6 +155,7 @@ struct h2e_program {
             (void)hipFree(d_vpieces);
             (void)hipFree(d_lrecs);
             (void)hipFree(d_lrefs);
+            (void)hipFree(d_lrounds);
             for (int i = 0; i < 3; i++) (void)hipFree(d_flags[i]);
         }
         for (int i = 0; i < 3; i++) (void)hipFree(d_fix[i]);
@@ -373,6 +378,8 @@ struct h2e_program {
         seg_l_steps.assign(r.segments.size(), 0);
         seg_l_slots.assign(r.segments.size(), 0);
         seg_l_pair.assign(r.segments.size(), 0);
+        seg_lr_begin.assign(r.segments.size(), 0);
+        seg_l_recs.assign(r.segments.size(), 0);
         for (auto& c : cs) compile_replay(c.sg, c.ops, c.n_ops, c.first, c.last, [&](uint32_t region, uint32_t row) { return producer(c, region, row); });
     }
 
@@ -674,7 +681,7 @@ struct h2e_program {
                     if (level[a] != level[b]) return level[a] < level[b];
                     return vop_of(a) < vop_of(b);
                 });
-                const size_t NW = H2E_LEVEL_WAVES;
+                size_t NW = H2E_LEVEL_WAVES;   // steps (waves) per round; 1 in wave mode
                 std::vector<uint32_t> step_of(alive.size(), 0);   // the *round* an op runs in (see below)
                 std::vector<std::vector<uint32_t>> steps;            // steps[NW * round + wave]: the ops one wave runs in a round
                 std::vector<int> lslot;
@@ -686,10 +693,10 @@ struct h2e_program {
                 // average: one instance leaves two thirds of every wave instruction idle).  Otherwise one instance per
                 // workgroup and steps of 64.
                 bool paired = false;
+                std::function<bool(int)> alloc_slots;
                 auto schedule = [&](size_t step_ops, int cap) -> bool {
                 steps.clear();
                 std::fill(step_of.begin(), step_of.end(), 0u);
-                slot_cap = cap;
                 // rounds: H2E_LEVEL_WAVES waves share an instance's value slots; in a round each wave runs one step (up to 64
                 // ops of one opcode), all steps of a round come from the same level, a barrier separates rounds.  An op
                 // that goes through cells (V_FULL) is a round of its own.
@@ -728,6 +735,190 @@ struct h2e_program {
                         for (uint32_t pos : lvl_steps[k]) step_of[pos] = (uint32_t)rd;
                     }
                 }
+                return alloc_slots(cap);
+                };   // schedule
+                // ---- cost-class rounds (default) ---------------------------------------------------------------------
+                // Rounds by level put a product into 62 % of the rounds of a pairing check although its multiplicative depth
+                // is a tenth of its depth: an Fq12 product is one level of int_mul between a dozen levels of int_add / int_sub /
+                // reduce, and ALAP levels scatter the products of independent branches over all of them.  A round costs what
+                // its most expensive lane costs (a product ~2.5 us, a reduce ~1 us, an addition ~0.5 us), so the rounds are
+                // built by cost class instead: walking the dependency graph from the results backwards (as late as possible:
+                // a value is made just before its first use, which keeps the value slots few), a round takes every ready op of
+                // the *cheapest* class that has ready ops - expensive ops wait until nothing cheaper can go, and so meet the
+                // products of the other branches in one round.  Light ops of different opcodes share a step (the kernel
+                // dispatches them per lane: H2E_VFLAG_MIXED); products, reduces and divisions keep one opcode per step.
+                auto cls_of = [&](uint32_t pos) -> int {   // 0 light, 1 medium, 2 heavy, 3 through cells
+                    switch (vop_of(pos)) {
+                        case H2E_V_FULL: return 3;
+                        case H2E_V_MUL: case H2E_V_DIV: return 2;
+                        case H2E_V_REDUCE: case H2E_V_MUL_SMALL: case H2E_V_CONST: case H2E_V_HINT: return 1;
+                        default: return 0;
+                    }
+                };
+                std::vector<std::vector<uint32_t>> preds(alive.size()), succs(alive.size());
+                auto build_deps = [&]() {
+                    if (!succs.empty() && !preds.empty() && (!preds[alive.size() - 1].empty() || !succs[0].empty())) return;
+                    for (uint32_t pos = 0; pos < alive.size(); pos++) {
+                        const H2EOp& op = ops[alive[pos]];
+                        auto add = [&](uint32_t pp) {
+                            if (pp == pos || pp == 0xffffffffu) return;
+                            if (std::find(preds[pos].begin(), preds[pos].end(), pp) != preds[pos].end()) return;
+                            preds[pos].push_back(pp);
+                            succs[pp].push_back(pos);
+                        };
+                        for (int q = 0; q < 3; q++)
+                            if (dec[pos].val[q] >= 0) add(alive_pos[dec[pos].val[q] / 2]);
+                        for (int q = 0; q < H2E_OP_MAX_REFS; q++) {
+                            int wtr = writer_of(op.refs[q]);
+                            if (wtr >= 0 && (uint32_t)wtr != alive[pos] && alive_pos[wtr] != 0xffffffffu && alive_pos[wtr] < pos) add(alive_pos[wtr]);
+                        }
+                    }
+                };
+                double modelled_us = 0;
+                auto schedule_classes = [&](size_t step_ops, int cap, int policy) -> bool {
+                    build_deps();
+                    steps.clear();
+                    std::fill(step_of.begin(), step_of.end(), 0u);
+                    const size_t n = alive.size();
+                    // sinks (results nothing in the replay reads: they are only stored) do not take part in the backward walk:
+                    // at the end of the program they would pin their operands' slots; they are placed forward afterwards
+                    std::vector<uint8_t> is_sink(n, 0);
+                    for (uint32_t pos = 0; pos < n; pos++) is_sink[pos] = succs[pos].empty() ? 1 : 0;
+                    std::vector<uint32_t> left(n, 0);
+                    for (uint32_t pos = 0; pos < n; pos++)
+                        for (uint32_t s : succs[pos])
+                            if (!is_sink[s]) left[pos]++;
+                    // ready ops by class; an op released while round r is formed may go into round r - 1 (backwards) at the earliest
+                    std::vector<uint32_t> ready[4], released;
+                    std::vector<uint8_t> done(n, 0);
+                    size_t n_left = 0;
+                    for (uint32_t pos = 0; pos < n; pos++) {
+                        if (is_sink[pos]) {   // a sink whose operands are sinks' operands only: its preds count it as scheduled
+                            continue;
+                        }
+                        n_left++;
+                        if (left[pos] == 0) ready[cls_of(pos)].push_back(pos);
+                    }
+                    // sinks with non-sink consumers do not exist; sinks release their preds right away
+                    std::vector<std::vector<std::vector<uint32_t>>> rounds_rev;   // [round][step] -> ops
+                    std::vector<int> round_cls_rev;
+                    auto take_steps = [&](std::vector<uint32_t>& pool, bool uniform_vop, std::vector<std::vector<uint32_t>>& rsteps) {
+                        // as many steps as the round has waves left; ops that do not fit stay in the pool
+                        std::vector<uint32_t> rest;
+                        if (!uniform_vop) {
+                            size_t i = 0;
+                            while (i < pool.size() && rsteps.size() < NW) {
+                                size_t j = std::min(pool.size(), i + step_ops);
+                                rsteps.emplace_back(pool.begin() + i, pool.begin() + j);
+                                i = j;
+                            }
+                            rest.assign(pool.begin() + i, pool.end());
+                        } else {
+                            std::stable_sort(pool.begin(), pool.end(), [&](uint32_t a, uint32_t b) { return vop_of(a) < vop_of(b); });
+                            size_t i = 0;
+                            while (i < pool.size()) {
+                                size_t j = i + 1;
+                                while (j < pool.size() && j - i < step_ops && vop_of(pool[j]) == vop_of(pool[i])) j++;
+                                if (rsteps.size() < NW) rsteps.emplace_back(pool.begin() + i, pool.begin() + j);
+                                else rest.insert(rest.end(), pool.begin() + i, pool.begin() + j);
+                                i = j;
+                            }
+                        }
+                        pool.swap(rest);
+                    };
+                    while (n_left > 0) {
+                        std::vector<std::vector<uint32_t>> rsteps;
+                        int rc = -1;
+                        if (!ready[0].empty()) {
+                            rc = 0;
+                            take_steps(ready[0], false, rsteps);
+                        } else if (!ready[3].empty()) {
+                            rc = 3;
+                            rsteps.push_back({ready[3].back()});
+                            ready[3].pop_back();
+                        } else if (policy == 0 ? !ready[1].empty() : (ready[2].empty() && !ready[1].empty())) {
+                            rc = 1;   // policy 0: cheapest class first; policy 1: reduces ride along with products when both are ready
+                            take_steps(ready[1], true, rsteps);
+                        } else if (!ready[2].empty()) {
+                            rc = 2;
+                            take_steps(ready[2], true, rsteps);
+                            if (policy == 1 && rsteps.size() < NW) take_steps(ready[1], true, rsteps);
+                        } else {
+                            throw std::runtime_error("replay compile: class scheduler stalled");
+                        }
+                        for (auto& st : rsteps)
+                            for (uint32_t pos : st) {
+                                done[pos] = 1;
+                                n_left--;
+                                for (uint32_t pp : preds[pos])
+                                    if (--left[pp] == 0) released.push_back(pp);
+                            }
+                        for (uint32_t pp : released) ready[cls_of(pp)].push_back(pp);
+                        released.clear();
+                        rounds_rev.push_back(std::move(rsteps));
+                        round_cls_rev.push_back(rc);
+                    }
+                    // forward order
+                    std::vector<std::vector<std::vector<uint32_t>>> rounds(rounds_rev.rbegin(), rounds_rev.rend());
+                    std::vector<int> round_cls(round_cls_rev.rbegin(), round_cls_rev.rend());
+                    std::vector<uint32_t> round_of(n, 0);
+                    for (size_t rd = 0; rd < rounds.size(); rd++)
+                        for (auto& st : rounds[rd])
+                            for (uint32_t pos : st) round_of[pos] = (uint32_t)rd;
+                    // sinks: the first round after their operands that can take them without getting more expensive
+                    for (uint32_t pos = 0; pos < n; pos++) {
+                        if (!is_sink[pos]) continue;
+                        size_t rd0 = 0;
+                        for (uint32_t pp : preds[pos]) {
+                            if (is_sink[pp] && !done[pp]) throw std::runtime_error("replay compile: sink reads an unplaced sink");
+                            rd0 = std::max<size_t>(rd0, (size_t)round_of[pp] + 1);
+                        }
+                        int c = cls_of(pos);
+                        uint32_t vop = vop_of(pos);
+                        bool placed = false;
+                        for (size_t rd = rd0; rd < rounds.size() && !placed; rd++) {
+                            if (round_cls[rd] == 3 || c == 3) continue;
+                            if (round_cls[rd] < c) continue;   // would make the round more expensive
+                            for (auto& st : rounds[rd]) {
+                                bool light_step = cls_of(st[0]) == 0;
+                                if (st.size() < step_ops && ((c == 0 && light_step) || (c != 0 && vop_of(st[0]) == vop))) {
+                                    st.push_back(pos);
+                                    placed = true;
+                                    break;
+                                }
+                            }
+                            if (!placed && rounds[rd].size() < NW) {
+                                rounds[rd].push_back({pos});
+                                placed = true;
+                            }
+                            if (placed) round_of[pos] = (uint32_t)rd;
+                        }
+                        if (!placed) {
+                            rounds.push_back({{pos}});
+                            round_cls.push_back(c);
+                            round_of[pos] = (uint32_t)rounds.size() - 1;
+                        }
+                        done[pos] = 1;
+                    }
+                    size_t cnt[4] = {0, 0, 0, 0};
+                    for (size_t rd = 0; rd < rounds.size(); rd++) {
+                        for (size_t w = 0; w < NW; w++) steps.emplace_back();
+                        // heavier steps first, rotated over the waves like the level rounds
+                        for (size_t k = 0; k < rounds[rd].size(); k++) {
+                            steps[rd * NW + (round_cls[rd] == 3 ? k : (k % NW + rd) % NW)] = rounds[rd][k];
+                            for (uint32_t pos : rounds[rd][k]) step_of[pos] = (uint32_t)rd;
+                        }
+                        cnt[round_cls[rd]]++;
+                    }
+                    n_rounds = rounds.size();
+                    modelled_us = 0.55 * cnt[0] + 1.2 * cnt[1] + 3.0 * cnt[2] + 3.0 * cnt[3];
+                    if (dbg_env("H2E_DUMP_TAPE"))
+                        fprintf(stderr, "   class rounds (policy %d, steps of %zu): %zu light, %zu medium, %zu heavy, %zu through cells = %zu rounds, modelled %.2f ms\n",
+                                policy, step_ops, cnt[0], cnt[1], cnt[2], cnt[3], n_rounds, modelled_us * 1e-3);
+                    return alloc_slots(cap);
+                };
+                alloc_slots = [&](int cap) -> bool {
+                slot_cap = cap;
                 n_rounds = steps.size() / NW;
                 // value slots over the round order: a slot freed in round r is reusable from round r + 1
                 std::vector<uint32_t> last_step(2 * (size_t)n_ops, 0);
@@ -764,14 +955,115 @@ struct h2e_program {
                 }
                 return fits;
                 };   // schedule
+                // A/B knobs of the program compiler, read when a program is recorded (never while a run is queued):
+                // H2E_LEVEL_MODE=pair (default) | single | wave : kernel shape - four waves and two / one instance(s) per workgroup
+                //     (h2e_replay_levels) | one wave per instance, no barriers, compact records streamed through LDS (h2e_replay_wave:
+                //     measured 26.5 vs 24.3 ms for 64 bn256 checks - a light round is ~3 k cycles of multi-word additions either way);
+                // H2E_LEVEL_SCHED=levels|classes0|classes1 (default: the cheaper of the two class policies by the cost model;
+                //     `levels` only with the four-wave kernels)
+                bool by_classes = true, wave_mode = false;
                 {
                     const uint32_t slot_bytes = (2 * (uint32_t)L + 4) * 8;
-                    paired = schedule(32, (int)((160u * 1024 - 4u * 1024) / 2 / slot_bytes));
-                    if (!paired) eligible = schedule(64, (int)((160u * 1024 - 30u * 1024) / slot_bytes));
+                    const int cap_pair = (int)((160u * 1024 - 4u * 1024) / 2 / slot_bytes), cap_single = (int)((160u * 1024 - 30u * 1024) / slot_bytes);
+                    const char* mode = getenv("H2E_LEVEL_SCHED");
+                    const char* kmode = getenv("H2E_LEVEL_MODE");
+                    const bool allow_pair = !(kmode && !strcmp(kmode, "single"));
+                    wave_mode = kmode && !strcmp(kmode, "wave") && !(mode && !strcmp(mode, "levels"));
+                    int forced = mode && !strcmp(mode, "classes0") ? 0 : mode && !strcmp(mode, "classes1") ? 1 : -1;
+                    auto best_policy = [&](size_t step_ops, int cap) -> bool {
+                        double best = 0;
+                        int pick = -1;
+                        for (int pol = 0; pol < 2; pol++) {
+                            if (forced >= 0 && pol != forced) continue;
+                            if (NW == 1 && pol == 1) continue;   // one step per round: nothing can ride along
+                            if (schedule_classes(step_ops, cap, pol) && (pick < 0 || modelled_us < best)) {
+                                pick = pol;
+                                best = modelled_us;
+                            }
+                        }
+                        if (pick < 0) return false;
+                        return schedule_classes(step_ops, cap, pick);
+                    };
+                    if (wave_mode) {
+                        NW = 1;
+                        // (chunk buffers, ceil tables and a margin for other workgroups' static LDS come off the CU's 160 KB)
+                        eligible = best_policy(64, (int)((160u * 1024 - 2u * H2E_WCHUNK * 32u - 8u * 1024) / slot_bytes));
+                    } else if (mode && !strcmp(mode, "levels")) {
+                        by_classes = false;
+                        paired = allow_pair && schedule(32, cap_pair);
+                        if (!paired) eligible = schedule(64, cap_single);
+                    } else {
+                        paired = allow_pair && best_policy(32, cap_pair);
+                        if (!paired) eligible = best_policy(64, cap_single);
+                    }
                 }
                 if (!eligible && dbg_env("H2E_DUMP_TAPE"))
                     fprintf(stderr, "segment %zu: level-parallel replay needs more than %d value slots (depth %u, %zu rounds)\n", si, slot_cap, depth, n_rounds);
-                if (eligible) {
+                // one op of the schedule as a level record
+                auto make_rec = [&](uint32_t pos, bool mixed) -> H2EVRec {
+                    H2EVRec h{{0, 0, 0, 0, 0, 0, 0, 0}};
+                    uint32_t i = alive[pos];
+                    const H2EOp& op = ops[i];
+                    int k = kind_of(op);
+                    uint32_t vop = vop_of(pos), vflags = 0;
+                    bool store = !(op.flags & H2E_FLAG_LOCAL_RESULT) || vals[2 * (size_t)i].force_store;
+                    if (op.opcode == H2E_OP_AND || op.opcode == H2E_OP_OR || op.opcode == H2E_OP_XNOR || op.opcode == H2E_OP_BISEC_INT)
+                        store = true;
+                    if (store) vflags |= H2E_VFLAG_STORE;
+                    if (vop == H2E_V_HINT && (op.flags & H2E_FLAG_HINT_STRIDED)) vflags |= H2E_VFLAG_HINT_STRIDED;
+                    if (mixed) vflags |= H2E_VFLAG_MIXED;
+                    int dsl = lslot[2 * (size_t)i];
+                    h.w[0] = vop | (vflags << 8) | ((uint32_t)(dsl >= 0 ? dsl : 0xffff) << 16);
+                    h.w[1] = vop == H2E_V_FULL ? i : op.imm;   // V_FULL: index of the tape op (segment relative)
+                    h.w[5] = k == K_FE ? fe_row(op) : op.base_row;
+                    h.w[6] = op.range_row;
+                    if (vop != H2E_V_FULL) {
+                        Opd o[3];
+                        int n = operands(op, o);
+                        for (int q = 0; q < n; q++) {
+                            int v = dec[pos].val[q];
+                            if (v >= 0) {
+                                h.w[7] |= (uint32_t)(o[q].is_int ? H2E_VSRC_INT_SLOT : H2E_VSRC_FE_SLOT) << (3 * q);
+                                h.w[2 + q] = (uint32_t)lslot[v];
+                            } else {
+                                h.w[7] |= (uint32_t)H2E_VSRC_GLOBAL << (3 * q);
+                                if (o[q].is_int) {
+                                    h.w[2 + q] = (uint32_t)h_lrefs.size();
+                                    for (int j = 0; j <= L; j++) h_lrefs.push_back(op.refs[o[q].refpos + j]);
+                                } else {
+                                    h.w[2 + q] = o[q].ref;
+                                }
+                            }
+                        }
+                    }
+                    return h;
+                };
+                if (eligible && wave_mode) {
+                    // compact records in round order, padded so that no round straddles an H2E_WCHUNK-record chunk (the kernel
+                    // streams the records through two LDS chunk buffers); per round: first record, count | kind << 8
+                    // (kind: 0 = light ops of mixed opcodes, else the round's one opcode)
+                    while (h_lrecs.size() % H2E_WCHUNK) h_lrecs.push_back(H2EVRec{{H2E_V_NOP, 0, 0, 0, 0, 0, 0, 0}});
+                    seg_l_begin[si] = (uint32_t)h_lrecs.size();
+                    seg_lr_begin[si] = (uint32_t)h_lrounds.size();
+                    seg_l_steps[si] = (uint32_t)n_rounds;
+                    seg_l_slots[si] = (uint32_t)std::max(1, n_slots);
+                    seg_l_pair[si] = 2u;
+                    for (size_t rd = 0; rd < n_rounds; rd++) {
+                        auto& stp = steps[rd];
+                        if (stp.empty() || stp.size() > 64) throw std::runtime_error("replay compile: bad wave round");
+                        size_t at = h_lrecs.size() - seg_l_begin[si];
+                        if (at % H2E_WCHUNK + stp.size() > H2E_WCHUNK)
+                            while ((h_lrecs.size() - seg_l_begin[si]) % H2E_WCHUNK) h_lrecs.push_back(H2EVRec{{H2E_V_NOP, 0, 0, 0, 0, 0, 0, 0}});
+                        at = h_lrecs.size() - seg_l_begin[si];
+                        const bool mixed = cls_of(stp[0]) == 0;
+                        h_lrounds.push_back((uint32_t)at);
+                        h_lrounds.push_back((uint32_t)stp.size() | ((mixed ? 0u : vop_of(stp[0])) << 8));
+                        for (uint32_t pos : stp) h_lrecs.push_back(make_rec(pos, mixed));
+                    }
+                    while ((h_lrecs.size() - seg_l_begin[si]) % H2E_WCHUNK) h_lrecs.push_back(H2EVRec{{H2E_V_NOP, 0, 0, 0, 0, 0, 0, 0}});
+                    seg_l_recs[si] = (uint32_t)(h_lrecs.size() - seg_l_begin[si]);
+                }
+                if (eligible && !wave_mode) {
                     seg_l_begin[si] = (uint32_t)h_lrecs.size();
                     seg_l_steps[si] = (uint32_t)n_rounds;
                     seg_l_slots[si] = (uint32_t)std::max(1, n_slots);
@@ -779,55 +1071,28 @@ struct h2e_program {
                     for (size_t sidx = 0; sidx < steps.size(); sidx++) {
                         auto& stp = steps[sidx];
                         // the other waves of a V_FULL round fence their stores before the barrier (lane 0 of their NOP step says so)
-                        const auto& lead = steps[sidx / NW * NW];
-                        bool full_round = !lead.empty() && vop_of(lead[0]) == H2E_V_FULL;
+                        bool full_round = false;
+                        for (size_t w = 0; w < NW; w++) {
+                            const auto& other = steps[sidx / NW * NW + w];
+                            full_round = full_round || (!other.empty() && vop_of(other[0]) == H2E_V_FULL);
+                        }
                         const size_t step_lanes = paired ? 32 : 64;
+                        // a step of light ops holds any mix of their opcodes (class rounds): the kernel dispatches per lane
+                        const bool mixed = by_classes && !stp.empty() && cls_of(stp[0]) == 0;
                         std::vector<H2EVRec> step_recs;
                         for (size_t lane = 0; lane < step_lanes; lane++) {
                             H2EVRec h{{H2E_V_NOP | ((full_round && lane == 0) ? (H2E_VFLAG_FENCE << 8) : 0u), 0, 0, 0, 0, 0, 0, 0}};
-                            if (lane < stp.size()) {
-                                uint32_t pos = stp[lane], i = alive[pos];
-                                const H2EOp& op = ops[i];
-                                int k = kind_of(op);
-                                uint32_t vop = vop_of(pos), vflags = 0;
-                                bool store = !(op.flags & H2E_FLAG_LOCAL_RESULT) || vals[2 * (size_t)i].force_store;
-                                if (op.opcode == H2E_OP_AND || op.opcode == H2E_OP_OR || op.opcode == H2E_OP_XNOR || op.opcode == H2E_OP_BISEC_INT)
-                                    store = true;
-                                if (store) vflags |= H2E_VFLAG_STORE;
-                                if (vop == H2E_V_HINT && (op.flags & H2E_FLAG_HINT_STRIDED)) vflags |= H2E_VFLAG_HINT_STRIDED;
-                                int dsl = lslot[2 * (size_t)i];
-                                h.w[0] = vop | (vflags << 8) | ((uint32_t)(dsl >= 0 ? dsl : 0xffff) << 16);
-                                h.w[1] = vop == H2E_V_FULL ? i : op.imm;   // V_FULL: index of the tape op (segment relative)
-                                h.w[5] = k == K_FE ? fe_row(op) : op.base_row;
-                                h.w[6] = op.range_row;
-                                if (vop != H2E_V_FULL) {
-                                    Opd o[3];
-                                    int n = operands(op, o);
-                                    for (int q = 0; q < n; q++) {
-                                        int v = dec[pos].val[q];
-                                        if (v >= 0) {
-                                            h.w[7] |= (uint32_t)(o[q].is_int ? H2E_VSRC_INT_SLOT : H2E_VSRC_FE_SLOT) << (3 * q);
-                                            h.w[2 + q] = (uint32_t)lslot[v];
-                                        } else {
-                                            h.w[7] |= (uint32_t)H2E_VSRC_GLOBAL << (3 * q);
-                                            if (o[q].is_int) {
-                                                h.w[2 + q] = (uint32_t)h_lrefs.size();
-                                                for (int j = 0; j <= L; j++) h_lrefs.push_back(op.refs[o[q].refpos + j]);
-                                            } else {
-                                                h.w[2 + q] = o[q].ref;
-                                            }
-                                        }
-                                    }
-                                }
-                            }
+                            if (lane < stp.size()) h = make_rec(stp[lane], mixed);
                             step_recs.push_back(h);
                         }
                         // (paired: the second half of the wave runs the same records for the workgroup's other instance)
                         for (size_t rep2 = 0; rep2 < 64 / step_lanes; rep2++) h_lrecs.insert(h_lrecs.end(), step_recs.begin(), step_recs.end());
                     }
+                }
+                if (eligible) {
                     if (dbg_env("H2E_DUMP_TAPE")) {
                         fprintf(stderr, "segment %zu: level-parallel replay: %zu alive ops, depth %u, %zu rounds of %zu waves, %d value slots, %s\n", si,
-                                alive.size(), depth, n_rounds, NW, n_slots, paired ? "two instances per workgroup" : "one instance per workgroup");
+                                alive.size(), depth, n_rounds, NW, n_slots, wave_mode ? "one wave per instance" : paired ? "two instances per workgroup" : "one instance per workgroup");
                         // rounds by their most expensive op kind, and how many of them read an operand from global cells
                         std::map<uint32_t, std::pair<size_t, size_t>> by_vop;
                         size_t global_rounds = 0, global_operands = 0;
@@ -1926,6 +2191,7 @@ static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
     HIP_TRY(up((void**)&p->d_vpieces, p->h_vpieces.empty() ? nullptr : p->h_vpieces.data(), p->h_vpieces.size() * 4));
     HIP_TRY(up((void**)&p->d_lrecs, p->h_lrecs.empty() ? nullptr : p->h_lrecs.data(), p->h_lrecs.size() * sizeof(H2EVRec)));
     HIP_TRY(up((void**)&p->d_lrefs, p->h_lrefs.empty() ? nullptr : p->h_lrefs.data(), p->h_lrefs.size() * 4));
+    HIP_TRY(up((void**)&p->d_lrounds, p->h_lrounds.empty() ? nullptr : p->h_lrounds.data(), p->h_lrounds.size() * 4));
     p->device = ctx->device;
     return 0;
 }
@@ -2211,6 +2477,8 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         bool levels = compiled && si < p->seg_l_steps.size() && p->seg_l_steps[si] > 0;
         L.lrecs = levels ? p->d_lrecs + p->seg_l_begin[si] : nullptr;
         L.lrefs = p->d_lrefs;
+        L.lrounds = levels && p->seg_l_pair[si] == 2 ? p->d_lrounds + p->seg_lr_begin[si] : nullptr;
+        L.l_recs = levels ? p->seg_l_recs[si] : 0;
         L.l_steps = levels ? p->seg_l_steps[si] : 0;
         L.l_slots = levels ? p->seg_l_slots[si] : 0;
         L.l_pair = levels ? p->seg_l_pair[si] : 0;
@@ -2406,8 +2674,9 @@ int h2e_submit(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d
 }
 
 int h2e_wait(h2e_ctx* ctx, int job, void* stream_) {
-    if (!ctx || job < 0 || job >= h2e_ctx::N_SLOTS || !ctx->slots[job].done) return fail(H2E_ERR_INVALID, "bad job");
-    std::lock_guard<std::mutex> guard(ctx->mu);
+    if (!ctx) return fail(H2E_ERR_INVALID, "null ctx");
+    std::lock_guard<std::mutex> guard(ctx->mu);   // (the slot's event is created under this lock by run_impl)
+    if (job < 0 || job >= (int)ctx->depth || !ctx->slots[job].done) return fail(H2E_ERR_INVALID, "bad job");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamWaitEvent((hipStream_t)stream_, ctx->slots[job].done, 0));
     return 0;
@@ -2432,11 +2701,31 @@ int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value) {
             HIP_TRY(hipDeviceSynchronize());
             h2e_engine_set_tuning(3, (int)value);
             return 0;
+        case H2E_OPT_PREFAULT_HBM: {
+            // The first process that touches the HBM of a freshly booted device pays for it: kernels that stream into memory
+            // nobody has written since boot run at half their rate (a 2^16-point MSM step 47 instead of 24 ms; any later
+            // process - or this one, after the first pass over the memory - is unaffected).  One throw-away allocate / fill /
+            // free of `value` percent of the free memory (0.3 s for 270 GB) takes that out of the caller's first runs.
+            if (value <= 0) return 0;
+            HIP_TRY(hipSetDevice(ctx->device));
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            size_t want = (size_t)((double)free_b * (double)std::min<int64_t>(value, 98) / 100.0) & ~(size_t)0xfffff;
+            if (want == 0) return 0;
+            void* scratch = nullptr;
+            HIP_TRY(hipMalloc(&scratch, want));
+            hipError_t e = hipMemset(scratch, 0xff, want);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            (void)hipFree(scratch);
+            if (e != hipSuccess) return fail(H2E_ERR_HIP, std::string("prefault: ") + hipGetErrorString(e));
+            return 0;
+        }
         default: return fail(H2E_ERR_INVALID, "unknown option");
     }
 }
 int64_t h2e_ctx_get_stat(h2e_ctx* ctx, int stat) {
     if (!ctx) return -1;
+    std::lock_guard<std::mutex> guard(ctx->mu);
     switch (stat) {
         case H2E_STAT_LAST_SPLIT_SEGMENTS: return ctx->last_split_segments;
         case H2E_STAT_RUNS: return (int64_t)ctx->n_runs;

@@ -179,7 +179,10 @@ typedef struct H2ELaunch {
     uint32_t l_steps, l_slots;
     uint32_t field_pair;          // the W field of this segment's integer ops (host side: which kernel instantiation)
     uint32_t slot_words;          // words per input slot (the program's: 6 for a bls12_381 Fq program even in its Fr segments)
-    uint32_t l_pair;              // level-parallel replay: 1 = two instances per workgroup (lanes 0-31 / 32-63), steps of 32 ops
+    uint32_t l_pair;              // level-parallel replay: 1 = two instances per workgroup (lanes 0-31 / 32-63), steps of 32 ops;
+                                  // 2 = wave mode: one wave per instance, rounds of up to 64 compact records (lrounds / l_recs)
+    const uint32_t* lrounds;      // wave mode: per round (first record, count | kind << 8); kind 0 = light ops of mixed opcodes
+    uint32_t l_recs;              // wave mode: records incl. padding (a multiple of H2E_WCHUNK)
 } H2ELaunch;
 
 // ---- compiled values-only replay ("V-tape") ----------------------------------------------------
@@ -219,6 +222,8 @@ enum H2EVOpcode {
 #define H2E_VFLAG_HINT_STRIDED 2u
 #define H2E_VFLAG_STAGED 4u         // H2E_V_HINT: imm is a staging unit
 #define H2E_VFLAG_FENCE 8u          // level-parallel replay: this round holds an H2E_V_FULL op - fence before the barrier
+#define H2E_VFLAG_MIXED 16u         // level-parallel replay: a step of light ops (additions, selections, conditions) of any
+                                    // mix of opcodes - every lane runs its own record's opcode
 #define H2E_VSRC_NONE 0u
 #define H2E_VSRC_INT_SLOT 1u
 #define H2E_VSRC_FE_SLOT 2u
@@ -226,6 +231,7 @@ enum H2EVOpcode {
 #define H2E_VSRC_STAGE 4u
 #define H2E_V_NO_SLOT 0xffu
 #define H2E_LEVEL_WAVES 4u   // waves of a level-parallel replay workgroup (they share one instance's value slots)
+#define H2E_WCHUNK 256u      // wave mode: records per LDS chunk buffer; a round never straddles a chunk (host pads with H2E_V_NOP)
 
 // ---- value-predictor ("V") kernels for the MSM ---------------------------------------------------
 // They run native Montgomery / Jacobian arithmetic over the same inputs, write numerator/denominator pairs of

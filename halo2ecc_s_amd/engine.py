@@ -17,6 +17,7 @@ LAYOUT_ROWS, LAYOUT_COLUMNS = 0, 1
 FORM_CANONICAL, FORM_MONTGOMERY = 0, 1
 OPT_X_SPLIT_PCT, OPT_X_SPLIT_MIN_LANES, OPT_TEST_SKIP_EXPANSION, OPT_PIPELINE_DEPTH, OPT_TEST_SCAN_FALLBACK = 1, 2, 3, 4, 5
 STAT_LAST_SPLIT_SEGMENTS, STAT_RUNS, STAT_PIPELINE_DEPTH, STAT_MAX_PIPELINE_DEPTH, STAT_SCAN_FALLBACKS = 1, 2, 3, 4, 5
+OPT_PREFAULT_HBM = 6
 OPT_OFF = -(1 << 63)
 COLS = (5, 3, 2)
 

@@ -174,6 +174,10 @@ int h2e_wait(h2e_ctx* ctx, int job, void* stream);
 #define H2E_OPT_TEST_SCAN_FALLBACK 5    /* TEST HOOK: bit mask - the MSM scan predictors treat some of their (valid) start values as degenerate
                                           and walk the real chain instead (1 window chunks, 2 tail chunk sums, 4 tail in-chunk starts).
                                           The results are the same; what it covers is the fallback path.  Process-wide; 0 = off. */
+#define H2E_OPT_PREFAULT_HBM 6          /* one throw-away allocate / fill / free of <value> percent of the device's free memory, now
+                                          (synchronous, ~0.3 s for 270 GB).  The first process that streams into HBM nobody has
+                                          written since the device booted runs at about half the rate of any later one; a host
+                                          that cares about its first runs calls this once after h2e_ctx_create. */
 int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value);
 #define H2E_STAT_LAST_SPLIT_SEGMENTS 1 /* segments of the last run whose expansion went out as two launches */
 #define H2E_STAT_RUNS 2

@@ -45,8 +45,9 @@ def test_bench_streaming_job_digest_and_records():
     # 8 tiles of 33 points through a ring of two 2-tile buffer sets: 4 steps, digest consumer on, records gathered
     d = _bench("--units", "2", "--points", "33", "--job-tiles", "8", "--warmup", "1", "--traffic", "off", "--no-cpu-baseline")
     _check_contract(d, 1, 4, 1)
-    assert d["gathered_records"]["shape"] == [2, 29] and d["gathered_records"]["status_or"] == 0
+    assert d["gathered_records"]["shape"] == [8, 29] and d["gathered_records"]["status_or"] == 0   # one gather of the whole job
     assert len(d["digest_sample"]) == 4 and any(d["digest_sample"])
+    assert d["single_batch_ms"] > 0
 
 
 @pytest.mark.parametrize("workload", ["pairing_bn256", "pairing_bls12_381"])
@@ -55,10 +56,38 @@ def test_bench_small_pairing(workload):
     _check_contract(d, 1, 3, 1)
 
 
+def test_bench_job_128_tiles_ring_digest_vs_oracle(tmp_path):
+    """configs[2]'s per-GPU share at size: 128 tiles x 1024 points as one streaming job through the ring of two 64-tile
+    buffer sets (2 steps, 220 GB of arrays), every tile its own inputs, digest consumer on, the job's records gathered once.
+    Sampled tiles (one per step): the record's status, Offset and the three 32-byte digests equal what the oracle
+    computes from the same input vector - i.e. every advice cell of those tiles, at full size, through bench.py's own path."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    dump = str(tmp_path / "job.npz")
+    d = _bench("--job-tiles", "128", "--warmup", "1", "--traffic", "off", "--no-cpu-baseline", "--latency-steps", "0",
+               "--dump-records", dump, "--dump-tiles", "5,100")
+    _check_contract(d, 1, 2, 1)
+    assert d["gathered_records"]["shape"] == [128, 29] and d["gathered_records"]["status_or"] == 0
+    z = np.load(dump)
+    rec = z["records"]
+    assert len({tuple(r[17:29]) for r in rec}) == 128    # 128 different tiles
+    for t in (5, 100):
+        orun = oracle_lib.run_msm_bn256_tile(1024, z[f"inputs_{t}"], threads=os.cpu_count())
+        assert orun.info.status == 0, orun.error
+        i = orun.info
+        assert [int(x) for x in rec[t, 1:4]] == [i.base_offset, i.range_offset, i.select_offset]
+        for region in range(3):
+            got = rec[t, 17 + 4 * region:21 + 4 * region].view(np.uint64)
+            assert np.array_equal(got, orun.digest(region)), (t, region)
+        orun.close()
+
+
 def test_bench_two_ranks_one_gpu_gloo():
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                 "--master-port", str(29600 + os.getpid() % 300)]
-    d = _bench("--gpus", "2", "--units", "2", "--points", "33", "--steps", "2", "--warmup", "1", "--traffic", "off", "--no-cpu-baseline",
-               "--dist-backend", "gloo", "--device", "0", "--digest", launcher=launcher)
+    d = _bench("--gpus", "2", "--units", "2", "--points", "33", "--job-tiles", "8", "--warmup", "1", "--traffic", "off", "--no-cpu-baseline",
+               "--dist-backend", "gloo", "--device", "0", launcher=launcher)   # configs[2]'s command at a small size: --job-tiles N --gpus G
     _check_contract(d, 2, 2, 1)
-    assert d["gathered_records"]["shape"] == [4, 29] and d["gathered_records"]["status_or"] == 0
+    assert d["gathered_records"]["shape"] == [8, 29] and d["gathered_records"]["status_or"] == 0   # 2 steps x 2 ranks x 2 units
+    assert len(d["per_rank_ms_per_step"]) == 2

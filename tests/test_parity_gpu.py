@@ -338,6 +338,35 @@ def test_msm_wrong_expected_sets_status(engine):
     assert status[0] & 1  # ASSERT_FAILED, like the reference's assert_true panic
 
 
+@pytest.mark.parametrize("n", [7, 33])
+def test_msm_unsafe_error_is_a_retry_status(engine, oracle, n):
+    """UnsafeError (src/circuit/ecc_chip.rs:23-34): ecc_add_unsafe returns Err(AddSameOrNegPoint) when the two x coordinates
+    are equal (:850-857) and the reference's test draws new blinding points and retries
+    (src/tests/native_scalar_ecc_chip.rs:52-57).  Here: the middle instance's line blinding point r2 equals its first input
+    point, so the first candidate addition of group 0 (rand_line_point + P_0, :265-268) is P + P.
+    The engine reports H2E_ST_RETRY_ADD_SAME_OR_NEG_POINT on that instance only (its rows are garbage, as after a failed
+    reference run) and the neighbours stay bit-exact.  The oracle, which restates the reference as written, *panics* on that
+    input: `try_assert_false` (base_chip.rs:497-500) calls `assert_constant` first, whose `assert_eq!(a.val, b)`
+    (base_chip.rs:377) fires before the bool is formed - at v0.3.2 the Err branch of ecc_add_unsafe is unreachable.  The
+    engine's status names the reference's intent (a retryable failure), the oracle documents what the crate does."""
+    from halo2ecc_s_amd.engine import ST_RETRY_ADD_SAME_OR_NEG_POINT
+    ins = [synth.msm_bn256_tile_inputs(n, tile=300 + t)[0] for t in range(3)]
+    bad = ins[1].copy()
+    bad[4 * n + 4] = bad[0]   # r2.x = P_0.x
+    bad[4 * n + 5] = bad[1]   # r2.y = P_0.y
+    ins[1] = bad
+    prog = Program.msm_bn256_tile(n)
+    base, rng, sel, status = _run(engine, prog, ins)
+    assert status[0] == 0 and status[2] == 0, status
+    assert status[1] & ST_RETRY_ADD_SAME_OR_NEG_POINT, status
+    orun_bad = oracle_lib.run_msm_bn256_tile(n, bad)
+    assert orun_bad.info.status == 1 and "assert_constant" in orun_bad.error, (orun_bad.info.status, orun_bad.error)
+    for k in (0, 2):
+        orun = oracle_lib.run_msm_bn256_tile(n, ins[k])
+        assert orun.info.status == 0, orun.error
+        compare_advice(prog, orun, base, rng, sel, instance=k)
+
+
 def test_pairing_check_bn256(engine, oracle):
     """config 4 unit: check_pairing([(a,b),(-a,b)]) — 6.17M advice cells per instance, bit-exact"""
     ins = [synth.pairing_check_bn256_inputs(instance=k) for k in range(2)]
