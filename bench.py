@@ -280,11 +280,14 @@ def main():
         make = lambda shape: Program.pairing_check_bn256(emit_shape=shape)   # noqa: E731
     else:
         make = lambda shape: Program.pairing_check_bls12_381(emit_shape=shape)   # noqa: E731
-    prog = make(False)
     shape_prog = make(True)  # shape-only artefacts, once per shape (not timed)
     cells_per_unit = shape_prog.n_advice_cells
     launches = shape_prog.launches()
-    shape_prog.close()
+    if args.digest:
+        prog = shape_prog    # the digest is over the assigned cells: it needs the program's assigned / permute flags
+    else:
+        prog = make(False)
+        shape_prog.close()
     # the launch with the most cells (MSM: the window strands; pairing: the whole check)
     dom = max(range(len(launches)), key=lambda i: launches[i]["cells"])
 

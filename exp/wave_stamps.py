@@ -24,7 +24,7 @@ assert int(arrs[3].abs().max()) == 0
 buf = (C.c_ulonglong * 32)()
 lib().h2e_engine_wave_stamps_fp0.argtypes = [C.POINTER(C.c_ulonglong)]
 assert lib().h2e_engine_wave_stamps_fp0(buf) == 0
-names = ["light", "medium (reduce, const)", "mul", "div", "through cells", "chunk switch", "-", "-"]
+names = ["light / linear combinations", "medium / loads", "mul", "div", "through cells", "chunk switch", "-", "-"]   # (field chain: kinds 0-3)
 tot = sum(buf[k] for k in range(8))
 for k in range(6):
     if buf[8 + k]:

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "tape.h"
 #include "wide_int.h"
 
@@ -68,6 +69,15 @@ static constexpr int NK = 254;  // bit length of bn256 Fr modulus
 // device pointer each modulus / Barrett / ceil-table word was a dependent VMEM round trip: ~90 of them per
 // ecc_add_unsafe in the value chain (PMC: 47 % of that kernel's cycles in s_waitcnt).
 __constant__ H2EFieldConsts g_fc[3];
+#ifdef H2E_WAVE_STAMPS
+// diagnostic build only (exp/wave_stamps.sh): cycles and rounds per round kind of workgroup 0, read back by
+// h2e_engine_wave_stamps ([0..7] cycles, [8..15] rounds of h2e_replay_wave / h2e_field_chain, [16..19] light-round detail)
+__device__ unsigned long long g_wave_stamps[32];
+extern "C" int H2E_UNIT(h2e_engine_wave_stamps)(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_stamps), sizeof(g_wave_stamps));
+}
+#define WAVE_STAMP() __builtin_amdgcn_s_memtime()
+#endif
 
 typedef Wd<2> Limb;   // <= 114 bit
 typedef Wd<4> Fe;     // canonical bn256-Fr value
@@ -296,6 +306,11 @@ WI_INLINE void rowS(const LC& c, u32 row, u32 mask, const Fe& value, const Fe& s
     if (mask & 2) st_cell(p + (size_t)2 * hs, hs, selector);
 }
 WI_INLINE void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Round barriers of the level / wave / field-chain kernels.  `__syncthreads()` is a workgroup-scope release fence + barrier:
+// the fence waits for every outstanding *global* store of the wave (s_waitcnt vmcnt(0)) - a round trip to HBM, ~3 k cycles,
+// per round, although the rounds only exchange values through LDS.  These wait for the LDS accesses alone.
+WI_INLINE void lds_round_barrier_wave() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }                  // one-wave workgroups
+WI_INLINE void lds_round_barrier_workgroup() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 static __device__ const Fe FE0 = {{0, 0, 0, 0}};
 // base row with cols 0..k-1 and/or the last column
 #define ROW_B1(c, row, a, last) rowB(c, row, 0x11, a, FE0, FE0, FE0, last)
@@ -1866,7 +1881,7 @@ __global__ void __launch_bounds__(64 * H2E_LEVEL_WAVES) h2e_replay_levels(H2ELau
         } else if ((h.w[0] & 0xffu) != H2E_V_NOP) {
             exec_lop<FP>(lv, c, opc, h, L.lrefs);   // (a round without its op costs 0.44 us; with it 3.0 us on average)
         }
-        __syncthreads();   // the round's values are in their slots
+        lds_round_barrier_workgroup();   // the round's values are in their slots
     }
 }
 
@@ -1879,14 +1894,6 @@ __global__ void __launch_bounds__(64 * H2E_LEVEL_WAVES) h2e_replay_levels(H2ELau
 //  * the ceil tables sit in LDS; nothing in a round's body loads from global memory (a few hundred ops of a pairing
 //    check read cells of other kernels - they do wait);
 //  * result cells that later kernels need are stored and never waited for.
-#ifdef H2E_WAVE_STAMPS
-// diagnostic build only (exp/wave_stamps.sh): cycles and rounds per round kind of workgroup 0, read back by h2e_engine_wave_stamps
-__device__ unsigned long long g_wave_stamps[32];
-extern "C" int H2E_UNIT(h2e_engine_wave_stamps)(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_stamps), sizeof(g_wave_stamps));
-}
-#define WAVE_STAMP() __builtin_amdgcn_s_memtime()
-#endif
 template <class FP>
 __global__ void __launch_bounds__(64) h2e_replay_wave(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
     const u32 lane = threadIdx.x;
@@ -1996,7 +2003,7 @@ __global__ void __launch_bounds__(64) h2e_replay_wave(H2ELaunch L, const Instanc
             t_exec = WAVE_STAMP();
 #endif
         }
-        __syncthreads();   // (one wave: no barrier instruction, only the LDS accesses of the round are ordered)
+        lds_round_barrier_wave();   // (one wave: only the LDS accesses of the round are ordered; global stores stay in flight)
 #ifdef H2E_WAVE_STAMPS
         {
             u32 k = kind == 0 ? 0u : kind == H2E_V_MUL ? 2u : kind == H2E_V_DIV ? 3u : kind == H2E_V_FULL ? 4u : 1u;
@@ -2020,6 +2027,129 @@ __global__ void __launch_bounds__(64) h2e_replay_wave(H2ELaunch L, const Instanc
             if (k < 4) g_wave_stamps[16 + k] = st_light[k];
         }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hint store (field_chain.hpp HintStore): the cells the full expansion needs in place, straight from the hint slots.
+// One lane per (store op, instance), instances minor: the lanes of a wave read the same hint slots and write the same
+// cells of consecutive instances (contiguous runs, like the expansion).
+template <class FP>
+WI_INLINE Wd<FP::WW> hs_leaf(const LC& c, u32 t) {
+    u32 kind = t >> 30, index = t & 0x3fffffu;
+    if (kind == 0) return ws_load<FP::WW>(c.hints + (size_t)index * c.ws);
+    if (kind == 1) return g_load<FP::WW>(c.pool + index);
+    return g_load<FP::WW>(c.inputs + (size_t)index * c.sw);
+}
+template <class FP>
+__global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_hint_store(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
+    constexpr int NL = FP::L;
+    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 total = L.n_sops * n_instances;
+    bool active = gid < total;
+    if (!active) gid = total - 1;
+    u32 instance = gid % n_instances, sop = gid / n_instances;
+    InstanceDesc d = inst[instance];
+    LC c;
+    c.base = d.base;
+    c.range = d.range;
+    c.select = d.select;
+    c.inputs = d.inputs;
+    c.status = d.status;
+    c.ob = L.strand_base0;
+    c.orr = L.strand_range0;
+    c.os = L.strand_select0;
+    c.params = L.params;
+    c.aux = L.aux;
+    c.pool = L.const_pool;
+    c.fc = &g_fc[FP::ID];
+    c.strand = 0;
+    c.input_stride = L.input_stride;
+    c.sw = L.slot_words;
+    c.hints = d.hints;
+    c.ws = d.ws;
+    c.hint_stride = L.hint_stride;
+    c.sel = d.sel;
+    c.sel_stride = L.sel_stride;
+    c.hs = 2 * n_instances;
+    c.active = active;
+    const u32* rec = L.s_words + L.s_offsets[sop];
+    u32 w0 = rec[0], row = rec[1], rrow = rec[2];
+    u32 kind = w0 & 0xffu, n_terms = (w0 >> 8) & 0xffu, kidx = w0 >> 16;
+    if (kind == H2E_S_W) {   // a mul-like result: limbs in its range rows, native in its base row
+        Wd<FP::WW> x = hs_leaf<FP>(c, rec[3]);
+        Limb l[NL];
+        split_limbs<FP>(x, l);
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) stR(c, rrow + 3 * i, 0, fe_of(l[i]));
+            stB(c, row, 4, native_of_w<FP>(c, x));
+        }
+    } else if (kind == H2E_S_LIN) {
+        // limbs modulo 2^128 (the true values are non-negative and below 2^114), native as a non-negative sum reduced mod n
+        Limb acc[NL];
+        const u64* kt = L.s_ktab + (size_t)kidx * (2 * NL + 4);
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            acc[i].v[0] = g_ld8(kt + 2 * i);
+            acc[i].v[1] = g_ld8(kt + 2 * i + 1);
+        }
+        Wd<5> nat = wd_resize<5>(g_load<4>(kt + 2 * NL));
+        Fe n = n_of(c);
+        for (u32 t = 0; t < n_terms; t++) {
+            u32 tw = rec[3 + t];
+            int coef = (int)((tw >> 22) & 0xffu) - 128;
+            Wd<FP::WW> x = hs_leaf<FP>(c, tw);
+            Limb l[NL];
+            split_limbs<FP>(x, l);
+            Fe xn = native_of_w<FP>(c, x);
+            u32 m = (u32)(coef < 0 ? -coef : coef);
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                Limb p = wd_resize<2>(wd_mul_small<2>(l[i], m));
+                acc[i] = coef < 0 ? wd_sub<2>(acc[i], p) : wd_add<2>(acc[i], p);
+            }
+            if (coef < 0) xn = wd_sub<4>(n, xn);   // -x = n - x (in (0, n])
+            wd_mac_small<4>(nat, xn, m);
+        }
+        // nat < (1 + 255 * 127) n: small-quotient reduction
+        Fe natr;
+        {
+            constexpr int SH = NK - 52;
+            u64 a_top = wd_shr<1, SH>(nat).v[0];
+            double inv = 1.0 / (double)(wd_shr<1, SH>(n).v[0] + 1);
+            u64 qe = (u64)((double)a_top * inv);
+            qe = qe > 0 ? qe - 1 : 0;
+            Wd<5> ne = wd_resize<5>(n);
+            Wd<5> r = wd_sub<5>(nat, wd_mul_small<4>(n, (u32)qe));
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                bool ge = wd_geq<5>(r, ne);
+                r = wd_select<5>(ge, wd_sub<5>(r, ne), r);
+            }
+            natr = wd_resize<4>(r);
+        }
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) stB(c, row + i, 4, fe_of(acc[i]));
+            stB(c, row + NL, 4, natr);
+        }
+    } else if (kind == H2E_S_FE) {
+        Wd<FP::WW> x = hs_leaf<FP>(c, rec[3]);
+        if (active) stB(c, row, 4, fe_u64(x.v[0] & 1));
+    } else if (kind == H2E_S_CONST) {   // assign_int_constant: limb i in (row + i, col 0), native in (row + L, col 0)
+        Wd<FP::WW> x = hs_leaf<FP>(c, rec[3]);
+        Limb l[NL];
+        split_limbs<FP>(x, l);
+        Fe native = mod_n<FP::WW>(c, x);
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) stB(c, row + i, 0, fe_of(l[i]));
+            stB(c, row + NL, 0, native);
+        }
+    } else if (kind == H2E_S_FULL) {
+        H2EOp op = L.tape[row];
+        exec_op<FP, false>(c, op);
+    }
 }
 
 // ================================================================================================
@@ -2368,6 +2498,206 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_predict(H2EPreKernel 
             st_jac<FP>(v, j0 + i, r);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Field-domain predictor chain (field_chain.hpp; tape.h H2E_PRE_FIELD_CHAIN): the canonical value of every mul-like result
+// of a pairing check, computed as plain arithmetic mod w on Montgomery residues - ~1.3 k rounds of up to 64 independent
+// records (linear combinations / Montgomery products) instead of the 16 k rounds of the integer-chip replay.  One wave
+// per instance, values in LDS slots ([slot][WW] words, fully reduced), records streamed through two LDS chunk buffers
+// like h2e_replay_wave.  A record with a hint slot stores its value (still in Montgomery form) into the hint workspace.
+template <class FP>
+WI_INLINE Wd<FP::WW> f_ld(const u64* fv, u32 slot) {
+    const u64* p = fv + (size_t)slot * FP::WW;
+    Wd<FP::WW> r;
+#pragma unroll
+    for (int i = 0; i < FP::WW / 2; i++) {
+        u64x2 q = l_ld16(p + 2 * i);
+        r.v[2 * i] = q.x;
+        r.v[2 * i + 1] = q.y;
+    }
+    return r;
+}
+template <class FP>
+WI_INLINE void f_st(u64* fv, u32 slot, const Wd<FP::WW>& v) {
+    u64* p = fv + (size_t)slot * FP::WW;
+#pragma unroll
+    for (int i = 0; i < FP::WW / 2; i++) l_st16(p + 2 * i, v.v[2 * i], v.v[2 * i + 1]);
+}
+// A < 2^11 w  ->  A mod w: quotient estimate from the top 52 bits of w in double precision, then corrections
+template <class FP>
+WI_INLINE Wd<FP::WW> f_reduce_small(const Wd<FP::WW + 1>& A, const Wd<FP::WW>& w, double inv_w_top) {
+    constexpr int N = FP::WW, SH = FP::K - 52;
+    u64 a_top = wd_shr<1, SH>(A).v[0];                       // < 2^(11 + 52)
+    u64 qe = (u64)((double)a_top * inv_w_top);                // inv_w_top = 1 / (w_top + 1): never more than ~1 too small ...
+    qe = qe > 0 ? qe - 1 : 0;                                 // ... and with this never too large
+    Wd<N + 1> we = wd_resize<N + 1>(w);
+    Wd<N + 1> r = wd_sub<N + 1>(A, wd_mul_small<N>(w, (u32)qe));
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+        bool ge = wd_geq<N + 1>(r, we);
+        r = wd_select<N + 1>(ge, wd_sub<N + 1>(r, we), r);
+    }
+    return wd_resize<N>(r);
+}
+template <class FP>
+__global__ void __launch_bounds__(128) h2e_field_chain(H2EPreKernel K, const u32* __restrict__ args, const u64* __restrict__ pool,
+                                                        const InstanceDesc* __restrict__ inst, u32 n_instances) {
+    // Two waves per instance: wave 0 computes, wave 1 only streams the record chunks into LDS (LDS-DMA) - loads and stores
+    // share one in-order counter per wave, so a computing wave that waited for its own chunk loads would also wait for every
+    // hint store it has issued since (a round trip to HBM).  The waves meet at one barrier per chunk.
+    constexpr int N = FP::WW;
+    const u32 lane = threadIdx.x & 63u;
+    const bool loader = threadIdx.x >= 64;
+    const u32 instance = blockIdx.x;
+    InstanceDesc d = inst[instance];
+    const H2EFieldConsts* fc = &g_fc[FP::ID];
+    extern __shared__ ulonglong2 f_dyn[];
+    H2EVRec* rbuf = (H2EVRec*)f_dyn;                       // [2][H2E_WCHUNK]
+    u64* fv = (u64*)(rbuf + 2 * H2E_WCHUNK);                // [f_slots][N]
+    __builtin_amdgcn_s_setprio(3);
+    const H2EVRec* recs = (const H2EVRec*)(args + K.f_recs);
+    const u32 n_chunks = K.f_n_recs / H2E_WCHUNK;
+    auto load_chunk = [&](u32 chunk) {
+        const char* src = (const char*)(recs + (size_t)chunk * H2E_WCHUNK);
+        char* dst = (char*)(rbuf + (size_t)(chunk & 1u) * H2E_WCHUNK);
+#pragma unroll
+        for (u32 k = 0; k < H2E_WCHUNK * 32u / 1024u; k++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * 1024u + lane * 16u),
+                                             (__attribute__((address_space(3))) void*)(dst + k * 1024u), 16, 0, 0);
+    };
+    if (loader) {
+        load_chunk(0);
+        if (n_chunks > 1) load_chunk(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // barrier 0: chunks 0 and 1 are in LDS
+        for (u32 c = 1; c < n_chunks; c++) {
+            __builtin_amdgcn_s_barrier();                   // barrier c: the computing wave has left chunk c - 1
+            if (c + 1 < n_chunks) {
+                load_chunk(c + 1);                          // ... into that buffer
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        return;
+    }
+    Mont<N> M = mont_w<FP>(fc);
+    const Wd<N> w = M.p;
+    const double inv_w_top = 1.0 / (double)(wd_shr<1, FP::K - 52>(w).v[0] + 1);
+    __builtin_amdgcn_s_barrier();
+    u32 cur_chunk = 0;
+#ifdef H2E_WAVE_STAMPS
+    unsigned long long fst_cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fst_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    u32 pos = 0;   // record index of the next round's header (wave-uniform)
+    // one round; LOADS = the leading rounds that bring inputs and constants in (global loads), otherwise everything else:
+    // two loops, so that the main loop's body contains no global load
+    auto run_round = [&](auto loads_tag) {
+        constexpr bool LOADS = decltype(loads_tag)::value;
+#ifdef H2E_WAVE_STAMPS
+        unsigned long long ft0 = WAVE_STAMP();
+#endif
+        u32 chunk = pos / H2E_WCHUNK;
+        if (chunk != cur_chunk) {   // (chunks follow each other: chunk == cur_chunk + 1)
+            lds_round_barrier_workgroup();   // barrier `chunk`: the loader had this chunk in LDS before the previous barrier
+            cur_chunk = chunk;
+        }
+        // the round's header record (word 0: count | kind << 8) sits in LDS in front of its records
+        const H2E_AS_LDS u32* hp = (const H2E_AS_LDS u32*)(rbuf + (size_t)(chunk & 1u) * H2E_WCHUNK + pos % H2E_WCHUNK);
+        u32 meta = __builtin_amdgcn_readfirstlane(hp[0]);
+        u32 max_terms = __builtin_amdgcn_readfirstlane(hp[1]);   // the round's longest linear combination
+        u32 cnt = meta & 0xffu, kind = (meta >> 8) & 0xffu;
+        if (kind == 0xffu) {        // the rest of this chunk is padding
+            pos = (chunk + 1) * H2E_WCHUNK;
+            return false;
+        }
+        const u32 first = pos + 1;
+        pos += 1 + cnt;
+        if (lane < cnt) {
+            const H2E_AS_LDS u32x4* rp = (const H2E_AS_LDS u32x4*)(rbuf + (size_t)(chunk & 1u) * H2E_WCHUNK + first % H2E_WCHUNK + lane);
+            u32x4 ra = rp[0], rb = rp[1];
+            u32 opc = ra.x & 0xffu, dst = ra.x >> 16, hint = ra.y;
+            Wd<N> out = wd_zero<N>();
+            if constexpr (LOADS) {   // values entering: inputs and pool constants
+                if (opc == H2E_F_INPUT_W) out = to_mont<N>(M, g_load<N>(d.inputs + (size_t)ra.z * K.n_params));
+                else if (opc == H2E_F_CONST_W) out = to_mont<N>(M, g_load<N>(pool + ra.z));
+                else if (opc == H2E_F_INPUT_FE) out.v[0] = g_ld8(d.inputs + (size_t)ra.z * K.n_params);
+                else if (opc == H2E_F_CONST_FE) out.v[0] = g_ld8(pool + ra.z);
+            } else if (kind == 2) {           // Montgomery products
+                out = mont_mul_w<FP>(f_ld<FP>(fv, ra.z), f_ld<FP>(fv, ra.w));
+            } else if (kind == 0) {    // light: linear combinations, conditions, selections
+                if (opc == H2E_F_LIN) {
+                    u32 terms[H2E_F_MAX_TERMS] = {ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+                    Wd<N + 1> acc = wd_zero<N + 1>();
+#pragma unroll
+                    for (int t = 0; t < H2E_F_MAX_TERMS; t++) {
+                        u32 sl = terms[t] & 0xffffu;
+                        if ((u32)t < max_terms && sl != 0xffffu) {   // (t < max_terms is wave-uniform: whole term blocks are skipped)
+                            int coef = (int)(int16_t)(terms[t] >> 16);
+                            Wd<N> x = f_ld<FP>(fv, sl);
+                            if (coef < 0) x = wd_sub<N>(w, x);   // -x = w - x (in (0, w]: the sum stays below 2^11 w)
+                            wd_mac_small<N>(acc, x, (u32)(coef < 0 ? -coef : coef));
+                        }
+                    }
+                    out = f_reduce_small<FP>(acc, w, inv_w_top);
+                } else if (opc == H2E_F_ISZERO) {
+                    out.v[0] = wd_is_zero<N>(f_ld<FP>(fv, ra.z)) ? 1 : 0;
+                } else if (opc == H2E_F_NOT) {
+                    out.v[0] = 1 ^ (f_ld<FP>(fv, ra.z).v[0] & 1);
+                } else if (opc == H2E_F_AND || opc == H2E_F_OR || opc == H2E_F_XNOR) {
+                    u64 a = f_ld<FP>(fv, ra.z).v[0] & 1, b = f_ld<FP>(fv, ra.w).v[0] & 1;
+                    out.v[0] = opc == H2E_F_AND ? (a & b) : opc == H2E_F_OR ? (a | b) : (1 ^ a ^ b);
+                } else if (opc == H2E_F_SELECT) {
+                    bool take_a = f_ld<FP>(fv, ra.z).v[0] != 0;
+                    Wd<N> a = f_ld<FP>(fv, ra.w);
+                    Wd<N> b = (rb.x & 0xffffu) != 0xffffu ? f_ld<FP>(fv, rb.x & 0xffffu) : wd_zero<N>();
+                    out = take_a ? a : b;
+                }
+            } else {                   // division: a / b, 0 for b = 0 (integer_chip.rs:524-527)
+                Wd<N> a = f_ld<FP>(fv, ra.z), b = f_ld<FP>(fv, ra.w);
+                Wd<N> binv = wd_inv_mod<N>(from_mont<N>(M, b), w);          // plain b^-1 (0 for 0)
+                out = mont_mul_w<FP>(a, to_mont<N>(M, binv));                // a R * b^-1 R / R
+            }
+            if (dst != 0xffffu) f_st<FP>(fv, dst, out);
+            if (hint) {
+                // (conditions are raw 0 / 1: stored as the Montgomery form of that number, so that the finalize kernel's
+                // conversion of the whole slot range gives 0 / 1 back)
+                bool raw = opc == H2E_F_ISZERO || opc == H2E_F_NOT || opc == H2E_F_AND || opc == H2E_F_OR || opc == H2E_F_XNOR ||
+                           opc == H2E_F_INPUT_FE || opc == H2E_F_CONST_FE;
+                Wd<N> hv = raw ? ((out.v[0] & 1) ? M.r1 : wd_zero<N>()) : out;
+                ws_store<N>(d.hints + (size_t)(hint - 1) * d.ws, hv);
+            }
+        }
+        lds_round_barrier_wave();
+#ifdef H2E_WAVE_STAMPS
+        fst_cyc[kind & 7] += WAVE_STAMP() - ft0;
+        fst_n[kind & 7]++;
+#endif
+        return true;
+    };
+    for (u32 round = 0; round < K.f_n_load_rounds;)
+        if (run_round(std::true_type())) round++;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loads are done: from here on the wave only stores to global memory
+    for (u32 round = K.f_n_load_rounds; round < K.f_n_rounds;)
+        if (run_round(std::false_type())) round++;
+#ifdef H2E_WAVE_STAMPS
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 8; k++) {
+            g_wave_stamps[k] = fst_cyc[k];
+            g_wave_stamps[8 + k] = fst_n[k];
+        }
+#endif
+}
+// hint slots [first, first + n) of every instance: Montgomery form -> canonical value
+template <class FP>
+__global__ void __launch_bounds__(64) h2e_field_finalize(u32 first, u32 n, const InstanceDesc* inst, u32 n_instances) {
+    constexpr int N = FP::WW;
+    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * n_instances) return;
+    u32 instance = gid % n_instances, slot = first + gid / n_instances;   // instance-minor like the workspace
+    InstanceDesc d = inst[instance];
+    Mont<N> M = mont_w<FP>(&g_fc[FP::ID]);
+    u64* p = d.hints + (size_t)slot * d.ws;
+    ws_store<N>(p, from_mont<N>(M, ws_load<N>(p)));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3128,6 +3458,11 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
     if (xcache_on) launch_x.rel_refs |= 4u;
     if (g_tune[1] & 2) launch_x.rel_refs |= 8u;
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
+    if ((mode & 1) && launch->s_words) {                                                                                        \
+        u32 lanes = launch->n_sops * n_instances;                                                                              \
+        if (lanes) hipLaunchKernelGGL(h2e_hint_store<FP>, dim3((lanes + 63) / 64), dim3(64), 0, stream, *launch, inst, n_instances); \
+        mode &= ~1;                                                                                                            \
+    }                                                                                                                          \
     if ((mode & 1) && launch->lrecs && launch->l_pair == 2) {                                                                   \
         hipLaunchKernelGGL(h2e_replay_wave<FP>, dim3(n_instances * launch->n_strands), dim3(64),                                \
                            (size_t)2 * H2E_WCHUNK * 32 + (64 * H2E_MAX_L * 2 + 64 * 4) * 8 + (size_t)launch->l_slots * LVals<FP>::W * 8, \
@@ -3195,6 +3530,15 @@ extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2E
     u32 ecc_chunks = (k->ecc_ops + ECC_CH - 1) / ECC_CH;
     dim3 grid3((n_instances * k->n_lanes * ecc_chunks + 63) / 64);
 #define H2E_PREDICT_FP(FP)                                                                                                          \
+    if (k->kind == H2E_PRE_FIELD_CHAIN) {   /* params_dev carries the constant pool, n_params the words per input slot */          \
+        if (phase & 1)                                                                                                              \
+            hipLaunchKernelGGL(h2e_field_chain<FP>, dim3(n_instances), dim3(128), (size_t)2 * H2E_WCHUNK * 32 + (size_t)k->f_slots * FP::WW * 8, \
+                               stream, *k, args_dev, (const u64*)params_dev, inst, n_instances);                                    \
+        if ((phase & 2) && k->hints_per_lane)                                                                                       \
+            hipLaunchKernelGGL(h2e_field_finalize<FP>, dim3((n_instances * k->hints_per_lane + 63) / 64), block, 0, stream,         \
+                               k->hint_base, k->hints_per_lane, inst, n_instances);                                                \
+        break;                                                                                                                      \
+    }                                                                                                                               \
     if (k->kind == H2E_PRE_MSM_SELECT) {                                                                                            \
         if (phase & 1) hipLaunchKernelGGL(h2e_select<FP>, grid, block, 0, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev); \
         break;                                                                                                                      \

@@ -1,0 +1,823 @@
+// Field-domain predictor chain ("field hints", Recorder::hint_mode 3): host compiler.
+//
+// A pairing check is ~175 k integer-chip ops whose dependency graph is 8.5 k levels deep - but only ~650 of those levels
+// are products.  Everything between two products is linear (int_add / int_sub / int_neg / int_mul_small_constant,
+// src/circuit/integer_chip.rs:384-464, :618-658) or a `reduce` (:283-373), and as *values mod w* a reduce is the identity
+// and a chain of additions is one linear combination: the `find_w_modulus_of_ceil_times` constants int_sub / int_neg add
+// (range_info.rs:334-359) are multiples of w.  So the canonical value of every mul-like result (what the values-only
+// replay needs as a hint, tape.h H2E_FLAG_HINTED) is computed by a much shorter program over plain residues mod w in
+// Montgomery form: one round of linear combinations, one round of Montgomery products, and so on - ~1.3 k rounds instead
+// of 16 k.  This file turns a recorded segment into that program: records of 8 words, rounds of up to 64 independent
+// records (one wave, engine.hip h2e_field_chain), values in LDS slots.
+//
+// Node kinds (= record opcodes):
+//   LIN      dst = sum of up to F_MAX_TERMS terms coef * slot (coef a small signed integer)
+//   MUL      dst = a * b                       DIV   dst = a / b (0 if b = 0: integer_chip.rs:524-527)
+//   ISZERO   cond = (a == 0)                   NOT / AND / OR / XNOR on conditions (0 / 1)
+//   SELECT   dst = cond ? a : b (b = none: 0)  (int_div's mask :511-520, bisec_int :660-681)
+//   INPUT_W / CONST_W    a canonical W value from the instance inputs / the constant pool -> Montgomery form
+//   INPUT_FE / CONST_FE  a condition from the inputs (assign_bit) / the pool (assign_constant)
+// A record with a hint slot also stores its value (Montgomery form) into the hint workspace; h2e_field_finalize turns
+// the slots into canonical values afterwards.
+#pragma once
+#include <algorithm>
+#include <functional>
+#include <map>
+#include <stdexcept>
+#include <vector>
+#include <cstdlib>
+#include <cstdio>
+#include <string>
+#include "tape.h"
+#include "hbig.hpp"
+
+namespace h2e {
+
+struct FieldChain {
+    std::vector<uint32_t> recs;     // 8 words per record, no round straddles an H2E_WCHUNK-record chunk
+    std::vector<uint32_t> rounds;   // per round: first record, count | kind << 8
+    uint32_t n_slots = 0, n_load_rounds = 0;
+    uint32_t n_nodes = 0, n_mul = 0, n_lin = 0;
+    uint32_t hint_lo = 0xffffffffu, hint_hi = 0;   // hint slots written: [hint_lo, hint_hi)
+    std::string why;                // why a segment is not eligible
+};
+
+struct FieldCompiler {
+    const H2EOp* ops;
+    uint32_t n_ops;
+    int L;
+    int pw_check_limbs;
+    std::function<int(uint32_t, uint32_t)> producer;   // (region, row) -> op index of this segment or -1
+    uint32_t rel;                                      // 1: the segment's own cells are strand-relative refs
+    uint32_t first[3], last[3];
+    // further results the hint store wants in hint slots (conditions as raw 0 / 1, masked integers): op index -> slot
+    const std::map<uint32_t, uint32_t>* aux = nullptr;
+
+    struct Node {
+        uint8_t opc = 0;
+        int a = -1, b = -1, c = -1;                       // operand nodes
+        std::vector<std::pair<int, int>> terms;           // LIN: (node, coef)
+        uint32_t imm = 0;                                 // input slot / pool offset
+        uint32_t hint = 0xffffffffu;
+    };
+    std::vector<Node> nodes;
+    struct Expr {
+        std::vector<std::pair<int, int>> t;               // (base node, coef), sorted by node
+    };
+
+    static bool is_int_op(uint16_t oc) {
+        switch (oc) {
+            case H2E_OP_INT_MUL: case H2E_OP_REDUCE: case H2E_OP_DIV_CORE: case H2E_OP_INT_ADD: case H2E_OP_INT_SUB: case H2E_OP_INT_NEG:
+            case H2E_OP_INT_MUL_SMALL: case H2E_OP_MASK_INT: case H2E_OP_BISEC_INT: case H2E_OP_CONST_INT: case H2E_OP_CONST_INT_INPUT:
+            case H2E_OP_ASSIGN_W: return true;
+            default: return false;
+        }
+    }
+    static bool is_cond_op(uint16_t oc) {
+        switch (oc) {
+            case H2E_OP_IS_INT_ZERO: case H2E_OP_NOT: case H2E_OP_AND: case H2E_OP_OR: case H2E_OP_XNOR: case H2E_OP_ASSIGN_BIT:
+            case H2E_OP_CONST: case H2E_OP_ASSIGN: return true;
+            default: return false;
+        }
+    }
+    uint32_t fe_row(const H2EOp& op) const {
+        if (op.opcode == H2E_OP_IS_INT_ZERO) return op.base_row + 6 + 4 * (uint32_t)pw_check_limbs;
+        return op.base_row;
+    }
+    // the op of this segment whose integer / condition result starts at `ref`, or -1
+    int int_producer(uint32_t ref) const {
+        if (ref == H2E_NO_REF || H2E_REF_REGION(ref) == H2E_REGION_PARAM || H2E_REF_REL(ref) != rel) return -1;
+        uint32_t region = H2E_REF_REGION(ref), row = H2E_REF_ROW(ref), col = H2E_REF_COL(ref);
+        if (region > 1) return -1;
+        if (!rel && (row < first[region] || row >= last[region])) return -1;
+        int p = producer(region, row);
+        if (p < 0) return -1;
+        const H2EOp& po = ops[p];
+        switch (po.opcode) {
+            case H2E_OP_INT_MUL: case H2E_OP_REDUCE: case H2E_OP_DIV_CORE: case H2E_OP_ASSIGN_W:
+                return (region == 1 && col == 0 && row == po.range_row) ? p : -1;
+            case H2E_OP_INT_ADD: case H2E_OP_INT_SUB: case H2E_OP_INT_NEG: case H2E_OP_INT_MUL_SMALL: case H2E_OP_MASK_INT: case H2E_OP_BISEC_INT:
+                return (region == 0 && col == 4 && row == po.base_row) ? p : -1;
+            case H2E_OP_CONST_INT: case H2E_OP_CONST_INT_INPUT:
+                return (region == 0 && col == 0 && row == po.base_row) ? p : -1;
+            default: return -1;
+        }
+    }
+    int cond_producer(uint32_t ref) const {
+        if (ref == H2E_NO_REF || H2E_REF_REGION(ref) == H2E_REGION_PARAM || H2E_REF_REL(ref) != rel) return -1;
+        uint32_t region = H2E_REF_REGION(ref), row = H2E_REF_ROW(ref), col = H2E_REF_COL(ref);
+        if (region != 0) return -1;
+        if (!rel && (row < first[0] || row >= last[0])) return -1;
+        int p = producer(region, row);
+        if (p < 0) return -1;
+        const H2EOp& po = ops[p];
+        switch (po.opcode) {
+            case H2E_OP_IS_INT_ZERO: case H2E_OP_NOT: case H2E_OP_AND: case H2E_OP_OR: case H2E_OP_XNOR:
+                return (col == 4 && row == fe_row(po)) ? p : -1;
+            case H2E_OP_ASSIGN_BIT: case H2E_OP_CONST: case H2E_OP_ASSIGN:
+                return (col == 0 && row == po.base_row) ? p : -1;
+            default: return -1;
+        }
+    }
+    struct Opd { int refpos; bool is_int; };
+    int operands(const H2EOp& op, Opd* o) const {
+        int n = 0;
+        switch (op.opcode) {
+            case H2E_OP_INT_MUL: case H2E_OP_DIV_CORE: case H2E_OP_INT_ADD: case H2E_OP_INT_SUB:
+                o[n++] = {0, true}; o[n++] = {L + 1, true}; break;
+            case H2E_OP_REDUCE: case H2E_OP_INT_NEG: case H2E_OP_INT_MUL_SMALL: case H2E_OP_IS_INT_ZERO:
+                o[n++] = {0, true}; break;
+            case H2E_OP_MASK_INT:
+                o[n++] = {0, true}; o[n++] = {L + 1, false}; break;
+            case H2E_OP_BISEC_INT:
+                o[n++] = {0, false}; o[n++] = {1, true}; o[n++] = {L + 2, true}; break;
+            case H2E_OP_NOT:
+                o[n++] = {0, false}; break;
+            case H2E_OP_AND: case H2E_OP_OR: case H2E_OP_XNOR:
+                o[n++] = {0, false}; o[n++] = {1, false}; break;
+            default: break;
+        }
+        return n;
+    }
+
+    int F_MAX_TERMS = getenv("H2E_FIELD_TERMS") ? atoi(getenv("H2E_FIELD_TERMS")) : 6;
+    static constexpr int F_MAX_COEF = 255;
+    enum { F_NOP = 0, F_LIN, F_MUL, F_DIV, F_ISZERO, F_NOT, F_AND, F_OR, F_XNOR, F_SELECT, F_INPUT_W, F_INPUT_FE, F_CONST_W, F_CONST_FE };
+
+    int new_node(uint8_t opc) {
+        nodes.emplace_back();
+        nodes.back().opc = opc;
+        return (int)nodes.size() - 1;
+    }
+    static int max_coef(const Expr& e) {
+        int m = 0;
+        for (auto& kv : e.t) m = std::max(m, std::abs(kv.second));
+        return m;
+    }
+    static Expr merged(const Expr& a, int sa, const Expr& b, int sb) {
+        std::map<int, long long> acc;
+        for (auto& kv : a.t) acc[kv.first] += (long long)sa * kv.second;
+        for (auto& kv : b.t) acc[kv.first] += (long long)sb * kv.second;
+        Expr r;
+        for (auto& kv : acc)
+            if (kv.second != 0) r.t.push_back({kv.first, (int)std::max<long long>(-(1 << 30), std::min<long long>(1 << 30, kv.second))});
+        return r;
+    }
+    bool fits(const Expr& e) const { return (int)e.t.size() <= F_MAX_TERMS && max_coef(e) <= F_MAX_COEF; }
+    static Expr single(int node) {
+        Expr e;
+        e.t.push_back({node, 1});
+        return e;
+    }
+    std::vector<Expr> expr;          // per op: its integer result as a linear combination of nodes
+    // the node that holds the value of op p's result; from then on the op's expression is that node (every consumer
+    // shares it, and later combinations start from one term)
+    int mat(int p) {
+        Expr& e = expr[p];
+        if (e.t.size() == 1 && e.t[0].second == 1) return e.t[0].first;
+        int n = new_node(F_LIN);
+        nodes[n].terms = e.t;   // (an empty expression is the value 0)
+        e = single(n);
+        return n;
+    }
+    // sa * result(pa) + sb * result(pb) (pb < 0: no second operand), materialising operands when the combination would
+    // not fit a LIN record
+    Expr combine(int pa, int sa, int pb, int sb) {
+        static const Expr none;
+        auto eb = [&]() -> const Expr& { return pb >= 0 ? expr[pb] : none; };
+        Expr r = merged(expr[pa], sa, eb(), sb);
+        if (fits(r)) return r;
+        bool a_first = pb < 0 || expr[pa].t.size() >= expr[pb].t.size();
+        mat(a_first ? pa : pb);
+        r = merged(expr[pa], sa, eb(), sb);
+        if (fits(r)) return r;
+        if (pb >= 0) mat(a_first ? pb : pa);
+        r = merged(expr[pa], sa, eb(), sb);
+        if (!fits(r)) throw std::runtime_error("field chain: a two-term combination does not fit a record");
+        return r;
+    }
+
+    // Which ops of the segment carry a hint the replay / expansion will ask for, and can all of them be predicted?
+    // `check_only`: feasibility (before the compiler's dead-op pass), nothing is built.
+    bool compile(FieldChain& out, bool check_only) {
+        std::vector<uint8_t> needed(n_ops, 0);
+        std::vector<uint32_t> stack;
+        for (uint32_t i = 0; i < n_ops; i++) {
+            const H2EOp& op = ops[i];
+            if ((op.flags & H2E_FLAG_HINTED) && (op.opcode == H2E_OP_INT_MUL || op.opcode == H2E_OP_REDUCE || op.opcode == H2E_OP_DIV_CORE)) {
+                if (op.flags & H2E_FLAG_HINT_STRIDED) { out.why = "strided hint"; return false; }
+                needed[i] = 1;
+                stack.push_back(i);
+            }
+        }
+        if (aux)
+            for (auto& kv : *aux)
+                if (!needed[kv.first]) {
+                    needed[kv.first] = 1;
+                    stack.push_back(kv.first);
+                }
+        if (stack.empty()) { out.why = "no hinted op"; return false; }
+        while (!stack.empty()) {
+            uint32_t i = stack.back();
+            stack.pop_back();
+            const H2EOp& op = ops[i];
+            if (!is_int_op(op.opcode) && !is_cond_op(op.opcode)) { out.why = "op " + std::to_string(op.opcode) + " in the value cone"; return false; }
+            if ((op.opcode == H2E_OP_ASSIGN_W || op.opcode == H2E_OP_ASSIGN_BIT || op.opcode == H2E_OP_ASSIGN) && (op.flags & H2E_FLAG_INPUT_STRIDED)) {
+                out.why = "strided input";
+                return false;
+            }
+            Opd o[3];
+            int n = operands(op, o);
+            for (int q = 0; q < n; q++) {
+                int p = o[q].is_int ? int_producer(op.refs[o[q].refpos]) : cond_producer(op.refs[o[q].refpos]);
+                if (p < 0 || (uint32_t)p >= i) { out.why = "operand of op " + std::to_string(i) + " (opcode " + std::to_string(op.opcode) + ") is not a result of this segment"; return false; }
+                if (!needed[p]) {
+                    needed[p] = 1;
+                    stack.push_back((uint32_t)p);
+                }
+            }
+        }
+        if (check_only) return true;
+
+        // ---- expressions / nodes, in program order -----------------------------------------------------------------
+        expr.assign(n_ops, Expr());            // integer results
+        std::vector<int> cond(n_ops, -1);       // condition results: node
+        for (uint32_t i = 0; i < n_ops; i++) {
+            if (!needed[i]) continue;
+            const H2EOp& op = ops[i];
+            Opd o[3];
+            int n = operands(op, o);
+            int prod[3] = {-1, -1, -1};
+            for (int q = 0; q < n; q++) prod[q] = o[q].is_int ? int_producer(op.refs[o[q].refpos]) : cond_producer(op.refs[o[q].refpos]);
+            const bool hinted = (op.flags & H2E_FLAG_HINTED) != 0;
+            switch (op.opcode) {
+                case H2E_OP_INT_MUL: {
+                    int a = mat(prod[0]), b = mat(prod[1]);
+                    int m = new_node(F_MUL);
+                    nodes[m].a = a;
+                    nodes[m].b = b;
+                    if (hinted) nodes[m].hint = op.imm;
+                    expr[i] = single(m);
+                } break;
+                case H2E_OP_DIV_CORE: {   // refs: b, a'
+                    int b = mat(prod[0]), a = mat(prod[1]);
+                    int m = new_node(F_DIV);
+                    nodes[m].a = a;
+                    nodes[m].b = b;
+                    if (hinted) nodes[m].hint = op.imm;
+                    expr[i] = single(m);
+                } break;
+                case H2E_OP_REDUCE: {
+                    const Expr& e = expr[prod[0]];
+                    if (!hinted) {
+                        expr[i] = e;
+                    } else if (e.t.size() == 1 && e.t[0].second == 1 && nodes[e.t[0].first].hint == op.imm) {
+                        expr[i] = e;   // the reduce of a tagged value: the slot is already being filled
+                    } else {
+                        // a node of its own that owns the hint slot; consumers keep combining the operand's expression (as a
+                        // value mod w the reduce is the identity), so the hint store is off the dependency path
+                        int m = new_node(F_LIN);
+                        nodes[m].terms = e.t;
+                        nodes[m].hint = op.imm;
+                        expr[i] = getenv("H2E_FIELD_REDUCE_NODES") ? single(m) : e;
+                    }
+                } break;
+                case H2E_OP_INT_ADD: expr[i] = combine(prod[0], 1, prod[1], 1); break;
+                case H2E_OP_INT_SUB: expr[i] = combine(prod[0], 1, prod[1], -1); break;
+                case H2E_OP_INT_NEG: expr[i] = combine(prod[0], -1, -1, 1); break;
+                case H2E_OP_INT_MUL_SMALL: expr[i] = combine(prod[0], (int)op.imm, -1, 1); break;
+                case H2E_OP_MASK_INT: {   // a * coeff, coeff a condition
+                    int m = new_node(F_SELECT);
+                    nodes[m].c = cond[prod[1]];
+                    nodes[m].a = mat(prod[0]);
+                    nodes[m].b = -1;
+                    expr[i] = single(m);
+                } break;
+                case H2E_OP_BISEC_INT: {
+                    if (op.imm != 0 && (int)op.imm != L) { out.why = "bisec_int of another field"; return false; }
+                    int m = new_node(F_SELECT);
+                    nodes[m].c = cond[prod[0]];
+                    nodes[m].a = mat(prod[1]);
+                    nodes[m].b = mat(prod[2]);
+                    expr[i] = single(m);
+                } break;
+                case H2E_OP_CONST_INT: {
+                    int m = new_node(F_CONST_W);
+                    nodes[m].imm = op.imm;
+                    expr[i] = single(m);
+                } break;
+                case H2E_OP_CONST_INT_INPUT: case H2E_OP_ASSIGN_W: {
+                    int m = new_node(F_INPUT_W);
+                    nodes[m].imm = op.imm;
+                    expr[i] = single(m);
+                } break;
+                case H2E_OP_IS_INT_ZERO: {
+                    int m = new_node(F_ISZERO);
+                    nodes[m].a = mat(prod[0]);
+                    cond[i] = m;
+                } break;
+                case H2E_OP_NOT: {
+                    int m = new_node(F_NOT);
+                    nodes[m].a = cond[prod[0]];
+                    cond[i] = m;
+                } break;
+                case H2E_OP_AND: case H2E_OP_OR: case H2E_OP_XNOR: {
+                    int m = new_node(op.opcode == H2E_OP_AND ? F_AND : op.opcode == H2E_OP_OR ? F_OR : F_XNOR);
+                    nodes[m].a = cond[prod[0]];
+                    nodes[m].b = cond[prod[1]];
+                    cond[i] = m;
+                } break;
+                case H2E_OP_ASSIGN_BIT: case H2E_OP_ASSIGN: {
+                    int m = new_node(F_INPUT_FE);
+                    nodes[m].imm = op.imm;
+                    cond[i] = m;
+                } break;
+                case H2E_OP_CONST: {
+                    int m = new_node(F_CONST_FE);
+                    nodes[m].imm = op.imm;
+                    cond[i] = m;
+                } break;
+                default: out.why = "unexpected op"; return false;
+            }
+            if (aux) {
+                auto it = aux->find(i);
+                if (it != aux->end()) {
+                    int node = is_cond_op(op.opcode) ? cond[i] : (expr[i].t.size() == 1 && expr[i].t[0].second == 1 ? expr[i].t[0].first : -1);
+                    if (node < 0 || nodes[node].hint != 0xffffffffu) { out.why = "aux hint on a node that cannot take it"; return false; }
+                    nodes[node].hint = it->second;
+                }
+            }
+        }
+        // ---- alive nodes: what a hint-bearing node depends on --------------------------------------------------------
+        const size_t N = nodes.size();
+        std::vector<std::vector<uint32_t>> preds(N);
+        auto deps_of = [&](const Node& nd, std::vector<uint32_t>& d) {
+            d.clear();
+            auto add = [&](int x) {
+                if (x >= 0 && std::find(d.begin(), d.end(), (uint32_t)x) == d.end()) d.push_back((uint32_t)x);
+            };
+            add(nd.a);
+            add(nd.b);
+            add(nd.c);
+            for (auto& kv : nd.terms) add(kv.first);
+        };
+        std::vector<uint8_t> alive(N, 0);
+        {
+            std::vector<uint32_t> st, d;
+            for (size_t k = 0; k < N; k++)
+                if (nodes[k].hint != 0xffffffffu) {
+                    alive[k] = 1;
+                    st.push_back((uint32_t)k);
+                }
+            while (!st.empty()) {
+                uint32_t k = st.back();
+                st.pop_back();
+                deps_of(nodes[k], d);
+                for (uint32_t x : d)
+                    if (!alive[x]) {
+                        alive[x] = 1;
+                        st.push_back(x);
+                    }
+            }
+        }
+        std::vector<std::vector<uint32_t>> succs(N);
+        for (size_t k = 0; k < N; k++) {
+            if (!alive[k]) continue;
+            deps_of(nodes[k], preds[k]);
+            for (uint32_t x : preds[k]) succs[x].push_back((uint32_t)k);
+        }
+        // ---- rounds: backwards, cheapest class first (see schedule_classes in h2e_capi.cpp), 64 records per round ---------
+        auto cls_of = [&](uint32_t k) -> int {   // 0 light, 1 loads, 2 products, 3 divisions
+            switch (nodes[k].opc) {
+                case F_MUL: return 2;
+                case F_DIV: return 3;
+                case F_INPUT_W: case F_INPUT_FE: case F_CONST_W: case F_CONST_FE: return 1;
+                default: return 0;
+            }
+        };
+        const size_t STEP = 64;
+        std::vector<uint8_t> is_sink(N, 0), done(N, 0);
+        std::vector<uint32_t> left(N, 0);
+        size_t n_left = 0;
+        for (size_t k = 0; k < N; k++) {
+            if (!alive[k]) continue;
+            is_sink[k] = succs[k].empty() ? 1 : 0;
+        }
+        std::vector<uint32_t> ready[4], released;
+        for (size_t k = 0; k < N; k++) {
+            if (!alive[k] || is_sink[k]) continue;
+            for (uint32_t s : succs[k])
+                if (!is_sink[s]) left[k]++;
+            n_left++;
+        }
+        for (size_t k = 0; k < N; k++)
+            if (alive[k] && !is_sink[k] && left[k] == 0) ready[cls_of((uint32_t)k)].push_back((uint32_t)k);
+        std::vector<std::vector<uint32_t>> rounds_rev;
+        std::vector<int> rcls_rev;
+        while (n_left > 0) {
+            int c = -1;
+            for (int q = 0; q < 4 && c < 0; q++)
+                if (!ready[q].empty()) c = q;
+            if (c < 0) throw std::runtime_error("field chain: scheduler stalled");
+            std::vector<uint32_t> rd;
+            size_t take = std::min(STEP, ready[c].size());
+            rd.assign(ready[c].end() - take, ready[c].end());
+            ready[c].resize(ready[c].size() - take);
+            for (uint32_t k : rd) {
+                done[k] = 1;
+                n_left--;
+                for (uint32_t pp : preds[k])
+                    if (!is_sink[pp] && --left[pp] == 0) released.push_back(pp);
+            }
+            for (uint32_t pp : released) ready[cls_of(pp)].push_back(pp);
+            released.clear();
+            rounds_rev.push_back(std::move(rd));
+            rcls_rev.push_back(c);
+        }
+        std::vector<std::vector<uint32_t>> rounds(rounds_rev.rbegin(), rounds_rev.rend());
+        std::vector<int> rcls(rcls_rev.rbegin(), rcls_rev.rend());
+        std::vector<uint32_t> round_of(N, 0);
+        for (size_t r = 0; r < rounds.size(); r++)
+            for (uint32_t k : rounds[r]) round_of[k] = (uint32_t)r;
+        // sinks (nodes that only feed a hint slot): the first round of their class after their operands with a free lane
+        for (size_t k = 0; k < N; k++) {
+            if (!alive[k] || !is_sink[k]) continue;
+            size_t r0 = 0;
+            for (uint32_t pp : preds[k]) {
+                if (!done[pp]) throw std::runtime_error("field chain: sink reads an unplaced node");
+                r0 = std::max<size_t>(r0, (size_t)round_of[pp] + 1);
+            }
+            int c = cls_of((uint32_t)k);
+            bool placed = false;
+            for (size_t r = r0; r < rounds.size() && !placed; r++)
+                if (rcls[r] == c && rounds[r].size() < STEP) {
+                    rounds[r].push_back((uint32_t)k);
+                    round_of[k] = (uint32_t)r;
+                    placed = true;
+                }
+            if (!placed) {
+                rounds.push_back({(uint32_t)k});
+                rcls.push_back(c);
+                round_of[k] = (uint32_t)rounds.size() - 1;
+            }
+            done[k] = 1;
+        }
+        // the rounds of loads (inputs, constants: no operands) go first: the kernel runs them in a loop of its own, so that
+        // the main loop's body has no global load in it (a load anywhere in the body makes the compiler wait for the vector
+        // memory counter - i.e. for the hint stores in flight - on every path)
+        {
+            std::vector<std::vector<uint32_t>> front, rest;
+            std::vector<int> fcls, rcls2;
+            for (size_t r = 0; r < rounds.size(); r++) {
+                if (rcls[r] == 1) {
+                    front.push_back(std::move(rounds[r]));
+                    fcls.push_back(1);
+                } else {
+                    rest.push_back(std::move(rounds[r]));
+                    rcls2.push_back(rcls[r]);
+                }
+            }
+            out.n_load_rounds = (uint32_t)front.size();
+            rounds = std::move(front);
+            rounds.insert(rounds.end(), std::make_move_iterator(rest.begin()), std::make_move_iterator(rest.end()));
+            rcls = fcls;
+            rcls.insert(rcls.end(), rcls2.begin(), rcls2.end());
+            for (size_t r = 0; r < rounds.size(); r++)
+                for (uint32_t k : rounds[r]) round_of[k] = (uint32_t)r;
+        }
+        // ---- value slots by liveness over the rounds -------------------------------------------------------------------
+        std::vector<uint32_t> last_use(N, 0);
+        for (size_t k = 0; k < N; k++)
+            if (alive[k])
+                for (uint32_t pp : preds[k]) last_use[pp] = std::max(last_use[pp], round_of[k]);
+        std::vector<int> slot(N, -1);
+        std::vector<std::vector<int>> free_at(rounds.size() + 1);
+        std::vector<int> free_list;
+        int n_slots = 0;
+        for (size_t r = 0; r < rounds.size(); r++) {
+            for (int sl : free_at[r]) free_list.push_back(sl);
+            for (uint32_t k : rounds[r]) {
+                if (succs[k].empty()) continue;   // only stored to its hint slot
+                int sl;
+                if (!free_list.empty()) {
+                    sl = free_list.back();
+                    free_list.pop_back();
+                } else {
+                    sl = n_slots++;
+                }
+                slot[k] = sl;
+                free_at[std::min<size_t>((size_t)last_use[k] + 1, rounds.size())].push_back(sl);
+            }
+        }
+        if (n_slots >= 0xfff0) { out.why = "too many value slots"; return false; }
+        // ---- records -----------------------------------------------------------------------------------------------------
+        auto pad_chunk = [&]() {
+            while ((out.recs.size() / 8) % H2E_WCHUNK) out.recs.insert(out.recs.end(), 8, 0u);
+        };
+        auto slot_of = [&](int node) -> uint32_t {
+            if (node < 0) return 0xffffu;
+            if (slot[node] < 0) throw std::runtime_error("field chain: operand without a slot");
+            return (uint32_t)slot[node];
+        };
+        // a round = one header record (word 0: count | kind << 8) followed by its records; a round never straddles a chunk:
+        // a header with kind 0xff sends the kernel to the start of the next chunk (the rest of the chunk is padding).  The
+        // headers travel through LDS with the records: a header read from global memory would make the computing wave wait
+        // for every hint store it has in flight (loads and stores share one in-order counter).
+        size_t term_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t r = 0; r < rounds.size(); r++) {
+            auto& rd = rounds[r];
+            size_t at = out.recs.size() / 8;
+            if (at % H2E_WCHUNK + 1 + rd.size() > H2E_WCHUNK) {
+                uint32_t padh[8] = {0xff00u, 0, 0, 0, 0, 0, 0, 0};
+                out.recs.insert(out.recs.end(), padh, padh + 8);
+                pad_chunk();
+            }
+            at = out.recs.size() / 8;
+            out.rounds.push_back((uint32_t)at);
+            out.rounds.push_back((uint32_t)rd.size() | ((uint32_t)rcls[r] << 8));
+            {
+                uint32_t max_terms = 0;   // of the round's linear combinations (the kernel's term loop runs that far)
+                for (uint32_t k : rd)
+                    if (nodes[k].opc == F_LIN) max_terms = std::max<uint32_t>(max_terms, (uint32_t)nodes[k].terms.size());
+                term_hist[std::min<uint32_t>(max_terms, 7)]++;
+                uint32_t hdr[8] = {(uint32_t)rd.size() | ((uint32_t)rcls[r] << 8), max_terms, 0, 0, 0, 0, 0, 0};
+                out.recs.insert(out.recs.end(), hdr, hdr + 8);
+            }
+            for (uint32_t k : rd) {
+                const Node& nd = nodes[k];
+                uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                w[0] = nd.opc | ((slot[k] >= 0 ? (uint32_t)slot[k] : 0xffffu) << 16);
+                w[1] = nd.hint == 0xffffffffu ? 0u : nd.hint + 1;
+                if (nd.hint != 0xffffffffu) {
+                    out.hint_lo = std::min(out.hint_lo, nd.hint);
+                    out.hint_hi = std::max(out.hint_hi, nd.hint + 1);
+                }
+                switch (nd.opc) {
+                    case F_LIN:
+                        if ((int)nd.terms.size() > F_MAX_TERMS) throw std::runtime_error("field chain: LIN with too many terms");
+                        for (size_t t = 0; t < (size_t)6; t++)
+                            w[2 + t] = t < nd.terms.size() ? (slot_of(nd.terms[t].first) | ((uint32_t)(uint16_t)(int16_t)nd.terms[t].second << 16)) : 0xffffu;
+                        out.n_lin++;
+                        break;
+                    case F_MUL: case F_DIV: case F_AND: case F_OR: case F_XNOR:
+                        w[2] = slot_of(nd.a);
+                        w[3] = slot_of(nd.b);
+                        if (nd.opc == F_MUL) out.n_mul++;
+                        break;
+                    case F_ISZERO: case F_NOT: w[2] = slot_of(nd.a); break;
+                    case F_SELECT:
+                        w[2] = slot_of(nd.c);
+                        w[3] = slot_of(nd.a);
+                        w[4] = slot_of(nd.b);
+                        break;
+                    default: w[2] = nd.imm; break;
+                }
+                out.recs.insert(out.recs.end(), w, w + 8);
+            }
+        }
+        pad_chunk();
+        if (getenv("H2E_FIELD_STATS")) {
+            size_t cnt[4] = {0, 0, 0, 0}, ops_in[4] = {0, 0, 0, 0};
+            for (size_t r = 0; r < rounds.size(); r++) {
+                cnt[rcls[r]]++;
+                ops_in[rcls[r]] += rounds[r].size();
+            }
+            fprintf(stderr, "field chain rounds: light %zu (%zu ops), loads %zu, products %zu (%zu ops), divisions %zu\n", cnt[0], ops_in[0], cnt[1], cnt[2], ops_in[2], cnt[3]);
+            fprintf(stderr, "   rounds by their longest linear combination (0 .. 6 terms): %zu %zu %zu %zu %zu %zu %zu\n", term_hist[0], term_hist[1], term_hist[2],
+                    term_hist[3], term_hist[4], term_hist[5], term_hist[6]);
+        }
+        out.n_slots = (uint32_t)std::max(1, n_slots);
+        out.n_nodes = 0;
+        for (size_t k = 0; k < N; k++) out.n_nodes += alive[k];
+        return true;
+    }
+};
+
+
+
+// ================================================================================================
+// Hint store: what the values-only replay of a segment with field hints shrinks to.
+//
+// Once every mul-like result has its canonical value in a hint slot, every value the full expansion needs in place
+// before it starts - the results that escape their sub-range (tape.h H2E_FLAG_LOCAL_RESULT) - is a function of hints,
+// constants and inputs alone: a mul-like result *is* its hint, and a light result (int_add / int_sub / int_neg /
+// int_mul_small_constant chains, src/circuit/integer_chip.rs:384-464, :618-658) is a limb-wise integer combination
+//     limb_i = sum_j coef_j * limb_i(leaf_j) + K_i,       native = sum_j coef_j * native(leaf_j) + K_native  (mod n)
+// of the mul-like results / constants / inputs it was built from, K being the (signed) sum of the
+// find_w_modulus_of_ceil_times constants its int_sub / int_neg steps added - known when the program is compiled.  No
+// stored value depends on another stored value, so there is no chain left: one lane per (stored op, instance), instances
+// minor (coalesced like the expansion), engine.hip h2e_hint_store.
+//
+// Store op record (32-bit words):  w0 = kind | n_terms << 8 | K index << 16,  w1 = base row,  w2 = range row,
+//   w3.. = terms: leaf kind (bits 30-31: 0 hint slot, 1 pool word offset, 2 input slot) | (coef + 128) << 22 | index (22 bits)
+// kinds: S_W      mul-like result cells (limbs: range column 0 of rows w2 + 3 i, native: base (w1, 4)) <- its one leaf
+//        S_LIN    add-like result cells (limb i: base (w1 + i, 4), native: base (w1 + L, 4)) <- the combination
+//        S_FE     a condition cell base (w1, 4) <- raw word of hint slot (term 0)
+//        S_CONST  assign_int_constant rows (limb i: base (w1 + i, 0), native (w1 + L, 0)) <- pool constant (term 0)
+//        S_FULL   the tape op w1 (segment relative) run as it is (assign / assign_w / constants made from inputs)
+struct HintStore {
+    std::vector<uint32_t> words;      // the records
+    std::vector<uint32_t> offsets;    // per store op: first word of its record
+    std::vector<uint64_t> ktab;       // K constants: (2 L + 4) words each (limbs: 2 words each, native: 4 words)
+    std::map<uint32_t, uint32_t> aux_hint;   // op index -> hint slot the field chain must fill (conditions, masked integers)
+    uint32_t n_terms_max = 0;
+    std::string why;
+};
+
+struct StoreCompiler {
+    const H2EOp* ops;
+    uint32_t n_ops;
+    int L;
+    const H2EFieldConsts* fc;
+    const FieldCompiler* fcmp;      // operand resolution (shares producer / bounds)
+    uint32_t next_aux;              // first free hint slot
+
+    struct Lin {
+        std::map<uint32_t, int> leaf;      // leaf word (kind << 30 | index) -> coef
+        std::map<uint32_t, int> ceil;      // times -> multiplicity of ceil constant C_times
+    };
+    static void add_scaled(Lin& r, const Lin& a, int s) {
+        for (auto& kv : a.leaf) {
+            int& c = r.leaf[kv.first];
+            c += s * kv.second;
+            if (c == 0) r.leaf.erase(kv.first);
+        }
+        for (auto& kv : a.ceil) {
+            int& c = r.ceil[kv.first];
+            c += s * kv.second;
+            if (c == 0) r.ceil.erase(kv.first);
+        }
+    }
+    static bool supported(uint16_t oc) {
+        switch (oc) {
+            case H2E_OP_NOP: case H2E_OP_ASSIGN_W: case H2E_OP_ASSIGN: case H2E_OP_ASSIGN_BIT: case H2E_OP_CONST_INT: case H2E_OP_CONST_INT_INPUT:
+            case H2E_OP_CONST: case H2E_OP_INT_ADD: case H2E_OP_INT_SUB: case H2E_OP_INT_NEG: case H2E_OP_INT_MUL_SMALL: case H2E_OP_INT_MUL:
+            case H2E_OP_REDUCE: case H2E_OP_IS_INT_ZERO: case H2E_OP_NOT: case H2E_OP_MASK_INT: case H2E_OP_DIV_CORE: case H2E_OP_SUM_LIMBS:
+            case H2E_OP_ASSERT_CONST: case H2E_OP_AND: case H2E_OP_OR: case H2E_OP_XNOR:
+                return true;
+            default: return false;
+        }
+    }
+    // can every op of the segment be handled (before the dead-op pass: any of them may turn out to be stored)?
+    bool feasible(std::string& why) const {
+        for (uint32_t i = 0; i < n_ops; i++) {
+            const H2EOp& op = ops[i];
+            if (!supported(op.opcode)) { why = "hint store: opcode " + std::to_string(op.opcode); return false; }
+            if ((op.opcode == H2E_OP_ASSIGN_W || op.opcode == H2E_OP_ASSIGN || op.opcode == H2E_OP_ASSIGN_BIT) && (op.flags & H2E_FLAG_INPUT_STRIDED)) {
+                why = "hint store: strided input";
+                return false;
+            }
+            if (op.opcode == H2E_OP_INT_ADD || op.opcode == H2E_OP_INT_SUB || op.opcode == H2E_OP_INT_NEG || op.opcode == H2E_OP_INT_MUL_SMALL) {
+                FieldCompiler::Opd o[3];
+                int n = fcmp->operands(op, o);
+                for (int q = 0; q < n; q++)
+                    if (fcmp->int_producer(op.refs[o[q].refpos]) < 0) { why = "hint store: operand of a light op from outside the segment"; return false; }
+            }
+        }
+        return true;
+    }
+    std::vector<Lin> lin;
+    std::vector<uint8_t> have;
+    uint32_t aux_of(HintStore& out, uint32_t i) {
+        auto it = out.aux_hint.find(i);
+        if (it != out.aux_hint.end()) return it->second;
+        uint32_t s = next_aux++;
+        out.aux_hint[i] = s;
+        return s;
+    }
+    // the integer result of op p as a combination of leaves
+    const Lin& flatten(HintStore& out, uint32_t p) {
+        if (have[p]) return lin[p];
+        const H2EOp& op = ops[p];
+        Lin r;
+        auto leaf = [&](uint32_t kind, uint32_t index) {
+            if (index >= (1u << 22)) throw std::runtime_error("hint store: leaf index out of range");
+            r.leaf[(kind << 30) | index] = 1;
+        };
+        FieldCompiler::Opd o[3];
+        int n = fcmp->operands(op, o);
+        int prod[3] = {-1, -1, -1};
+        for (int q = 0; q < n; q++)
+            if (o[q].is_int) prod[q] = fcmp->int_producer(op.refs[o[q].refpos]);
+        switch (op.opcode) {
+            case H2E_OP_INT_MUL: case H2E_OP_REDUCE: case H2E_OP_DIV_CORE:
+                if (!(op.flags & H2E_FLAG_HINTED)) throw std::runtime_error("hint store: a live mul-like result without a hint");
+                leaf(0, op.imm);
+                break;
+            case H2E_OP_MASK_INT: leaf(0, aux_of(out, p)); break;
+            case H2E_OP_CONST_INT: leaf(1, op.imm); break;
+            case H2E_OP_ASSIGN_W: case H2E_OP_CONST_INT_INPUT: leaf(2, op.imm); break;
+            case H2E_OP_INT_ADD:
+                add_scaled(r, flatten(out, (uint32_t)prod[0]), 1);
+                add_scaled(r, flatten(out, (uint32_t)prod[1]), 1);
+                break;
+            case H2E_OP_INT_SUB:   // a - b + C_(b.times)   (integer_chip.rs:408-437)
+                add_scaled(r, flatten(out, (uint32_t)prod[0]), 1);
+                add_scaled(r, flatten(out, (uint32_t)prod[1]), -1);
+                r.ceil[op.imm] += 1;
+                if (r.ceil[op.imm] == 0) r.ceil.erase(op.imm);
+                break;
+            case H2E_OP_INT_NEG:   // C_(a.times) - a       (:439-464)
+                add_scaled(r, flatten(out, (uint32_t)prod[0]), -1);
+                r.ceil[op.imm] += 1;
+                if (r.ceil[op.imm] == 0) r.ceil.erase(op.imm);
+                break;
+            case H2E_OP_INT_MUL_SMALL:
+                add_scaled(r, flatten(out, (uint32_t)prod[0]), (int)op.imm);
+                break;
+            default: throw std::runtime_error("hint store: not an integer result");
+        }
+        lin[p] = std::move(r);
+        have[p] = 1;
+        return lin[p];
+    }
+    std::map<std::vector<uint64_t>, uint32_t> k_index;
+    uint32_t k_of(HintStore& out, const Lin& e) {
+        // K = sum mult_t * C_t: limbs modulo 2^128 (the true limb values are non-negative and below 2^128), native modulo n
+        std::vector<uint64_t> k((size_t)2 * L + 4, 0);
+        for (int i = 0; i < L; i++) {
+            unsigned __int128 acc = 0;
+            for (auto& kv : e.ceil) {
+                unsigned __int128 c = ((unsigned __int128)fc->ceil_limbs[kv.first][i][1] << 64) | fc->ceil_limbs[kv.first][i][0];
+                acc += (unsigned __int128)(__int128)kv.second * c;   // two's complement: a negative multiplicity wraps
+            }
+            k[2 * i] = (uint64_t)acc;
+            k[2 * i + 1] = (uint64_t)(acc >> 64);
+        }
+        HBig n = HBig::from_words(fc->n, 4), pos, neg;
+        for (auto& kv : e.ceil) {
+            HBig c = HBig::from_words(fc->ceil_native[kv.first], 4);
+            if (kv.second > 0) pos = pos + c * HBig((uint64_t)kv.second);
+            else neg = neg + c * HBig((uint64_t)(-kv.second));
+        }
+        HBig nat = (pos + n * (neg / n + HBig(1)) - neg) % n;
+        nat.to_words(&k[(size_t)2 * L], 4);
+        auto it = k_index.find(k);
+        if (it != k_index.end()) return it->second;
+        uint32_t idx = (uint32_t)(out.ktab.size() / ((size_t)2 * L + 4));
+        out.ktab.insert(out.ktab.end(), k.begin(), k.end());
+        k_index[k] = idx;
+        return idx;
+    }
+    bool compile(HintStore& out) {
+        lin.assign(n_ops, Lin());
+        have.assign(n_ops, 0);
+        {   // entry 0 of the K table: zero
+            Lin zero;
+            k_of(out, zero);
+        }
+        auto emit = [&](uint32_t kind, uint32_t k_idx, uint32_t w1, uint32_t w2, const std::vector<uint32_t>& terms) {
+            if (terms.size() > 255 || k_idx > 0xffff) throw std::runtime_error("hint store: record field overflow");
+            out.offsets.push_back((uint32_t)out.words.size());
+            out.words.push_back(kind | ((uint32_t)terms.size() << 8) | (k_idx << 16));
+            out.words.push_back(w1);
+            out.words.push_back(w2);
+            out.words.insert(out.words.end(), terms.begin(), terms.end());
+            out.n_terms_max = std::max<uint32_t>(out.n_terms_max, (uint32_t)terms.size());
+        };
+        auto term = [](uint32_t leaf_word, int coef) -> uint32_t {
+            if (coef < -127 || coef > 127) throw std::runtime_error("hint store: coefficient out of range");
+            return (leaf_word & 0xc0000000u) | ((uint32_t)(coef + 128) << 22) | (leaf_word & 0x3fffffu);
+        };
+        for (uint32_t i = 0; i < n_ops; i++) {
+            const H2EOp& op = ops[i];
+            if (op.flags & H2E_FLAG_VALUES_SKIP) continue;
+            bool local = (op.flags & H2E_FLAG_LOCAL_RESULT) != 0;
+            switch (op.opcode) {
+                case H2E_OP_NOP: case H2E_OP_ASSERT_CONST: case H2E_OP_SUM_LIMBS: break;
+                case H2E_OP_ASSIGN_W: case H2E_OP_ASSIGN: case H2E_OP_ASSIGN_BIT: case H2E_OP_CONST: case H2E_OP_CONST_INT_INPUT:
+                    emit(H2E_S_FULL, 0, i, 0, {});
+                    break;
+                case H2E_OP_CONST_INT: emit(H2E_S_CONST, 0, op.base_row, 0, {term((1u << 30) | op.imm, 1)}); break;
+                case H2E_OP_INT_MUL: case H2E_OP_REDUCE: case H2E_OP_DIV_CORE:
+                    if (local) break;
+                    if (!(op.flags & H2E_FLAG_HINTED)) { out.why = "hint store: stored mul-like result without a hint"; return false; }
+                    emit(H2E_S_W, 0, op.base_row, op.range_row, {term(op.imm, 1)});
+                    break;
+                case H2E_OP_MASK_INT:
+                    if (local) break;
+                    emit(H2E_S_LIN, 0, op.base_row, 0, {term(aux_of(out, i), 1)});
+                    break;
+                case H2E_OP_INT_ADD: case H2E_OP_INT_SUB: case H2E_OP_INT_NEG: case H2E_OP_INT_MUL_SMALL: {
+                    if (local) break;
+                    const Lin& e = flatten(out, i);
+                    std::vector<uint32_t> terms;
+                    for (auto& kv : e.leaf) terms.push_back(term(kv.first, kv.second));
+                    emit(H2E_S_LIN, k_of(out, e), op.base_row, 0, terms);
+                } break;
+                case H2E_OP_IS_INT_ZERO: case H2E_OP_NOT:
+                    if (local) break;
+                    emit(H2E_S_FE, 0, fcmp->fe_row(op), 0, {term(aux_of(out, i), 1)});
+                    break;
+                case H2E_OP_AND: case H2E_OP_OR: case H2E_OP_XNOR:
+                    emit(H2E_S_FE, 0, op.base_row, 0, {term(aux_of(out, i), 1)});
+                    break;
+                default: out.why = "hint store: opcode " + std::to_string(op.opcode); return false;
+            }
+        }
+        // masked integers that only feed other values still need their aux hint: flatten() registered them
+        return true;
+    }
+};
+
+}  // namespace h2e

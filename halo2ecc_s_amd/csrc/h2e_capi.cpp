@@ -11,6 +11,7 @@
 #include <cstring>
 #include "../../include/h2e.h"
 #include "recorder_pairing.hpp"
+#include "field_chain.hpp"
 
 extern "C" int h2e_engine_set_consts(int field_pair, const H2EFieldConsts* host);
 extern "C" int h2e_engine_export(uint32_t cols, int columns, int mont, const void* in, void* out, const uint8_t* flags, uint64_t rows,
@@ -129,6 +130,11 @@ struct h2e_program {
     std::vector<H2EVRec> h_lrecs;               // 64 records per step (lane l of a step runs record 64 * step + l)
     std::vector<uint32_t> h_lrefs;              // cell refs of global integer operands
     std::vector<uint32_t> seg_l_begin, seg_l_steps, seg_l_slots, seg_l_pair;
+    // hint store (field_chain.hpp): per segment with field hints, in place of a compiled replay
+    std::vector<uint32_t> h_swords, h_soffsets, seg_s_begin, seg_so_begin, seg_sk_begin, seg_n_sops;
+    std::vector<uint64_t> h_sktab;
+    uint32_t *d_swords = nullptr, *d_soffsets = nullptr;
+    uint64_t* d_sktab = nullptr;
     std::vector<uint32_t> h_lrounds;            // wave mode: per round (first record, count | kind << 8)
     std::vector<uint32_t> seg_lr_begin, seg_l_recs;
     H2EVRec* d_lrecs = nullptr;
@@ -156,6 +162,9 @@ struct h2e_program {
             (void)hipFree(d_lrecs);
             (void)hipFree(d_lrefs);
             (void)hipFree(d_lrounds);
+            (void)hipFree(d_swords);
+            (void)hipFree(d_soffsets);
+            (void)hipFree(d_sktab);
             for (int i = 0; i < 3; i++) (void)hipFree(d_flags[i]);
         }
         for (int i = 0; i < 3; i++) (void)hipFree(d_fix[i]);
@@ -237,7 +246,6 @@ struct h2e_program {
             }
             cs.push_back(std::move(c));
         }
-        if (cs.empty()) return;
         // producer of a row (strand-relative row for forks, absolute row for the main context) inside a cut segment
         auto producer = [&](const CutSeg& c, uint32_t region, uint32_t row) -> int {
             int lo = 0, hi = (int)c.n_ops - 1, ans = -1;
@@ -253,6 +261,57 @@ struct h2e_program {
             }
             return ans;
         };
+        // Field hints (Recorder::begin_field_hints): a segment whose mul-like ops carry hints of the field-domain predictor
+        // keeps them only if the predictor can be compiled for it (every op in the value cone of the hinted ops is one it
+        // knows, every operand a result of the segment itself); otherwise the flags go and the segment replays as before.
+        auto field_compiler = [&](const CutSeg& c) {
+            h2e::FieldCompiler fcmp;
+            fcmp.ops = c.ops;
+            fcmp.n_ops = c.n_ops;
+            fcmp.L = r.fp.limbs;
+            fcmp.pw_check_limbs = r.fp.pure_w_check_limbs;
+            fcmp.rel = c.sg->is_fork ? 1 : 0;
+            for (int reg = 0; reg < 3; reg++) {
+                fcmp.first[reg] = c.first[reg];
+                fcmp.last[reg] = c.last[reg];
+            }
+            const CutSeg* cp = &c;
+            fcmp.producer = [cp, &producer](uint32_t region, uint32_t row) { return producer(*cp, region, row); };
+            return fcmp;
+        };
+        for (auto& sg : r.segments) {
+            if (!sg.field_hints) continue;
+            bool ok = false;
+            std::string why = "segment has no cuts";
+            for (auto& c : cs)
+                if (c.sg == &sg) {
+                    h2e::FieldChain chain;
+                    h2e::FieldCompiler fcmp = field_compiler(c);
+                    ok = sg.n_strands == 1 && !sg.is_fork && sg.field_pair == r.fp.id && !getenv("H2E_NO_FIELD_CHAIN") && fcmp.compile(chain, true);
+                    why = chain.why;
+                    if (ok) {
+                        h2e::StoreCompiler sc;
+                        sc.ops = c.ops;
+                        sc.n_ops = c.n_ops;
+                        sc.L = r.fp.limbs;
+                        sc.fc = &r.fp.fc;
+                        sc.fcmp = &fcmp;
+                        sc.next_aux = 0;
+                        ok = sc.feasible(why);
+                    }
+                }
+            if (!ok) {
+                for (uint32_t i = sg.tape_begin; i < sg.tape_end; i++) {
+                    H2EOp& op = r.tape[i];
+                    if ((op.flags & H2E_FLAG_HINTED) && !(op.flags & H2E_FLAG_HINT_STRIDED) &&
+                        (op.opcode == H2E_OP_INT_MUL || op.opcode == H2E_OP_REDUCE || op.opcode == H2E_OP_DIV_CORE))
+                        op.flags &= ~(uint16_t)H2E_FLAG_HINTED;
+                }
+                sg.field_hints = false;
+                if (dbg_env("H2E_DUMP_TAPE")) fprintf(stderr, "segment %zu: no field chain (%s)\n", (size_t)(&sg - r.segments.data()), why.c_str());
+            }
+        }
+        if (cs.empty()) return;
         // an absolute reference from anywhere
         auto quote_abs = [&](uint32_t ref, const h2e::Segment* own = nullptr) {
             if (ref == H2E_NO_REF || H2E_REF_REGION(ref) == H2E_REGION_PARAM || H2E_REF_REL(ref)) return;
@@ -380,7 +439,67 @@ struct h2e_program {
         seg_l_pair.assign(r.segments.size(), 0);
         seg_lr_begin.assign(r.segments.size(), 0);
         seg_l_recs.assign(r.segments.size(), 0);
-        for (auto& c : cs) compile_replay(c.sg, c.ops, c.n_ops, c.first, c.last, [&](uint32_t region, uint32_t row) { return producer(c, region, row); });
+        seg_s_begin.assign(r.segments.size(), 0);
+        seg_so_begin.assign(r.segments.size(), 0);
+        seg_sk_begin.assign(r.segments.size(), 0);
+        seg_n_sops.assign(r.segments.size(), 0);
+        for (auto& c : cs)
+            if (!c.sg->field_hints)
+                compile_replay(c.sg, c.ops, c.n_ops, c.first, c.last, [&](uint32_t region, uint32_t row) { return producer(c, region, row); });
+        // 6. segments with field hints: the hint store in place of a replay, and the field-domain predictor whose program
+        // goes into the pre-kernel args
+        for (auto& c : cs) {
+            if (!c.sg->field_hints) continue;
+            size_t si = (size_t)(c.sg - r.segments.data());
+            h2e::FieldCompiler fcmp = field_compiler(c);
+            h2e::HintStore hs;
+            {
+                h2e::StoreCompiler sc;
+                sc.ops = c.ops;
+                sc.n_ops = c.n_ops;
+                sc.L = r.fp.limbs;
+                sc.fc = &r.fp.fc;
+                sc.fcmp = &fcmp;
+                sc.next_aux = r.n_hint_slots;
+                if (!sc.compile(hs)) throw std::runtime_error(hs.why);
+                r.n_hint_slots = sc.next_aux;
+                seg_s_begin[si] = (uint32_t)h_swords.size();
+                seg_so_begin[si] = (uint32_t)h_soffsets.size();
+                seg_sk_begin[si] = (uint32_t)h_sktab.size();
+                seg_n_sops[si] = (uint32_t)hs.offsets.size();
+                h_swords.insert(h_swords.end(), hs.words.begin(), hs.words.end());
+                h_soffsets.insert(h_soffsets.end(), hs.offsets.begin(), hs.offsets.end());
+                h_sktab.insert(h_sktab.end(), hs.ktab.begin(), hs.ktab.end());
+                if (dbg_env("H2E_DUMP_TAPE"))
+                    fprintf(stderr, "segment %zu: hint store: %zu store ops, %zu words, %zu K constants, at most %u terms, %zu aux hint slots\n", si,
+                            hs.offsets.size(), hs.words.size(), hs.ktab.size() / (2 * (size_t)r.fp.limbs + 4), hs.n_terms_max, hs.aux_hint.size());
+            }
+            fcmp.aux = &hs.aux_hint;
+            h2e::FieldChain chain;
+            if (!fcmp.compile(chain, false)) throw std::runtime_error("field chain: " + chain.why);
+            h2e::PreKernel pk;
+            std::memset(&pk.k, 0, sizeof(pk.k));
+            pk.k.kind = H2E_PRE_FIELD_CHAIN;
+            pk.k.n_lanes = 1;
+            pk.k.hint_base = chain.hint_hi > chain.hint_lo ? chain.hint_lo : 0;
+            pk.k.hints_per_lane = chain.hint_hi > chain.hint_lo ? chain.hint_hi - chain.hint_lo : 0;
+            pk.k.n_params = (uint32_t)r.fp.w_words;   // words per input slot
+            while (r.pre_args.size() % 8) r.pre_args.push_back(0);   // records are read 32 bytes at a time
+            pk.k.f_recs = (uint32_t)r.pre_args.size();
+            pk.k.f_n_recs = (uint32_t)(chain.recs.size() / 8);
+            r.pre_args.insert(r.pre_args.end(), chain.recs.begin(), chain.recs.end());
+            pk.k.f_rounds = (uint32_t)r.pre_args.size();
+            pk.k.f_n_rounds = (uint32_t)(chain.rounds.size() / 2);
+            r.pre_args.insert(r.pre_args.end(), chain.rounds.begin(), chain.rounds.end());
+            pk.k.f_slots = chain.n_slots;
+            pk.k.f_n_load_rounds = chain.n_load_rounds;
+            pk.before_segment = (uint32_t)(c.sg - r.segments.data());
+            pk.early_after_segment = -1;
+            r.pre_kernels.push_back(pk);
+            if (dbg_env("H2E_DUMP_TAPE"))
+                fprintf(stderr, "segment %u: field chain: %u nodes (%u products, %u linear combinations), %u rounds, %u value slots, hint slots [%u, %u)\n",
+                        pk.before_segment, chain.n_nodes, chain.n_mul, chain.n_lin, pk.k.f_n_rounds, chain.n_slots, chain.hint_lo, chain.hint_hi);
+        }
     }
 
     // Compile one cut segment into V-tape records (tape.h).  Values = results of alive ops; each gets an LDS slot for
@@ -1843,7 +1962,19 @@ struct h2e_ctx {
     int64_t test_skip_expansion = INT64_MIN;   // test hook (h2e_ctx_set_option): see H2E_OPT_TEST_SKIP_EXPANSION
     uint32_t last_split_segments = 0;          // segments of the last run whose expansion was split (h2e_ctx_get_stat)
     std::mutex mu;                             // h2e_run / h2e_submit on one context are serialised on the host
+    // Operator API: programs of the ops recorded so far, keyed by (op, arguments, operand handles, cursors, heights, msm prefix):
+    // a records object that repeats an op sequence (the next batch of the same circuit) re-uses them - no host-side recording,
+    // no new device tapes.  `outs` = the handles the op returned, byte for byte.
+    struct OpEntry {
+        h2e_program* prog = nullptr;
+        std::vector<std::vector<uint8_t>> outs;
+        size_t msm_prefix_after = 0;
+    };
+    std::map<std::string, OpEntry> op_cache;
+    std::mutex op_mu;
+    uint64_t op_hits = 0, op_misses = 0;
     ~h2e_ctx() {
+        for (auto& kv : op_cache) delete kv.second.prog;
         for (auto& kv : cache) delete kv.second;
         for (int i = 0; i < 3; i++)
             if (d_fc[i]) (void)hipFree(d_fc[i]);
@@ -2023,12 +2154,14 @@ int h2e_program_pairing_check_bn256(int emit_shape, h2e_program** out) {
         uint32_t s = r.alloc_inputs(10);
         h2e::NativeScalarEccContext ecc(r, h2e::bn256_g1_params(), 0);
         h2e::Bn256PairingOps po(r);
+        r.begin_field_hints();
         h2e::AssignedFq2 bx{r.assign_int_constant_input(s + 0), r.assign_int_constant_input(s + 1)};
         h2e::AssignedFq2 by{r.assign_int_constant_input(s + 2), r.assign_int_constant_input(s + 3)};
         h2e::AssignedG2Affine B{bx, by, h2e::AssignedCondition{r.assign_constant_u64(0)}};
         h2e::AssignedPoint neg_a = ecc.assign_point(h2e::PointInput{s + 4, s + 5, s + 6, false});
         h2e::AssignedPoint a = ecc.assign_point(h2e::PointInput{s + 7, s + 8, s + 9, false});
         po.check_pairing({h2e::PairingOps::Term(&a, &B), h2e::PairingOps::Term(&neg_a, &B)});
+        r.end_field_hints();
         p->finish();
     })
     *out = p;
@@ -2045,6 +2178,7 @@ int h2e_program_pairing_check_bls12_381(int emit_shape, h2e_program** out) {
         uint32_t s = r.alloc_inputs(14);
         h2e::NativeScalarEccContext ecc(r, h2e::bls12_381_g1_params(), 0);  // EccChipBaseOps of GeneralScalarEccContext
         h2e::Bls12381PairingOps po(r);
+        r.begin_field_hints();
         h2e::AssignedFq2 bx{r.assign_int_constant_input(s + 0), r.assign_int_constant_input(s + 1)};
         h2e::AssignedFq2 by{r.assign_int_constant_input(s + 2), r.assign_int_constant_input(s + 3)};
         h2e::AssignedG2Affine B{bx, by, h2e::AssignedCondition{r.assign_constant_u64(0)}};
@@ -2054,6 +2188,7 @@ int h2e_program_pairing_check_bls12_381(int emit_shape, h2e_program** out) {
         h2e::AssignedPoint neg_a = ecc.assign_point(h2e::PointInput{s + 8, s + 9, s + 10, false});
         h2e::AssignedPoint ac = ecc.assign_point(h2e::PointInput{s + 11, s + 12, s + 13, false});
         po.check_pairing({h2e::PairingOps::Term(&ac, &B), h2e::PairingOps::Term(&neg_a, &BC)});
+        r.end_field_hints();
         p->finish();
     })
     *out = p;
@@ -2077,6 +2212,7 @@ int h2e_program_pairing(int curve, uint32_t n_pairs, int with_expected, int emit
         if (curve == 0) po.reset(new h2e::Bn256PairingOps(r));
         else po.reset(new h2e::Bls12381PairingOps(r));
         std::vector<h2e::AssignedG2Affine> g2;
+        r.begin_field_hints();
         for (uint32_t k = 0; k < n_pairs; k++) {
             h2e::AssignedFq2 x{r.assign_int_constant_input(s + 4 * k + 0), r.assign_int_constant_input(s + 4 * k + 1)};
             h2e::AssignedFq2 y{r.assign_int_constant_input(s + 4 * k + 2), r.assign_int_constant_input(s + 4 * k + 3)};
@@ -2103,6 +2239,7 @@ int h2e_program_pairing(int curve, uint32_t n_pairs, int with_expected, int emit
                 for (int i = 0; i < r.fp.limbs; i++) r.outputs.push_back(a->limbs_le[i]);
                 r.outputs.push_back(a->native);
             }
+        r.end_field_hints();
         p->finish();
     })
     *out = p;
@@ -2192,6 +2329,9 @@ static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
     HIP_TRY(up((void**)&p->d_lrecs, p->h_lrecs.empty() ? nullptr : p->h_lrecs.data(), p->h_lrecs.size() * sizeof(H2EVRec)));
     HIP_TRY(up((void**)&p->d_lrefs, p->h_lrefs.empty() ? nullptr : p->h_lrefs.data(), p->h_lrefs.size() * 4));
     HIP_TRY(up((void**)&p->d_lrounds, p->h_lrounds.empty() ? nullptr : p->h_lrounds.data(), p->h_lrounds.size() * 4));
+    HIP_TRY(up((void**)&p->d_swords, p->h_swords.empty() ? nullptr : p->h_swords.data(), p->h_swords.size() * 4));
+    HIP_TRY(up((void**)&p->d_soffsets, p->h_soffsets.empty() ? nullptr : p->h_soffsets.data(), p->h_soffsets.size() * 4));
+    HIP_TRY(up((void**)&p->d_sktab, p->h_sktab.empty() ? nullptr : p->h_sktab.data(), p->h_sktab.size() * 8));
     p->device = ctx->device;
     return 0;
 }
@@ -2388,6 +2528,10 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         have_pending = false;
         return 0;
     };
+    // (the field chain reads the constant pool where the MSM predictors read strand parameters)
+    auto pk_params = [&](const h2e::PreKernel& pk) -> const uint32_t* {
+        return pk.k.kind == H2E_PRE_FIELD_CHAIN ? (const uint32_t*)p->d_pool : p->d_params;
+    };
     for (size_t si = 0; si < r.segments.size(); si++) {
         const h2e::Segment& s = r.segments[si];
         if (s.tape_end <= s.tape_begin) continue;
@@ -2417,7 +2561,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
                 HIP_TRY(hipStreamWaitEvent(sa, early_done[pi], 0));
                 continue;
             }
-            int prc = H2E_PREDICT(fp, 1, &pk.k, p->d_pre_args, p->d_params, p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sa);
+            int prc = H2E_PREDICT(fp, 1, &pk.k, p->d_pre_args, pk_params(pk), p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sa);
             if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
         }
         if (have_pending && hold_longer && s.sel_stride) {
@@ -2431,7 +2575,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             hipEvent_t e0 = sync_event();
             HIP_TRY(hipEventRecord(e0, sa));
             HIP_TRY(hipStreamWaitEvent(sc, e0, 0));
-            int prc = H2E_PREDICT(fp, 3, &pk.k, p->d_pre_args, p->d_params, p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sc);
+            int prc = H2E_PREDICT(fp, 3, &pk.k, p->d_pre_args, pk_params(pk), p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sc);
             if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
             hipEvent_t e1 = sync_event();
             HIP_TRY(hipEventRecord(e1, sc));
@@ -2441,7 +2585,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         for (size_t pi = 0; pi < r.pre_kernels.size(); pi++) {
             const h2e::PreKernel& pk = r.pre_kernels[pi];
             if (pk.before_segment != si || early_done[pi]) continue;
-            int prc = H2E_PREDICT(fp, 2, &pk.k, p->d_pre_args, p->d_params, p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sa);
+            int prc = H2E_PREDICT(fp, 2, &pk.k, p->d_pre_args, pk_params(pk), p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sa);
             if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
         }
         H2ELaunch L;
@@ -2479,6 +2623,11 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         L.lrefs = p->d_lrefs;
         L.lrounds = levels && p->seg_l_pair[si] == 2 ? p->d_lrounds + p->seg_lr_begin[si] : nullptr;
         L.l_recs = levels ? p->seg_l_recs[si] : 0;
+        bool hstore = si < p->seg_n_sops.size() && p->seg_n_sops[si] > 0;
+        L.s_words = hstore ? p->d_swords + p->seg_s_begin[si] : nullptr;
+        L.s_offsets = hstore ? p->d_soffsets + p->seg_so_begin[si] : nullptr;
+        L.s_ktab = hstore ? p->d_sktab + p->seg_sk_begin[si] : nullptr;
+        L.n_sops = hstore ? p->seg_n_sops[si] : 0;
         L.l_steps = levels ? p->seg_l_steps[si] : 0;
         L.l_slots = levels ? p->seg_l_slots[si] : 0;
         L.l_pair = levels ? p->seg_l_pair[si] : 0;
@@ -2734,6 +2883,14 @@ int64_t h2e_ctx_get_stat(h2e_ctx* ctx, int stat) {
             return (int64_t)h2e_engine_scan_fallbacks();
         case H2E_STAT_PIPELINE_DEPTH: return ctx->depth;
         case H2E_STAT_MAX_PIPELINE_DEPTH: return h2e_ctx::N_SLOTS;
+        case H2E_STAT_OP_CACHE_HITS: {
+            std::lock_guard<std::mutex> g2(ctx->op_mu);
+            return (int64_t)ctx->op_hits;
+        }
+        case H2E_STAT_OP_CACHE_MISSES: {
+            std::lock_guard<std::mutex> g2(ctx->op_mu);
+            return (int64_t)ctx->op_misses;
+        }
         default: return -1;
     }
 }
@@ -3010,14 +3167,14 @@ struct h2e_records {
     std::vector<uint8_t> flags[3];
     std::vector<uint32_t> perm_flat;
     std::vector<uint32_t> patch_flat;   // [row, fixed col, op index << 16 | input slot, limb]
-    std::vector<h2e_program*> programs; // the ops' programs (their device tapes are in use until the stream has drained)
+    void* d_dummy = nullptr;            // input vector of ops that take none (the engine wants a valid pointer)
     h2e_records() { dict.push_back(h2e::FrVal{0, 0, 0, 0}); }
     ~h2e_records() {
         if (ctx) {
             (void)hipSetDevice(ctx->device);
             (void)hipDeviceSynchronize();
         }
-        for (auto* p : programs) delete p;
+        (void)hipFree(d_dummy);
         if (own_arrays) {
             for (int i = 0; i < 3; i++) (void)hipFree(d_arr[i]);
             (void)hipFree(d_status);
@@ -3058,60 +3215,103 @@ h2e_point from_point(const h2e::AssignedPoint& p) {
     return r;
 }
 
-// Record one op at the records' current state, run it, merge its shape artefacts and advance the Context.
-int records_op(h2e_records* R, uint32_t n_slots, const void* d_inputs, void* stream,
+// Record one op at the records' current state (or take its program from the context's op cache), run it, merge its shape
+// artefacts and advance the Context.  `key` names the op and everything its recording depends on besides the records' state;
+// `outs` lists the caller's output handles (filled by `body` when the op is recorded, from the cache otherwise).
+struct OpOut {
+    void* ptr;
+    size_t bytes;
+};
+std::string key_of(const char* name, std::initializer_list<std::pair<const void*, size_t>> blobs) {
+    std::string k(name);
+    for (auto& b : blobs) {
+        k.push_back('|');
+        if (b.first) k.append((const char*)b.first, b.second);
+    }
+    return k;
+}
+int records_op(h2e_records* R, const std::string& key, uint32_t n_slots, const void* d_inputs, void* stream, std::initializer_list<OpOut> outs,
                const std::function<void(h2e::Recorder&, h2e::NativeScalarEccContext&, uint32_t)>& body) {
     if (!R) return fail(H2E_ERR_INVALID, "null records");
     if (n_slots && !d_inputs) return fail(H2E_ERR_INVALID, "the op takes inputs: d_inputs is null");
-    h2e_program* p = new h2e_program();
-    p->field_pair = R->field_pair;
-    try {
-        p->rec.reset(new h2e::Recorder(field_pair(R->field_pair)));
-        h2e::Recorder& r = *p->rec;
-        r.emit_shape = R->emit_shape;
-        // clone_with_offset of the caller's context (context.rs:145-158): cursors and heights carry over
-        r.base_offset = R->off[0];
-        r.range_offset = R->off[1];
-        r.select_offset = R->off[2];
-        r.base_height = R->height[0];
-        r.range_height = R->height[1];
-        r.select_height = R->height[2];
-        h2e::NativeScalarEccContext ecc(r, R->field_pair == H2E_FIELD_BN256_FQ ? h2e::bn256_g1_params() : h2e::bls12_381_g1_params(), R->msm_prefix);
-        ecc.scalar_field = R->scalar_field;
-        uint32_t s0 = r.alloc_inputs(std::max<uint32_t>(1, n_slots));
-        body(r, ecc, s0);
-        p->finish();
-        if (p->base_rows > R->cap[0] || p->range_rows > R->cap[1] || p->select_rows > R->cap[2]) {
-            delete p;
-            return fail(H2E_ERR_SHAPE, "records: the op does not fit the arrays' capacity (like HALO2ECC_S_MAX_ROWS, src/context.rs:36)");
-        }
-        R->msm_prefix = ecc.msm_prefix;
-    } catch (std::exception& e) {
-        delete p;
-        return fail(H2E_ERR_SHAPE, e.what());
+    if (R->n_ops >= 65535) return fail(H2E_ERR_SHAPE, "records: more than 65535 ops (the fixed-patch list packs the op index in 16 bits)");
+    h2e_ctx* ctx = R->ctx;
+    std::string full = key;
+    {
+        uint64_t st[9] = {R->off[0], R->off[1], R->off[2], R->height[0], R->height[1], R->height[2], (uint64_t)R->msm_prefix,
+                          (uint64_t)(R->field_pair * 8 + (R->scalar_field + 1)), (uint64_t)(R->emit_shape ? 1 : 0) | ((uint64_t)n_slots << 8)};
+        full.push_back('#');
+        full.append((const char*)st, sizeof(st));
     }
+    h2e_program* p = nullptr;
+    {
+        std::lock_guard<std::mutex> g(ctx->op_mu);
+        auto it = ctx->op_cache.find(full);
+        if (it != ctx->op_cache.end()) {
+            p = it->second.prog;
+            size_t k = 0;
+            for (auto& o : outs) {
+                if (o.ptr && k < it->second.outs.size() && it->second.outs[k].size() == o.bytes) std::memcpy(o.ptr, it->second.outs[k].data(), o.bytes);
+                k++;
+            }
+            R->msm_prefix = it->second.msm_prefix_after;
+            ctx->op_hits++;
+        }
+    }
+    if (!p) {
+        std::unique_ptr<h2e_program> np(new h2e_program());
+        np->field_pair = R->field_pair;
+        size_t prefix_after = R->msm_prefix;
+        try {
+            np->rec.reset(new h2e::Recorder(field_pair(R->field_pair)));
+            h2e::Recorder& r = *np->rec;
+            r.emit_shape = R->emit_shape;
+            // clone_with_offset of the caller's context (context.rs:145-158): cursors and heights carry over
+            r.base_offset = R->off[0];
+            r.range_offset = R->off[1];
+            r.select_offset = R->off[2];
+            r.base_height = R->height[0];
+            r.range_height = R->height[1];
+            r.select_height = R->height[2];
+            h2e::NativeScalarEccContext ecc(r, R->field_pair == H2E_FIELD_BN256_FQ ? h2e::bn256_g1_params() : h2e::bls12_381_g1_params(), R->msm_prefix);
+            ecc.scalar_field = R->scalar_field;
+            uint32_t s0 = r.alloc_inputs(std::max<uint32_t>(1, n_slots));
+            body(r, ecc, s0);
+            np->finish();
+            prefix_after = ecc.msm_prefix;
+        } catch (std::exception& e) {
+            return fail(H2E_ERR_SHAPE, e.what());
+        }
+        if (np->base_rows > R->cap[0] || np->range_rows > R->cap[1] || np->select_rows > R->cap[2])
+            return fail(H2E_ERR_SHAPE, "records: the op does not fit the arrays' capacity (like HALO2ECC_S_MAX_ROWS, src/context.rs:36)");
+        R->msm_prefix = prefix_after;
+        std::lock_guard<std::mutex> g(ctx->op_mu);
+        h2e_ctx::OpEntry& e = ctx->op_cache[full];
+        if (!e.prog) {
+            e.prog = np.release();
+            for (auto& o : outs) e.outs.emplace_back((const uint8_t*)o.ptr, (const uint8_t*)o.ptr + (o.ptr ? o.bytes : 0));
+            e.msm_prefix_after = prefix_after;
+            ctx->op_misses++;
+        }
+        p = e.prog;
+    }
+    if (p->base_rows > R->cap[0] || p->range_rows > R->cap[1] || p->select_rows > R->cap[2])
+        return fail(H2E_ERR_SHAPE, "records: the op does not fit the arrays' capacity (like HALO2ECC_S_MAX_ROWS, src/context.rs:36)");
     h2e::Recorder& r = *p->rec;
-    static const uint64_t dummy_zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    (void)dummy_zero;
     int rc = 0;
     if (!r.tape.empty()) {
         const void* in = d_inputs;
-        void* scratch = nullptr;
         if (!in) {   // ops without inputs still get a valid (unused) pointer
-            HIP_TRY(hipSetDevice(R->ctx->device));
-            HIP_TRY(hipMalloc(&scratch, (size_t)R->n_instances * 64));
-            in = scratch;
+            if (!R->d_dummy) {
+                HIP_TRY(hipSetDevice(ctx->device));
+                HIP_TRY(hipMalloc(&R->d_dummy, (size_t)R->n_instances * 64));
+                HIP_TRY(hipMemset(R->d_dummy, 0, (size_t)R->n_instances * 64));
+            }
+            in = R->d_dummy;
         }
-        rc = h2e_run(R->ctx, p, R->n_instances, in, R->d_arr[0], R->d_arr[1], R->d_arr[2], R->d_status, stream);
-        if (scratch) {
-            (void)hipStreamSynchronize((hipStream_t)stream);
-            (void)hipFree(scratch);
-        }
+        rc = h2e_run(ctx, p, R->n_instances, in, R->d_arr[0], R->d_arr[1], R->d_arr[2], R->d_status, stream);
     }
-    if (rc) {
-        delete p;
-        return rc;
-    }
+    if (rc) return rc;
     // merge (ParallelClone::merge + apply_offset_diff)
     uint64_t before[3] = {R->off[0], R->off[1], R->off[2]};
     R->off[0] = r.base_offset;
@@ -3161,7 +3361,6 @@ int records_op(h2e_records* R, uint32_t n_slots, const void* d_inputs, void* str
         R->n_advice_cells += r.n_advice_cells;
     }
     R->n_ops++;
-    R->programs.push_back(p);
     return 0;
 }
 }  // namespace
@@ -3193,6 +3392,36 @@ int h2e_records_create(h2e_ctx* ctx, int field_pair_id, int scalar_field, uint32
         delete R;
         return fail(H2E_ERR_HIP, std::string("records: ") + hipGetErrorString(e));
     }
+    *out = R;
+    return 0;
+}
+int h2e_records_attach(h2e_ctx* ctx, int field_pair_id, int scalar_field, uint32_t n_instances, void* d_base, void* d_range, void* d_select,
+                       void* d_status, const uint64_t capacity_rows[3], const uint64_t offset0[3], uint64_t msm_prefix0, int emit_shape,
+                       h2e_records** out) {
+    if (!ctx || !out || !capacity_rows || !offset0) return fail(H2E_ERR_INVALID, "null argument");
+    if (!d_base || !d_range || !d_select || !d_status) return fail(H2E_ERR_INVALID, "null device pointer");
+    if (field_pair_id < 0 || field_pair_id > 2 || scalar_field < -1 || scalar_field > 2) return fail(H2E_ERR_INVALID, "bad field pair");
+    if (n_instances == 0) return fail(H2E_ERR_INVALID, "empty records");
+    for (int i = 0; i < 3; i++)
+        if (capacity_rows[i] == 0 || offset0[i] >= capacity_rows[i] || capacity_rows[i] > (1ull << 26))
+            return fail(H2E_ERR_INVALID, "offsets must lie inside the arrays (at most 2^26 rows)");
+    h2e_records* R = new h2e_records();
+    R->ctx = ctx;
+    R->field_pair = field_pair_id;
+    R->scalar_field = scalar_field;
+    R->n_instances = n_instances;
+    R->emit_shape = emit_shape != 0;
+    R->own_arrays = false;
+    R->d_arr[0] = d_base;
+    R->d_arr[1] = d_range;
+    R->d_arr[2] = d_select;
+    R->d_status = (uint32_t*)d_status;
+    for (int i = 0; i < 3; i++) {
+        R->cap[i] = capacity_rows[i];
+        R->off[i] = offset0[i];
+        R->height[i] = offset0[i];
+    }
+    R->msm_prefix = (size_t)msm_prefix0;
     *out = R;
     return 0;
 }
@@ -3247,15 +3476,19 @@ int h2e_records_shape(const h2e_records* R, h2e_shape* out) {
 // ---- ops: same names and argument meaning as the reference's traits -------------------------------------------------
 int h2e_op_assign_w(h2e_records* R, const void* d_inputs, h2e_int* out, void* stream) {   // IntegerChipOps::assign_w (integer_chip.rs:236-258)
     if (!out) return fail(H2E_ERR_INVALID, "out is null");
-    return records_op(R, 1, d_inputs, stream, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t s) { *out = from_int(r.assign_w(s)); });
+    return records_op(R, key_of("assign_w", {}), 1, d_inputs, stream, {OpOut{out, sizeof(*out)}}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t s) { *out = from_int(r.assign_w(s)); });
 }
 int h2e_op_assign(h2e_records* R, const void* d_inputs, uint32_t* out_cell, void* stream) {   // BaseChipOps::assign (base_chip.rs:351-355)
     if (!out_cell) return fail(H2E_ERR_INVALID, "out is null");
-    return records_op(R, 1, d_inputs, stream, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t s) { *out_cell = r.assign(s).ref; });
+    return records_op(R, key_of("assign", {}), 1, d_inputs, stream, {OpOut{out_cell, sizeof(*out_cell)}}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t s) { *out_cell = r.assign(s).ref; });
 }
 int h2e_op_int(h2e_records* R, int which, const h2e_int* a, const h2e_int* b, h2e_int* out, uint32_t* out_cond, void* stream) {
-    if (!a || !out || (which != H2E_INT_REDUCE && !b)) return fail(H2E_ERR_INVALID, "null operand");
-    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
+    const bool binary = which == H2E_INT_ADD || which == H2E_INT_SUB || which == H2E_INT_MUL || which == H2E_INT_DIV || which == H2E_INT_IS_EQUAL ||
+                        which == H2E_INT_ASSERT_EQUAL;
+    const bool no_out = which == H2E_INT_IS_ZERO || which == H2E_INT_IS_EQUAL || which == H2E_INT_ASSERT_EQUAL;
+    if (!a || (binary && !b) || (!no_out && !out)) return fail(H2E_ERR_INVALID, "null operand");
+    if (no_out) out = nullptr;
+    return records_op(R, key_of("int", {{&which, sizeof(which)}, {a, sizeof(*a)}, {b, b ? sizeof(*b) : 0}}), 0, nullptr, stream, {OpOut{out, out ? sizeof(*out) : 0}, OpOut{out_cond, out_cond ? sizeof(*out_cond) : 0}}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
         h2e::AssignedInteger x = to_int(*a), y = b ? to_int(*b) : h2e::AssignedInteger();
         switch (which) {
             case H2E_INT_ADD: *out = from_int(r.int_add(x, y)); break;
@@ -3267,20 +3500,136 @@ int h2e_op_int(h2e_records* R, int which, const h2e_int* a, const h2e_int* b, h2
                 *out = from_int(d.second);
                 if (out_cond) *out_cond = d.first.v.ref;
             } break;
+            case H2E_INT_NEG: *out = from_int(r.int_neg(x)); break;
+            case H2E_INT_SQUARE: *out = from_int(r.int_square(x)); break;
+            case H2E_INT_UNSAFE_INVERT: *out = from_int(r.int_unsafe_invert(x)); break;
+            case H2E_INT_IS_ZERO: {
+                h2e::AssignedCondition c = r.is_int_zero(x);
+                if (out_cond) *out_cond = c.v.ref;
+            } break;
+            case H2E_INT_IS_EQUAL: {
+                h2e::AssignedCondition c = r.is_int_equal(x, y);
+                if (out_cond) *out_cond = c.v.ref;
+            } break;
+            case H2E_INT_ASSERT_EQUAL: r.assert_int_equal(x, y); break;
             default: throw std::runtime_error("h2e_op_int: unknown op");
+        }
+    });
+}
+int h2e_op_int_mul_small_constant(h2e_records* R, const h2e_int* a, uint64_t k, h2e_int* out, void* stream) {   // integer_chip.rs:618-658
+    if (!a || !out) return fail(H2E_ERR_INVALID, "null operand");
+    return records_op(R, key_of("int_mul_small", {{a, sizeof(*a)}, {&k, sizeof(k)}}), 0, nullptr, stream, {OpOut{out, sizeof(*out)}}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) { *out = from_int(r.int_mul_small_constant(to_int(*a), k)); });
+}
+int h2e_op_assign_int_constant(h2e_records* R, const uint64_t* w_words, h2e_int* out, void* stream) {   // integer_chip.rs:580-598
+    if (!w_words || !out) return fail(H2E_ERR_INVALID, "null operand");
+    return records_op(R, key_of("int_const", {{w_words, (size_t)field_pair(R ? R->field_pair : 0).w_words * 8}}), 0, nullptr, stream, {OpOut{out, sizeof(*out)}}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
+        *out = from_int(r.assign_int_constant(h2e::HBig::from_words(w_words, r.fp.w_words)));
+    });
+}
+int h2e_op_bisec_int(h2e_records* R, uint32_t cond_cell, const h2e_int* a, const h2e_int* b, h2e_int* out, void* stream) {   // integer_chip.rs:660-681
+    if (!a || !b || !out) return fail(H2E_ERR_INVALID, "null operand");
+    return records_op(R, key_of("bisec_int", {{&cond_cell, sizeof(cond_cell)}, {a, sizeof(*a)}, {b, sizeof(*b)}}), 0, nullptr, stream, {OpOut{out, sizeof(*out)}}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
+        *out = from_int(r.bisec_int(h2e::AssignedCondition{h2e::AssignedValue{cond_cell}}, to_int(*a), to_int(*b)));
+    });
+}
+namespace {
+h2e::AssignedFq2 to_fq2(const h2e_int* a) { return h2e::AssignedFq2{to_int(a[0]), to_int(a[1])}; }
+h2e::AssignedFq6 to_fq6(const h2e_int* a) { return h2e::AssignedFq6{to_fq2(a), to_fq2(a + 2), to_fq2(a + 4)}; }
+h2e::AssignedFq12 to_fq12(const h2e_int* a) { return h2e::AssignedFq12{to_fq6(a), to_fq6(a + 6)}; }
+void from_fq2(const h2e::AssignedFq2& x, h2e_int* o) {
+    o[0] = from_int(x.c0);
+    o[1] = from_int(x.c1);
+}
+void from_fq6(const h2e::AssignedFq6& x, h2e_int* o) {
+    from_fq2(x.c0, o);
+    from_fq2(x.c1, o + 2);
+    from_fq2(x.c2, o + 4);
+}
+void from_fq12(const h2e::AssignedFq12& x, h2e_int* o) {
+    from_fq6(x.c0, o);
+    from_fq6(x.c1, o + 6);
+}
+std::unique_ptr<h2e::PairingOps> tower_of(h2e::Recorder& r) {
+    if (r.fp.id == H2E_FIELD_BN256_FQ) return std::unique_ptr<h2e::PairingOps>(new h2e::Bn256PairingOps(r));
+    if (r.fp.id == H2E_FIELD_BLS12_381_FQ) return std::unique_ptr<h2e::PairingOps>(new h2e::Bls12381PairingOps(r));
+    throw std::runtime_error("no extension tower over this field");
+}
+}  // namespace
+// Fq2ChipOps / Fq6ChipOps / Fq12ChipOps (src/circuit/fq12.rs:24-459) on assigned elements
+int h2e_op_fq(h2e_records* R, int degree, int which, const h2e_int* a, const h2e_int* b, uint64_t imm, h2e_int* out, void* stream) {
+    if (!a || (degree != 2 && degree != 6 && degree != 12)) return fail(H2E_ERR_INVALID, "bad argument");
+    bool binary = which == H2E_FQ_ADD || which == H2E_FQ_SUB || which == H2E_FQ_MUL || which == H2E_FQ_ASSERT_EQUAL;
+    if ((binary && !b) || (which != H2E_FQ_ASSERT_EQUAL && !out)) return fail(H2E_ERR_INVALID, "null operand");
+    return records_op(R, key_of("fq", {{&degree, sizeof(degree)}, {&which, sizeof(which)}, {a, sizeof(*a) * (size_t)degree}, {b, b ? sizeof(*b) * (size_t)degree : 0}, {&imm, sizeof(imm)}}), 0, nullptr, stream, {OpOut{out, out ? sizeof(*out) * (size_t)degree : 0}}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
+        std::unique_ptr<h2e::PairingOps> t = tower_of(r);
+        r.auto_cut_every = 16;
+        auto bad = [] { throw std::runtime_error("h2e_op_fq: no such op at this degree"); };
+        if (degree == 2) {
+            h2e::AssignedFq2 x = to_fq2(a), y = b ? to_fq2(b) : h2e::AssignedFq2(), o;
+            switch (which) {
+                case H2E_FQ_ADD: o = t->fq2_add(x, y); break;
+                case H2E_FQ_SUB: o = t->fq2_sub(x, y); break;
+                case H2E_FQ_MUL: o = t->fq2_mul(x, y); break;
+                case H2E_FQ_SQUARE: o = t->fq2_square(x); break;
+                case H2E_FQ_NEG: o = t->fq2_neg(x); break;
+                case H2E_FQ_DOUBLE: o = t->fq2_double(x); break;
+                case H2E_FQ_CONJUGATE: o = t->fq2_conjugate(x); break;
+                case H2E_FQ_UNSAFE_INVERT: o = t->fq2_unsafe_invert(x); break;
+                case H2E_FQ_MUL_BY_NONRESIDUE: o = t->fq2_mul_by_nonresidue(x); break;
+                case H2E_FQ_FROBENIUS_MAP: o = t->fq2_frobenius_map(x, (size_t)imm); break;
+                case H2E_FQ_REDUCE: o = t->fq2_reduce(x); break;
+                case H2E_FQ_ASSERT_EQUAL: t->fq2_assert_equal(x, y); return;
+                default: bad();
+            }
+            from_fq2(o, out);
+        } else if (degree == 6) {
+            h2e::AssignedFq6 x = to_fq6(a), y = b ? to_fq6(b) : h2e::AssignedFq6(), o;
+            switch (which) {
+                case H2E_FQ_ADD: o = t->fq6_add(x, y); break;
+                case H2E_FQ_SUB: o = t->fq6_sub(x, y); break;
+                case H2E_FQ_MUL: o = t->fq6_mul(x, y); break;
+                case H2E_FQ_SQUARE: o = t->fq6_square(x); break;
+                case H2E_FQ_NEG: o = t->fq6_neg(x); break;
+                case H2E_FQ_DOUBLE: o = t->fq6_double(x); break;
+                case H2E_FQ_UNSAFE_INVERT: o = t->fq6_unsafe_invert(x); break;
+                case H2E_FQ_MUL_BY_NONRESIDUE: o = t->fq6_mul_by_nonresidue(x); break;
+                case H2E_FQ_FROBENIUS_MAP: o = t->fq6_frobenius_map(x, (size_t)imm); break;
+                case H2E_FQ_REDUCE: o = t->fq6_reduce(x); break;
+                case H2E_FQ_ASSERT_EQUAL: t->fq6_assert_equal(x, y); return;
+                default: bad();
+            }
+            from_fq6(o, out);
+        } else {
+            h2e::AssignedFq12 x = to_fq12(a), y = b ? to_fq12(b) : h2e::AssignedFq12(), o;
+            switch (which) {
+                case H2E_FQ_ADD: o = t->fq12_add(x, y); break;
+                case H2E_FQ_SUB: o = t->fq12_sub(x, y); break;
+                case H2E_FQ_MUL: o = t->fq12_mul(x, y); break;
+                case H2E_FQ_SQUARE: o = t->fq12_square(x); break;
+                case H2E_FQ_NEG: o = t->fq12_neg(x); break;
+                case H2E_FQ_DOUBLE: o = t->fq12_double(x); break;
+                case H2E_FQ_CONJUGATE: o = t->fq12_conjugate(x); break;
+                case H2E_FQ_UNSAFE_INVERT: o = t->fq12_unsafe_invert(x); break;
+                case H2E_FQ_FROBENIUS_MAP: o = t->fq12_frobenius_map(x, (size_t)imm); break;
+                case H2E_FQ_CYCLOTOMIC_SQUARE: o = t->fq12_cyclotomic_square(x); break;
+                case H2E_FQ_REDUCE: o = t->fq12_reduce(x); break;
+                case H2E_FQ_ASSERT_EQUAL: t->fq12_assert_eq(x, y); return;
+                default: bad();
+            }
+            from_fq12(o, out);
         }
     });
 }
 int h2e_op_assign_points(h2e_records* R, uint32_t n, const void* d_inputs, h2e_point* out, void* stream) {   // EccChipBaseOps::assign_point x n
     if (!out || n == 0) return fail(H2E_ERR_INVALID, "bad argument");
-    return records_op(R, 3 * n, d_inputs, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& ecc, uint32_t s) {
+    return records_op(R, key_of("assign_points", {{&n, sizeof(n)}}), 3 * n, d_inputs, stream, {OpOut{out, sizeof(*out) * (size_t)n}}, [&](h2e::Recorder&, h2e::NativeScalarEccContext& ecc, uint32_t s) {
         std::vector<h2e::AssignedPoint> pts = ecc.assign_points_from_inputs(n, s);
         for (uint32_t k = 0; k < n; k++) out[k] = from_point(pts[k]);
     });
 }
 int h2e_op_assign_scalars(h2e_records* R, uint32_t n, const void* d_inputs, h2e_int* out, void* stream) {   // ctx.assign / scalar_integer_ctx.assign_w x n
     if (!out || n == 0) return fail(H2E_ERR_INVALID, "bad argument");
-    return records_op(R, n, d_inputs, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& ecc, uint32_t s) {
+    return records_op(R, key_of("assign_scalars", {{&n, sizeof(n)}}), n, d_inputs, stream, {OpOut{out, sizeof(*out) * (size_t)n}}, [&](h2e::Recorder&, h2e::NativeScalarEccContext& ecc, uint32_t s) {
         std::vector<h2e::AssignedInteger> sc = ecc.assign_scalars_from_inputs(n, s);
         for (uint32_t k = 0; k < n; k++) out[k] = from_int(sc[k]);
     });
@@ -3288,7 +3637,7 @@ int h2e_op_assign_scalars(h2e_records* R, uint32_t n, const void* d_inputs, h2e_
 int h2e_op_msm_unsafe(h2e_records* R, uint32_t n, const h2e_point* points, const h2e_int* scalars, const void* d_inputs, h2e_point* out,
                       void* stream) {   // EccChipScalarOps::msm_unsafe (ecc_chip.rs:373-408); inputs: generator (x, y), r1 (x, y), r2 (x, y)
     if (!points || !scalars || !out || n == 0) return fail(H2E_ERR_INVALID, "bad argument");
-    return records_op(R, 6, d_inputs, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& ecc, uint32_t s) {
+    return records_op(R, key_of("msm_unsafe", {{&n, sizeof(n)}, {points, sizeof(*points) * (size_t)n}, {scalars, sizeof(*scalars) * (size_t)n}}), 6, d_inputs, stream, {OpOut{out, sizeof(*out)}}, [&](h2e::Recorder&, h2e::NativeScalarEccContext& ecc, uint32_t s) {
         std::vector<h2e::AssignedPoint> pts;
         std::vector<h2e::AssignedInteger> sc;
         for (uint32_t k = 0; k < n; k++) {
@@ -3301,7 +3650,7 @@ int h2e_op_msm_unsafe(h2e_records* R, uint32_t n, const h2e_point* points, const
 }
 int h2e_op_ecc_assert_equal(h2e_records* R, const h2e_point* a, const h2e_point* b, void* stream) {   // ecc_chip.rs:644-658
     if (!a || !b) return fail(H2E_ERR_INVALID, "null operand");
-    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& ecc, uint32_t) { ecc.ecc_assert_equal(to_point(*a), to_point(*b)); });
+    return records_op(R, key_of("ecc_assert_equal", {{a, sizeof(*a)}, {b, sizeof(*b)}}), 0, nullptr, stream, {}, [&](h2e::Recorder&, h2e::NativeScalarEccContext& ecc, uint32_t) { ecc.ecc_assert_equal(to_point(*a), to_point(*b)); });
 }
 // ---- the complete-addition / curvature surface of EccChipBaseOps ----
 namespace {
@@ -3319,28 +3668,28 @@ h2e_point_c from_pc(const h2e::AssignedPointWithCurvature& a) {
 }  // namespace
 int h2e_op_to_point_with_curvature(h2e_records* R, const h2e_point* a, h2e_point_c* out, void* stream) {   // ecc_chip.rs:695-708
     if (!a || !out) return fail(H2E_ERR_INVALID, "null operand");
-    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { *out = from_pc(e.to_point_with_curvature(to_point(*a))); });
+    return records_op(R, key_of("to_point_with_curvature", {{a, sizeof(*a)}}), 0, nullptr, stream, {OpOut{out, sizeof(*out)}}, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { *out = from_pc(e.to_point_with_curvature(to_point(*a))); });
 }
 int h2e_op_ecc_reduce_with_curvature(h2e_records* R, const h2e_point* a, h2e_point_c* out, void* stream) {   // :677-693 (ecc_reduce :668-675, assign_identity :514-529)
     if (!a || !out) return fail(H2E_ERR_INVALID, "null operand");
-    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { *out = from_pc(e.ecc_reduce_with_curvature(to_point(*a))); });
+    return records_op(R, key_of("ecc_reduce_with_curvature", {{a, sizeof(*a)}}), 0, nullptr, stream, {OpOut{out, sizeof(*out)}}, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { *out = from_pc(e.ecc_reduce_with_curvature(to_point(*a))); });
 }
 int h2e_op_ecc_double(h2e_records* R, const h2e_point_c* a, h2e_point* out, void* stream) {   // :630-642
     if (!a || !out) return fail(H2E_ERR_INVALID, "null operand");
-    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { *out = from_point(e.ecc_double(to_pc(*a))); });
+    return records_op(R, key_of("ecc_double", {{a, sizeof(*a)}}), 0, nullptr, stream, {OpOut{out, sizeof(*out)}}, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { *out = from_point(e.ecc_double(to_pc(*a))); });
 }
 int h2e_op_ecc_add(h2e_records* R, const h2e_point_c* a, const h2e_point* b, h2e_point* out, void* stream) {   // :606-628
     if (!a || !b || !out) return fail(H2E_ERR_INVALID, "null operand");
-    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { *out = from_point(e.ecc_add(to_pc(*a), to_point(*b))); });
+    return records_op(R, key_of("ecc_add", {{a, sizeof(*a)}, {b, sizeof(*b)}}), 0, nullptr, stream, {OpOut{out, sizeof(*out)}}, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { *out = from_point(e.ecc_add(to_pc(*a), to_point(*b))); });
 }
 int h2e_op_ecc_neg(h2e_records* R, const h2e_point* a, h2e_point* out, void* stream) {   // :660-666
     if (!a || !out) return fail(H2E_ERR_INVALID, "null operand");
-    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { *out = from_point(e.ecc_neg(to_point(*a))); });
+    return records_op(R, key_of("ecc_neg", {{a, sizeof(*a)}}), 0, nullptr, stream, {OpOut{out, sizeof(*out)}}, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { *out = from_point(e.ecc_neg(to_point(*a))); });
 }
 int h2e_op_ecc_encode(h2e_records* R, const h2e_point* a, uint32_t* out_cells3, void* stream) {   // :710-732
     if (!a || !out_cells3) return fail(H2E_ERR_INVALID, "null operand");
     if (R && field_pair(R->field_pair).limbs != 3) return fail(H2E_ERR_INVALID, "ecc_encode packs two 3-limb coordinates");
-    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) {
+    return records_op(R, key_of("ecc_encode", {{a, sizeof(*a)}}), 0, nullptr, stream, {OpOut{out_cells3, 3 * sizeof(uint32_t)}}, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) {
         std::vector<h2e::AssignedValue> v = e.ecc_encode(to_point(*a));
         for (int i = 0; i < 3; i++) out_cells3[i] = v[i].ref;
     });
@@ -3350,7 +3699,7 @@ int h2e_op_ecc_mul(h2e_records* R, const h2e_point* a, const h2e_int* scalar, co
 }
 int h2e_op_assign_constant_point(h2e_records* R, const uint64_t* x_words, const uint64_t* y_words, int is_identity, h2e_point* out, void* stream) {   // :441-456
     if (!out || (!is_identity && (!x_words || !y_words))) return fail(H2E_ERR_INVALID, "null operand");
-    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder& r, h2e::NativeScalarEccContext& e, uint32_t) {
+    return records_op(R, key_of("assign_constant_point", {{x_words, x_words ? (size_t)field_pair(R ? R->field_pair : 0).w_words * 8 : 0}, {y_words, y_words ? (size_t)field_pair(R ? R->field_pair : 0).w_words * 8 : 0}, {&is_identity, sizeof(is_identity)}}), 0, nullptr, stream, {OpOut{out, sizeof(*out)}}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext& e, uint32_t) {
         h2e::HBig x, y;
         if (!is_identity) {
             x = h2e::HBig::from_words(x_words, r.fp.w_words);
@@ -3361,18 +3710,18 @@ int h2e_op_assign_constant_point(h2e_records* R, const uint64_t* x_words, const 
 }
 int h2e_op_bisec_point_with_curvature(h2e_records* R, uint32_t cond_cell, const h2e_point_c* a, const h2e_point_c* b, h2e_point_c* out, void* stream) {   // :562-578
     if (!a || !b || !out) return fail(H2E_ERR_INVALID, "null operand");
-    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) {
+    return records_op(R, key_of("bisec_point_with_curvature", {{&cond_cell, sizeof(cond_cell)}, {a, sizeof(*a)}, {b, sizeof(*b)}}), 0, nullptr, stream, {OpOut{out, sizeof(*out)}}, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) {
         *out = from_pc(e.bisec_point_with_curvature(h2e::AssignedCondition{h2e::AssignedValue{cond_cell}}, to_pc(*a), to_pc(*b)));
     });
 }
 int h2e_op_assign_cache_point(h2e_records* R, const h2e_point_c* p, uint64_t group, uint64_t selector, void* stream) {   // :779-788
     if (!p) return fail(H2E_ERR_INVALID, "null operand");
-    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { e.assign_cache_point(to_pc(*p), (size_t)group, (size_t)selector); });
+    return records_op(R, key_of("assign_cache_point", {{p, sizeof(*p)}, {&group, sizeof(group)}, {&selector, sizeof(selector)}}), 0, nullptr, stream, {}, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) { e.assign_cache_point(to_pc(*p), (size_t)group, (size_t)selector); });
 }
 int h2e_op_assign_selected_point(h2e_records* R, uint32_t n, const h2e_point_c* candidates, uint32_t index_cell, uint64_t group, h2e_point_c* out,
                                  void* stream) {   // :790-812, the candidate picked on the device by the value of the index cell
     if (!candidates || !out || n == 0) return fail(H2E_ERR_INVALID, "bad argument");
-    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) {
+    return records_op(R, key_of("assign_selected_point", {{&n, sizeof(n)}, {candidates, sizeof(*candidates) * (size_t)n}, {&index_cell, sizeof(index_cell)}, {&group, sizeof(group)}}), 0, nullptr, stream, {OpOut{out, sizeof(*out)}}, [&](h2e::Recorder&, h2e::NativeScalarEccContext& e, uint32_t) {
         std::vector<h2e::AssignedPointWithCurvature> c;
         for (uint32_t k = 0; k < n; k++) c.push_back(to_pc(candidates[k]));
         *out = from_pc(e.assign_selected_point(c, h2e::AssignedValue{index_cell}, (size_t)group));
@@ -3380,7 +3729,7 @@ int h2e_op_assign_selected_point(h2e_records* R, uint32_t n, const h2e_point_c* 
 }
 int h2e_op_assign_g2_constant(h2e_records* R, const void* d_inputs, h2e_g2* out, void* stream) {   // fq2_assign_constant x 2 + assign_constant(0)
     if (!out) return fail(H2E_ERR_INVALID, "out is null");
-    return records_op(R, 4, d_inputs, stream, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t s) {
+    return records_op(R, key_of("assign_g2_constant", {}), 4, d_inputs, stream, {OpOut{out, sizeof(*out)}}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t s) {
         out->x0 = from_int(r.assign_int_constant_input(s + 0));
         out->x1 = from_int(r.assign_int_constant_input(s + 1));
         out->y0 = from_int(r.assign_int_constant_input(s + 2));
@@ -3391,7 +3740,7 @@ int h2e_op_assign_g2_constant(h2e_records* R, const void* d_inputs, h2e_g2* out,
 int h2e_op_check_pairing(h2e_records* R, uint32_t n_pairs, const h2e_point* g1, const h2e_g2* g2, void* stream) {   // pairing_chip.rs:173-176
     if (!g1 || !g2 || n_pairs == 0) return fail(H2E_ERR_INVALID, "bad argument");
     if (R && R->field_pair == H2E_FIELD_BLS12_381_FR) return fail(H2E_ERR_INVALID, "no pairing over this field");
-    return records_op(R, 0, nullptr, stream, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
+    return records_op(R, key_of("check_pairing", {{&n_pairs, sizeof(n_pairs)}, {g1, sizeof(*g1) * (size_t)n_pairs}, {g2, sizeof(*g2) * (size_t)n_pairs}}), 0, nullptr, stream, {}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
         r.auto_cut_every = 16;
         std::unique_ptr<h2e::PairingOps> po;
         if (r.fp.id == H2E_FIELD_BN256_FQ) po.reset(new h2e::Bn256PairingOps(r));
@@ -3406,6 +3755,24 @@ int h2e_op_check_pairing(h2e_records* R, uint32_t n_pairs, const h2e_point* g1, 
         std::vector<h2e::PairingOps::Term> terms;
         for (uint32_t k = 0; k < n_pairs; k++) terms.push_back(h2e::PairingOps::Term(&a[k], &b[k]));
         po->check_pairing(terms);
+    });
+}
+int h2e_op_pairing(h2e_records* R, uint32_t n_pairs, const h2e_point* g1, const h2e_g2* g2, h2e_int* out12, void* stream) {   // pairing_chip.rs:157-171
+    if (!g1 || !g2 || !out12 || n_pairs == 0) return fail(H2E_ERR_INVALID, "bad argument");
+    if (R && R->field_pair == H2E_FIELD_BLS12_381_FR) return fail(H2E_ERR_INVALID, "no pairing over this field");
+    return records_op(R, key_of("pairing", {{&n_pairs, sizeof(n_pairs)}, {g1, sizeof(*g1) * (size_t)n_pairs}, {g2, sizeof(*g2) * (size_t)n_pairs}}), 0, nullptr, stream, {OpOut{out12, sizeof(*out12) * 12}}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
+        r.auto_cut_every = 16;
+        std::unique_ptr<h2e::PairingOps> po = tower_of(r);
+        std::vector<h2e::AssignedPoint> a;
+        std::vector<h2e::AssignedG2Affine> b;
+        for (uint32_t k = 0; k < n_pairs; k++) {
+            a.push_back(to_point(g1[k]));
+            b.push_back(h2e::AssignedG2Affine{h2e::AssignedFq2{to_int(g2[k].x0), to_int(g2[k].x1)}, h2e::AssignedFq2{to_int(g2[k].y0), to_int(g2[k].y1)},
+                                              h2e::AssignedCondition{h2e::AssignedValue{g2[k].z}}});
+        }
+        std::vector<h2e::PairingOps::Term> terms;
+        for (uint32_t k = 0; k < n_pairs; k++) terms.push_back(h2e::PairingOps::Term(&a[k], &b[k]));
+        from_fq12(po->pairing(terms), out12);
     });
 }
 

@@ -202,6 +202,7 @@ struct Segment {  // one engine launch
     // segment's bandwidth-bound expansion would starve it, so the expansion is launched behind that chain
     bool expand_after_next = false;
     uint32_t sel_stride = 0;   // selection-buffer entries per strand (segments with pre-selected points)
+    bool field_hints = false;  // recorded with Recorder::begin_field_hints: its mul-like ops carry hints of a field-domain predictor
 };
 
 struct PreKernel {  // a value-predictor launch that must run before segment `before_segment`
@@ -251,6 +252,10 @@ struct Recorder {
     // hint_mode 2 ("full value hints", MSM chains): every ecc op owns a block of H2E_ECC_HINT_SLOTS slots that the
     // predictor + finalize kernels fill with the canonical value of every mul-like result of that op (tape.h);
     // hint_count then counts blocks and block `n_blocks` of a strand holds the chain's initial point.
+    // hint_mode 3 ("field hints", the pairings): every int_mul / reduce / int_div of the main context gets a hint slot of
+    // its own; a field-domain predictor (h2e_capi.cpp compile_field_chain, engine.hip h2e_field_chain) walks the same
+    // computation as plain arithmetic mod w - where a reduce is free and a chain of additions is one linear combination -
+    // and fills the slots with the canonical values.
     int hint_mode = 0;
     uint32_t ecc_block = H2E_NO_REF;   // first slot of the current ecc op's block
     uint32_t next_vtag = H2E_NO_REF;   // tag for the result of the next integer op
@@ -378,6 +383,15 @@ struct Recorder {
         return hint_count;
     }
     uint32_t hint_slots_used() const { return hint_mode == 2 ? H2E_ECC_HINT_SLOTS * (hint_count + 1) : hint_count; }
+    bool field_hints() const { return hint_on && hint_mode == 3 && !in_strand; }
+    // program level: switch field hints on for everything recorded from here (main context)
+    void begin_field_hints() {
+        if (hint_on) throw std::runtime_error("begin_field_hints: hints already on");
+        begin_hints(n_hint_slots, 3);
+    }
+    void end_field_hints() {
+        if (hint_on && hint_mode == 3) n_hint_slots += end_hints();
+    }
     void begin_ecc_op() {
         if (hint_on && hint_mode == 2) ecc_block = hint_base + H2E_ECC_HINT_SLOTS * hint_count++;
     }
@@ -721,6 +735,7 @@ struct Recorder {
     void push(const H2EOp& op) {
         if (!record_tape) return;
         tape.push_back(op);
+        if (hint_on && hint_mode == 3 && !in_strand) segments.back().field_hints = true;
         if (auto_cut_every && !in_strand) {
             uint32_t at = (uint32_t)tape.size() - cur_tape_begin;
             uint32_t last = cuts.size() > segments.back().cuts_begin ? cuts.back() : 0;
@@ -903,15 +918,21 @@ struct Recorder {
         if (a.times == 1) return a;
         if (!(a.times < (uint64_t)OVERFLOW_LIMIT)) throw std::runtime_error("reduce: times >= overflow_limit");
         H2EOp op = new_op(H2E_OP_REDUCE);
-        if (a.vtag != H2E_NO_REF) {
-            op.flags |= H2E_FLAG_HINTED | (a.vtag_strided ? H2E_FLAG_HINT_STRIDED : 0);
-            op.imm = a.vtag;
+        uint32_t tag = a.vtag;
+        bool tag_strided = a.vtag_strided;
+        if (tag == H2E_NO_REF && field_hints()) {
+            tag = hint_base + hint_count++;
+            tag_strided = false;
+        }
+        if (tag != H2E_NO_REF) {
+            op.flags |= H2E_FLAG_HINTED | (tag_strided ? H2E_FLAG_HINT_STRIDED : 0);
+            op.imm = tag;
         }
         put_int(op, 0, a);
         push(op);
         AssignedInteger rem = shape_assigned(false);
-        rem.vtag = a.vtag;
-        rem.vtag_strided = a.vtag_strided;
+        rem.vtag = tag;
+        rem.vtag_strided = tag_strided;
         uint32_t d = assign_common();
         base_line({A(d, id_w_native), A(rem.native, id_one)}, A(a.native, id_neg_one));
         uint32_t last_v = H2E_NO_REF;
@@ -971,6 +992,7 @@ struct Recorder {
     }
     AssignedInteger int_mul(const AssignedInteger& a, const AssignedInteger& b) {  // :466-483
         H2EOp op = new_op(H2E_OP_INT_MUL);
+        if (next_vtag == H2E_NO_REF && field_hints()) next_vtag = hint_base + hint_count++;
         if (next_vtag != H2E_NO_REF) {
             op.flags |= H2E_FLAG_HINTED | (in_strand ? H2E_FLAG_HINT_STRIDED : 0);
             op.imm = next_vtag;
@@ -1056,7 +1078,7 @@ struct Recorder {
         if (hint_on && hint_mode == 2 && ecc_block != H2E_NO_REF) {
             op.flags |= H2E_FLAG_HINTED | (in_strand ? H2E_FLAG_HINT_STRIDED : 0);
             op.imm = ecc_block + H2E_HINT_LAMBDA;
-        } else if (hint_on && hint_mode == 1) {
+        } else if (hint_on && (hint_mode == 1 || field_hints())) {
             op.flags |= H2E_FLAG_HINTED | (in_strand ? H2E_FLAG_HINT_STRIDED : 0);
             op.imm = hint_base + hint_count++;
         }

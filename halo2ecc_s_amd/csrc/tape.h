@@ -183,7 +183,14 @@ typedef struct H2ELaunch {
                                   // 2 = wave mode: one wave per instance, rounds of up to 64 compact records (lrounds / l_recs)
     const uint32_t* lrounds;      // wave mode: per round (first record, count | kind << 8); kind 0 = light ops of mixed opcodes
     uint32_t l_recs;              // wave mode: records incl. padding (a multiple of H2E_WCHUNK)
+    // hint store (field_chain.hpp HintStore): replaces the values-only replay of a segment whose mul-like results all have
+    // hints - one lane per (store op, instance)
+    const uint32_t* s_words;      // store op records
+    const uint32_t* s_offsets;    // [n_sops] first word of each record
+    const uint64_t* s_ktab;       // K constants, (2 L + 4) words each
+    uint32_t n_sops;
 } H2ELaunch;
+enum H2EStoreKind { H2E_S_W = 1, H2E_S_LIN = 2, H2E_S_FE = 3, H2E_S_CONST = 4, H2E_S_FULL = 5 };
 
 // ---- compiled values-only replay ("V-tape") ----------------------------------------------------
 // The values-only replay of a cut segment does not interpret the witness tape: the host compiles it (once per
@@ -237,7 +244,8 @@ enum H2EVOpcode {
 // They run native Montgomery / Jacobian arithmetic over the same inputs, write numerator/denominator pairs of
 // every lambda = dy/dx the ecc_add_unsafe / ecc_double_unsafe chain will divide (src/circuit/ecc_chip.rs:840-882),
 // and one batch inversion turns them into hints for H2E_OP_DIV_CORE.
-enum H2EPreKind { H2E_PRE_MSM_CANDIDATES = 1, H2E_PRE_MSM_WINDOWS = 2, H2E_PRE_MSM_TAIL = 3, H2E_PRE_MSM_SELECT = 4 };
+enum H2EPreKind { H2E_PRE_MSM_CANDIDATES = 1, H2E_PRE_MSM_WINDOWS = 2, H2E_PRE_MSM_TAIL = 3, H2E_PRE_MSM_SELECT = 4,
+                  H2E_PRE_FIELD_CHAIN = 5 };   // field_chain.hpp: residues mod w in Montgomery form, one wave per instance
 // selection buffer: per (strand, group) the picked candidate, x then y, canonical, H2E_W_WORDS_MAX words each
 #define H2E_SEL_WORDS (2 * H2E_W_WORDS_MAX)
 // selection buffer entry = 4 value slots: x, y canonical (what the replay / expansion read), x, y in Montgomery form (what the
@@ -260,7 +268,16 @@ typedef struct H2EPreKernel {
     uint32_t sel_begin;      // first entry of this kernel's strands in the selection buffer (SELECT writes, WINDOWS reads)
     uint32_t used_slots;     // full value hints: bit k set = slot k of the ecc blocks is read by someone (host, after the DCE pass)
     uint32_t scan_begin;     // WINDOWS / TAIL: first Jacobian scratch slot of the chain's scan (sizes: H2E_WIN_SCAN_SLOTS / H2E_TAIL_SCAN_SLOTS)
+    // FIELD_CHAIN: the program sits in the pre-kernel args array (32-byte aligned): records of 8 words from word f_recs
+    // (f_n_recs of them, a multiple of H2E_WCHUNK), (first record, count | kind << 8) per round from word f_rounds;
+    // hint slots [hint_base, hint_base + hints_per_lane) are turned into canonical values by the finalize kernel
+    uint32_t f_recs, f_n_recs, f_rounds, f_n_rounds, f_slots;
+    uint32_t f_n_load_rounds;   // the first rounds: loads of inputs / constants (a loop of their own in the kernel)
 } H2EPreKernel;
+// field chain record opcodes (field_chain.hpp FieldCompiler::F_*)
+enum H2EFieldOp { H2E_F_NOP = 0, H2E_F_LIN, H2E_F_MUL, H2E_F_DIV, H2E_F_ISZERO, H2E_F_NOT, H2E_F_AND, H2E_F_OR, H2E_F_XNOR, H2E_F_SELECT,
+                  H2E_F_INPUT_W, H2E_F_INPUT_FE, H2E_F_CONST_W, H2E_F_CONST_FE };
+#define H2E_F_MAX_TERMS 6
 // The MSM chains are walked as scans (engine.hip "scan predictors"): a window's sum over its groups in H2E_WIN_CHUNKS
 // chunks (chunk sums -> offsets -> the real additions of every chunk in parallel), the tail's accumulation
 // acc <- 2 acc + line_w [- r2] in chunks of H2E_TAIL_CHUNK windows (local Horner sums B, the doubling chain D of the

@@ -73,9 +73,44 @@ WI_INLINE bool wd_eq(const Wd<N>& a, const Wd<N>& b) {
     for (int i = 0; i < N; i++) o |= a.v[i] ^ b.v[i];
     return o == 0;
 }
+// Carry chains.  hipcc turns neither `s < a` carries nor __builtin_addcll into v_addc_co_u32 chains (a 256-bit addition
+// came out as 24 instructions: a 64-bit add, two 64-bit compares and a select per word); with the carry as an explicit
+// SGPR-pair operand of the VOP3 forms it is one instruction per 32-bit limb, and the data dependency through that operand
+// keeps the chain intact whatever the scheduler puts in between.
+WI_INLINE u32 add_co32(u32 a, u32 b, u64& c) {
+    u32 r;
+    asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(c) : "v"(a), "v"(b));
+    return r;
+}
+WI_INLINE u32 addc_co32(u32 a, u32 b, u64& c) {
+    u32 r;
+    u64 co;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(co) : "v"(a), "v"(b), "s"(c));
+    c = co;
+    return r;
+}
+WI_INLINE u32 sub_co32(u32 a, u32 b, u64& c) {
+    u32 r;
+    asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(c) : "v"(a), "v"(b));
+    return r;
+}
+WI_INLINE u32 subb_co32(u32 a, u32 b, u64& c) {
+    u32 r;
+    u64 co;
+    asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(co) : "v"(a), "v"(b), "s"(c));
+    c = co;
+    return r;
+}
+WI_INLINE u32 carry_bit(u64 c) {   // this lane's bit of a carry mask as 0 / 1
+    u32 r;
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(c));
+    return r;
+}
+WI_INLINE u64 pack64(u32 lo, u32 hi) { return (u64)lo | ((u64)hi << 32); }
 // a >= b
 template <int N>
 WI_INLINE bool wd_geq(const Wd<N>& a, const Wd<N>& b) {
+#ifdef H2E_PLAIN_CARRY
     u64 borrow = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -85,25 +120,22 @@ WI_INLINE bool wd_geq(const Wd<N>& a, const Wd<N>& b) {
         borrow = b1 | b2;
     }
     return borrow == 0;
-}
-template <int N>
-WI_INLINE Wd<N> wd_add(const Wd<N>& a, const Wd<N>& b) {
-    Wd<N> r;
-    u64 c = 0;
+#else
+    u64 c;
+    (void)sub_co32((u32)a.v[0], (u32)b.v[0], c);
+    (void)subb_co32((u32)(a.v[0] >> 32), (u32)(b.v[0] >> 32), c);
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        u64 s = a.v[i] + b.v[i];
-        u64 c1 = s < a.v[i];
-        u64 s2 = s + c;
-        u64 c2 = s2 < s;
-        r.v[i] = s2;
-        c = c1 | c2;
+    for (int i = 1; i < N; i++) {
+        (void)subb_co32((u32)a.v[i], (u32)b.v[i], c);
+        (void)subb_co32((u32)(a.v[i] >> 32), (u32)(b.v[i] >> 32), c);
     }
-    return r;
+    return carry_bit(c) == 0;
+#endif
 }
 template <int N>
 WI_INLINE Wd<N> wd_add_c(const Wd<N>& a, const Wd<N>& b, u64& carry_out) {
     Wd<N> r;
+#ifdef H2E_PLAIN_CARRY
     u64 c = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -115,11 +147,45 @@ WI_INLINE Wd<N> wd_add_c(const Wd<N>& a, const Wd<N>& b, u64& carry_out) {
         c = c1 | c2;
     }
     carry_out = c;
+#else
+    u64 c;
+    u32 lo = add_co32((u32)a.v[0], (u32)b.v[0], c);
+    u32 hi = addc_co32((u32)(a.v[0] >> 32), (u32)(b.v[0] >> 32), c);
+    r.v[0] = pack64(lo, hi);
+#pragma unroll
+    for (int i = 1; i < N; i++) {
+        lo = addc_co32((u32)a.v[i], (u32)b.v[i], c);
+        hi = addc_co32((u32)(a.v[i] >> 32), (u32)(b.v[i] >> 32), c);
+        r.v[i] = pack64(lo, hi);
+    }
+    carry_out = carry_bit(c);
+#endif
     return r;
+}
+template <int N>
+WI_INLINE Wd<N> wd_add(const Wd<N>& a, const Wd<N>& b) {
+#ifdef H2E_PLAIN_CARRY
+    u64 c;
+    return wd_add_c<N>(a, b, c);
+#else
+    Wd<N> r;
+    u64 c;
+    u32 lo = add_co32((u32)a.v[0], (u32)b.v[0], c);
+    u32 hi = addc_co32((u32)(a.v[0] >> 32), (u32)(b.v[0] >> 32), c);
+    r.v[0] = pack64(lo, hi);
+#pragma unroll
+    for (int i = 1; i < N; i++) {
+        lo = addc_co32((u32)a.v[i], (u32)b.v[i], c);
+        hi = addc_co32((u32)(a.v[i] >> 32), (u32)(b.v[i] >> 32), c);
+        r.v[i] = pack64(lo, hi);
+    }
+    return r;
+#endif
 }
 template <int N>
 WI_INLINE Wd<N> wd_sub(const Wd<N>& a, const Wd<N>& b) {
     Wd<N> r;
+#ifdef H2E_PLAIN_CARRY
     u64 borrow = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -130,6 +196,39 @@ WI_INLINE Wd<N> wd_sub(const Wd<N>& a, const Wd<N>& b) {
         r.v[i] = d2;
         borrow = b1 | b2;
     }
+#else
+    u64 c;
+    u32 lo = sub_co32((u32)a.v[0], (u32)b.v[0], c);
+    u32 hi = subb_co32((u32)(a.v[0] >> 32), (u32)(b.v[0] >> 32), c);
+    r.v[0] = pack64(lo, hi);
+#pragma unroll
+    for (int i = 1; i < N; i++) {
+        lo = subb_co32((u32)a.v[i], (u32)b.v[i], c);
+        hi = subb_co32((u32)(a.v[i] >> 32), (u32)(b.v[i] >> 32), c);
+        r.v[i] = pack64(lo, hi);
+    }
+#endif
+    return r;
+}
+// acc += a * m for a 32-bit multiplier: one v_mad_u64_u32 and one 64-bit add per 32-bit limb of a
+template <int N>
+WI_INLINE void wd_mac_small(Wd<N + 1>& acc, const Wd<N>& a, u32 m) {
+    u32 carry = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        u64 lo = (u64)(u32)a.v[i] * m + (u32)acc.v[i] + carry;
+        u64 hi = (u64)(u32)(a.v[i] >> 32) * m + (u32)(acc.v[i] >> 32) + (u32)(lo >> 32);
+        acc.v[i] = pack64((u32)lo, (u32)hi);
+        carry = (u32)(hi >> 32);
+    }
+    acc.v[N] += carry;
+}
+template <int N>
+WI_INLINE Wd<N + 1> wd_mul_small(const Wd<N>& a, u32 m) {
+    Wd<N + 1> r;
+#pragma unroll
+    for (int i = 0; i <= N; i++) r.v[i] = 0;
+    wd_mac_small<N>(r, a, m);
     return r;
 }
 template <int N>

@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = [
     "h2e_op_ecc_double", "h2e_op_ecc_add", "h2e_op_ecc_neg", "h2e_op_ecc_encode", "h2e_op_ecc_mul", "h2e_op_assign_constant_point",
     "h2e_op_bisec_point_with_curvature", "h2e_op_assign_cache_point", "h2e_op_assign_selected_point", "h2e_export_fixed", "h2e_range_table", "h2e_export_copy_constraints", "h2e_ctx_set_option", "h2e_ctx_get_stat",
     "h2e_program_msm_bn256_tile_no_select", "h2e_last_run_expansion_launches",
+    "h2e_records_attach", "h2e_op_int_mul_small_constant", "h2e_op_assign_int_constant", "h2e_op_bisec_int", "h2e_op_fq", "h2e_op_pairing",
 ]
 
 
@@ -77,6 +78,10 @@ class HG2(C.Structure):       # h2e_g2: AssignedG2Affine
 
 
 INT_ADD, INT_SUB, INT_MUL, INT_DIV, INT_REDUCE = 0, 1, 2, 3, 4
+INT_NEG, INT_SQUARE, INT_UNSAFE_INVERT, INT_IS_ZERO, INT_IS_EQUAL, INT_ASSERT_EQUAL = 5, 6, 7, 8, 9, 10
+(FQ_ADD, FQ_SUB, FQ_MUL, FQ_SQUARE, FQ_NEG, FQ_DOUBLE, FQ_CONJUGATE, FQ_UNSAFE_INVERT, FQ_MUL_BY_NONRESIDUE, FQ_FROBENIUS_MAP,
+ FQ_CYCLOTOMIC_SQUARE, FQ_REDUCE, FQ_ASSERT_EQUAL) = range(13)
+STAT_OP_CACHE_HITS, STAT_OP_CACHE_MISSES = 6, 7
 
 _lib = None
 
@@ -108,6 +113,12 @@ def lib():
     L.h2e_range_table.argtypes = [vp, i32, vp, vp]
     L.h2e_export_copy_constraints.argtypes = [vp, vp, vp, vp]
     L.h2e_records_create.argtypes = [vp, i32, i32, u32, C.c_uint64, C.c_uint64, C.c_uint64, i32, C.POINTER(vp)]
+    L.h2e_records_attach.argtypes = [vp, i32, i32, u32, vp, vp, vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint64, i32, C.POINTER(vp)]
+    L.h2e_op_int_mul_small_constant.argtypes = [vp, C.POINTER(HInt), C.c_uint64, C.POINTER(HInt), vp]
+    L.h2e_op_assign_int_constant.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(HInt), vp]
+    L.h2e_op_bisec_int.argtypes = [vp, u32, C.POINTER(HInt), C.POINTER(HInt), C.POINTER(HInt), vp]
+    L.h2e_op_fq.argtypes = [vp, i32, i32, C.POINTER(HInt), C.POINTER(HInt), C.c_uint64, C.POINTER(HInt), vp]
+    L.h2e_op_pairing.argtypes = [vp, u32, C.POINTER(HPoint), C.POINTER(HG2), C.POINTER(HInt), vp]
     L.h2e_records_destroy.argtypes = [vp]
     L.h2e_records_destroy.restype = None
     L.h2e_records_arrays.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
@@ -285,6 +296,24 @@ class Records:
         self._h = h
         self._keep = []   # input tensors stay alive while kernels may read them
 
+    @classmethod
+    def attach(cls, engine, field_pair, arrays, offsets, msm_prefix=0, scalar_field=-1, emit_shape=True):
+        """h2e_records_attach: a forked context over arrays the caller owns - `arrays` = (base, range, select, status) torch
+        tensors (batch-interleaved [rows][cols][2][n][2]), ops start at `offsets` = (base, range, select) and `msm_prefix`"""
+        base, rng, sel, status = arrays
+        self = cls.__new__(cls)
+        self.engine, self.n, self.field_pair = engine, base.shape[3], field_pair
+        self.rows = (base.shape[0], rng.shape[0], sel.shape[0])
+        self.slot_words = 6 if field_pair == FIELD_BLS12_381_FQ else 4
+        self._keep = [base, rng, sel, status]
+        cap = (C.c_uint64 * 3)(*self.rows)
+        off = (C.c_uint64 * 3)(*offsets)
+        h = C.c_void_p()
+        _check(lib().h2e_records_attach(engine._h, field_pair, scalar_field, self.n, base.data_ptr(), rng.data_ptr(), sel.data_ptr(),
+                                        status.data_ptr(), cap, off, msm_prefix, int(emit_shape), C.byref(h)))
+        self._h = h
+        return self
+
     def _in(self, values):
         """numpy uint64 [n_instances][slots][slot_words] -> device pointer"""
         t = self.engine.torch
@@ -311,6 +340,44 @@ class Records:
         out, cond = HInt(), C.c_uint32()
         _check(lib().h2e_op_int(self._h, which, C.byref(a), C.byref(b) if b is not None else None, C.byref(out), C.byref(cond), self._s()))
         return (out, cond.value) if which == INT_DIV else out
+
+    def int_unary(self, which, a, b=None):
+        """int_neg / int_square / int_unsafe_invert -> HInt; is_int_zero / is_int_equal -> condition cell; assert_int_equal -> None"""
+        out, cond = HInt(), C.c_uint32()
+        _check(lib().h2e_op_int(self._h, which, C.byref(a), C.byref(b) if b is not None else None, C.byref(out), C.byref(cond), self._s()))
+        return cond.value if which in (INT_IS_ZERO, INT_IS_EQUAL) else None if which == INT_ASSERT_EQUAL else out
+
+    def int_mul_small_constant(self, a, k):
+        out = HInt()
+        _check(lib().h2e_op_int_mul_small_constant(self._h, C.byref(a), k, C.byref(out), self._s()))
+        return out
+
+    def assign_int_constant(self, value):
+        n = self.slot_words
+        ws = (C.c_uint64 * n)(*[(value >> (64 * k)) & (2**64 - 1) for k in range(n)])
+        out = HInt()
+        _check(lib().h2e_op_assign_int_constant(self._h, ws, C.byref(out), self._s()))
+        return out
+
+    def bisec_int(self, cond_cell, a, b):
+        out = HInt()
+        _check(lib().h2e_op_bisec_int(self._h, cond_cell, C.byref(a), C.byref(b), C.byref(out), self._s()))
+        return out
+
+    def fq(self, degree, which, a, b=None, imm=0):
+        """Fq2 / Fq6 / Fq12 op on assigned elements (lists of `degree` HInt); returns a list of HInt (None for assert_equal)"""
+        A = (HInt * degree)(*a)
+        B = (HInt * degree)(*b) if b is not None else None
+        out = (HInt * degree)()
+        _check(lib().h2e_op_fq(self._h, degree, which, A, B, imm, out if which != FQ_ASSERT_EQUAL else None, self._s()))
+        return None if which == FQ_ASSERT_EQUAL else list(out)
+
+    def pairing(self, g1, g2):
+        a = (HPoint * len(g1))(*g1)
+        b = (HG2 * len(g2))(*g2)
+        out = (HInt * 12)()
+        _check(lib().h2e_op_pairing(self._h, len(g1), a, b, out, self._s()))
+        return list(out)
 
     def assign_points(self, n, values):
         out = (HPoint * n)()

@@ -184,6 +184,8 @@ int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value);
 #define H2E_STAT_PIPELINE_DEPTH 3
 #define H2E_STAT_MAX_PIPELINE_DEPTH 4
 #define H2E_STAT_SCAN_FALLBACKS 5      /* lanes of the MSM scan predictors that had to walk the real chain so far (process-wide; synchronises) */
+#define H2E_STAT_OP_CACHE_HITS 6       /* operator API: ops whose program came from the context's cache (keyed by op, arguments, */
+#define H2E_STAT_OP_CACHE_MISSES 7     /* operand handles, cursors, heights, msm prefix) / ops that had to be recorded */
 int64_t h2e_ctx_get_stat(h2e_ctx* ctx, int stat);
 
 /* Named entry points of SURVEY.md §8(b): build-or-reuse the program for the shape, then run it. */
@@ -251,6 +253,16 @@ typedef struct h2e_point { h2e_int x, y; uint32_t z; } h2e_point;               
 typedef struct h2e_g2 { h2e_int x0, x1, y0, y1; uint32_t z; } h2e_g2;                         /* AssignedG2Affine (src/assign.rs:171-192) */
 int h2e_records_create(h2e_ctx* ctx, int field_pair, int scalar_field, uint32_t n_instances, uint64_t base_rows, uint64_t range_rows,
                        uint64_t select_rows, int emit_shape, h2e_records** out);
+/* The splice seam itself (ParallelClone: clone_with_offset + merge + apply_offset_diff, src/circuit/ecc_chip.rs:64-77, used at
+ * :289-352; NativeScalarEccContext clone / merge, src/circuit/native_scalar_ecc_chip.rs:50-90, msm prefix :173-178): a records
+ * object over arrays the CALLER allocated (batch-interleaved, capacity_rows[3] rows), whose ops start at the caller's cursors
+ * offset0 = (base, range, select) and msm prefix - i.e. a forked context that writes its disjoint rows into the caller's Records.
+ * Rows below the offsets are the caller's and are never touched; heights start at the offsets; h2e_records_shape then reports
+ * the new offsets / heights (what apply_offset_diff / merge need) and the fixed cells / flags / permutations of the spliced rows.
+ * The engine never frees the arrays.  d_status: n_instances uint32 (or-ed). */
+int h2e_records_attach(h2e_ctx* ctx, int field_pair, int scalar_field, uint32_t n_instances, void* d_base, void* d_range, void* d_select,
+                       void* d_status, const uint64_t capacity_rows[3], const uint64_t offset0[3], uint64_t msm_prefix0, int emit_shape,
+                       h2e_records** out);
 void h2e_records_destroy(h2e_records* rec);
 int h2e_records_arrays(h2e_records* rec, void** d_base, void** d_range, void** d_select, void** d_status);
 /* offsets, heights, accumulated fixed cells / flags / permutations over rows [0, capacity); *_rows = the capacity;
@@ -263,7 +275,34 @@ int h2e_op_assign(h2e_records* rec, const void* d_inputs /* 1 slot */, uint32_t*
 #define H2E_INT_MUL 2
 #define H2E_INT_DIV 3      /* out_cond = the is_b_zero condition cell */
 #define H2E_INT_REDUCE 4   /* b unused */
+/* the rest of IntegerChipOps (src/circuit/integer_chip.rs:15-70) through the same entry: */
+#define H2E_INT_NEG 5            /* int_neg :439-464; b unused */
+#define H2E_INT_SQUARE 6         /* int_square :614-616; b unused */
+#define H2E_INT_UNSAFE_INVERT 7  /* int_unsafe_invert :485-491; b unused */
+#define H2E_INT_IS_ZERO 8        /* is_int_zero :540-578; out unused, out_cond = the condition cell */
+#define H2E_INT_IS_EQUAL 9       /* is_int_equal :47-54; out unused, out_cond = the condition cell */
+#define H2E_INT_ASSERT_EQUAL 10  /* assert_int_equal :600-612; out, out_cond unused */
 int h2e_op_int(h2e_records* rec, int which, const h2e_int* a, const h2e_int* b, h2e_int* out, uint32_t* out_cond, void* stream);
+int h2e_op_int_mul_small_constant(h2e_records* rec, const h2e_int* a, uint64_t k, h2e_int* out, void* stream);         /* :618-658 */
+int h2e_op_assign_int_constant(h2e_records* rec, const uint64_t* w_words /* canonical, slot_words */, h2e_int* out, void* stream);   /* :580-598 */
+int h2e_op_bisec_int(h2e_records* rec, uint32_t cond_cell, const h2e_int* a, const h2e_int* b, h2e_int* out, void* stream);       /* :660-681 */
+/* Fq2 / Fq6 / Fq12 ops on assigned elements (Fq2ChipOps / Fq6ChipOps / Fq12ChipOps, src/circuit/fq12.rs:24-459): what a circuit
+ * calls between pairings.  An element of degree k is k h2e_int in the order of fq12_assign_constant (fq12.rs:453-458):
+ * c0.c0.c0, c0.c0.c1, c0.c1.c0, ...  `a`, `b`, `out`: arrays of `degree` integers (b / out NULL where the op has none). */
+#define H2E_FQ_ADD 0
+#define H2E_FQ_SUB 1
+#define H2E_FQ_MUL 2
+#define H2E_FQ_SQUARE 3
+#define H2E_FQ_NEG 4
+#define H2E_FQ_DOUBLE 5
+#define H2E_FQ_CONJUGATE 6            /* degree 2, 12 */
+#define H2E_FQ_UNSAFE_INVERT 7
+#define H2E_FQ_MUL_BY_NONRESIDUE 8    /* degree 2, 6 */
+#define H2E_FQ_FROBENIUS_MAP 9        /* imm = power */
+#define H2E_FQ_CYCLOTOMIC_SQUARE 10   /* degree 12 */
+#define H2E_FQ_REDUCE 11
+#define H2E_FQ_ASSERT_EQUAL 12        /* no out */
+int h2e_op_fq(h2e_records* rec, int degree, int which, const h2e_int* a, const h2e_int* b, uint64_t imm, h2e_int* out, void* stream);
 int h2e_op_assign_points(h2e_records* rec, uint32_t n, const void* d_inputs /* (x, y, z) x n */, h2e_point* out, void* stream);
 int h2e_op_assign_scalars(h2e_records* rec, uint32_t n, const void* d_inputs /* n slots */, h2e_int* out, void* stream);
 /* EccChipScalarOps::msm_unsafe on assigned points / scalars (ecc_chip.rs:373-408).  d_inputs: generator x, y, then the blinding
@@ -291,6 +330,8 @@ int h2e_op_assign_selected_point(h2e_records* rec, uint32_t n, const h2e_point_c
                                  h2e_point_c* out, void* stream);
 int h2e_op_assign_g2_constant(h2e_records* rec, const void* d_inputs /* x.c0, x.c1, y.c0, y.c1 */, h2e_g2* out, void* stream);
 int h2e_op_check_pairing(h2e_records* rec, uint32_t n_pairs, const h2e_point* g1, const h2e_g2* g2, void* stream);
+/* PairingChipOps::pairing on assigned terms (src/circuit/pairing_chip.rs:157-171): out12 = the 12 integers of the Fq12 result */
+int h2e_op_pairing(h2e_records* rec, uint32_t n_pairs, const h2e_point* g1, const h2e_g2* g2, h2e_int* out12, void* stream);
 
 /* On-device consumer for streaming jobs (SURVEY.md 8d cfg 3, 8e): a 32-byte digest per instance of one region's
  * batch-interleaved array, d_digests = [n_instances][4] words:

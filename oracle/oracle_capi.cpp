@@ -255,6 +255,77 @@ void* oracle_run_pairing(int curve, uint32_t n_pairs, int with_expected, const u
     });
 }
 
+// Operator-API scenario over the rest of IntegerChipOps (src/circuit/integer_chip.rs:15-70: int_neg, int_square,
+// int_unsafe_invert, is_int_zero, is_int_equal, assign_int_constant, int_mul_small_constant, bisec_int, assert_int_equal) and
+// the Fq2 / Fq6 / Fq12 surface (src/circuit/fq12.rs:24-459) on assigned elements (tests/test_ops_gpu.py).
+// inputs: a, b, x_0 .. x_11, y_0 .. y_11 (W values; x, y = two Fq12 elements in fq12_assign_constant order)
+void* oracle_run_ops_int_tower(int curve, const uint64_t* inputs) {
+    return guarded([&](Run& r) {
+        IntegerContext ic(r.ctx, curve == 0 ? BnFq::modulus() : BlsFq::modulus());
+        Inputs in{inputs, curve == 0 ? 4 : 6};
+        NativeScalarEccContext ecc(ic, curve == 0 ? bn256_g1_params() : bls12_381_g1_params(), 0);
+        std::unique_ptr<PairingOps> po;
+        if (curve == 0) po.reset(new Bn256PairingOps(ecc.base));
+        else po.reset(new Bls12381PairingOps(ecc.base));
+        IntegerContext& c = ecc.base;
+        AssignedInteger A = c.assign_w(in.w(0)), B = c.assign_w(in.w(1));
+        std::vector<AssignedInteger> X, Y;
+        for (int i = 0; i < 12; i++) X.push_back(c.assign_w(in.w(2 + i)));
+        for (int i = 0; i < 12; i++) Y.push_back(c.assign_w(in.w(14 + i)));
+        c.int_neg(A);
+        c.int_square(A);
+        AssignedInteger inv = c.int_unsafe_invert(B);
+        AssignedCondition z = c.is_int_zero(A);
+        c.is_int_equal(A, B);
+        c.assign_int_constant(c.info->w_modulus - BigUint(5));
+        c.int_mul_small_constant(A, 5);
+        c.bisec_int(z, A, B);
+        AssignedInteger t = c.int_mul(inv, B);
+        AssignedInteger one = c.assign_int_constant(BigUint(1));
+        c.assert_int_equal(t, one);
+        auto f2 = [&](const std::vector<AssignedInteger>& v, int k) { return AssignedFq2{v[k], v[k + 1]}; };
+        auto f6 = [&](const std::vector<AssignedInteger>& v, int k) { return AssignedFq6{f2(v, k), f2(v, k + 2), f2(v, k + 4)}; };
+        AssignedFq2 x2 = f2(X, 0), y2 = f2(Y, 0);
+        AssignedFq2 a2 = po->fq2_add(x2, y2);
+        po->fq2_sub(x2, y2);
+        AssignedFq2 m2 = po->fq2_mul(x2, y2);
+        po->fq2_square(x2);
+        po->fq2_neg(x2);
+        po->fq2_double(x2);
+        po->fq2_conjugate(x2);
+        po->fq2_unsafe_invert(y2);
+        po->fq2_mul_by_nonresidue(m2);
+        po->fq2_frobenius_map(x2, 1);
+        AssignedFq2 r2 = po->fq2_reduce(a2);
+        po->fq2_assert_equal(r2, a2);
+        AssignedFq6 x6 = f6(X, 0), y6 = f6(Y, 0);
+        AssignedFq6 a6 = po->fq6_add(x6, y6);
+        po->fq6_sub(x6, y6);
+        AssignedFq6 m6 = po->fq6_mul(x6, y6);
+        po->fq6_square(x6);
+        po->fq6_neg(x6);
+        po->fq6_double(x6);
+        po->fq6_unsafe_invert(y6);
+        po->fq6_mul_by_nonresidue(m6);
+        po->fq6_frobenius_map(x6, 1);
+        AssignedFq6 r6 = po->fq6_reduce(a6);
+        po->fq6_assert_equal(r6, a6);
+        AssignedFq12 x12{f6(X, 0), f6(X, 6)}, y12{f6(Y, 0), f6(Y, 6)};
+        AssignedFq12 a12 = po->fq12_add(x12, y12);
+        po->fq12_sub(x12, y12);
+        po->fq12_mul(x12, y12);
+        po->fq12_square(x12);
+        po->fq12_neg(x12);
+        po->fq12_double(x12);
+        po->fq12_conjugate(x12);
+        po->fq12_frobenius_map(x12, 1);
+        po->fq12_cyclotomic_square(x12);
+        po->fq12_unsafe_invert(y12);
+        AssignedFq12 r12 = po->fq12_reduce(a12);
+        po->fq12_assert_eq(r12, a12);
+    });
+}
+
 // second block of src/tests/general_scalar_pairing_chip.rs:74-105
 void* oracle_run_pairing_check_bls12_381(const uint64_t* inputs) {
     return guarded([&](Run& r) {

@@ -31,7 +31,7 @@ def load():
     L = C.CDLL(LIB)
     vp = C.c_void_p
     for name in ("oracle_run_int_mul_batch", "oracle_run_integer_chip_st", "oracle_run_msm_bn256_tile",
-                 "oracle_run_msm_bn256_tile_no_select", "oracle_run_pairing_check_bn256", "oracle_run_pairing_check_bls12_381", "oracle_run_pairing", "oracle_run_msm_bls12_381_tile", "oracle_run_ops_msm_twice", "oracle_run_ops_ecc_surface"):
+                 "oracle_run_msm_bn256_tile_no_select", "oracle_run_pairing_check_bn256", "oracle_run_pairing_check_bls12_381", "oracle_run_pairing", "oracle_run_msm_bls12_381_tile", "oracle_run_ops_msm_twice", "oracle_run_ops_ecc_surface", "oracle_run_ops_int_tower"):
         getattr(L, name).restype = vp
     L.oracle_run_int_mul_batch.argtypes = [C.c_int, C.c_uint32, vp]
     L.oracle_run_integer_chip_st.argtypes = [C.c_int, vp]
@@ -40,6 +40,7 @@ def load():
     L.oracle_run_msm_bls12_381_tile.argtypes = [C.c_uint32, vp]
     L.oracle_run_ops_msm_twice.argtypes = [C.c_uint32, vp]
     L.oracle_run_ops_ecc_surface.argtypes = [vp]
+    L.oracle_run_ops_int_tower.argtypes = [C.c_int, vp]
     L.oracle_run_pairing.argtypes = [C.c_int, C.c_uint32, C.c_int, vp]
     L.oracle_run_pairing_check_bn256.argtypes = [vp]
     L.oracle_run_pairing_check_bls12_381.argtypes = [vp]
@@ -167,3 +168,8 @@ def run_ops_msm_twice(n, inputs):
 def run_ops_ecc_surface(inputs):
     a, p = _ptr(inputs)
     return Run(load().oracle_run_ops_ecc_surface(p))
+
+
+def run_ops_int_tower(curve, inputs):
+    a, p = _ptr(inputs)
+    return Run(load().oracle_run_ops_int_tower(curve, p))

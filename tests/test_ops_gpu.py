@@ -143,3 +143,162 @@ def test_ops_complete_addition_surface(engine, oracle):
         for region, got, ovals in _rows_of(engine, rec, orun, n_inst):
             assert np.array_equal(got[k], ovals), f"instance {k}: advice differs in region {region}"
     rec.close()
+
+
+def test_ops_attach_splices_into_caller_arrays(engine, oracle):
+    """The splice seam (ParallelClone, src/circuit/ecc_chip.rs:64-77, :289-352; native_scalar_ecc_chip.rs:50-90,
+    :173-178): the first half of the nine-op MSM scenario runs on a records object that owns its arrays; a second records
+    object is then *attached* to those arrays at the first one's cursors and msm prefix (h2e_records_attach: caller-allocated
+    arrays, starting offsets deep inside them, prefix 2^20) and runs the second msm_unsafe + ecc_assert_equal.  The arrays
+    then equal the oracle's single context cell for cell, and the attached object reports the offsets / heights the caller's
+    apply_offset_diff / merge need."""
+    n, n_inst = 6, 3
+    ins = [synth.msm_bn256_tile_inputs(n, tile=820 + k)[0] for k in range(n_inst)]
+    oruns = [oracle_lib.run_ops_msm_twice(n, inp) for inp in ins]
+    i = oruns[0].info
+    rows = (max(i.base_height, i.base_offset) + 1, max(i.range_height, i.range_offset) + 1, max(i.select_height, i.select_offset) + 1)
+    rec = Records(engine, E.FIELD_BN256_FQ, n_inst, rows, emit_shape=False)
+    a = np.stack(ins)
+    pts = rec.assign_points(n, a[:, 0:3 * n])
+    scs = rec.assign_scalars(n, a[:, 3 * n:4 * n])
+    m = rec.int_op(E.INT_MUL, pts[0].x, pts[0].y)
+    s = rec.int_op(E.INT_ADD, m, m)
+    s2 = rec.int_op(E.INT_SUB, s, pts[0].x)
+    rd = rec.int_op(E.INT_REDUCE, s2)
+    rec.int_op(E.INT_DIV, rd, pts[0].y)
+    g, r1, r2 = a[:, 4 * n:4 * n + 2], a[:, 4 * n + 2:4 * n + 4], a[:, 4 * n + 4:4 * n + 6]
+    res1 = rec.msm_unsafe(pts, scs, np.concatenate([g, r1, r2], axis=1))
+    sh = rec.shape()
+    off = (sh.base_offset, sh.range_offset, sh.select_offset)
+    assert all(o > 0 for o in off)
+    arrs = rec.arrays()
+    fork = Records.attach(engine, E.FIELD_BN256_FQ, arrs, off, msm_prefix=1 << 20, emit_shape=False)   # MSM_PREFIX_OFFSET: one msm so far
+    res2 = fork.msm_unsafe(pts, scs, np.concatenate([g, r2, r1], axis=1))
+    fork.ecc_assert_equal(res1, res2)
+    engine.torch.cuda.synchronize()
+    assert (arrs[3].cpu().numpy() == 0).all()
+    fs = fork.shape()
+    assert (fs.base_offset, fs.range_offset, fs.select_offset) == (i.base_offset, i.range_offset, i.select_offset)
+    for k, orun in enumerate(oruns):
+        for region in range(3):
+            ovals, oflags = orun.adv(region, rows[region])
+            got = arrs[region][:, :, :, k, :].cpu().numpy().view(np.uint64).reshape(rows[region], E.COLS[region], 4)
+            mask = (oflags & 1).astype(bool)
+            assert np.array_equal(got[mask], ovals[mask]), f"instance {k}: advice differs in region {region}"
+    fork.close()
+    rec.close()
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_ops_integer_and_tower_surface(engine, oracle, curve):
+    """The rest of IntegerChipOps (int_neg, int_square, int_unsafe_invert, is_int_zero, is_int_equal, assign_int_constant,
+    int_mul_small_constant, bisec_int, assert_int_equal: src/circuit/integer_chip.rs:15-70) and the Fq2 / Fq6 / Fq12 surface
+    (src/circuit/fq12.rs:24-459: add, sub, mul, square, neg, double, conjugate, unsafe_invert, mul_by_nonresidue, frobenius_map,
+    cyclotomic_square, reduce, assert_equal) as ops on assigned elements, bn256 and bls12_381 towers - ~70 ops equal the oracle
+    calling the same methods on one context.  A second records object then repeats the sequence: every op comes from the
+    context's op-program cache (no host-side recording) and the arrays are the same."""
+    n_inst = 2
+    fp = E.FIELD_BN256_FQ if curve == 0 else E.FIELD_BLS12_381_FQ
+    w = synth.W_MODULUS[curve]
+    sw = synth.SLOT_WORDS[curve]
+    ins = []
+    for k in range(n_inst):
+        rng = synth.SplitMix64(synth.SEED0 + 77 + curve + 1000003 * k)
+        ins.append(synth.pack([rng.below(w) for _ in range(26)], sw))
+    oruns = [oracle_lib.run_ops_int_tower(curve, inp) for inp in ins]
+    i = oruns[0].info
+    assert i.status == 0, oruns[0].error
+    rows = (max(i.base_height, i.base_offset) + 1, max(i.range_height, i.range_offset) + 1, 1)
+    a = np.stack(ins)
+
+    def scenario(rec):
+        A, B = rec.assign_w(a[:, 0:1]), rec.assign_w(a[:, 1:2])
+        X = [rec.assign_w(a[:, 2 + j:3 + j]) for j in range(12)]
+        Y = [rec.assign_w(a[:, 14 + j:15 + j]) for j in range(12)]
+        rec.int_unary(E.INT_NEG, A)
+        rec.int_unary(E.INT_SQUARE, A)
+        inv = rec.int_unary(E.INT_UNSAFE_INVERT, B)
+        z = rec.int_unary(E.INT_IS_ZERO, A)
+        rec.int_unary(E.INT_IS_EQUAL, A, B)
+        rec.assign_int_constant(w - 5)
+        rec.int_mul_small_constant(A, 5)
+        rec.bisec_int(z, A, B)
+        t = rec.int_op(E.INT_MUL, inv, B)
+        one = rec.assign_int_constant(1)
+        rec.int_unary(E.INT_ASSERT_EQUAL, t, one)
+        for deg in (2, 6, 12):
+            x, y = X[:deg], Y[:deg]
+            s = rec.fq(deg, E.FQ_ADD, x, y)
+            rec.fq(deg, E.FQ_SUB, x, y)
+            m = rec.fq(deg, E.FQ_MUL, x, y)
+            rec.fq(deg, E.FQ_SQUARE, x)
+            rec.fq(deg, E.FQ_NEG, x)
+            rec.fq(deg, E.FQ_DOUBLE, x)
+            if deg == 2:
+                rec.fq(deg, E.FQ_CONJUGATE, x)
+                rec.fq(deg, E.FQ_UNSAFE_INVERT, y)
+                rec.fq(deg, E.FQ_MUL_BY_NONRESIDUE, m)
+                rec.fq(deg, E.FQ_FROBENIUS_MAP, x, imm=1)
+            elif deg == 6:
+                rec.fq(deg, E.FQ_UNSAFE_INVERT, y)
+                rec.fq(deg, E.FQ_MUL_BY_NONRESIDUE, m)
+                rec.fq(deg, E.FQ_FROBENIUS_MAP, x, imm=1)
+            else:
+                rec.fq(deg, E.FQ_CONJUGATE, x)
+                rec.fq(deg, E.FQ_FROBENIUS_MAP, x, imm=1)
+                rec.fq(deg, E.FQ_CYCLOTOMIC_SQUARE, x)
+                rec.fq(deg, E.FQ_UNSAFE_INVERT, y)
+            r = rec.fq(deg, E.FQ_REDUCE, s)
+            rec.fq(deg, E.FQ_ASSERT_EQUAL, r, s)
+
+    rec = Records(engine, fp, n_inst, rows)
+    scenario(rec)
+    engine.torch.cuda.synchronize()
+    assert (rec.arrays()[3].cpu().numpy() == 0).all(), rec.arrays()[3].cpu().numpy()
+    for k, orun in enumerate(oruns):
+        for region, got, ovals in _rows_of(engine, rec, orun, n_inst):
+            assert np.array_equal(got[k], ovals), f"instance {k}: advice differs in region {region}"
+    first = [x.clone() for x in rec.arrays()[:2]]
+    hits0, miss0 = engine.get_stat(E.STAT_OP_CACHE_HITS), engine.get_stat(E.STAT_OP_CACHE_MISSES)
+    rec2 = Records(engine, fp, n_inst, rows)
+    scenario(rec2)
+    engine.torch.cuda.synchronize()
+    assert engine.get_stat(E.STAT_OP_CACHE_MISSES) == miss0 and engine.get_stat(E.STAT_OP_CACHE_HITS) > hits0
+    for region in range(2):
+        assert engine.torch.equal(rec2.arrays()[region], first[region])
+    sh1, sh2 = rec.shape(), rec2.shape()
+    assert (sh1.base_offset, sh1.range_offset, sh1.n_permutations) == (sh2.base_offset, sh2.range_offset, sh2.n_permutations)
+    rec2.close()
+    rec.close()
+
+
+def test_ops_pairing_on_assigned_terms(engine, oracle):
+    """PairingChipOps::pairing (src/circuit/pairing_chip.rs:157-171) as an op on assigned terms - the G2 constants, the G1
+    points, then pairing() returning the Fq12 result's twelve integers as handles - equals the oracle running
+    pairing(terms) in one context (src/tests/native_scalar_pairing_chip.rs:20-65 without the final constant comparison);
+    one more op on the returned handles (fq12 square) checks that they are the result's cells"""
+    n_inst = 2
+    ins = [synth.pairing_inputs(0, 1, instance=830 + k) for k in range(n_inst)]
+    oruns = [oracle_lib.run_pairing(0, 1, False, x) for x in ins]
+    i = oruns[0].info
+    assert i.status == 0, oruns[0].error
+    rows = (max(i.base_height, i.base_offset) + 1 + 4096, max(i.range_height, i.range_offset) + 1 + 4096, 1)
+    rec = Records(engine, E.FIELD_BN256_FQ, n_inst, rows, emit_shape=False)
+    a = np.stack(ins)
+    b = rec.assign_g2_constant(a[:, 0:4])
+    g1 = rec.assign_points(1, a[:, 4:7])[0]
+    res = rec.pairing([g1], [b])
+    assert len(res) == 12
+    sh = rec.shape()
+    assert (sh.base_offset, sh.range_offset) == (i.base_offset, i.range_offset)
+    rec.fq(12, E.FQ_SQUARE, res)            # the handles are usable operands
+    engine.torch.cuda.synchronize()
+    arrs = rec.arrays()
+    assert (arrs[3].cpu().numpy() == 0).all()
+    for k, orun in enumerate(oruns):
+        for region in range(2):
+            nrow = (i.base_offset, i.range_offset)[region]
+            ovals, _ = orun.adv(region, rows[region])
+            got = arrs[region][:, :, :, k, :].cpu().numpy().view(np.uint64).reshape(rows[region], E.COLS[region], 4)
+            assert np.array_equal(got[:nrow], ovals[:nrow]), f"instance {k}: advice differs in region {region}"
+    rec.close()
