@@ -191,7 +191,7 @@ def main():
     ap.add_argument("--points", type=int, default=1024, help="points per MSM tile")
     ap.add_argument("--ring", type=int, default=None, help="output-buffer sets steps rotate through = runs in flight (default: 2 for the MSM - step k+1's value chain runs under "
                     "step k's expansion, 2 x 110 GB of arrays; 8 / 16 for the bn256 / bls12_381 pairing checks, whose value chains are latency-bound; 1: h2e_run, no overlap)")
-    ap.add_argument("--digest", action="store_true", help="consume every step's arrays with the on-device digest kernel (streaming-job mode, configs[2])")
+    ap.add_argument("--digest", action="store_true", help="consume every step's arrays with the stream digest (h2e_submit_digest; streaming-job mode, configs[2])")
     ap.add_argument("--job-tiles", type=int, default=None, help="run one MSM job of this many tiles over all ranks (2^20 points = 1024; `--job-tiles 1024 --gpus 8` is configs[2]): "
                     "steps = job_tiles / (units x gpus), every tile with its own inputs, digest on, one gather of the job's records at the end")
     ap.add_argument("--suite", default=None, choices=["all", "main"], help="all (default for the plain N = 1 MSM invocation): also measure the pairing configs and the 2^20-point job "
@@ -283,11 +283,8 @@ def main():
     shape_prog = make(True)  # shape-only artefacts, once per shape (not timed)
     cells_per_unit = shape_prog.n_advice_cells
     launches = shape_prog.launches()
-    if args.digest:
-        prog = shape_prog    # the digest is over the assigned cells: it needs the program's assigned / permute flags
-    else:
-        prog = make(False)
-        shape_prog.close()
+    prog = make(False)
+    shape_prog.close()
     # the launch with the most cells (MSM: the window strands; pairing: the whole check)
     dom = max(range(len(launches)), key=lambda i: launches[i]["cells"])
 
@@ -367,9 +364,7 @@ def main():
         job: SURVEY 8d cfg 3), and its rows of the job's record table"""
         base, rng, sel, status = bufs[slot]
         status_any.bitwise_or_(status)
-        if args.digest:
-            for region, arr in enumerate((base, rng, sel)):
-                eng.digest(prog, region, arr, out=digests[slot][region])
+        if args.digest:   # (the stream digest was accumulated by the run itself: nothing to launch here)
             digest_any[0] = digests[slot]
         if want_records and timing[0]:
             parallel.unit_records(status, offsets, base, out_refs, digests[slot] if args.digest else None, out=job_rec[k - timed_from[0]])
@@ -394,7 +389,10 @@ def main():
         base, rng, sel, status = bufs[slot]
         if ring == 1:
             status.zero_()
-            eng.run(prog, batch_of(k), base, rng, sel, status)
+            if args.digest:
+                eng.run_digest(prog, batch_of(k), base, rng, sel, status, digests[slot])
+            else:
+                eng.run(prog, batch_of(k), base, rng, sel, status)
             consume(slot, k)
             if timing[0]:
                 torch.cuda.current_stream().synchronize()
@@ -403,7 +401,10 @@ def main():
         while len(pending) >= ring:                     # the slot's previous step must have been consumed
             retire(*pending.pop(0))
         status.zero_()
-        job = eng.submit(prog, batch_of(k), base, rng, sel, status)
+        if args.digest:
+            job = eng.submit_digest(prog, batch_of(k), base, rng, sel, status, digests[slot])
+        else:
+            job = eng.submit(prog, batch_of(k), base, rng, sel, status)
         pending.append((job, slot, k))
         while len(pending) > ring - 1:                  # consume the step before this one (its expansion overlaps our chain)
             retire(*pending.pop(0))
@@ -501,8 +502,8 @@ def main():
         # replay): that kernel is the time-dominant one, priced against the bytes of the cells it is the critical path of
         c_ach = dom_bytes * dom_n / (chain_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": c_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c_ach / HBM_PEAK_GBS, "traffic": None,
-                "kernel": f"h2e_replay_levels<{fpname}> (values-only level-parallel replay: the value chain the expansion waits for; latency-bound - "
-                          "priced against the algorithmic bytes of the cells it is the critical path of)",
+                "kernel": f"h2e_field_chain<{fpname}> (+ h2e_field_finalize, h2e_hint_store: the value chain the expansion waits for - residues mod w, "
+                          "~4.5 k dependent rounds, latency-bound; priced against the algorithmic bytes of the cells it is the critical path of)",
                 "launch_ms": chain_ms, "algorithmic_bytes_per_launch": dom_bytes * dom_n, "launches_per_step": 1, "expansion": x_roof}
     else:
         roof = x_roof
@@ -535,7 +536,8 @@ def main():
         out["config"].update(tiles_per_gpu=units, points_per_tile=n, cells_per_tile=cells_per_unit,
                              points_note="per-tile-batch rate; the test body's assign_point / assign rows are part of every tile")
     if args.digest:
-        out["config"]["consumer"] = "h2e_digest over the three advice arrays of every step (32 B per array and unit), inside the timed region"
+        out["config"]["consumer"] = ("stream digest of the three advice arrays of every step (h2e_submit_digest: 32 B per array and unit, accumulated by the "
+                                     "expansion while it stores), inside the timed region")
         out["digest_sample"] = [int(x) & 0xFFFFFFFFFFFFFFFF for x in digest_any[0][0, 0].cpu().tolist()] if digest_any[0] is not None else None
     if gathered is not None:
         out["gathered_records"] = {"shape": list(gathered.shape), "status_or": int(gathered[:, 0].abs().max())}

@@ -175,7 +175,31 @@ struct LC {  // lane context
     // words).  Their index is per lane, so from constant memory they are vector loads - and a vector load waits for every
     // older store of the wave (one counter, in order).
     const u64* ceil_lds = nullptr;
+    // Stream digest (include/h2e.h h2e_run_digest): the expansion adds every cell it stores to 3 x 4 per-lane sums kept in
+    // LDS ([region][word][lane], this lane's words at dg + (4 region + word) * 64), flushed to the run's digest array when
+    // the lane is done.  nullptr = off.
+    u64* dg = nullptr;
 };
+// key of a cell position and the digest contribution of one 64-bit word of its value (h2e.h: stream digest)
+WI_INLINE void dg_keys(u32 pos, u32& k0, u32& k1) {
+    u32 h = pos * 0x9E3779B1u;
+    k0 = (h ^ (h >> 15)) | 1u;
+    k1 = (h * 0x85EBCA77u + 0xC2B2AE3Du) | 1u;
+}
+WI_INLINE void dg_word(u64* slot, u64 w, u32 k0, u32 k1) {
+    u64 t = (u64)(u32)w * k0 + (u64)(u32)(w >> 32) * k1;
+    __hip_atomic_fetch_add((H2E_AS_LDS u64*)slot, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+// NW = words of the value that can be non-zero (4: any cell, 2: a limb, 1: an 18-bit chunk / small value)
+template <int NW>
+WI_INLINE void dg_cell(const LC& c, u32 region, u32 abs_row, u32 col, u32 cols, const u64* w) {
+    if (c.dg == nullptr) return;
+    u32 k0, k1;
+    dg_keys(abs_row * cols + col, k0, k1);
+    u64* base = c.dg + (size_t)region * 4 * 64;
+#pragma unroll
+    for (int j = 0; j < NW; j++) dg_word(base + j * 64, w[j], k0, k1);
+}
 WI_INLINE Limb ceil_limb(const LC& c, u32 t, int i) {
     if (c.ceil_lds) {
         u64x2 q = l_ld16(c.ceil_lds + ((size_t)t * H2E_MAX_L + i) * 2);
@@ -289,6 +313,14 @@ WI_INLINE void rowB(const LC& c, u32 row, u32 mask, const Fe& v0, const Fe& v1, 
     if (mask & 4) st_cell(p + (size_t)4 * hs, hs, v2);
     if (mask & 8) st_cell(p + (size_t)6 * hs, hs, v3);
     if (mask & 16) st_cell(p + (size_t)8 * hs, hs, v4);
+    if (c.dg != nullptr) {
+        u32 ar = row + c.ob;
+        if (mask & 1) dg_cell<4>(c, 0, ar, 0, 5, v0.v);
+        if (mask & 2) dg_cell<4>(c, 0, ar, 1, 5, v1.v);
+        if (mask & 4) dg_cell<4>(c, 0, ar, 2, 5, v2.v);
+        if (mask & 8) dg_cell<4>(c, 0, ar, 3, 5, v3.v);
+        if (mask & 16) dg_cell<4>(c, 0, ar, 4, 5, v4.v);
+    }
 }
 WI_INLINE void rowR(const LC& c, u32 row, u32 mask, const Fe& acc, const Fe& tagged, const Fe& common) {
     if (!c.active) return;
@@ -297,6 +329,12 @@ WI_INLINE void rowR(const LC& c, u32 row, u32 mask, const Fe& acc, const Fe& tag
     if (mask & 1) st_cell(p, hs, acc);
     if (mask & 2) st_cell(p + (size_t)2 * hs, hs, tagged);
     if (mask & 4) st_cell(p + (size_t)4 * hs, hs, common);
+    if (c.dg != nullptr) {
+        u32 ar = row + c.orr;
+        if (mask & 1) dg_cell<4>(c, 1, ar, 0, 3, acc.v);
+        if (mask & 2) dg_cell<4>(c, 1, ar, 1, 3, tagged.v);
+        if (mask & 4) dg_cell<4>(c, 1, ar, 2, 3, common.v);
+    }
 }
 WI_INLINE void rowS(const LC& c, u32 row, u32 mask, const Fe& value, const Fe& selector) {
     if (!c.active) return;
@@ -304,6 +342,11 @@ WI_INLINE void rowS(const LC& c, u32 row, u32 mask, const Fe& value, const Fe& s
     u32 hs = c.hs;
     if (mask & 1) st_cell(p, hs, value);
     if (mask & 2) st_cell(p + (size_t)2 * hs, hs, selector);
+    if (c.dg != nullptr) {
+        u32 ar = row + c.os;
+        if (mask & 1) dg_cell<4>(c, 2, ar, 0, 2, value.v);
+        if (mask & 2) dg_cell<4>(c, 2, ar, 1, 2, selector.v);
+    }
 }
 WI_INLINE void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // Round barriers of the level / wave / field-chain kernels.  `__syncthreads()` is a workgroup-scope release fence + barrier:
@@ -349,6 +392,18 @@ WI_INLINE void emit_limb3(const LC& c, u32 row, const Limb& x) {
     st_small(p + rs + 2 * cs, hs, chunk18(x, 1));
     st_small(p + 2 * rs + cs, hs, chunk18(x, 5));
     st_small(p + 2 * rs + 2 * cs, hs, chunk18(x, 2));
+    if (c.dg != nullptr) {
+        u32 ar = row + c.orr;
+        dg_cell<2>(c, 1, ar, 0, 3, x.v);
+        const int chunk_of[3][2] = {{3, 0}, {4, 1}, {5, 2}};   // (tagged, common) chunk of each of the three rows
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                u64 v = chunk18(x, chunk_of[r][k]);
+                dg_cell<1>(c, 1, ar + r, 1 + k, 3, &v);
+            }
+    }
 }
 // leading limb in a 2-line range value (36..72 bits): 2 rows, 5 cells
 WI_INLINE void emit_lead2(const LC& c, u32 row, const Limb& x) {
@@ -361,6 +416,18 @@ WI_INLINE void emit_lead2(const LC& c, u32 row, const Limb& x) {
     st_small(p + 2 * cs, hs, chunk18(x, 0));
     st_small(p + rs + cs, hs, chunk18(x, 3));
     st_small(p + rs + 2 * cs, hs, chunk18(x, 1));
+    if (c.dg != nullptr) {
+        u32 ar = row + c.orr;
+        dg_cell<2>(c, 1, ar, 0, 3, x.v);
+        const int chunk_of[2][2] = {{2, 0}, {3, 1}};
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                u64 v = chunk18(x, chunk_of[r][k]);
+                dg_cell<1>(c, 1, ar + r, 1 + k, 3, &v);
+            }
+    }
 }
 // assign_common: 1 row, 2 cells
 WI_INLINE void emit_common(const LC& c, u32 row, u64 x) {
@@ -368,6 +435,10 @@ WI_INLINE void emit_common(const LC& c, u32 row, u64 x) {
     u64* p = rowR_ptr(c, row);
     st_small(p, c.hs, x);
     st_small(p + (size_t)2 * c.hs, c.hs, x);
+    if (c.dg != nullptr) {
+        dg_cell<1>(c, 1, row + c.orr, 0, 3, &x);
+        dg_cell<1>(c, 1, row + c.orr, 1, 3, &x);
+    }
 }
 
 template <class FP>
@@ -1151,6 +1222,13 @@ __global__ void __launch_bounds__(64, H2E_X_WAVES) h2e_run_tape(H2ELaunch L, con
     extern __shared__ u64 xcache_dyn[];   // [3][2 L + 4][64] words when the result cache is on (H2ELaunch.rel_refs bit 2)
     c.active = active;
     c.xc = (L.rel_refs & 4) ? xcache_dyn : nullptr;
+    // stream digest: this lane's 3 x 4 sums, [region][word][lane] in LDS
+    __shared__ u64 dg_sums[12 * 64];
+    if (!VALUES_ONLY && L.dg_out != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) l_st8(dg_sums + k * 64 + threadIdx.x, 0);
+        c.dg = dg_sums + threadIdx.x;
+    }
     if (L.rel_refs & 8) __builtin_amdgcn_s_setprio(3);   // the expansion's waves at the chain kernels' priority (g_tune[1] bit 1)
     {
         for (u32 i0 = op_lo; i0 < op_hi; i0 += 64) {
@@ -1160,6 +1238,14 @@ __global__ void __launch_bounds__(64, H2E_X_WAVES) h2e_run_tape(H2ELaunch L, con
                 H2EOp op = chunk_op(&chunk, k);
                 exec_op<FP, false>(c, op);
             }
+        }
+    }
+    if (c.dg != nullptr && active) {
+        lds_fence();
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            u64 v = l_ld8(dg_sums + k * 64 + threadIdx.x);
+            if (v) atomicAdd((unsigned long long*)(L.dg_out + ((size_t)(k / 4) * n_instances + instance) * 4 + (k % 4)), (unsigned long long)v);
         }
     }
 }
@@ -2287,6 +2373,7 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_fixup_inverses(H2ELau
         }
     }
     Fe ainv = wd_inv_mod<4>(acc, M.p);
+    u64 dgv[4] = {0, 0, 0, 0};
     for (u32 i1 = hi; i1 > lo;) {
         u32 cnt = min(FB, i1 - lo);   // rows i1-1 ... i1-cnt, in that order
         u64* rows[FB];
@@ -2307,10 +2394,20 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_fixup_inverses(H2ELau
                     ainv = mont_mul<4>(M, ainv, xs[j]);
                 }
                 st_cell(rows[j] + (size_t)2 * hs, hs, out);
+                if (L.dg_out != nullptr) {   // the inverse witness is a cell of the base array: (row, column 1)
+                    u32 k0, k1;
+                    dg_keys((L.fixups[i1 - 1 - j] + ob) * 5u + 1u, k0, k1);
+#pragma unroll
+                    for (int w = 0; w < 4; w++) dgv[w] += (u64)(u32)out.v[w] * k0 + (u64)(u32)(out.v[w] >> 32) * k1;
+                }
             }
         }
         i1 -= cnt;
     }
+    if (L.dg_out != nullptr)
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+            if (dgv[w]) atomicAdd((unsigned long long*)(L.dg_out + (size_t)instance * 4 + w), (unsigned long long)dgv[w]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -2356,7 +2356,7 @@ static hipError_t make_stream(h2e_ctx* ctx, hipStream_t* out, int prio, int kind
 }
 
 static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
-                    void* d_select, void* d_status, hipStream_t stream, bool join, int* slot_out) {
+                    void* d_select, void* d_status, hipStream_t stream, bool join, int* slot_out, void* d_digests = nullptr) {
     if (!ctx || !p) return fail(H2E_ERR_INVALID, "null ctx/program");
     if (!d_inputs || !d_base || !d_range || !d_select || !d_status) return fail(H2E_ERR_INVALID, "null device pointer");
     std::lock_guard<std::mutex> guard(ctx->mu);
@@ -2462,6 +2462,8 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     }
     HIP_TRY(hipMemcpyAsync(J.d_inst, J.h_inst.data(), (size_t)n_instances * sizeof(InstanceDescHost),
                            hipMemcpyHostToDevice, sa));
+    // stream digest: the expansion and fix-up kernels of this run add to it (every other stream starts behind this point)
+    if (d_digests) HIP_TRY(hipMemsetAsync(d_digests, 0, (size_t)3 * n_instances * 4 * sizeof(uint64_t), sa));
     bool used_sd = false;
     std::vector<hipEvent_t> early_done(r.pre_kernels.size(), nullptr);
     size_t n_sync = 0;
@@ -2628,6 +2630,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         L.s_offsets = hstore ? p->d_soffsets + p->seg_so_begin[si] : nullptr;
         L.s_ktab = hstore ? p->d_sktab + p->seg_sk_begin[si] : nullptr;
         L.n_sops = hstore ? p->seg_n_sops[si] : 0;
+        L.dg_out = (uint64_t*)d_digests;
         L.l_steps = levels ? p->seg_l_steps[si] : 0;
         L.l_slots = levels ? p->seg_l_slots[si] : 0;
         L.l_pair = levels ? p->seg_l_pair[si] : 0;
@@ -2820,6 +2823,21 @@ int h2e_submit(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d
     *job = -1;
     if (n_instances == 0) return fail(H2E_ERR_INVALID, "n_instances must be > 0");
     return run_impl(ctx, p, n_instances, d_inputs, d_base, d_range, d_select, d_status, (hipStream_t)stream_, false, job);
+}
+
+int h2e_run_digest(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
+                   void* d_select, void* d_status, void* d_digests, void* stream_) {
+    if (n_instances == 0) return 0;
+    if (!d_digests) return fail(H2E_ERR_INVALID, "d_digests is null");
+    return run_impl(ctx, p, n_instances, d_inputs, d_base, d_range, d_select, d_status, (hipStream_t)stream_, true, nullptr, d_digests);
+}
+int h2e_submit_digest(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
+                      void* d_select, void* d_status, void* d_digests, void* stream_, int* job) {
+    if (!job) return fail(H2E_ERR_INVALID, "job is null");
+    *job = -1;
+    if (n_instances == 0) return fail(H2E_ERR_INVALID, "n_instances must be > 0");
+    if (!d_digests) return fail(H2E_ERR_INVALID, "d_digests is null");
+    return run_impl(ctx, p, n_instances, d_inputs, d_base, d_range, d_select, d_status, (hipStream_t)stream_, false, job, d_digests);
 }
 
 int h2e_wait(h2e_ctx* ctx, int job, void* stream_) {

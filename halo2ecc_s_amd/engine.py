@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "h2e_op_ecc_double", "h2e_op_ecc_add", "h2e_op_ecc_neg", "h2e_op_ecc_encode", "h2e_op_ecc_mul", "h2e_op_assign_constant_point",
     "h2e_op_bisec_point_with_curvature", "h2e_op_assign_cache_point", "h2e_op_assign_selected_point", "h2e_export_fixed", "h2e_range_table", "h2e_export_copy_constraints", "h2e_ctx_set_option", "h2e_ctx_get_stat",
     "h2e_program_msm_bn256_tile_no_select", "h2e_last_run_expansion_launches",
-    "h2e_records_attach", "h2e_op_int_mul_small_constant", "h2e_op_assign_int_constant", "h2e_op_bisec_int", "h2e_op_fq", "h2e_op_pairing",
+    "h2e_run_digest", "h2e_submit_digest", "h2e_records_attach", "h2e_op_int_mul_small_constant", "h2e_op_assign_int_constant", "h2e_op_bisec_int", "h2e_op_fq", "h2e_op_pairing",
 ]
 
 
@@ -163,6 +163,8 @@ def lib():
     L.h2e_digest.argtypes = [vp, vp, u32, i32, vp, vp, vp]
     L.h2e_submit.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
     L.h2e_wait.argtypes = [vp, i32, vp]
+    L.h2e_run_digest.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
+    L.h2e_submit_digest.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
     L.h2e_ctx_set_option.argtypes = [vp, i32, C.c_int64]
     L.h2e_ctx_get_stat.argtypes = [vp, i32]
     L.h2e_ctx_get_stat.restype = C.c_int64
@@ -555,6 +557,25 @@ class Engine:
         job = C.c_int(-1)
         _check(lib().h2e_submit(self._h, program._h, n, d_inputs.data_ptr(), base.data_ptr(), rng.data_ptr(),
                                 sel.data_ptr(), status.data_ptr(), self._stream(stream).cuda_stream, C.byref(job)))
+        return job.value
+
+    def run_digest(self, program, d_inputs, base, rng, sel, status, digests=None, stream=None):
+        """h2e_run_digest: h2e_run + the stream digest of the run's three arrays, int64 [3][instances][4] (accumulated by the
+        expansion while it stores: no second pass over the cells)"""
+        n = d_inputs.shape[0]
+        if digests is None:
+            digests = self.torch.empty((3, n, 4), dtype=self.torch.int64, device=base.device)
+        assert tuple(digests.shape) == (3, n, 4) and digests.is_contiguous()
+        _check(lib().h2e_run_digest(self._h, program._h, n, d_inputs.data_ptr(), base.data_ptr(), rng.data_ptr(), sel.data_ptr(),
+                                    status.data_ptr(), digests.data_ptr(), self._stream(stream).cuda_stream))
+        return digests
+
+    def submit_digest(self, program, d_inputs, base, rng, sel, status, digests, stream=None):
+        n = d_inputs.shape[0]
+        assert tuple(digests.shape) == (3, n, 4) and digests.is_contiguous()
+        job = C.c_int(-1)
+        _check(lib().h2e_submit_digest(self._h, program._h, n, d_inputs.data_ptr(), base.data_ptr(), rng.data_ptr(), sel.data_ptr(),
+                                       status.data_ptr(), digests.data_ptr(), self._stream(stream).cuda_stream, C.byref(job)))
         return job.value
 
     def wait(self, job, stream=None):

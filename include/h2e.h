@@ -341,6 +341,20 @@ int h2e_op_pairing(h2e_records* rec, uint32_t n_pairs, const h2e_point* g1, cons
  * without their shape digest every cell of the array.  Asynchronous on `stream`. */
 int h2e_digest(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, const void* d_batch, void* d_digests, void* stream);
 
+/* The same consumer at no extra pass: the STREAM DIGEST.  h2e_run_digest / h2e_submit_digest are h2e_run / h2e_submit whose
+ * expansion (and inverse fix-up) kernels add every cell they store to a position-keyed linear checksum while the value is
+ * still in registers - a streaming job that only needs a fingerprint of each tile (SURVEY.md 8d cfg 3, 8e) does not read its
+ * 78 GB of cells a second time (h2e_digest above is such a second pass: it more than doubles the step).
+ * d_digests = [3][n_instances][4] words (region-major: base, range, select), zeroed by the engine, complete with the run:
+ *   pos = row * COLS + col (32 bit), h = pos * 0x9E3779B1 (mod 2^32), k0 = (h ^ (h >> 15)) | 1, k1 = (h * 0x85EBCA77 + 0xC2B2AE3D) | 1
+ *   digest[j] = sum over assigned cells of lo32(w_j) * k0 + hi32(w_j) * k1        (mod 2^64), w_0..w_3 the cell's canonical words.
+ * Linear in the values, keyed by position: any single-cell change and any swap of two different cells changes it; it is a
+ * transport checksum, not a cryptographic hash.  tests: == the oracle's stream digest of its Records (every cell, at full size). */
+int h2e_run_digest(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
+                   void* d_select, void* d_status, void* d_digests, void* stream);
+int h2e_submit_digest(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
+                      void* d_select, void* d_status, void* d_digests, void* stream, int* job);
+
 /* Timing hook used by bench.py: HIP events recorded by the engine on the stream each kernel group is launched
  * on.  Returns the number of launched segments and fills two numbers per segment: ms[2i] = value chain
  * (predictor kernels + values-only replay), ms[2i+1] = full expansion (the inverse fix-up runs on its own stream and is not included; call after synchronising).

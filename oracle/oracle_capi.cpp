@@ -414,6 +414,23 @@ void oracle_digest(void* h, int region, uint64_t* out4) {
         for (int j = 0; j < 4; j++) out4[j] += digest_sm64(w[j] ^ t ^ ((uint64_t)j * 0xA24BAED4963EE407ull));
     }
 }
+// the stream digest of include/h2e.h (h2e_run_digest): the position-keyed linear checksum the engine's expansion accumulates
+// while it stores: per assigned cell, pos = row * COLS + col (32 bit), h = pos * 0x9E3779B1, k0 = (h ^ h >> 15) | 1,
+// k1 = (h * 0x85EBCA77 + 0xC2B2AE3D) | 1; digest[j] += lo32(w_j) * k0 + hi32(w_j) * k1  (mod 2^64)
+void oracle_stream_digest(void* h, int region, uint64_t* out4) {
+    Run* r = (Run*)h;
+    RecordsInner& in = *r->ctx->records.inner;
+    const std::vector<AdvCell>& v = region == 0 ? in.base_adv : region == 1 ? in.range_adv : in.select_adv;
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    for (size_t cell = 0; cell < v.size(); cell++) {
+        if (!v[cell].present) continue;
+        uint64_t w[4];
+        v[cell].val.to_canonical(w);
+        uint32_t hh = (uint32_t)cell * 0x9E3779B1u;
+        uint32_t k0 = (hh ^ (hh >> 15)) | 1u, k1 = (hh * 0x85EBCA77u + 0xC2B2AE3Du) | 1u;
+        for (int j = 0; j < 4; j++) out4[j] += (uint64_t)(uint32_t)w[j] * k0 + (uint64_t)(uint32_t)(w[j] >> 32) * k1;
+    }
+}
 void oracle_export_fix(void* h, int region, uint64_t* out, uint8_t* present, uint64_t rows) {
     Run* r = (Run*)h;
     RecordsInner& in = *r->ctx->records.inner;

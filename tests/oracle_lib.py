@@ -50,6 +50,8 @@ def load():
     L.oracle_export_adv.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
     L.oracle_digest.argtypes = [vp, C.c_int, vp]
     L.oracle_digest.restype = None
+    L.oracle_stream_digest.argtypes = [vp, C.c_int, vp]
+    L.oracle_stream_digest.restype = None
     L.oracle_export_fix.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
     L.oracle_export_permutations.argtypes = [vp, vp]
     L.oracle_check.argtypes = [vp, C.c_char_p, C.c_int]
@@ -91,6 +93,12 @@ class Run:
         """32-byte streaming-job digest of one advice array (definition: include/h2e.h, h2e_digest)"""
         out = np.zeros(4, dtype=np.uint64)
         self.L.oracle_digest(self.h, region, out.ctypes.data)
+        return out
+
+    def stream_digest(self, region):
+        """32-byte stream digest of one advice array (definition: include/h2e.h, h2e_run_digest: what the expansion accumulates)"""
+        out = np.zeros(4, dtype=np.uint64)
+        self.L.oracle_stream_digest(self.h, region, out.ctypes.data)
         return out
 
     def permutations(self):

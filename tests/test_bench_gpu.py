@@ -58,7 +58,8 @@ def test_bench_small_pairing(workload):
 
 def test_bench_job_128_tiles_ring_digest_vs_oracle(tmp_path):
     """configs[2]'s per-GPU share at size: 128 tiles x 1024 points as one streaming job through the ring of two 64-tile
-    buffer sets (2 steps, 220 GB of arrays), every tile its own inputs, digest consumer on, the job's records gathered once.
+    buffer sets (2 steps, 220 GB of arrays), every tile its own inputs, stream-digest consumer on (accumulated by the
+    expansion itself), the job's records gathered once.
     Sampled tiles (one per step): the record's status, Offset and the three 32-byte digests equal what the oracle
     computes from the same input vector - i.e. every advice cell of those tiles, at full size, through bench.py's own path."""
     import numpy as np
@@ -79,7 +80,7 @@ def test_bench_job_128_tiles_ring_digest_vs_oracle(tmp_path):
         assert [int(x) for x in rec[t, 1:4]] == [i.base_offset, i.range_offset, i.select_offset]
         for region in range(3):
             got = rec[t, 17 + 4 * region:21 + 4 * region].view(np.uint64)
-            assert np.array_equal(got, orun.digest(region)), (t, region)
+            assert np.array_equal(got, orun.stream_digest(region)), (t, region)
         orun.close()
 
 

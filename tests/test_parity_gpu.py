@@ -435,6 +435,52 @@ def test_digest_matches_oracle(engine, oracle):
             assert np.array_equal(dg[region][k].cpu().numpy().view(np.uint64), orun.digest(region)), (k, region)
 
 
+@pytest.mark.parametrize("workload", ["msm", "msm_no_select", "pairing_bn256", "integer_chip"])
+def test_stream_digest_matches_oracle(engine, oracle, workload):
+    """h2e_run_digest / h2e_submit_digest: the digest the expansion (and the inverse fix-up) accumulate while they store ==
+    the oracle's stream digest of its Records (same definition, include/h2e.h) for every array of every instance - i.e. every
+    assigned cell went into it exactly once, with its position - and the arrays themselves are what a plain run writes.
+    MSM tiles (forks, candidate tables, the tail), the no-select variant, a pairing check (field chain + hint store) and the
+    integer-chip test body (is_zero rows: fix-up cells)."""
+    t = engine.torch
+    if workload == "msm":
+        n, prog = 33, Program.msm_bn256_tile(33)
+        ins = [synth.msm_bn256_tile_inputs(n, tile=90 + k)[0] for k in range(5)]
+        oracle_run = lambda inp: oracle_lib.run_msm_bn256_tile(n, inp)   # noqa: E731
+    elif workload == "msm_no_select":
+        n, prog = 12, Program.msm_bn256_tile(12, with_select=False)
+        ins = [synth.msm_bn256_tile_inputs(n, tile=95 + k)[0] for k in range(3)]
+        oracle_run = lambda inp: oracle_lib.run_msm_bn256_tile(n, inp, with_select=False)   # noqa: E731
+    elif workload == "pairing_bn256":
+        prog = Program.pairing_check_bn256(emit_shape=False)
+        ins = [synth.pairing_check_bn256_inputs(instance=40 + k) for k in range(3)]
+        oracle_run = oracle_lib.run_pairing_check_bn256
+    else:
+        prog = Program.integer_chip_st(1)
+        ins = [synth.integer_chip_st_inputs(1, seed_index=60 + k) for k in range(4)]
+        oracle_run = lambda inp: oracle_lib.run_integer_chip_st(1, inp)   # noqa: E731
+    d_in = engine.upload_inputs(prog, np.stack(ins))
+    arrs = engine.alloc(prog, len(ins))
+    dg = engine.run_digest(prog, d_in, *arrs)
+    t.cuda.synchronize()
+    assert (arrs[3].cpu().numpy() == 0).all(), arrs[3].cpu().numpy()
+    for k, inp in enumerate(ins):
+        orun = oracle_run(inp)
+        assert orun.info.status == 0, orun.error
+        for region in range(3):
+            assert np.array_equal(dg[region, k].cpu().numpy().view(np.uint64), orun.stream_digest(region)), (workload, k, region)
+        orun.close()
+    # pipelined: the same digests through h2e_submit_digest into a second set of arrays
+    arrs2 = engine.alloc(prog, len(ins))
+    dg2 = t.full((3, len(ins), 4), -1, dtype=t.int64, device=dg.device)
+    job = engine.submit_digest(prog, d_in, *arrs2, dg2)
+    engine.wait(job)
+    t.cuda.synchronize()
+    assert t.equal(dg, dg2)
+    for region in range(3):
+        assert t.equal(arrs[region], arrs2[region])
+
+
 def test_pipelined_submit_matches_run(engine, oracle):
     """h2e_submit / h2e_wait: runs queued back to back into a ring of two output-buffer sets (the value chain of run
     k + 1 overlaps the expansion of run k; each run owns its workspace and instance table) give exactly the arrays of
