@@ -217,8 +217,10 @@ def main():
     if args.units is None:
         args.units = DEFAULT_UNITS[args.workload]
     if args.ring is None:
-        # MSM: two 110 GB buffer sets; pairing checks: their value chains are latency (a few dozen workgroups): 8 / 16 runs in flight
-        args.ring = {"msm": 2, "pairing_bn256": 8, "pairing_bls12_381": 16}[args.workload]
+        # MSM: two 110 GB buffer sets; pairing checks: three runs in flight - a run's value chain (one 1024-thread workgroup per
+        # check, VALU-bound on its CU) under the expansions of the other two; deeper rings only make the chains fight each other
+        # (64 x bn256: 3.7 ms / step at 3, 4.1 at 8; 16 x bls12-381: 2.4 at 3, 3.9 at 16)
+        args.ring = {"msm": 2, "pairing_bn256": 3, "pairing_bls12_381": 3}[args.workload]
     if args.job_tiles:
         args.digest = True
         args.steps = max(1, args.job_tiles // (args.units * max(1, args.gpus)))

@@ -31,4 +31,8 @@ for k in range(6):
         print(f"{names[k]:24s} rounds {buf[8 + k]:6d}  cycles {buf[k]:10d}  per round {buf[k] / buf[8 + k]:8.0f}  ({100.0 * buf[k] / tot:.1f} %)")
 print("total cycles", tot, "=", tot / 100e6 * 1e3, "ms at the 100 MHz s_memtime clock" if False else "")
 n_light = max(1, buf[8])
-print("light rounds, lane 0: header %.0f, record %.0f, op %.0f, barrier %.0f cycles per round" % tuple(buf[16 + k] / n_light for k in range(4)))
+print("(digits kernel, wave 0) light rounds: header %.0f, records %.0f, barrier %.0f cycles per round; product rounds: barrier %.0f" % (buf[16] / n_light, buf[17] / n_light, buf[18] / n_light, buf[19] / max(1, buf[10])))
+print("(lane kernels) light rounds, lane 0: header %.0f, record %.0f, op %.0f, barrier %.0f cycles per round" % tuple(buf[16 + k] / n_light for k in range(4)))
+if buf[20]:
+    print("(digits kernel, wave 0) a linear combination: digits in %.0f, columns %.0f, carry resolve %.0f, quotient estimate %.0f, q w and subtraction %.0f, conditional subtraction %.0f cycles (%d records)"
+          % tuple([buf[21 + k] / buf[20] for k in range(6)] + [buf[20]]))

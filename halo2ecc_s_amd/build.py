@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libh2e.so")
 DEPS = ["tape.h", "wide_int.h", "modinv62.h", "hbig.hpp", "recorder.hpp", "recorder_ecc.hpp", "recorder_pairing.hpp",
-        "pairing_constants.hpp", os.path.join("..", "..", "include", "h2e.h")]
+        "pairing_constants.hpp", "field_chain.hpp", os.path.join("..", "..", "include", "h2e.h")]
 
 
 def _stale(target, deps):

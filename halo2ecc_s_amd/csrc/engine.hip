@@ -2728,7 +2728,7 @@ __global__ void __launch_bounds__(128) h2e_field_chain(H2EPreKernel K, const u32
 #pragma unroll
                     for (int t = 0; t < H2E_F_MAX_TERMS; t++) {
                         u32 sl = terms[t] & 0xffffu;
-                        if ((u32)t < max_terms && sl != 0xffffu) {   // (t < max_terms is wave-uniform: whole term blocks are skipped)
+                        if ((u32)t < max_terms && (terms[t] >> 16) != 0u) {   // (t < max_terms is wave-uniform: whole term blocks are skipped; an unused term has coefficient 0)
                             int coef = (int)(int16_t)(terms[t] >> 16);
                             Wd<N> x = f_ld<FP>(fv, sl);
                             if (coef < 0) x = wd_sub<N>(w, x);   // -x = w - x (in (0, w]: the sum stays below 2^11 w)
@@ -2782,6 +2782,379 @@ __global__ void __launch_bounds__(128) h2e_field_chain(H2EPreKernel K, const u32
             g_wave_stamps[k] = fst_cyc[k];
             g_wave_stamps[8 + k] = fst_n[k];
         }
+#endif
+}
+// ------------------------------------------------------------------------------------------------
+// Digit-parallel field chain.  The lane-per-record kernel above is bound by its instruction count: one lane walks a whole
+// 256 / 384-bit value through its carry chains (~600 instructions per linear combination, ~700 per Montgomery product) while
+// a round rarely has more than 20 - 40 records, so most of the wave idles.  Here a record is a DPP row of 16 lanes and a lane
+// owns ONE 32-bit digit of the value: column sums are per-lane 64-bit multiply-adds with no carries at all, a carry chain
+// over the whole value is resolved wave-wide in a handful of instructions (generate mask from v_add_co, propagate mask from
+// a compare, the ripple itself is one scalar addition: ((P + (G << 1)) ^ P) is the mask of carry-ins), digits move between
+// lanes by DPP (row_shr / row_shl / row_newbcast) without touching LDS.  15 computing waves (60 records per pass) + the
+// loader wave; one s_barrier per round.
+//   linear combination: acc_j = beta_j + sum coef_t * x_t,j  with beta = the digits of a multiple of w that are all >= 2^44
+//     (H2EFieldConsts::lin_bias), so every column stays positive whatever the signs; one carry resolve, quotient estimate from
+//     the two top digits in double precision, q * w by one multiply-add per lane, one borrow resolve, two conditional
+//     subtractions of w.
+//   Montgomery product: digit-serial (one round per digit of a), the columns are kept as unnormalised 64-bit values between
+//     the rounds - T_j <- lo(Q_j+1) + hi(Q_j) + hi(P_j), P = a_i b_j + T_j, Q = m w_j + lo(P_j) - so the loop has no carry
+//     propagation either; one carry resolve and one conditional subtraction at the end.
+#define H2E_DPP_ROW_SHL1 0x101
+#define H2E_DPP_ROW_SHR1 0x111
+#define H2E_DPP_ROW_BCAST(n) (0x150 + (n))
+#define H2E_DP_WAVES 15u
+#define H2E_DP_GROUPS (H2E_DP_WAVES * 4u)
+template <int CTRL>
+WI_INLINE u32 dpp_mov(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
+WI_INLINE u32 sel_by_mask(u32 if0, u32 if1, u64 m) {
+    u32 r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(m));
+    return r;
+}
+template <int T, int NT, class F>
+WI_INLINE void static_for(F&& f) {
+    if constexpr (T < NT) {
+        f(std::integral_constant<int, T>());
+        static_for<T + 1, NT>(f);
+    }
+}
+template <int D>
+struct DigitRow {
+    u32 j;         // this lane's digit index within its row
+    u32 wj;        // digit j of w (0 above the top digit)
+    u64 digits;    // mask: lanes that hold a digit (j < D)
+    u64 pmask;     // mask: lanes a borrow may ripple through (j <= D)
+    // digits with the carry-out mask G of the addition that made them: the carries go in (never across a row: the lanes
+    // above the top digit hold zeros)
+    WI_INLINE static u32 carry(u32 d, u64 G) {
+        u64 P = __builtin_amdgcn_ballot_w64(d == 0xffffffffu);
+        u64 C = (P + (G << 1)) ^ P;
+        return addc_co32(d, 0u, C);
+    }
+    // sum_j (lo_j + 2^32 hi_j) 2^(32 j)  ->  digits (lane D takes what exceeds the D digits)
+    WI_INLINE static u32 normalize(u32 lo, u32 hi) {
+        u32 up = dpp_mov<H2E_DPP_ROW_SHR1>(hi);
+        u64 G;
+        u32 d = add_co32(lo, up, G);
+        return carry(d, G);
+    }
+    WI_INLINE u32 sub(u32 a, u32 b) const {   // a - b of two digit rows, a >= b
+        u64 G;
+        u32 u = sub_co32(a, b, G);
+        u64 P = __builtin_amdgcn_ballot_w64(u == 0u) & pmask;
+        u64 B = (P + (G << 1)) ^ P;
+        return subb_co32(u, 0u, B);
+    }
+    WI_INLINE u32 csub_w(u32 r) const {       // r >= w ? r - w : r
+        u64 G;
+        u32 u = sub_co32(r, wj, G);
+        u64 P = __builtin_amdgcn_ballot_w64(u == 0u) & pmask;
+        u64 B = (P + (G << 1)) ^ P;
+        u64 X = (B >> (D + 1)) & 0x0001000100010001ull;   // the borrow out of each row's number ...
+        u64 neg = (X << 16) - X;                          // ... spread over the row's lanes
+        u = subb_co32(u, 0u, B);
+        return sel_by_mask(u, r, neg);
+    }
+    // a b / R mod w for digit rows a, b (zero above the top digit), R = 2^(32 D).  Values live in [0, 2 w): R > 4 w for both
+    // base fields (R / w = 5.3 and 9.8), so a b < R w, the result (a b + m w) / R is below 2 w again and the chain never needs
+    // the canonical representative - h2e_field_finalize makes it from the stored hint values.
+    template <int I>
+    WI_INLINE void mont_step(u32 a, u32 b, u32 minv32, u64& T) const {   // digits i = I .. D - 1 of a
+        if constexpr (I < D) {
+            u32 ai = dpp_mov<H2E_DPP_ROW_BCAST(I)>(a);
+            u64 P = (u64)ai * b + T;
+            u32 m = dpp_mov<H2E_DPP_ROW_BCAST(0)>((u32)P * minv32);
+            u64 Q = (u64)m * wj + (u32)P;
+            u32 down = dpp_mov<H2E_DPP_ROW_SHL1>((u32)Q);
+            T = (u64)(u32)(P >> 32) + (u32)(Q >> 32) + down;
+            mont_step<I + 1>(a, b, minv32, T);
+        }
+    }
+    WI_INLINE u32 mont_mul(u32 a, u32 b, u32 minv32) const {
+        u64 T = 0;
+        mont_step<0>(a, b, minv32, T);
+        return normalize((u32)T, (u32)(T >> 32));
+    }
+};
+template <class FP>
+__global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, const u32* __restrict__ args, const u64* __restrict__ pool,
+                                                                const InstanceDesc* __restrict__ inst, u32 n_instances) {
+    constexpr int N = FP::WW, D = 2 * N;
+    static_assert(D + 2 <= 16, "a value and its overflow lanes fit one DPP row");
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const bool loader = wave == H2E_DP_WAVES;
+    const u32 instance = blockIdx.x;
+    InstanceDesc d = inst[instance];
+    const H2EFieldConsts* fc = &g_fc[FP::ID];
+    extern __shared__ ulonglong2 f_dyn[];
+    typedef u32 Rec[16];                                     // a record: 16 words
+    Rec* rbuf = (Rec*)f_dyn;                                // [2][H2E_WCHUNK]
+    u64* fv = (u64*)(rbuf + 2 * H2E_WCHUNK);                // [f_slots][N]
+    const Rec* recs = (const Rec*)(args + K.f_recs);
+    const u32 n_chunks = K.f_n_recs / H2E_WCHUNK;
+    auto header = [&](u32 pos, u32& cnt, u32& kind, u32& max_terms) {
+        const H2E_AS_LDS u32* hp = (const H2E_AS_LDS u32*)(rbuf + (size_t)((pos / H2E_WCHUNK) & 1u) * H2E_WCHUNK + pos % H2E_WCHUNK);
+        u32 meta = __builtin_amdgcn_readfirstlane(hp[0]);
+        max_terms = __builtin_amdgcn_readfirstlane(hp[1]);
+        cnt = meta & 0xffu;
+        kind = (meta >> 8) & 0xffu;
+    };
+    if (loader) {
+        // follows the round structure (every wave meets at one barrier per round) and keeps one chunk of records ahead: on
+        // entering chunk c - every wave has left chunk c - 1 - it loads chunk c + 1 over it, and waits for that data only
+        // in front of the barrier that ends chunk c's last round
+        auto load_chunk = [&](u32 chunk) {
+            const char* src = (const char*)(recs + (size_t)chunk * H2E_WCHUNK);
+            char* dst = (char*)(rbuf + (size_t)(chunk & 1u) * H2E_WCHUNK);
+#pragma unroll
+            for (u32 k = 0; k < H2E_WCHUNK * 64u / 1024u; k++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * 1024u + lane * 16u),
+                                                 (__attribute__((address_space(3))) void*)(dst + k * 1024u), 16, 0, 0);
+        };
+        load_chunk(0);
+        if (n_chunks > 1) load_chunk(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // (every wave looks at the header behind its round BEFORE the round's barrier - a padding header sends it to the next
+        // chunk there - so that after the last barrier of a chunk nobody reads that chunk's buffer again)
+        u32 pos = 0, cur = 0;
+        for (u32 round = 0; round < K.f_n_rounds; round++) {
+            u32 chunk = pos / H2E_WCHUNK;
+            if (chunk != cur) {
+                cur = chunk;
+                if (chunk + 1 < n_chunks) load_chunk(chunk + 1);
+            }
+            u32 cnt, kind, mt;
+            header(pos, cnt, kind, mt);
+            pos += 1 + cnt;
+            if (pos % H2E_WCHUNK != 0) {
+                u32 c2, k2, m2;
+                header(pos, c2, k2, m2);
+                if (k2 == 0xffu) pos = (chunk + 1) * H2E_WCHUNK;
+            }
+            if (pos / H2E_WCHUNK != chunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chunk's last round
+            lds_round_barrier_workgroup();
+        }
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    DigitRow<D> R;
+    R.j = lane & 15u;
+    const u32 j = R.j, row_base = lane & 48u;
+    const bool digit_lane = j < (u32)D;
+    const u32 jd = digit_lane ? j : 0u;
+    R.wj = digit_lane ? ((const H2E_AS_GLOBAL u32*)fc->w)[jd] : 0u;
+    const u32 r1j = digit_lane ? ((const H2E_AS_GLOBAL u32*)fc->w_r1)[jd] : 0u;
+    const u32 r2j = digit_lane ? ((const H2E_AS_GLOBAL u32*)fc->w_r2)[jd] : 0u;
+    const u64 beta = digit_lane ? ((const H2E_AS_GLOBAL u64*)fc->lin_bias)[jd] : 0ull;
+    const u32 minv32 = (u32)fc->w_minv;
+    const u32 ej = R.wj - (j == 0u ? 2u : 0u);   // digit j of w - 2 (w is odd and > 2: no borrow leaves digit 0)
+    // quotient estimate of a linear combination: (its top three digits) / (w's top two digits + 1) in double precision, the
+    // reciprocal slightly low on purpose - the estimate is then never above the quotient and at most one below it
+    const double w_top2 = (double)((const H2E_AS_GLOBAL u32*)fc->w)[D - 1] * 4294967296.0 + (double)((const H2E_AS_GLOBAL u32*)fc->w)[D - 2];
+    const double inv_top = (1.0 / (w_top2 + 2.0)) * (1.0 - 0x1p-48);
+    R.digits = __builtin_amdgcn_ballot_w64(digit_lane);
+    R.pmask = __builtin_amdgcn_ballot_w64(j <= (u32)D);
+    const u32 grp = wave * 4u + (lane >> 4);
+    const H2E_AS_LDS u32* fv32 = (const H2E_AS_LDS u32*)fv;
+    auto ld_digit = [&](u32 slot) -> u32 {       // digit j of a value slot (whatever lies behind it for the lanes above: masked by the caller)
+        return fv32[slot * (u32)D + j];
+    };
+    auto ld_value = [&](u32 slot) -> u32 { return sel_by_mask(0u, ld_digit(slot), R.digits); };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    u32 pos = 0, n_cnt = 0, n_kind = 0, n_mt = 0;
+    bool n_valid = false;
+    u32 n_rec = 0;   // this row's record of the next round: lane j holds word j (a word is broadcast over the row by DPP when it is used)
+#ifdef H2E_WAVE_STAMPS
+    unsigned long long fst_cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fst_n[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fst_part[4] = {0, 0, 0, 0};
+    unsigned long long dps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dpt = 0, dpn = 0;
+    // stage stamps of a linear combination (wave 0; `v` = the value the stage ends with, so that the stamp stays behind it)
+#define DP_STAMP(i, v)                                        \
+    do {                                                      \
+        asm volatile("" : "+v"(v));                           \
+        unsigned long long t_ = WAVE_STAMP();                 \
+        if ((i) > 0) dps[i] += t_ - dpt;                      \
+        else dpn++;                                           \
+        dpt = t_;                                             \
+    } while (0)
+#else
+#define DP_STAMP(i, v)
+#endif
+    auto run_round = [&](auto loads_tag) {
+        constexpr bool LOADS = decltype(loads_tag)::value;
+#ifdef H2E_WAVE_STAMPS
+        unsigned long long ft0 = WAVE_STAMP();
+#endif
+        u32 chunk = pos / H2E_WCHUNK;
+        u32 cnt = n_cnt, kind = n_kind, max_terms = n_mt;
+        const Rec* cbuf = rbuf + (size_t)(chunk & 1u) * H2E_WCHUNK;
+        auto rec_ptr = [&](u32 at) {   // record `at` of this chunk (a row beyond the round's records reads some record: unused)
+            return (const H2E_AS_LDS u32*)(cbuf + (at < H2E_WCHUNK ? at : H2E_WCHUNK - 1u));
+        };
+        u32 r0 = n_rec;
+        if (!n_valid) {   // the first round of a chunk
+            header(pos, cnt, kind, max_terms);
+            r0 = rec_ptr(pos % H2E_WCHUNK + 1u + grp)[j];
+        }
+        const u32 first = pos + 1;
+        pos += 1 + cnt;
+        // What lies behind this round is read now, before the round's barrier - the loader may overwrite this chunk's buffer
+        // after the barrier of the chunk's last round - and used after the round's work, so that these LDS round trips run
+        // under it: the next header (padding = on to the next chunk, whose first header is read after the barrier that its
+        // data is complete at) and this row's record of the next round.
+        const bool same_chunk = pos % H2E_WCHUNK != 0;
+        u32 ph0 = 0, ph1 = 0;
+        u32 pr = r0;
+        if (same_chunk) {
+            const H2E_AS_LDS u32* hp = rec_ptr(pos % H2E_WCHUNK);
+            ph0 = hp[0];
+            ph1 = hp[1];
+            pr = rec_ptr(pos % H2E_WCHUNK + 1u + grp)[j];
+        }
+#ifdef H2E_WAVE_STAMPS
+        unsigned long long ft1 = WAVE_STAMP();
+#endif
+        for (u32 op = grp; op < cnt; op += H2E_DP_GROUPS) {
+            u32 rw = r0;
+            if (op != grp) rw = rec_ptr(first % H2E_WCHUNK + op)[j];   // (a round of more than H2E_DP_GROUPS records: the host does not make them)
+            const u32 w0 = dpp_mov<H2E_DPP_ROW_BCAST(0)>(rw), hint = dpp_mov<H2E_DPP_ROW_BCAST(1)>(rw);
+            const u32 w2 = dpp_mov<H2E_DPP_ROW_BCAST(2)>(rw), w3 = dpp_mov<H2E_DPP_ROW_BCAST(3)>(rw), w4 = dpp_mov<H2E_DPP_ROW_BCAST(4)>(rw);
+            u32 opc = w0 & 0xffu, dst = w0 >> 16;
+            u32 out = 0;
+            bool raw = false;
+            if constexpr (LOADS) {   // values entering: inputs and pool constants
+                const u64* src = (opc == H2E_F_INPUT_W || opc == H2E_F_INPUT_FE) ? d.inputs + (size_t)w2 * K.n_params : pool + w2;
+                bool wide = opc == H2E_F_INPUT_W || opc == H2E_F_CONST_W;
+                u32 x = 0;
+                if (wide ? digit_lane : j < 2u) x = ((const H2E_AS_GLOBAL u32*)src)[j];
+                if (wide) out = R.mont_mul(x, r2j, minv32);
+                else {
+                    out = x;
+                    raw = true;
+                }
+            } else if (kind == 2) {           // Montgomery products
+                out = R.mont_mul(ld_value(w2), ld_value(w3), minv32);
+            } else if (kind == 0) {    // light: linear combinations, conditions, selections
+                if (opc == H2E_F_LIN) {
+                    u64 acc = beta;
+                    DP_STAMP(0, acc);
+                    // (an unused term has coefficient 0 and slot 0; all digits are read before the first is used: one LDS
+                    // round trip per record, not one per term)
+                    auto combine = [&](auto nt_tag) {
+                        constexpr int NT = decltype(nt_tag)::value;
+                        u32 x[NT];
+                        int coef[NT];
+                        static_for<0, NT>([&](auto tc) {
+                            constexpr int T = decltype(tc)::value;
+                            u32 term = dpp_mov<H2E_DPP_ROW_BCAST(2 + T)>(rw);
+                            x[T] = ld_digit(term & 0xffffu);
+                            coef[T] = (int)term >> 16;
+                        });
+                        DP_STAMP(1, x[NT - 1]);
+#pragma unroll
+                        for (int t = 0; t < NT; t++) {
+                            acc += (u64)(u32)coef[t] * x[t];                       // coef x + 2^32 x for a negative coef ...
+                            acc -= (u64)((u32)(coef[t] >> 31) & x[t]) << 32;      // ... corrected here
+                        }
+                    };
+                    // the term loop of this wave's longest combination (the host sorts a round's records by their length)
+                    const u32 nt = (w0 >> 8) & 0xffu;
+                    if (__builtin_amdgcn_ballot_w64(nt > 10u)) combine(std::integral_constant<int, H2E_F_MAX_TERMS_WIDE>());
+                    else if (__builtin_amdgcn_ballot_w64(nt > 6u)) combine(std::integral_constant<int, 10>());
+                    else if (__builtin_amdgcn_ballot_w64(nt > 2u)) combine(std::integral_constant<int, 6>());
+                    else combine(std::integral_constant<int, 2>());
+                    u32 lo = sel_by_mask(0u, (u32)acc, R.digits), hi = sel_by_mask(0u, (u32)(acc >> 32), R.digits);
+                    DP_STAMP(2, lo);
+                    u32 v = R.normalize(lo, hi);                             // < 2^15 w, the overflow digit in lane D
+                    DP_STAMP(3, v);
+                    u32 o = dpp_mov<H2E_DPP_ROW_BCAST(D)>(v), t1 = dpp_mov<H2E_DPP_ROW_BCAST(D - 1)>(v), t2 = dpp_mov<H2E_DPP_ROW_BCAST(D - 2)>(v);
+                    double top = ((double)o * 4294967296.0 + (double)t1) * 4294967296.0 + (double)t2;
+                    u32 qe = (u32)(top * inv_top);                           // quotient - 1 <= qe <= quotient
+                    DP_STAMP(4, qe);
+                    u64 qw = (u64)qe * R.wj;
+                    u32 r = R.sub(v, R.normalize((u32)qw, (u32)(qw >> 32)));
+                    DP_STAMP(5, r);
+                    out = r;                                                 // in [0, 2 w)
+                    DP_STAMP(6, out);
+                } else if (opc == H2E_F_ISZERO) {
+                    u32 x = ld_value(w2);                                    // in [0, 2 w): zero is 0 or w
+                    u64 nz = __builtin_amdgcn_ballot_w64(x != 0u), nw = __builtin_amdgcn_ballot_w64(x != R.wj);
+                    out = (j == 0u && (((u32)(nz >> row_base) & 0xffffu) == 0u || ((u32)(nw >> row_base) & 0xffffu) == 0u)) ? 1u : 0u;
+                    raw = true;
+                } else if (opc == H2E_F_NOT) {
+                    out = j == 0u ? 1u ^ (ld_digit(w2) & 1u) : 0u;
+                    raw = true;
+                } else if (opc == H2E_F_AND || opc == H2E_F_OR || opc == H2E_F_XNOR) {
+                    u32 a = ld_digit(w2) & 1u, b = ld_digit(w3) & 1u;
+                    u32 v = opc == H2E_F_AND ? (a & b) : opc == H2E_F_OR ? (a | b) : (1u ^ a ^ b);
+                    out = j == 0u ? v : 0u;
+                    raw = true;
+                } else if (opc == H2E_F_SELECT) {
+                    u32 cd = ld_digit(w2);
+                    u32 c0 = dpp_mov<H2E_DPP_ROW_BCAST(0)>(cd) | dpp_mov<H2E_DPP_ROW_BCAST(1)>(cd);
+                    u32 a = ld_value(w3);
+                    u32 b = (w4 & 0xffffu) != 0xffffu ? ld_value(w4 & 0xffffu) : 0u;
+                    out = c0 != 0u ? a : b;
+                }
+            } else {                   // division: a / b, 0 for b = 0 (integer_chip.rs:524-527): b^(w - 2) by square and multiply
+                u32 a = ld_value(w2), b = ld_value(w3);
+                u32 e = r1j;                                                  // 1 in Montgomery form
+                for (int bit = (int)FP::K - 1; bit >= 0; bit--) {             // (w - 2's digits sit in the lanes of every row: ej)
+                    e = R.mont_mul(e, e, minv32);
+                    u32 ew = (u32)__builtin_amdgcn_readlane((int)ej, bit >> 5);
+                    if ((ew >> ((u32)bit & 31u)) & 1u) e = R.mont_mul(e, b, minv32);
+                }
+                out = R.mont_mul(a, e, minv32);
+            }
+            if (dst != 0xffffu && digit_lane) ((H2E_AS_LDS u32*)fv)[dst * (u32)D + j] = out;
+            if (hint) {
+                // (conditions are raw 0 / 1: stored as the Montgomery form of that number, so that the finalize kernel's
+                // conversion of the whole slot range gives 0 / 1 back)
+                u32 hv = out;
+                if (raw) hv = (dpp_mov<H2E_DPP_ROW_BCAST(0)>(out) & 1u) ? r1j : 0u;
+                if (digit_lane) ((H2E_AS_GLOBAL u32*)(d.hints + (size_t)(hint - 1) * d.ws))[j] = hv;
+            }
+        }
+        n_valid = false;
+        if (same_chunk) {
+            u32 meta = __builtin_amdgcn_readfirstlane(ph0);
+            n_mt = __builtin_amdgcn_readfirstlane(ph1);
+            n_cnt = meta & 0xffu;
+            n_kind = (meta >> 8) & 0xffu;
+            if (n_kind == 0xffu) pos = (chunk + 1) * H2E_WCHUNK;
+            else n_valid = true;
+            n_rec = pr;
+        }
+#ifdef H2E_WAVE_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        unsigned long long ft2 = WAVE_STAMP();
+#endif
+        lds_round_barrier_workgroup();
+#ifdef H2E_WAVE_STAMPS
+        unsigned long long ft3 = WAVE_STAMP();
+        fst_cyc[kind & 7] += ft3 - ft0;
+        fst_n[kind & 7]++;
+        if (kind == 0) {
+            fst_part[0] += ft1 - ft0;
+            fst_part[1] += ft2 - ft1;
+            fst_part[2] += ft3 - ft2;
+        } else if (kind == 2) fst_part[3] += ft3 - ft2;
+#endif
+    };
+    for (u32 round = 0; round < K.f_n_load_rounds; round++) run_round(std::true_type());
+    for (u32 round = K.f_n_load_rounds; round < K.f_n_rounds; round++) run_round(std::false_type());
+#ifdef H2E_WAVE_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int k = 0; k < 8; k++) {
+            g_wave_stamps[k] = fst_cyc[k];
+            g_wave_stamps[8 + k] = fst_n[k];
+        }
+        for (int k = 0; k < 4; k++) g_wave_stamps[16 + k] = fst_part[k];
+        for (int k = 1; k < 7; k++) g_wave_stamps[20 + k] = dps[k];
+        g_wave_stamps[20] = dpn;
+    }
 #endif
 }
 // hint slots [first, first + n) of every instance: Montgomery form -> canonical value
@@ -3629,8 +4002,17 @@ extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2E
 #define H2E_PREDICT_FP(FP)                                                                                                          \
     if (k->kind == H2E_PRE_FIELD_CHAIN) {   /* params_dev carries the constant pool, n_params the words per input slot */          \
         if (phase & 1)                                                                                                              \
-            hipLaunchKernelGGL(h2e_field_chain<FP>, dim3(n_instances), dim3(128), (size_t)2 * H2E_WCHUNK * 32 + (size_t)k->f_slots * FP::WW * 8, \
-                               stream, *k, args_dev, (const u64*)params_dev, inst, n_instances);                                    \
+        {                                                                                                                           \
+            size_t lds = (size_t)2 * H2E_WCHUNK * (k->f_mode == 1 ? 64 : 32) + (size_t)k->f_slots * FP::WW * 8 + 64;                \
+            static const size_t lds_floor = getenv("H2E_FIELD_LDS") ? (size_t)atol(getenv("H2E_FIELD_LDS")) : 0;   /* experiment: the CU to itself */ \
+            if (lds < lds_floor) lds = lds_floor;                                                                                   \
+            if (k->f_mode == 1)                                                                                                     \
+                hipLaunchKernelGGL(h2e_field_chain_digits<FP>, dim3(n_instances), dim3((H2E_DP_WAVES + 1) * 64), lds, stream, *k, args_dev, \
+                                   (const u64*)params_dev, inst, n_instances);                                                     \
+            else                                                                                                                    \
+                hipLaunchKernelGGL(h2e_field_chain<FP>, dim3(n_instances), dim3(128), lds, stream, *k, args_dev,                    \
+                                   (const u64*)params_dev, inst, n_instances);                                                     \
+        }                                                                                                                           \
         if ((phase & 2) && k->hints_per_lane)                                                                                       \
             hipLaunchKernelGGL(h2e_field_finalize<FP>, dim3((n_instances * k->hints_per_lane + 63) / 64), block, 0, stream,         \
                                k->hint_base, k->hints_per_lane, inst, n_instances);                                                \

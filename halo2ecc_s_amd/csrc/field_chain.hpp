@@ -34,7 +34,8 @@
 namespace h2e {
 
 struct FieldChain {
-    std::vector<uint32_t> recs;     // 8 words per record, no round straddles an H2E_WCHUNK-record chunk
+    std::vector<uint32_t> recs;     // rec_words (8 or 16) words per record, no round straddles an H2E_WCHUNK-record chunk
+    uint32_t rec_words = 8;
     std::vector<uint32_t> rounds;   // per round: first record, count | kind << 8
     uint32_t n_slots = 0, n_load_rounds = 0;
     uint32_t n_nodes = 0, n_mul = 0, n_lin = 0;
@@ -52,6 +53,7 @@ struct FieldCompiler {
     uint32_t first[3], last[3];
     // further results the hint store wants in hint slots (conditions as raw 0 / 1, masked integers): op index -> slot
     const std::map<uint32_t, uint32_t>* aux = nullptr;
+    bool digit_rows = true;                            // for h2e_field_chain_digits: rounds of at most 60 records sorted by opcode, 16-word records
 
     struct Node {
         uint8_t opc = 0;
@@ -140,7 +142,7 @@ struct FieldCompiler {
         return n;
     }
 
-    int F_MAX_TERMS = getenv("H2E_FIELD_TERMS") ? atoi(getenv("H2E_FIELD_TERMS")) : 6;
+    int F_MAX_TERMS = 6;   // terms of a LIN record: its words less two (compile() sets it)
     static constexpr int F_MAX_COEF = 255;
     enum { F_NOP = 0, F_LIN, F_MUL, F_DIV, F_ISZERO, F_NOT, F_AND, F_OR, F_XNOR, F_SELECT, F_INPUT_W, F_INPUT_FE, F_CONST_W, F_CONST_FE };
 
@@ -200,6 +202,10 @@ struct FieldCompiler {
     // Which ops of the segment carry a hint the replay / expansion will ask for, and can all of them be predicted?
     // `check_only`: feasibility (before the compiler's dead-op pass), nothing is built.
     bool compile(FieldChain& out, bool check_only) {
+        const size_t RW = digit_rows ? 16 : 8;
+        out.rec_words = (uint32_t)RW;
+        F_MAX_TERMS = (int)RW - 2;
+        if (getenv("H2E_FIELD_TERMS")) F_MAX_TERMS = std::min(F_MAX_TERMS, atoi(getenv("H2E_FIELD_TERMS")));
         std::vector<uint8_t> needed(n_ops, 0);
         std::vector<uint32_t> stack;
         for (uint32_t i = 0; i < n_ops; i++) {
@@ -348,9 +354,6 @@ struct FieldCompiler {
                 }
             }
         }
-        // ---- alive nodes: what a hint-bearing node depends on --------------------------------------------------------
-        const size_t N = nodes.size();
-        std::vector<std::vector<uint32_t>> preds(N);
         auto deps_of = [&](const Node& nd, std::vector<uint32_t>& d) {
             d.clear();
             auto add = [&](int x) {
@@ -361,6 +364,53 @@ struct FieldCompiler {
             add(nd.c);
             for (auto& kv : nd.terms) add(kv.first);
         };
+        // ---- linear combinations of linear combinations ---------------------------------------------------------------
+        // A LIN node exists where some consumer needed the value in a slot (an operand of a product, a hint); a later
+        // combination that reads it pays a whole round for that.  Its terms are taken over instead - the deepest operands
+        // first, for as long as the result fits a record: the same residue, one level less on the path (the inner node stays
+        // for its other readers; recomputing is free here, rounds are not).
+        if (!getenv("H2E_FIELD_NO_INLINE")) {
+            std::vector<uint32_t> depth(nodes.size(), 0);
+            std::vector<uint32_t> dp;
+            for (size_t k = 0; k < nodes.size(); k++) {
+                Node& nd = nodes[k];
+                if (nd.opc == F_LIN) {
+                    for (int iter = 0; iter < 64; iter++) {
+                        uint32_t dm = 0;
+                        for (auto& t : nd.terms) dm = std::max(dm, depth[t.first]);
+                        if (dm <= 1) break;
+                        std::map<int, long long> acc;
+                        bool ok = true;
+                        for (auto& t : nd.terms) {
+                            if (depth[t.first] == dm) {
+                                const Node& in = nodes[t.first];
+                                if (in.opc != F_LIN) { ok = false; break; }
+                                for (auto& u : in.terms) acc[u.first] += (long long)t.second * u.second;
+                            } else {
+                                acc[t.first] += t.second;
+                            }
+                        }
+                        if (!ok) break;
+                        std::vector<std::pair<int, int>> r;
+                        for (auto& kv : acc) {
+                            if (kv.second == 0) continue;
+                            if (std::llabs(kv.second) > F_MAX_COEF) { ok = false; break; }
+                            r.push_back({kv.first, (int)kv.second});
+                        }
+                        if (!ok || (int)r.size() > F_MAX_TERMS) break;
+                        nd.terms = r;
+                    }
+                }
+                dp.clear();
+                deps_of(nd, dp);
+                uint32_t dd = 0;
+                for (uint32_t pp : dp) dd = std::max(dd, depth[pp]);
+                depth[k] = dd + 1;
+            }
+        }
+        // ---- alive nodes: what a hint-bearing node depends on --------------------------------------------------------
+        const size_t N = nodes.size();
+        std::vector<std::vector<uint32_t>> preds(N);
         std::vector<uint8_t> alive(N, 0);
         {
             std::vector<uint32_t> st, d;
@@ -395,7 +445,7 @@ struct FieldCompiler {
                 default: return 0;
             }
         };
-        const size_t STEP = 64;
+        const size_t STEP = digit_rows ? 60 : 64;
         std::vector<uint8_t> is_sink(N, 0), done(N, 0);
         std::vector<uint32_t> left(N, 0);
         size_t n_left = 0;
@@ -512,7 +562,7 @@ struct FieldCompiler {
         if (n_slots >= 0xfff0) { out.why = "too many value slots"; return false; }
         // ---- records -----------------------------------------------------------------------------------------------------
         auto pad_chunk = [&]() {
-            while ((out.recs.size() / 8) % H2E_WCHUNK) out.recs.insert(out.recs.end(), 8, 0u);
+            while ((out.recs.size() / RW) % H2E_WCHUNK) out.recs.insert(out.recs.end(), RW, 0u);
         };
         auto slot_of = [&](int node) -> uint32_t {
             if (node < 0) return 0xffffu;
@@ -526,27 +576,33 @@ struct FieldCompiler {
         size_t term_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (size_t r = 0; r < rounds.size(); r++) {
             auto& rd = rounds[r];
-            size_t at = out.recs.size() / 8;
+            // (a row of 16 lanes per record: the four records of a wave should be of one kind)
+            if (digit_rows)
+                std::stable_sort(rd.begin(), rd.end(), [&](uint32_t x, uint32_t y) {
+                    if (nodes[x].opc != nodes[y].opc) return nodes[x].opc < nodes[y].opc;
+                    return nodes[x].terms.size() < nodes[y].terms.size();   // (a wave runs its longest combination's term loop)
+                });
+            size_t at = out.recs.size() / RW;
             if (at % H2E_WCHUNK + 1 + rd.size() > H2E_WCHUNK) {
-                uint32_t padh[8] = {0xff00u, 0, 0, 0, 0, 0, 0, 0};
-                out.recs.insert(out.recs.end(), padh, padh + 8);
+                uint32_t padh[16] = {0xff00u};
+                out.recs.insert(out.recs.end(), padh, padh + RW);
                 pad_chunk();
             }
-            at = out.recs.size() / 8;
+            at = out.recs.size() / RW;
             out.rounds.push_back((uint32_t)at);
             out.rounds.push_back((uint32_t)rd.size() | ((uint32_t)rcls[r] << 8));
             {
                 uint32_t max_terms = 0;   // of the round's linear combinations (the kernel's term loop runs that far)
                 for (uint32_t k : rd)
                     if (nodes[k].opc == F_LIN) max_terms = std::max<uint32_t>(max_terms, (uint32_t)nodes[k].terms.size());
-                term_hist[std::min<uint32_t>(max_terms, 7)]++;
-                uint32_t hdr[8] = {(uint32_t)rd.size() | ((uint32_t)rcls[r] << 8), max_terms, 0, 0, 0, 0, 0, 0};
-                out.recs.insert(out.recs.end(), hdr, hdr + 8);
+                term_hist[std::min<uint32_t>(max_terms <= 6 ? max_terms : 7, 7)]++;
+                uint32_t hdr[16] = {(uint32_t)rd.size() | ((uint32_t)rcls[r] << 8), max_terms};
+                out.recs.insert(out.recs.end(), hdr, hdr + RW);
             }
             for (uint32_t k : rd) {
                 const Node& nd = nodes[k];
-                uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                w[0] = nd.opc | ((slot[k] >= 0 ? (uint32_t)slot[k] : 0xffffu) << 16);
+                uint32_t w[16] = {0};
+                w[0] = nd.opc | ((uint32_t)std::min<size_t>(nd.terms.size(), 255) << 8) | ((slot[k] >= 0 ? (uint32_t)slot[k] : 0xffffu) << 16);   // (bits 8-15: terms of a LIN)
                 w[1] = nd.hint == 0xffffffffu ? 0u : nd.hint + 1;
                 if (nd.hint != 0xffffffffu) {
                     out.hint_lo = std::min(out.hint_lo, nd.hint);
@@ -555,8 +611,8 @@ struct FieldCompiler {
                 switch (nd.opc) {
                     case F_LIN:
                         if ((int)nd.terms.size() > F_MAX_TERMS) throw std::runtime_error("field chain: LIN with too many terms");
-                        for (size_t t = 0; t < (size_t)6; t++)
-                            w[2 + t] = t < nd.terms.size() ? (slot_of(nd.terms[t].first) | ((uint32_t)(uint16_t)(int16_t)nd.terms[t].second << 16)) : 0xffffu;
+                        for (size_t t = 0; t + 2 < RW; t++)
+                            w[2 + t] = t < nd.terms.size() ? (slot_of(nd.terms[t].first) | ((uint32_t)(uint16_t)(int16_t)nd.terms[t].second << 16)) : 0u;   // unused: coefficient 0 (slot 0)
                         out.n_lin++;
                         break;
                     case F_MUL: case F_DIV: case F_AND: case F_OR: case F_XNOR:
@@ -572,19 +628,83 @@ struct FieldCompiler {
                         break;
                     default: w[2] = nd.imm; break;
                 }
-                out.recs.insert(out.recs.end(), w, w + 8);
+                out.recs.insert(out.recs.end(), w, w + RW);
             }
         }
         pad_chunk();
         if (getenv("H2E_FIELD_STATS")) {
+            {   // the dependency depth: what a schedule with mixed rounds could get down to
+                std::vector<uint32_t> depth(N, 0), depth_mul(N, 0);
+                uint32_t dmax = 0, dmul = 0;
+                for (size_t k = 0; k < N; k++) {
+                    if (!alive[k]) continue;
+                    uint32_t dd = 0, dm = 0;
+                    for (uint32_t pp : preds[k]) {
+                        dd = std::max(dd, depth[pp]);
+                        dm = std::max(dm, depth_mul[pp]);
+                    }
+                    depth[k] = dd + 1;
+                    depth_mul[k] = dm + (nodes[k].opc == F_MUL ? 1 : 0);
+                    dmax = std::max(dmax, depth[k]);
+                    dmul = std::max(dmul, depth_mul[k]);
+                }
+                fprintf(stderr, "field chain: dependency depth %u nodes (%u products on the deepest product path)\n", dmax, dmul);
+                if (getenv("H2E_FIELD_PATH")) {   // the deepest path, last node first: opcode / terms
+                    size_t at = 0;
+                    for (size_t k = 0; k < N; k++)
+                        if (alive[k] && depth[k] == dmax) at = k;
+                    std::string line;
+                    size_t hist[16] = {0};
+                    while (true) {
+                        hist[nodes[at].opc & 15]++;
+                        char b[32];
+                        snprintf(b, sizeof b, nodes[at].opc == F_LIN ? "L%zu " : "%c ", nodes[at].opc == F_LIN ? nodes[at].terms.size() : (size_t)"?LMDZNAOXS"[nodes[at].opc < 10 ? nodes[at].opc : 0]);
+                        line += b;
+                        size_t nxt = N;
+                        for (uint32_t pp : preds[at])
+                            if (depth[pp] + 1 == depth[at]) nxt = pp;
+                        if (nxt == N) break;
+                        at = nxt;
+                    }
+                    fprintf(stderr, "%s\n", line.substr(0, 6000).c_str());
+                    for (int q = 0; q < 14; q++) fprintf(stderr, "opc %d: %zu  ", q, hist[q]);
+                    fprintf(stderr, "\n");
+                }
+            }
+            {   // sinks: records that only feed a hint slot
+                size_t n_sink = 0, n_sink_lin = 0, n_sink_easy = 0, n_lin = 0, sink_terms = 0;
+                for (size_t k = 0; k < N; k++) {
+                    if (!alive[k]) continue;
+                    if (nodes[k].opc == F_LIN) n_lin++;
+                    if (!is_sink[k]) continue;
+                    n_sink++;
+                    if (nodes[k].opc != F_LIN) continue;
+                    n_sink_lin++;
+                    sink_terms += nodes[k].terms.size();
+                    bool easy = true;
+                    for (auto& t : nodes[k].terms) {
+                        const Node& in = nodes[t.first];
+                        if (!(in.hint != 0xffffffffu || in.opc == F_INPUT_W || in.opc == F_CONST_W)) easy = false;
+                    }
+                    n_sink_easy += easy;
+                }
+                size_t th[16] = {0};
+                for (size_t k = 0; k < N; k++)
+                    if (alive[k] && nodes[k].opc == F_LIN) th[std::min<size_t>(nodes[k].terms.size(), 15)]++;
+                fprintf(stderr, "field chain: linear combinations by terms:");
+                for (int q = 0; q < 16; q++) fprintf(stderr, " %zu", th[q]);
+                fprintf(stderr, "\n");
+                fprintf(stderr, "field chain: %zu linear combinations, %zu sinks (%zu linear combinations, %zu terms; %zu of them over hinted values / inputs only)\n", n_lin, n_sink,
+                        n_sink_lin, sink_terms, n_sink_easy);
+            }
             size_t cnt[4] = {0, 0, 0, 0}, ops_in[4] = {0, 0, 0, 0};
             for (size_t r = 0; r < rounds.size(); r++) {
                 cnt[rcls[r]]++;
                 ops_in[rcls[r]] += rounds[r].size();
             }
             fprintf(stderr, "field chain rounds: light %zu (%zu ops), loads %zu, products %zu (%zu ops), divisions %zu\n", cnt[0], ops_in[0], cnt[1], cnt[2], ops_in[2], cnt[3]);
-            fprintf(stderr, "   rounds by their longest linear combination (0 .. 6 terms): %zu %zu %zu %zu %zu %zu %zu\n", term_hist[0], term_hist[1], term_hist[2],
-                    term_hist[3], term_hist[4], term_hist[5], term_hist[6]);
+            fprintf(stderr, "   rounds by their longest linear combination (0 .. 6 terms, more): %zu %zu %zu %zu %zu %zu %zu, %zu\n", term_hist[0], term_hist[1],
+                    term_hist[2], term_hist[3], term_hist[4], term_hist[5], term_hist[6], term_hist[7]);
         }
         out.n_slots = (uint32_t)std::max(1, n_slots);
         out.n_nodes = 0;

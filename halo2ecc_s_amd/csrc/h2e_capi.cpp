@@ -277,6 +277,9 @@ struct h2e_program {
             }
             const CutSeg* cp = &c;
             fcmp.producer = [cp, &producer](uint32_t region, uint32_t row) { return producer(*cp, region, row); };
+            // H2E_FIELD_CHAIN=lanes: the one-lane-per-record kernel (A/B); default: a 16-lane row per record, 60 rows per pass
+            const char* fm = getenv("H2E_FIELD_CHAIN");
+            fcmp.digit_rows = !(fm && !strcmp(fm, "lanes"));
             return fcmp;
         };
         for (auto& sg : r.segments) {
@@ -484,15 +487,16 @@ struct h2e_program {
             pk.k.hint_base = chain.hint_hi > chain.hint_lo ? chain.hint_lo : 0;
             pk.k.hints_per_lane = chain.hint_hi > chain.hint_lo ? chain.hint_hi - chain.hint_lo : 0;
             pk.k.n_params = (uint32_t)r.fp.w_words;   // words per input slot
-            while (r.pre_args.size() % 8) r.pre_args.push_back(0);   // records are read 32 bytes at a time
+            while (r.pre_args.size() % 16) r.pre_args.push_back(0);   // records are read 16 bytes at a time from 64-byte aligned chunks
             pk.k.f_recs = (uint32_t)r.pre_args.size();
-            pk.k.f_n_recs = (uint32_t)(chain.recs.size() / 8);
+            pk.k.f_n_recs = (uint32_t)(chain.recs.size() / chain.rec_words);
             r.pre_args.insert(r.pre_args.end(), chain.recs.begin(), chain.recs.end());
             pk.k.f_rounds = (uint32_t)r.pre_args.size();
             pk.k.f_n_rounds = (uint32_t)(chain.rounds.size() / 2);
             r.pre_args.insert(r.pre_args.end(), chain.rounds.begin(), chain.rounds.end());
             pk.k.f_slots = chain.n_slots;
             pk.k.f_n_load_rounds = chain.n_load_rounds;
+            pk.k.f_mode = fcmp.digit_rows ? 1 : 0;
             pk.before_segment = (uint32_t)(c.sg - r.segments.data());
             pk.early_after_segment = -1;
             r.pre_kernels.push_back(pk);

@@ -153,6 +153,16 @@ struct FieldPair {
         fc.n_minv = minv(n.word(0));
         ((Rn * Rn) % n).to_words(fc.n_r2, 4);
         (Rn % n).to_words(fc.n_r1, 4);
+        {   // lin_bias (tape.h): digits 2^44 + delta_j of a multiple of w
+            HBig ones;
+            for (int j = 0; j < 2 * w_words; j++) ones = ones + HBig(1).shl(32 * j);
+            HBig base = ones.shl(44);
+            HBig delta = (w - (base % w)) % w;
+            uint64_t dw[H2E_W_WORDS_MAX];
+            delta.to_words(dw, H2E_W_WORDS_MAX);
+            for (int j = 0; j < 2 * w_words; j++)
+                fc.lin_bias[j] = ((uint64_t)1 << 44) + (uint32_t)(dw[j / 2] >> (32 * (j % 2)));
+        }
     }
 };
 

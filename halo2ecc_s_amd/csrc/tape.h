@@ -144,6 +144,10 @@ typedef struct H2EFieldConsts {
     uint64_t n_minv;                        // -n^-1 mod 2^64
     uint64_t n_r2[4];                       // R^2 mod n
     uint64_t n_r1[4];                       // R mod n
+    // digit-parallel field chain (engine.hip h2e_field_chain_digits): the 32-bit "digits" beta_j = 2^44 + delta_j of a multiple
+    // of w, delta = (-2^44 * sum_j 2^(32 j)) mod w - added to the columns of a signed linear combination they keep every
+    // column positive without changing the value mod w
+    uint64_t lin_bias[2 * H2E_W_WORDS_MAX];
 } H2EFieldConsts;
 
 struct H2EVRec;
@@ -275,11 +279,14 @@ typedef struct H2EPreKernel {
     // hint slots [hint_base, hint_base + hints_per_lane) are turned into canonical values by the finalize kernel
     uint32_t f_recs, f_n_recs, f_rounds, f_n_rounds, f_slots;
     uint32_t f_n_load_rounds;   // the first rounds: loads of inputs / constants (a loop of their own in the kernel)
+    uint32_t f_mode;            // 0 = one lane per record, records of 8 words (h2e_field_chain); 1 = one 16-lane row per record, records of
+                                // 16 words = up to 14 terms per linear combination (h2e_field_chain_digits)
 } H2EPreKernel;
 // field chain record opcodes (field_chain.hpp FieldCompiler::F_*)
 enum H2EFieldOp { H2E_F_NOP = 0, H2E_F_LIN, H2E_F_MUL, H2E_F_DIV, H2E_F_ISZERO, H2E_F_NOT, H2E_F_AND, H2E_F_OR, H2E_F_XNOR, H2E_F_SELECT,
                   H2E_F_INPUT_W, H2E_F_INPUT_FE, H2E_F_CONST_W, H2E_F_CONST_FE };
-#define H2E_F_MAX_TERMS 6
+#define H2E_F_MAX_TERMS 6        // 8-word records
+#define H2E_F_MAX_TERMS_WIDE 14   // 16-word records
 // The MSM chains are walked as scans (engine.hip "scan predictors"): a window's sum over its groups in H2E_WIN_CHUNKS
 // chunks (chunk sums -> offsets -> the real additions of every chunk in parallel), the tail's accumulation
 // acc <- 2 acc + line_w [- r2] in chunks of H2E_TAIL_CHUNK windows (local Horner sums B, the doubling chain D of the
