@@ -165,7 +165,10 @@ def run_children(args):
     base = [sys.executable, os.path.abspath(__file__), "--sub", "--suite", "main", "--traffic", "off", "--gpus", "1"]
     jobs = [("pairing_bn256", ["--workload", "pairing_bn256"]),
             ("pairing_bls12_381", ["--workload", "pairing_bls12_381"]),
-            ("msm_job_2e20", ["--workload", "msm", "--job-tiles", "1024", "--no-cpu-baseline"])]
+            ("msm_job_2e20", ["--workload", "msm", "--job-tiles", "1024", "--no-cpu-baseline"]),
+            # the headline batch all the way to what halo2 consumes: per-instance advice columns
+            ("msm_consumer_ready", ["--workload", "msm", "--ring", "1", "--steps", "3", "--warmup", "1", "--latency-steps", "0", "--consumer-ready", "3",
+                                    "--no-cpu-baseline"])]
     for name, extra in jobs:
         t0 = time.perf_counter()
         try:
@@ -206,6 +209,9 @@ def main():
     ap.add_argument("--child-timeout", type=int, default=900)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--sub", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--consumer-ready", type=int, default=0, metavar="K",
+                    help="after the timed region: K times (one batch through h2e_run, then h2e_export of its three advice arrays into halo2's per-instance "
+                         "column-major Montgomery-form arrays) -> consumer_ready_ms_per_step; needs a second copy of the arrays in HBM (use --ring 1)")
     ap.add_argument("--no-check", action="store_true", help="A/B experiments with deliberately broken arithmetic")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on GPUs; gloo only to exercise the N>1 path on one GPU")
     ap.add_argument("--device", type=int, default=None, help="override the CUDA device index (default: LOCAL_RANK)")
@@ -472,6 +478,26 @@ def main():
                 assert int(status.abs().max()) == 0
         single_ms = float(np.median(lat))
 
+    # consumer-ready output: the batch as halo2's advice columns (one array per instance, column-major, Montgomery-form cells)
+    consumer_ms = None
+    if args.consumer_ready > 0:
+        from halo2ecc_s_amd.engine import FORM_MONTGOMERY, LAYOUT_COLUMNS
+        base, rng, sel, status = bufs[0]
+        outs = [None, None, None]
+        lat = []
+        for i in range(args.consumer_ready + 1):   # (the first pass allocates the column arrays and is not counted)
+            status.zero_()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            eng.run(prog, batches[i % n_batches], base, rng, sel, status)
+            for region, arr in enumerate((base, rng, sel)):
+                outs[region] = eng.export(prog, region, arr, layout=LAYOUT_COLUMNS, form=FORM_MONTGOMERY, out=outs[region])
+            torch.cuda.synchronize()
+            if i > 0:
+                lat.append(1e3 * (time.perf_counter() - t1))
+        consumer_ms = float(np.median(lat))
+        del outs
+
     # per-launch times of every timed step (HIP events recorded by the engine on the launching streams)
     launch_ms = [ms for ms in launch_ms if len(ms) > dom]
     dom_n = eng.last_run_expansion_launches()[dom]
@@ -528,6 +554,7 @@ def main():
                    "pipeline": f"ring of {ring} output-buffer sets, steps submitted with h2e_submit" if ring > 1 else "h2e_run, one step after the other",
                    "sharding": f"units round-robin over {world} GPU(s); one all_gather of the job's per-unit records at the end of the timed region"},
         "single_batch_ms": single_ms,
+        "consumer_ready_ms_per_step": consumer_ms,
         "per_rank_ms_per_step": per_rank_ms,
         "whole_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                        "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -565,6 +592,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_points, msm_inputs)
     if also is not None:
         out["also"] = also
+        if out["consumer_ready_ms_per_step"] is None:   # measured by the child that has the memory for it (one buffer set + the column arrays)
+            out["consumer_ready_ms_per_step"] = also.get("msm_consumer_ready", {}).get("consumer_ready_ms_per_step")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

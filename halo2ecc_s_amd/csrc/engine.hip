@@ -1187,7 +1187,17 @@ __global__ void __launch_bounds__(64, H2E_X_WAVES) h2e_run_tape(H2ELaunch L, con
     // arrays), so the wave's loads and stores of a cell are contiguous
     u32 per_sub = n_instances * L.n_strands;
     u32 blocks_per_sub = (per_sub + 63) / 64;
-    u32 sub = blockIdx.x / blocks_per_sub, idx = (blockIdx.x % blocks_per_sub) * 64 + threadIdx.x;  // sub is wave-uniform
+    __shared__ TapeChunk chunk;
+    extern __shared__ u64 xcache_dyn[];   // [3][2 L + 4][64] words when the result cache is on (H2ELaunch.rel_refs bit 2)
+    __shared__ u64 dg_sums[12 * 64];      // stream digest: this lane's 3 x 4 sums, [region][word][lane]
+    if (L.rel_refs & 8) __builtin_amdgcn_s_setprio(3);   // the expansion's waves at the chain kernels' priority (g_tune[1] bit 1)
+    // One workgroup (= wave) per 64 lanes, or - a launch with fewer workgroups than that (persistent form, L.x_blocks = the
+    // real count) - every workgroup takes the blocks blockIdx.x, + gridDim.x, ...: the launch then holds a fixed share of every
+    // SIMD's registers for its whole duration and leaves the rest to the kernels of other streams (the next run's value chain),
+    // instead of refilling every slot a retiring wave frees before another queue gets a look at it.
+    const u32 n_blocks = VALUES_ONLY || L.x_blocks == 0 ? gridDim.x : L.x_blocks;
+    for (u32 blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    u32 sub = blk / blocks_per_sub, idx = (blk % blocks_per_sub) * 64 + threadIdx.x;  // sub is wave-uniform
     // padding lanes of the last wave replay the last valid lane's work but store nothing
     bool active = idx < per_sub;
     if (!active) idx = per_sub - 1;
@@ -1218,18 +1228,13 @@ __global__ void __launch_bounds__(64, H2E_X_WAVES) h2e_run_tape(H2ELaunch L, con
     c.ws = d.ws;
     c.hint_stride = L.hint_stride;
     c.hs = 2 * n_instances;
-    __shared__ TapeChunk chunk;
-    extern __shared__ u64 xcache_dyn[];   // [3][2 L + 4][64] words when the result cache is on (H2ELaunch.rel_refs bit 2)
     c.active = active;
     c.xc = (L.rel_refs & 4) ? xcache_dyn : nullptr;
-    // stream digest: this lane's 3 x 4 sums, [region][word][lane] in LDS
-    __shared__ u64 dg_sums[12 * 64];
     if (!VALUES_ONLY && L.dg_out != nullptr) {
 #pragma unroll
         for (int k = 0; k < 12; k++) l_st8(dg_sums + k * 64 + threadIdx.x, 0);
         c.dg = dg_sums + threadIdx.x;
     }
-    if (L.rel_refs & 8) __builtin_amdgcn_s_setprio(3);   // the expansion's waves at the chain kernels' priority (g_tune[1] bit 1)
     {
         for (u32 i0 = op_lo; i0 < op_hi; i0 += 64) {
             load_chunk(&chunk, L.tape, i0, op_hi);
@@ -1247,6 +1252,7 @@ __global__ void __launch_bounds__(64, H2E_X_WAVES) h2e_run_tape(H2ELaunch L, con
             u64 v = l_ld8(dg_sums + k * 64 + threadIdx.x);
             if (v) atomicAdd((unsigned long long*)(L.dg_out + ((size_t)(k / 4) * n_instances + instance) * 4 + (k % 4)), (unsigned long long)v);
         }
+    }
     }
 }
 
@@ -2259,7 +2265,8 @@ WI_INLINE void mac64(u64 a, u64 b, u64 c, u64& carry, u64& out) {  // out = low(
 // v_mad_u64_u32 into the low 64 bits plus one add-with-carry into the third word, and nothing else - the operand
 // scanning (CIOS) form the compiler was given before spent as many instructions again on zero-extending and
 // re-pairing its 32-bit carries (600 instructions per multiplication against 330; 78 -> 108 G multiplications/s on
-// the whole device, exp/mm_bench).  a, b < p < 2^(64 N - 2); result < p.
+// the whole device, exp/mm_bench).  a, b < p, p odd and below 2^(64 N) (the sum a b + m p may need bit 64 N: the third
+// accumulator word carries it into the final comparison); result < p.
 template <int N>
 WI_INLINE Wd<N> mont_mul(const Mont<N>& M, const Wd<N>& a, const Wd<N>& b) {
     constexpr int L32 = 2 * N;
@@ -3900,14 +3907,16 @@ extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances,
 // (95-135 KB of LDS each) of the next run from sharing CUs with the expansion: pipelined step 24.0 -> 20.9 ms.
 // [1] bit 1: the expansion's waves run at the chain kernels' priority (s_setprio 3) - the shared expansion stream is the
 // pipelined step's busiest resource: 16.17 -> 16.02 ms, window expansion 11.85 -> 11.4 ms; on by default.
-static int g_tune[3] = {0, 2, 0};
+// [4]: persistent expansion (experiment): big expansions are launched with this many workgroups per CU, each looping over its share
+// of the blocks (0 = one workgroup per block)
+static int g_tune[5] = {0, 2, 0, 0, 0};
 extern "C" long long H2E_UNIT(h2e_engine_scan_fallbacks)(void) {
     unsigned long long n = 0;
     if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_scan_fallbacks), sizeof(n)) != hipSuccess) return -1;
     return (long long)n;
 }
 extern "C" void H2E_UNIT(h2e_engine_set_tuning)(int key, int value) {
-    if (key >= 0 && key < 3) g_tune[key] = value;
+    if ((key >= 0 && key < 3) || key == 4) g_tune[key] = value;
     if (key == 3) {
         u32 m = (u32)value;
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_test), &m, sizeof(m));
@@ -3927,6 +3936,19 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
     H2ELaunch launch_x = *launch;
     if (xcache_on) launch_x.rel_refs |= 4u;
     if (g_tune[1] & 2) launch_x.rel_refs |= 8u;
+    dim3 grid_x = grid;
+    launch_x.x_blocks = 0;
+    if (g_tune[4] > 0 && grid.x > 16384) {
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+            if (n_cu <= 0) n_cu = 256;
+        }
+        launch_x.x_blocks = grid.x;
+        grid_x = dim3((u32)n_cu * (u32)g_tune[4]);
+    }
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
     if ((mode & 1) && launch->s_words) {                                                                                        \
         u32 lanes = launch->n_sops * n_instances;                                                                              \
@@ -3955,7 +3977,7 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
                            stream, *launch, inst, n_instances);                                                                \
     if ((mode & 1) && !launch->vtape) return -2;   /* a values-only replay always runs from the compiled V-tape */          \
     if (mode & 2)                                                                                                              \
-        hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid, block,                                                             \
+        hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid_x, block,                                                           \
                            (xcache_on ? (size_t)3 * (2 * FP::L + 4) * 64 * 8 : 0) + (grid.x > 4096 ? (size_t)g_tune[2] : 0),   \
                            stream, launch_x, inst, n_instances, fc_dev);
     switch (field_pair) {
@@ -4004,8 +4026,6 @@ extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2E
         if (phase & 1)                                                                                                              \
         {                                                                                                                           \
             size_t lds = (size_t)2 * H2E_WCHUNK * (k->f_mode == 1 ? 64 : 32) + (size_t)k->f_slots * FP::WW * 8 + 64;                \
-            static const size_t lds_floor = getenv("H2E_FIELD_LDS") ? (size_t)atol(getenv("H2E_FIELD_LDS")) : 0;   /* experiment: the CU to itself */ \
-            if (lds < lds_floor) lds = lds_floor;                                                                                   \
             if (k->f_mode == 1)                                                                                                     \
                 hipLaunchKernelGGL(h2e_field_chain_digits<FP>, dim3(n_instances), dim3((H2E_DP_WAVES + 1) * 64), lds, stream, *k, args_dev, \
                                    (const u64*)params_dev, inst, n_instances);                                                     \

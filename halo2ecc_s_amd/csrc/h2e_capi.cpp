@@ -1907,7 +1907,8 @@ struct JobSlot {
     size_t ws_hints_words = 0, ws_nd_words = 0, ws_jac_words = 0, ws_sel_words = 0;
     InstanceDescHost* d_inst = nullptr;
     uint32_t inst_cap = 0;
-    std::vector<InstanceDescHost> h_inst;
+    InstanceDescHost* h_inst = nullptr;   // pinned (hipHostMalloc): the upload below is a real asynchronous copy ...
+    hipEvent_t upload_ev = nullptr;       // ... and this event says when the host may rewrite the table
     std::vector<hipEvent_t> ev;       // profiling: 4 per launched segment (value-chain begin/end, expansion begin/end)
     std::vector<hipEvent_t> sync_ev;  // cross-stream dependencies
     hipEvent_t done = nullptr;        // recorded when every stream of the slot's last run has finished
@@ -1936,6 +1937,8 @@ struct JobSlot {
         (void)hipFree(ws_jac);
         (void)hipFree(ws_sel);
         (void)hipFree(d_inst);
+        if (h_inst) (void)hipHostFree(h_inst);
+        if (upload_ev) (void)hipEventDestroy(upload_ev);
     }
 };
 
@@ -2005,9 +2008,10 @@ int h2e_ctx_create(int device, h2e_ctx** out) {
     // tuning knobs are read once, here (nothing reads the environment while a run is being queued)
     if (const char* e1 = getenv("H2E_X_SPLIT")) c->x_split_pct = (uint32_t)std::max(0, std::min(100, atoi(e1)));
     if (const char* e2 = getenv("H2E_X_SPLIT_MIN_LANES")) c->x_split_min_lanes = (uint64_t)atoll(e2);
-    if (const char* e4 = getenv("H2E_TUNE")) {   // "reserve,xcache,xpad" (engine.hip g_tune)
-        int a = 0, b = 0, d = 0, t = 0;
-        sscanf(e4, "%d,%d,%d,%d", &a, &b, &d, &t);
+    if (const char* e4 = getenv("H2E_TUNE")) {   // "reserve,xcache,xpad,scan test mask,persistent workgroups per CU" (engine.hip g_tune)
+        int a = 0, b = 0, d = 0, t = 0, pw = 0;
+        sscanf(e4, "%d,%d,%d,%d,%d", &a, &b, &d, &t, &pw);
+        h2e_engine_set_tuning(4, pw);   // persistent expansion: workgroups per CU (experiment)
         h2e_engine_set_tuning(0, a);
         h2e_engine_set_tuning(1, b);
         h2e_engine_set_tuning(2, d);
@@ -2420,9 +2424,15 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             J.d_inst = nullptr;
         }
         HIP_TRY(hipMalloc((void**)&J.d_inst, (size_t)n_instances * sizeof(InstanceDescHost)));
+        if (J.h_inst) HIP_TRY(hipHostFree(J.h_inst));
+        J.h_inst = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&J.h_inst, (size_t)n_instances * sizeof(InstanceDescHost), hipHostMallocDefault));
         J.inst_cap = n_instances;
     }
-    J.h_inst.resize(n_instances);
+    // the table is uploaded from pinned memory by an asynchronous copy: the copy of the slot's previous run (ring depth
+    // submissions ago) must have read it before the host writes the new one - a host wait that never waits in a pipeline
+    if (!J.upload_ev) HIP_TRY(hipEventCreateWithFlags(&J.upload_ev, hipEventDisableTiming));
+    else HIP_TRY(hipEventSynchronize(J.upload_ev));
     size_t slot_words = r.fp.w_words;
     // workspace
     auto grow = [&](uint64_t** buf, size_t* have, size_t need) -> hipError_t {
@@ -2464,8 +2474,8 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         d.ws = (uint32_t)(n_instances * wsw);
         d.pad_ = 0;
     }
-    HIP_TRY(hipMemcpyAsync(J.d_inst, J.h_inst.data(), (size_t)n_instances * sizeof(InstanceDescHost),
-                           hipMemcpyHostToDevice, sa));
+    HIP_TRY(hipMemcpyAsync(J.d_inst, J.h_inst, (size_t)n_instances * sizeof(InstanceDescHost), hipMemcpyHostToDevice, sa));
+    HIP_TRY(hipEventRecord(J.upload_ev, sa));
     // stream digest: the expansion and fix-up kernels of this run add to it (every other stream starts behind this point)
     if (d_digests) HIP_TRY(hipMemsetAsync(d_digests, 0, (size_t)3 * n_instances * 4 * sizeof(uint64_t), sa));
     bool used_sd = false;

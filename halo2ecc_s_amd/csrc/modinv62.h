@@ -5,9 +5,12 @@
 // the binary extended Euclid this replaces (the dominant cost of every batched inversion in the value chain: inverse
 // fix-ups, hint finalisation).
 //
-// Values are signed, in limbs of 62 bits: x = sum v[i] 2^(62 i).  modinv62<N>(a, p) returns a^-1 mod p for an odd
-// modulus p < 2^(64 N - 2) and 0 <= a < p, and 0 for a = 0 (what Field::invert() -> None maps to in the reference:
-// base_chip.rs:301, integer_chip.rs:524-527).  Host-compilable (tests/test_modinv_cpu.py builds it with g++).
+// Values are signed, in NL = ceil(64 N / 62) limbs of 62 bits: x = sum v[i] 2^(62 i).  modinv62<N>(a, p) returns a^-1 mod p
+// for ANY odd modulus p < 2^(64 N) and 0 <= a < p, and 0 for a = 0 (what Field::invert() -> None maps to in the reference:
+// base_chip.rs:301, integer_chip.rs:524-527).  What the representation needs is room for the intermediate values, which stay
+// inside (-2 p, 2 p): 2 p < 2^(62 NL - 1), i.e. 64 N + 2 <= 62 NL - true for every N up to 15 and asserted in inv<N>() - so
+// the 255-bit bls12-381 Fr (above 2^254) is as good a modulus as the 254-bit bn256 fields.  Host-compilable
+// (tests/test_modinv_cpu.py builds it with g++).
 #pragma once
 #include <stdint.h>
 
@@ -164,6 +167,7 @@ MI_INLINE void from_s62(const S62<NL>& a, uint64_t* w) {   // a normalised: limb
 template <int N>
 MI_INLINE void inv(const uint64_t* a, const uint64_t* pw, uint64_t* out) {
     constexpr int NL = (64 * N + 61) / 62;
+    static_assert(64 * N + 2 <= 62 * NL, "the signed 62-bit limbs must hold every value in (-2 p, 2 p) for p < 2^(64 N)");
     // bound on the division steps for inputs below 2^(64 N): (49 d + 80) / 17 (Bernstein-Yang theorem 11.2), in batches of 62
     constexpr int MAX_BATCHES = ((49 * 64 * N + 80) / 17 + 61) / 62;
     S62<NL> p = to_s62<N, NL>(pw), f = p, g = to_s62<N, NL>(a), d, e;

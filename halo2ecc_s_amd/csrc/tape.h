@@ -176,6 +176,7 @@ typedef struct H2ELaunch {
     uint32_t n_vpieces;
     uint32_t v_int_slots, v_units; // LDS sizing of the replay kernel: integer slots and 16-byte staging units per lane
     uint32_t sel_stride;          // selection-buffer entries per strand (H2E_FLAG_PRESELECTED)
+    uint32_t x_blocks;            // expansion launched in its persistent form: the 64-lane blocks the launch's workgroups share (0: one each)
     // level-parallel replay (h2e_capi.cpp compile_replay): H2E_LEVEL_WAVES x 64 records per round; thread t of the
     // workgroup runs record 64 * H2E_LEVEL_WAVES * round + t; l_steps = rounds
     const struct H2EVRec* lrecs;
