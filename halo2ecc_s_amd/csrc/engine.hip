@@ -2628,7 +2628,7 @@ WI_INLINE void f_st(u64* fv, u32 slot, const Wd<FP::WW>& v) {
 #pragma unroll
     for (int i = 0; i < FP::WW / 2; i++) l_st16(p + 2 * i, v.v[2 * i], v.v[2 * i + 1]);
 }
-// A < 2^11 w  ->  A mod w: quotient estimate from the top 52 bits of w in double precision, then corrections
+// A < 2^12 w  ->  A mod w: quotient estimate from the top 52 bits of w in double precision, then corrections
 template <class FP>
 WI_INLINE Wd<FP::WW> f_reduce_small(const Wd<FP::WW + 1>& A, const Wd<FP::WW>& w, double inv_w_top) {
     constexpr int N = FP::WW, SH = FP::K - 52;
@@ -3175,6 +3175,33 @@ __global__ void __launch_bounds__(64) h2e_field_finalize(u32 first, u32 n, const
     Mont<N> M = mont_w<FP>(&g_fc[FP::ID]);
     u64* p = d.hints + (size_t)slot * d.ws;
     ws_store<N>(p, from_mont<N>(M, ws_load<N>(p)));
+}
+
+// hint-only linear combinations, after the chain and its finalize kernel (field_chain.hpp "hint-only combinations leave the
+// chain"): one lane per (combination, instance), terms = canonical values in hint slots / inputs / pool constants
+template <class FP>
+__global__ void __launch_bounds__(64) h2e_field_sinks(H2EPreKernel K, const u32* __restrict__ args, const u64* __restrict__ pool,
+                                                       const InstanceDesc* __restrict__ inst, u32 n_instances) {
+    constexpr int N = FP::WW;
+    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= K.f_n_sinks * n_instances) return;
+    u32 instance = gid % n_instances, sink = gid / n_instances;   // instance-minor like the workspace
+    InstanceDesc d = inst[instance];
+    Mont<N> M = mont_w<FP>(&g_fc[FP::ID]);
+    const Wd<N> w = M.p;
+    const double inv_w_top = 1.0 / (double)(wd_shr<1, FP::K - 52>(w).v[0] + 1);
+    const u32* rec = args + K.f_sink_words + args[K.f_sinks + sink];
+    const u32 nt = rec[1];
+    Wd<N + 1> acc = wd_zero<N + 1>();
+    for (u32 t = 0; t < nt; t++) {
+        u32 term = rec[2 + t];
+        int coef = (int)term >> 23;   // 9 bits, signed
+        u32 kind = (term >> 21) & 3u, index = term & 0x1fffffu;
+        Wd<N> x = kind == 0 ? ws_load<N>(d.hints + (size_t)index * d.ws) : kind == 1 ? g_load<N>(d.inputs + (size_t)index * K.n_params) : g_load<N>(pool + index);
+        if (coef < 0) x = wd_sub<N>(w, x);   // (in (0, w]: at most 14 x 255 terms, the sum stays below 2^12 w)
+        wd_mac_small<N>(acc, x, (u32)(coef < 0 ? -coef : coef));
+    }
+    ws_store<N>(d.hints + (size_t)rec[0] * d.ws, f_reduce_small<FP>(acc, w, inv_w_top));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4036,6 +4063,9 @@ extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2E
         if ((phase & 2) && k->hints_per_lane)                                                                                       \
             hipLaunchKernelGGL(h2e_field_finalize<FP>, dim3((n_instances * k->hints_per_lane + 63) / 64), block, 0, stream,         \
                                k->hint_base, k->hints_per_lane, inst, n_instances);                                                \
+        if ((phase & 2) && k->f_n_sinks)                                                                                            \
+            hipLaunchKernelGGL(h2e_field_sinks<FP>, dim3((n_instances * k->f_n_sinks + 63) / 64), block, 0, stream, *k, args_dev,    \
+                               (const u64*)params_dev, inst, n_instances);                                                         \
         break;                                                                                                                      \
     }                                                                                                                               \
     if (k->kind == H2E_PRE_MSM_SELECT) {                                                                                            \

@@ -40,6 +40,9 @@ struct FieldChain {
     uint32_t n_slots = 0, n_load_rounds = 0;
     uint32_t n_nodes = 0, n_mul = 0, n_lin = 0;
     uint32_t hint_lo = 0xffffffffu, hint_hi = 0;   // hint slots written: [hint_lo, hint_hi)
+    // hint-only linear combinations computed outside the chain (h2e_field_sinks): per sink its first word in sink_words;
+    // a sink = hint slot, terms, then per term (coef & 0x1ff) << 23 | kind << 21 | index  (kind 0 hint slot, 1 input slot, 2 pool word)
+    std::vector<uint32_t> sink_offsets, sink_words;
     std::string why;                // why a segment is not eligible
 };
 
@@ -53,6 +56,7 @@ struct FieldCompiler {
     uint32_t first[3], last[3];
     // further results the hint store wants in hint slots (conditions as raw 0 / 1, masked integers): op index -> slot
     const std::map<uint32_t, uint32_t>* aux = nullptr;
+    uint32_t* next_hint = nullptr;                     // further hint slots may be taken from here (values the sinks kernel reads)
     bool digit_rows = true;                            // for h2e_field_chain_digits: rounds of at most 60 records sorted by opcode, 16-word records
 
     struct Node {
@@ -408,6 +412,63 @@ struct FieldCompiler {
                 depth[k] = dd + 1;
             }
         }
+        // ---- hint-only combinations leave the chain -------------------------------------------------------------------
+        // A quarter of the linear combinations feed nothing but their own hint slot (the reduce of a value nobody multiplies
+        // again).  The chain is bound by its CU's instruction issue, and these are not on any path: they are computed after it
+        // by a kernel of their own, one lane per (combination, instance), from the *finalized* values of their terms - the
+        // combination is linear, so it holds for the canonical values as well as for the Montgomery residues.  A term that
+        // has no hint slot of its own gets one (a store in the chain instead of a record).
+        if (digit_rows && next_hint && !getenv("H2E_FIELD_NO_SINKS")) {
+            std::vector<uint8_t> live(nodes.size(), 0), read(nodes.size(), 0);
+            std::vector<uint32_t> st, dd;
+            for (size_t k = 0; k < nodes.size(); k++)
+                if (nodes[k].hint != 0xffffffffu) {
+                    live[k] = 1;
+                    st.push_back((uint32_t)k);
+                }
+            while (!st.empty()) {
+                uint32_t k = st.back();
+                st.pop_back();
+                deps_of(nodes[k], dd);
+                for (uint32_t x : dd) {
+                    read[x] = 1;
+                    if (!live[x]) {
+                        live[x] = 1;
+                        st.push_back(x);
+                    }
+                }
+            }
+            for (size_t k = 0; k < nodes.size(); k++) {
+                Node& nd = nodes[k];
+                if (!live[k] || read[k] || nd.opc != F_LIN || nd.hint == 0xffffffffu) continue;
+                bool ok = nd.terms.size() <= 255;
+                for (auto& t : nd.terms) {
+                    const Node& in = nodes[t.first];
+                    bool value_node = in.opc == F_LIN || in.opc == F_MUL || in.opc == F_DIV || in.opc == F_SELECT || in.opc == F_INPUT_W || in.opc == F_CONST_W;
+                    if (!value_node || std::abs(t.second) > 255) ok = false;
+                    if ((in.opc == F_INPUT_W || in.opc == F_CONST_W) && in.imm >= (1u << 21)) ok = false;
+                }
+                if (!ok) continue;
+                out.sink_offsets.push_back((uint32_t)out.sink_words.size());
+                out.sink_words.push_back(nd.hint);
+                out.sink_words.push_back((uint32_t)nd.terms.size());
+                for (auto& t : nd.terms) {
+                    Node& in = nodes[t.first];
+                    uint32_t kind, index;
+                    if (in.opc == F_INPUT_W || in.opc == F_CONST_W) {
+                        kind = in.opc == F_INPUT_W ? 1u : 2u;
+                        index = in.imm;
+                    } else {
+                        if (in.hint == 0xffffffffu) in.hint = (*next_hint)++;
+                        kind = 0;
+                        index = in.hint;
+                        if (index >= (1u << 21)) throw std::runtime_error("field chain: hint slot index beyond the sink records' 21 bits");
+                    }
+                    out.sink_words.push_back(((uint32_t)t.second & 0x1ffu) << 23 | kind << 21 | index);
+                }
+                nd.hint = 0xffffffffu;   // no longer a root: the node (and what only it needed) drops out of the chain
+            }
+        }
         // ---- alive nodes: what a hint-bearing node depends on --------------------------------------------------------
         const size_t N = nodes.size();
         std::vector<std::vector<uint32_t>> preds(N);
@@ -658,7 +719,8 @@ struct FieldCompiler {
                     while (true) {
                         hist[nodes[at].opc & 15]++;
                         char b[32];
-                        snprintf(b, sizeof b, nodes[at].opc == F_LIN ? "L%zu " : "%c ", nodes[at].opc == F_LIN ? nodes[at].terms.size() : (size_t)"?LMDZNAOXS"[nodes[at].opc < 10 ? nodes[at].opc : 0]);
+                        if (nodes[at].opc == F_LIN) snprintf(b, sizeof b, "L%zu ", nodes[at].terms.size());
+                        else snprintf(b, sizeof b, "%c ", "?LMDZNAOXS"[nodes[at].opc < 10 ? nodes[at].opc : 0]);
                         line += b;
                         size_t nxt = N;
                         for (uint32_t pp : preds[at])

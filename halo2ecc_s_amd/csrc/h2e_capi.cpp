@@ -478,8 +478,11 @@ struct h2e_program {
                             hs.offsets.size(), hs.words.size(), hs.ktab.size() / (2 * (size_t)r.fp.limbs + 4), hs.n_terms_max, hs.aux_hint.size());
             }
             fcmp.aux = &hs.aux_hint;
+            uint32_t next_hint = r.n_hint_slots;
+            fcmp.next_hint = &next_hint;
             h2e::FieldChain chain;
             if (!fcmp.compile(chain, false)) throw std::runtime_error("field chain: " + chain.why);
+            r.n_hint_slots = next_hint;
             h2e::PreKernel pk;
             std::memset(&pk.k, 0, sizeof(pk.k));
             pk.k.kind = H2E_PRE_FIELD_CHAIN;
@@ -497,6 +500,11 @@ struct h2e_program {
             pk.k.f_slots = chain.n_slots;
             pk.k.f_n_load_rounds = chain.n_load_rounds;
             pk.k.f_mode = fcmp.digit_rows ? 1 : 0;
+            pk.k.f_sinks = (uint32_t)r.pre_args.size();
+            r.pre_args.insert(r.pre_args.end(), chain.sink_offsets.begin(), chain.sink_offsets.end());
+            pk.k.f_sink_words = (uint32_t)r.pre_args.size();
+            r.pre_args.insert(r.pre_args.end(), chain.sink_words.begin(), chain.sink_words.end());
+            pk.k.f_n_sinks = (uint32_t)chain.sink_offsets.size();
             pk.before_segment = (uint32_t)(c.sg - r.segments.data());
             pk.early_after_segment = -1;
             r.pre_kernels.push_back(pk);
@@ -3224,7 +3232,7 @@ struct h2e_records {
 
 namespace {
 const int FIXC[3] = {9, 2, 2}, ADVC[3] = {5, 3, 2};
-h2e::AssignedInteger to_int(const h2e_int& a) {
+static h2e::AssignedInteger to_int(const h2e_int& a) {
     h2e::AssignedInteger r;
     for (int i = 0; i < H2E_MAX_L; i++) r.limbs_le[i] = a.limbs[i];
     r.native = a.native;
@@ -3238,7 +3246,7 @@ h2e_int from_int(const h2e::AssignedInteger& a) {
     r.times = (uint32_t)a.times;
     return r;
 }
-h2e::AssignedPoint to_point(const h2e_point& p) { return h2e::AssignedPoint{to_int(p.x), to_int(p.y), h2e::AssignedCondition{h2e::AssignedValue{p.z}}}; }
+static h2e::AssignedPoint to_point(const h2e_point& p) { return h2e::AssignedPoint{to_int(p.x), to_int(p.y), h2e::AssignedCondition{h2e::AssignedValue{p.z}}}; }
 h2e_point from_point(const h2e::AssignedPoint& p) {
     h2e_point r;
     r.x = from_int(p.x);
@@ -3254,7 +3262,7 @@ struct OpOut {
     void* ptr;
     size_t bytes;
 };
-std::string key_of(const char* name, std::initializer_list<std::pair<const void*, size_t>> blobs) {
+static std::string key_of(const char* name, std::initializer_list<std::pair<const void*, size_t>> blobs) {
     std::string k(name);
     for (auto& b : blobs) {
         k.push_back('|');
@@ -3565,9 +3573,9 @@ int h2e_op_bisec_int(h2e_records* R, uint32_t cond_cell, const h2e_int* a, const
     });
 }
 namespace {
-h2e::AssignedFq2 to_fq2(const h2e_int* a) { return h2e::AssignedFq2{to_int(a[0]), to_int(a[1])}; }
-h2e::AssignedFq6 to_fq6(const h2e_int* a) { return h2e::AssignedFq6{to_fq2(a), to_fq2(a + 2), to_fq2(a + 4)}; }
-h2e::AssignedFq12 to_fq12(const h2e_int* a) { return h2e::AssignedFq12{to_fq6(a), to_fq6(a + 6)}; }
+static h2e::AssignedFq2 to_fq2(const h2e_int* a) { return h2e::AssignedFq2{to_int(a[0]), to_int(a[1])}; }
+static h2e::AssignedFq6 to_fq6(const h2e_int* a) { return h2e::AssignedFq6{to_fq2(a), to_fq2(a + 2), to_fq2(a + 4)}; }
+static h2e::AssignedFq12 to_fq12(const h2e_int* a) { return h2e::AssignedFq12{to_fq6(a), to_fq6(a + 6)}; }
 void from_fq2(const h2e::AssignedFq2& x, h2e_int* o) {
     o[0] = from_int(x.c0);
     o[1] = from_int(x.c1);
@@ -3581,7 +3589,7 @@ void from_fq12(const h2e::AssignedFq12& x, h2e_int* o) {
     from_fq6(x.c0, o);
     from_fq6(x.c1, o + 6);
 }
-std::unique_ptr<h2e::PairingOps> tower_of(h2e::Recorder& r) {
+static std::unique_ptr<h2e::PairingOps> tower_of(h2e::Recorder& r) {
     if (r.fp.id == H2E_FIELD_BN256_FQ) return std::unique_ptr<h2e::PairingOps>(new h2e::Bn256PairingOps(r));
     if (r.fp.id == H2E_FIELD_BLS12_381_FQ) return std::unique_ptr<h2e::PairingOps>(new h2e::Bls12381PairingOps(r));
     throw std::runtime_error("no extension tower over this field");
@@ -3686,7 +3694,7 @@ int h2e_op_ecc_assert_equal(h2e_records* R, const h2e_point* a, const h2e_point*
 }
 // ---- the complete-addition / curvature surface of EccChipBaseOps ----
 namespace {
-h2e::AssignedPointWithCurvature to_pc(const h2e_point_c& a) {
+static h2e::AssignedPointWithCurvature to_pc(const h2e_point_c& a) {
     return h2e::AssignedPointWithCurvature{to_int(a.p.x), to_int(a.p.y), h2e::AssignedCondition{h2e::AssignedValue{a.p.z}},
                                            h2e::AssignedCurvature{to_int(a.cv), h2e::AssignedCondition{h2e::AssignedValue{a.cz}}}};
 }

@@ -280,6 +280,8 @@ typedef struct H2EPreKernel {
     // hint slots [hint_base, hint_base + hints_per_lane) are turned into canonical values by the finalize kernel
     uint32_t f_recs, f_n_recs, f_rounds, f_n_rounds, f_slots;
     uint32_t f_n_load_rounds;   // the first rounds: loads of inputs / constants (a loop of their own in the kernel)
+    uint32_t f_sinks, f_sink_words, f_n_sinks;   // hint-only linear combinations computed after the chain (h2e_field_sinks): word index of the
+                                                 // per-sink offsets / of the sink records in the args array (field_chain.hpp FieldChain), count
     uint32_t f_mode;            // 0 = one lane per record, records of 8 words (h2e_field_chain); 1 = one 16-lane row per record, records of
                                 // 16 words = up to 14 terms per linear combination (h2e_field_chain_digits)
 } H2EPreKernel;
