@@ -51,6 +51,7 @@ struct FieldCompiler {
     uint32_t n_ops;
     int L;
     int pw_check_limbs;
+    int w_words = 4;                                   // 64-bit words of a W value (a value slot)
     std::function<int(uint32_t, uint32_t)> producer;   // (region, row) -> op index of this segment or -1
     uint32_t rel;                                      // 1: the segment's own cells are strand-relative refs
     uint32_t first[3], last[3];
@@ -621,6 +622,11 @@ struct FieldCompiler {
             }
         }
         if (n_slots >= 0xfff0) { out.why = "too many value slots"; return false; }
+        // the kernels keep two record chunks and every value slot in LDS (160 KB per workgroup on gfx950)
+        if ((size_t)2 * H2E_WCHUNK * RW * 4 + (size_t)n_slots * w_words * 8 + 64 > (size_t)160 * 1024) {
+            out.why = "the value slots (" + std::to_string(n_slots) + ") do not fit the LDS";
+            return false;
+        }
         // ---- records -----------------------------------------------------------------------------------------------------
         auto pad_chunk = [&]() {
             while ((out.recs.size() / RW) % H2E_WCHUNK) out.recs.insert(out.recs.end(), RW, 0u);
@@ -765,6 +771,8 @@ struct FieldCompiler {
                 ops_in[rcls[r]] += rounds[r].size();
             }
             fprintf(stderr, "field chain rounds: light %zu (%zu ops), loads %zu, products %zu (%zu ops), divisions %zu\n", cnt[0], ops_in[0], cnt[1], cnt[2], ops_in[2], cnt[3]);
+            fprintf(stderr, "   %d value slots = %zu KB of LDS next to %zu KB of record chunks; %zu hint-only combinations computed after the chain\n", n_slots,
+                    (size_t)n_slots * w_words * 8 / 1024, (size_t)2 * H2E_WCHUNK * RW * 4 / 1024, out.sink_offsets.size());
             fprintf(stderr, "   rounds by their longest linear combination (0 .. 6 terms, more): %zu %zu %zu %zu %zu %zu %zu, %zu\n", term_hist[0], term_hist[1],
                     term_hist[2], term_hist[3], term_hist[4], term_hist[5], term_hist[6], term_hist[7]);
         }

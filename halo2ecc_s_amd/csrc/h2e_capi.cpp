@@ -270,6 +270,7 @@ struct h2e_program {
             fcmp.n_ops = c.n_ops;
             fcmp.L = r.fp.limbs;
             fcmp.pw_check_limbs = r.fp.pure_w_check_limbs;
+            fcmp.w_words = r.fp.w_words;
             fcmp.rel = c.sg->is_fork ? 1 : 0;
             for (int reg = 0; reg < 3; reg++) {
                 fcmp.first[reg] = c.first[reg];

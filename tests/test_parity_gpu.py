@@ -379,6 +379,35 @@ def test_pairing_check_bn256(engine, oracle):
     compare_advice(prog, orun, base, rng, sel, instance=1)
 
 
+@pytest.mark.parametrize("curve", ["bn256", "bls12_381"])
+@pytest.mark.parametrize("knob", [("H2E_FIELD_CHAIN", "lanes"), ("H2E_NO_FIELD_CHAIN", "1"), ("H2E_FIELD_NO_SINKS", "1"), ("H2E_FIELD_NO_INLINE", "1")],
+                         ids=["lane_kernel", "level_parallel_replay", "sinks_in_chain", "no_inlining"])
+def test_pairing_value_chain_variants(engine, oracle, curve, knob):
+    """The pairing checks' value chain has a default form (field-domain program, digit-parallel kernel, hint-only combinations
+    computed after the chain, combinations inlined) and fall-backs a program is compiled to when a knob says so or the
+    field-domain compiler meets an op outside its vocabulary: the lane-per-record kernel, the level-parallel replay of the
+    integer-chip ops, the chain with its sinks inside, the chain without inlining.  Every form must give the same cells.
+    (The knobs are read when the program is recorded.)"""
+    import os
+    name, value = knob
+    make_inputs = synth.pairing_check_bn256_inputs if curve == "bn256" else synth.pairing_check_bls12_381_inputs
+    ins = [make_inputs(instance=40 + k) for k in range(3)]
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        prog = Program.pairing_check_bn256(emit_shape=False) if curve == "bn256" else Program.pairing_check_bls12_381(emit_shape=False)
+    finally:
+        if old is None:
+            del os.environ[name]
+        else:
+            os.environ[name] = old
+    base, rng, sel, status = _run(engine, prog, ins)
+    assert (status == 0).all(), status
+    orun = (oracle_lib.run_pairing_check_bn256 if curve == "bn256" else oracle_lib.run_pairing_check_bls12_381)(ins[2])
+    assert orun.info.status == 0, orun.error
+    compare_advice(prog, orun, base, rng, sel, instance=2)
+
+
 def test_pairing_check_bls12_381(engine, oracle):
     """config 5 unit: check_pairing([(ac,b),(-a,bc)]) over the 4-limb bls12_381 Fq — 7.95M cells, bit-exact"""
     ins = [synth.pairing_check_bls12_381_inputs(instance=k) for k in range(2)]

@@ -57,6 +57,26 @@ def test_msm_tile_no_select_shape(oracle, h2e_built, n):
     compare_shape(prog, orun)
 
 
+@pytest.mark.parametrize("knob", [("H2E_FIELD_CHAIN", "lanes"), ("H2E_NO_FIELD_CHAIN", "1"), ("H2E_FIELD_NO_SINKS", "1"), ("H2E_FIELD_NO_INLINE", "1")],
+                         ids=["lane_kernel", "level_parallel_replay", "sinks_in_chain", "no_inlining"])
+def test_pairing_value_chain_variants_compile(h2e_built, knob):
+    """every form of the pairing checks' value chain (tests/test_parity_gpu.py::test_pairing_value_chain_variants runs them) compiles on
+    the host, for the same rows: the knobs only choose how the hints are computed"""
+    import os
+    ref = Program.pairing_check_bn256(emit_shape=False)
+    name, value = knob
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        prog = Program.pairing_check_bn256(emit_shape=False)
+    finally:
+        if old is None:
+            del os.environ[name]
+        else:
+            os.environ[name] = old
+    assert (prog.base_offset, prog.range_offset, prog.select_offset, prog.n_advice_cells) == (ref.base_offset, ref.range_offset, ref.select_offset, ref.n_advice_cells)
+
+
 def test_pairing_check_bn256_shape(oracle, h2e_built):
     """config 4 unit (2-pair bn256 check_pairing, G2 as per-instance constants -> fixed patches)"""
     inputs = synth.pairing_check_bn256_inputs()
