@@ -3043,8 +3043,11 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                 }
             } else if (kind == 2) {           // Montgomery products
                 out = R.mont_mul(ld_value(w2), ld_value(w3), minv32);
-            } else if (kind == 0) {    // light: linear combinations, conditions, selections
-                if (opc == H2E_F_LIN) {
+            } else if (kind == 0) {    // linear combinations, conditions, selections - and products (mixed rounds: the host gives every
+                                       // kind its own waves)
+                if (opc == H2E_F_MUL) {
+                    out = R.mont_mul(ld_value(w2), ld_value(w3), minv32);
+                } else if (opc == H2E_F_LIN) {
                     u64 acc = beta;
                     DP_STAMP(0, acc);
                     // (an unused term has coefficient 0 and slot 0; all digits are read before the first is used: one LDS

@@ -499,15 +499,21 @@ struct FieldCompiler {
             for (uint32_t x : preds[k]) succs[x].push_back((uint32_t)k);
         }
         // ---- rounds: backwards, cheapest class first (see schedule_classes in h2e_capi.cpp), 64 records per round ---------
+        // Digit rows: a record is a row of some wave and rows do not wait for each other inside a round, so a round may mix
+        // products with light records - what matters is that the four rows of a WAVE are of one kind (a wave executes every kind
+        // its rows hold, one after the other).  Rounds are therefore scheduled by dependency alone (their number drops from
+        // class-pure 2 808 to 2 06x for bn256, the dependency depth being 1 950) and the emission below pads each kind to a
+        // multiple of four rows; 54 records leave room for the padding in a pass of 60 rows.
+        const bool mixed_rounds = digit_rows && !getenv("H2E_FIELD_PURE_ROUNDS");
+        const size_t STEP = digit_rows ? (mixed_rounds ? 54 : 60) : 64;
         auto cls_of = [&](uint32_t k) -> int {   // 0 light, 1 loads, 2 products, 3 divisions
             switch (nodes[k].opc) {
-                case F_MUL: return 2;
+                case F_MUL: return mixed_rounds ? 0 : 2;   // (digit rows: a product is a row like any other - see the round emission)
                 case F_DIV: return 3;
                 case F_INPUT_W: case F_INPUT_FE: case F_CONST_W: case F_CONST_FE: return 1;
                 default: return 0;
             }
         };
-        const size_t STEP = digit_rows ? 60 : 64;
         std::vector<uint8_t> is_sink(N, 0), done(N, 0);
         std::vector<uint32_t> left(N, 0);
         size_t n_left = 0;
@@ -644,11 +650,27 @@ struct FieldCompiler {
         for (size_t r = 0; r < rounds.size(); r++) {
             auto& rd = rounds[r];
             // (a row of 16 lanes per record: the four records of a wave should be of one kind)
-            if (digit_rows)
+            const uint32_t PAD = 0xffffffffu;   // a padding row (NOP record)
+            if (digit_rows) {
                 std::stable_sort(rd.begin(), rd.end(), [&](uint32_t x, uint32_t y) {
                     if (nodes[x].opc != nodes[y].opc) return nodes[x].opc < nodes[y].opc;
                     return nodes[x].terms.size() < nodes[y].terms.size();   // (a wave runs its longest combination's term loop)
                 });
+                if (mixed_rounds) {   // kinds: linear combinations | products | everything else, each from a wave boundary
+                    auto kind_of = [&](uint32_t k) { return nodes[k].opc == F_LIN ? 0 : nodes[k].opc == F_MUL ? 1 : 2; };
+                    std::vector<uint32_t> padded;
+                    for (int kd = 0; kd < 3; kd++) {
+                        size_t before = padded.size();
+                        for (uint32_t k : rd)
+                            if (kind_of(k) == kd) padded.push_back(k);
+                        if (padded.size() > before)
+                            while (padded.size() % 4) padded.push_back(PAD);
+                    }
+                    while (!padded.empty() && padded.back() == PAD) padded.pop_back();
+                    if (padded.size() > 60) throw std::runtime_error("field chain: a padded round exceeds a pass of the kernel");
+                    rd = padded;
+                }
+            }
             size_t at = out.recs.size() / RW;
             if (at % H2E_WCHUNK + 1 + rd.size() > H2E_WCHUNK) {
                 uint32_t padh[16] = {0xff00u};
@@ -661,14 +683,19 @@ struct FieldCompiler {
             {
                 uint32_t max_terms = 0;   // of the round's linear combinations (the kernel's term loop runs that far)
                 for (uint32_t k : rd)
-                    if (nodes[k].opc == F_LIN) max_terms = std::max<uint32_t>(max_terms, (uint32_t)nodes[k].terms.size());
+                    if (k != PAD && nodes[k].opc == F_LIN) max_terms = std::max<uint32_t>(max_terms, (uint32_t)nodes[k].terms.size());
                 term_hist[std::min<uint32_t>(max_terms <= 6 ? max_terms : 7, 7)]++;
                 uint32_t hdr[16] = {(uint32_t)rd.size() | ((uint32_t)rcls[r] << 8), max_terms};
                 out.recs.insert(out.recs.end(), hdr, hdr + RW);
             }
             for (uint32_t k : rd) {
-                const Node& nd = nodes[k];
                 uint32_t w[16] = {0};
+                if (k == PAD) {
+                    w[0] = F_NOP | 0xffffu << 16;
+                    out.recs.insert(out.recs.end(), w, w + RW);
+                    continue;
+                }
+                const Node& nd = nodes[k];
                 w[0] = nd.opc | ((uint32_t)std::min<size_t>(nd.terms.size(), 255) << 8) | ((slot[k] >= 0 ? (uint32_t)slot[k] : 0xffffu) << 16);   // (bits 8-15: terms of a LIN)
                 w[1] = nd.hint == 0xffffffffu ? 0u : nd.hint + 1;
                 if (nd.hint != 0xffffffffu) {

@@ -1974,6 +1974,7 @@ struct h2e_ctx {
     // CU partition (H2E_CU_RESERVE="n[,fixup_side]"): the value-chain streams of pipelined runs get the device's last n CUs for
     // themselves, the expansion stream the others (fix-up stream: the expansion's CUs, or with fixup_side = 1 the chain's, 2 all)
     uint32_t cu_reserve = 0, cu_fixup_side = 0, cu_pattern = 0;   // pattern 1: every (n_cu / n)-th CU instead of the last n
+    uint32_t cu_chain_all = 0;   // 1: the value-chain streams may use every CU (only the expansion streams are kept off the reserved ones)
     int prio_expand = 0, prio_side = 0, prio_fixup = 0;   // HIP stream priorities (H2E_STREAM_PRIORITIES="x,s,f"; lower = higher priority)
     int64_t test_skip_expansion = INT64_MIN;   // test hook (h2e_ctx_set_option): see H2E_OPT_TEST_SKIP_EXPANSION
     uint32_t last_split_segments = 0;          // segments of the last run whose expansion was split (h2e_ctx_get_stat)
@@ -2031,7 +2032,7 @@ int h2e_ctx_create(int device, h2e_ctx** out) {
     }
     if (const char* e5 = getenv("H2E_SCHED")) c->sched = (uint32_t)atoi(e5);
     if (const char* e7 = getenv("H2E_SMALL_X_LANES")) c->small_x_lanes = (uint64_t)atoll(e7);
-    if (const char* e6 = getenv("H2E_CU_RESERVE")) sscanf(e6, "%u,%u,%u", &c->cu_reserve, &c->cu_fixup_side, &c->cu_pattern);
+    if (const char* e6 = getenv("H2E_CU_RESERVE")) sscanf(e6, "%u,%u,%u,%u", &c->cu_reserve, &c->cu_fixup_side, &c->cu_pattern, &c->cu_chain_all);
     if (const char* e3 = getenv("H2E_STREAM_PRIORITIES")) sscanf(e3, "%d,%d,%d", &c->prio_expand, &c->prio_side, &c->prio_fixup);
     *out = c;
     return 0;
@@ -2359,6 +2360,7 @@ static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
 // kind: 0 expansion, 1 value chain / side, 2 fix-up
 static hipError_t make_stream(h2e_ctx* ctx, hipStream_t* out, int prio, int kind) {
     if (!ctx->cu_reserve) return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
+    if (ctx->cu_chain_all && kind == 1) return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
     if (e != hipSuccess) return e;
