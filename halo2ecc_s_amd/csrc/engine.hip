@@ -2807,6 +2807,7 @@ __global__ void __launch_bounds__(128) h2e_field_chain(H2EPreKernel K, const u32
 //   Montgomery product: digit-serial (one round per digit of a), the columns are kept as unnormalised 64-bit values between
 //     the rounds - T_j <- lo(Q_j+1) + hi(Q_j) + hi(P_j), P = a_i b_j + T_j, Q = m w_j + lo(P_j) - so the loop has no carry
 //     propagation either; one carry resolve and one conditional subtraction at the end.
+typedef long long i64;
 #define H2E_DPP_ROW_SHL1 0x101
 #define H2E_DPP_ROW_SHR1 0x111
 #define H2E_DPP_ROW_BCAST(n) (0x150 + (n))
@@ -2814,6 +2815,11 @@ __global__ void __launch_bounds__(128) h2e_field_chain(H2EPreKernel K, const u32
 #define H2E_DP_GROUPS (H2E_DP_WAVES * 4u)
 template <int CTRL>
 WI_INLINE u32 dpp_mov(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
+WI_INLINE u32 mad_u32_u16(u32 a16, u32 b16, u32 c) {   // (low 16 bits of a) x (low 16 bits of b) + c
+    u32 r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a16), "v"(b16), "v"(c));
+    return r;
+}
 WI_INLINE u32 sel_by_mask(u32 if0, u32 if1, u64 m) {
     u32 r;
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(m));
@@ -2965,6 +2971,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
     R.pmask = __builtin_amdgcn_ballot_w64(j <= (u32)D);
     const u32 grp = wave * 4u + (lane >> 4);
     const H2E_AS_LDS u32* fv32 = (const H2E_AS_LDS u32*)fv;
+    const u32 fv_digit_addr = (u32)(size_t)fv32 + j * 4u;   // LDS address of digit j of value slot 0
     auto ld_digit = [&](u32 slot) -> u32 {       // digit j of a value slot (whatever lies behind it for the lanes above: masked by the caller)
         return fv32[slot * (u32)D + j];
     };
@@ -3026,7 +3033,8 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
         for (u32 op = grp; op < cnt; op += H2E_DP_GROUPS) {
             u32 rw = r0;
             if (op != grp) rw = rec_ptr(first % H2E_WCHUNK + op)[j];   // (a round of more than H2E_DP_GROUPS records: the host does not make them)
-            const u32 w0 = dpp_mov<H2E_DPP_ROW_BCAST(0)>(rw), hint = dpp_mov<H2E_DPP_ROW_BCAST(1)>(rw);
+            const u32 w0 = dpp_mov<H2E_DPP_ROW_BCAST(0)>(rw), w1 = dpp_mov<H2E_DPP_ROW_BCAST(1)>(rw);
+            const u32 hint = w1 & 0x3ffffu;   // (bits 18-31: the sum of a linear combination's coefficients)
             const u32 w2 = dpp_mov<H2E_DPP_ROW_BCAST(2)>(rw), w3 = dpp_mov<H2E_DPP_ROW_BCAST(3)>(rw), w4 = dpp_mov<H2E_DPP_ROW_BCAST(4)>(rw);
             u32 opc = w0 & 0xffu, dst = w0 >> 16;
             u32 out = 0;
@@ -3048,7 +3056,10 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                 if (opc == H2E_F_MUL) {
                     out = R.mont_mul(ld_value(w2), ld_value(w3), minv32);
                 } else if (opc == H2E_F_LIN) {
-                    u64 acc = beta;
+                    // columns: acc_j = beta_j + sum coef_t x_t,j.  The digits are read as x - 2^31 (one xor), which makes the
+                    // product one signed multiply-add; the host put sum coef_t into the record (w1 bits 18-31) and
+                    // (sum coef_t) 2^31 goes back in at the end.
+                    i64 acc = (i64)beta + ((i64)((int)w1 >> 18) << 31);
                     DP_STAMP(0, acc);
                     // (an unused term has coefficient 0 and slot 0; all digits are read before the first is used: one LDS
                     // round trip per record, not one per term)
@@ -3059,15 +3070,12 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                         static_for<0, NT>([&](auto tc) {
                             constexpr int T = decltype(tc)::value;
                             u32 term = dpp_mov<H2E_DPP_ROW_BCAST(2 + T)>(rw);
-                            x[T] = ld_digit(term & 0xffffu);
+                            x[T] = *(const H2E_AS_LDS u32*)(size_t)mad_u32_u16(term, (u32)D * 4u, fv_digit_addr);   // slot (low 16 bits) x 4 D + (slot 0's digit j)
                             coef[T] = (int)term >> 16;
                         });
                         DP_STAMP(1, x[NT - 1]);
 #pragma unroll
-                        for (int t = 0; t < NT; t++) {
-                            acc += (u64)(u32)coef[t] * x[t];                       // coef x + 2^32 x for a negative coef ...
-                            acc -= (u64)((u32)(coef[t] >> 31) & x[t]) << 32;      // ... corrected here
-                        }
+                        for (int t = 0; t < NT; t++) acc += (i64)coef[t] * (i64)(int)(x[t] ^ 0x80000000u);
                     };
                     // the term loop of this wave's longest combination (the host sorts a round's records by their length)
                     const u32 nt = (w0 >> 8) & 0xffu;
@@ -3075,7 +3083,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                     else if (__builtin_amdgcn_ballot_w64(nt > 6u)) combine(std::integral_constant<int, 10>());
                     else if (__builtin_amdgcn_ballot_w64(nt > 2u)) combine(std::integral_constant<int, 6>());
                     else combine(std::integral_constant<int, 2>());
-                    u32 lo = sel_by_mask(0u, (u32)acc, R.digits), hi = sel_by_mask(0u, (u32)(acc >> 32), R.digits);
+                    u32 lo = sel_by_mask(0u, (u32)(u64)acc, R.digits), hi = sel_by_mask(0u, (u32)((u64)acc >> 32), R.digits);
                     DP_STAMP(2, lo);
                     u32 v = R.normalize(lo, hi);                             // < 2^15 w, the overflow digit in lane D
                     DP_STAMP(3, v);

@@ -698,6 +698,13 @@ struct FieldCompiler {
                 const Node& nd = nodes[k];
                 w[0] = nd.opc | ((uint32_t)std::min<size_t>(nd.terms.size(), 255) << 8) | ((slot[k] >= 0 ? (uint32_t)slot[k] : 0xffffu) << 16);   // (bits 8-15: terms of a LIN)
                 w[1] = nd.hint == 0xffffffffu ? 0u : nd.hint + 1;
+                if (digit_rows) {   // 16-word records: the hint slot in 18 bits, the sum of a combination's coefficients above it
+                    if (w[1] >= (1u << 18)) throw std::runtime_error("field chain: hint slot index beyond the records' 18 bits");
+                    int sum = 0;
+                    if (nd.opc == F_LIN)
+                        for (auto& t : nd.terms) sum += t.second;
+                    w[1] |= (uint32_t)sum << 18;   // (|sum| <= 14 x 255: 13 bits and a sign)
+                }
                 if (nd.hint != 0xffffffffu) {
                     out.hint_lo = std::min(out.hint_lo, nd.hint);
                     out.hint_hi = std::max(out.hint_hi, nd.hint + 1);
