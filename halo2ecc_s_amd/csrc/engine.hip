@@ -3074,8 +3074,13 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                             coef[T] = (int)term >> 16;
                         });
                         DP_STAMP(1, x[NT - 1]);
+                        i64 acc1 = 0;   // (two chains of multiply-adds instead of one of NT)
 #pragma unroll
-                        for (int t = 0; t < NT; t++) acc += (i64)coef[t] * (i64)(int)(x[t] ^ 0x80000000u);
+                        for (int t = 0; t < NT; t += 2) {
+                            acc += (i64)coef[t] * (i64)(int)(x[t] ^ 0x80000000u);
+                            acc1 += (i64)coef[t + 1] * (i64)(int)(x[t + 1] ^ 0x80000000u);
+                        }
+                        acc += acc1;
                     };
                     // the term loop of this wave's longest combination (the host sorts a round's records by their length)
                     const u32 nt = (w0 >> 8) & 0xffu;
