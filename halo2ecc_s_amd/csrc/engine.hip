@@ -1250,7 +1250,7 @@ __global__ void __launch_bounds__(64, H2E_X_WAVES) h2e_run_tape(H2ELaunch L, con
 #pragma unroll
         for (int k = 0; k < 12; k++) {
             u64 v = l_ld8(dg_sums + k * 64 + threadIdx.x);
-            if (v) atomicAdd((unsigned long long*)(L.dg_out + ((size_t)(k / 4) * n_instances + instance) * 4 + (k % 4)), (unsigned long long)v);
+            if (v) atomicAdd((unsigned long long*)(L.dg_out + (((size_t)(blockIdx.x & (L.dg_shards - 1u)) * 3 + k / 4) * n_instances + instance) * 4 + (k % 4)), (unsigned long long)v);
         }
     }
     }
@@ -2414,7 +2414,7 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_fixup_inverses(H2ELau
     if (L.dg_out != nullptr)
 #pragma unroll
         for (int w = 0; w < 4; w++)
-            if (dgv[w]) atomicAdd((unsigned long long*)(L.dg_out + (size_t)instance * 4 + w), (unsigned long long)dgv[w]);
+            if (dgv[w]) atomicAdd((unsigned long long*)(L.dg_out + ((size_t)(blockIdx.x & (L.dg_shards - 1u)) * 3 * n_instances + instance) * 4 + w), (unsigned long long)dgv[w]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3934,6 +3934,18 @@ extern "C" int h2e_engine_copy_constraints(const uint32_t* perms, uint64_t n, vo
 __global__ void h2e_or_status(const InstanceDesc* inst, u32 n_instances, u32 bits) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_instances) atomicOr(inst[i].status, bits);
+}
+// the run's stream digest: the sum of its shards (tape.h H2ELaunch::dg_out)
+__global__ void __launch_bounds__(256) h2e_digest_reduce(const u64* __restrict__ shards, u32 n_shards, u32 n_words, u64* __restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_words) return;
+    u64 s = 0;
+    for (u32 k = 0; k < n_shards; k++) s += shards[(size_t)k * n_words + i];
+    out[i] = s;
+}
+extern "C" int h2e_engine_digest_reduce(const void* shards, uint32_t n_shards, uint32_t n_words, void* out, hipStream_t stream) {
+    hipLaunchKernelGGL(h2e_digest_reduce, dim3((n_words + 255) / 256), dim3(256), 0, stream, (const u64*)shards, n_shards, n_words, (u64*)out);
+    return (int)hipGetLastError();
 }
 extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances, uint32_t bits, hipStream_t stream) {
     if (n_instances == 0) return 0;

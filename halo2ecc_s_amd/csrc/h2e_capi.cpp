@@ -26,6 +26,7 @@ extern "C" int h2e_engine_fixed(int field_pair, const uint32_t* ids, const uint6
 extern "C" int h2e_engine_range_table(int mont, const H2EFieldConsts* fc_dev, void* out, hipStream_t stream);
 extern "C" int h2e_engine_copy_constraints(const uint32_t* perms, uint64_t n, void* out, hipStream_t stream);
 extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances, uint32_t bits, hipStream_t stream);
+extern "C" int h2e_engine_digest_reduce(const void* shards, uint32_t n_shards, uint32_t n_words, void* out, hipStream_t stream);
 extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
                                  uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream);
 extern "C" int h2e_engine_predict(int field_pair, int phase, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,
@@ -1910,12 +1911,15 @@ struct h2e_program {
 // Everything one run owns while it is in flight: engine workspace, instance table, events.  A context keeps a small
 // ring of these, so that h2e_submit can queue the value chain of run k + 1 (caller's stream) while run k's expansion is
 // still streaming on the expansion stream; h2e_run uses the same slots and joins before it returns.
+#define H2E_DG_SHARDS 64u
 struct JobSlot {
     // engine workspace (grow-only): quotient hints, numerator/denominator pairs, Jacobian scratch, selected points
     uint64_t *ws_hints = nullptr, *ws_nd = nullptr, *ws_jac = nullptr, *ws_sel = nullptr;
     size_t ws_hints_words = 0, ws_nd_words = 0, ws_jac_words = 0, ws_sel_words = 0;
     InstanceDescHost* d_inst = nullptr;
     uint32_t inst_cap = 0;
+    uint64_t* dg_shards = nullptr;    // stream digest accumulators of the slot's run: [H2E_DG_SHARDS][3][instances][4] words
+    uint32_t dg_cap = 0;              // instances they are sized for
     InstanceDescHost* h_inst = nullptr;   // pinned (hipHostMalloc): the upload below is a real asynchronous copy ...
     hipEvent_t upload_ev = nullptr;       // ... and this event says when the host may rewrite the table
     std::vector<hipEvent_t> ev;       // profiling: 4 per launched segment (value-chain begin/end, expansion begin/end)
@@ -1946,6 +1950,7 @@ struct JobSlot {
         (void)hipFree(ws_jac);
         (void)hipFree(ws_sel);
         (void)hipFree(d_inst);
+        (void)hipFree(dg_shards);
         if (h_inst) (void)hipHostFree(h_inst);
         if (upload_ev) (void)hipEventDestroy(upload_ev);
     }
@@ -2488,7 +2493,18 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     HIP_TRY(hipMemcpyAsync(J.d_inst, J.h_inst, (size_t)n_instances * sizeof(InstanceDescHost), hipMemcpyHostToDevice, sa));
     HIP_TRY(hipEventRecord(J.upload_ev, sa));
     // stream digest: the expansion and fix-up kernels of this run add to it (every other stream starts behind this point)
-    if (d_digests) HIP_TRY(hipMemsetAsync(d_digests, 0, (size_t)3 * n_instances * 4 * sizeof(uint64_t), sa));
+    if (d_digests) {
+        if (J.dg_cap < n_instances) {
+            if (J.dg_shards) {
+                HIP_TRY(hipDeviceSynchronize());
+                HIP_TRY(hipFree(J.dg_shards));
+                J.dg_shards = nullptr;
+            }
+            HIP_TRY(hipMalloc((void**)&J.dg_shards, (size_t)H2E_DG_SHARDS * 3 * n_instances * 4 * sizeof(uint64_t)));
+            J.dg_cap = n_instances;
+        }
+        HIP_TRY(hipMemsetAsync(J.dg_shards, 0, (size_t)H2E_DG_SHARDS * 3 * n_instances * 4 * sizeof(uint64_t), sa));
+    }
     bool used_sd = false;
     std::vector<hipEvent_t> early_done(r.pre_kernels.size(), nullptr);
     size_t n_sync = 0;
@@ -2655,7 +2671,8 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         L.s_offsets = hstore ? p->d_soffsets + p->seg_so_begin[si] : nullptr;
         L.s_ktab = hstore ? p->d_sktab + p->seg_sk_begin[si] : nullptr;
         L.n_sops = hstore ? p->seg_n_sops[si] : 0;
-        L.dg_out = (uint64_t*)d_digests;
+        L.dg_out = d_digests ? J.dg_shards : nullptr;
+        L.dg_shards = H2E_DG_SHARDS;
         L.l_steps = levels ? p->seg_l_steps[si] : 0;
         L.l_slots = levels ? p->seg_l_slots[si] : 0;
         L.l_pair = levels ? p->seg_l_pair[si] : 0;
@@ -2830,6 +2847,10 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             HIP_TRY(hipStreamWaitEvent(sd, e4, 0));
         }
         (void)used_sd;
+        if (d_digests) {   // every kernel that adds to the digest shards has finished here
+            int drc = h2e_engine_digest_reduce(J.dg_shards, H2E_DG_SHARDS, 3 * n_instances * 4, d_digests, sd);
+            if (drc != 0) return fail(H2E_ERR_HIP, std::string("digest kernel launch failed: ") + hipGetErrorString((hipError_t)drc));
+        }
         HIP_TRY(hipEventRecord(J.done, sd));
         if (join) HIP_TRY(hipStreamWaitEvent(sa_main, J.done, 0));
     }

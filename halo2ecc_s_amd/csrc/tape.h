@@ -194,8 +194,11 @@ typedef struct H2ELaunch {
     const uint32_t* s_offsets;    // [n_sops] first word of each record
     const uint64_t* s_ktab;       // K constants, (2 L + 4) words each
     uint32_t n_sops;
-    // stream digest of the run (h2e.h h2e_run_digest): [3][n_instances][4] words the expansion / fix-up kernels add to; NULL = off
+    // stream digest of the run (h2e.h h2e_run_digest): [dg_shards][3][n_instances][4] words the expansion / fix-up kernels add to
+    // (a workgroup adds to shard blockIdx.x mod dg_shards - 3.3 M lanes adding to the 768 words of 64 instances would queue up
+    // behind a handful of L2 channels; h2e_digest_reduce sums the shards at the end of the run); NULL = off
     uint64_t* dg_out;
+    uint32_t dg_shards;           // a power of two
 } H2ELaunch;
 enum H2EStoreKind { H2E_S_W = 1, H2E_S_LIN = 2, H2E_S_FE = 3, H2E_S_CONST = 4, H2E_S_FULL = 5 };
 
