@@ -2886,7 +2886,11 @@ struct DigitRow {
     }
     WI_INLINE u32 mont_mul(u32 a, u32 b, u32 minv32) const {
         u64 T = 0;
+#ifdef H2E_EXP_MUL_STEPS   // timing experiment (wrong products): only that many of the D digit rounds
+        mont_step<D - H2E_EXP_MUL_STEPS>(a, b, minv32, T);
+#else
         mont_step<0>(a, b, minv32, T);
+#endif
         return normalize((u32)T, (u32)(T >> 32));
     }
 };
@@ -3084,6 +3088,10 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                     };
                     // the term loop of this wave's longest combination (the host sorts a round's records by their length)
                     const u32 nt = (w0 >> 8) & 0xffu;
+#ifdef H2E_EXP_LIN_TERMS   // timing experiment (wrong sums): every combination as if it had at most that many terms
+                    if (true) combine(std::integral_constant<int, H2E_EXP_LIN_TERMS>());
+                    else
+#endif
                     if (__builtin_amdgcn_ballot_w64(nt > 10u)) combine(std::integral_constant<int, H2E_F_MAX_TERMS_WIDE>());
                     else if (__builtin_amdgcn_ballot_w64(nt > 6u)) combine(std::integral_constant<int, 10>());
                     else if (__builtin_amdgcn_ballot_w64(nt > 2u)) combine(std::integral_constant<int, 6>());
