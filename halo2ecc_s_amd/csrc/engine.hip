@@ -2838,6 +2838,7 @@ struct DigitRow {
     u32 wj;        // digit j of w (0 above the top digit)
     u64 digits;    // mask: lanes that hold a digit (j < D)
     u64 pmask;     // mask: lanes a borrow may ripple through (j <= D)
+    double inv_top;   // ~ 2^64 / (w's top two digits), see make()
     // digits with the carry-out mask G of the addition that made them: the carries go in (never across a row: the lanes
     // above the top digit hold zeros)
     WI_INLINE static u32 carry(u32 d, u64 G) {
@@ -2868,6 +2869,29 @@ struct DigitRow {
         u64 neg = (X << 16) - X;                          // ... spread over the row's lanes
         u = subb_co32(u, 0u, B);
         return sel_by_mask(u, r, neg);
+    }
+    // columns of a linear combination (lo_j + 2^32 hi_j, everything above the digits zero; below 2^15 w as a number) -> the
+    // value mod w in [0, 2 w): one carry resolve, the quotient from the top three digits in double precision (never above
+    // the true quotient, at most one below), q w by one multiply-add per lane, one more carry resolve, one borrow resolve
+    WI_INLINE u32 reduce_columns(u32 lo, u32 hi) const {
+        u32 v = normalize(lo, hi);   // the overflow digit in lane D
+        u32 o = dpp_mov<H2E_DPP_ROW_BCAST(D)>(v), t1 = dpp_mov<H2E_DPP_ROW_BCAST(D - 1)>(v), t2 = dpp_mov<H2E_DPP_ROW_BCAST(D - 2)>(v);
+        double top = ((double)o * 4294967296.0 + (double)t1) * 4294967296.0 + (double)t2;
+        u32 qe = (u32)(top * inv_top);
+        u64 qw = (u64)qe * wj;
+        return sub(v, normalize((u32)qw, (u32)(qw >> 32)));
+    }
+    // this lane's view of the field (digit j of w, masks, the reciprocal of w's top two digits - slightly low on purpose)
+    WI_INLINE static DigitRow make(const H2EFieldConsts* fc, u32 lane) {
+        DigitRow R;
+        R.j = lane & 15u;
+        const bool digit_lane = R.j < (u32)D;
+        R.wj = digit_lane ? ((const H2E_AS_GLOBAL u32*)fc->w)[digit_lane ? R.j : 0u] : 0u;
+        const double w_top2 = (double)((const H2E_AS_GLOBAL u32*)fc->w)[D - 1] * 4294967296.0 + (double)((const H2E_AS_GLOBAL u32*)fc->w)[D - 2];
+        R.inv_top = (1.0 / (w_top2 + 2.0)) * (1.0 - 0x1p-48);
+        R.digits = __builtin_amdgcn_ballot_w64(digit_lane);
+        R.pmask = __builtin_amdgcn_ballot_w64(R.j <= (u32)D);
+        return R;
     }
     // a b / R mod w for digit rows a, b (zero above the top digit), R = 2^(32 D).  Values live in [0, 2 w): R > 4 w for both
     // base fields (R / w = 5.3 and 9.8), so a b < R w, the result (a b + m w) / R is below 2 w again and the chain never needs
@@ -2956,23 +2980,15 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
         return;
     }
     __builtin_amdgcn_s_setprio(3);
-    DigitRow<D> R;
-    R.j = lane & 15u;
+    DigitRow<D> R = DigitRow<D>::make(fc, lane);
     const u32 j = R.j, row_base = lane & 48u;
     const bool digit_lane = j < (u32)D;
     const u32 jd = digit_lane ? j : 0u;
-    R.wj = digit_lane ? ((const H2E_AS_GLOBAL u32*)fc->w)[jd] : 0u;
     const u32 r1j = digit_lane ? ((const H2E_AS_GLOBAL u32*)fc->w_r1)[jd] : 0u;
     const u32 r2j = digit_lane ? ((const H2E_AS_GLOBAL u32*)fc->w_r2)[jd] : 0u;
     const u64 beta = digit_lane ? ((const H2E_AS_GLOBAL u64*)fc->lin_bias)[jd] : 0ull;
     const u32 minv32 = (u32)fc->w_minv;
     const u32 ej = R.wj - (j == 0u ? 2u : 0u);   // digit j of w - 2 (w is odd and > 2: no borrow leaves digit 0)
-    // quotient estimate of a linear combination: (its top three digits) / (w's top two digits + 1) in double precision, the
-    // reciprocal slightly low on purpose - the estimate is then never above the quotient and at most one below it
-    const double w_top2 = (double)((const H2E_AS_GLOBAL u32*)fc->w)[D - 1] * 4294967296.0 + (double)((const H2E_AS_GLOBAL u32*)fc->w)[D - 2];
-    const double inv_top = (1.0 / (w_top2 + 2.0)) * (1.0 - 0x1p-48);
-    R.digits = __builtin_amdgcn_ballot_w64(digit_lane);
-    R.pmask = __builtin_amdgcn_ballot_w64(j <= (u32)D);
     const u32 grp = wave * 4u + (lane >> 4);
     const H2E_AS_LDS u32* fv32 = (const H2E_AS_LDS u32*)fv;
     const u32 fv_digit_addr = (u32)(size_t)fv32 + j * 4u;   // LDS address of digit j of value slot 0
@@ -3098,16 +3114,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                     else combine(std::integral_constant<int, 2>());
                     u32 lo = sel_by_mask(0u, (u32)(u64)acc, R.digits), hi = sel_by_mask(0u, (u32)((u64)acc >> 32), R.digits);
                     DP_STAMP(2, lo);
-                    u32 v = R.normalize(lo, hi);                             // < 2^15 w, the overflow digit in lane D
-                    DP_STAMP(3, v);
-                    u32 o = dpp_mov<H2E_DPP_ROW_BCAST(D)>(v), t1 = dpp_mov<H2E_DPP_ROW_BCAST(D - 1)>(v), t2 = dpp_mov<H2E_DPP_ROW_BCAST(D - 2)>(v);
-                    double top = ((double)o * 4294967296.0 + (double)t1) * 4294967296.0 + (double)t2;
-                    u32 qe = (u32)(top * inv_top);                           // quotient - 1 <= qe <= quotient
-                    DP_STAMP(4, qe);
-                    u64 qw = (u64)qe * R.wj;
-                    u32 r = R.sub(v, R.normalize((u32)qw, (u32)(qw >> 32)));
-                    DP_STAMP(5, r);
-                    out = r;                                                 // in [0, 2 w)
+                    out = R.reduce_columns(lo, hi);                          // in [0, 2 w)
                     DP_STAMP(6, out);
                 } else if (opc == H2E_F_ISZERO) {
                     u32 x = ld_value(w2);                                    // in [0, 2 w): zero is 0 or w
@@ -3187,6 +3194,40 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
         g_wave_stamps[20] = dpn;
     }
 #endif
+}
+// TEST HOOK: the digit-row primitives on caller-supplied rows, one 16-lane row per case (tests/test_digit_rows_gpu.py feeds
+// the patterns random data never produces: runs of 0xffffffff digits under a carry, runs of equal digits under a borrow,
+// quotient estimates on the boundary).  in: [cases][2][16] words, out: [cases][16] words.
+//   op 0: normalize(lo = in0, hi = in1)   1: sub(in0, in1)   2: mont_mul(in0, in1)   3: reduce_columns(lo = in0, hi = in1)
+template <class FP>
+__global__ void __launch_bounds__(64) h2e_digit_rows_selftest(u32 op, u32 n_cases, const u32* __restrict__ in, u32* __restrict__ out) {
+    constexpr int D = 2 * FP::WW;
+    const H2EFieldConsts* fc = &g_fc[FP::ID];
+    DigitRow<D> R = DigitRow<D>::make(fc, threadIdx.x);
+    u32 c = blockIdx.x * 4u + (threadIdx.x >> 4);
+    bool live = c < n_cases;
+    if (!live) c = n_cases - 1;
+    u32 a = in[((size_t)c * 2 + 0) * 16 + R.j], b = in[((size_t)c * 2 + 1) * 16 + R.j];
+    u32 r = 0;
+    if (op == 0) r = R.normalize(a, b);
+    else if (op == 1) r = R.sub(a, b);
+    else if (op == 2) r = R.mont_mul(a, b, (u32)fc->w_minv);
+    else r = R.reduce_columns(a, b);
+    if (live) out[(size_t)c * 16 + R.j] = r;
+}
+extern "C" int H2E_UNIT(h2e_engine_digit_rows_selftest)(int field_pair, uint32_t op, uint32_t n_cases, const void* in, void* out, hipStream_t stream) {
+    if (n_cases == 0) return 0;
+    dim3 grid((n_cases + 3) / 4), block(64);
+    switch (field_pair) {
+#if H2E_HAS_FP(0)
+        case 0: hipLaunchKernelGGL(h2e_digit_rows_selftest<FP_BN256_FQ>, grid, block, 0, stream, op, n_cases, (const u32*)in, (u32*)out); break;
+#endif
+#if H2E_HAS_FP(1)
+        case 1: hipLaunchKernelGGL(h2e_digit_rows_selftest<FP_BLS_FQ>, grid, block, 0, stream, op, n_cases, (const u32*)in, (u32*)out); break;
+#endif
+        default: return -1;
+    }
+    return (int)hipGetLastError();
 }
 // hint slots [first, first + n) of every instance: Montgomery form -> canonical value
 template <class FP>
