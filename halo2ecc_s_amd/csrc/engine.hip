@@ -2934,10 +2934,10 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
     u64* fv = (u64*)(rbuf + 2 * H2E_WCHUNK);                // [f_slots][N]
     const Rec* recs = (const Rec*)(args + K.f_recs);
     const u32 n_chunks = K.f_n_recs / H2E_WCHUNK;
-    auto header = [&](u32 pos, u32& cnt, u32& kind, u32& max_terms) {
+    auto header = [&](u32 pos, u32& cnt, u32& kind, u32& n_conts) {   // rows of the round, its kind, second records behind the rows
         const H2E_AS_LDS u32* hp = (const H2E_AS_LDS u32*)(rbuf + (size_t)((pos / H2E_WCHUNK) & 1u) * H2E_WCHUNK + pos % H2E_WCHUNK);
         u32 meta = __builtin_amdgcn_readfirstlane(hp[0]);
-        max_terms = __builtin_amdgcn_readfirstlane(hp[1]);
+        n_conts = __builtin_amdgcn_readfirstlane(hp[1]);
         cnt = meta & 0xffu;
         kind = (meta >> 8) & 0xffu;
     };
@@ -2966,9 +2966,9 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                 cur = chunk;
                 if (chunk + 1 < n_chunks) load_chunk(chunk + 1);
             }
-            u32 cnt, kind, mt;
-            header(pos, cnt, kind, mt);
-            pos += 1 + cnt;
+            u32 cnt, kind, nc;
+            header(pos, cnt, kind, nc);
+            pos += 1 + cnt + nc;
             if (pos % H2E_WCHUNK != 0) {
                 u32 c2, k2, m2;
                 header(pos, c2, k2, m2);
@@ -2998,7 +2998,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
     auto ld_value = [&](u32 slot) -> u32 { return sel_by_mask(0u, ld_digit(slot), R.digits); };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    u32 pos = 0, n_cnt = 0, n_kind = 0, n_mt = 0;
+    u32 pos = 0, n_cnt = 0, n_kind = 0, n_nc = 0;
     bool n_valid = false;
     u32 n_rec = 0;   // this row's record of the next round: lane j holds word j (a word is broadcast over the row by DPP when it is used)
 #ifdef H2E_WAVE_STAMPS
@@ -3022,18 +3022,18 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
         unsigned long long ft0 = WAVE_STAMP();
 #endif
         u32 chunk = pos / H2E_WCHUNK;
-        u32 cnt = n_cnt, kind = n_kind, max_terms = n_mt;
+        u32 cnt = n_cnt, kind = n_kind, n_conts = n_nc;
         const Rec* cbuf = rbuf + (size_t)(chunk & 1u) * H2E_WCHUNK;
         auto rec_ptr = [&](u32 at) {   // record `at` of this chunk (a row beyond the round's records reads some record: unused)
             return (const H2E_AS_LDS u32*)(cbuf + (at < H2E_WCHUNK ? at : H2E_WCHUNK - 1u));
         };
         u32 r0 = n_rec;
         if (!n_valid) {   // the first round of a chunk
-            header(pos, cnt, kind, max_terms);
+            header(pos, cnt, kind, n_conts);
             r0 = rec_ptr(pos % H2E_WCHUNK + 1u + grp)[j];
         }
         const u32 first = pos + 1;
-        pos += 1 + cnt;
+        pos += 1 + cnt + n_conts;   // (the second records of the round's fused products sit behind its rows)
         // What lies behind this round is read now, before the round's barrier - the loader may overwrite this chunk's buffer
         // after the barrier of the chunk's last round - and used after the round's work, so that these LDS round trips run
         // under it: the next header (padding = on to the next chunk, whose first header is read after the barrier that its
@@ -3056,7 +3056,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
             const u32 w0 = dpp_mov<H2E_DPP_ROW_BCAST(0)>(rw), w1 = dpp_mov<H2E_DPP_ROW_BCAST(1)>(rw);
             const u32 hint = w1 & 0x3ffffu;   // (bits 18-31: the sum of a linear combination's coefficients)
             const u32 w2 = dpp_mov<H2E_DPP_ROW_BCAST(2)>(rw), w3 = dpp_mov<H2E_DPP_ROW_BCAST(3)>(rw), w4 = dpp_mov<H2E_DPP_ROW_BCAST(4)>(rw);
-            u32 opc = w0 & 0xffu, dst = w0 >> 16;
+            u32 opc = w0 & 0xfu, dst = w0 >> 16;   // (bits 4-7: terms of a combination, 8-15: a fused product's second record)
             u32 out = 0;
             bool raw = false;
             if constexpr (LOADS) {   // values entering: inputs and pool constants
@@ -3075,46 +3075,71 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                                        // kind its own waves)
                 if (opc == H2E_F_MUL) {
                     out = R.mont_mul(ld_value(w2), ld_value(w3), minv32);
-                } else if (opc == H2E_F_LIN) {
-                    // columns: acc_j = beta_j + sum coef_t x_t,j.  The digits are read as x - 2^31 (one xor), which makes the
-                    // product one signed multiply-add; the host put sum coef_t into the record (w1 bits 18-31) and
-                    // (sum coef_t) 2^31 goes back in at the end.
-                    i64 acc = (i64)beta + ((i64)((int)w1 >> 18) << 31);
-                    DP_STAMP(0, acc);
-                    // (an unused term has coefficient 0 and slot 0; all digits are read before the first is used: one LDS
-                    // round trip per record, not one per term)
-                    auto combine = [&](auto nt_tag) {
-                        constexpr int NT = decltype(nt_tag)::value;
-                        u32 x[NT];
-                        int coef[NT];
-                        static_for<0, NT>([&](auto tc) {
-                            constexpr int T = decltype(tc)::value;
-                            u32 term = dpp_mov<H2E_DPP_ROW_BCAST(2 + T)>(rw);
-                            x[T] = *(const H2E_AS_LDS u32*)(size_t)mad_u32_u16(term, (u32)D * 4u, fv_digit_addr);   // slot (low 16 bits) x 4 D + (slot 0's digit j)
-                            coef[T] = (int)term >> 16;
-                        });
-                        DP_STAMP(1, x[NT - 1]);
-                        i64 acc1 = 0;   // (two chains of multiply-adds instead of one of NT)
+                } else if (opc == H2E_F_LIN || opc == H2E_F_MULX) {
+                    // A linear combination - or (H2E_FIELD_FUSE programs) a product whose operands are linear combinations: two
+                    // records, this row's and one behind the round's rows (field_chain.hpp); the combinations one after the other,
+                    // then the multiplication.  Per combination: columns acc_j = beta_j + sum coef_t x_t,j.  The digits are read as
+                    // x - 2^31 (one xor), which makes a term one signed multiply-add; the host put sum coef_t into the record
+                    // (word 1, bits 18-31) and (sum coef_t) 2^31 goes back in at the start.
+                    auto combination = [&](u32 rwx, u32 nt, u32 v1) -> u32 {
+                        i64 acc = (i64)beta + ((i64)((int)v1 >> 18) << 31);
+                        // (an unused term has coefficient 0 and slot 0; all digits are read before the first is used: one LDS
+                        // round trip per combination, not one per term)
+                        auto combine = [&](auto nt_tag) {
+                            constexpr int NT = decltype(nt_tag)::value;
+                            u32 x[NT];
+                            int coef[NT];
+                            static_for<0, NT>([&](auto tc) {
+                                constexpr int T = decltype(tc)::value;
+                                u32 term = dpp_mov<H2E_DPP_ROW_BCAST(2 + T)>(rwx);
+                                x[T] = *(const H2E_AS_LDS u32*)(size_t)mad_u32_u16(term, (u32)D * 4u, fv_digit_addr);   // slot (low 16 bits) x 4 D + (slot 0's digit j)
+                                coef[T] = (int)term >> 16;
+                            });
+                            DP_STAMP(1, x[NT - 1]);
+                            i64 acc1 = 0;   // (two chains of multiply-adds instead of one of NT)
 #pragma unroll
-                        for (int t = 0; t < NT; t += 2) {
-                            acc += (i64)coef[t] * (i64)(int)(x[t] ^ 0x80000000u);
-                            acc1 += (i64)coef[t + 1] * (i64)(int)(x[t + 1] ^ 0x80000000u);
-                        }
-                        acc += acc1;
-                    };
-                    // the term loop of this wave's longest combination (the host sorts a round's records by their length)
-                    const u32 nt = (w0 >> 8) & 0xffu;
+                            for (int t = 0; t < NT; t += 2) {
+                                acc += (i64)coef[t] * (i64)(int)(x[t] ^ 0x80000000u);
+                                acc1 += (i64)coef[t + 1] * (i64)(int)(x[t + 1] ^ 0x80000000u);
+                            }
+                            acc += acc1;
+                        };
+                        // the term loop of this wave's longest combination (the host sorts a round's records by their length)
 #ifdef H2E_EXP_LIN_TERMS   // timing experiment (wrong sums): every combination as if it had at most that many terms
-                    if (true) combine(std::integral_constant<int, H2E_EXP_LIN_TERMS>());
-                    else
+                        if (true) combine(std::integral_constant<int, H2E_EXP_LIN_TERMS>());
+                        else
 #endif
-                    if (__builtin_amdgcn_ballot_w64(nt > 10u)) combine(std::integral_constant<int, H2E_F_MAX_TERMS_WIDE>());
-                    else if (__builtin_amdgcn_ballot_w64(nt > 6u)) combine(std::integral_constant<int, 10>());
-                    else if (__builtin_amdgcn_ballot_w64(nt > 2u)) combine(std::integral_constant<int, 6>());
-                    else combine(std::integral_constant<int, 2>());
-                    u32 lo = sel_by_mask(0u, (u32)(u64)acc, R.digits), hi = sel_by_mask(0u, (u32)((u64)acc >> 32), R.digits);
-                    DP_STAMP(2, lo);
-                    out = R.reduce_columns(lo, hi);                          // in [0, 2 w)
+                        if (__builtin_amdgcn_ballot_w64(nt > 10u)) combine(std::integral_constant<int, H2E_F_MAX_TERMS_WIDE>());
+                        else if (__builtin_amdgcn_ballot_w64(nt > 6u)) combine(std::integral_constant<int, 10>());
+                        else if (__builtin_amdgcn_ballot_w64(nt > 2u)) combine(std::integral_constant<int, 6>());
+                        else combine(std::integral_constant<int, 2>());
+                        u32 lo = sel_by_mask(0u, (u32)(u64)acc, R.digits), hi = sel_by_mask(0u, (u32)((u64)acc >> 32), R.digits);
+                        DP_STAMP(2, lo);
+                        return R.reduce_columns(lo, hi);                     // in [0, 2 w)
+                    };
+                    DP_STAMP(0, rw);
+                    if (opc == H2E_F_LIN) {
+                        out = combination(rw, (w0 >> 4) & 0xfu, w1);
+                    } else {
+                        const u32 cidx = (w0 >> 8) & 0xffu;
+                        u32 rwx = rw, val0 = 0;
+#pragma unroll 1
+                        for (u32 side = 0; side < 2u; side++) {
+                            u32 val;
+                            if (side == 1 && cidx == 0xffu) {   // (b = a)
+                                val = val0;
+                            } else {
+                                if (side == 1) rwx = rec_ptr(first % H2E_WCHUNK + cidx)[j];   // the second record: b's terms
+                                const u32 v0 = dpp_mov<H2E_DPP_ROW_BCAST(0)>(rwx), v1 = dpp_mov<H2E_DPP_ROW_BCAST(1)>(rwx);
+                                const u32 nt = (v0 >> 4) & 0xfu;
+                                if (nt == 15u) val = ld_value(dpp_mov<H2E_DPP_ROW_BCAST(2)>(rwx) & 0xffffu);   // a plain operand: the slot in the first term word
+                                else val = combination(rwx, nt, v1);
+                            }
+                            if (side == 0) val0 = val;
+                            out = val;
+                        }
+                        out = R.mont_mul(val0, out, minv32);
+                    }
                     DP_STAMP(6, out);
                 } else if (opc == H2E_F_ISZERO) {
                     u32 x = ld_value(w2);                                    // in [0, 2 w): zero is 0 or w
@@ -3158,7 +3183,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
         n_valid = false;
         if (same_chunk) {
             u32 meta = __builtin_amdgcn_readfirstlane(ph0);
-            n_mt = __builtin_amdgcn_readfirstlane(ph1);
+            n_nc = __builtin_amdgcn_readfirstlane(ph1);
             n_cnt = meta & 0xffu;
             n_kind = (meta >> 8) & 0xffu;
             if (n_kind == 0xffu) pos = (chunk + 1) * H2E_WCHUNK;

@@ -66,6 +66,12 @@ struct FieldCompiler {
         std::vector<std::pair<int, int>> terms;           // LIN: (node, coef)
         uint32_t imm = 0;                                 // input slot / pool offset
         uint32_t hint = 0xffffffffu;
+        // a product whose operand is a linear combination computed in the product's own row (digit rows, "fused"): the terms
+        // taken over from the LIN node that was the operand (a / b stay -1 then); sq: b is the same combination as a
+        std::vector<std::pair<int, int>> ta, tb;
+        bool fa = false, fb = false, sq = false;
+        bool fused() const { return fa || fb; }
+        int rows() const { return 1; }                    // rows of a round the node takes (a fused product's second record sits behind the round's rows)
     };
     std::vector<Node> nodes;
     struct Expr {
@@ -149,7 +155,7 @@ struct FieldCompiler {
 
     int F_MAX_TERMS = 6;   // terms of a LIN record: its words less two (compile() sets it)
     static constexpr int F_MAX_COEF = 255;
-    enum { F_NOP = 0, F_LIN, F_MUL, F_DIV, F_ISZERO, F_NOT, F_AND, F_OR, F_XNOR, F_SELECT, F_INPUT_W, F_INPUT_FE, F_CONST_W, F_CONST_FE };
+    enum { F_NOP = 0, F_LIN, F_MUL, F_DIV, F_ISZERO, F_NOT, F_AND, F_OR, F_XNOR, F_SELECT, F_INPUT_W, F_INPUT_FE, F_CONST_W, F_CONST_FE, F_MULX, F_CONT };
 
     int new_node(uint8_t opc) {
         nodes.emplace_back();
@@ -368,6 +374,8 @@ struct FieldCompiler {
             add(nd.b);
             add(nd.c);
             for (auto& kv : nd.terms) add(kv.first);
+            for (auto& kv : nd.ta) add(kv.first);
+            for (auto& kv : nd.tb) add(kv.first);
         };
         // ---- linear combinations of linear combinations ---------------------------------------------------------------
         // A LIN node exists where some consumer needed the value in a slot (an operand of a product, a hint); a later
@@ -411,6 +419,31 @@ struct FieldCompiler {
                 uint32_t dd = 0;
                 for (uint32_t pp : dp) dd = std::max(dd, depth[pp]);
                 depth[k] = dd + 1;
+            }
+        }
+        // ---- products take over their operands' combinations (H2E_FIELD_FUSE=1: off by default) ---------------------------
+        // mul -> (add, sub, ...) -> mul is the shape of the whole pairing.  A product whose operand is a linear combination can
+        // compute that combination itself, in its own row, right before the multiplication: one round instead of two on every
+        // such path (the LIN node stays for its other readers and for its hint - where nobody reads it any more it becomes a
+        // sink or disappears).  Measured: bn256 1 950 -> 1 456 levels, 2 261 -> 1 538 rounds - and the chain 2.9 -> 3.4 ms
+        // (bls12-381: 2.7 -> 2.8): a fused round is as long as the two it replaces, because mixed rounds already run the
+        // combinations of one level next to the products of another; what a round costs is its longest row.
+        if (digit_rows && getenv("H2E_FIELD_FUSE") && !getenv("H2E_FIELD_PURE_ROUNDS")) {   // (= `fuse` below)
+            for (size_t k = 0; k < nodes.size(); k++) {
+                Node& nd = nodes[k];
+                if (nd.opc != F_MUL) continue;
+                const int oa = nd.a, ob = nd.b;
+                if (oa >= 0 && nodes[oa].opc == F_LIN) {
+                    nd.ta = nodes[oa].terms;
+                    nd.fa = true;
+                    nd.a = -1;
+                }
+                if (ob >= 0 && nodes[ob].opc == F_LIN) {
+                    if (nd.fa && ob == oa) nd.sq = true;
+                    else nd.tb = nodes[ob].terms;
+                    nd.fb = true;
+                    nd.b = -1;
+                }
             }
         }
         // ---- hint-only combinations leave the chain -------------------------------------------------------------------
@@ -503,9 +536,10 @@ struct FieldCompiler {
         // products with light records - what matters is that the four rows of a WAVE are of one kind (a wave executes every kind
         // its rows hold, one after the other).  Rounds are therefore scheduled by dependency alone (their number drops from
         // class-pure 2 808 to 2 06x for bn256, the dependency depth being 1 950) and the emission below pads each kind to a
-        // multiple of four rows; 54 records leave room for the padding in a pass of 60 rows.
+        // multiple of four rows; 54 rows (51 with fused products) leave room for the padding in a pass of 60.
         const bool mixed_rounds = digit_rows && !getenv("H2E_FIELD_PURE_ROUNDS");
-        const size_t STEP = digit_rows ? (mixed_rounds ? 54 : 60) : 64;
+        const bool fuse = mixed_rounds && getenv("H2E_FIELD_FUSE");   // (fused products are a fourth kind of row: three more padding rows)
+        const size_t STEP = digit_rows ? (mixed_rounds ? (fuse ? 51 : 54) : 60) : 64;
         auto cls_of = [&](uint32_t k) -> int {   // 0 light, 1 loads, 2 products, 3 divisions
             switch (nodes[k].opc) {
                 case F_MUL: return mixed_rounds ? 0 : 2;   // (digit rows: a product is a row like any other - see the round emission)
@@ -530,6 +564,11 @@ struct FieldCompiler {
         }
         for (size_t k = 0; k < N; k++)
             if (alive[k] && !is_sink[k] && left[k] == 0) ready[cls_of((uint32_t)k)].push_back((uint32_t)k);
+        auto rows_of = [&](const std::vector<uint32_t>& rd) {
+            size_t n = 0;
+            for (uint32_t k : rd) n += (size_t)nodes[k].rows();
+            return n;
+        };
         std::vector<std::vector<uint32_t>> rounds_rev;
         std::vector<int> rcls_rev;
         while (n_left > 0) {
@@ -538,7 +577,11 @@ struct FieldCompiler {
                 if (!ready[q].empty()) c = q;
             if (c < 0) throw std::runtime_error("field chain: scheduler stalled");
             std::vector<uint32_t> rd;
-            size_t take = std::min(STEP, ready[c].size());
+            size_t take = 0, rows_taken = 0;   // (a fused product takes two rows)
+            while (take < ready[c].size() && rows_taken + (size_t)nodes[ready[c][ready[c].size() - 1 - take]].rows() <= STEP) {
+                rows_taken += (size_t)nodes[ready[c][ready[c].size() - 1 - take]].rows();
+                take++;
+            }
             rd.assign(ready[c].end() - take, ready[c].end());
             ready[c].resize(ready[c].size() - take);
             for (uint32_t k : rd) {
@@ -568,7 +611,7 @@ struct FieldCompiler {
             int c = cls_of((uint32_t)k);
             bool placed = false;
             for (size_t r = r0; r < rounds.size() && !placed; r++)
-                if (rcls[r] == c && rounds[r].size() < STEP) {
+                if (rcls[r] == c && rows_of(rounds[r]) + (size_t)nodes[k].rows() <= STEP) {
                     rounds[r].push_back((uint32_t)k);
                     round_of[k] = (uint32_t)r;
                     placed = true;
@@ -651,15 +694,17 @@ struct FieldCompiler {
             auto& rd = rounds[r];
             // (a row of 16 lanes per record: the four records of a wave should be of one kind)
             const uint32_t PAD = 0xffffffffu;   // a padding row (NOP record)
+            size_t n_conts = 0;                 // second records of fused products: behind the round's rows
             if (digit_rows) {
+                auto op_terms = [&](uint32_t k) { return nodes[k].opc == F_MUL ? std::max(nodes[k].ta.size(), nodes[k].tb.size()) : nodes[k].terms.size(); };
                 std::stable_sort(rd.begin(), rd.end(), [&](uint32_t x, uint32_t y) {
                     if (nodes[x].opc != nodes[y].opc) return nodes[x].opc < nodes[y].opc;
-                    return nodes[x].terms.size() < nodes[y].terms.size();   // (a wave runs its longest combination's term loop)
+                    return op_terms(x) < op_terms(y);   // (a wave runs its longest combination's term loop)
                 });
-                if (mixed_rounds) {   // kinds: linear combinations | products | everything else, each from a wave boundary
-                    auto kind_of = [&](uint32_t k) { return nodes[k].opc == F_LIN ? 0 : nodes[k].opc == F_MUL ? 1 : 2; };
+                if (mixed_rounds) {   // kinds: linear combinations | fused products | products | everything else, each from a wave boundary
+                    auto kind_of = [&](uint32_t k) { return nodes[k].opc == F_LIN ? 0 : nodes[k].opc == F_MUL ? (nodes[k].fused() ? 1 : 2) : 3; };
                     std::vector<uint32_t> padded;
-                    for (int kd = 0; kd < 3; kd++) {
+                    for (int kd = 0; kd < 4; kd++) {
                         size_t before = padded.size();
                         for (uint32_t k : rd)
                             if (kind_of(k) == kd) padded.push_back(k);
@@ -670,9 +715,15 @@ struct FieldCompiler {
                     if (padded.size() > 60) throw std::runtime_error("field chain: a padded round exceeds a pass of the kernel");
                     rd = padded;
                 }
+                for (uint32_t k : rd)
+                    if (k != PAD && nodes[k].fused()) {
+                        if (!mixed_rounds) throw std::runtime_error("field chain: fused products need mixed rounds");
+                        if (!nodes[k].sq || !nodes[k].fa) n_conts++;   // (a square of a combination needs no second record)
+                    }
+                if (rd.size() + n_conts > 254) throw std::runtime_error("field chain: a round's records exceed the 8-bit record index");
             }
             size_t at = out.recs.size() / RW;
-            if (at % H2E_WCHUNK + 1 + rd.size() > H2E_WCHUNK) {
+            if (at % H2E_WCHUNK + 1 + rd.size() + n_conts > H2E_WCHUNK) {
                 uint32_t padh[16] = {0xff00u};
                 out.recs.insert(out.recs.end(), padh, padh + RW);
                 pad_chunk();
@@ -685,9 +736,11 @@ struct FieldCompiler {
                 for (uint32_t k : rd)
                     if (k != PAD && nodes[k].opc == F_LIN) max_terms = std::max<uint32_t>(max_terms, (uint32_t)nodes[k].terms.size());
                 term_hist[std::min<uint32_t>(max_terms <= 6 ? max_terms : 7, 7)]++;
-                uint32_t hdr[16] = {(uint32_t)rd.size() | ((uint32_t)rcls[r] << 8), max_terms};
+                // (word 1: the lane kernel's longest combination of the round / the digit kernel's count of second records behind the rows)
+                uint32_t hdr[16] = {(uint32_t)rd.size() | ((uint32_t)rcls[r] << 8), digit_rows ? (uint32_t)n_conts : max_terms};
                 out.recs.insert(out.recs.end(), hdr, hdr + RW);
             }
+            std::vector<uint32_t> conts;
             for (uint32_t k : rd) {
                 uint32_t w[16] = {0};
                 if (k == PAD) {
@@ -696,7 +749,45 @@ struct FieldCompiler {
                     continue;
                 }
                 const Node& nd = nodes[k];
-                w[0] = nd.opc | ((uint32_t)std::min<size_t>(nd.terms.size(), 255) << 8) | ((slot[k] >= 0 ? (uint32_t)slot[k] : 0xffffu) << 16);   // (bits 8-15: terms of a LIN)
+                // digit rows: word 0 = opcode (4 bits) | terms of the combination (4 bits; 15 = a plain operand) | index of the second
+                // record of a fused product, counted from the round's first record (8 bits; 0xff = b is a) | destination slot
+                auto head = [&](uint32_t opc, uint32_t nt, uint32_t cidx, uint32_t dst) { return opc | nt << 4 | cidx << 8 | dst << 16; };
+                if (nd.opc == F_MUL && nd.fused()) {
+                    // two records: [MULX, hint | sum of a's coefficients << 18, a's terms] and - behind the round's rows -
+                    // [CONT, sum of b's coefficients << 18, b's terms]
+                    auto side = [&](uint32_t* r, bool fused, const std::vector<std::pair<int, int>>& t, int plain) -> uint32_t {
+                        int sum = 0;
+                        if ((int)t.size() > F_MAX_TERMS) throw std::runtime_error("field chain: fused operand with too many terms");
+                        for (size_t q = 0; q < t.size(); q++) {
+                            r[2 + q] = slot_of(t[q].first) | ((uint32_t)(uint16_t)(int16_t)t[q].second << 16);
+                            sum += t[q].second;
+                        }
+                        if (!fused) r[2] = slot_of(plain);
+                        r[1] |= (uint32_t)sum << 18;
+                        return fused ? (uint32_t)t.size() : 15u;
+                    };
+                    w[1] = nd.hint == 0xffffffffu ? 0u : nd.hint + 1;
+                    if (w[1] >= (1u << 18)) throw std::runtime_error("field chain: hint slot index beyond the records' 18 bits");
+                    if (nd.hint != 0xffffffffu) {
+                        out.hint_lo = std::min(out.hint_lo, nd.hint);
+                        out.hint_hi = std::max(out.hint_hi, nd.hint + 1);
+                    }
+                    uint32_t nta = side(w, nd.fa, nd.ta, nd.a);
+                    uint32_t cidx = 0xffu;
+                    if (!(nd.sq && nd.fa)) {
+                        uint32_t w2[16] = {0};
+                        uint32_t ntb = side(w2, nd.fb && !nd.sq, nd.tb, nd.b);
+                        w2[0] = head(F_CONT, ntb, 0, 0xffffu);
+                        cidx = (uint32_t)(rd.size() + conts.size() / RW);
+                        conts.insert(conts.end(), w2, w2 + RW);
+                    }
+                    w[0] = head(F_MULX, nta, cidx, slot[k] >= 0 ? (uint32_t)slot[k] : 0xffffu);
+                    out.recs.insert(out.recs.end(), w, w + RW);
+                    out.n_mul++;
+                    continue;
+                }
+                w[0] = digit_rows ? head(nd.opc, (uint32_t)std::min<size_t>(nd.terms.size(), 14), 0, slot[k] >= 0 ? (uint32_t)slot[k] : 0xffffu)
+                                  : nd.opc | ((slot[k] >= 0 ? (uint32_t)slot[k] : 0xffffu) << 16);
                 w[1] = nd.hint == 0xffffffffu ? 0u : nd.hint + 1;
                 if (digit_rows) {   // 16-word records: the hint slot in 18 bits, the sum of a combination's coefficients above it
                     if (w[1] >= (1u << 18)) throw std::runtime_error("field chain: hint slot index beyond the records' 18 bits");
@@ -731,6 +822,8 @@ struct FieldCompiler {
                 }
                 out.recs.insert(out.recs.end(), w, w + RW);
             }
+            if (conts.size() != n_conts * RW) throw std::runtime_error("field chain: second records miscounted");
+            out.recs.insert(out.recs.end(), conts.begin(), conts.end());
         }
         pad_chunk();
         if (getenv("H2E_FIELD_STATS")) {

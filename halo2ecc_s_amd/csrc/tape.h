@@ -290,7 +290,8 @@ typedef struct H2EPreKernel {
 } H2EPreKernel;
 // field chain record opcodes (field_chain.hpp FieldCompiler::F_*)
 enum H2EFieldOp { H2E_F_NOP = 0, H2E_F_LIN, H2E_F_MUL, H2E_F_DIV, H2E_F_ISZERO, H2E_F_NOT, H2E_F_AND, H2E_F_OR, H2E_F_XNOR, H2E_F_SELECT,
-                  H2E_F_INPUT_W, H2E_F_INPUT_FE, H2E_F_CONST_W, H2E_F_CONST_FE };
+                  H2E_F_INPUT_W, H2E_F_INPUT_FE, H2E_F_CONST_W, H2E_F_CONST_FE,
+                  H2E_F_MULX, H2E_F_CONT };   // a product that computes its operands' linear combinations itself: two records (field_chain.hpp)
 #define H2E_F_MAX_TERMS 6        // 8-word records
 #define H2E_F_MAX_TERMS_WIDE 14   // 16-word records
 // The MSM chains are walked as scans (engine.hip "scan predictors"): a window's sum over its groups in H2E_WIN_CHUNKS
