@@ -3050,6 +3050,9 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
 #ifdef H2E_WAVE_STAMPS
         unsigned long long ft1 = WAVE_STAMP();
 #endif
+#ifdef H2E_EXP_NO_OPS   // timing experiment: rounds without their records (header, prefetch, barrier only)
+        if (false)
+#endif
         for (u32 op = grp; op < cnt; op += H2E_DP_GROUPS) {
             u32 rw = r0;
             if (op != grp) rw = rec_ptr(first % H2E_WCHUNK + op)[j];   // (a round of more than H2E_DP_GROUPS records: the host does not make them)
