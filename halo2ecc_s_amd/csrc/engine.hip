@@ -2815,6 +2815,11 @@ typedef long long i64;
 #define H2E_DP_GROUPS (H2E_DP_WAVES * 4u)
 template <int CTRL>
 WI_INLINE u32 dpp_mov(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
+WI_INLINE u64 mad64_co(u32 a, u32 b, u64 c, u64& carry) {   // a b + c (mod 2^64), bit 64 of the sum as a lane mask
+    u64 r;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 WI_INLINE u32 mad_u32_u16(u32 a16, u32 b16, u32 c) {   // (low 16 bits of a) x (low 16 bits of b) + c
     u32 r;
     asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a16), "v"(b16), "v"(c));
@@ -2899,12 +2904,19 @@ struct DigitRow {
     template <int I>
     WI_INLINE void mont_step(u32 a, u32 b, u32 minv32, u64& T) const {   // digits i = I .. D - 1 of a
         if constexpr (I < D) {
+            // P = a_i b_j + T_j (fits 64 bits: T_j < 3 2^32); m from column 0; Q = m w_j + P with its bit 64 as the multiply-add's
+            // carry-out; T'_j = hi(Q_j) + 2^32 carry_j + lo(Q_j+1).  Nine instructions: written with the carry operands spelled
+            // out, because from `(u64)m * w + (u32)P` the compiler builds zero-extended register pairs with moves (16).
             u32 ai = dpp_mov<H2E_DPP_ROW_BCAST(I)>(a);
-            u64 P = (u64)ai * b + T;
+            u64 c0, cq, c2;
+            u64 P = mad64_co(ai, b, T, c0);
             u32 m = dpp_mov<H2E_DPP_ROW_BCAST(0)>((u32)P * minv32);
-            u64 Q = (u64)m * wj + (u32)P;
+            u64 Q = mad64_co(m, wj, P, cq);
             u32 down = dpp_mov<H2E_DPP_ROW_SHL1>((u32)Q);
-            T = (u64)(u32)(P >> 32) + (u32)(Q >> 32) + down;
+            u32 t_lo = add_co32((u32)(Q >> 32), down, c2);
+            u32 t_hi = addc_co32(0u, 0u, cq);
+            t_hi = addc_co32(t_hi, 0u, c2);
+            T = pack64(t_lo, t_hi);
             mont_step<I + 1>(a, b, minv32, T);
         }
     }
