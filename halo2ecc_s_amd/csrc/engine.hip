@@ -2801,12 +2801,12 @@ __global__ void __launch_bounds__(128) h2e_field_chain(H2EPreKernel K, const u32
 // lanes by DPP (row_shr / row_shl / row_newbcast) without touching LDS.  15 computing waves (60 records per pass) + the
 // loader wave; one s_barrier per round.
 //   linear combination: acc_j = beta_j + sum coef_t * x_t,j  with beta = the digits of a multiple of w that are all >= 2^44
-//     (H2EFieldConsts::lin_bias), so every column stays positive whatever the signs; one carry resolve, quotient estimate from
-//     the two top digits in double precision, q * w by one multiply-add per lane, one borrow resolve, two conditional
-//     subtractions of w.
+//     (H2EFieldConsts::lin_bias), so every column stays positive whatever the signs; quotient estimate from the three top
+//     columns in double precision, E_j = acc_j - q w_j + (a zero-sum bias that keeps the columns positive), ONE carry resolve
+//     (DigitRow::reduce_columns).  Values stay in [0, 2 w): no conditional subtraction anywhere.
 //   Montgomery product: digit-serial (one round per digit of a), the columns are kept as unnormalised 64-bit values between
-//     the rounds - T_j <- lo(Q_j+1) + hi(Q_j) + hi(P_j), P = a_i b_j + T_j, Q = m w_j + lo(P_j) - so the loop has no carry
-//     propagation either; one carry resolve and one conditional subtraction at the end.
+//     the rounds - P = a_i b_j + T_j, Q = m w_j + P with the multiply-add's carry-out as bit 64, T_j <- hi(Q_j) + 2^32 carry_j +
+//     lo(Q_j+1): nine instructions per digit and no carry propagation in the loop; one carry resolve at the end.
 typedef long long i64;
 #define H2E_DPP_ROW_SHL1 0x101
 #define H2E_DPP_ROW_SHR1 0x111
@@ -2815,6 +2815,12 @@ typedef long long i64;
 #define H2E_DP_GROUPS (H2E_DP_WAVES * 4u)
 template <int CTRL>
 WI_INLINE u32 dpp_mov(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+WI_INLINE double dpp_mov_f64(double x) {
+    u64 b = (u64)__double_as_longlong(x);
+    u64 r = pack64(dpp_mov<CTRL>((u32)b), dpp_mov<CTRL>((u32)(b >> 32)));
+    return __longlong_as_double((long long)r);
+}
 WI_INLINE u64 mad64_co(u32 a, u32 b, u64 c, u64& carry) {   // a b + c (mod 2^64), bit 64 of the sum as a lane mask
     u64 r;
     asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "v"(b), "v"(c));
@@ -2843,7 +2849,8 @@ struct DigitRow {
     u32 wj;        // digit j of w (0 above the top digit)
     u64 digits;    // mask: lanes that hold a digit (j < D)
     u64 pmask;     // mask: lanes a borrow may ripple through (j <= D)
-    double inv_top;   // ~ 2^64 / (w's top two digits), see make()
+    double inv_top;   // ~ 1 / (w's top three digits), see make() and reduce_columns()
+    u64 rbias;        // this lane's column of the zero-sum bias of reduce_columns()
     // digits with the carry-out mask G of the addition that made them: the carries go in (never across a row: the lanes
     // above the top digit hold zeros)
     WI_INLINE static u32 carry(u32 d, u64 G) {
@@ -2875,16 +2882,19 @@ struct DigitRow {
         u = subb_co32(u, 0u, B);
         return sel_by_mask(u, r, neg);
     }
-    // columns of a linear combination (lo_j + 2^32 hi_j, everything above the digits zero; below 2^15 w as a number) -> the
-    // value mod w in [0, 2 w): one carry resolve, the quotient from the top three digits in double precision (never above
-    // the true quotient, at most one below), q w by one multiply-add per lane, one more carry resolve, one borrow resolve
+    // columns of a linear combination (c_j = lo_j + 2^32 hi_j < 2^47, everything above the digits zero; below 2^15 w as a
+    // number) -> the value mod w in [0, 2 w), with ONE carry resolve:
+    //   quotient estimate from the three top *columns* as they are (in double precision; never above the true quotient, at
+    //   most one below: inv_top is the reciprocal of w's top three digits, slightly low on purpose);
+    //   E_j = c_j - q w_j + bias_j, the bias K 2^32 - K [j > 0] (- K alone in lane D, K = 2^17) keeps every column positive
+    //   and sums to zero over the lanes; the digits of E are the result (lane D comes out 0, what it pushes up is dropped).
     WI_INLINE u32 reduce_columns(u32 lo, u32 hi) const {
-        u32 v = normalize(lo, hi);   // the overflow digit in lane D
-        u32 o = dpp_mov<H2E_DPP_ROW_BCAST(D)>(v), t1 = dpp_mov<H2E_DPP_ROW_BCAST(D - 1)>(v), t2 = dpp_mov<H2E_DPP_ROW_BCAST(D - 2)>(v);
-        double top = ((double)o * 4294967296.0 + (double)t1) * 4294967296.0 + (double)t2;
+        double cd = (double)hi * 4294967296.0 + (double)lo;
+        double c1 = dpp_mov_f64<H2E_DPP_ROW_BCAST(D - 1)>(cd), c2 = dpp_mov_f64<H2E_DPP_ROW_BCAST(D - 2)>(cd), c3 = dpp_mov_f64<H2E_DPP_ROW_BCAST(D - 3)>(cd);
+        double top = (c1 * 4294967296.0 + c2) * 4294967296.0 + c3;
         u32 qe = (u32)(top * inv_top);
-        u64 qw = (u64)qe * wj;
-        return sub(v, normalize((u32)qw, (u32)(qw >> 32)));
+        u64 E = pack64(lo, hi) + rbias - (u64)qe * wj;
+        return sel_by_mask(0u, normalize((u32)E, (u32)(E >> 32)), digits);
     }
     // this lane's view of the field (digit j of w, masks, the reciprocal of w's top two digits - slightly low on purpose)
     WI_INLINE static DigitRow make(const H2EFieldConsts* fc, u32 lane) {
@@ -2892,8 +2902,11 @@ struct DigitRow {
         R.j = lane & 15u;
         const bool digit_lane = R.j < (u32)D;
         R.wj = digit_lane ? ((const H2E_AS_GLOBAL u32*)fc->w)[digit_lane ? R.j : 0u] : 0u;
-        const double w_top2 = (double)((const H2E_AS_GLOBAL u32*)fc->w)[D - 1] * 4294967296.0 + (double)((const H2E_AS_GLOBAL u32*)fc->w)[D - 2];
-        R.inv_top = (1.0 / (w_top2 + 2.0)) * (1.0 - 0x1p-48);
+        const H2E_AS_GLOBAL u32* wd = (const H2E_AS_GLOBAL u32*)fc->w;
+        const double w_top3 = ((double)wd[D - 1] * 4294967296.0 + (double)wd[D - 2]) * 4294967296.0 + (double)wd[D - 3];
+        R.inv_top = (1.0 / w_top3) * (1.0 - 0x1p-45);
+        constexpr u64 K = 1ull << 17;
+        R.rbias = R.j == 0u ? K << 32 : R.j < (u32)D ? (K << 32) - K : R.j == (u32)D ? 0ull - K : 0ull;
         R.digits = __builtin_amdgcn_ballot_w64(digit_lane);
         R.pmask = __builtin_amdgcn_ballot_w64(R.j <= (u32)D);
         return R;
