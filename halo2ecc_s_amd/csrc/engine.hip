@@ -2848,7 +2848,6 @@ struct DigitRow {
     u32 j;         // this lane's digit index within its row
     u32 wj;        // digit j of w (0 above the top digit)
     u64 digits;    // mask: lanes that hold a digit (j < D)
-    u64 pmask;     // mask: lanes a borrow may ripple through (j <= D)
     double inv_top;   // ~ 1 / (w's top three digits), see make() and reduce_columns()
     u64 rbias;        // this lane's column of the zero-sum bias of reduce_columns()
     // digits with the carry-out mask G of the addition that made them: the carries go in (never across a row: the lanes
@@ -2864,23 +2863,6 @@ struct DigitRow {
         u64 G;
         u32 d = add_co32(lo, up, G);
         return carry(d, G);
-    }
-    WI_INLINE u32 sub(u32 a, u32 b) const {   // a - b of two digit rows, a >= b
-        u64 G;
-        u32 u = sub_co32(a, b, G);
-        u64 P = __builtin_amdgcn_ballot_w64(u == 0u) & pmask;
-        u64 B = (P + (G << 1)) ^ P;
-        return subb_co32(u, 0u, B);
-    }
-    WI_INLINE u32 csub_w(u32 r) const {       // r >= w ? r - w : r
-        u64 G;
-        u32 u = sub_co32(r, wj, G);
-        u64 P = __builtin_amdgcn_ballot_w64(u == 0u) & pmask;
-        u64 B = (P + (G << 1)) ^ P;
-        u64 X = (B >> (D + 1)) & 0x0001000100010001ull;   // the borrow out of each row's number ...
-        u64 neg = (X << 16) - X;                          // ... spread over the row's lanes
-        u = subb_co32(u, 0u, B);
-        return sel_by_mask(u, r, neg);
     }
     // columns of a linear combination (c_j = lo_j + 2^32 hi_j < 2^47, everything above the digits zero; below 2^15 w as a
     // number) -> the value mod w in [0, 2 w), with ONE carry resolve:
@@ -2908,7 +2890,6 @@ struct DigitRow {
         constexpr u64 K = 1ull << 17;
         R.rbias = R.j == 0u ? K << 32 : R.j < (u32)D ? (K << 32) - K : R.j == (u32)D ? 0ull - K : 0ull;
         R.digits = __builtin_amdgcn_ballot_w64(digit_lane);
-        R.pmask = __builtin_amdgcn_ballot_w64(R.j <= (u32)D);
         return R;
     }
     // a b / R mod w for digit rows a, b (zero above the top digit), R = 2^(32 D).  Values live in [0, 2 w): R > 4 w for both
@@ -3249,9 +3230,8 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
 #endif
 }
 // TEST HOOK: the digit-row primitives on caller-supplied rows, one 16-lane row per case (tests/test_digit_rows_gpu.py feeds
-// the patterns random data never produces: runs of 0xffffffff digits under a carry, runs of equal digits under a borrow,
-// quotient estimates on the boundary).  in: [cases][2][16] words, out: [cases][16] words.
-//   op 0: normalize(lo = in0, hi = in1)   1: sub(in0, in1)   2: mont_mul(in0, in1)   3: reduce_columns(lo = in0, hi = in1)
+// the patterns random data never produces: runs of 0xffffffff digits under a carry, quotient estimates on the boundary).  in: [cases][2][16] words, out: [cases][16] words.
+//   op 0: normalize(lo = in0, hi = in1)   2: mont_mul(in0, in1)   3: reduce_columns(lo = in0, hi = in1)
 template <class FP>
 __global__ void __launch_bounds__(64) h2e_digit_rows_selftest(u32 op, u32 n_cases, const u32* __restrict__ in, u32* __restrict__ out) {
     constexpr int D = 2 * FP::WW;
@@ -3263,7 +3243,6 @@ __global__ void __launch_bounds__(64) h2e_digit_rows_selftest(u32 op, u32 n_case
     u32 a = in[((size_t)c * 2 + 0) * 16 + R.j], b = in[((size_t)c * 2 + 1) * 16 + R.j];
     u32 r = 0;
     if (op == 0) r = R.normalize(a, b);
-    else if (op == 1) r = R.sub(a, b);
     else if (op == 2) r = R.mont_mul(a, b, (u32)fc->w_minv);
     else r = R.reduce_columns(a, b);
     if (live) out[(size_t)c * 16 + R.j] = r;

@@ -1,6 +1,6 @@
 """The digit-row primitives of the field-chain kernel (engine.hip DigitRow: one 16-lane DPP row per value, one lane per 32-bit
 digit) against Python integers, on the patterns the parity tests never produce: a carry that has to ripple through a run of
-0xffffffff digits, a borrow through a run of equal digits (each has probability 2^-32 per digit on random data), quotient
+0xffffffff digits (probability 2^-32 per digit on random data), quotient
 estimates on the boundary (exact multiples of w and their neighbours), operands at the ends of the lazy range [0, 2w).
 Through the engine's test hook h2e_engine_digit_rows_selftest_fp<k> (one row per case)."""
 import ctypes as C
@@ -78,33 +78,6 @@ def test_normalize_resolves_carries_through_runs_of_ones(rows, fp):
     for (lo, hi), got in zip(cases, out):
         want = sum((lo[j] + (hi[j] << 32)) << (32 * j) for j in range(D))
         assert _value(got) == want, (lo, hi)
-
-
-@pytest.mark.parametrize("fp", [0, 1])
-def test_sub_resolves_borrows_through_runs_of_equal_digits(rows, fp):
-    D = DIGITS[fp]
-    rnd = random.Random(23 + fp)
-    cases = []
-    for trial in range(400):
-        a = [rnd.getrandbits(32) for _ in range(D + 1)] + [0] * (15 - D)
-        b = [rnd.getrandbits(32) for _ in range(D + 1)] + [0] * (15 - D)
-        if trial % 2 == 0:
-            # equal digits k0 .. k1 - 1 with a borrow generated right below them: it has to ripple through the whole run
-            k0 = rnd.randrange(1, D)
-            k1 = rnd.randrange(k0 + 1, D + 1)
-            for j in range(k0, k1):
-                b[j] = a[j]
-            a[k0 - 1], b[k0 - 1] = 5, 9
-        if trial % 7 == 0:   # 100...0 - 1
-            a, b = [0] * 16, [1] + [0] * 15
-            a[rnd.randrange(1, D + 1)] = 1
-        if _value(a) < _value(b):
-            b[D] = min(b[D], M32 - 1)
-            a[D] = b[D] + 1
-        cases.append((a, b))
-    out = rows(fp, 1, cases)
-    for (a, b), got in zip(cases, out):
-        assert _value(got) == _value(a) - _value(b)
 
 
 @pytest.mark.parametrize("fp", [0, 1])
