@@ -671,6 +671,23 @@ def test_pairing_bls12_381_batch_16(engine, oracle):
         compare_advice(prog, orun, *rows, instance=k)
 
 
+@pytest.mark.parametrize("curve", ["bn256", "bls12_381"])
+def test_pairing_soak_statuses(engine, curve):
+    """Every hint the value chain produces is checked by the expansion that consumes it (a differing hint sets H2E_ST_ARITH) and
+    the circuit itself asserts e(a, b) e(-a, b) = 1: four more batches of fresh inputs through the digit-parallel chain - 256
+    bn256 / 128 bls12-381 checks, ~2 x 10^7 residue operations per batch - must come back with every status word 0."""
+    n_inst = 64 if curve == "bn256" else 32
+    make = synth.pairing_check_bn256_inputs if curve == "bn256" else synth.pairing_check_bls12_381_inputs
+    prog = Program.pairing_check_bn256(emit_shape=False) if curve == "bn256" else Program.pairing_check_bls12_381(emit_shape=False)
+    arrs = engine.alloc(prog, n_inst)
+    for batch in range(4):
+        ins = [make(instance=7000 + 100 * batch + k) for k in range(n_inst)]
+        arrs[3].zero_()
+        engine.run(prog, engine.upload_inputs(prog, np.stack(ins)), *arrs)
+        engine.torch.cuda.synchronize()
+        assert (arrs[3].cpu().numpy() == 0).all(), (batch, arrs[3].cpu().numpy())
+
+
 def test_msm_batch_64_tiles_full_size(engine, oracle):
     """BASELINE configs[1] at its batch size: 64 tiles x 1024 points in one run (110 GB of advice arrays): every status
     word 0 once each tile's expected result is fed back, and the last tile cell for cell against the oracle"""
