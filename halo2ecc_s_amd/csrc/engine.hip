@@ -2998,6 +2998,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
     const u32 grp = wave * 4u + (lane >> 4);
     const H2E_AS_LDS u32* fv32 = (const H2E_AS_LDS u32*)fv;
     const u32 fv_digit_addr = (u32)(size_t)fv32 + j * 4u;   // LDS address of digit j of value slot 0
+    const u32 fv_digit_addr_half = (u32)(size_t)fv32 + (j & 7u) * 4u;   // ... of digit j mod 8 (eight-digit fields: two terms per instruction)
     auto ld_digit = [&](u32 slot) -> u32 {       // digit j of a value slot (whatever lies behind it for the lanes above: masked by the caller)
         return fv32[slot * (u32)D + j];
     };
@@ -3096,22 +3097,42 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                         // round trip per combination, not one per term)
                         auto combine = [&](auto nt_tag) {
                             constexpr int NT = decltype(nt_tag)::value;
-                            u32 x[NT];
-                            int coef[NT];
-                            static_for<0, NT>([&](auto tc) {
-                                constexpr int T = decltype(tc)::value;
-                                u32 term = dpp_mov<H2E_DPP_ROW_BCAST(2 + T)>(rwx);
-                                x[T] = *(const H2E_AS_LDS u32*)(size_t)mad_u32_u16(term, (u32)D * 4u, fv_digit_addr);   // slot (low 16 bits) x 4 D + (slot 0's digit j)
-                                coef[T] = (int)term >> 16;
-                            });
-                            DP_STAMP(1, x[NT - 1]);
-                            i64 acc1 = 0;   // (two chains of multiply-adds instead of one of NT)
+                            if constexpr (D == 8) {
+                                // eight digits leave half of the row idle: lanes 0-7 take the even terms, lanes 8-15 the odd ones
+                                // (digit j - 8), the two half sums meet at the end - half the instructions per term
+                                u32 x[NT / 2];
+                                int coef[NT / 2];
+                                static_for<0, NT / 2>([&](auto tc) {
+                                    constexpr int P = decltype(tc)::value;
+                                    u32 term = (u32)__builtin_amdgcn_update_dpp(0, (int)rwx, H2E_DPP_ROW_BCAST(2 + 2 * P), 0xf, 0x3, true);        // banks 0-1: lanes 0-7
+                                    term = (u32)__builtin_amdgcn_update_dpp((int)term, (int)rwx, H2E_DPP_ROW_BCAST(3 + 2 * P), 0xf, 0xc, true);   // banks 2-3: lanes 8-15
+                                    x[P] = *(const H2E_AS_LDS u32*)(size_t)mad_u32_u16(term, (u32)D * 4u, fv_digit_addr_half);
+                                    coef[P] = (int)term >> 16;
+                                });
+                                DP_STAMP(1, x[NT / 2 - 1]);
+                                if (j >= 8u) acc = 0;   // (beta is zero up there already; the coefficient sum goes in once)
 #pragma unroll
-                            for (int t = 0; t < NT; t += 2) {
-                                acc += (i64)coef[t] * (i64)(int)(x[t] ^ 0x80000000u);
-                                acc1 += (i64)coef[t + 1] * (i64)(int)(x[t + 1] ^ 0x80000000u);
+                                for (int t = 0; t < NT / 2; t++) acc += (i64)coef[t] * (i64)(int)(x[t] ^ 0x80000000u);
+                                u32 up_lo = dpp_mov<0x108>((u32)(u64)acc), up_hi = dpp_mov<0x108>((u32)((u64)acc >> 32));   // row_shl:8: lane j gets lane j + 8
+                                acc += (i64)pack64(up_lo, up_hi);
+                            } else {
+                                u32 x[NT];
+                                int coef[NT];
+                                static_for<0, NT>([&](auto tc) {
+                                    constexpr int T = decltype(tc)::value;
+                                    u32 term = dpp_mov<H2E_DPP_ROW_BCAST(2 + T)>(rwx);
+                                    x[T] = *(const H2E_AS_LDS u32*)(size_t)mad_u32_u16(term, (u32)D * 4u, fv_digit_addr);   // slot (low 16 bits) x 4 D + (slot 0's digit j)
+                                    coef[T] = (int)term >> 16;
+                                });
+                                DP_STAMP(1, x[NT - 1]);
+                                i64 acc1 = 0;   // (two chains of multiply-adds instead of one of NT)
+#pragma unroll
+                                for (int t = 0; t < NT; t += 2) {
+                                    acc += (i64)coef[t] * (i64)(int)(x[t] ^ 0x80000000u);
+                                    acc1 += (i64)coef[t + 1] * (i64)(int)(x[t + 1] ^ 0x80000000u);
+                                }
+                                acc += acc1;
                             }
-                            acc += acc1;
                         };
                         // the term loop of this wave's longest combination (the host sorts a round's records by their length)
 #ifdef H2E_EXP_LIN_TERMS   // timing experiment (wrong sums): every combination as if it had at most that many terms
