@@ -2813,6 +2813,7 @@ typedef long long i64;
 #define H2E_DPP_ROW_BCAST(n) (0x150 + (n))
 #define H2E_DP_WAVES 15u
 #define H2E_DP_GROUPS (H2E_DP_WAVES * 4u)
+#define H2E_DP_CHUNKS 4u   // record chunks in LDS (16 KB each)
 template <int CTRL>
 WI_INLINE u32 dpp_mov(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
 template <int CTRL>
@@ -2936,31 +2937,32 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
     const H2EFieldConsts* fc = &g_fc[FP::ID];
     extern __shared__ ulonglong2 f_dyn[];
     typedef u32 Rec[16];                                     // a record: 16 words
-    Rec* rbuf = (Rec*)f_dyn;                                // [2][H2E_WCHUNK]
-    u64* fv = (u64*)(rbuf + 2 * H2E_WCHUNK);                // [f_slots][N]
+    Rec* rbuf = (Rec*)f_dyn;                                // [H2E_DP_CHUNKS][H2E_WCHUNK]: a ring of record chunks
+    u64* fv = (u64*)(rbuf + H2E_DP_CHUNKS * H2E_WCHUNK);    // [f_slots][N]
     const Rec* recs = (const Rec*)(args + K.f_recs);
     const u32 n_chunks = K.f_n_recs / H2E_WCHUNK;
     auto header = [&](u32 pos, u32& cnt, u32& kind, u32& n_conts) {   // rows of the round, its kind, second records behind the rows
-        const H2E_AS_LDS u32* hp = (const H2E_AS_LDS u32*)(rbuf + (size_t)((pos / H2E_WCHUNK) & 1u) * H2E_WCHUNK + pos % H2E_WCHUNK);
+        const H2E_AS_LDS u32* hp = (const H2E_AS_LDS u32*)(rbuf + (size_t)((pos / H2E_WCHUNK) % H2E_DP_CHUNKS) * H2E_WCHUNK + pos % H2E_WCHUNK);
         u32 meta = __builtin_amdgcn_readfirstlane(hp[0]);
         n_conts = __builtin_amdgcn_readfirstlane(hp[1]);
         cnt = meta & 0xffu;
         kind = (meta >> 8) & 0xffu;
     };
     if (loader) {
-        // follows the round structure (every wave meets at one barrier per round) and keeps one chunk of records ahead: on
-        // entering chunk c - every wave has left chunk c - 1 - it loads chunk c + 1 over it, and waits for that data only
-        // in front of the barrier that ends chunk c's last round
+        // follows the round structure (every wave meets at one barrier per round) and keeps the record stream
+        // H2E_DP_CHUNKS - 1 chunks ahead: on entering chunk c - every wave has left chunk c - 1 - it loads chunk
+        // c + H2E_DP_CHUNKS - 1 over it, and in front of the barrier that ends chunk c's last round it waits for chunk c + 1 only
+        // (the loads complete in order: the younger ones stay in flight).  One chunk ahead (~6 rounds, 7 us) was enough for a
+        // run alone, not next to another run's expansion, when a load can take longer than that.
         auto load_chunk = [&](u32 chunk) {
             const char* src = (const char*)(recs + (size_t)chunk * H2E_WCHUNK);
-            char* dst = (char*)(rbuf + (size_t)(chunk & 1u) * H2E_WCHUNK);
+            char* dst = (char*)(rbuf + (size_t)(chunk % H2E_DP_CHUNKS) * H2E_WCHUNK);
 #pragma unroll
             for (u32 k = 0; k < H2E_WCHUNK * 64u / 1024u; k++)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * 1024u + lane * 16u),
                                                  (__attribute__((address_space(3))) void*)(dst + k * 1024u), 16, 0, 0);
         };
-        load_chunk(0);
-        if (n_chunks > 1) load_chunk(1);
+        for (u32 c = 0; c < H2E_DP_CHUNKS && c < n_chunks; c++) load_chunk(c);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // (every wave looks at the header behind its round BEFORE the round's barrier - a padding header sends it to the next
@@ -2970,7 +2972,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
             u32 chunk = pos / H2E_WCHUNK;
             if (chunk != cur) {
                 cur = chunk;
-                if (chunk + 1 < n_chunks) load_chunk(chunk + 1);
+                if (chunk + H2E_DP_CHUNKS - 1u < n_chunks) load_chunk(chunk + H2E_DP_CHUNKS - 1u);
             }
             u32 cnt, kind, nc;
             header(pos, cnt, kind, nc);
@@ -2980,7 +2982,9 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                 header(pos, c2, k2, m2);
                 if (k2 == 0xffu) pos = (chunk + 1) * H2E_WCHUNK;
             }
-            if (pos / H2E_WCHUNK != chunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chunk's last round
+            // the chunk's last round: the next chunk must be there, the two behind it may still be on their way (16 loads each)
+            static_assert(H2E_DP_CHUNKS == 4u && H2E_WCHUNK * 64u / 1024u == 16u, "the wait below counts the loads of two chunks");
+            if (pos / H2E_WCHUNK != chunk) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             lds_round_barrier_workgroup();
         }
         return;
@@ -3030,7 +3034,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
 #endif
         u32 chunk = pos / H2E_WCHUNK;
         u32 cnt = n_cnt, kind = n_kind, n_conts = n_nc;
-        const Rec* cbuf = rbuf + (size_t)(chunk & 1u) * H2E_WCHUNK;
+        const Rec* cbuf = rbuf + (size_t)(chunk % H2E_DP_CHUNKS) * H2E_WCHUNK;
         auto rec_ptr = [&](u32 at) {   // record `at` of this chunk (a row beyond the round's records reads some record: unused)
             return (const H2E_AS_LDS u32*)(cbuf + (at < H2E_WCHUNK ? at : H2E_WCHUNK - 1u));
         };
@@ -3207,7 +3211,9 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                 // conversion of the whole slot range gives 0 / 1 back)
                 u32 hv = out;
                 if (raw) hv = (dpp_mov<H2E_DPP_ROW_BCAST(0)>(out) & 1u) ? r1j : 0u;
+#ifndef H2E_EXP_NO_HINT_STORES   // (timing experiment: the chain without its global stores)
                 if (digit_lane) ((H2E_AS_GLOBAL u32*)(d.hints + (size_t)(hint - 1) * d.ws))[j] = hv;
+#endif
             }
         }
         n_valid = false;
@@ -4182,7 +4188,7 @@ extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2E
     if (k->kind == H2E_PRE_FIELD_CHAIN) {   /* params_dev carries the constant pool, n_params the words per input slot */          \
         if (phase & 1)                                                                                                              \
         {                                                                                                                           \
-            size_t lds = (size_t)2 * H2E_WCHUNK * (k->f_mode == 1 ? 64 : 32) + (size_t)k->f_slots * FP::WW * 8 + 64;                \
+            size_t lds = (k->f_mode == 1 ? (size_t)H2E_DP_CHUNKS * H2E_WCHUNK * 64 : (size_t)2 * H2E_WCHUNK * 32) + (size_t)k->f_slots * FP::WW * 8 + 64; \
             if (k->f_mode == 1)                                                                                                     \
                 hipLaunchKernelGGL(h2e_field_chain_digits<FP>, dim3(n_instances), dim3((H2E_DP_WAVES + 1) * 64), lds, stream, *k, args_dev, \
                                    (const u64*)params_dev, inst, n_instances);                                                     \
