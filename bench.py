@@ -165,6 +165,9 @@ def run_children(args):
     base = [sys.executable, os.path.abspath(__file__), "--sub", "--suite", "main", "--traffic", "off", "--gpus", "1"]
     jobs = [("pairing_bn256", ["--workload", "pairing_bn256"]),
             ("pairing_bls12_381", ["--workload", "pairing_bls12_381"]),
+            # one GPU's share of configs[3] / configs[4] when the batch is dealt over 8 GPUs: batches smaller than a wave
+            ("pairing_bn256_share8", ["--workload", "pairing_bn256", "--units", "8", "--no-cpu-baseline"]),
+            ("pairing_bls12_381_share8", ["--workload", "pairing_bls12_381", "--units", "2", "--no-cpu-baseline"]),
             ("msm_job_2e20", ["--workload", "msm", "--job-tiles", "1024", "--no-cpu-baseline"]),
             # the headline batch all the way to what halo2 consumes: per-instance advice columns
             ("msm_consumer_ready", ["--workload", "msm", "--ring", "1", "--steps", "3", "--warmup", "1", "--latency-steps", "0", "--consumer-ready", "3",
@@ -184,6 +187,10 @@ def run_children(args):
     return also
 
 
+def job_tiles_mode(args):
+    return bool(args.job_tiles)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,6 +199,10 @@ def main():
     ap.add_argument("--workload", default="msm", choices=sorted(DEFAULT_UNITS))
     ap.add_argument("--units", "--tiles", type=int, default=None, help="units per GPU: MSM tiles (64 x 1024 = 2^16 points) / pairing instances")
     ap.add_argument("--points", type=int, default=1024, help="points per MSM tile")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --units per GPU at every N; strong: BASELINE's totals (64 MSM tiles / 64 bn256 checks / 16 bls12_381 checks, or --total-units) "
+                         "dealt round-robin over the N ranks (SURVEY 8d items 4-5: 8 bn256 / 2 bls12_381 checks per GPU at N = 8; shares may be ragged)")
+    ap.add_argument("--total-units", type=int, default=None, help="--scaling strong: units of the whole job (default: the workload's BASELINE batch)")
     ap.add_argument("--ring", type=int, default=None, help="output-buffer sets steps rotate through = runs in flight (default: 2 for the MSM - step k+1's value chain runs under "
                     "step k's expansion, 2 x 110 GB of arrays; 8 / 16 for the bn256 / bls12_381 pairing checks, whose value chains are latency-bound; 1: h2e_run, no overlap)")
     ap.add_argument("--digest", action="store_true", help="consume every step's arrays with the stream digest (h2e_submit_digest; streaming-job mode, configs[2])")
@@ -243,6 +254,15 @@ def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "32" if args.ring > 8 else "16")
     if world > 1 and args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    total_units = None
+    if args.scaling == "strong":
+        if job_tiles_mode(args):
+            sys.exit("bench.py: --job-tiles is a job of fixed size already (strong by construction)")
+        total_units = args.total_units or DEFAULT_UNITS[args.workload]
+        # this rank's share: unit indices rank, rank + world, ... (halo2ecc_s_amd.parallel.shard_units)
+        args.units = len(range(rank, total_units, world))
+        if args.units == 0:
+            sys.exit(f"bench.py: rank {rank} has no unit of {total_units} (more ranks than units)")
 
     also = None
     if args.suite == "all" and rank == 0 and world == 1 and not args.pmc_child and not args.sub:
@@ -254,10 +274,13 @@ def main():
     # MSM tiles are generated by a process pool *before* this process initialises HIP (fork is only safe until then).
     job_mode = bool(args.job_tiles)
     n_batches = args.steps if job_mode else 2
-    first_of = lambda bi: (bi * world + rank) * units   # noqa: E731
+    # units of one step over all ranks, and the global index of this rank's unit t of step / batch k (weak: rank-major blocks
+    # of `units`; strong: round-robin shares of BASELINE's batch, possibly ragged)
+    T = total_units if total_units is not None else units * world
+    gidx = (lambda k, t: k * T + rank + t * world) if total_units is not None else (lambda k, t: (k * world + rank) * units + t)   # noqa: E731
     host_batches = None
     if args.workload == "msm":
-        jobs = [(n, first_of(bi) + t) for bi in range(n_batches) for t in range(units)]
+        jobs = [(n, gidx(bi, t)) for bi in range(n_batches) for t in range(units)]
         workers = max(1, min(64, (os.cpu_count() or 1) // max(1, world), len(jobs)))
         if workers > 1 and len(jobs) >= 16:
             with concurrent.futures.ProcessPoolExecutor(workers) as ex:
@@ -315,17 +338,19 @@ def main():
             print(f"bench.py: first-touch pass skipped ({str(e).splitlines()[0]})", file=sys.stderr)
     bufs = [eng.alloc(prog, units) for _ in range(ring)]   # (base, range, select, status) per ring slot
     out_refs = prog.outputs()
-    L = 3
+    # the MSM's result point as cell references (x limbs, x native, y limbs, y native, z): 3-limb coordinates for bn256, 4-limb
+    # ones for a bls12_381 tile; a pairing check has no result point (its records carry status, Offset and digests)
+    point_refs = out_refs if args.workload == "msm" else []
+    L = (len(point_refs) - 3) // 2 if point_refs else 3
 
     batches = []
     for bi in range(n_batches):
-        first = first_of(bi)
         if args.workload == "msm":
             ins = host_batches[bi]
         elif args.workload == "pairing_bn256":
-            ins = np.stack([synth.pairing_check_bn256_inputs(instance=first + t) for t in range(units)])
+            ins = np.stack([synth.pairing_check_bn256_inputs(instance=gidx(bi, t)) for t in range(units)])
         else:
-            ins = np.stack([synth.pairing_check_bls12_381_inputs(instance=first + t) for t in range(units)])
+            ins = np.stack([synth.pairing_check_bls12_381_inputs(instance=gidx(bi, t)) for t in range(units)])
         d_in = eng.upload_inputs(prog, ins)
         if args.workload == "msm" and not args.pmc_child:
             # pass 0: learn each tile's MSM result, then feed it back as the `expected` input so that the in-circuit
@@ -358,14 +383,15 @@ def main():
     # Per-unit records {status, Offset, result point cells, 32-byte digest per advice array} of every timed step, built on the
     # device as the steps retire (no host synchronisation), gathered ONCE at the end of the timed region: the one collective
     # of the path (RCCL all_gather over xGMI).  Global unit index of step k's unit t on this rank:
-    # (k * world + rank) * units + t.
+    # gidx(k, t).
     want_records = world > 1 or args.digest or args.dump_records
-    R = parallel.record_words(3)
+    R = parallel.record_words(L)
     job_rec = torch.zeros((max(1, args.steps), units, R), dtype=torch.int64, device=dev) if want_records else None
+    scratch_rec = torch.zeros((units, R), dtype=torch.int64, device=dev) if want_records else None
     plan = None
     if want_records:
-        mine = [(k * world + rank) * units + t for k in range(args.steps) for t in range(units)]
-        plan = parallel.GatherPlan(mine, args.steps * world * units, world, coll_dev)
+        mine = [gidx(k, t) for k in range(args.steps) for t in range(units)]
+        plan = parallel.GatherPlan(mine, args.steps * T, world, coll_dev)
 
     def consume(slot, k):
         """what happens to a finished step's arrays: status OR, optional on-device digest (the consumer of a streaming
@@ -374,8 +400,9 @@ def main():
         status_any.bitwise_or_(status)
         if args.digest:   # (the stream digest was accumulated by the run itself: nothing to launch here)
             digest_any[0] = digests[slot]
-        if want_records and timing[0]:
-            parallel.unit_records(status, offsets, base, out_refs, digests[slot] if args.digest else None, out=job_rec[k - timed_from[0]])
+        if want_records:   # (warm-up steps write a scratch row: torch loads its indexing kernels on first use - tens of ms)
+            row = job_rec[k - timed_from[0]] if timing[0] else scratch_rec
+            parallel.unit_records(status, offsets, base, point_refs, digests[slot] if args.digest else None, out=row, limbs=L)
 
     launch_ms = []      # per timed step: (value chain ms, expansion ms) per launched segment, from the engine's HIP events
     timed_from = [0]
@@ -429,6 +456,12 @@ def main():
     if args.warmup > 0 and not args.no_check and not args.pmc_child:
         assert int(status_any.abs().max()) == 0, f"unit status {status_any.cpu().numpy()}"
 
+    if want_records:
+        # The job's one collective, once outside the timed region: the first call loads torch's gather / scatter kernels (and
+        # opens RCCL's rings) - 150 ms of one-off host work that round 3's 16-step job paid inside its timed region (the
+        # driver's 27.5 vs the 16.4 ms per step its kernel trace shows)
+        parallel.gather_records(plan, job_rec.reshape(-1, R).to(coll_dev))
+        torch.cuda.synchronize()
     eng.set_profiling(True)
     timing[0] = True
     timed_from[0] = step_no[0]
@@ -503,7 +536,7 @@ def main():
     dom_n = eng.last_run_expansion_launches()[dom]
     if traffic:
         traffic = dominant_traffic(traffic, dom_n)
-    total_cells = cells_per_unit * units * world * args.steps
+    total_cells = cells_per_unit * T * args.steps
     # a big expansion goes out as two back-to-back kernel launches over a prefix / the rest of its sub-ranges (h2e.h):
     # the events bracket both, so the per-launch figures are bracket / n and bytes / n
     dom_ms = float(np.mean([ms[dom][1] for ms in launch_ms])) / dom_n
@@ -530,8 +563,9 @@ def main():
         # replay): that kernel is the time-dominant one, priced against the bytes of the cells it is the critical path of
         c_ach = dom_bytes * dom_n / (chain_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": c_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c_ach / HBM_PEAK_GBS, "traffic": None,
-                "kernel": f"h2e_field_chain<{fpname}> (+ h2e_field_finalize, h2e_hint_store: the value chain the expansion waits for - residues mod w, "
-                          "~4.5 k dependent rounds, latency-bound; priced against the algorithmic bytes of the cells it is the critical path of)",
+                "kernel": f"h2e_field_chain_digits<{fpname}> (+ h2e_field_finalize, h2e_field_sinks, h2e_hint_store: the value chain the expansion waits for - "
+                          "residues mod w, one dependent round per level of the program, latency-bound; priced against the algorithmic bytes of the cells it is "
+                          "the critical path of)",
                 "launch_ms": chain_ms, "algorithmic_bytes_per_launch": dom_bytes * dom_n, "launches_per_step": 1, "expansion": x_roof}
     else:
         roof = x_roof
@@ -546,11 +580,11 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
-        "config": {"workload": desc, "units_per_gpu": units, "cells_per_unit": cells_per_unit,
+        "config": {"workload": desc, "units_per_gpu": units, "units_per_step_all_gpus": T, "cells_per_unit": cells_per_unit,
                    "pipeline": f"ring of {ring} output-buffer sets, steps submitted with h2e_submit" if ring > 1 else "h2e_run, one step after the other",
                    "sharding": f"units round-robin over {world} GPU(s); one all_gather of the job's per-unit records at the end of the timed region"},
         "single_batch_ms": single_ms,
@@ -561,7 +595,7 @@ def main():
         "roofline": roof,
     }
     if args.workload == "msm":
-        out["msm_points_per_sec"] = n * units * world * args.steps / elapsed
+        out["msm_points_per_sec"] = n * T * args.steps / elapsed
         out["config"].update(tiles_per_gpu=units, points_per_tile=n, cells_per_tile=cells_per_unit,
                              points_note="per-tile-batch rate; the test body's assign_point / assign rows are part of every tile")
     if args.digest:
@@ -574,9 +608,10 @@ def main():
             tiles = [int(x) for x in args.dump_tiles.split(",") if x != ""]
             keep = {}
             for t in tiles:   # inputs of global tile t, if this rank ran it (single-GPU tests: always)
-                k, rem = divmod(t, world * units)
-                if rem // units == rank and k < n_batches:
-                    keep[f"inputs_{t}"] = batches[k][rem % units].cpu().numpy().view(np.uint64)
+                for k in range(n_batches):
+                    for lt in range(units):
+                        if gidx(k, lt) == t:
+                            keep[f"inputs_{t}"] = batches[k][lt].cpu().numpy().view(np.uint64)
             np.savez(args.dump_records, records=gathered.cpu().numpy(), **keep)
     if traffic:
         x_roof["traffic_detail"] = traffic
@@ -594,6 +629,16 @@ def main():
         out["also"] = also
         if out["consumer_ready_ms_per_step"] is None:   # measured by the child that has the memory for it (one buffer set + the column arrays)
             out["consumer_ready_ms_per_step"] = also.get("msm_consumer_ready", {}).get("consumer_ready_ms_per_step")
+    # LAST key: every config's headline in a few hundred bytes, so that a truncated tail of the line still carries all of them:
+    # [ms_per_step, single_batch_ms, whole-step fraction of the HBM roof, dominant kernel's roofline fraction]
+    brief = lambda d: [round(d["ms_per_step"], 3), None if d.get("single_batch_ms") is None else round(d["single_batch_ms"], 3),   # noqa: E731
+                       round(d["whole_step"]["frac"], 4), round(d["roofline"]["frac"], 4)]
+    summary = {"columns": ["ms_per_step", "single_batch_ms", "whole_step_frac", "roofline_frac"], "msm_2e16" if not job_mode else "msm_job": brief(out)}
+    for name, blk in (also or {}).items():
+        summary[name] = brief(blk) if "ms_per_step" in blk else blk.get("error", "failed")[:80]
+    if out.get("consumer_ready_ms_per_step") is not None:
+        summary["consumer_ready_ms_per_step"] = round(out["consumer_ready_ms_per_step"], 3)
+    out["summary"] = summary
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

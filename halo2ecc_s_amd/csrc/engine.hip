@@ -2203,7 +2203,8 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_hint_store(H2ELaunch 
             if (coef < 0) xn = wd_sub<4>(n, xn);   // -x = n - x (in (0, n])
             wd_mac_small<4>(nat, xn, m);
         }
-        // nat < (1 + 255 * 127) n: small-quotient reduction
+        // nat < 2^12 n (the host rejects a combination whose |coefficients| sum to 4096 or more, field_chain.hpp HintStore::compile:
+        // the top word taken below is 64 bits): small-quotient reduction
         Fe natr;
         {
             constexpr int SH = NK - 52;
@@ -2813,7 +2814,7 @@ typedef long long i64;
 #define H2E_DPP_ROW_BCAST(n) (0x150 + (n))
 #define H2E_DP_WAVES 15u
 #define H2E_DP_GROUPS (H2E_DP_WAVES * 4u)
-#define H2E_DP_CHUNKS 4u   // record chunks in LDS (16 KB each)
+// (H2E_DP_CHUNKS - record chunks in LDS, 16 KB each - lives in tape.h: the host compiler budgets the LDS with it)
 template <int CTRL>
 WI_INLINE u32 dpp_mov(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
 template <int CTRL>
@@ -2984,7 +2985,13 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
             }
             // the chunk's last round: the next chunk must be there, the two behind it may still be on their way (16 loads each)
             static_assert(H2E_DP_CHUNKS == 4u && H2E_WCHUNK * 64u / 1024u == 16u, "the wait below counts the loads of two chunks");
-            if (pos / H2E_WCHUNK != chunk) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            // (in the tail no younger loads were issued behind chunk + 1: the count to leave in flight shrinks with them - a
+            // fixed vmcnt(32) would let the last two chunks go unwaited-for)
+            if (pos / H2E_WCHUNK != chunk) {
+                if (chunk + 3u < n_chunks) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                else if (chunk + 2u < n_chunks) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             lds_round_barrier_workgroup();
         }
         return;

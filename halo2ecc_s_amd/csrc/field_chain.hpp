@@ -671,8 +671,9 @@ struct FieldCompiler {
             }
         }
         if (n_slots >= 0xfff0) { out.why = "too many value slots"; return false; }
-        // the kernels keep two record chunks and every value slot in LDS (160 KB per workgroup on gfx950)
-        if ((size_t)2 * H2E_WCHUNK * RW * 4 + (size_t)n_slots * w_words * 8 + 64 > (size_t)160 * 1024) {
+        // the kernels keep their record chunks (a ring of H2E_DP_CHUNKS for the digit-row kernel, two for the lane kernel) and
+        // every value slot in LDS (160 KB per workgroup on gfx950)
+        if ((size_t)(digit_rows ? H2E_DP_CHUNKS : 2u) * H2E_WCHUNK * RW * 4 + (size_t)n_slots * w_words * 8 + 64 > (size_t)160 * 1024) {
             out.why = "the value slots (" + std::to_string(n_slots) + ") do not fit the LDS";
             return false;
         }
@@ -1119,7 +1120,13 @@ struct StoreCompiler {
                     if (local) break;
                     const Lin& e = flatten(out, i);
                     std::vector<uint32_t> terms;
-                    for (auto& kv : e.leaf) terms.push_back(term(kv.first, kv.second));
+                    long weight = 1;   // the native sum is below (1 + sum |coef|) n; the kernel's quotient estimate (h2e_hint_store, H2E_S_LIN)
+                                       // takes one 64-bit word off its top: good below 2^12 n
+                    for (auto& kv : e.leaf) {
+                        terms.push_back(term(kv.first, kv.second));
+                        weight += std::abs(kv.second);
+                    }
+                    if (weight >= 4096) { out.why = "hint store: a combination's coefficients sum to 4096 or more"; return false; }
                     emit(H2E_S_LIN, k_of(out, e), op.base_row, 0, terms);
                 } break;
                 case H2E_OP_IS_INT_ZERO: case H2E_OP_NOT:

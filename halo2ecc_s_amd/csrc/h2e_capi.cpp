@@ -1987,14 +1987,31 @@ struct h2e_ctx {
     // Operator API: programs of the ops recorded so far, keyed by (op, arguments, operand handles, cursors, heights, msm prefix):
     // a records object that repeats an op sequence (the next batch of the same circuit) re-uses them - no host-side recording,
     // no new device tapes.  `outs` = the handles the op returned, byte for byte.
+    // The cache is bounded (keys hold value-dependent arguments - constants, offsets - so a long-lived context would otherwise
+    // keep one program with its device tapes per distinct key): at `op_cache_cap` entries the least recently used ones that no
+    // call is running go (H2E_OP_CACHE_CAP, default 4096; a proving loop's working set is its ops per batch).
     struct OpEntry {
         h2e_program* prog = nullptr;
         std::vector<std::vector<uint8_t>> outs;
         size_t msm_prefix_after = 0;
+        uint64_t last_use = 0;
+        uint32_t in_use = 0;
     };
     std::map<std::string, OpEntry> op_cache;
     std::mutex op_mu;
-    uint64_t op_hits = 0, op_misses = 0;
+    uint64_t op_hits = 0, op_misses = 0, op_tick = 0, op_evictions = 0;
+    size_t op_cache_cap = 4096;
+    void op_cache_trim() {   // (op_mu held)
+        while (op_cache.size() > op_cache_cap) {
+            auto victim = op_cache.end();
+            for (auto it = op_cache.begin(); it != op_cache.end(); ++it)
+                if (it->second.in_use == 0 && (victim == op_cache.end() || it->second.last_use < victim->second.last_use)) victim = it;
+            if (victim == op_cache.end()) break;
+            delete victim->second.prog;   // (frees its device tapes: hipFree waits for the work that still reads them)
+            op_cache.erase(victim);
+            op_evictions++;
+        }
+    }
     ~h2e_ctx() {
         for (auto& kv : op_cache) delete kv.second.prog;
         for (auto& kv : cache) delete kv.second;
@@ -2036,6 +2053,7 @@ int h2e_ctx_create(int device, h2e_ctx** out) {
         }
     }
     if (const char* e5 = getenv("H2E_SCHED")) c->sched = (uint32_t)atoi(e5);
+    if (const char* e8 = getenv("H2E_OP_CACHE_CAP")) c->op_cache_cap = (size_t)std::max(1, atoi(e8));
     if (const char* e7 = getenv("H2E_SMALL_X_LANES")) c->small_x_lanes = (uint64_t)atoll(e7);
     if (const char* e6 = getenv("H2E_CU_RESERVE")) sscanf(e6, "%u,%u,%u,%u", &c->cu_reserve, &c->cu_fixup_side, &c->cu_pattern, &c->cu_chain_all);
     if (const char* e3 = getenv("H2E_STREAM_PRIORITIES")) sscanf(e3, "%d,%d,%d", &c->prio_expand, &c->prio_side, &c->prio_fixup);
@@ -2933,6 +2951,13 @@ int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value) {
             if (e != hipSuccess) return fail(H2E_ERR_HIP, std::string("prefault: ") + hipGetErrorString(e));
             return 0;
         }
+        case H2E_OPT_OP_CACHE_CAP: {
+            if (value < 1) return fail(H2E_ERR_INVALID, "op cache capacity must be at least 1");
+            std::lock_guard<std::mutex> g2(ctx->op_mu);
+            ctx->op_cache_cap = (size_t)value;
+            ctx->op_cache_trim();
+            return 0;
+        }
         default: return fail(H2E_ERR_INVALID, "unknown option");
     }
 }
@@ -2954,6 +2979,14 @@ int64_t h2e_ctx_get_stat(h2e_ctx* ctx, int stat) {
         case H2E_STAT_OP_CACHE_MISSES: {
             std::lock_guard<std::mutex> g2(ctx->op_mu);
             return (int64_t)ctx->op_misses;
+        }
+        case H2E_STAT_OP_CACHE_EVICTIONS: {
+            std::lock_guard<std::mutex> g2(ctx->op_mu);
+            return (int64_t)ctx->op_evictions;
+        }
+        case H2E_STAT_OP_CACHE_SIZE: {
+            std::lock_guard<std::mutex> g2(ctx->op_mu);
+            return (int64_t)ctx->op_cache.size();
         }
         default: return -1;
     }
@@ -3308,6 +3341,18 @@ int records_op(h2e_records* R, const std::string& key, uint32_t n_slots, const v
         full.append((const char*)st, sizeof(st));
     }
     h2e_program* p = nullptr;
+    size_t prefix_after = R->msm_prefix;   // (applied when the op has run: a failing op leaves the records' state as it was)
+    struct Release {   // the entry cannot be evicted while this call runs its program
+        h2e_ctx* ctx;
+        const std::string* key;
+        bool held = false;
+        ~Release() {
+            if (!held) return;
+            std::lock_guard<std::mutex> g(ctx->op_mu);
+            auto it = ctx->op_cache.find(*key);
+            if (it != ctx->op_cache.end() && it->second.in_use) it->second.in_use--;
+        }
+    } release{ctx, &full};
     {
         std::lock_guard<std::mutex> g(ctx->op_mu);
         auto it = ctx->op_cache.find(full);
@@ -3318,14 +3363,16 @@ int records_op(h2e_records* R, const std::string& key, uint32_t n_slots, const v
                 if (o.ptr && k < it->second.outs.size() && it->second.outs[k].size() == o.bytes) std::memcpy(o.ptr, it->second.outs[k].data(), o.bytes);
                 k++;
             }
-            R->msm_prefix = it->second.msm_prefix_after;
+            prefix_after = it->second.msm_prefix_after;
+            it->second.last_use = ++ctx->op_tick;
+            it->second.in_use++;
+            release.held = true;
             ctx->op_hits++;
         }
     }
     if (!p) {
         std::unique_ptr<h2e_program> np(new h2e_program());
         np->field_pair = R->field_pair;
-        size_t prefix_after = R->msm_prefix;
         try {
             np->rec.reset(new h2e::Recorder(field_pair(R->field_pair)));
             h2e::Recorder& r = *np->rec;
@@ -3348,7 +3395,6 @@ int records_op(h2e_records* R, const std::string& key, uint32_t n_slots, const v
         }
         if (np->base_rows > R->cap[0] || np->range_rows > R->cap[1] || np->select_rows > R->cap[2])
             return fail(H2E_ERR_SHAPE, "records: the op does not fit the arrays' capacity (like HALO2ECC_S_MAX_ROWS, src/context.rs:36)");
-        R->msm_prefix = prefix_after;
         std::lock_guard<std::mutex> g(ctx->op_mu);
         h2e_ctx::OpEntry& e = ctx->op_cache[full];
         if (!e.prog) {
@@ -3357,7 +3403,11 @@ int records_op(h2e_records* R, const std::string& key, uint32_t n_slots, const v
             e.msm_prefix_after = prefix_after;
             ctx->op_misses++;
         }
+        e.last_use = ++ctx->op_tick;
+        e.in_use++;
+        release.held = true;
         p = e.prog;
+        ctx->op_cache_trim();
     }
     if (p->base_rows > R->cap[0] || p->range_rows > R->cap[1] || p->select_rows > R->cap[2])
         return fail(H2E_ERR_SHAPE, "records: the op does not fit the arrays' capacity (like HALO2ECC_S_MAX_ROWS, src/context.rs:36)");
@@ -3376,6 +3426,7 @@ int records_op(h2e_records* R, const std::string& key, uint32_t n_slots, const v
         rc = h2e_run(ctx, p, R->n_instances, in, R->d_arr[0], R->d_arr[1], R->d_arr[2], R->d_status, stream);
     }
     if (rc) return rc;
+    R->msm_prefix = prefix_after;
     // merge (ParallelClone::merge + apply_offset_diff)
     uint64_t before[3] = {R->off[0], R->off[1], R->off[2]};
     R->off[0] = r.base_offset;

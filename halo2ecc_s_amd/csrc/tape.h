@@ -249,6 +249,8 @@ enum H2EVOpcode {
 #define H2E_V_NO_SLOT 0xffu
 #define H2E_LEVEL_WAVES 4u   // waves of a level-parallel replay workgroup (they share one instance's value slots)
 #define H2E_WCHUNK 256u      // wave mode: records per LDS chunk buffer; a round never straddles a chunk (host pads with H2E_V_NOP)
+#define H2E_DP_CHUNKS 4u     // digit-parallel field chain: record chunks the kernel keeps in LDS (a ring, 16 KB each); the host's
+                             // LDS budget check (field_chain.hpp) and the launcher (engine.hip) size from this one constant
 
 // ---- value-predictor ("V") kernels for the MSM ---------------------------------------------------
 // They run native Montgomery / Jacobian arithmetic over the same inputs, write numerator/denominator pairs of

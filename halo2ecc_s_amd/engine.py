@@ -18,6 +18,7 @@ FORM_CANONICAL, FORM_MONTGOMERY = 0, 1
 OPT_X_SPLIT_PCT, OPT_X_SPLIT_MIN_LANES, OPT_TEST_SKIP_EXPANSION, OPT_PIPELINE_DEPTH, OPT_TEST_SCAN_FALLBACK = 1, 2, 3, 4, 5
 STAT_LAST_SPLIT_SEGMENTS, STAT_RUNS, STAT_PIPELINE_DEPTH, STAT_MAX_PIPELINE_DEPTH, STAT_SCAN_FALLBACKS = 1, 2, 3, 4, 5
 OPT_PREFAULT_HBM = 6
+OPT_OP_CACHE_CAP = 7
 OPT_OFF = -(1 << 63)
 COLS = (5, 3, 2)
 
@@ -81,7 +82,7 @@ INT_ADD, INT_SUB, INT_MUL, INT_DIV, INT_REDUCE = 0, 1, 2, 3, 4
 INT_NEG, INT_SQUARE, INT_UNSAFE_INVERT, INT_IS_ZERO, INT_IS_EQUAL, INT_ASSERT_EQUAL = 5, 6, 7, 8, 9, 10
 (FQ_ADD, FQ_SUB, FQ_MUL, FQ_SQUARE, FQ_NEG, FQ_DOUBLE, FQ_CONJUGATE, FQ_UNSAFE_INVERT, FQ_MUL_BY_NONRESIDUE, FQ_FROBENIUS_MAP,
  FQ_CYCLOTOMIC_SQUARE, FQ_REDUCE, FQ_ASSERT_EQUAL) = range(13)
-STAT_OP_CACHE_HITS, STAT_OP_CACHE_MISSES = 6, 7
+STAT_OP_CACHE_HITS, STAT_OP_CACHE_MISSES, STAT_OP_CACHE_EVICTIONS, STAT_OP_CACHE_SIZE = 6, 7, 8, 9
 
 _lib = None
 

@@ -178,6 +178,8 @@ int h2e_wait(h2e_ctx* ctx, int job, void* stream);
                                           (synchronous, ~0.3 s for 270 GB).  The first process that streams into HBM nobody has
                                           written since the device booted runs at about half the rate of any later one; a host
                                           that cares about its first runs calls this once after h2e_ctx_create. */
+#define H2E_OPT_OP_CACHE_CAP 7           /* operator API: programs the context keeps for ops it has seen (default 4096, >= 1).  Beyond it the
+                                          least recently used programs that no call is running are freed with their device tapes. */
 int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value);
 #define H2E_STAT_LAST_SPLIT_SEGMENTS 1 /* segments of the last run whose expansion went out as two launches */
 #define H2E_STAT_RUNS 2
@@ -186,6 +188,8 @@ int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value);
 #define H2E_STAT_SCAN_FALLBACKS 5      /* lanes of the MSM scan predictors that had to walk the real chain so far (process-wide; synchronises) */
 #define H2E_STAT_OP_CACHE_HITS 6       /* operator API: ops whose program came from the context's cache (keyed by op, arguments, */
 #define H2E_STAT_OP_CACHE_MISSES 7     /* operand handles, cursors, heights, msm prefix) / ops that had to be recorded */
+#define H2E_STAT_OP_CACHE_EVICTIONS 8  /* programs the cache let go (H2E_OPT_OP_CACHE_CAP) */
+#define H2E_STAT_OP_CACHE_SIZE 9
 int64_t h2e_ctx_get_stat(h2e_ctx* ctx, int stat);
 
 /* Named entry points of SURVEY.md §8(b): build-or-reuse the program for the shape, then run it. */
