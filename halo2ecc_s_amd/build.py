@@ -23,7 +23,8 @@ def build(force=False, verbose=True):
     deps = [os.path.join(CSRC, d) for d in DEPS]
     objs = []
     running = []
-    units = [("engine.hip", f"engine_fp{k}.o", [f"-DH2E_FP_ONLY={k}"]) for k in range(3)] + [("h2e_capi.cpp", "h2e_capi.o", [])]
+    units = ([("engine.hip", f"engine_fp{k}.o", [f"-DH2E_FP_ONLY={k}"]) for k in range(3)] + [("h2e_capi.cpp", "h2e_capi.o", [])]
+             + [("checker.hip", "checker.o", [])])   # the device-side constraint check: a unit of its own, no code shared with the engine
     for src, obj, defs in units:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, obj)

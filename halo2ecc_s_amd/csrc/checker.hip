@@ -15,6 +15,7 @@
 // cells of a row are the same address for every lane of that row.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/h2e.h"
 #include "tape.h"
 
 typedef uint64_t u64;

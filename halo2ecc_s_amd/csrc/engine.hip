@@ -913,10 +913,14 @@ WI_INLINE void op_bisec_int(const LC& c, const H2EOp& op) {
     Fe cond = ld_fe(c, op.refs[0]);
     bool take_a = !wd_is_zero<4>(cond);
     u32 r = op.base_row;
+    static_assert(H2E_MAX_L == 4 && H2E_OP_MAX_REFS >= 11, "b's references start at 5 (three limbs) or 6 (four)");
 #pragma unroll
     for (int i = 0; i <= H2E_MAX_L; i++) {
         if (i <= L) {
-            Fe av = ld_fe(c, op.refs[1 + i]), bv = ld_fe(c, op.refs[1 + L + 1 + i]);
+            // (constant indices only: where the op is per-lane data - the packed expansion - a runtime index would send the whole
+            // reference array to scratch memory)
+            const u32 rb = L == 3 ? op.refs[i + 5 <= 10 ? i + 5 : 10] : op.refs[i + 6 <= 10 ? i + 6 : 10];
+            Fe av = ld_fe(c, op.refs[1 + i]), bv = ld_fe(c, rb);
             ROW_B4(c, r + i, cond, av, cond, bv, take_a ? av : bv);
         }
     }
@@ -1253,6 +1257,131 @@ __global__ void __launch_bounds__(64, H2E_X_WAVES) h2e_run_tape(H2ELaunch L, con
             if (v) atomicAdd((unsigned long long*)(L.dg_out + (((size_t)(blockIdx.x & (L.dg_shards - 1u)) * 3 + k / 4) * n_instances + instance) * 4 + (k % 4)), (unsigned long long)v);
         }
     }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packed expansion: batches smaller than a wave.  h2e_run_tape's lanes are (strand, instance) of ONE sub-range, so a launch
+// with n_strands x n_instances < 64 - a pairing check has one strand: 16 bls12_381 checks per GPU (configs[4]), 8 bn256 / 2
+// bls12_381 checks when the batch is dealt over 8 GPUs - leaves most of every wave instruction idle and stores 256 / 128 / 32-byte
+// runs.  Here a wave takes G = 64 / P sub-ranges at once (P = the lanes of one sub-range rounded up to a power of two): lane
+// = (group, instance).  The groups run different op sequences, so an op is per-lane data (rows and cell references in VGPRs)
+// and the wave executes one opcode at a time: every group looks at the op at its own cursor, the wave picks the LIGHTEST
+// opcode any cursor shows and runs it for the groups that show it.  Light ops (additions, selections, conditions) so run ahead
+// until every cursor stands at a multiplication-like op (int_mul / div / reduce: 3/4 of the cells), and those run for all groups
+// in one pass - the wave synchronises itself on the heavy ops without any host-side alignment of the sub-ranges.
+// Op records reach the lanes through LDS: each group keeps a chunk of H2E_PK_CH ops, refilled by the group's own lanes.
+#define H2E_PK_CH 8u
+// opcodes from light to heavy (cells an op writes ~ the instructions it costs)
+static __constant__ unsigned char g_pk_rank_of[H2E_OP_COUNT] = {
+    /* NOP */ 0, /* ASSIGN_W */ 20, /* ASSIGN */ 1, /* ASSIGN_BIT */ 2, /* CONST_INT */ 12, /* CONST_INT_INPUT */ 13, /* CONST */ 3,
+    /* INT_ADD */ 14, /* INT_SUB */ 15, /* INT_NEG */ 16, /* INT_MUL_SMALL */ 17, /* INT_MUL */ 30, /* REDUCE */ 28, /* IS_INT_ZERO */ 22,
+    /* NOT */ 4, /* MASK_INT */ 18, /* DIV_CORE */ 31, /* BISEC_INT */ 19, /* SUM_LIMBS */ 5, /* ASSERT_CONST */ 6, /* BISEC */ 7, /* AND */ 8,
+    /* OR */ 9, /* XNOR */ 10, /* DECOMPOSE_NATIVE */ 26, /* PICK_INDEX */ 11, /* CACHE_INT */ 21, /* SELECT_POINT */ 23,
+    /* DECOMPOSE_LIMB */ 25, /* SHIFT_ADD */ 24};
+static_assert(H2E_OP_COUNT == 30, "g_pk_rank_of lists every opcode of tape.h");
+template <class FP>
+__global__ void __launch_bounds__(64) h2e_run_tape_packed(H2ELaunch L, const InstanceDesc* inst, u32 n_instances, u32 log2p) {
+    __shared__ u32x4 opbuf[32 * H2E_PK_CH * 4];   // [group][op in chunk][4 x 16 bytes]
+    __shared__ u64 dg_sums[12 * 64];
+    __shared__ u32 rank_lds[32];                  // g_pk_rank_of, read per lane in the loop: from LDS (a global load there would wait
+                                                  // for every store the wave has in flight - one counter, in order)
+    if (L.rel_refs & 8) __builtin_amdgcn_s_setprio(3);
+    const u32 lane = threadIdx.x, P = 1u << log2p, G = 64u >> log2p;
+    if (lane < 32u) rank_lds[lane] = lane < (u32)H2E_OP_COUNT ? (u32)g_pk_rank_of[lane] : 0xffu;
+    const u32 g = lane >> log2p, ii = lane & (P - 1u);
+    const u32 per_sub = n_instances * L.n_strands;
+    const u32 n_sub = L.n_sub > 1 ? L.n_sub : 1;
+    const u32 sub = blockIdx.x * G + g;
+    const bool group_on = sub < n_sub;
+    const u32 idx = ii < per_sub ? ii : per_sub - 1;      // padding lanes of a group replay its last lane and store nothing
+    const u32 instance = idx % n_instances, strand = idx / n_instances;
+    u32 pos = 0, end = 0;
+    if (group_on) {
+        pos = L.n_sub > 1 ? L.sub[sub] : 0u;
+        end = L.n_sub > 1 ? L.sub[sub + 1] : L.n_ops;
+    }
+    InstanceDesc d = inst[instance];
+    LC c;
+    c.base = d.base;
+    c.range = d.range;
+    c.select = d.select;
+    c.inputs = d.inputs;
+    c.status = d.status;
+    c.ob = L.strand_base0 + strand * L.delta_base;
+    c.orr = L.strand_range0 + strand * L.delta_range;
+    c.os = L.strand_select0 + strand * L.delta_select;
+    c.params = L.params + (size_t)strand * L.n_params;
+    c.aux = L.aux;
+    c.pool = L.const_pool;
+    c.fc = &g_fc[FP::ID];
+    c.strand = strand;
+    c.input_stride = L.input_stride;
+    c.sw = L.slot_words;
+    c.hints = d.hints;
+    c.ws = d.ws;
+    c.hint_stride = L.hint_stride;
+    c.hs = 2 * n_instances;
+    c.active = group_on && ii < per_sub;
+    if (L.dg_out != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) l_st8(dg_sums + k * 64 + lane, 0);
+        c.dg = dg_sums + lane;
+    }
+    u32 cbase = pos;          // first op of the chunk this group holds in LDS ...
+    bool filled = false;      // ... once it has loaded one
+    const H2E_AS_LDS u32x4* my_ops = (const H2E_AS_LDS u32x4*)opbuf + (size_t)g * H2E_PK_CH * 4;
+    for (;;) {
+        const bool need = pos < end && (!filled || pos >= cbase + H2E_PK_CH);
+        if (__builtin_amdgcn_ballot_w64(need)) {
+            if (need) {
+                cbase = pos;
+                filled = true;
+                for (u32 e = ii; e < H2E_PK_CH * 4u; e += P) {
+                    u32 at = cbase + e / 4u;
+                    if (at < end) ((H2E_AS_LDS u32x4*)opbuf)[((size_t)g * H2E_PK_CH + e / 4u) * 4u + e % 4u] =
+                        ((const H2E_AS_GLOBAL u32x4*)(L.tape + at))[e % 4u];
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        u32 rank = 0xffu;
+        if (pos < end) {
+            u32 w0 = my_ops[(pos - cbase) * 4u].x;
+            rank = ((const H2E_AS_LDS u32*)rank_lds)[w0 & 31u];
+        }
+        // the lightest op any cursor shows (ranks are below 32)
+        u32 pick = 0xffu;
+        for (u32 r = 0; r < 32u; r++)
+            if (__builtin_amdgcn_ballot_w64(rank == r)) {
+                pick = r;
+                break;
+            }
+        if (pick == 0xffu) break;   // every group is through its sub-range
+        if (rank == pick) {
+            const H2E_AS_LDS u32x4* q = my_ops + (pos - cbase) * 4u;
+            u32x4 x0 = q[0], x1 = q[1], x2 = q[2], x3 = q[3];
+            H2EOp op;
+            op.opcode = (uint16_t)__builtin_amdgcn_readfirstlane(x0.x & 0xffffu);   // the same for every lane in here: a scalar switch
+            op.flags = (uint16_t)(x0.x >> 16);
+            op.imm = x0.y;
+            op.base_row = x0.z;
+            op.range_row = x0.w;
+            op.select_row = x1.x;
+            op.refs[0] = x1.y; op.refs[1] = x1.z; op.refs[2] = x1.w;
+            op.refs[3] = x2.x; op.refs[4] = x2.y; op.refs[5] = x2.z; op.refs[6] = x2.w;
+            op.refs[7] = x3.x; op.refs[8] = x3.y; op.refs[9] = x3.z; op.refs[10] = x3.w;
+            exec_op<FP, false>(c, op);
+            pos++;
+        }
+    }
+    if (c.dg != nullptr && c.active) {
+        lds_fence();
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            u64 v = l_ld8(dg_sums + k * 64 + lane);
+            if (v) atomicAdd((unsigned long long*)(L.dg_out + (((size_t)(blockIdx.x & (L.dg_shards - 1u)) * 3 + k / 4) * n_instances + instance) * 4 + (k % 4)), (unsigned long long)v);
+        }
     }
 }
 
@@ -3980,8 +4109,9 @@ __global__ void h2e_fixed_patches(const u32* __restrict__ patches, u32 n_patches
         Mont<4> M = mont_n(fc);
         v = mont_mul<4>(M, v, M.r2);
     }
-    u64 o = columns ? (u64)col * rows + row : (u64)row * cols + col;
-    ulonglong2* q = out + ((u64)i * rows * cols + o) * 2;
+    // rows = 0: the values alone, [instance][patch][4 words] (h2e_engine_patch_values: the device-side constraint check)
+    u64 o = rows == 0 ? (u64)k : columns ? (u64)col * rows + row : (u64)row * cols + col;
+    ulonglong2* q = out + ((u64)i * (rows == 0 ? (u64)n_patches : rows * cols) + o) * 2;
     q[0] = make_ulonglong2(v.v[0], v.v[1]);
     q[1] = make_ulonglong2(v.v[2], v.v[3]);
 }
@@ -4036,6 +4166,22 @@ extern "C" int h2e_engine_fixed(int field_pair, const uint32_t* ids, const uint6
     }
     return (int)hipGetLastError();
 }
+extern "C" int h2e_engine_patch_values(int field_pair, const uint32_t* patches, uint32_t n_patches, const uint64_t* inputs, uint32_t n_slots,
+                                       uint32_t slot_words, uint32_t n_instances, const H2EFieldConsts* fc_dev, void* out, hipStream_t stream) {
+    if (n_patches == 0 || n_instances == 0) return 0;
+    dim3 g2((n_patches * n_instances + 63) / 64), b2(64);
+#define H2E_PATCHV(FP)                                                                                                                  \
+    hipLaunchKernelGGL(h2e_fixed_patches<FP>, g2, b2, 0, stream, patches, n_patches, inputs, n_slots, slot_words, (u64)0, 0u, 0u, n_instances, 0u, \
+                       fc_dev, (ulonglong2*)out)
+    switch (field_pair) {
+        case 0: H2E_PATCHV(FP_BN256_FQ); break;
+        case 1: H2E_PATCHV(FP_BLS_FQ); break;
+        case 2: H2E_PATCHV(FP_BLS_FR); break;
+        default: return -1;
+    }
+#undef H2E_PATCHV
+    return (int)hipGetLastError();
+}
 extern "C" int h2e_engine_range_table(int mont, const H2EFieldConsts* fc_dev, void* out, hipStream_t stream) {
     hipLaunchKernelGGL(h2e_range_table, dim3(((1u << 19) - 1 + 255) / 256), dim3(256), 0, stream, (u32)mont, fc_dev, (ulonglong2*)out);
     return (int)hipGetLastError();
@@ -4079,14 +4225,15 @@ extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances,
 // pipelined step's busiest resource: 16.17 -> 16.02 ms, window expansion 11.85 -> 11.4 ms; on by default.
 // [4]: persistent expansion (experiment): big expansions are launched with this many workgroups per CU, each looping over its share
 // of the blocks (0 = one workgroup per block)
-static int g_tune[5] = {0, 2, 0, 0, 0};
+// [5]: 1 = no packed expansion for batches smaller than a wave (h2e_run_tape_packed; A/B)
+static int g_tune[6] = {0, 2, 0, 0, 0, 0};
 extern "C" long long H2E_UNIT(h2e_engine_scan_fallbacks)(void) {
     unsigned long long n = 0;
     if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_scan_fallbacks), sizeof(n)) != hipSuccess) return -1;
     return (long long)n;
 }
 extern "C" void H2E_UNIT(h2e_engine_set_tuning)(int key, int value) {
-    if ((key >= 0 && key < 3) || key == 4) g_tune[key] = value;
+    if ((key >= 0 && key < 3) || key == 4 || key == 5) g_tune[key] = value;
     if (key == 3) {
         u32 m = (u32)value;
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_test), &m, sizeof(m));
@@ -4119,6 +4266,12 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
         launch_x.x_blocks = grid.x;
         grid_x = dim3((u32)n_cu * (u32)g_tune[4]);
     }
+    // batches smaller than half a wave: several sub-ranges per wave (h2e_run_tape_packed); g_tune[5] = 1 switches it off (A/B)
+    int pack_log2p = -1;
+    if (per_sub <= 32 && n_sub >= 2 && g_tune[5] == 0) {
+        pack_log2p = 0;
+        while ((1u << pack_log2p) < per_sub) pack_log2p++;
+    }
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
     if ((mode & 1) && launch->s_words) {                                                                                        \
         u32 lanes = launch->n_sops * n_instances;                                                                              \
@@ -4146,7 +4299,10 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
                            ((size_t)launch->v_units * 2 + ((size_t)launch->v_int_slots * VSlots<FP>::W + VSlots<FP>::NF * 4)) * 64 * 8, \
                            stream, *launch, inst, n_instances);                                                                \
     if ((mode & 1) && !launch->vtape) return -2;   /* a values-only replay always runs from the compiled V-tape */          \
-    if (mode & 2)                                                                                                              \
+    if ((mode & 2) && pack_log2p >= 0)                                                                                         \
+        hipLaunchKernelGGL(h2e_run_tape_packed<FP>, dim3((n_sub + (64u >> pack_log2p) - 1) / (64u >> pack_log2p)), block, 0, stream, launch_x, inst, \
+                           n_instances, (u32)pack_log2p);                                                                      \
+    else if (mode & 2)                                                                                                         \
         hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid_x, block,                                                           \
                            (xcache_on ? (size_t)3 * (2 * FP::L + 4) * 64 * 8 : 0) + (grid.x > 4096 ? (size_t)g_tune[2] : 0),   \
                            stream, launch_x, inst, n_instances, fc_dev);

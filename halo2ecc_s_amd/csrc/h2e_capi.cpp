@@ -24,6 +24,21 @@ extern "C" int h2e_engine_fixed(int field_pair, const uint32_t* ids, const uint6
                                 const uint32_t* patches, uint32_t n_patches, const uint64_t* inputs, uint32_t n_slots, uint32_t slot_words,
                                 uint32_t n_instances, const H2EFieldConsts* fc_dev, void* out, hipStream_t stream);
 extern "C" int h2e_engine_range_table(int mont, const H2EFieldConsts* fc_dev, void* out, hipStream_t stream);
+extern "C" int h2e_engine_patch_values(int field_pair, const uint32_t* patches, uint32_t n_patches, const uint64_t* inputs, uint32_t n_slots,
+                                       uint32_t slot_words, uint32_t n_instances, const H2EFieldConsts* fc_dev, void* out, hipStream_t stream);
+// checker.hip: the device-side constraint check (include/h2e.h h2e_check)
+struct H2ECheckRegion {
+    const void* adv;
+    const uint8_t* flags;
+    const uint32_t* fix;
+    uint64_t rows, height;
+};
+extern "C" int h2e_engine_check_consts(const uint64_t n[4], uint64_t n_minv, const uint64_t r2[4]);
+extern "C" int h2e_engine_check_to_mont(const uint64_t* in, uint64_t* out, uint64_t n, hipStream_t stream);
+extern "C" int h2e_engine_check(const H2ECheckRegion* regs, const uint64_t* dict, const uint64_t* dict_m, const uint64_t* shifts_m,
+                                const uint64_t* patch_vals, uint32_t n_patches, const uint64_t* sel_keys, const uint32_t* sel_key_rows,
+                                uint32_t n_sel_keys, const uint32_t* perms, uint64_t n_pairs, uint32_t n_instances, uint32_t classes,
+                                uint64_t* fail, hipStream_t stream);
 extern "C" int h2e_engine_copy_constraints(const uint32_t* perms, uint64_t n, void* out, hipStream_t stream);
 extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances, uint32_t bits, hipStream_t stream);
 extern "C" int h2e_engine_digest_reduce(const void* shards, uint32_t n_shards, uint32_t n_words, void* out, hipStream_t stream);
@@ -148,6 +163,14 @@ struct h2e_program {
     uint64_t* d_dict = nullptr;
     uint32_t* d_patches = nullptr;
     uint32_t* d_perms = nullptr;
+    // h2e_check: base fixed ids with the cells made from instance inputs marked (bit 31 | patch index), the dictionary and the
+    // range gates' shifts in Montgomery form, the select chip's table rows sorted by their encode cell, per-instance patch values
+    uint32_t* d_fix_ck = nullptr;
+    uint64_t *d_dict_m = nullptr, *d_shifts_m = nullptr, *d_sel_keys = nullptr, *d_patch_vals = nullptr;
+    uint32_t* d_sel_key_rows = nullptr;
+    uint32_t n_sel_keys = 0;
+    size_t patch_vals_cap = 0;
+    bool check_ready = false;
 
     ~h2e_program() {
         if (device >= 0) {
@@ -172,6 +195,12 @@ struct h2e_program {
         (void)hipFree(d_dict);
         (void)hipFree(d_patches);
         (void)hipFree(d_perms);
+        (void)hipFree(d_fix_ck);
+        (void)hipFree(d_dict_m);
+        (void)hipFree(d_shifts_m);
+        (void)hipFree(d_sel_keys);
+        (void)hipFree(d_patch_vals);
+        (void)hipFree(d_sel_key_rows);
     }
     // Liveness over sub-ranges: an arithmetic op whose result cells are only read by ops of its own sub-range gets
     // H2E_FLAG_LOCAL_RESULT, so the values-only replay keeps that result in LDS and does not store it (the full
@@ -2040,10 +2069,11 @@ int h2e_ctx_create(int device, h2e_ctx** out) {
     // tuning knobs are read once, here (nothing reads the environment while a run is being queued)
     if (const char* e1 = getenv("H2E_X_SPLIT")) c->x_split_pct = (uint32_t)std::max(0, std::min(100, atoi(e1)));
     if (const char* e2 = getenv("H2E_X_SPLIT_MIN_LANES")) c->x_split_min_lanes = (uint64_t)atoll(e2);
-    if (const char* e4 = getenv("H2E_TUNE")) {   // "reserve,xcache,xpad,scan test mask,persistent workgroups per CU" (engine.hip g_tune)
-        int a = 0, b = 0, d = 0, t = 0, pw = 0;
-        sscanf(e4, "%d,%d,%d,%d,%d", &a, &b, &d, &t, &pw);
+    if (const char* e4 = getenv("H2E_TUNE")) {   // "reserve,xcache,xpad,scan test mask,persistent workgroups per CU,no packed expansion" (engine.hip g_tune)
+        int a = 0, b = 0, d = 0, t = 0, pw = 0, nopack = 0;
+        sscanf(e4, "%d,%d,%d,%d,%d,%d", &a, &b, &d, &t, &pw, &nopack);
         h2e_engine_set_tuning(4, pw);   // persistent expansion: workgroups per CU (experiment)
+        h2e_engine_set_tuning(5, nopack);   // 1: batches smaller than a wave through the plain expansion kernel (A/B)
         h2e_engine_set_tuning(0, a);
         h2e_engine_set_tuning(1, b);
         h2e_engine_set_tuning(2, d);
@@ -3156,6 +3186,155 @@ int h2e_export_copy_constraints(h2e_ctx* ctx, h2e_program* p, void* d_out, void*
     }
     int rc = h2e_engine_copy_constraints(p->d_perms, n, d_out, (hipStream_t)stream);
     if (rc != 0) return fail(H2E_ERR_HIP, std::string("copy-constraint launch failed: ") + hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
+// Device-side constraint check (include/h2e.h): the shape artefacts the kernels of checker.hip read are uploaded once per program.
+static int ensure_check_artefacts(h2e_ctx* ctx, h2e_program* p) {
+    if (p->check_ready) return 0;
+    h2e::Recorder& r = *p->rec;
+    const uint64_t rows[3] = {p->base_rows, p->range_rows, p->select_rows};
+    const uint32_t fcols[3] = {9, 2, 2};
+    const std::vector<uint32_t>* ids[3] = {&r.base_fix, &r.range_fix, &r.select_fix};
+    for (int reg = 0; reg < 3; reg++) {
+        if (ids[reg]->size() < rows[reg] * fcols[reg]) return fail(H2E_ERR_SHAPE, "internal: fixed array shorter than the region");
+        const uint8_t* fl = nullptr;
+        int rc = device_flags(p, reg, &fl);
+        if (rc) return rc;
+        if (reg > 0 && !p->d_fix[reg]) {
+            HIP_TRY(hipMalloc((void**)&p->d_fix[reg], std::max<size_t>(16, rows[reg] * fcols[reg] * 4)));
+            HIP_TRY(hipMemcpy(p->d_fix[reg], ids[reg]->data(), rows[reg] * fcols[reg] * 4, hipMemcpyHostToDevice));
+        }
+    }
+    {   // base ids, cells made from instance inputs marked with their patch index
+        std::vector<uint32_t> ck(r.base_fix.begin(), r.base_fix.begin() + rows[0] * 9);
+        for (size_t k = 0; k < r.fixed_patches.size(); k++) {
+            const h2e::FixedPatch& f = r.fixed_patches[k];
+            if (f.col != 8 || f.row >= rows[0]) return fail(H2E_ERR_SHAPE, "internal: a fixed patch outside the constant column");
+            ck[(size_t)f.row * 9 + 8] = 0x80000000u | (uint32_t)k;
+        }
+        HIP_TRY(hipMalloc((void**)&p->d_fix_ck, std::max<size_t>(16, ck.size() * 4)));
+        HIP_TRY(hipMemcpy(p->d_fix_ck, ck.data(), ck.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (!p->d_dict) {
+        HIP_TRY(hipMalloc((void**)&p->d_dict, r.dict.size() * 32));
+        HIP_TRY(hipMemcpy(p->d_dict, r.dict.data(), r.dict.size() * 32, hipMemcpyHostToDevice));
+    }
+    uint32_t n_patches = (uint32_t)r.fixed_patches.size();
+    if (n_patches && !p->d_patches) {
+        HIP_TRY(hipMalloc((void**)&p->d_patches, (size_t)n_patches * 16));
+        HIP_TRY(hipMemcpy(p->d_patches, p->patch_flat.data(), (size_t)n_patches * 16, hipMemcpyHostToDevice));
+    }
+    size_t n_perm = r.permutations.size();
+    if (n_perm && !p->d_perms) {
+        HIP_TRY(hipMalloc((void**)&p->d_perms, n_perm * 8));
+        HIP_TRY(hipMemcpy(p->d_perms, p->perm_flat.data(), n_perm * 8, hipMemcpyHostToDevice));
+    }
+    {   // Fr constants of the check: once per process is enough, once per program is simpler and costs nothing
+        const H2EFieldConsts& fc = field_pair(0).fc;
+        HIP_TRY((hipError_t)h2e_engine_check_consts(fc.n, fc.n_minv, fc.n_r2));
+    }
+    HIP_TRY(hipMalloc((void**)&p->d_dict_m, r.dict.size() * 32));
+    HIP_TRY((hipError_t)h2e_engine_check_to_mont(p->d_dict, p->d_dict_m, r.dict.size(), nullptr));
+    {   // 2^(18 k), k = 0..5: the range gates' shifts (range_chip.rs:160-218)
+        uint64_t sh[6][4];
+        std::memset(sh, 0, sizeof(sh));
+        for (int k = 0; k < 6; k++) sh[k][(18 * k) / 64] = 1ull << ((18 * k) % 64);
+        HIP_TRY(hipMalloc((void**)&p->d_shifts_m, sizeof(sh)));
+        HIP_TRY(hipMemcpy(p->d_shifts_m, sh, sizeof(sh), hipMemcpyHostToDevice));
+        HIP_TRY((hipError_t)h2e_engine_check_to_mont(p->d_shifts_m, p->d_shifts_m, 6, nullptr));
+    }
+    {   // the select chip's table: rows whose is_lookup cell is zero, keyed by their (fixed) encode cell; the all-zero rows of
+        // the unused part of the circuit are one entry (row 0xffffffff)
+        struct Ent {
+            h2e::FrVal key;
+            uint32_t row;
+        };
+        std::vector<Ent> tab;
+        h2e::FrVal zero{};
+        for (int i = 0; i < 4; i++) zero[i] = 0;
+        tab.push_back(Ent{zero, 0xffffffffu});
+        const uint64_t height = std::min<uint64_t>(rows[2], (uint64_t)r.select_height + 1);
+        for (uint64_t row = 0; row < height; row++) {
+            uint32_t enc = r.select_fix[row * 2], look = r.select_fix[row * 2 + 1];
+            bool is_lookup = false;
+            if (look) {
+                const h2e::FrVal& lv = r.dict[look];
+                is_lookup = (lv[0] | lv[1] | lv[2] | lv[3]) != 0;
+            }
+            if (is_lookup) continue;
+            tab.push_back(Ent{enc ? r.dict[enc] : zero, (uint32_t)row});
+        }
+        std::sort(tab.begin(), tab.end(), [](const Ent& a, const Ent& b) {
+            for (int i = 3; i >= 0; i--)
+                if (a.key[i] != b.key[i]) return a.key[i] < b.key[i];
+            return a.row < b.row;
+        });
+        std::vector<uint64_t> keys(tab.size() * 4);
+        std::vector<uint32_t> krows(tab.size());
+        for (size_t k = 0; k < tab.size(); k++) {
+            for (int i = 0; i < 4; i++) keys[4 * k + i] = tab[k].key[i];
+            krows[k] = tab[k].row;
+        }
+        p->n_sel_keys = (uint32_t)tab.size();
+        HIP_TRY(hipMalloc((void**)&p->d_sel_keys, keys.size() * 8));
+        HIP_TRY(hipMemcpy(p->d_sel_keys, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&p->d_sel_key_rows, krows.size() * 4));
+        HIP_TRY(hipMemcpy(p->d_sel_key_rows, krows.data(), krows.size() * 4, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    p->check_ready = true;
+    (void)ctx;
+    return 0;
+}
+
+int h2e_check(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, const void* d_base, const void* d_range,
+              const void* d_select, uint32_t classes, void* d_fail, void* stream) {
+    if (!ctx || !p || !d_base || !d_range || !d_select || !d_fail) return fail(H2E_ERR_INVALID, "null argument");
+    if (n_instances == 0) return fail(H2E_ERR_INVALID, "n_instances must be > 0");
+    h2e::Recorder& r = *p->rec;
+    if (!r.emit_shape) return fail(H2E_ERR_INVALID, "the program was recorded without its shape (emit_shape = 0): nothing to check the cells against");
+    if (!r.fixed_patches.empty() && !d_inputs) return fail(H2E_ERR_INVALID, "this program has fixed cells made from instance inputs: d_inputs is needed");
+    if (classes == 0) classes = (1u << H2E_CHECK_CLASSES) - 1u;
+    std::lock_guard<std::mutex> guard(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_fc(ctx, p->field_pair);
+    if (rc) return rc;
+    rc = ensure_check_artefacts(ctx, p);
+    if (rc) return rc;
+    uint32_t n_patches = (uint32_t)r.fixed_patches.size();
+    if (n_patches) {
+        size_t need = (size_t)n_patches * n_instances * 32;
+        if (need > p->patch_vals_cap) {
+            if (p->d_patch_vals) {
+                HIP_TRY(hipDeviceSynchronize());
+                (void)hipFree(p->d_patch_vals);
+                p->d_patch_vals = nullptr;
+            }
+            HIP_TRY(hipMalloc((void**)&p->d_patch_vals, need));
+            p->patch_vals_cap = need;
+        }
+        rc = h2e_engine_patch_values(p->field_pair, p->d_patches, n_patches, (const uint64_t*)d_inputs, r.n_input_slots, (uint32_t)r.fp.w_words,
+                                     n_instances, ctx->d_fc[p->field_pair], p->d_patch_vals, (hipStream_t)stream);
+        if (rc != 0) return fail(H2E_ERR_HIP, "check: patch values launch failed");
+    }
+    H2ECheckRegion regs[3];
+    const void* adv[3] = {d_base, d_range, d_select};
+    const uint64_t rows[3] = {p->base_rows, p->range_rows, p->select_rows};
+    // gates run over the rows MockProver sees cells in: [0, height) for the base gate, one more row for the range and select
+    // chips (their heights are "last used row + 1" with the quirks of context.rs:716-720; the oracle's checker does the same)
+    const uint64_t heights[3] = {std::min<uint64_t>(rows[0], r.base_height), std::min<uint64_t>(rows[1], (uint64_t)r.range_height + 1),
+                                 std::min<uint64_t>(rows[2], (uint64_t)r.select_height + 1)};
+    for (int reg = 0; reg < 3; reg++) {
+        regs[reg].adv = adv[reg];
+        regs[reg].flags = p->d_flags[reg];
+        regs[reg].fix = reg == 0 ? p->d_fix_ck : p->d_fix[reg];
+        regs[reg].rows = rows[reg];
+        regs[reg].height = heights[reg];
+    }
+    rc = h2e_engine_check(regs, p->d_dict, p->d_dict_m, p->d_shifts_m, p->d_patch_vals, n_patches, p->d_sel_keys, p->d_sel_key_rows, p->n_sel_keys,
+                          p->d_perms, r.permutations.size(), n_instances, classes, (uint64_t*)d_fail, (hipStream_t)stream);
+    if (rc != 0) return fail(H2E_ERR_HIP, rc < 0 ? "check: bad geometry" : std::string("check launch failed: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }
 

@@ -21,6 +21,8 @@ OPT_PREFAULT_HBM = 6
 OPT_OP_CACHE_CAP = 7
 OPT_OFF = -(1 << 63)
 COLS = (5, 3, 2)
+CHECK_BASE_GATE, CHECK_RANGE_GATE, CHECK_RANGE_LOOKUP, CHECK_SELECT_LOOKUP, CHECK_COPY = range(5)
+CHECK_CLASSES = 5
 
 EXPORTED_SYMBOLS = [
     "h2e_last_error", "h2e_version", "h2e_ctx_create", "h2e_ctx_destroy", "h2e_program_int_mul_batch",
@@ -36,6 +38,7 @@ EXPORTED_SYMBOLS = [
     "h2e_op_bisec_point_with_curvature", "h2e_op_assign_cache_point", "h2e_op_assign_selected_point", "h2e_export_fixed", "h2e_range_table", "h2e_export_copy_constraints", "h2e_ctx_set_option", "h2e_ctx_get_stat",
     "h2e_program_msm_bn256_tile_no_select", "h2e_last_run_expansion_launches",
     "h2e_run_digest", "h2e_submit_digest", "h2e_records_attach", "h2e_op_int_mul_small_constant", "h2e_op_assign_int_constant", "h2e_op_bisec_int", "h2e_op_fq", "h2e_op_pairing",
+    "h2e_check",
 ]
 
 
@@ -166,6 +169,7 @@ def lib():
     L.h2e_wait.argtypes = [vp, i32, vp]
     L.h2e_run_digest.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
     L.h2e_submit_digest.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
+    L.h2e_check.argtypes = [vp, vp, u32, vp, vp, vp, vp, u32, vp, vp]
     L.h2e_ctx_set_option.argtypes = [vp, i32, C.c_int64]
     L.h2e_ctx_get_stat.argtypes = [vp, i32]
     L.h2e_ctx_get_stat.restype = C.c_int64
@@ -606,6 +610,19 @@ class Engine:
         if out is None:
             out = t.empty((n, 4), dtype=t.int64, device=batch.device)
         _check(lib().h2e_digest(self._h, program._h, n, region, batch.data_ptr(), out.data_ptr(), self._stream(stream).cuda_stream))
+        return out
+
+    def check(self, program, d_inputs, base, rng, sel, classes=0, stream=None, out=None):
+        """h2e_check: the reference's MockProver criterion (base gate, range gates + lookups, select lookup, copy constraints) over
+        the batch-interleaved arrays of every instance -> int64 [instances][10]: failing rows per class, then the lowest failing
+        row of each class (-1 = none).  An instance passes iff out[i, :5] is all zero."""
+        t = self.torch
+        n = base.shape[3]
+        assert base.is_contiguous() and rng.is_contiguous() and sel.is_contiguous()
+        if out is None:
+            out = t.empty((n, 2 * CHECK_CLASSES), dtype=t.int64, device=base.device)
+        _check(lib().h2e_check(self._h, program._h, n, d_inputs.data_ptr() if d_inputs is not None else None, base.data_ptr(), rng.data_ptr(),
+                               sel.data_ptr(), classes, out.data_ptr(), self._stream(stream).cuda_stream))
         return out
 
     def export_fixed(self, program, region, n_instances=1, d_inputs=None, layout=LAYOUT_COLUMNS, form=FORM_CANONICAL, stream=None):

@@ -238,6 +238,26 @@ int h2e_export_fixed(h2e_ctx* ctx, h2e_program* p, int region, int layout, int f
 int h2e_range_table(h2e_ctx* ctx, int form, void* d_out, void* stream);
 int h2e_export_copy_constraints(h2e_ctx* ctx, h2e_program* p, void* d_out, void* stream);
 
+/* ---- the reference's acceptance criterion, on the device, for every instance of a run -----------------------------------
+ * Every test of the reference ends in `MockProver::run(k, &circuit, vec![]).verify() == Ok(())` (src/tests/mod.rs:117-132):
+ * the arrays satisfy the base gate (src/circuit/base_chip.rs:50-69), the three range accumulation gates and the two range
+ * lookups (src/circuit/range_chip.rs:119-220, table :230-258), the select chip's lookup_any (src/circuit/select_chip.rs:71-88)
+ * and every copy constraint (src/context.rs:523-541).  h2e_check evaluates exactly those over the batch-interleaved advice
+ * arrays a run (or an operator-API context) left in HBM and the program's own fixed cells, flags and permutation list
+ * (unassigned / unset cells = 0, as in MockProver), for all n_instances at once; `p` must have been recorded with its shape
+ * (emit_shape = 1) and d_inputs is the run's input vector (fixed cells made from instance inputs: the G2 constants).
+ * d_fail = uint64 [n_instances][2 * H2E_CHECK_CLASSES]: per instance the number of failing rows (pairs) of each class, then
+ * the lowest failing row (pair index) of each class, ~0 when none.  An instance passes iff its first five words are zero.
+ * `classes` = bit mask of H2E_CHECK_* to evaluate (0 = all).  Asynchronous on `stream`. */
+#define H2E_CHECK_BASE_GATE 0
+#define H2E_CHECK_RANGE_GATE 1
+#define H2E_CHECK_RANGE_LOOKUP 2
+#define H2E_CHECK_SELECT_LOOKUP 3
+#define H2E_CHECK_COPY 4
+#define H2E_CHECK_CLASSES 5
+int h2e_check(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, const void* d_base, const void* d_range,
+              const void* d_select, uint32_t classes, void* d_fail, void* stream);
+
 /* ---- operator API: a device-resident Context -----------------------------------------------------
  * The reference's operator surface is a Context you call chip ops on (`IntegerChipOps` src/circuit/integer_chip.rs:15-70,
  * `EccChipBaseOps` / `EccChipScalarOps` src/circuit/ecc_chip.rs:79-430, `PairingChipOps` src/circuit/pairing_chip.rs:157-176); its own

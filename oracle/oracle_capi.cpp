@@ -466,6 +466,18 @@ int oracle_check(void* h, char* msg, int cap) {
     }
     return rep.ok() ? 0 : 1;
 }
+// the same, per class: failing rows of the base gate, the range gates, the range lookups, the select lookup, failing copy constraints
+// (the order of include/h2e.h H2E_CHECK_*: the device-side check of the engine's arrays is held against these counts)
+int oracle_check_counts(void* h, uint64_t* out5) {
+    Run* r = (Run*)h;
+    CheckReport rep = check_records(r->ctx->records);
+    out5[0] = rep.base_gate_failures;
+    out5[1] = rep.range_gate_failures;
+    out5[2] = rep.range_lookup_failures;
+    out5[3] = rep.select_lookup_failures;
+    out5[4] = rep.permutation_failures;
+    return rep.ok() ? 0 : 1;
+}
 // flip one advice cell (for checker self-tests)
 void oracle_corrupt_adv(void* h, int region, uint64_t row, int col) {
     Run* r = (Run*)h;

@@ -55,6 +55,7 @@ def load():
     L.oracle_export_fix.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
     L.oracle_export_permutations.argtypes = [vp, vp]
     L.oracle_check.argtypes = [vp, C.c_char_p, C.c_int]
+    L.oracle_check_counts.argtypes = [vp, vp]
     L.oracle_corrupt_adv.argtypes = [vp, C.c_int, C.c_uint64, C.c_int]
     L.oracle_free.argtypes = [vp]
     L.oracle_free.restype = None
@@ -111,6 +112,12 @@ class Run:
         buf = C.create_string_buffer(512)
         rc = self.L.oracle_check(self.h, buf, 512)
         return rc == 0, buf.value.decode()
+
+    def check_counts(self):
+        """failing rows per class: base gate, range gates, range lookups, select lookup, copy constraints"""
+        out = np.zeros(5, dtype=np.uint64)
+        self.L.oracle_check_counts(self.h, out.ctypes.data)
+        return out
 
     def corrupt(self, region, row, col):
         self.L.oracle_corrupt_adv(self.h, region, row, col)
