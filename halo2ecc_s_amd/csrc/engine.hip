@@ -4269,7 +4269,7 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
     // batches smaller than half a wave: several sub-ranges per wave (h2e_run_tape_packed); g_tune[5] = 1 switches it off (A/B)
     int pack_log2p = -1;
     if (per_sub <= 32 && n_sub >= 2 && g_tune[5] == 0) {
-        pack_log2p = 0;
+        pack_log2p = 1;   // (at most 32 groups per wave: the kernel's op buffer holds that many chunks)
         while ((1u << pack_log2p) < per_sub) pack_log2p++;
     }
 #define H2E_LAUNCH_FP(FP)                                                                                                     \

@@ -2215,13 +2215,19 @@ int h2e_program_msm_bls12_381_tile(uint32_t n, int emit_shape, h2e_program** out
     return 0;
 }
 
+// ops per expansion sub-range of the pairing programs (a cut wherever the recorder allows one after that many ops);
+// H2E_PAIRING_CUT overrides it when the program is recorded (experiments)
+static uint32_t pairing_cut_every() {
+    if (const char* e = getenv("H2E_PAIRING_CUT")) return (uint32_t)std::max(2, atoi(e));
+    return 16;
+}
 int h2e_program_pairing_check_bn256(int emit_shape, h2e_program** out) {
     h2e_program* p = nullptr;
     int rc = new_program(H2E_FIELD_BN256_FQ, emit_shape, out, p);
     if (rc) return rc;
     GUARDED({
         h2e::Recorder& r = *p->rec;
-        r.auto_cut_every = 16;
+        r.auto_cut_every = pairing_cut_every();
         uint32_t s = r.alloc_inputs(10);
         h2e::NativeScalarEccContext ecc(r, h2e::bn256_g1_params(), 0);
         h2e::Bn256PairingOps po(r);
@@ -2245,7 +2251,7 @@ int h2e_program_pairing_check_bls12_381(int emit_shape, h2e_program** out) {
     if (rc) return rc;
     GUARDED({
         h2e::Recorder& r = *p->rec;
-        r.auto_cut_every = 16;
+        r.auto_cut_every = pairing_cut_every();
         uint32_t s = r.alloc_inputs(14);
         h2e::NativeScalarEccContext ecc(r, h2e::bls12_381_g1_params(), 0);  // EccChipBaseOps of GeneralScalarEccContext
         h2e::Bls12381PairingOps po(r);
@@ -2276,7 +2282,7 @@ int h2e_program_pairing(int curve, uint32_t n_pairs, int with_expected, int emit
     if (rc) return rc;
     GUARDED({
         h2e::Recorder& r = *p->rec;
-        r.auto_cut_every = 16;
+        r.auto_cut_every = pairing_cut_every();
         uint32_t s = r.alloc_inputs(7 * n_pairs + (with_expected ? 12 : 0));
         h2e::NativeScalarEccContext ecc(r, curve == 0 ? h2e::bn256_g1_params() : h2e::bls12_381_g1_params(), 0);
         std::unique_ptr<h2e::PairingOps> po;
@@ -3048,6 +3054,32 @@ int h2e_program_launches(const h2e_program* p, uint64_t* out, uint32_t cap) {
         k++;
     }
     return (int)k;
+}
+
+// Diagnostics: the opcodes of one launch's tape (the k-th segment h2e_program_launches lists) and the op indices its expansion's
+// sub-ranges start at - what exp/pack_sim.py replays on the host to price a packing of sub-ranges into waves.  Returns the
+// number of ops; *n_subs = sub-range bounds written (first = 0, last = the number of ops).
+int h2e_program_tape_opcodes(const h2e_program* p, uint32_t launch, uint16_t* opcodes, uint32_t cap, uint32_t* subs, uint32_t subs_cap,
+                             uint32_t* n_subs) {
+    if (!p) return fail(H2E_ERR_INVALID, "null program");
+    const h2e::Recorder& r = *p->rec;
+    uint32_t k = 0;
+    for (auto& s : r.segments) {
+        if (s.tape_end <= s.tape_begin) continue;
+        if (k++ != launch) continue;
+        uint32_t n_ops = s.tape_end - s.tape_begin;
+        for (uint32_t i = 0; i < n_ops && i < cap; i++) opcodes[i] = r.tape[s.tape_begin + i].opcode;
+        std::vector<uint32_t> b{0};
+        for (uint32_t c = 0; c < s.n_cuts; c++) {
+            uint32_t at = r.cuts[s.cuts_begin + c];
+            if (at > b.back() && at < n_ops) b.push_back(at);
+        }
+        b.push_back(n_ops);
+        if (n_subs) *n_subs = (uint32_t)b.size();
+        for (size_t i = 0; i < b.size() && i < subs_cap; i++) subs[i] = b[i];
+        return (int)n_ops;
+    }
+    return fail(H2E_ERR_INVALID, "no such launch");
 }
 
 // the program's assigned / permute bytes of one region on the device (nullptr for programs recorded without their shape)
@@ -3856,7 +3888,7 @@ int h2e_op_fq(h2e_records* R, int degree, int which, const h2e_int* a, const h2e
     if ((binary && !b) || (which != H2E_FQ_ASSERT_EQUAL && !out)) return fail(H2E_ERR_INVALID, "null operand");
     return records_op(R, key_of("fq", {{&degree, sizeof(degree)}, {&which, sizeof(which)}, {a, sizeof(*a) * (size_t)degree}, {b, b ? sizeof(*b) * (size_t)degree : 0}, {&imm, sizeof(imm)}}), 0, nullptr, stream, {OpOut{out, out ? sizeof(*out) * (size_t)degree : 0}}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
         std::unique_ptr<h2e::PairingOps> t = tower_of(r);
-        r.auto_cut_every = 16;
+        r.auto_cut_every = pairing_cut_every();
         auto bad = [] { throw std::runtime_error("h2e_op_fq: no such op at this degree"); };
         if (degree == 2) {
             h2e::AssignedFq2 x = to_fq2(a), y = b ? to_fq2(b) : h2e::AssignedFq2(), o;
@@ -4035,7 +4067,7 @@ int h2e_op_check_pairing(h2e_records* R, uint32_t n_pairs, const h2e_point* g1, 
     if (!g1 || !g2 || n_pairs == 0) return fail(H2E_ERR_INVALID, "bad argument");
     if (R && R->field_pair == H2E_FIELD_BLS12_381_FR) return fail(H2E_ERR_INVALID, "no pairing over this field");
     return records_op(R, key_of("check_pairing", {{&n_pairs, sizeof(n_pairs)}, {g1, sizeof(*g1) * (size_t)n_pairs}, {g2, sizeof(*g2) * (size_t)n_pairs}}), 0, nullptr, stream, {}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
-        r.auto_cut_every = 16;
+        r.auto_cut_every = pairing_cut_every();
         std::unique_ptr<h2e::PairingOps> po;
         if (r.fp.id == H2E_FIELD_BN256_FQ) po.reset(new h2e::Bn256PairingOps(r));
         else po.reset(new h2e::Bls12381PairingOps(r));
@@ -4055,7 +4087,7 @@ int h2e_op_pairing(h2e_records* R, uint32_t n_pairs, const h2e_point* g1, const 
     if (!g1 || !g2 || !out12 || n_pairs == 0) return fail(H2E_ERR_INVALID, "bad argument");
     if (R && R->field_pair == H2E_FIELD_BLS12_381_FR) return fail(H2E_ERR_INVALID, "no pairing over this field");
     return records_op(R, key_of("pairing", {{&n_pairs, sizeof(n_pairs)}, {g1, sizeof(*g1) * (size_t)n_pairs}, {g2, sizeof(*g2) * (size_t)n_pairs}}), 0, nullptr, stream, {OpOut{out12, sizeof(*out12) * 12}}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
-        r.auto_cut_every = 16;
+        r.auto_cut_every = pairing_cut_every();
         std::unique_ptr<h2e::PairingOps> po = tower_of(r);
         std::vector<h2e::AssignedPoint> a;
         std::vector<h2e::AssignedG2Affine> b;

@@ -139,6 +139,9 @@ int h2e_program_outputs(const h2e_program* p, uint32_t* refs, uint32_t cap);
 /* One entry of 8 words per engine launch of a run: n_strands, n_ops, advice cells written per instance
  * (0 unless emit_shape), per-strand Offset (base, range, select), n_params, first base row.  Returns the count. */
 int h2e_program_launches(const h2e_program* p, uint64_t* out, uint32_t cap);
+/* diagnostics: opcodes (tape.h H2EOpcode) of the k-th launch's tape and the op indices its expansion's sub-ranges start at */
+int h2e_program_tape_opcodes(const h2e_program* p, uint32_t launch, uint16_t* opcodes, uint32_t cap, uint32_t* subs, uint32_t subs_cap,
+                             uint32_t* n_subs);
 
 /* ---- execution --------------------------------------------------------------------------------- */
 /* Fill the advice values of n_instances instances.  d_base/d_range/d_select: batch-interleaved device arrays of

@@ -83,7 +83,7 @@ def test_check_small_cases_match_the_oracles_checker(engine, oracle, name, make,
         o.corrupt(region, row, col)
         want = o.check_counts().astype(np.int64)
         assert want.sum() > 0, (region, row, col)
-        cell = arrs[region][row, col, 0, 1, 0]
+        cell = int(arrs[region][row, col, 0, 1, 0])   # (a Python int: indexing gives a view that would follow the write)
         arrs[region][row, col, 0, 1, 0] = cell + 1
         f = _fail(engine, prog, d_in, base, rng, sel)
         arrs[region][row, col, 0, 1, 0] = cell
@@ -124,7 +124,7 @@ def _flip_and_check(engine, prog, d_in, base, rng, sel, n, victims):
         if arrs[region].shape[0] == 0:
             continue
         row, col = _assigned_cell(prog, region, start=arrs[region].shape[0] // 2)
-        cell = arrs[region][row, col, 0, inst, 0]
+        cell = int(arrs[region][row, col, 0, inst, 0])   # (a Python int: indexing gives a view that would follow the write)
         arrs[region][row, col, 0, inst, 0] = cell ^ 1
         f = _fail(engine, prog, d_in, base, rng, sel)
         arrs[region][row, col, 0, inst, 0] = cell
