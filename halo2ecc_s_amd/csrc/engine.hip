@@ -2254,21 +2254,35 @@ __global__ void __launch_bounds__(64) h2e_replay_wave(H2ELaunch L, const Instanc
 // Hint store (field_chain.hpp HintStore): the cells the full expansion needs in place, straight from the hint slots.
 // One lane per (store op, instance), instances minor: the lanes of a wave read the same hint slots and write the same
 // cells of consecutive instances (contiguous runs, like the expansion).
+// Leaves of a store record (field_chain.hpp): kind 0 hint slot, 1 pool word offset, 2 input slot, 3 = entry `index` of the
+// launch's extension table (H2ELaunch::s_ext, 8 words each: type, arguments) - what the forked MSM segments need:
+//   H2E_SX_HINT   a0 = hint slot of strand 0 (+ strand * hint_stride)
+//   H2E_SX_SEL    a0 = selection-buffer entry of strand 0 (+ strand * sel_stride), a1 = 0: x, 1: y (canonical, from the select pre-kernel)
+//   H2E_SX_INPUT  a0 = input slot of strand 0 (+ strand * input_stride)
+//   H2E_SX_CELLS  an integer that lives in cells written before this launch: a0 .. a(L-1) limb cells, aL native cell
+//                 (references like an op's: absolute, strand-relative or through the strand's parameters)
 template <class FP>
-WI_INLINE Wd<FP::WW> hs_leaf(const LC& c, u32 t) {
+WI_INLINE Wd<FP::WW> hs_leaf(const LC& c, u32 t, const u32* ext) {
     u32 kind = t >> 30, index = t & 0x3fffffu;
     if (kind == 0) return ws_load<FP::WW>(c.hints + (size_t)index * c.ws);
     if (kind == 1) return g_load<FP::WW>(c.pool + index);
-    return g_load<FP::WW>(c.inputs + (size_t)index * c.sw);
+    if (kind == 2) return g_load<FP::WW>(c.inputs + (size_t)index * c.sw);
+    const u32* e = ext + (size_t)index * H2E_SX_WORDS;
+    u32 type = e[0];
+    if (type == H2E_SX_HINT) return ws_load<FP::WW>(c.hints + (size_t)(e[1] + c.strand * c.hint_stride) * c.ws);
+    if (type == H2E_SX_SEL) return ws_load<FP::WW>(c.sel + ((size_t)H2E_SEL_SLOTS * (e[1] + c.strand * c.sel_stride) + e[2]) * c.ws);
+    return g_load<FP::WW>(c.inputs + (size_t)(e[1] + c.strand * c.input_stride) * c.sw);
 }
 template <class FP>
 __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_hint_store(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
     constexpr int NL = FP::L;
+    // lanes: [store op][strand][instance], instances minor (a forked segment's store ops run once per strand, at the strand's
+    // row offsets, with its hint / selection / input slots and parameters)
     u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 total = L.n_sops * n_instances;
+    u32 total = L.n_sops * L.n_strands * n_instances;
     bool active = gid < total;
     if (!active) gid = total - 1;
-    u32 instance = gid % n_instances, sop = gid / n_instances;
+    u32 instance = gid % n_instances, strand = (gid / n_instances) % L.n_strands, sop = gid / n_instances / L.n_strands;
     InstanceDesc d = inst[instance];
     LC c;
     c.base = d.base;
@@ -2276,14 +2290,14 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_hint_store(H2ELaunch 
     c.select = d.select;
     c.inputs = d.inputs;
     c.status = d.status;
-    c.ob = L.strand_base0;
-    c.orr = L.strand_range0;
-    c.os = L.strand_select0;
-    c.params = L.params;
+    c.ob = L.strand_base0 + strand * L.delta_base;
+    c.orr = L.strand_range0 + strand * L.delta_range;
+    c.os = L.strand_select0 + strand * L.delta_select;
+    c.params = L.params + (size_t)strand * L.n_params;
     c.aux = L.aux;
     c.pool = L.const_pool;
     c.fc = &g_fc[FP::ID];
-    c.strand = 0;
+    c.strand = strand;
     c.input_stride = L.input_stride;
     c.sw = L.slot_words;
     c.hints = d.hints;
@@ -2293,11 +2307,12 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_hint_store(H2ELaunch 
     c.sel_stride = L.sel_stride;
     c.hs = 2 * n_instances;
     c.active = active;
+    const u32* ext = L.s_ext;
     const u32* rec = L.s_words + L.s_offsets[sop];
     u32 w0 = rec[0], row = rec[1], rrow = rec[2];
     u32 kind = w0 & 0xffu, n_terms = (w0 >> 8) & 0xffu, kidx = w0 >> 16;
     if (kind == H2E_S_W) {   // a mul-like result: limbs in its range rows, native in its base row
-        Wd<FP::WW> x = hs_leaf<FP>(c, rec[3]);
+        Wd<FP::WW> x = hs_leaf<FP>(c, rec[3], ext);
         Limb l[NL];
         split_limbs<FP>(x, l);
         if (active) {
@@ -2319,10 +2334,19 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_hint_store(H2ELaunch 
         for (u32 t = 0; t < n_terms; t++) {
             u32 tw = rec[3 + t];
             int coef = (int)((tw >> 22) & 0xffu) - 128;
-            Wd<FP::WW> x = hs_leaf<FP>(c, tw);
             Limb l[NL];
-            split_limbs<FP>(x, l);
-            Fe xn = native_of_w<FP>(c, x);
+            Fe xn;
+            if ((tw >> 30) == 3u && ext[(size_t)(tw & 0x3fffffu) * H2E_SX_WORDS] == H2E_SX_CELLS) {
+                // an integer from outside the segment, as its cells hold it (its limbs need not be the canonical split)
+                const u32* e = ext + (size_t)(tw & 0x3fffffu) * H2E_SX_WORDS + 1;
+#pragma unroll
+                for (int i = 0; i < NL; i++) l[i] = ld_limb(c, e[i]);
+                xn = ld_fe(c, e[NL]);
+            } else {
+                Wd<FP::WW> x = hs_leaf<FP>(c, tw, ext);
+                split_limbs<FP>(x, l);
+                xn = native_of_w<FP>(c, x);
+            }
             u32 m = (u32)(coef < 0 ? -coef : coef);
 #pragma unroll
             for (int i = 0; i < NL; i++) {
@@ -2356,10 +2380,10 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_hint_store(H2ELaunch 
             stB(c, row + NL, 4, natr);
         }
     } else if (kind == H2E_S_FE) {
-        Wd<FP::WW> x = hs_leaf<FP>(c, rec[3]);
+        Wd<FP::WW> x = hs_leaf<FP>(c, rec[3], ext);
         if (active) stB(c, row, 4, fe_u64(x.v[0] & 1));
     } else if (kind == H2E_S_CONST) {   // assign_int_constant: limb i in (row + i, col 0), native in (row + L, col 0)
-        Wd<FP::WW> x = hs_leaf<FP>(c, rec[3]);
+        Wd<FP::WW> x = hs_leaf<FP>(c, rec[3], ext);
         Limb l[NL];
         split_limbs<FP>(x, l);
         Fe native = mod_n<FP::WW>(c, x);
@@ -4274,7 +4298,7 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
     }
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
     if ((mode & 1) && launch->s_words) {                                                                                        \
-        u32 lanes = launch->n_sops * n_instances;                                                                              \
+        u32 lanes = launch->n_sops * launch->n_strands * n_instances;                                                          \
         if (lanes) hipLaunchKernelGGL(h2e_hint_store<FP>, dim3((lanes + 63) / 64), dim3(64), 0, stream, *launch, inst, n_instances); \
         mode &= ~1;                                                                                                            \
     }                                                                                                                          \

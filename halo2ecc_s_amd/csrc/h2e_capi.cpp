@@ -148,6 +148,8 @@ struct h2e_program {
     std::vector<uint32_t> seg_l_begin, seg_l_steps, seg_l_slots, seg_l_pair;
     // hint store (field_chain.hpp): per segment with field hints, in place of a compiled replay
     std::vector<uint32_t> h_swords, h_soffsets, seg_s_begin, seg_so_begin, seg_sk_begin, seg_n_sops;
+    std::vector<uint32_t> h_sext, seg_sx_begin;   // extension leaves of the store records (tape.h H2EStoreExt)
+    uint32_t* d_sext = nullptr;
     std::vector<uint64_t> h_sktab;
     uint32_t *d_swords = nullptr, *d_soffsets = nullptr;
     uint64_t* d_sktab = nullptr;
@@ -189,6 +191,7 @@ struct h2e_program {
             (void)hipFree(d_swords);
             (void)hipFree(d_soffsets);
             (void)hipFree(d_sktab);
+            (void)hipFree(d_sext);
             for (int i = 0; i < 3; i++) (void)hipFree(d_flags[i]);
         }
         for (int i = 0; i < 3; i++) (void)hipFree(d_fix[i]);
@@ -477,8 +480,205 @@ struct h2e_program {
         seg_so_begin.assign(r.segments.size(), 0);
         seg_sk_begin.assign(r.segments.size(), 0);
         seg_n_sops.assign(r.segments.size(), 0);
+        // A segment whose mul-like results all have hints from the MSM predictors (the windows' strands, the tail) needs no
+        // chain to put its escaping values in place either: every one of them is a hint or a limb-wise combination of hints,
+        // pre-selected candidates and integers that were stored before the segment started (field_chain.hpp "hint store",
+        // records with extension leaves).  Whatever does not fit that description keeps its compiled replay.
+        seg_sx_begin.assign(r.segments.size(), 0);
+        auto compile_plain_store = [&](const CutSeg& c) -> bool {
+            const h2e::Segment& sg = *c.sg;
+            if (getenv("H2E_NO_PLAIN_STORE") || sg.field_pair != r.fp.id) return false;
+            const int L = r.fp.limbs;
+            const uint32_t rel = sg.is_fork ? 1 : 0;
+            h2e::FieldCompiler fcmp = field_compiler(c);
+            h2e::HintStore hs;
+            h2e::StoreCompiler sc;
+            sc.ops = c.ops;
+            sc.n_ops = c.n_ops;
+            sc.L = L;
+            sc.fc = &r.fp.fc;
+            sc.fcmp = &fcmp;
+            sc.next_aux = 0;
+            typedef h2e::StoreCompiler::Lin Lin;
+            std::vector<uint32_t> ext;
+            std::map<std::array<uint32_t, H2E_SX_WORDS>, uint32_t> ext_index;
+            bool overflow = false;
+            auto ext_leaf = [&](const std::array<uint32_t, H2E_SX_WORDS>& e) -> uint32_t {
+                auto it = ext_index.find(e);
+                uint32_t idx;
+                if (it != ext_index.end()) idx = it->second;
+                else {
+                    idx = (uint32_t)(ext.size() / H2E_SX_WORDS);
+                    ext.insert(ext.end(), e.begin(), e.end());
+                    ext_index[e] = idx;
+                }
+                if (idx >= (1u << 22)) overflow = true;
+                return (3u << 30) | (idx & 0x3fffffu);
+            };
+            auto small_leaf = [&](uint32_t kind, uint32_t index) -> uint32_t {
+                if (index >= (1u << 22)) overflow = true;
+                return (kind << 30) | (index & 0x3fffffu);
+            };
+            std::vector<Lin> lin(c.n_ops);
+            std::vector<uint8_t> have(c.n_ops, 0);   // 1 done, 2 failed
+            auto add_leaf = [](Lin& t, uint32_t leaf, int scale) {
+                int& v = t.leaf[leaf];
+                v += scale;
+                if (v == 0) t.leaf.erase(leaf);
+            };
+            auto add_ceil = [](Lin& t, uint32_t times) {
+                int& v = t.ceil[times];
+                v += 1;
+                if (v == 0) t.ceil.erase(times);
+            };
+            std::function<bool(uint32_t)> flatten = [&](uint32_t pi) -> bool {
+                if (have[pi]) return have[pi] == 1;
+                have[pi] = 2;
+                const H2EOp& op = c.ops[pi];
+                Lin rr;
+                auto opd = [&](int refpos, int scale) -> bool {   // rr += scale * (the integer whose first limb cell is refs[refpos])
+                    uint32_t ref = op.refs[refpos];
+                    if (ref == H2E_NO_REF) return false;
+                    uint32_t region = H2E_REF_REGION(ref), row = H2E_REF_ROW(ref);
+                    bool internal = region != H2E_REGION_PARAM && H2E_REF_REL(ref) == rel && (rel || (row >= c.first[region] && row < c.last[region]));
+                    if (internal && region <= 1) {
+                        int q = fcmp.int_producer(ref);
+                        if (q < 0 || (uint32_t)q >= pi || !flatten((uint32_t)q)) return false;
+                        h2e::StoreCompiler::add_scaled(rr, lin[q], scale);
+                        return true;
+                    }
+                    if (internal) {   // select rows: a coordinate of the point the select pre-kernel picked
+                        int q = producer(c, 2, row);
+                        if (q < 0 || (uint32_t)q >= pi) return false;
+                        const H2EOp& so = c.ops[q];
+                        if (so.opcode != H2E_OP_SELECT_POINT || !(so.flags & H2E_FLAG_PRESELECTED) || ((so.flags >> 8) & 0xffu) != 0 || H2E_REF_COL(ref) != 0) return false;
+                        uint32_t off = row - so.select_row;
+                        if (off != 0 && off != (uint32_t)L + 1) return false;
+                        std::array<uint32_t, H2E_SX_WORDS> e{};
+                        e[0] = H2E_SX_SEL;
+                        e[1] = so.refs[1];
+                        e[2] = off ? 1u : 0u;
+                        add_leaf(rr, ext_leaf(e), scale);
+                        return true;
+                    }
+                    // an integer of another segment (or reached through the strand's parameters): its cells were stored before this
+                    // segment's value chain started - the replay read them from there as well
+                    std::array<uint32_t, H2E_SX_WORDS> e{};
+                    e[0] = H2E_SX_CELLS;
+                    for (int i = 0; i <= L; i++) e[1 + i] = op.refs[refpos + i];
+                    add_leaf(rr, ext_leaf(e), scale);
+                    return true;
+                };
+                bool ok = true;
+                switch (op.opcode) {
+                    case H2E_OP_INT_MUL: case H2E_OP_REDUCE: case H2E_OP_DIV_CORE:
+                        if (!(op.flags & H2E_FLAG_HINTED)) { ok = false; break; }
+                        if (op.flags & H2E_FLAG_HINT_STRIDED) {
+                            std::array<uint32_t, H2E_SX_WORDS> e{};
+                            e[0] = H2E_SX_HINT;
+                            e[1] = op.imm;
+                            add_leaf(rr, ext_leaf(e), 1);
+                        } else add_leaf(rr, small_leaf(0, op.imm), 1);
+                        break;
+                    case H2E_OP_CONST_INT: add_leaf(rr, small_leaf(1, op.imm), 1); break;
+                    case H2E_OP_ASSIGN_W: case H2E_OP_CONST_INT_INPUT:
+                        if (op.flags & H2E_FLAG_INPUT_STRIDED) {
+                            std::array<uint32_t, H2E_SX_WORDS> e{};
+                            e[0] = H2E_SX_INPUT;
+                            e[1] = op.imm;
+                            add_leaf(rr, ext_leaf(e), 1);
+                        } else add_leaf(rr, small_leaf(2, op.imm), 1);
+                        break;
+                    case H2E_OP_INT_ADD: ok = opd(0, 1) && opd(L + 1, 1); break;
+                    case H2E_OP_INT_SUB:   // a - b + C_(b.times)   (integer_chip.rs:408-437)
+                        ok = opd(0, 1) && opd(L + 1, -1);
+                        add_ceil(rr, op.imm);
+                        break;
+                    case H2E_OP_INT_NEG:   // C_(a.times) - a       (:439-464)
+                        ok = opd(0, -1);
+                        add_ceil(rr, op.imm);
+                        break;
+                    case H2E_OP_INT_MUL_SMALL: ok = opd(0, (int)op.imm); break;
+                    default: ok = false; break;
+                }
+                if (!ok) return false;
+                lin[pi] = std::move(rr);
+                have[pi] = 1;
+                return true;
+            };
+            {
+                Lin zero;
+                sc.k_of(hs, zero);   // entry 0 of the K table
+            }
+            auto emit = [&](uint32_t kind, uint32_t k_idx, uint32_t w1, uint32_t w2, const std::vector<uint32_t>& terms) -> bool {
+                if (terms.size() > 255 || k_idx > 0xffff) return false;
+                hs.offsets.push_back((uint32_t)hs.words.size());
+                hs.words.push_back(kind | ((uint32_t)terms.size() << 8) | (k_idx << 16));
+                hs.words.push_back(w1);
+                hs.words.push_back(w2);
+                hs.words.insert(hs.words.end(), terms.begin(), terms.end());
+                return true;
+            };
+            auto term = [](uint32_t leaf_word, int coef) -> uint32_t { return (leaf_word & 0xc0000000u) | ((uint32_t)(coef + 128) << 22) | (leaf_word & 0x3fffffu); };
+            for (uint32_t i = 0; i < c.n_ops; i++) {
+                const H2EOp& op = c.ops[i];
+                if (op.flags & H2E_FLAG_VALUES_SKIP) continue;
+                const bool stored = c.escapes[i] || !c.sub_fits[c.sub_of[i]];
+                switch (op.opcode) {
+                    case H2E_OP_NOP: case H2E_OP_ASSERT_CONST: case H2E_OP_SUM_LIMBS: case H2E_OP_CACHE_INT: break;   // nothing in values mode
+                    case H2E_OP_PICK_INDEX:
+                        if (!(op.flags & H2E_FLAG_PRESELECTED) && stored) return false;
+                        break;
+                    case H2E_OP_SELECT_POINT:
+                        if (!(op.flags & H2E_FLAG_PRESELECTED) || stored) return false;
+                        break;
+                    case H2E_OP_ASSIGN_W: case H2E_OP_ASSIGN: case H2E_OP_ASSIGN_BIT: case H2E_OP_CONST: case H2E_OP_CONST_INT_INPUT:
+                        if (!emit(H2E_S_FULL, 0, i, 0, {})) return false;   // ops without operands: run as they are
+                        break;
+                    case H2E_OP_CONST_INT:
+                        if (stored && !emit(H2E_S_CONST, 0, op.base_row, 0, {term(small_leaf(1, op.imm), 1)})) return false;
+                        break;
+                    case H2E_OP_INT_MUL: case H2E_OP_REDUCE: case H2E_OP_DIV_CORE: {
+                        if (!stored) break;
+                        if (!flatten(i)) return false;
+                        if (!emit(H2E_S_W, 0, op.base_row, op.range_row, {term(lin[i].leaf.begin()->first, 1)})) return false;
+                    } break;
+                    case H2E_OP_INT_ADD: case H2E_OP_INT_SUB: case H2E_OP_INT_NEG: case H2E_OP_INT_MUL_SMALL: {
+                        if (!stored) break;
+                        if (!flatten(i)) return false;
+                        std::vector<uint32_t> terms;
+                        long weight = 1;
+                        for (auto& kv : lin[i].leaf) {
+                            if (kv.second < -127 || kv.second > 127) return false;
+                            terms.push_back(term(kv.first, kv.second));
+                            weight += std::abs(kv.second);
+                        }
+                        if (weight >= 4096) return false;
+                        if (!emit(H2E_S_LIN, sc.k_of(hs, lin[i]), op.base_row, 0, terms)) return false;
+                    } break;
+                    default:   // conditions, selections, decompositions ...: only if nothing outside their sub-range reads them
+                        if (stored) return false;
+                        break;
+                }
+            }
+            if (overflow || hs.offsets.empty()) return false;
+            size_t si = (size_t)(c.sg - r.segments.data());
+            seg_s_begin[si] = (uint32_t)h_swords.size();
+            seg_so_begin[si] = (uint32_t)h_soffsets.size();
+            seg_sk_begin[si] = (uint32_t)h_sktab.size();
+            seg_sx_begin[si] = (uint32_t)h_sext.size();
+            seg_n_sops[si] = (uint32_t)hs.offsets.size();
+            h_swords.insert(h_swords.end(), hs.words.begin(), hs.words.end());
+            h_soffsets.insert(h_soffsets.end(), hs.offsets.begin(), hs.offsets.end());
+            h_sktab.insert(h_sktab.end(), hs.ktab.begin(), hs.ktab.end());
+            h_sext.insert(h_sext.end(), ext.begin(), ext.end());
+            if (dbg_env("H2E_DUMP_TAPE"))
+                fprintf(stderr, "segment %zu: plain hint store in place of the replay: %zu store ops per strand, %zu words, %zu extension leaves\n", si,
+                        hs.offsets.size(), hs.words.size(), ext.size() / H2E_SX_WORDS);
+            return true;
+        };
         for (auto& c : cs)
-            if (!c.sg->field_hints)
+            if (!c.sg->field_hints && !compile_plain_store(c))
                 compile_replay(c.sg, c.ops, c.n_ops, c.first, c.last, [&](uint32_t region, uint32_t row) { return producer(c, region, row); });
         // 6. segments with field hints: the hint store in place of a replay, and the field-domain predictor whose program
         // goes into the pre-kernel args
@@ -2409,6 +2609,7 @@ static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
     HIP_TRY(up((void**)&p->d_swords, p->h_swords.empty() ? nullptr : p->h_swords.data(), p->h_swords.size() * 4));
     HIP_TRY(up((void**)&p->d_soffsets, p->h_soffsets.empty() ? nullptr : p->h_soffsets.data(), p->h_soffsets.size() * 4));
     HIP_TRY(up((void**)&p->d_sktab, p->h_sktab.empty() ? nullptr : p->h_sktab.data(), p->h_sktab.size() * 8));
+    HIP_TRY(up((void**)&p->d_sext, p->h_sext.empty() ? nullptr : p->h_sext.data(), p->h_sext.size() * 4));
     p->device = ctx->device;
     return 0;
 }
@@ -2725,6 +2926,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         L.s_offsets = hstore ? p->d_soffsets + p->seg_so_begin[si] : nullptr;
         L.s_ktab = hstore ? p->d_sktab + p->seg_sk_begin[si] : nullptr;
         L.n_sops = hstore ? p->seg_n_sops[si] : 0;
+        L.s_ext = hstore && si < p->seg_sx_begin.size() ? p->d_sext + p->seg_sx_begin[si] : nullptr;
         L.dg_out = d_digests ? J.dg_shards : nullptr;
         L.dg_shards = H2E_DG_SHARDS;
         L.l_steps = levels ? p->seg_l_steps[si] : 0;
@@ -3049,7 +3251,7 @@ int h2e_program_launches(const h2e_program* p, uint64_t* out, uint32_t cap) {
             o[4] = s.drange;
             o[5] = s.dselect;
             o[6] = s.n_params;
-            o[7] = s.base0;
+            o[7] = s.is_fork ? s.base0 : r.tape[s.tape_begin].base_row;   // (main context: the base row its first op starts at)
         }
         k++;
     }
@@ -3078,6 +3280,24 @@ int h2e_program_tape_opcodes(const h2e_program* p, uint32_t launch, uint16_t* op
         if (n_subs) *n_subs = (uint32_t)b.size();
         for (size_t i = 0; i < b.size() && i < subs_cap; i++) subs[i] = b[i];
         return (int)n_ops;
+    }
+    return fail(H2E_ERR_INVALID, "no such launch");
+}
+
+// Diagnostics: how the value chain of the k-th launch puts its escaping values in place: out[0] = store ops per strand of a hint
+// store (0: none), out[1] = pieces of a compiled replay (0: none), out[2] = 1 if the segment has a field chain
+int h2e_program_value_chain_kind(const h2e_program* p, uint32_t launch, uint32_t* out3) {
+    if (!p || !out3) return fail(H2E_ERR_INVALID, "null argument");
+    const h2e::Recorder& r = *p->rec;
+    uint32_t k = 0;
+    for (size_t si = 0; si < r.segments.size(); si++) {
+        const h2e::Segment& s = r.segments[si];
+        if (s.tape_end <= s.tape_begin) continue;
+        if (k++ != launch) continue;
+        out3[0] = si < p->seg_n_sops.size() ? p->seg_n_sops[si] : 0;
+        out3[1] = si < p->seg_n_pieces.size() ? p->seg_n_pieces[si] : 0;
+        out3[2] = s.field_hints ? 1 : 0;
+        return 0;
     }
     return fail(H2E_ERR_INVALID, "no such launch");
 }

@@ -369,6 +369,14 @@ struct Recorder {
         segments.back().n_fixups = (uint32_t)fixups.size() - segments.back().fixups_begin;
         segments.back().n_cuts = (uint32_t)cuts.size() - segments.back().cuts_begin;
     }
+    // End the main context's current segment here and open the next one: what follows becomes a launch of its own, with its own
+    // kind of value chain (the MSM's accumulation loop - every mul-like result hinted - ahead of the unhinted rest of the call).
+    void split_segment() {
+        if (in_strand) throw std::runtime_error("split_segment inside a fork");
+        if (tape.size() == cur_tape_begin) return;
+        close_segment();
+        begin_segment();
+    }
     // Mark a point where the full expansion of the current segment may be split (see H2ELaunch.sub).
     void cut() {
         if (!record_tape) return;

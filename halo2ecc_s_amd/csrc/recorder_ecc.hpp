@@ -859,8 +859,10 @@ struct NativeScalarEccContext {
         }
         c.end_hints();
         // the rest of the main context (final curvature + carry add, then the caller's ecc_assert_equal) holds two
-        // unhinted divisions: split its expansion finely, or one lane carries both inversions (3 ms of a 4 ms kernel)
+        // unhinted divisions: a segment of its own (the loop above then needs no replay: every value that escapes one of its
+        // sub-ranges is a combination of hints), its expansion split finely, or one lane carries both inversions (3 ms of a 4 ms kernel)
         c.cut();
+        c.split_segment();
         c.auto_cut_every = 4;
         AssignedPoint accp = ecc_non_zero_point_downgrade(acc);
         AssignedPointWithCurvature accc = to_point_with_curvature(accp);

@@ -194,6 +194,7 @@ typedef struct H2ELaunch {
     const uint32_t* s_offsets;    // [n_sops] first word of each record
     const uint64_t* s_ktab;       // K constants, (2 L + 4) words each
     uint32_t n_sops;
+    const uint32_t* s_ext;        // extension table of the store records' leaves (H2E_SX_WORDS words per entry, engine.hip hs_leaf)
     // stream digest of the run (h2e.h h2e_run_digest): [dg_shards][3][n_instances][4] words the expansion / fix-up kernels add to
     // (a workgroup adds to shard blockIdx.x mod dg_shards - 3.3 M lanes adding to the 768 words of 64 instances would queue up
     // behind a handful of L2 channels; h2e_digest_reduce sums the shards at the end of the run); NULL = off
@@ -201,6 +202,10 @@ typedef struct H2ELaunch {
     uint32_t dg_shards;           // a power of two
 } H2ELaunch;
 enum H2EStoreKind { H2E_S_W = 1, H2E_S_LIN = 2, H2E_S_FE = 3, H2E_S_CONST = 4, H2E_S_FULL = 5 };
+// leaves that do not fit a term word (kind 3: index into H2ELaunch::s_ext): strand-strided hint / selection / input slots and
+// integers read from cells that were written before the launch
+enum H2EStoreExt { H2E_SX_HINT = 0, H2E_SX_SEL = 1, H2E_SX_CELLS = 2, H2E_SX_INPUT = 3 };
+#define H2E_SX_WORDS 8u
 
 // ---- compiled values-only replay ("V-tape") ----------------------------------------------------
 // The values-only replay of a cut segment does not interpret the witness tape: the host compiles it (once per

@@ -78,17 +78,19 @@ def test_check_small_cases_match_the_oracles_checker(engine, oracle, name, make,
                 continue
             picks.append((region, row, col))
     assert picks
+    n_caught = 0
     for region, row, col in picks:
         o = orun(ins[1])
         o.corrupt(region, row, col)
-        want = o.check_counts().astype(np.int64)
-        assert want.sum() > 0, (region, row, col)
+        want = o.check_counts().astype(np.int64)   # (all zero for a cell no gate constrains: the second copy of an assign_bit, quirk Q2)
+        n_caught += int(want.sum() > 0)
         cell = int(arrs[region][row, col, 0, 1, 0])   # (a Python int: indexing gives a view that would follow the write)
         arrs[region][row, col, 0, 1, 0] = cell + 1
         f = _fail(engine, prog, d_in, base, rng, sel)
         arrs[region][row, col, 0, 1, 0] = cell
         assert (f[0, :E.CHECK_CLASSES] == 0).all() and (f[2, :E.CHECK_CLASSES] == 0).all(), (region, row, col, f)
         assert np.array_equal(f[1, :E.CHECK_CLASSES], want), (name, region, row, col, f[1], want)
+    assert n_caught > 0
     # a single class on request
     f = _fail(engine, prog, d_in, base, rng, sel, classes=1 << E.CHECK_BASE_GATE)
     assert (f[:, :E.CHECK_CLASSES] == 0).all()

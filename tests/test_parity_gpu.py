@@ -180,8 +180,9 @@ def test_export_columns_and_montgomery_of_a_witness(engine, oracle):
 def test_msm_value_chain_does_not_depend_on_expansion(engine, oracle):
     """The expansion of a cut segment runs on its own stream, concurrently with the value chain of the following
     segments, so the value chain may only read cells the value chain itself stored.  With the expansion of every
-    cut segment but the last left out (test hook), the last segment - the MSM tail, which reads the windows' sums -
-    must still come out exactly right.  (Regression: the tail's references into the windows were not counted.)"""
+    cut segment but the last left out (test hook), the last segment - what follows the MSM's accumulation loop, whose
+    sums come from the windows' sums - must still come out exactly right.  (Regression: the tail's references into the
+    windows were not counted.)"""
     n = 24
     inp, _ = synth.msm_bn256_tile_inputs(n, tile=3)
     prog = Program.msm_bn256_tile(n)
@@ -194,12 +195,15 @@ def test_msm_value_chain_does_not_depend_on_expansion(engine, oracle):
     assert (status == E.ST_TEST_HOOK).all(), status   # the hook marks the run: its arrays are not a witness
     orun = oracle_lib.run_msm_bn256_tile(n, inp)
     assert orun.info.status == 0, orun.error
-    win = prog.launches()[-2]
-    tail0 = win["base0"] + win["dbase"] * win["n_strands"]
+    # the last launch: what follows the accumulation loop (final curvature + carry add + the test body's ecc_assert_equal); its
+    # value chain reads the loop's last sum, which the loop's value chain made from the windows' sums, which ...
+    launches = prog.launches()
+    assert launches[-1]["n_strands"] == 1 and launches[-2]["n_strands"] == 1 and launches[-3]["n_strands"] == 254
+    last0 = launches[-1]["base0"]
     ovals, _ = orun.adv(0, prog.base_rows)
     got = base[0].cpu().numpy().view(np.uint64)
-    assert np.array_equal(got[tail0:], ovals[tail0:]), "tail differs when the windows' expansion is left out"
-    assert not np.array_equal(got[:tail0], ovals[:tail0]), "the hook left nothing out"
+    assert np.array_equal(got[last0:], ovals[last0:]), "the last segment differs when the expansions before it are left out"
+    assert not np.array_equal(got[:last0], ovals[:last0]), "the hook left nothing out"
 
 
 @pytest.mark.parametrize("pct", [10, 45, 90])
