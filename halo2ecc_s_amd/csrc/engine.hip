@@ -1286,6 +1286,7 @@ __global__ void __launch_bounds__(64) h2e_run_tape_packed(H2ELaunch L, const Ins
     __shared__ u64 dg_sums[12 * 64];
     __shared__ u32 rank_lds[32];                  // g_pk_rank_of, read per lane in the loop: from LDS (a global load there would wait
                                                   // for every store the wave has in flight - one counter, in order)
+    extern __shared__ u64 xcache_dyn[];           // [3][2 L + 4][64] words when the result cache is on (H2ELaunch.rel_refs bit 2)
     if (L.rel_refs & 8) __builtin_amdgcn_s_setprio(3);
     const u32 lane = threadIdx.x, P = 1u << log2p, G = 64u >> log2p;
     if (lane < 32u) rank_lds[lane] = lane < (u32)H2E_OP_COUNT ? (u32)g_pk_rank_of[lane] : 0xffu;
@@ -1323,6 +1324,7 @@ __global__ void __launch_bounds__(64) h2e_run_tape_packed(H2ELaunch L, const Ins
     c.hint_stride = L.hint_stride;
     c.hs = 2 * n_instances;
     c.active = group_on && ii < per_sub;
+    c.xc = (L.rel_refs & 4) ? xcache_dyn : nullptr;
     if (L.dg_out != nullptr) {
 #pragma unroll
         for (int k = 0; k < 12; k++) l_st8(dg_sums + k * 64 + lane, 0);
@@ -2331,30 +2333,63 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_hint_store(H2ELaunch 
         }
         Wd<5> nat = wd_resize<5>(g_load<4>(kt + 2 * NL));
         Fe n = n_of(c);
-        for (u32 t = 0; t < n_terms; t++) {
-            u32 tw = rec[3 + t];
-            int coef = (int)((tw >> 22) & 0xffu) - 128;
-            Limb l[NL];
-            Fe xn;
-            if ((tw >> 30) == 3u && ext[(size_t)(tw & 0x3fffffu) * H2E_SX_WORDS] == H2E_SX_CELLS) {
-                // an integer from outside the segment, as its cells hold it (its limbs need not be the canonical split)
-                const u32* e = ext + (size_t)(tw & 0x3fffffu) * H2E_SX_WORDS + 1;
+        // Terms in batches of TB: the term words, then their extension entries, then the leaves themselves - three rounds of
+        // independent loads per batch instead of three dependent loads per term (a windows' record has ~10 terms, and a dependent
+        // load costs microseconds next to a running expansion).  A padding term has coefficient 0; every load of a batch is
+        // unconditional (a leaf that is not a W value - an integer in cells - or a padding term reads hint slot 0 and ignores it).
+        constexpr u32 TB = 6;
+        for (u32 t0 = 0; t0 < n_terms; t0 += TB) {
+            u32 tw[TB], e0[TB], e1[TB], e2[TB];
 #pragma unroll
-                for (int i = 0; i < NL; i++) l[i] = ld_limb(c, e[i]);
-                xn = ld_fe(c, e[NL]);
-            } else {
-                Wd<FP::WW> x = hs_leaf<FP>(c, tw, ext);
-                split_limbs<FP>(x, l);
-                xn = native_of_w<FP>(c, x);
-            }
-            u32 m = (u32)(coef < 0 ? -coef : coef);
+            for (u32 k = 0; k < TB; k++) tw[k] = t0 + k < n_terms ? rec[3 + t0 + k] : (128u << 22);
 #pragma unroll
-            for (int i = 0; i < NL; i++) {
-                Limb p = wd_resize<2>(wd_mul_small<2>(l[i], m));
-                acc[i] = coef < 0 ? wd_sub<2>(acc[i], p) : wd_add<2>(acc[i], p);
+            for (u32 k = 0; k < TB; k++) {
+                const u32* e = ext + (size_t)((tw[k] >> 30) == 3u ? (tw[k] & 0x3fffffu) : 0u) * H2E_SX_WORDS;
+                e0[k] = e[0];
+                e1[k] = e[1];
+                e2[k] = e[2];
             }
-            if (coef < 0) xn = wd_sub<4>(n, xn);   // -x = n - x (in (0, n])
-            wd_mac_small<4>(nat, xn, m);
+            Wd<FP::WW> x[TB];
+            bool cells[TB];
+#pragma unroll
+            for (u32 k = 0; k < TB; k++) {
+                u32 kind = tw[k] >> 30, index = tw[k] & 0x3fffffu;
+                const u64* p = c.hints + (size_t)index * c.ws;                                   // kind 0: hint slot
+                if (kind == 1) p = c.pool + index;
+                if (kind == 2) p = c.inputs + (size_t)index * c.sw;
+                cells[k] = kind == 3u && e0[k] == H2E_SX_CELLS;
+                if (kind == 3u) {
+                    p = c.hints + (size_t)(e1[k] + c.strand * c.hint_stride) * c.ws;             // H2E_SX_HINT
+                    if (e0[k] == H2E_SX_SEL) p = c.sel + ((size_t)H2E_SEL_SLOTS * (e1[k] + c.strand * c.sel_stride) + e2[k]) * c.ws;
+                    if (e0[k] == H2E_SX_INPUT) p = c.inputs + (size_t)(e1[k] + c.strand * c.input_stride) * c.sw;
+                    if (cells[k]) p = c.hints;
+                }
+                x[k] = g_load<FP::WW>(p);
+            }
+#pragma unroll
+            for (u32 k = 0; k < TB; k++) {
+                int coef = (int)((tw[k] >> 22) & 0xffu) - 128;
+                Limb l[NL];
+                Fe xn;
+                if (cells[k]) {
+                    // an integer from outside the segment, as its cells hold it (its limbs need not be the canonical split)
+                    const u32* e = ext + (size_t)(tw[k] & 0x3fffffu) * H2E_SX_WORDS + 1;
+#pragma unroll
+                    for (int i = 0; i < NL; i++) l[i] = ld_limb(c, e[i]);
+                    xn = ld_fe(c, e[NL]);
+                } else {
+                    split_limbs<FP>(x[k], l);
+                    xn = native_of_w<FP>(c, x[k]);
+                }
+                u32 m = (u32)(coef < 0 ? -coef : coef);
+#pragma unroll
+                for (int i = 0; i < NL; i++) {
+                    Limb p = wd_resize<2>(wd_mul_small<2>(l[i], m));
+                    acc[i] = coef < 0 ? wd_sub<2>(acc[i], p) : wd_add<2>(acc[i], p);
+                }
+                if (coef < 0) xn = wd_sub<4>(n, xn);   // -x = n - x (in (0, n])
+                wd_mac_small<4>(nat, xn, m);
+            }
         }
         // nat < 2^12 n (the host rejects a combination whose |coefficients| sum to 4096 or more, field_chain.hpp HintStore::compile:
         // the top word taken below is 64 bits): small-quotient reduction
@@ -4324,8 +4359,8 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
                            stream, *launch, inst, n_instances);                                                                \
     if ((mode & 1) && !launch->vtape) return -2;   /* a values-only replay always runs from the compiled V-tape */          \
     if ((mode & 2) && pack_log2p >= 0)                                                                                         \
-        hipLaunchKernelGGL(h2e_run_tape_packed<FP>, dim3((n_sub + (64u >> pack_log2p) - 1) / (64u >> pack_log2p)), block, 0, stream, launch_x, inst, \
-                           n_instances, (u32)pack_log2p);                                                                      \
+        hipLaunchKernelGGL(h2e_run_tape_packed<FP>, dim3((n_sub + (64u >> pack_log2p) - 1) / (64u >> pack_log2p)), block,              \
+                           xcache_on ? (size_t)3 * (2 * FP::L + 4) * 64 * 8 : 0, stream, launch_x, inst, n_instances, (u32)pack_log2p);  \
     else if (mode & 2)                                                                                                         \
         hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid_x, block,                                                           \
                            (xcache_on ? (size_t)3 * (2 * FP::L + 4) * 64 * 8 : 0) + (grid.x > 4096 ? (size_t)g_tune[2] : 0),   \
