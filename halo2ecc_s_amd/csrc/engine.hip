@@ -2911,7 +2911,7 @@ __global__ void __launch_bounds__(128) h2e_field_chain(H2EPreKernel K, const u32
             u32 opc = ra.x & 0xffu, dst = ra.x >> 16, hint = ra.y;
             Wd<N> out = wd_zero<N>();
             if constexpr (LOADS) {   // values entering: inputs and pool constants
-                if (opc == H2E_F_INPUT_W) out = to_mont<N>(M, g_load<N>(d.inputs + (size_t)ra.z * K.n_params));
+                if (opc == H2E_F_INPUT_W) out = to_mont<N>(M, (ra.x & H2E_F_FROM_HINTS) ? ws_load<N>(d.hints + (size_t)ra.z * d.ws) : g_load<N>(d.inputs + (size_t)ra.z * K.n_params));
                 else if (opc == H2E_F_CONST_W) out = to_mont<N>(M, g_load<N>(pool + ra.z));
                 else if (opc == H2E_F_INPUT_FE) out.v[0] = g_ld8(d.inputs + (size_t)ra.z * K.n_params);
                 else if (opc == H2E_F_CONST_FE) out.v[0] = g_ld8(pool + ra.z);
@@ -3270,6 +3270,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
             bool raw = false;
             if constexpr (LOADS) {   // values entering: inputs and pool constants
                 const u64* src = (opc == H2E_F_INPUT_W || opc == H2E_F_INPUT_FE) ? d.inputs + (size_t)w2 * K.n_params : pool + w2;
+                if (opc == H2E_F_INPUT_W && (w0 & H2E_F_FROM_HINTS)) src = d.hints + (size_t)w2 * d.ws;   // a value an earlier segment left in a hint slot
                 bool wide = opc == H2E_F_INPUT_W || opc == H2E_F_CONST_W;
                 u32 x = 0;
                 if (wide ? digit_lane : j < 2u) x = ((const H2E_AS_GLOBAL u32*)src)[j];
@@ -4308,7 +4309,15 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
     u32 n_sub = launch->n_sub > 1 ? launch->n_sub : 1;
     dim3 block(64), grid1(blocks_per_sub), grid(blocks_per_sub * n_sub);
     const InstanceDesc* inst = (const InstanceDesc*)instances;
-    const bool xcache_on = (g_tune[1] & 1) != 0;
+    // batches smaller than half a wave: several sub-ranges per wave (h2e_run_tape_packed); g_tune[5] = 1 switches it off (A/B)
+    int pack_log2p = -1;
+    if (per_sub <= 32 && n_sub >= 2 && g_tune[5] == 0) {
+        pack_log2p = 1;   // (at most 32 groups per wave: the kernel's op buffer holds that many chunks)
+        while ((1u << pack_log2p) < per_sub) pack_log2p++;
+    }
+    // the result cache: on request - and for the packed form, whose launches are too small for its LDS to be in anybody's way
+    // (16 x bls12_381: 1.32 -> 1.30 ms, 2 x: 0.58 -> 0.52, 8 x bn256: 0.69 -> 0.61)
+    const bool xcache_on = (g_tune[1] & 1) != 0 || pack_log2p >= 0;
     H2ELaunch launch_x = *launch;
     if (xcache_on) launch_x.rel_refs |= 4u;
     if (g_tune[1] & 2) launch_x.rel_refs |= 8u;
@@ -4324,12 +4333,6 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
         }
         launch_x.x_blocks = grid.x;
         grid_x = dim3((u32)n_cu * (u32)g_tune[4]);
-    }
-    // batches smaller than half a wave: several sub-ranges per wave (h2e_run_tape_packed); g_tune[5] = 1 switches it off (A/B)
-    int pack_log2p = -1;
-    if (per_sub <= 32 && n_sub >= 2 && g_tune[5] == 0) {
-        pack_log2p = 1;   // (at most 32 groups per wave: the kernel's op buffer holds that many chunks)
-        while ((1u << pack_log2p) < per_sub) pack_log2p++;
     }
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
     if ((mode & 1) && launch->s_words) {                                                                                        \
@@ -4421,6 +4424,9 @@ extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2E
         if ((phase & 2) && k->hints_per_lane)                                                                                       \
             hipLaunchKernelGGL(h2e_field_finalize<FP>, dim3((n_instances * k->hints_per_lane + 63) / 64), block, 0, stream,         \
                                k->hint_base, k->hints_per_lane, inst, n_instances);                                                \
+        if ((phase & 2) && k->hints2_per_lane)                                                                                      \
+            hipLaunchKernelGGL(h2e_field_finalize<FP>, dim3((n_instances * k->hints2_per_lane + 63) / 64), block, 0, stream,        \
+                               k->hint2_base, k->hints2_per_lane, inst, n_instances);                                              \
         if ((phase & 2) && k->f_n_sinks)                                                                                            \
             hipLaunchKernelGGL(h2e_field_sinks<FP>, dim3((n_instances * k->f_n_sinks + 63) / 64), block, 0, stream, *k, args_dev,    \
                                (const u64*)params_dev, inst, n_instances);                                                         \

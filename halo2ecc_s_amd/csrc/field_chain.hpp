@@ -20,6 +20,7 @@
 // A record with a hint slot also stores its value (Montgomery form) into the hint workspace; h2e_field_finalize turns
 // the slots into canonical values afterwards.
 #pragma once
+#include <array>
 #include <algorithm>
 #include <functional>
 #include <map>
@@ -40,6 +41,17 @@ struct FieldChain {
     uint32_t n_slots = 0, n_load_rounds = 0;
     uint32_t n_nodes = 0, n_mul = 0, n_lin = 0;
     uint32_t hint_lo = 0xffffffffu, hint_hi = 0;   // hint slots written: [hint_lo, hint_hi)
+    uint32_t hint2_lo = 0xffffffffu, hint2_hi = 0; // ... and those at or above FieldCompiler::hint_split (slots taken at compile time: with several
+                                                   // segments another segment's recorded slots lie between the two ranges, and a finalize must not touch them)
+    void note_hint(uint32_t h, uint32_t split) {
+        if (h >= split) {
+            hint2_lo = std::min(hint2_lo, h);
+            hint2_hi = std::max(hint2_hi, h + 1);
+        } else {
+            hint_lo = std::min(hint_lo, h);
+            hint_hi = std::max(hint_hi, h + 1);
+        }
+    }
     // hint-only linear combinations computed outside the chain (h2e_field_sinks): per sink its first word in sink_words;
     // a sink = hint slot, terms, then per term (coef & 0x1ff) << 23 | kind << 21 | index  (kind 0 hint slot, 1 input slot, 2 pool word)
     std::vector<uint32_t> sink_offsets, sink_words;
@@ -59,12 +71,27 @@ struct FieldCompiler {
     const std::map<uint32_t, uint32_t>* aux = nullptr;
     uint32_t* next_hint = nullptr;                     // further hint slots may be taken from here (values the sinks kernel reads)
     bool digit_rows = true;                            // for h2e_field_chain_digits: rounds of at most 60 records sorted by opcode, 16-word records
+    // A context cut into several segments with field hints (a pairing check: Miller loop | final exponentiation, so that one
+    // segment's expansion runs under the next one's chain): an integer operand produced by an EARLIER segment enters this
+    // segment's program as a load - of the hint slot the producer's chain left its value in (canonical once that segment's
+    // finalize has run; `exports` tells the producer which of its results must get one), or of the constant / input the
+    // producer itself loaded.  import_of resolves such an operand (false: nobody knows it), note_import reports every one
+    // the value cone reaches (the analysis pass that collects the earlier segments' exports).
+    struct Import {
+        uint32_t kind;   // 0: hint slot, 1: pool constant (word offset), 2: input slot
+        uint32_t imm;
+    };
+    std::function<bool(uint32_t ref, Import&)> import_of;
+    std::function<void(uint32_t ref)> note_import;
+    const std::map<uint32_t, uint32_t>* exports = nullptr;   // op index -> hint slot its value must be left in
+    uint32_t hint_split = 0xffffffffu;                       // hint slots from here on were taken at compile time (FieldChain::hint2_lo / hi)
 
     struct Node {
         uint8_t opc = 0;
         int a = -1, b = -1, c = -1;                       // operand nodes
         std::vector<std::pair<int, int>> terms;           // LIN: (node, coef)
         uint32_t imm = 0;                                 // input slot / pool offset
+        bool hint_src = false;                            // F_INPUT_W: imm is a hint slot of an earlier segment (record flag 0x100)
         uint32_t hint = 0xffffffffu;
         // a product whose operand is a linear combination computed in the product's own row (digit rows, "fused"): the terms
         // taken over from the LIN node that was the operand (a / b stay -1 then); sq: b is the same combination as a
@@ -233,7 +260,15 @@ struct FieldCompiler {
                     needed[kv.first] = 1;
                     stack.push_back(kv.first);
                 }
+        if (exports)
+            for (auto& kv : *exports)
+                if (!needed[kv.first]) {
+                    needed[kv.first] = 1;
+                    stack.push_back(kv.first);
+                }
         if (stack.empty()) { out.why = "no hinted op"; return false; }
+        std::map<uint32_t, int> import_index;   // first limb reference of an imported integer -> its virtual op index (n_ops + k)
+        std::vector<Import> imports;
         while (!stack.empty()) {
             uint32_t i = stack.back();
             stack.pop_back();
@@ -247,6 +282,18 @@ struct FieldCompiler {
             int n = operands(op, o);
             for (int q = 0; q < n; q++) {
                 int p = o[q].is_int ? int_producer(op.refs[o[q].refpos]) : cond_producer(op.refs[o[q].refpos]);
+                if (p < 0 && o[q].is_int && import_of) {
+                    Import imp;
+                    uint32_t ref = op.refs[o[q].refpos];
+                    if (import_of(ref, imp)) {
+                        if (!import_index.count(ref)) {
+                            import_index[ref] = (int)(n_ops + imports.size());
+                            imports.push_back(imp);
+                            if (note_import) note_import(ref);
+                        }
+                        continue;
+                    }
+                }
                 if (p < 0 || (uint32_t)p >= i) { out.why = "operand of op " + std::to_string(i) + " (opcode " + std::to_string(op.opcode) + ") is not a result of this segment"; return false; }
                 if (!needed[p]) {
                     needed[p] = 1;
@@ -257,7 +304,13 @@ struct FieldCompiler {
         if (check_only) return true;
 
         // ---- expressions / nodes, in program order -----------------------------------------------------------------
-        expr.assign(n_ops, Expr());            // integer results
+        expr.assign(n_ops + imports.size(), Expr());   // integer results (+ the imported integers, as virtual ops behind the segment's own)
+        for (size_t k = 0; k < imports.size(); k++) {
+            int m = new_node(imports[k].kind == 1 ? F_CONST_W : F_INPUT_W);
+            nodes[m].imm = imports[k].imm;
+            nodes[m].hint_src = imports[k].kind == 0;
+            expr[n_ops + k] = single(m);
+        }
         std::vector<int> cond(n_ops, -1);       // condition results: node
         for (uint32_t i = 0; i < n_ops; i++) {
             if (!needed[i]) continue;
@@ -265,7 +318,13 @@ struct FieldCompiler {
             Opd o[3];
             int n = operands(op, o);
             int prod[3] = {-1, -1, -1};
-            for (int q = 0; q < n; q++) prod[q] = o[q].is_int ? int_producer(op.refs[o[q].refpos]) : cond_producer(op.refs[o[q].refpos]);
+            for (int q = 0; q < n; q++) {
+                prod[q] = o[q].is_int ? int_producer(op.refs[o[q].refpos]) : cond_producer(op.refs[o[q].refpos]);
+                if (prod[q] < 0 && o[q].is_int) {
+                    auto it = import_index.find(op.refs[o[q].refpos]);
+                    if (it != import_index.end()) prod[q] = it->second;
+                }
+            }
             const bool hinted = (op.flags & H2E_FLAG_HINTED) != 0;
             switch (op.opcode) {
                 case H2E_OP_INT_MUL: {
@@ -365,6 +424,18 @@ struct FieldCompiler {
                 }
             }
         }
+        if (exports)
+            for (auto& kv : *exports) {
+                if (!is_int_op(ops[kv.first].opcode)) { out.why = "a later segment reads a result that is not an integer"; return false; }
+                int node = mat((int)kv.first);
+                if (nodes[node].hint == kv.second) continue;
+                if (nodes[node].hint != 0xffffffffu) {   // the node already fills another slot: a copy for this one
+                    int m = new_node(F_LIN);
+                    nodes[m].terms.push_back({node, 1});
+                    node = m;
+                }
+                nodes[node].hint = kv.second;
+            }
         auto deps_of = [&](const Node& nd, std::vector<uint32_t>& d) {
             d.clear();
             auto add = [&](int x) {
@@ -489,7 +560,10 @@ struct FieldCompiler {
                 for (auto& t : nd.terms) {
                     Node& in = nodes[t.first];
                     uint32_t kind, index;
-                    if (in.opc == F_INPUT_W || in.opc == F_CONST_W) {
+                    if (in.opc == F_INPUT_W && in.hint_src) {   // a value an earlier segment left in a hint slot: canonical already
+                        kind = 0;
+                        index = in.imm;
+                    } else if (in.opc == F_INPUT_W || in.opc == F_CONST_W) {
                         kind = in.opc == F_INPUT_W ? 1u : 2u;
                         index = in.imm;
                     } else {
@@ -770,8 +844,7 @@ struct FieldCompiler {
                     w[1] = nd.hint == 0xffffffffu ? 0u : nd.hint + 1;
                     if (w[1] >= (1u << 18)) throw std::runtime_error("field chain: hint slot index beyond the records' 18 bits");
                     if (nd.hint != 0xffffffffu) {
-                        out.hint_lo = std::min(out.hint_lo, nd.hint);
-                        out.hint_hi = std::max(out.hint_hi, nd.hint + 1);
+                        out.note_hint(nd.hint, hint_split);
                     }
                     uint32_t nta = side(w, nd.fa, nd.ta, nd.a);
                     uint32_t cidx = 0xffu;
@@ -798,8 +871,7 @@ struct FieldCompiler {
                     w[1] |= (uint32_t)sum << 18;   // (|sum| <= 14 x 255: 13 bits and a sign)
                 }
                 if (nd.hint != 0xffffffffu) {
-                    out.hint_lo = std::min(out.hint_lo, nd.hint);
-                    out.hint_hi = std::max(out.hint_hi, nd.hint + 1);
+                    out.note_hint(nd.hint, hint_split);
                 }
                 switch (nd.opc) {
                     case F_LIN:
@@ -819,7 +891,10 @@ struct FieldCompiler {
                         w[3] = slot_of(nd.a);
                         w[4] = slot_of(nd.b);
                         break;
-                    default: w[2] = nd.imm; break;
+                    default:
+                        w[2] = nd.imm;
+                        if (nd.hint_src) w[0] |= 0x100u;   // H2E_F_INPUT_W from the hint workspace (tape.h)
+                        break;
                 }
                 out.recs.insert(out.recs.end(), w, w + RW);
             }
@@ -938,6 +1013,8 @@ struct HintStore {
     std::vector<uint32_t> offsets;    // per store op: first word of its record
     std::vector<uint64_t> ktab;       // K constants: (2 L + 4) words each (limbs: 2 words each, native: 4 words)
     std::map<uint32_t, uint32_t> aux_hint;   // op index -> hint slot the field chain must fill (conditions, masked integers)
+    std::vector<uint32_t> ext;               // extension leaves (tape.h H2EStoreExt), H2E_SX_WORDS words each
+    std::map<std::array<uint32_t, H2E_SX_WORDS>, uint32_t> ext_index;
     uint32_t n_terms_max = 0;
     std::string why;
 };
@@ -989,7 +1066,12 @@ struct StoreCompiler {
                 FieldCompiler::Opd o[3];
                 int n = fcmp->operands(op, o);
                 for (int q = 0; q < n; q++)
-                    if (fcmp->int_producer(op.refs[o[q].refpos]) < 0) { why = "hint store: operand of a light op from outside the segment"; return false; }
+                    if (fcmp->int_producer(op.refs[o[q].refpos]) < 0) {
+                        FieldCompiler::Import imp;   // (a value of an earlier segment of the same context: read from where its chain left it)
+                        if (fcmp->import_of && fcmp->import_of(op.refs[o[q].refpos], imp)) continue;
+                        why = "hint store: operand of a light op from outside the segment";
+                        return false;
+                    }
             }
         }
         return true;
@@ -1017,6 +1099,33 @@ struct StoreCompiler {
         int prod[3] = {-1, -1, -1};
         for (int q = 0; q < n; q++)
             if (o[q].is_int) prod[q] = fcmp->int_producer(op.refs[o[q].refpos]);
+        // the integer operand q as a combination: a result of this segment, or - a context cut into several segments - a value an
+        // earlier one left in a hint slot (its limbs there are the canonical split: what the cells hold only if the value was
+        // reduced; an unreduced one would need its own limbs, so the producer exports REDUCED values only - see import_of)
+        auto operand = [&](int q) -> Lin {
+            if (prod[q] >= 0) return flatten(out, (uint32_t)prod[q]);
+            // an integer of an earlier segment of the same context: read as its cells hold it (that segment's own store - or its
+            // expansion's inputs before it - put them in place before this segment's value chain starts).  Not through a hint slot:
+            // the limbs of an unreduced value are not the canonical split of its residue.
+            FieldCompiler::Import imp;
+            uint32_t ref = op.refs[o[q].refpos];
+            if (!fcmp->import_of || !fcmp->import_of(ref, imp)) throw std::runtime_error("hint store: operand from outside the segment");
+            std::array<uint32_t, H2E_SX_WORDS> e{};
+            e[0] = H2E_SX_CELLS;
+            for (int i = 0; i <= L; i++) e[1 + i] = op.refs[o[q].refpos + i];
+            uint32_t idx;
+            auto it = out.ext_index.find(e);
+            if (it != out.ext_index.end()) idx = it->second;
+            else {
+                idx = (uint32_t)(out.ext.size() / H2E_SX_WORDS);
+                out.ext.insert(out.ext.end(), e.begin(), e.end());
+                out.ext_index[e] = idx;
+            }
+            if (idx >= (1u << 22)) throw std::runtime_error("hint store: leaf index out of range");
+            Lin x;
+            x.leaf[(3u << 30) | idx] = 1;
+            return x;
+        };
         switch (op.opcode) {
             case H2E_OP_INT_MUL: case H2E_OP_REDUCE: case H2E_OP_DIV_CORE:
                 if (!(op.flags & H2E_FLAG_HINTED)) throw std::runtime_error("hint store: a live mul-like result without a hint");
@@ -1026,22 +1135,22 @@ struct StoreCompiler {
             case H2E_OP_CONST_INT: leaf(1, op.imm); break;
             case H2E_OP_ASSIGN_W: case H2E_OP_CONST_INT_INPUT: leaf(2, op.imm); break;
             case H2E_OP_INT_ADD:
-                add_scaled(r, flatten(out, (uint32_t)prod[0]), 1);
-                add_scaled(r, flatten(out, (uint32_t)prod[1]), 1);
+                add_scaled(r, operand(0), 1);
+                add_scaled(r, operand(1), 1);
                 break;
             case H2E_OP_INT_SUB:   // a - b + C_(b.times)   (integer_chip.rs:408-437)
-                add_scaled(r, flatten(out, (uint32_t)prod[0]), 1);
-                add_scaled(r, flatten(out, (uint32_t)prod[1]), -1);
+                add_scaled(r, operand(0), 1);
+                add_scaled(r, operand(1), -1);
                 r.ceil[op.imm] += 1;
                 if (r.ceil[op.imm] == 0) r.ceil.erase(op.imm);
                 break;
             case H2E_OP_INT_NEG:   // C_(a.times) - a       (:439-464)
-                add_scaled(r, flatten(out, (uint32_t)prod[0]), -1);
+                add_scaled(r, operand(0), -1);
                 r.ceil[op.imm] += 1;
                 if (r.ceil[op.imm] == 0) r.ceil.erase(op.imm);
                 break;
             case H2E_OP_INT_MUL_SMALL:
-                add_scaled(r, flatten(out, (uint32_t)prod[0]), (int)op.imm);
+                add_scaled(r, operand(0), (int)op.imm);
                 break;
             default: throw std::runtime_error("hint store: not an integer result");
         }

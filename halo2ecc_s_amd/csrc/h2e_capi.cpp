@@ -316,36 +316,130 @@ struct h2e_program {
             fcmp.digit_rows = !(fm && !strcmp(fm, "lanes"));
             return fcmp;
         };
-        for (auto& sg : r.segments) {
-            if (!sg.field_hints) continue;
-            bool ok = false;
-            std::string why = "segment has no cuts";
-            for (auto& c : cs)
-                if (c.sg == &sg) {
-                    h2e::FieldChain chain;
-                    h2e::FieldCompiler fcmp = field_compiler(c);
-                    ok = sg.n_strands == 1 && !sg.is_fork && sg.field_pair == r.fp.id && !getenv("H2E_NO_FIELD_CHAIN") && fcmp.compile(chain, true);
-                    why = chain.why;
-                    if (ok) {
-                        h2e::StoreCompiler sc;
-                        sc.ops = c.ops;
-                        sc.n_ops = c.n_ops;
-                        sc.L = r.fp.limbs;
-                        sc.fc = &r.fp.fc;
-                        sc.fcmp = &fcmp;
-                        sc.next_aux = 0;
-                        ok = sc.feasible(why);
+        // A context cut into several segments with field hints (a pairing check: Miller loop | final exponentiation ...): an
+        // integer a segment reads from an EARLIER one is found here - the producing segment and op - and enters the reader's
+        // programs as an import (field_chain.hpp FieldCompiler::Import).
+        struct FieldProducer {
+            const CutSeg* c = nullptr;
+            int op = -1;
+        };
+        std::vector<h2e::FieldCompiler> seg_fcmp;   // per cut segment: the producer lookups (no program state)
+        for (auto& c : cs) seg_fcmp.push_back(field_compiler(c));
+        auto find_field_producer = [&](const CutSeg& self, uint32_t ref) -> FieldProducer {
+            FieldProducer none;
+            if (ref == H2E_NO_REF || H2E_REF_REGION(ref) > 1 || H2E_REF_REL(ref)) return none;
+            uint32_t region = H2E_REF_REGION(ref), row = H2E_REF_ROW(ref);
+            for (size_t k = 0; k < cs.size(); k++) {
+                const CutSeg& c = cs[k];
+                if (&c == &self) break;   // (cs is in segment order: earlier segments only)
+                if (!c.sg->field_hints || c.sg->is_fork || row < c.first[region] || row >= c.last[region]) continue;
+                int q = seg_fcmp[k].int_producer(ref);
+                if (q >= 0) {
+                    FieldProducer fpd;
+                    fpd.c = &c;
+                    fpd.op = q;
+                    return fpd;
+                }
+            }
+            return none;
+        };
+        typedef std::map<const CutSeg*, std::map<uint32_t, uint32_t>> ExportMap;   // producing segment -> op -> hint slot
+        // the import callbacks of segment `self`: slots from `slots` (a value not in there yet - the analysis pass - reads as slot 0),
+        // every imported value that needs a slot noted in `wanted`
+        auto wire_imports = [&](h2e::FieldCompiler& fcmp, const CutSeg& self, const ExportMap* slots, ExportMap* wanted) {
+            const CutSeg* sp = &self;
+            fcmp.import_of = [sp, slots, &find_field_producer](uint32_t ref, h2e::FieldCompiler::Import& imp) -> bool {
+                FieldProducer fpd = find_field_producer(*sp, ref);
+                if (!fpd.c) return false;
+                const H2EOp& po = fpd.c->ops[fpd.op];
+                if (po.opcode == H2E_OP_CONST_INT) { imp.kind = 1; imp.imm = po.imm; return true; }
+                if (po.opcode == H2E_OP_ASSIGN_W || po.opcode == H2E_OP_CONST_INT_INPUT) {
+                    if (po.flags & H2E_FLAG_INPUT_STRIDED) return false;
+                    imp.kind = 2;
+                    imp.imm = po.imm;
+                    return true;
+                }
+                imp.kind = 0;
+                imp.imm = 0;
+                if (slots) {
+                    auto it = slots->find(fpd.c);
+                    if (it != slots->end()) {
+                        auto jt = it->second.find((uint32_t)fpd.op);
+                        if (jt != it->second.end()) imp.imm = jt->second;
                     }
                 }
-            if (!ok) {
-                for (uint32_t i = sg.tape_begin; i < sg.tape_end; i++) {
-                    H2EOp& op = r.tape[i];
-                    if ((op.flags & H2E_FLAG_HINTED) && !(op.flags & H2E_FLAG_HINT_STRIDED) &&
-                        (op.opcode == H2E_OP_INT_MUL || op.opcode == H2E_OP_REDUCE || op.opcode == H2E_OP_DIV_CORE))
-                        op.flags &= ~(uint16_t)H2E_FLAG_HINTED;
+                return true;
+            };
+            fcmp.note_import = nullptr;
+            if (wanted)
+                fcmp.note_import = [sp, wanted, &find_field_producer](uint32_t ref) {
+                    FieldProducer fpd = find_field_producer(*sp, ref);
+                    if (!fpd.c) return;
+                    uint16_t oc = fpd.c->ops[fpd.op].opcode;
+                    if (oc == H2E_OP_CONST_INT || oc == H2E_OP_ASSIGN_W || oc == H2E_OP_CONST_INT_INPUT) return;
+                    (*wanted)[fpd.c][(uint32_t)fpd.op] = 0;
+                };
+        };
+        // all field-hint segments of the program, last to first: can each one's chain and store be compiled, given what the
+        // later ones want exported?  (One verdict for the group: a segment that falls back to a replay stores no hint slots
+        // for the others to import.)
+        auto analyse_field_segments = [&](ExportMap& wanted, bool with_store, std::string& why) -> bool {
+            for (size_t k = cs.size(); k-- > 0;) {
+                const CutSeg& c = cs[k];
+                const h2e::Segment& sg = *c.sg;
+                if (!sg.field_hints) continue;
+                if (!(sg.n_strands == 1 && !sg.is_fork && sg.field_pair == r.fp.id) || getenv("H2E_NO_FIELD_CHAIN")) { why = "not a single-strand segment of the program's field"; return false; }
+                h2e::FieldCompiler fcmp = field_compiler(c);
+                wire_imports(fcmp, c, nullptr, &wanted);
+                h2e::StoreCompiler sc;
+                sc.ops = c.ops;
+                sc.n_ops = c.n_ops;
+                sc.L = r.fp.limbs;
+                sc.fc = &r.fp.fc;
+                sc.fcmp = &fcmp;
+                sc.next_aux = 0;
+                h2e::HintStore hs;
+                if (with_store) {
+                    if (!sc.compile(hs)) { why = hs.why; return false; }
+                    fcmp.aux = &hs.aux_hint;
+                } else if (!sc.feasible(why)) return false;
+                fcmp.exports = &wanted[&c];
+                h2e::FieldChain chain;
+                if (!fcmp.compile(chain, true)) { why = chain.why; return false; }
+            }
+            return true;
+        };
+        {
+            bool any = false, all_cut = true;
+            for (auto& sg : r.segments) {
+                if (!sg.field_hints) continue;
+                any = true;
+                bool cut = false;
+                for (auto& c : cs) cut = cut || c.sg == &sg;
+                all_cut = all_cut && cut;
+            }
+            if (any) {
+                ExportMap wanted;
+                std::string why = "segment has no cuts";
+                bool ok = all_cut;
+                try {
+                    ok = ok && analyse_field_segments(wanted, false, why);
+                } catch (std::exception& e) {
+                    ok = false;
+                    why = e.what();
                 }
-                sg.field_hints = false;
-                if (dbg_env("H2E_DUMP_TAPE")) fprintf(stderr, "segment %zu: no field chain (%s)\n", (size_t)(&sg - r.segments.data()), why.c_str());
+                if (!ok)
+                    for (auto& sg : r.segments) {
+                        if (!sg.field_hints) continue;
+                        for (uint32_t i = sg.tape_begin; i < sg.tape_end; i++) {
+                            H2EOp& op = r.tape[i];
+                            if ((op.flags & H2E_FLAG_HINTED) && !(op.flags & H2E_FLAG_HINT_STRIDED) &&
+                                (op.opcode == H2E_OP_INT_MUL || op.opcode == H2E_OP_REDUCE || op.opcode == H2E_OP_DIV_CORE))
+                                op.flags &= ~(uint16_t)H2E_FLAG_HINTED;
+                        }
+                        sg.field_hints = false;
+                        if (dbg_env("H2E_DUMP_TAPE")) fprintf(stderr, "segment %zu: no field chain (%s)\n", (size_t)(&sg - r.segments.data()), why.c_str());
+                    }
             }
         }
         if (cs.empty()) return;
@@ -681,11 +775,32 @@ struct h2e_program {
             if (!c.sg->field_hints && !compile_plain_store(c))
                 compile_replay(c.sg, c.ops, c.n_ops, c.first, c.last, [&](uint32_t region, uint32_t row) { return producer(c, region, row); });
         // 6. segments with field hints: the hint store in place of a replay, and the field-domain predictor whose program
-        // goes into the pre-kernel args
+        // goes into the pre-kernel args.  First (last segment to first) what each segment must leave in hint slots for the
+        // later ones, then the programs themselves, first to last, every segment's compile-time slots (exports, conditions,
+        // sink terms) in one block of their own.
+        ExportMap wanted;
+        {
+            bool any = false;
+            for (auto& c : cs) any = any || c.sg->field_hints;
+            std::string why;
+            if (any && !analyse_field_segments(wanted, true, why)) throw std::runtime_error("field chain: " + why);
+        }
+        ExportMap export_slots;
         for (auto& c : cs) {
             if (!c.sg->field_hints) continue;
             size_t si = (size_t)(c.sg - r.segments.data());
+            const uint32_t hint_split = r.n_hint_slots;
+            {
+                std::map<uint32_t, uint32_t>& mine = export_slots[&c];
+                for (auto& kv : wanted[&c]) {
+                    const H2EOp& op = c.ops[kv.first];
+                    bool own = (op.flags & H2E_FLAG_HINTED) && !(op.flags & H2E_FLAG_HINT_STRIDED) &&
+                               (op.opcode == H2E_OP_INT_MUL || op.opcode == H2E_OP_REDUCE || op.opcode == H2E_OP_DIV_CORE);
+                    mine[kv.first] = own ? op.imm : r.n_hint_slots++;
+                }
+            }
             h2e::FieldCompiler fcmp = field_compiler(c);
+            wire_imports(fcmp, c, &export_slots, nullptr);
             h2e::HintStore hs;
             {
                 h2e::StoreCompiler sc;
@@ -700,15 +815,19 @@ struct h2e_program {
                 seg_s_begin[si] = (uint32_t)h_swords.size();
                 seg_so_begin[si] = (uint32_t)h_soffsets.size();
                 seg_sk_begin[si] = (uint32_t)h_sktab.size();
+                seg_sx_begin[si] = (uint32_t)h_sext.size();
                 seg_n_sops[si] = (uint32_t)hs.offsets.size();
                 h_swords.insert(h_swords.end(), hs.words.begin(), hs.words.end());
                 h_soffsets.insert(h_soffsets.end(), hs.offsets.begin(), hs.offsets.end());
                 h_sktab.insert(h_sktab.end(), hs.ktab.begin(), hs.ktab.end());
+                h_sext.insert(h_sext.end(), hs.ext.begin(), hs.ext.end());
                 if (dbg_env("H2E_DUMP_TAPE"))
                     fprintf(stderr, "segment %zu: hint store: %zu store ops, %zu words, %zu K constants, at most %u terms, %zu aux hint slots\n", si,
                             hs.offsets.size(), hs.words.size(), hs.ktab.size() / (2 * (size_t)r.fp.limbs + 4), hs.n_terms_max, hs.aux_hint.size());
             }
             fcmp.aux = &hs.aux_hint;
+            fcmp.exports = &export_slots[&c];
+            fcmp.hint_split = hint_split;
             uint32_t next_hint = r.n_hint_slots;
             fcmp.next_hint = &next_hint;
             h2e::FieldChain chain;
@@ -720,6 +839,8 @@ struct h2e_program {
             pk.k.n_lanes = 1;
             pk.k.hint_base = chain.hint_hi > chain.hint_lo ? chain.hint_lo : 0;
             pk.k.hints_per_lane = chain.hint_hi > chain.hint_lo ? chain.hint_hi - chain.hint_lo : 0;
+            pk.k.hint2_base = chain.hint2_hi > chain.hint2_lo ? chain.hint2_lo : 0;
+            pk.k.hints2_per_lane = chain.hint2_hi > chain.hint2_lo ? chain.hint2_hi - chain.hint2_lo : 0;
             pk.k.n_params = (uint32_t)r.fp.w_words;   // words per input slot
             while (r.pre_args.size() % 16) r.pre_args.push_back(0);   // records are read 16 bytes at a time from 64-byte aligned chunks
             pk.k.f_recs = (uint32_t)r.pre_args.size();
@@ -739,9 +860,10 @@ struct h2e_program {
             pk.before_segment = (uint32_t)(c.sg - r.segments.data());
             pk.early_after_segment = -1;
             r.pre_kernels.push_back(pk);
-            if (dbg_env("H2E_DUMP_TAPE"))
-                fprintf(stderr, "segment %u: field chain: %u nodes (%u products, %u linear combinations), %u rounds, %u value slots, hint slots [%u, %u)\n",
-                        pk.before_segment, chain.n_nodes, chain.n_mul, chain.n_lin, pk.k.f_n_rounds, chain.n_slots, chain.hint_lo, chain.hint_hi);
+            if (dbg_env("H2E_DUMP_TAPE") || getenv("H2E_FIELD_STATS"))
+                fprintf(stderr, "segment %u: field chain: %u nodes (%u products, %u linear combinations), %u rounds, %u value slots, hint slots [%u, %u) + [%u, %u), %zu exports\n",
+                        pk.before_segment, chain.n_nodes, chain.n_mul, chain.n_lin, pk.k.f_n_rounds, chain.n_slots, chain.hint_lo, chain.hint_hi,
+                        chain.hint2_lo, chain.hint2_hi, export_slots[&c].size());
         }
     }
 
@@ -2417,9 +2539,17 @@ int h2e_program_msm_bls12_381_tile(uint32_t n, int emit_shape, h2e_program** out
 
 // ops per expansion sub-range of the pairing programs (a cut wherever the recorder allows one after that many ops);
 // H2E_PAIRING_CUT overrides it when the program is recorded (experiments)
-static uint32_t pairing_cut_every() {
+// bn256: 16 (64 checks per GPU fill the waves; finer cuts only add hint-store work to the pipelined step: 3.26 -> 3.38 ms);
+// bls12_381: 8 (16 checks per GPU: waves of two sub-ranges, twice as many of them - expansion 1.55 -> 1.30 ms, 2 checks: 1.34 -> 0.52)
+// how finely a pairing is cut into launches (recorder_pairing.hpp PairingOps::stage_splits); H2E_PAIRING_SPLITS overrides it when
+// the program is recorded
+static int pairing_stage_splits() {
+    if (const char* e = getenv("H2E_PAIRING_SPLITS")) return std::max(0, atoi(e));
+    return 0;
+}
+static uint32_t pairing_cut_every(int curve) {
     if (const char* e = getenv("H2E_PAIRING_CUT")) return (uint32_t)std::max(2, atoi(e));
-    return 16;
+    return curve == 0 ? 16 : 8;
 }
 int h2e_program_pairing_check_bn256(int emit_shape, h2e_program** out) {
     h2e_program* p = nullptr;
@@ -2427,10 +2557,11 @@ int h2e_program_pairing_check_bn256(int emit_shape, h2e_program** out) {
     if (rc) return rc;
     GUARDED({
         h2e::Recorder& r = *p->rec;
-        r.auto_cut_every = pairing_cut_every();
+        r.auto_cut_every = pairing_cut_every(0);
         uint32_t s = r.alloc_inputs(10);
         h2e::NativeScalarEccContext ecc(r, h2e::bn256_g1_params(), 0);
         h2e::Bn256PairingOps po(r);
+        po.stage_splits = pairing_stage_splits();
         r.begin_field_hints();
         h2e::AssignedFq2 bx{r.assign_int_constant_input(s + 0), r.assign_int_constant_input(s + 1)};
         h2e::AssignedFq2 by{r.assign_int_constant_input(s + 2), r.assign_int_constant_input(s + 3)};
@@ -2451,10 +2582,11 @@ int h2e_program_pairing_check_bls12_381(int emit_shape, h2e_program** out) {
     if (rc) return rc;
     GUARDED({
         h2e::Recorder& r = *p->rec;
-        r.auto_cut_every = pairing_cut_every();
+        r.auto_cut_every = pairing_cut_every(1);
         uint32_t s = r.alloc_inputs(14);
         h2e::NativeScalarEccContext ecc(r, h2e::bls12_381_g1_params(), 0);  // EccChipBaseOps of GeneralScalarEccContext
         h2e::Bls12381PairingOps po(r);
+        po.stage_splits = pairing_stage_splits();
         r.begin_field_hints();
         h2e::AssignedFq2 bx{r.assign_int_constant_input(s + 0), r.assign_int_constant_input(s + 1)};
         h2e::AssignedFq2 by{r.assign_int_constant_input(s + 2), r.assign_int_constant_input(s + 3)};
@@ -2482,12 +2614,13 @@ int h2e_program_pairing(int curve, uint32_t n_pairs, int with_expected, int emit
     if (rc) return rc;
     GUARDED({
         h2e::Recorder& r = *p->rec;
-        r.auto_cut_every = pairing_cut_every();
+        r.auto_cut_every = pairing_cut_every(curve);
         uint32_t s = r.alloc_inputs(7 * n_pairs + (with_expected ? 12 : 0));
         h2e::NativeScalarEccContext ecc(r, curve == 0 ? h2e::bn256_g1_params() : h2e::bls12_381_g1_params(), 0);
         std::unique_ptr<h2e::PairingOps> po;
         if (curve == 0) po.reset(new h2e::Bn256PairingOps(r));
         else po.reset(new h2e::Bls12381PairingOps(r));
+        po->stage_splits = pairing_stage_splits();
         std::vector<h2e::AssignedG2Affine> g2;
         r.begin_field_hints();
         for (uint32_t k = 0; k < n_pairs; k++) {
@@ -4108,7 +4241,7 @@ int h2e_op_fq(h2e_records* R, int degree, int which, const h2e_int* a, const h2e
     if ((binary && !b) || (which != H2E_FQ_ASSERT_EQUAL && !out)) return fail(H2E_ERR_INVALID, "null operand");
     return records_op(R, key_of("fq", {{&degree, sizeof(degree)}, {&which, sizeof(which)}, {a, sizeof(*a) * (size_t)degree}, {b, b ? sizeof(*b) * (size_t)degree : 0}, {&imm, sizeof(imm)}}), 0, nullptr, stream, {OpOut{out, out ? sizeof(*out) * (size_t)degree : 0}}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
         std::unique_ptr<h2e::PairingOps> t = tower_of(r);
-        r.auto_cut_every = pairing_cut_every();
+        r.auto_cut_every = pairing_cut_every(r.fp.id == H2E_FIELD_BN256_FQ ? 0 : 1);
         auto bad = [] { throw std::runtime_error("h2e_op_fq: no such op at this degree"); };
         if (degree == 2) {
             h2e::AssignedFq2 x = to_fq2(a), y = b ? to_fq2(b) : h2e::AssignedFq2(), o;
@@ -4287,7 +4420,7 @@ int h2e_op_check_pairing(h2e_records* R, uint32_t n_pairs, const h2e_point* g1, 
     if (!g1 || !g2 || n_pairs == 0) return fail(H2E_ERR_INVALID, "bad argument");
     if (R && R->field_pair == H2E_FIELD_BLS12_381_FR) return fail(H2E_ERR_INVALID, "no pairing over this field");
     return records_op(R, key_of("check_pairing", {{&n_pairs, sizeof(n_pairs)}, {g1, sizeof(*g1) * (size_t)n_pairs}, {g2, sizeof(*g2) * (size_t)n_pairs}}), 0, nullptr, stream, {}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
-        r.auto_cut_every = pairing_cut_every();
+        r.auto_cut_every = pairing_cut_every(r.fp.id == H2E_FIELD_BN256_FQ ? 0 : 1);
         std::unique_ptr<h2e::PairingOps> po;
         if (r.fp.id == H2E_FIELD_BN256_FQ) po.reset(new h2e::Bn256PairingOps(r));
         else po.reset(new h2e::Bls12381PairingOps(r));
@@ -4307,7 +4440,7 @@ int h2e_op_pairing(h2e_records* R, uint32_t n_pairs, const h2e_point* g1, const 
     if (!g1 || !g2 || !out12 || n_pairs == 0) return fail(H2E_ERR_INVALID, "bad argument");
     if (R && R->field_pair == H2E_FIELD_BLS12_381_FR) return fail(H2E_ERR_INVALID, "no pairing over this field");
     return records_op(R, key_of("pairing", {{&n_pairs, sizeof(n_pairs)}, {g1, sizeof(*g1) * (size_t)n_pairs}, {g2, sizeof(*g2) * (size_t)n_pairs}}), 0, nullptr, stream, {OpOut{out12, sizeof(*out12) * 12}}, [&](h2e::Recorder& r, h2e::NativeScalarEccContext&, uint32_t) {
-        r.auto_cut_every = pairing_cut_every();
+        r.auto_cut_every = pairing_cut_every(r.fp.id == H2E_FIELD_BN256_FQ ? 0 : 1);
         std::unique_ptr<h2e::PairingOps> po = tower_of(r);
         std::vector<h2e::AssignedPoint> a;
         std::vector<h2e::AssignedG2Affine> b;

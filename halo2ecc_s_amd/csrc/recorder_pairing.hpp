@@ -565,7 +565,16 @@ struct PairingOps : TowerOps {
         std::vector<PreparedTerm> pt;
         for (size_t i = 0; i < terms.size(); i++) pt.push_back(PreparedTerm(terms[i].first, &prepared[i]));
         AssignedFq12 res = multi_miller_loop(pt);
+        stage_boundary(1);
         return final_exponentiation(res);
+    }
+    // Engine detail, no counterpart in the reference: the places where a pairing may be cut into launches of its own (a segment's
+    // expansion then runs under the next segment's value chain).  Level 1: Miller loop | final exponentiation - one Fq12 value
+    // crosses, and the final exponentiation cannot start before it anyway; level 2: also inside the final exponentiation, after
+    // each exponentiation by x.  `stage_splits` = the highest level that is cut (0: one launch).
+    int stage_splits = 0;
+    void stage_boundary(int level) {
+        if (level <= stage_splits) ic.split_segment();
     }
     // pairing_chip.rs:173-176
     void check_pairing(const std::vector<Term>& terms) {
@@ -696,8 +705,11 @@ struct Bn256PairingOps : PairingOps {
         AssignedFq12 fp2 = fq12_frobenius_map(r, 2);
         AssignedFq12 fp3 = fq12_frobenius_map(fp2, 1);
         AssignedFq12 fu = exp_by_x(r);
+        stage_boundary(2);
         AssignedFq12 fu2 = exp_by_x(fu);
+        stage_boundary(2);
         AssignedFq12 fu3 = exp_by_x(fu2);
+        stage_boundary(3);
         AssignedFq12 y3 = fq12_frobenius_map(fu, 1);
         AssignedFq12 fu2p = fq12_frobenius_map(fu2, 1);
         AssignedFq12 fu3p = fq12_frobenius_map(fu3, 1);
@@ -841,8 +853,11 @@ struct Bls12381PairingOps : PairingOps {
         AssignedFq12 t3 = cycolotomic_exp(t2);
         AssignedFq12 t4 = fq12_cyclotomic_square(t3);
         AssignedFq12 t5 = fq12_mul(t1, t3);
+        stage_boundary(2);
         t1 = cycolotomic_exp(t5);
+        stage_boundary(3);
         t0 = cycolotomic_exp(t1);
+        stage_boundary(2);
         AssignedFq12 t6 = cycolotomic_exp(t0);
         t6 = fq12_mul(t6, t4);
         t4 = cycolotomic_exp(t6);

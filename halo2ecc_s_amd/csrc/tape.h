@@ -292,6 +292,9 @@ typedef struct H2EPreKernel {
     uint32_t f_n_load_rounds;   // the first rounds: loads of inputs / constants (a loop of their own in the kernel)
     uint32_t f_sinks, f_sink_words, f_n_sinks;   // hint-only linear combinations computed after the chain (h2e_field_sinks): word index of the
                                                  // per-sink offsets / of the sink records in the args array (field_chain.hpp FieldChain), count
+    uint32_t hint2_base, hints2_per_lane;   // FIELD_CHAIN: a second range of hint slots to finalize - the slots taken when the program was compiled
+                                            // (conditions, sink terms, values later segments import); with several segments another segment's
+                                            // recorded slots lie between the two ranges
     uint32_t f_mode;            // 0 = one lane per record, records of 8 words (h2e_field_chain); 1 = one 16-lane row per record, records of
                                 // 16 words = up to 14 terms per linear combination (h2e_field_chain_digits)
 } H2EPreKernel;
@@ -299,6 +302,7 @@ typedef struct H2EPreKernel {
 enum H2EFieldOp { H2E_F_NOP = 0, H2E_F_LIN, H2E_F_MUL, H2E_F_DIV, H2E_F_ISZERO, H2E_F_NOT, H2E_F_AND, H2E_F_OR, H2E_F_XNOR, H2E_F_SELECT,
                   H2E_F_INPUT_W, H2E_F_INPUT_FE, H2E_F_CONST_W, H2E_F_CONST_FE,
                   H2E_F_MULX, H2E_F_CONT };   // a product that computes its operands' linear combinations itself: two records (field_chain.hpp)
+#define H2E_F_FROM_HINTS 0x100u   // flag in word 0 of an H2E_F_INPUT_W record: word 2 is a hint slot an earlier segment's chain left the value in
 #define H2E_F_MAX_TERMS 6        // 8-word records
 #define H2E_F_MAX_TERMS_WIDE 14   // 16-word records
 // The MSM chains are walked as scans (engine.hip "scan predictors"): a window's sum over its groups in H2E_WIN_CHUNKS
