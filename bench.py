@@ -391,7 +391,7 @@ def main():
     plan = None
     if want_records:
         mine = [gidx(k, t) for k in range(args.steps) for t in range(units)]
-        plan = parallel.GatherPlan(mine, args.steps * T, world, coll_dev)
+        plan = parallel.GatherPlan(mine, args.steps * T, world, coll_dev, cap=args.steps * ((T + world - 1) // world))
 
     def consume(slot, k):
         """what happens to a finished step's arrays: status OR, optional on-device digest (the consumer of a streaming

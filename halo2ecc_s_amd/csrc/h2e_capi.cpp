@@ -3950,6 +3950,7 @@ int records_op(h2e_records* R, const std::string& key, uint32_t n_slots, const v
             r.select_height = R->height[2];
             h2e::NativeScalarEccContext ecc(r, R->field_pair == H2E_FIELD_BN256_FQ ? h2e::bn256_g1_params() : h2e::bls12_381_g1_params(), R->msm_prefix);
             ecc.scalar_field = R->scalar_field;
+            ecc.with_select = ecc.has_select_chip();
             uint32_t s0 = r.alloc_inputs(std::max<uint32_t>(1, n_slots));
             body(r, ecc, s0);
             np->finish();
@@ -4054,7 +4055,10 @@ int h2e_records_create(h2e_ctx* ctx, int field_pair_id, int scalar_field, uint32
     R->field_pair = field_pair_id;
     R->scalar_field = scalar_field;
     R->n_instances = n_instances;
-    R->emit_shape = emit_shape != 0;
+    R->emit_shape = (emit_shape & H2E_RECORDS_EMIT_SHAPE) != 0;
+    // NativeScalarEccContext::new_without_select_chip (src/context.rs:201-205): the msm prefix is usize::MAX and msm_unsafe takes
+    // the bisection form (src/circuit/ecc_chip.rs:373-408 dispatches on has_select_chip, native_scalar_ecc_chip.rs:27-46)
+    if (emit_shape & H2E_RECORDS_NO_SELECT_CHIP) R->msm_prefix = (size_t)-1;
     R->cap[0] = base_rows;
     R->cap[1] = range_rows;
     R->cap[2] = select_rows;

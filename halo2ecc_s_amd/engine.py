@@ -294,12 +294,14 @@ class Records:
     """Operator API (include/h2e.h): a device-resident Context for a batch of instances.  Mirrors the reference's usage:
     create a context, call chip ops on it with handles, read `Records` at the end."""
 
-    def __init__(self, engine, field_pair, n_instances, rows, scalar_field=-1, emit_shape=True):
+    def __init__(self, engine, field_pair, n_instances, rows, scalar_field=-1, emit_shape=True, select_chip=True):
+        """select_chip=False: NativeScalarEccContext::new_without_select_chip (src/context.rs:201-205) - msm_unsafe takes the bisection form"""
         self.engine, self.n, self.field_pair = engine, n_instances, field_pair
         self.rows = tuple(rows)
         self.slot_words = 6 if field_pair == FIELD_BLS12_381_FQ else 4
         h = C.c_void_p()
-        _check(lib().h2e_records_create(engine._h, field_pair, scalar_field, n_instances, rows[0], rows[1], rows[2], int(emit_shape), C.byref(h)))
+        flags = (1 if emit_shape else 0) | (0 if select_chip else 2)
+        _check(lib().h2e_records_create(engine._h, field_pair, scalar_field, n_instances, rows[0], rows[1], rows[2], flags, C.byref(h)))
         self._h = h
         self._keep = []   # input tensors stay alive while kernels may read them
 

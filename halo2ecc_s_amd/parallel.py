@@ -54,9 +54,11 @@ class GatherPlan:
     """Who owns which unit, uploaded once: `idx` = this rank's global unit indices padded with -1 to the per-rank
     capacity (ragged shards), on the device the collective runs on."""
 
-    def __init__(self, local_units, n_units, world, device):
+    def __init__(self, local_units, n_units, world, device, cap=None):
+        """cap: rows every rank contributes (the largest share; default: ceil(n_units / world), right when the job's units are
+        dealt round-robin as a whole - a job of several steps whose every step is dealt round-robin needs steps x ceil(step / world))"""
         self.n_units, self.world = n_units, world
-        self.cap = (n_units + world - 1) // world
+        self.cap = cap if cap is not None else (n_units + world - 1) // world
         assert len(local_units) <= self.cap
         idx = torch.full((self.cap,), -1, dtype=torch.int64)
         if len(local_units):

@@ -280,8 +280,12 @@ typedef struct h2e_records h2e_records;
 typedef struct h2e_int { uint32_t limbs[4]; uint32_t native; uint32_t times; } h2e_int;      /* AssignedInteger (src/assign.rs:31-37) */
 typedef struct h2e_point { h2e_int x, y; uint32_t z; } h2e_point;                            /* AssignedPoint (src/assign.rs:46-51) */
 typedef struct h2e_g2 { h2e_int x0, x1, y0, y1; uint32_t z; } h2e_g2;                         /* AssignedG2Affine (src/assign.rs:171-192) */
+#define H2E_RECORDS_EMIT_SHAPE 1       /* emit_shape / flags: keep the fixed cells, flags and permutation list of every op (h2e_records_shape) */
+#define H2E_RECORDS_NO_SELECT_CHIP 2   /* NativeScalarEccContext::new_without_select_chip (src/context.rs:201-205): msm prefix usize::MAX,
+                                          msm_unsafe / ecc_mul take the bisection form (src/circuit/ecc_chip.rs:91-221, dispatch :373-408);
+                                          with h2e_records_attach: msm_prefix0 = UINT64_MAX */
 int h2e_records_create(h2e_ctx* ctx, int field_pair, int scalar_field, uint32_t n_instances, uint64_t base_rows, uint64_t range_rows,
-                       uint64_t select_rows, int emit_shape, h2e_records** out);
+                       uint64_t select_rows, int emit_shape /* H2E_RECORDS_* flags; 0 / 1 as before */, h2e_records** out);
 /* The splice seam itself (ParallelClone: clone_with_offset + merge + apply_offset_diff, src/circuit/ecc_chip.rs:64-77, used at
  * :289-352; NativeScalarEccContext clone / merge, src/circuit/native_scalar_ecc_chip.rs:50-90, msm prefix :173-178): a records
  * object over arrays the CALLER allocated (batch-interleaved, capacity_rows[3] rows), whose ops start at the caller's cursors

@@ -21,12 +21,13 @@ def _bench(*args, env=None, launcher=None):
     return json.loads(lines[0])
 
 
-def _check_contract(d, n_gpus, steps, warmup):
+def _check_contract(d, n_gpus, steps, warmup, scaling="weak"):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline"):
         assert key in d, key
     assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["scaling"] == scaling and d["vs_baseline"] is None
+    assert list(d)[-1] == "summary" and d["summary"]["columns"] == ["ms_per_step", "single_batch_ms", "whole_step_frac", "roofline_frac"]
     assert "workload" in d["config"] and d["value"] > 0 and d["ms_per_step"] > 0
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -92,3 +93,17 @@ def test_bench_two_ranks_one_gpu_gloo():
     _check_contract(d, 2, 2, 1)
     assert d["gathered_records"]["shape"] == [8, 29] and d["gathered_records"]["status_or"] == 0   # 2 steps x 2 ranks x 2 units
     assert len(d["per_rank_ms_per_step"]) == 2
+
+
+@pytest.mark.parametrize("workload,total", [("pairing_bn256", 5), ("pairing_bls12_381", 3)])
+def test_bench_two_ranks_pairing_strong_shares_gloo(workload, total):
+    """configs[3] / configs[4] as the N > 1 launch deals them: BASELINE's batch round-robin over the ranks (--scaling strong; here 5
+    and 3 checks over two ranks: ragged shares 3 + 2 and 2 + 1), per-unit records of a workload without a result point, one
+    gather per job - two ranks on one GPU over gloo"""
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                "--master-port", str(29900 + os.getpid() % 90)]
+    d = _bench("--gpus", "2", "--workload", workload, "--scaling", "strong", "--total-units", str(total), "--steps", "2", "--warmup", "1",
+               "--ring", "2", "--latency-steps", "0", "--traffic", "off", "--no-cpu-baseline", "--dist-backend", "gloo", "--device", "0", launcher=launcher)
+    _check_contract(d, 2, 2, 1, scaling="strong")
+    assert d["gathered_records"]["shape"] == [2 * total, 29] and d["gathered_records"]["status_or"] == 0
+    assert d["config"]["units_per_step_all_gpus"] == total and len(d["per_rank_ms_per_step"]) == 2

@@ -76,6 +76,34 @@ def test_ops_msm_twice_in_one_context(engine, oracle):
     rec.close()
 
 
+def test_ops_msm_in_a_context_without_the_select_chip(engine, oracle):
+    """NativeScalarEccContext::new_without_select_chip (src/context.rs:201-205; the reference's
+    test_native_ecc_chip_without_select_chip, src/tests/native_scalar_ecc_chip.rs:63-110): a device-resident context created
+    without the select chip dispatches msm_unsafe to the bisection form (ecc_chip.rs:373-408 -> :91-221: groups of two points,
+    no cache / select rows).  assign_point x n, assign x n, msm_unsafe, assign_point(expected), ecc_assert_equal as five ops ==
+    the oracle's no-select test body, cell for cell, flags, fixed cells and permutations included."""
+    n, n_inst = 5, 2
+    ins = [synth.msm_bn256_tile_inputs(n, tile=830 + k)[0] for k in range(n_inst)]
+    oruns = [oracle_lib.run_msm_bn256_tile(n, inp, with_select=False) for inp in ins]
+    i = oruns[0].info
+    assert i.status == 0, oruns[0].error
+    assert i.select_height == 0 and i.select_offset == 0          # no select rows at all
+    rows = (max(i.base_height, i.base_offset) + 1, max(i.range_height, i.range_offset) + 1, 8)
+    rec = Records(engine, E.FIELD_BN256_FQ, n_inst, rows, select_chip=False)
+    a = np.stack(ins)
+    pts = rec.assign_points(n, a[:, 0:3 * n])
+    scs = rec.assign_scalars(n, a[:, 3 * n:4 * n])
+    res = rec.msm_unsafe(pts, scs, a[:, 4 * n:4 * n + 6])
+    exp = rec.assign_points(1, a[:, 4 * n + 6:4 * n + 9])
+    rec.ecc_assert_equal(res, exp[0])
+    engine.torch.cuda.synchronize()
+    assert (rec.arrays()[3].cpu().numpy() == 0).all()
+    for k, orun in enumerate(oruns):
+        for region, got, ovals in _rows_of(engine, rec, orun, n_inst):
+            assert np.array_equal(got[k], ovals), f"instance {k}: advice differs in region {region}"
+    rec.close()
+
+
 def test_ops_check_pairing_on_assigned_terms(engine, oracle):
     """PairingChipOps::check_pairing (src/circuit/pairing_chip.rs:173-176) as an op on terms assigned by earlier ops: the G2
     constants, two assign_point ops, then the check - the same rows as the reference's test body

@@ -82,3 +82,38 @@ def test_gather_world2_gloo(oracle):
     assert (table[:, 0] == 0).all()          # every unit OK
     assert len(set(table[:, 1])) == 1        # same shape -> same offsets
     assert len(set(map(tuple, table[:, 17:29]))) == n_units   # different inputs -> different digests
+
+
+def _plan_worker(rank, world, port, steps, total, q):
+    """a job of `steps` steps whose every step deals `total` units round-robin over the ranks (bench.py --scaling strong): the gather
+    plan's capacity is steps x ceil(total / world), not ceil(steps x total / world)"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from halo2ecc_s_amd.parallel import GatherPlan, gather_records
+    mine = [k * total + rank + t * world for k in range(steps) for t in range(len(range(rank, total, world)))]
+    plan = GatherPlan(mine, steps * total, world, "cpu", cap=steps * ((total + world - 1) // world))
+    local = torch.tensor([[u, 1000 + u] for u in mine], dtype=torch.int64)
+    table, seen = gather_records(plan, local)
+    q.put((rank, mine, table.tolist(), bool(seen.all())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_per_step_ragged_shares_world2_gloo():
+    world, steps, total = 2, 3, 5   # every step: 3 + 2 units; rank 0 holds 9 of the job's 15 units (more than ceil(15 / 2))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 17) % 1000)
+    procs = [ctx.Process(target=_plan_worker, args=(r, world, port, steps, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, mine, table, complete in results:
+        assert complete
+        assert table == [[u, 1000 + u] for u in range(steps * total)]
+    assert sorted(sum((m for _, m, _, _ in results), [])) == list(range(steps * total))
