@@ -2543,9 +2543,13 @@ int h2e_program_msm_bls12_381_tile(uint32_t n, int emit_shape, h2e_program** out
 // bls12_381: 8 (16 checks per GPU: waves of two sub-ranges, twice as many of them - expansion 1.55 -> 1.30 ms, 2 checks: 1.34 -> 0.52)
 // how finely a pairing is cut into launches (recorder_pairing.hpp PairingOps::stage_splits); H2E_PAIRING_SPLITS overrides it when
 // the program is recorded
+// Default 1: Miller loop | final exponentiation.  64 x bn256: one batch alone 5.29 -> 4.19 ms, pipelined 3.46 -> 3.11 ms; 16 x
+// bls12_381: 4.29 -> 3.61 ms alone, pipelined unchanged within noise (2.12 / 2.27).  Finer cuts (2: after each exponentiation
+// by x) gain little more alone and lose pipelined (3.29 / 2.72 ms): a chain next to its own context's expansion runs at about
+// 60 % of its rate alone (profiles/r4_*), so the overlap pays back only part of what it hides.
 static int pairing_stage_splits() {
     if (const char* e = getenv("H2E_PAIRING_SPLITS")) return std::max(0, atoi(e));
-    return 0;
+    return 1;
 }
 static uint32_t pairing_cut_every(int curve) {
     if (const char* e = getenv("H2E_PAIRING_CUT")) return (uint32_t)std::max(2, atoi(e));

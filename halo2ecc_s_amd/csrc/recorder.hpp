@@ -757,7 +757,9 @@ struct Recorder {
         if (auto_cut_every && !in_strand) {
             uint32_t at = (uint32_t)tape.size() - cur_tape_begin;
             uint32_t last = cuts.size() > segments.back().cuts_begin ? cuts.back() : 0;
-            if (at - last >= auto_cut_every) cuts.push_back(at);
+            // (never between a SUM_LIMBS and the ASSERT_CONST that reads its cell: no value chain stores that cell - it is an
+            // expansion-only row pair of assert_int_equal, integer_chip.rs:607-611 - so the two stay in one sub-range)
+            if (at - last >= auto_cut_every && op.opcode != H2E_OP_SUM_LIMBS) cuts.push_back(at);
         }
     }
     void put_int(H2EOp& op, int at, const AssignedInteger& a) const {
