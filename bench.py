@@ -514,7 +514,7 @@ def main():
     # consumer-ready output: the batch as halo2's advice columns (one array per instance, column-major, Montgomery-form cells)
     consumer_ms = None
     if args.consumer_ready > 0:
-        from halo2ecc_s_amd.engine import FORM_MONTGOMERY, LAYOUT_COLUMNS
+        from halo2ecc_s_amd.engine import FORM_MONTGOMERY, LAYOUT_COLUMNS_ASSIGNED_ONLY as LAYOUT_COLUMNS   # (column arrays zeroed once, by the first pass)
         base, rng, sel, status = bufs[0]
         outs = [None, None, None]
         lat = []

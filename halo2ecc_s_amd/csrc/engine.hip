@@ -1757,8 +1757,10 @@ WI_INLINE void exec_vop(const VSlots<FP>& vs, const LC& c, const VHdr& h, const 
     }
 }
 
+// (a six-word field does not fit the two-waves-per-SIMD register budget: 100 spilled registers for bls12_381 Fq, whose replays -
+// the general-scalar MSM's candidates - are small launches anyway: one wave per SIMD there)
 template <class FP>
-__global__ void __launch_bounds__(64, H2E_REPLAY_WAVES) h2e_replay(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
+__global__ void __launch_bounds__(64, (FP::WW > 4 ? 1 : H2E_REPLAY_WAVES)) h2e_replay(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
     // lanes: [piece][instance][strand]; pieces are independent stretches of the replay (host: compile_replay)
     u32 per = n_instances * L.n_strands;
     u32 blocks_per = (per + 63) / 64;
@@ -3972,7 +3974,10 @@ __global__ void __launch_bounds__(256) h2e_export(const ulonglong2* __restrict__
 // Column-major output wants long runs per (instance, column): a block takes 32 rows of ONE column of 32 instances
 // through LDS - 512 contiguous bytes per (row, half) on the way in, 1 KB per (instance, column) on the way out (the
 // generic tile above leaves 256-byte runs in this layout: 3.3 instead of 4.1 TB/s on the base array).
-template <int COLS>
+// SPARSE (H2E_LAYOUT_ASSIGNED_ONLY): cells the shape leaves unassigned are neither read nor written - the consumer's column arrays
+// were zeroed once and keep their zeros (the positions are the same for every batch of a shape); a third of the 220 GB a full export of
+// 64 tiles moves is such cells.
+template <int COLS, bool SPARSE>
 __global__ void __launch_bounds__(256) h2e_export_columns(const ulonglong2* __restrict__ in, ulonglong2* __restrict__ out,
                                                           const uint8_t* __restrict__ flags, u64 rows, u32 n_inst, u32 mont,
                                                           const H2EFieldConsts* fc) {
@@ -3983,6 +3988,7 @@ __global__ void __launch_bounds__(256) h2e_export_columns(const ulonglong2* __re
     u32 nr = (u32)min((u64)TR, rows - row0), ni = min((u32)TI, n_inst - inst0);
     for (u32 p = threadIdx.x; p < (u32)PER_I * TI; p += 256) {
         u32 i = p % TI, q = p / TI;   // q = r * 2 + half
+        if (SPARSE && q < nr * 2 && !(flags[(row0 + (q >> 1)) * COLS + col] & 1)) continue;
         if (i < ni && q < nr * 2) tile[i * PITCH + q] = in[(((row0 + (q >> 1)) * COLS + col) * 2 + (q & 1)) * n_inst + inst0 + i];
     }
     __syncthreads();
@@ -3990,6 +3996,7 @@ __global__ void __launch_bounds__(256) h2e_export_columns(const ulonglong2* __re
     for (u32 p = threadIdx.x; p < (u32)TR * TI; p += 256) {
         u32 i = p / TR, r = p % TR;
         if (i >= ni || r >= nr) continue;
+        if (SPARSE && !(flags[(row0 + r) * COLS + col] & 1)) continue;
         ulonglong2 lo = tile[i * PITCH + 2 * r], hi = tile[i * PITCH + 2 * r + 1];
         if (flags != nullptr && !(flags[(row0 + r) * COLS + col] & 1)) lo = hi = make_ulonglong2(0, 0);
         if (mont) {
@@ -4012,12 +4019,17 @@ extern "C" int h2e_engine_export(uint32_t cols, int columns, int mont, const voi
     dim3 grid((u32)tiles, (n_instances + 31) / 32), block(256);
     if (columns) {
         dim3 gridc((u32)((rows + 31) / 32), (n_instances + 31) / 32, cols);
+        const bool sparse = (columns & 2) != 0 && flags != nullptr;
+#define H2E_EXPORT_C(C)                                                                                                                  \
+    if (sparse) hipLaunchKernelGGL((h2e_export_columns<C, true>), gridc, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, flags, rows, n_instances, (u32)mont, fc_dev); \
+    else hipLaunchKernelGGL((h2e_export_columns<C, false>), gridc, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, flags, rows, n_instances, (u32)mont, fc_dev)
         switch (cols) {
-            case 5: hipLaunchKernelGGL(h2e_export_columns<5>, gridc, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, flags, rows, n_instances, (u32)mont, fc_dev); break;
-            case 3: hipLaunchKernelGGL(h2e_export_columns<3>, gridc, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, flags, rows, n_instances, (u32)mont, fc_dev); break;
-            case 2: hipLaunchKernelGGL(h2e_export_columns<2>, gridc, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, flags, rows, n_instances, (u32)mont, fc_dev); break;
+            case 5: H2E_EXPORT_C(5); break;
+            case 3: H2E_EXPORT_C(3); break;
+            case 2: H2E_EXPORT_C(2); break;
             default: return -1;
         }
+#undef H2E_EXPORT_C
         return (int)hipGetLastError();
     }
 #define H2E_EXPORT(C, COLMAJ)                                                                                                  \

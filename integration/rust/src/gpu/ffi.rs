@@ -12,6 +12,19 @@ pub const H2E_ST_RETRY_ADD_IDENTITY: u32 = 4;
 pub const H2E_ST_ARITH: u32 = 8;
 pub const H2E_LAYOUT_ROWS: c_int = 0;
 pub const H2E_LAYOUT_COLUMNS: c_int = 1;
+/// columns into arrays the caller zeroed once: unassigned cells are neither read nor written
+pub const H2E_LAYOUT_COLUMNS_ASSIGNED_ONLY: c_int = 3;
+/// flags of h2e_records_create's `emit_shape` argument
+pub const H2E_RECORDS_EMIT_SHAPE: c_int = 1;
+/// NativeScalarEccContext::new_without_select_chip (src/context.rs:201-205); with h2e_records_attach: msm_prefix0 = u64::MAX
+pub const H2E_RECORDS_NO_SELECT_CHIP: c_int = 2;
+/// classes of h2e_check (d_fail = [n_instances][2 * H2E_CHECK_CLASSES] u64: failing rows per class, then the lowest failing row)
+pub const H2E_CHECK_BASE_GATE: u32 = 0;
+pub const H2E_CHECK_RANGE_GATE: u32 = 1;
+pub const H2E_CHECK_RANGE_LOOKUP: u32 = 2;
+pub const H2E_CHECK_SELECT_LOOKUP: u32 = 3;
+pub const H2E_CHECK_COPY: u32 = 4;
+pub const H2E_CHECK_CLASSES: usize = 5;
 pub const H2E_FORM_CANONICAL: c_int = 0;
 pub const H2E_FORM_MONTGOMERY: c_int = 1;
 pub const H2E_INT_ADD: c_int = 0;
@@ -142,6 +155,10 @@ extern "C" {
     pub fn h2e_export_copy_constraints(ctx: *mut c_void, p: *mut c_void, d_out: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn h2e_digest(ctx: *mut c_void, p: *mut c_void, n_instances: u32, region: c_int, d_batch: *const c_void,
                       d_digests: *mut c_void, stream: *mut c_void) -> c_int;
+    /// MockProver's criterion (src/tests/mod.rs:117-132) over the arrays a run left on the device, for every instance at once:
+    /// base gate, range gates + lookups, select lookup, copy constraints; `classes` = bit mask of H2E_CHECK_* (0: all)
+    pub fn h2e_check(ctx: *mut c_void, p: *mut c_void, n_instances: u32, d_inputs: *const c_void, d_base: *const c_void,
+                     d_range: *const c_void, d_select: *const c_void, classes: u32, d_fail: *mut c_void, stream: *mut c_void) -> c_int;
     // ---- operator API: a device-resident Context ----
     pub fn h2e_records_create(ctx: *mut c_void, field_pair: c_int, scalar_field: c_int, n_instances: u32, base_rows: u64,
                               range_rows: u64, select_rows: u64, emit_shape: c_int, out: *mut *mut c_void) -> c_int;
