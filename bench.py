@@ -314,8 +314,11 @@ def main():
     shape_prog = make(True)  # shape-only artefacts, once per shape (not timed)
     cells_per_unit = shape_prog.n_advice_cells
     launches = shape_prog.launches()
-    prog = make(False)
-    shape_prog.close()
+    if args.consumer_ready > 0:   # (the assigned-only column export reads the shape's flags)
+        prog = shape_prog
+    else:
+        prog = make(False)
+        shape_prog.close()
     # the launch with the most cells (MSM: the window strands; pairing: the whole check)
     dom = max(range(len(launches)), key=lambda i: launches[i]["cells"])
 
