@@ -314,7 +314,7 @@ def main():
     shape_prog = make(True)  # shape-only artefacts, once per shape (not timed)
     cells_per_unit = shape_prog.n_advice_cells
     launches = shape_prog.launches()
-    if args.consumer_ready > 0:   # (the assigned-only column export reads the shape's flags)
+    if args.consumer_ready > 0:   # (the export masks with the shape's flags and does not read the cells they leave out)
         prog = shape_prog
     else:
         prog = make(False)
@@ -517,7 +517,7 @@ def main():
     # consumer-ready output: the batch as halo2's advice columns (one array per instance, column-major, Montgomery-form cells)
     consumer_ms = None
     if args.consumer_ready > 0:
-        from halo2ecc_s_amd.engine import FORM_MONTGOMERY, LAYOUT_COLUMNS_ASSIGNED_ONLY as LAYOUT_COLUMNS   # (column arrays zeroed once, by the first pass)
+        from halo2ecc_s_amd.engine import FORM_MONTGOMERY, LAYOUT_COLUMNS
         base, rng, sel, status = bufs[0]
         outs = [None, None, None]
         lat = []

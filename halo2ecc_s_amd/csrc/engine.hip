@@ -3947,6 +3947,7 @@ __global__ void __launch_bounds__(256) h2e_export(const ulonglong2* __restrict__
     u32 nr = (u32)min((u64)TR, rows - row0), ni = min((u32)TI, n_inst - inst0);
     for (u32 p = threadIdx.x; p < (u32)PER_I * TI; p += 256) {
         u32 i = p % TI, q = p / TI;   // q = (r * COLS + col) * 2 + half: memory order of the batch array
+        if (flags != nullptr && q < nr * COLS * 2 && !(flags[row0 * COLS + (q >> 1)] & 1)) continue;   // unassigned: not read (comes out as zero)
         if (i < ni && q < nr * COLS * 2) tile[i * PITCH + q] = in[(row0 * COLS * 2 + q) * n_inst + inst0 + i];
     }
     __syncthreads();
@@ -3974,10 +3975,10 @@ __global__ void __launch_bounds__(256) h2e_export(const ulonglong2* __restrict__
 // Column-major output wants long runs per (instance, column): a block takes 32 rows of ONE column of 32 instances
 // through LDS - 512 contiguous bytes per (row, half) on the way in, 1 KB per (instance, column) on the way out (the
 // generic tile above leaves 256-byte runs in this layout: 3.3 instead of 4.1 TB/s on the base array).
-// SPARSE (H2E_LAYOUT_ASSIGNED_ONLY): cells the shape leaves unassigned are neither read nor written - the consumer's column arrays
-// were zeroed once and keep their zeros (the positions are the same for every batch of a shape); a third of the 220 GB a full export of
-// 64 tiles moves is such cells.
-template <int COLS, bool SPARSE>
+// Cells the shape leaves unassigned (a third of an MSM tile's positions) are not read - they come out as zero whatever the array holds.
+// They ARE written: leaving them out (arrays zeroed once) was measured and is slower, 54.7 against 47 ms for 64 tiles - partial lines
+// cost the memory system more than the zeros do.
+template <int COLS>
 __global__ void __launch_bounds__(256) h2e_export_columns(const ulonglong2* __restrict__ in, ulonglong2* __restrict__ out,
                                                           const uint8_t* __restrict__ flags, u64 rows, u32 n_inst, u32 mont,
                                                           const H2EFieldConsts* fc) {
@@ -3988,7 +3989,7 @@ __global__ void __launch_bounds__(256) h2e_export_columns(const ulonglong2* __re
     u32 nr = (u32)min((u64)TR, rows - row0), ni = min((u32)TI, n_inst - inst0);
     for (u32 p = threadIdx.x; p < (u32)PER_I * TI; p += 256) {
         u32 i = p % TI, q = p / TI;   // q = r * 2 + half
-        if (SPARSE && q < nr * 2 && !(flags[(row0 + (q >> 1)) * COLS + col] & 1)) continue;
+        if (flags != nullptr && q < nr * 2 && !(flags[(row0 + (q >> 1)) * COLS + col] & 1)) continue;
         if (i < ni && q < nr * 2) tile[i * PITCH + q] = in[(((row0 + (q >> 1)) * COLS + col) * 2 + (q & 1)) * n_inst + inst0 + i];
     }
     __syncthreads();
@@ -3996,7 +3997,6 @@ __global__ void __launch_bounds__(256) h2e_export_columns(const ulonglong2* __re
     for (u32 p = threadIdx.x; p < (u32)TR * TI; p += 256) {
         u32 i = p / TR, r = p % TR;
         if (i >= ni || r >= nr) continue;
-        if (SPARSE && !(flags[(row0 + r) * COLS + col] & 1)) continue;
         ulonglong2 lo = tile[i * PITCH + 2 * r], hi = tile[i * PITCH + 2 * r + 1];
         if (flags != nullptr && !(flags[(row0 + r) * COLS + col] & 1)) lo = hi = make_ulonglong2(0, 0);
         if (mont) {
@@ -4019,17 +4019,12 @@ extern "C" int h2e_engine_export(uint32_t cols, int columns, int mont, const voi
     dim3 grid((u32)tiles, (n_instances + 31) / 32), block(256);
     if (columns) {
         dim3 gridc((u32)((rows + 31) / 32), (n_instances + 31) / 32, cols);
-        const bool sparse = (columns & 2) != 0 && flags != nullptr;
-#define H2E_EXPORT_C(C)                                                                                                                  \
-    if (sparse) hipLaunchKernelGGL((h2e_export_columns<C, true>), gridc, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, flags, rows, n_instances, (u32)mont, fc_dev); \
-    else hipLaunchKernelGGL((h2e_export_columns<C, false>), gridc, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, flags, rows, n_instances, (u32)mont, fc_dev)
         switch (cols) {
-            case 5: H2E_EXPORT_C(5); break;
-            case 3: H2E_EXPORT_C(3); break;
-            case 2: H2E_EXPORT_C(2); break;
+            case 5: hipLaunchKernelGGL(h2e_export_columns<5>, gridc, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, flags, rows, n_instances, (u32)mont, fc_dev); break;
+            case 3: hipLaunchKernelGGL(h2e_export_columns<3>, gridc, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, flags, rows, n_instances, (u32)mont, fc_dev); break;
+            case 2: hipLaunchKernelGGL(h2e_export_columns<2>, gridc, block, 0, stream, (const ulonglong2*)in, (ulonglong2*)out, flags, rows, n_instances, (u32)mont, fc_dev); break;
             default: return -1;
         }
-#undef H2E_EXPORT_C
         return (int)hipGetLastError();
     }
 #define H2E_EXPORT(C, COLMAJ)                                                                                                  \

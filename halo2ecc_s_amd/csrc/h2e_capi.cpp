@@ -3477,11 +3477,8 @@ int h2e_export(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, i
                void* d_out, void* stream) {
     if (!ctx || !p || !d_batch || !d_out) return fail(H2E_ERR_INVALID, "null argument");
     if (region < 0 || region > 2) return fail(H2E_ERR_INVALID, "region must be 0 (base), 1 (range) or 2 (select)");
-    const bool assigned_only = layout == H2E_LAYOUT_COLUMNS_ASSIGNED_ONLY;
-    if (assigned_only) layout = H2E_LAYOUT_COLUMNS;
     if (layout != H2E_LAYOUT_ROWS && layout != H2E_LAYOUT_COLUMNS) return fail(H2E_ERR_INVALID, "bad layout");
     if (form != H2E_FORM_CANONICAL && form != H2E_FORM_MONTGOMERY) return fail(H2E_ERR_INVALID, "bad number form");
-    if (assigned_only && !p->rec->emit_shape) return fail(H2E_ERR_INVALID, "assigned-only export needs the program's shape (emit_shape = 1)");
     if (n_instances == 0) return 0;
     std::lock_guard<std::mutex> guard(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
@@ -3499,7 +3496,7 @@ int h2e_export(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, i
         HIP_TRY(hipMemcpy(ctx->d_fc[fp], &field_pair(fp).fc, sizeof(H2EFieldConsts), hipMemcpyHostToDevice));
         HIP_TRY((hipError_t)h2e_engine_set_consts(fp, &field_pair(fp).fc));
     }
-    int rc = h2e_engine_export(cols, layout == H2E_LAYOUT_COLUMNS ? (assigned_only ? 3 : 1) : 0, form == H2E_FORM_MONTGOMERY, d_batch, d_out, d_flags, rows,
+    int rc = h2e_engine_export(cols, layout == H2E_LAYOUT_COLUMNS, form == H2E_FORM_MONTGOMERY, d_batch, d_out, d_flags, rows,
                                n_instances, ctx->d_fc[fp], (hipStream_t)stream);
     if (rc != 0) return fail(H2E_ERR_HIP, rc < 0 ? "export: bad geometry" : std::string("export launch failed: ") + hipGetErrorString((hipError_t)rc));
     return 0;

@@ -14,7 +14,6 @@ FIELD_BN256_FQ, FIELD_BLS12_381_FQ, FIELD_BLS12_381_FR = 0, 1, 2
 ST_OK, ST_ASSERT_FAILED, ST_RETRY_ADD_SAME_OR_NEG_POINT, ST_RETRY_ADD_IDENTITY, ST_ARITH = 0, 1, 2, 4, 8
 ST_TEST_HOOK = 0x80
 LAYOUT_ROWS, LAYOUT_COLUMNS = 0, 1
-LAYOUT_COLUMNS_ASSIGNED_ONLY = 3   # columns into arrays zeroed once: unassigned cells neither read nor written
 FORM_CANONICAL, FORM_MONTGOMERY = 0, 1
 OPT_X_SPLIT_PCT, OPT_X_SPLIT_MIN_LANES, OPT_TEST_SKIP_EXPANSION, OPT_PIPELINE_DEPTH, OPT_TEST_SCAN_FALLBACK = 1, 2, 3, 4, 5
 STAT_LAST_SPLIT_SEGMENTS, STAT_RUNS, STAT_PIPELINE_DEPTH, STAT_MAX_PIPELINE_DEPTH, STAT_SCAN_FALLBACKS = 1, 2, 3, 4, 5
@@ -598,8 +597,8 @@ class Engine:
         assert two == 2 and w == 2 and cols == COLS[region] and batch.is_contiguous()
         assert rows == (program.base_rows, program.range_rows, program.select_rows)[region]
         shape = (n, rows, cols, 4) if layout == LAYOUT_ROWS else (n, cols, rows, 4)
-        if out is None:   # (assigned-only: the array is zeroed once, here; a caller that re-uses it passes it back as `out`)
-            out = (t.zeros if layout == LAYOUT_COLUMNS_ASSIGNED_ONLY else t.empty)(shape, dtype=batch.dtype, device=batch.device)
+        if out is None:
+            out = t.empty(shape, dtype=batch.dtype, device=batch.device)
         assert tuple(out.shape) == shape and out.is_contiguous()
         _check(lib().h2e_export(self._h, program._h, n, region, layout, form, batch.data_ptr(), out.data_ptr(),
                                 self._stream(stream).cuda_stream))

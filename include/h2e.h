@@ -220,9 +220,6 @@ int h2e_pairing_check_bls12_381(h2e_ctx* ctx, uint32_t n_instances, const void* 
  * Asynchronous on `stream`. */
 #define H2E_LAYOUT_ROWS 0
 #define H2E_LAYOUT_COLUMNS 1
-#define H2E_LAYOUT_COLUMNS_ASSIGNED_ONLY 3   /* H2E_LAYOUT_COLUMNS into arrays the caller zeroed ONCE: cells the shape leaves unassigned are neither
-                                                read nor written (their positions are the same for every batch of a shape, so the zeros stay) -
-                                                a third of the bytes a full export of an MSM tile batch moves */
 #define H2E_FORM_CANONICAL 0
 #define H2E_FORM_MONTGOMERY 1
 int h2e_export(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, int layout, int form, const void* d_batch,

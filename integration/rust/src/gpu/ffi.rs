@@ -12,8 +12,6 @@ pub const H2E_ST_RETRY_ADD_IDENTITY: u32 = 4;
 pub const H2E_ST_ARITH: u32 = 8;
 pub const H2E_LAYOUT_ROWS: c_int = 0;
 pub const H2E_LAYOUT_COLUMNS: c_int = 1;
-/// columns into arrays the caller zeroed once: unassigned cells are neither read nor written
-pub const H2E_LAYOUT_COLUMNS_ASSIGNED_ONLY: c_int = 3;
 /// flags of h2e_records_create's `emit_shape` argument
 pub const H2E_RECORDS_EMIT_SHAPE: c_int = 1;
 /// NativeScalarEccContext::new_without_select_chip (src/context.rs:201-205); with h2e_records_attach: msm_prefix0 = u64::MAX

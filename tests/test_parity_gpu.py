@@ -151,37 +151,6 @@ def test_export_layouts(engine, n_inst):
         assert t.equal(got_c, want_rows.permute(0, 2, 1, 3).contiguous())
 
 
-def test_export_assigned_only_columns(engine, oracle):
-    """H2E_LAYOUT_COLUMNS_ASSIGNED_ONLY: the column export that neither reads nor writes cells the shape leaves unassigned.  Into an
-    array zeroed once it gives the full export's columns (two different batches through the same array: the zeros stay), and it
-    really leaves the other positions alone (a marked array keeps its marks exactly there); Montgomery form included."""
-    from halo2ecc_s_amd import engine as E
-    t = engine.torch
-    n = 7
-    prog = Program.msm_bn256_tile(n)
-    keep = [None, None, None]
-    for batch in range(2):
-        ins = [synth.msm_bn256_tile_inputs(n, tile=70 + 2 * batch + k)[0] for k in range(2)]
-        d_in = engine.upload_inputs(prog, np.stack(ins))
-        arrs = engine.alloc(prog, 2, fill=0xFF)
-        engine.run(prog, d_in, *arrs)
-        for region in range(3):
-            full = engine.export(prog, region, arrs[region], layout=E.LAYOUT_COLUMNS, form=E.FORM_MONTGOMERY)
-            keep[region] = engine.export(prog, region, arrs[region], layout=E.LAYOUT_COLUMNS_ASSIGNED_ONLY, form=E.FORM_MONTGOMERY, out=keep[region])
-            t.cuda.synchronize()
-            assert t.equal(full, keep[region]), (batch, region)
-            if batch == 0:
-                marked = t.full_like(full, 0x5A5A5A5A5A5A5A5A)
-                engine.export(prog, region, arrs[region], layout=E.LAYOUT_COLUMNS_ASSIGNED_ONLY, out=marked)
-                t.cuda.synchronize()
-                flags = (prog.base_flags(), prog.range_flags(), prog.select_flags())[region]          # [rows][cols]
-                assigned = t.from_numpy(np.ascontiguousarray((flags & 1).astype(bool).T)).to(marked.device)   # [cols][rows]
-                assert bool((marked[:, ~assigned] == 0x5A5A5A5A5A5A5A5A).all()) and bool(assigned.any()) and bool((~assigned).any())
-                canon = engine.export(prog, region, arrs[region], layout=E.LAYOUT_COLUMNS)
-                t.cuda.synchronize()
-                assert t.equal(marked[:, assigned], canon[:, assigned])
-
-
 def test_export_columns_and_montgomery_of_a_witness(engine, oracle):
     """the exported columns of an MSM tile equal the oracle's Records columns (unassigned cells zero although the run
     wrote into 0xFF-poisoned arrays), and the Montgomery-form export is x * 2^256 mod n of the canonical one
