@@ -3945,10 +3945,12 @@ __global__ void __launch_bounds__(256) h2e_export(const ulonglong2* __restrict__
     u64 row0 = (u64)blockIdx.x * TR;
     u32 inst0 = blockIdx.y * TI;
     u32 nr = (u32)min((u64)TR, rows - row0), ni = min((u32)TI, n_inst - inst0);
+    __shared__ uint8_t assigned[TR * COLS];   // the block's assigned flags, once; unassigned cells are not read (they come out as zero)
+    if (threadIdx.x < TR * COLS) assigned[threadIdx.x] = (flags == nullptr || threadIdx.x >= nr * COLS) ? 1 : (flags[row0 * COLS + threadIdx.x] & 1);
+    __syncthreads();
     for (u32 p = threadIdx.x; p < (u32)PER_I * TI; p += 256) {
         u32 i = p % TI, q = p / TI;   // q = (r * COLS + col) * 2 + half: memory order of the batch array
-        if (flags != nullptr && q < nr * COLS * 2 && !(flags[row0 * COLS + (q >> 1)] & 1)) continue;   // unassigned: not read (comes out as zero)
-        if (i < ni && q < nr * COLS * 2) tile[i * PITCH + q] = in[(row0 * COLS * 2 + q) * n_inst + inst0 + i];
+        if (i < ni && q < nr * COLS * 2 && assigned[q >> 1]) tile[i * PITCH + q] = in[(row0 * COLS * 2 + q) * n_inst + inst0 + i];
     }
     __syncthreads();
     Mont<4> M = mont_n(fc);
@@ -3959,7 +3961,7 @@ __global__ void __launch_bounds__(256) h2e_export(const ulonglong2* __restrict__
         if (i >= ni || r >= nr) continue;
         u32 q = (r * COLS + col) * 2;
         ulonglong2 lo = tile[i * PITCH + q], hi = tile[i * PITCH + q + 1];
-        if (flags != nullptr && !(flags[(row0 + r) * COLS + col] & 1)) lo = hi = make_ulonglong2(0, 0);
+        if (!assigned[r * COLS + col]) lo = hi = make_ulonglong2(0, 0);
         if (mont) {
             Fe x;
             x.v[0] = lo.x; x.v[1] = lo.y; x.v[2] = hi.x; x.v[3] = hi.y;
@@ -3987,10 +3989,13 @@ __global__ void __launch_bounds__(256) h2e_export_columns(const ulonglong2* __re
     u64 row0 = (u64)blockIdx.x * TR;
     u32 inst0 = blockIdx.y * TI, col = blockIdx.z;
     u32 nr = (u32)min((u64)TR, rows - row0), ni = min((u32)TI, n_inst - inst0);
+    // the block's assigned flags, once (a flag load in front of every cell load would be a dependent load per cell)
+    __shared__ uint8_t assigned[TR];
+    if (threadIdx.x < TR) assigned[threadIdx.x] = (flags == nullptr || threadIdx.x >= nr) ? 1 : (flags[(row0 + threadIdx.x) * COLS + col] & 1);
+    __syncthreads();
     for (u32 p = threadIdx.x; p < (u32)PER_I * TI; p += 256) {
         u32 i = p % TI, q = p / TI;   // q = r * 2 + half
-        if (flags != nullptr && q < nr * 2 && !(flags[(row0 + (q >> 1)) * COLS + col] & 1)) continue;
-        if (i < ni && q < nr * 2) tile[i * PITCH + q] = in[(((row0 + (q >> 1)) * COLS + col) * 2 + (q & 1)) * n_inst + inst0 + i];
+        if (i < ni && q < nr * 2 && assigned[q >> 1]) tile[i * PITCH + q] = in[(((row0 + (q >> 1)) * COLS + col) * 2 + (q & 1)) * n_inst + inst0 + i];
     }
     __syncthreads();
     Mont<4> M = mont_n(fc);
@@ -3998,7 +4003,7 @@ __global__ void __launch_bounds__(256) h2e_export_columns(const ulonglong2* __re
         u32 i = p / TR, r = p % TR;
         if (i >= ni || r >= nr) continue;
         ulonglong2 lo = tile[i * PITCH + 2 * r], hi = tile[i * PITCH + 2 * r + 1];
-        if (flags != nullptr && !(flags[(row0 + r) * COLS + col] & 1)) lo = hi = make_ulonglong2(0, 0);
+        if (!assigned[r]) lo = hi = make_ulonglong2(0, 0);
         if (mont) {
             Fe x;
             x.v[0] = lo.x; x.v[1] = lo.y; x.v[2] = hi.x; x.v[3] = hi.y;
