@@ -557,7 +557,9 @@ def main():
                     f"(2^{int(np.log2(max(1, args.job_tiles * n)))} points) over {world} GPU(s): {units} tiles per step and GPU, every tile its own inputs")
     else:
         desc = f"{units} x {args.workload} check_pairing (2 pairs, G2 constant) per GPU, reference test shape"
-    x_kernel = f"h2e_run_tape<{fpname}, false> (full expansion of " + ("the MSM window strands)" if args.workload == "msm" else "the pairing check)")
+    packed = args.workload != "msm" and units <= 32   # (batches smaller than half a wave: several sub-ranges per wave, engine.hip)
+    x_kernel = (f"h2e_run_tape_packed<{fpname}>" if packed else f"h2e_run_tape<{fpname}, false>") + " (full expansion of " + (
+        "the MSM window strands)" if args.workload == "msm" else "the pairing check: one launch per segment of the check)")
     x_roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes_per_launch"] if traffic else None,
               "kernel": x_kernel, "launch_ms": dom_ms, "algorithmic_bytes_per_launch": dom_bytes, "launches_per_step": dom_n}
