@@ -132,7 +132,8 @@ def measure_traffic(args):
                 return None, f"{counter} pass failed (rc {r.returncode}): {r.stderr[-300:]}"
             rows = []
             for row in csv.DictReader(open(files[0])):
-                if "h2e_run_tape" in row["Kernel_Name"] and "false" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                name = row["Kernel_Name"]   # the expansion: h2e_run_tape<FP, false>, or its packed form for batches smaller than half a wave
+                if "h2e_run_tape" in name and ("false" in name or "packed" in name) and row["Counter_Name"] == counter:
                     rows.append((int(row["Grid_Size"]), int(row["Dispatch_Id"]), float(row["Counter_Value"])))
             if not rows:
                 return None, f"{counter}: no dispatch of the expansion kernel in the counter file"
@@ -162,16 +163,18 @@ def _tile_inputs(job):
 def run_children(args):
     """the other configs of BASELINE's metric, one child process of this script each, before this process touches the GPU"""
     also = {}
-    base = [sys.executable, os.path.abspath(__file__), "--sub", "--suite", "main", "--traffic", "off", "--gpus", "1"]
+    base = [sys.executable, os.path.abspath(__file__), "--sub", "--suite", "main", "--gpus", "1"]
+    off = ["--traffic", "off"]
+    # (the two pairing batches also take their expansion's HBM traffic from the counters: two rocprofv3 --pmc child passes each)
     jobs = [("pairing_bn256", ["--workload", "pairing_bn256"]),
             ("pairing_bls12_381", ["--workload", "pairing_bls12_381"]),
             # one GPU's share of configs[3] / configs[4] when the batch is dealt over 8 GPUs (SURVEY 8d items 4-5): batches smaller than a wave
-            ("pairing_bn256_share8", ["--workload", "pairing_bn256", "--units", "8", "--no-cpu-baseline"]),
-            ("pairing_bls12_381_share8", ["--workload", "pairing_bls12_381", "--units", "2", "--no-cpu-baseline"]),
-            ("msm_job_2e20", ["--workload", "msm", "--job-tiles", "1024", "--no-cpu-baseline"]),
+            ("pairing_bn256_share8", ["--workload", "pairing_bn256", "--units", "8", "--no-cpu-baseline"] + off),
+            ("pairing_bls12_381_share8", ["--workload", "pairing_bls12_381", "--units", "2", "--no-cpu-baseline"] + off),
+            ("msm_job_2e20", ["--workload", "msm", "--job-tiles", "1024", "--no-cpu-baseline"] + off),
             # the headline batch all the way to what halo2 consumes: per-instance advice columns (SURVEY.md 8(f)-1)
             ("msm_consumer_ready", ["--workload", "msm", "--ring", "1", "--steps", "3", "--warmup", "1", "--latency-steps", "0", "--consumer-ready", "3",
-                                    "--no-cpu-baseline"])]
+                                    "--no-cpu-baseline"] + off)]
     for name, extra in jobs:
         t0 = time.perf_counter()
         try:
