@@ -1270,8 +1270,10 @@ __global__ void __launch_bounds__(64, H2E_X_WAVES) h2e_run_tape(H2ELaunch L, con
 // opcode any cursor shows and runs it for the groups that show it.  Light ops (additions, selections, conditions) so run ahead
 // until every cursor stands at a multiplication-like op (int_mul / div / reduce: 3/4 of the cells), and those run for all groups
 // in one pass - the wave synchronises itself on the heavy ops without any host-side alignment of the sub-ranges.
-// Op records reach the lanes through LDS: each group keeps a chunk of H2E_PK_CH ops, refilled by the group's own lanes.
-#define H2E_PK_CH 8u
+// Op records reach the lanes through LDS: each group keeps a chunk of min(32, 256 / G) ops - a whole sub-range of the pairing programs -
+// loaded by the group's own lanes.  (A refill waits for the loads, and with them for every store the wave has in flight - one counter, in
+// order: with 8-op chunks and 8 groups that was a store drain in nearly every step, 13 us per step against 8 us per op unpacked.)
+#define H2E_PK_BUF_OPS 256u   // ops the kernel's LDS buffer holds (16 KB), shared by the wave's groups
 // opcodes from light to heavy (cells an op writes ~ the instructions it costs)
 static __constant__ unsigned char g_pk_rank_of[H2E_OP_COUNT] = {
     /* NOP */ 0, /* ASSIGN_W */ 20, /* ASSIGN */ 1, /* ASSIGN_BIT */ 2, /* CONST_INT */ 12, /* CONST_INT_INPUT */ 13, /* CONST */ 3,
@@ -1282,7 +1284,7 @@ static __constant__ unsigned char g_pk_rank_of[H2E_OP_COUNT] = {
 static_assert(H2E_OP_COUNT == 30, "g_pk_rank_of lists every opcode of tape.h");
 template <class FP>
 __global__ void __launch_bounds__(64) h2e_run_tape_packed(H2ELaunch L, const InstanceDesc* inst, u32 n_instances, u32 log2p) {
-    __shared__ u32x4 opbuf[32 * H2E_PK_CH * 4];   // [group][op in chunk][4 x 16 bytes]
+    __shared__ u32x4 opbuf[H2E_PK_BUF_OPS * 4];   // [group][op in chunk][4 x 16 bytes]
     __shared__ u64 dg_sums[12 * 64];
     __shared__ u32 rank_lds[32];                  // g_pk_rank_of, read per lane in the loop: from LDS (a global load there would wait
                                                   // for every store the wave has in flight - one counter, in order)
@@ -1291,6 +1293,7 @@ __global__ void __launch_bounds__(64) h2e_run_tape_packed(H2ELaunch L, const Ins
     const u32 lane = threadIdx.x, P = 1u << log2p, G = 64u >> log2p;
     if (lane < 32u) rank_lds[lane] = lane < (u32)H2E_OP_COUNT ? (u32)g_pk_rank_of[lane] : 0xffu;
     const u32 g = lane >> log2p, ii = lane & (P - 1u);
+    const u32 CH = min(32u, H2E_PK_BUF_OPS / G);   // ops per group and chunk (sub-ranges of the pairing programs: 8 or 16-17 ops)
     const u32 per_sub = n_instances * L.n_strands;
     const u32 n_sub = L.n_sub > 1 ? L.n_sub : 1;
     const u32 sub = blockIdx.x * G + g;
@@ -1332,16 +1335,16 @@ __global__ void __launch_bounds__(64) h2e_run_tape_packed(H2ELaunch L, const Ins
     }
     u32 cbase = pos;          // first op of the chunk this group holds in LDS ...
     bool filled = false;      // ... once it has loaded one
-    const H2E_AS_LDS u32x4* my_ops = (const H2E_AS_LDS u32x4*)opbuf + (size_t)g * H2E_PK_CH * 4;
+    const H2E_AS_LDS u32x4* my_ops = (const H2E_AS_LDS u32x4*)opbuf + (size_t)g * CH * 4;
     for (;;) {
-        const bool need = pos < end && (!filled || pos >= cbase + H2E_PK_CH);
+        const bool need = pos < end && (!filled || pos >= cbase + CH);
         if (__builtin_amdgcn_ballot_w64(need)) {
             if (need) {
                 cbase = pos;
                 filled = true;
-                for (u32 e = ii; e < H2E_PK_CH * 4u; e += P) {
+                for (u32 e = ii; e < CH * 4u; e += P) {
                     u32 at = cbase + e / 4u;
-                    if (at < end) ((H2E_AS_LDS u32x4*)opbuf)[((size_t)g * H2E_PK_CH + e / 4u) * 4u + e % 4u] =
+                    if (at < end) ((H2E_AS_LDS u32x4*)opbuf)[((size_t)g * CH + e / 4u) * 4u + e % 4u] =
                         ((const H2E_AS_GLOBAL u32x4*)(L.tape + at))[e % 4u];
                 }
             }
