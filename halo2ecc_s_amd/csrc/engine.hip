@@ -3239,19 +3239,16 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
 #endif
     u32 rno = 0, n_hlog = 0, cur_hlog = 0, prev_hlog = 0;   // round parity; log word of the next / this / the previous round
     // the previous round's section -> the log: waves 14, 13, 12 take its first, second, third KB
-    // (the LDS read is issued at the start of the next round, the store behind that round's rows: the read's latency runs under them)
-    const u32 fl_piece = (H2E_DP_WAVES - 1u - wave) * 1024u + lane * 16u;
-    auto flush_read = [&](u32 hl, u32 sec, u32x4& v) -> bool {
-        const bool mine = wave + 3u >= H2E_DP_WAVES && fl_piece < (hl >> 24) * (u32)D * 4u;
-        if (mine) v = *(const H2E_AS_LDS u32x4*)((const char*)(hring + (size_t)sec * 64u * D) + fl_piece);
-        return mine;
+    auto flush_hints = [&](u32 hl, u32 sec) {
+        const u32 bytes = (hl >> 24) * (u32)D * 4u, piece = (H2E_DP_WAVES - 1u - wave) * 1024u + lane * 16u;
+        if (wave + 3u >= H2E_DP_WAVES && piece < bytes) {
+            u32x4 v = *(const H2E_AS_LDS u32x4*)((const char*)(hring + (size_t)sec * 64u * D) + piece);
+            *(H2E_AS_GLOBAL u32x4*)((char*)hlog + (size_t)(hl & 0xffffffu) * D * 4u + piece) = v;
+        }
     };
-    auto flush_write = [&](u32 hl, const u32x4& v) { *(H2E_AS_GLOBAL u32x4*)((char*)hlog + (size_t)(hl & 0xffffffu) * D * 4u + fl_piece) = v; };
     auto run_round = [&](auto loads_tag) {
         constexpr bool LOADS = decltype(loads_tag)::value;
-        u32x4 fl_v = {0u, 0u, 0u, 0u};
-        const u32 fl_hl = prev_hlog;
-        const bool fl_mine = rno > 0 && flush_read(fl_hl, (rno - 1u) & 1u, fl_v);
+        if (rno > 0) flush_hints(prev_hlog, (rno - 1u) & 1u);
 #ifdef H2E_WAVE_STAMPS
         unsigned long long ft0 = WAVE_STAMP();
 #endif
@@ -3443,7 +3440,6 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
 #endif
             }
         }
-        if (fl_mine) flush_write(fl_hl, fl_v);
         n_valid = false;
         if (same_chunk) {
             u32 meta = __builtin_amdgcn_readfirstlane(ph0);
@@ -3475,10 +3471,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
     };
     for (u32 round = 0; round < K.f_n_load_rounds; round++) run_round(std::true_type());
     for (u32 round = K.f_n_load_rounds; round < K.f_n_rounds; round++) run_round(std::false_type());
-    {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (rno > 0 && flush_read(prev_hlog, (rno - 1u) & 1u, v)) flush_write(prev_hlog, v);
-    }
+    if (rno > 0) flush_hints(prev_hlog, (rno - 1u) & 1u);
 #ifdef H2E_WAVE_STAMPS
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (int k = 0; k < 8; k++) {
