@@ -3133,22 +3133,12 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
     typedef u32 Rec[16];                                     // a record: 16 words
     Rec* rbuf = (Rec*)f_dyn;                                // [H2E_DP_CHUNKS][H2E_WCHUNK]: a ring of record chunks
     u64* fv = (u64*)(rbuf + H2E_DP_CHUNKS * H2E_WCHUNK);    // [f_slots][N]
-    // Hint log.  A round's hint values do not go to their (instance-minor, 32 bytes each, far apart) workspace slots from here: next
-    // to a saturated write stream - an expansion - every one of those partial-line stores queues for microseconds, 15 store
-    // instructions per round and CU, and the rows wait for them (a fill kernel beside the chain: 2.7 -> 3.4-4.5 ms; a copy: 3.0).
-    // They go to an LDS section of the round's parity, in the round's own order, and after the round's barrier three of the
-    // computing waves write that section as ONE contiguous run (<= 3 KB, whole lines) to this instance's log; h2e_field_finalize_log
-    // turns log entries into canonical values at their slots (the order of the log is the program's: K.f_log_slots).
-    u32* hring = (u32*)(fv + (size_t)K.f_slots * N);        // [2][64][D] digits
-    u64* hlog = (d.nd - (size_t)instance * (d.ws / n_instances)) + (size_t)instance * K.f_n_log * N;   // [f_n_log][N] words, this instance's
     const Rec* recs = (const Rec*)(args + K.f_recs);
     const u32 n_chunks = K.f_n_recs / H2E_WCHUNK;
-    u32 h_log = 0;   // (word 2 of the last header read: first log entry of that round | its number of hints << 24)
     auto header = [&](u32 pos, u32& cnt, u32& kind, u32& n_conts) {   // rows of the round, its kind, second records behind the rows
         const H2E_AS_LDS u32* hp = (const H2E_AS_LDS u32*)(rbuf + (size_t)((pos / H2E_WCHUNK) % H2E_DP_CHUNKS) * H2E_WCHUNK + pos % H2E_WCHUNK);
         u32 meta = __builtin_amdgcn_readfirstlane(hp[0]);
         n_conts = __builtin_amdgcn_readfirstlane(hp[1]);
-        h_log = __builtin_amdgcn_readfirstlane(hp[2]);
         cnt = meta & 0xffu;
         kind = (meta >> 8) & 0xffu;
     };
@@ -3237,18 +3227,8 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
 #else
 #define DP_STAMP(i, v)
 #endif
-    u32 rno = 0, n_hlog = 0, cur_hlog = 0, prev_hlog = 0;   // round parity; log word of the next / this / the previous round
-    // the previous round's section -> the log: waves 14, 13, 12 take its first, second, third KB
-    auto flush_hints = [&](u32 hl, u32 sec) {
-        const u32 bytes = (hl >> 24) * (u32)D * 4u, piece = (H2E_DP_WAVES - 1u - wave) * 1024u + lane * 16u;
-        if (wave + 3u >= H2E_DP_WAVES && piece < bytes) {
-            u32x4 v = *(const H2E_AS_LDS u32x4*)((const char*)(hring + (size_t)sec * 64u * D) + piece);
-            *(H2E_AS_GLOBAL u32x4*)((char*)hlog + (size_t)(hl & 0xffffffu) * D * 4u + piece) = v;
-        }
-    };
     auto run_round = [&](auto loads_tag) {
         constexpr bool LOADS = decltype(loads_tag)::value;
-        if (rno > 0) flush_hints(prev_hlog, (rno - 1u) & 1u);
 #ifdef H2E_WAVE_STAMPS
         unsigned long long ft0 = WAVE_STAMP();
 #endif
@@ -3259,10 +3239,8 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
             return (const H2E_AS_LDS u32*)(cbuf + (at < H2E_WCHUNK ? at : H2E_WCHUNK - 1u));
         };
         u32 r0 = n_rec;
-        cur_hlog = n_hlog;
         if (!n_valid) {   // the first round of a chunk
             header(pos, cnt, kind, n_conts);
-            cur_hlog = h_log;
             r0 = rec_ptr(pos % H2E_WCHUNK + 1u + grp)[j];
         }
         const u32 first = pos + 1;
@@ -3272,13 +3250,12 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
         // under it: the next header (padding = on to the next chunk, whose first header is read after the barrier that its
         // data is complete at) and this row's record of the next round.
         const bool same_chunk = pos % H2E_WCHUNK != 0;
-        u32 ph0 = 0, ph1 = 0, ph2 = 0;
+        u32 ph0 = 0, ph1 = 0;
         u32 pr = r0;
         if (same_chunk) {
             const H2E_AS_LDS u32* hp = rec_ptr(pos % H2E_WCHUNK);
             ph0 = hp[0];
             ph1 = hp[1];
-            ph2 = hp[2];
             pr = rec_ptr(pos % H2E_WCHUNK + 1u + grp)[j];
         }
 #ifdef H2E_WAVE_STAMPS
@@ -3435,8 +3412,8 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                 // conversion of the whole slot range gives 0 / 1 back)
                 u32 hv = out;
                 if (raw) hv = (dpp_mov<H2E_DPP_ROW_BCAST(0)>(out) & 1u) ? r1j : 0u;
-#ifndef H2E_EXP_NO_HINT_STORES   // (timing experiment: the chain without its hint values)
-                if (digit_lane) ((H2E_AS_LDS u32*)hring)[((rno & 1u) * 64u + (hint & 0x3fu)) * (u32)D + j] = hv;   // (entry within the round: low 6 bits)
+#ifndef H2E_EXP_NO_HINT_STORES   // (timing experiment: the chain without its global stores)
+                if (digit_lane) ((H2E_AS_GLOBAL u32*)(d.hints + (size_t)(hint - 1) * d.ws))[j] = hv;
 #endif
             }
         }
@@ -3444,7 +3421,6 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
         if (same_chunk) {
             u32 meta = __builtin_amdgcn_readfirstlane(ph0);
             n_nc = __builtin_amdgcn_readfirstlane(ph1);
-            n_hlog = __builtin_amdgcn_readfirstlane(ph2);
             n_cnt = meta & 0xffu;
             n_kind = (meta >> 8) & 0xffu;
             if (n_kind == 0xffu) pos = (chunk + 1) * H2E_WCHUNK;
@@ -3456,8 +3432,6 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
         unsigned long long ft2 = WAVE_STAMP();
 #endif
         lds_round_barrier_workgroup();
-        prev_hlog = cur_hlog;
-        rno++;
 #ifdef H2E_WAVE_STAMPS
         unsigned long long ft3 = WAVE_STAMP();
         fst_cyc[kind & 7] += ft3 - ft0;
@@ -3471,7 +3445,6 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
     };
     for (u32 round = 0; round < K.f_n_load_rounds; round++) run_round(std::true_type());
     for (u32 round = K.f_n_load_rounds; round < K.f_n_rounds; round++) run_round(std::false_type());
-    if (rno > 0) flush_hints(prev_hlog, (rno - 1u) & 1u);
 #ifdef H2E_WAVE_STAMPS
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (int k = 0; k < 8; k++) {
@@ -3527,19 +3500,6 @@ __global__ void __launch_bounds__(64) h2e_field_finalize(u32 first, u32 n, const
     Mont<N> M = mont_w<FP>(&g_fc[FP::ID]);
     u64* p = d.hints + (size_t)slot * d.ws;
     ws_store<N>(p, from_mont<N>(M, ws_load<N>(p)));
-}
-
-// the digit-row chain's hint log (its kernel above): entry `pos` of every instance's log -> canonical value at hint slot log_slots[pos]
-template <class FP>
-__global__ void __launch_bounds__(64) h2e_field_finalize_log(u32 n_log, const u32* __restrict__ log_slots, const InstanceDesc* inst, u32 n_instances) {
-    constexpr int N = FP::WW;
-    u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n_log * n_instances) return;
-    u32 instance = gid % n_instances, pos = gid / n_instances;   // instance-minor: the stores are the contiguous side
-    InstanceDesc d = inst[instance];
-    Mont<N> M = mont_w<FP>(&g_fc[FP::ID]);
-    const u64* e = (d.nd - (size_t)instance * (d.ws / n_instances)) + ((size_t)instance * n_log + pos) * N;
-    ws_store<N>(d.hints + (size_t)log_slots[pos] * d.ws, from_mont<N>(M, ws_load<N>(e)));
 }
 
 // hint-only linear combinations, after the chain and its finalize kernel (field_chain.hpp "hint-only combinations leave the
@@ -4468,8 +4428,7 @@ extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2E
     if (k->kind == H2E_PRE_FIELD_CHAIN) {   /* params_dev carries the constant pool, n_params the words per input slot */          \
         if (phase & 1)                                                                                                              \
         {                                                                                                                           \
-            size_t lds = (k->f_mode == 1 ? (size_t)H2E_DP_CHUNKS * H2E_WCHUNK * 64 + H2E_DP_HINT_RING_BYTES(FP::WW) : (size_t)2 * H2E_WCHUNK * 32) + \
-                         (size_t)k->f_slots * FP::WW * 8 + 64;                                                                      \
+            size_t lds = (k->f_mode == 1 ? (size_t)H2E_DP_CHUNKS * H2E_WCHUNK * 64 : (size_t)2 * H2E_WCHUNK * 32) + (size_t)k->f_slots * FP::WW * 8 + 64; \
             if (k->f_mode == 1)                                                                                                     \
                 hipLaunchKernelGGL(h2e_field_chain_digits<FP>, dim3(n_instances), dim3((H2E_DP_WAVES + 1) * 64), lds, stream, *k, args_dev, \
                                    (const u64*)params_dev, inst, n_instances);                                                     \
@@ -4477,13 +4436,10 @@ extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2E
                 hipLaunchKernelGGL(h2e_field_chain<FP>, dim3(n_instances), dim3(128), lds, stream, *k, args_dev,                    \
                                    (const u64*)params_dev, inst, n_instances);                                                     \
         }                                                                                                                           \
-        if ((phase & 2) && k->f_mode == 1 && k->f_n_log)   /* the digit-row chain wrote a log, not the slots */                   \
-            hipLaunchKernelGGL(h2e_field_finalize_log<FP>, dim3((n_instances * k->f_n_log + 63) / 64), block, 0, stream, k->f_n_log, \
-                               args_dev + k->f_log_slots, inst, n_instances);                                                      \
-        if ((phase & 2) && k->f_mode != 1 && k->hints_per_lane)                                                                     \
+        if ((phase & 2) && k->hints_per_lane)                                                                                       \
             hipLaunchKernelGGL(h2e_field_finalize<FP>, dim3((n_instances * k->hints_per_lane + 63) / 64), block, 0, stream,         \
                                k->hint_base, k->hints_per_lane, inst, n_instances);                                                \
-        if ((phase & 2) && k->f_mode != 1 && k->hints2_per_lane)                                                                    \
+        if ((phase & 2) && k->hints2_per_lane)                                                                                      \
             hipLaunchKernelGGL(h2e_field_finalize<FP>, dim3((n_instances * k->hints2_per_lane + 63) / 64), block, 0, stream,        \
                                k->hint2_base, k->hints2_per_lane, inst, n_instances);                                              \
         if ((phase & 2) && k->f_n_sinks)                                                                                            \

@@ -55,9 +55,6 @@ struct FieldChain {
     // hint-only linear combinations computed outside the chain (h2e_field_sinks): per sink its first word in sink_words;
     // a sink = hint slot, terms, then per term (coef & 0x1ff) << 23 | kind << 21 | index  (kind 0 hint slot, 1 input slot, 2 pool word)
     std::vector<uint32_t> sink_offsets, sink_words;
-    // digit rows: the hint log - the chain kernel leaves a round's hint values in its instance's log in the round's record order
-    // (contiguous stores); entry -> hint slot, for the finalize kernel that puts them where everybody reads them
-    std::vector<uint32_t> log_slots;
     std::string why;                // why a segment is not eligible
 };
 
@@ -750,8 +747,7 @@ struct FieldCompiler {
         if (n_slots >= 0xfff0) { out.why = "too many value slots"; return false; }
         // the kernels keep their record chunks (a ring of H2E_DP_CHUNKS for the digit-row kernel, two for the lane kernel) and
         // every value slot in LDS (160 KB per workgroup on gfx950)
-        if ((size_t)(digit_rows ? H2E_DP_CHUNKS : 2u) * H2E_WCHUNK * RW * 4 + (digit_rows ? H2E_DP_HINT_RING_BYTES(w_words) : 0u) + (size_t)n_slots * w_words * 8 + 64 >
-            (size_t)160 * 1024) {
+        if ((size_t)(digit_rows ? H2E_DP_CHUNKS : 2u) * H2E_WCHUNK * RW * 4 + (size_t)n_slots * w_words * 8 + 64 > (size_t)160 * 1024) {
             out.why = "the value slots (" + std::to_string(n_slots) + ") do not fit the LDS";
             return false;
         }
@@ -819,17 +815,6 @@ struct FieldCompiler {
                 uint32_t hdr[16] = {(uint32_t)rd.size() | ((uint32_t)rcls[r] << 8), digit_rows ? (uint32_t)n_conts : max_terms};
                 out.recs.insert(out.recs.end(), hdr, hdr + RW);
             }
-            const size_t hdr_at = out.recs.size() - RW;            // (word 2 of the header: the round's first log entry | its hints << 24)
-            const size_t round_log0 = out.log_slots.size();
-            // digit rows: a record's hint field is not the slot but (1 << 17 | entry within the round's stretch of the log)
-            auto hint_field = [&](uint32_t hint) -> uint32_t {
-                if (hint == 0xffffffffu) return 0u;
-                if (!digit_rows) return hint + 1;
-                uint32_t idx = (uint32_t)(out.log_slots.size() - round_log0);
-                if (idx >= 64) throw std::runtime_error("field chain: more than 64 hints in a round");
-                out.log_slots.push_back(hint);
-                return (1u << 17) | idx;
-            };
             std::vector<uint32_t> conts;
             for (uint32_t k : rd) {
                 uint32_t w[16] = {0};
@@ -856,7 +841,7 @@ struct FieldCompiler {
                         r[1] |= (uint32_t)sum << 18;
                         return fused ? (uint32_t)t.size() : 15u;
                     };
-                    w[1] = hint_field(nd.hint);
+                    w[1] = nd.hint == 0xffffffffu ? 0u : nd.hint + 1;
                     if (w[1] >= (1u << 18)) throw std::runtime_error("field chain: hint slot index beyond the records' 18 bits");
                     if (nd.hint != 0xffffffffu) {
                         out.note_hint(nd.hint, hint_split);
@@ -877,8 +862,8 @@ struct FieldCompiler {
                 }
                 w[0] = digit_rows ? head(nd.opc, (uint32_t)std::min<size_t>(nd.terms.size(), 14), 0, slot[k] >= 0 ? (uint32_t)slot[k] : 0xffffu)
                                   : nd.opc | ((slot[k] >= 0 ? (uint32_t)slot[k] : 0xffffu) << 16);
-                w[1] = hint_field(nd.hint);
-                if (digit_rows) {   // 16-word records: the hint field in 18 bits, the sum of a combination's coefficients above it
+                w[1] = nd.hint == 0xffffffffu ? 0u : nd.hint + 1;
+                if (digit_rows) {   // 16-word records: the hint slot in 18 bits, the sum of a combination's coefficients above it
                     if (w[1] >= (1u << 18)) throw std::runtime_error("field chain: hint slot index beyond the records' 18 bits");
                     int sum = 0;
                     if (nd.opc == F_LIN)
@@ -915,10 +900,6 @@ struct FieldCompiler {
             }
             if (conts.size() != n_conts * RW) throw std::runtime_error("field chain: second records miscounted");
             out.recs.insert(out.recs.end(), conts.begin(), conts.end());
-            if (digit_rows) {
-                if (round_log0 >= (1u << 24)) throw std::runtime_error("field chain: hint log beyond 2^24 entries");
-                out.recs[hdr_at + 2] = (uint32_t)round_log0 | ((uint32_t)(out.log_slots.size() - round_log0) << 24);
-            }
         }
         pad_chunk();
         if (getenv("H2E_FIELD_STATS")) {

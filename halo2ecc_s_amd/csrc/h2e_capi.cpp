@@ -857,9 +857,6 @@ struct h2e_program {
             pk.k.f_sink_words = (uint32_t)r.pre_args.size();
             r.pre_args.insert(r.pre_args.end(), chain.sink_words.begin(), chain.sink_words.end());
             pk.k.f_n_sinks = (uint32_t)chain.sink_offsets.size();
-            pk.k.f_log_slots = (uint32_t)r.pre_args.size();
-            pk.k.f_n_log = (uint32_t)chain.log_slots.size();
-            r.pre_args.insert(r.pre_args.end(), chain.log_slots.begin(), chain.log_slots.end());
             pk.before_segment = (uint32_t)(c.sg - r.segments.data());
             pk.early_after_segment = -1;
             r.pre_kernels.push_back(pk);

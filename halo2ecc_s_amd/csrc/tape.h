@@ -254,7 +254,6 @@ enum H2EVOpcode {
 #define H2E_V_NO_SLOT 0xffu
 #define H2E_LEVEL_WAVES 4u   // waves of a level-parallel replay workgroup (they share one instance's value slots)
 #define H2E_WCHUNK 256u      // wave mode: records per LDS chunk buffer; a round never straddles a chunk (host pads with H2E_V_NOP)
-#define H2E_DP_HINT_RING_BYTES(w_words) (2u * 64u * 2u * (w_words) * 4u)   /* digit-row chain: two LDS sections of 64 hint values */
 #define H2E_DP_CHUNKS 4u     // digit-parallel field chain: record chunks the kernel keeps in LDS (a ring, 16 KB each); the host's
                              // LDS budget check (field_chain.hpp) and the launcher (engine.hip) size from this one constant
 
@@ -296,9 +295,6 @@ typedef struct H2EPreKernel {
     uint32_t hint2_base, hints2_per_lane;   // FIELD_CHAIN: a second range of hint slots to finalize - the slots taken when the program was compiled
                                             // (conditions, sink terms, values later segments import); with several segments another segment's
                                             // recorded slots lie between the two ranges
-    uint32_t f_log_slots, f_n_log;   // FIELD_CHAIN, digit rows: the hint log - word index (args array) of the hint slot of every log entry, entries.
-                                     // The kernel writes a round's hint values to its instance's log as one contiguous run (engine.hip); the
-                                     // finalize kernel scatters them to their slots
     uint32_t f_mode;            // 0 = one lane per record, records of 8 words (h2e_field_chain); 1 = one 16-lane row per record, records of
                                 // 16 words = up to 14 terms per linear combination (h2e_field_chain_digits)
 } H2EPreKernel;
