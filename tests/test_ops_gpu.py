@@ -297,6 +297,23 @@ def test_ops_integer_and_tower_surface(engine, oracle, curve):
     sh1, sh2 = rec.shape(), rec2.shape()
     assert (sh1.base_offset, sh1.range_offset, sh1.n_permutations) == (sh2.base_offset, sh2.range_offset, sh2.n_permutations)
     rec2.close()
+    # a bounded cache (H2E_OPT_OP_CACHE_CAP): with room for four programs the scenario's ops evict each other; the third pass re-records
+    # what was let go and still writes the same arrays
+    if curve == 0:
+        ev0 = engine.get_stat(E.STAT_OP_CACHE_EVICTIONS)
+        engine.set_option(E.OPT_OP_CACHE_CAP, 4)
+        try:
+            assert engine.get_stat(E.STAT_OP_CACHE_SIZE) <= 4 and engine.get_stat(E.STAT_OP_CACHE_EVICTIONS) > ev0
+            miss1 = engine.get_stat(E.STAT_OP_CACHE_MISSES)
+            rec3 = Records(engine, fp, n_inst, rows)
+            scenario(rec3)
+            engine.torch.cuda.synchronize()
+            assert engine.get_stat(E.STAT_OP_CACHE_MISSES) > miss1 and engine.get_stat(E.STAT_OP_CACHE_SIZE) <= 4
+            for region in range(2):
+                assert engine.torch.equal(rec3.arrays()[region], first[region])
+            rec3.close()
+        finally:
+            engine.set_option(E.OPT_OP_CACHE_CAP, 4096)
     rec.close()
 
 
