@@ -1177,6 +1177,12 @@ WI_INLINE H2EOp chunk_op(const TapeChunk* tc, u32 k) {
 #ifndef H2E_X_WAVES
 #define H2E_X_WAVES 1
 #endif
+#ifndef H2E_X_WAVES_WIDE
+#define H2E_X_WAVES_WIDE 1   // the same for the 6-word fields (bls12_381: 299 + 43 registers; 2 = capped at 256, 32 of them spilled)
+#endif
+#ifndef H2E_XP_WAVES
+#define H2E_XP_WAVES 1       // the packed expansion (bn256 260 + 4 registers, bls12_381 304 + 48)
+#endif
 #ifndef H2E_REPLAY_WAVES
 #define H2E_REPLAY_WAVES 2
 #endif
@@ -1184,7 +1190,7 @@ WI_INLINE H2EOp chunk_op(const TapeChunk* tc, u32 k) {
 #define H2E_CHAIN_WAVES 1   // predictors / finalize / fix-up kernels: waves per SIMD their register budget must allow (experiments)
 #endif
 template <class FP, bool VALUES_ONLY>
-__global__ void __launch_bounds__(64, H2E_X_WAVES) h2e_run_tape(H2ELaunch L, const InstanceDesc* inst, u32 n_instances,
+__global__ void __launch_bounds__(64, (FP::WW > 4 ? H2E_X_WAVES_WIDE : H2E_X_WAVES)) h2e_run_tape(H2ELaunch L, const InstanceDesc* inst, u32 n_instances,
                                                    const H2EFieldConsts* fc) {
     // lanes: [sub-range][strand][instance], each sub-range padded to whole waves so a wave replays one op range; the
     // instance is the minor index: the lanes of a wave are consecutive instances (the minor dimension of the advice
@@ -1283,7 +1289,7 @@ static __constant__ unsigned char g_pk_rank_of[H2E_OP_COUNT] = {
     /* DECOMPOSE_LIMB */ 25, /* SHIFT_ADD */ 24};
 static_assert(H2E_OP_COUNT == 30, "g_pk_rank_of lists every opcode of tape.h");
 template <class FP>
-__global__ void __launch_bounds__(64) h2e_run_tape_packed(H2ELaunch L, const InstanceDesc* inst, u32 n_instances, u32 log2p) {
+__global__ void __launch_bounds__(64, H2E_XP_WAVES) h2e_run_tape_packed(H2ELaunch L, const InstanceDesc* inst, u32 n_instances, u32 log2p) {
     __shared__ u32x4 opbuf[H2E_PK_BUF_OPS * 4];   // [group][op in chunk][4 x 16 bytes]
     __shared__ u64 dg_sums[12 * 64];
     __shared__ u32 rank_lds[32];                  // g_pk_rank_of, read per lane in the loop: from LDS (a global load there would wait
@@ -1296,7 +1302,7 @@ __global__ void __launch_bounds__(64) h2e_run_tape_packed(H2ELaunch L, const Ins
     const u32 CH = min(32u, H2E_PK_BUF_OPS / G);   // ops per group and chunk (sub-ranges of the pairing programs: 8 or 16-17 ops)
     const u32 per_sub = n_instances * L.n_strands;
     const u32 n_sub = L.n_sub > 1 ? L.n_sub : 1;
-    const u32 sub = blockIdx.x * G + g;
+    const u32 sub = L.pk_order ? L.pk_order[blockIdx.x * G + g] : blockIdx.x * G + g;   // (~0u: an empty slot of the order table)
     const bool group_on = sub < n_sub;
     const u32 idx = ii < per_sub ? ii : per_sub - 1;      // padding lanes of a group replay its last lane and store nothing
     const u32 instance = idx % n_instances, strand = idx / n_instances;
@@ -4292,16 +4298,20 @@ extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances,
 #endif   // H2E_COMMON_UNIT
 // Tuning knobs (h2e_capi.cpp reads H2E_TUNE once, at h2e_ctx_create): [0] LDS bytes a small predictor grid reserves so
 // that no expansion wave shares its CU, [1] expansion result cache in LDS on / off, [2] extra dynamic LDS per expansion
-// workgroup (caps its waves per CU).  Defaults (profiles/r2_tune_sweep.txt): nothing reserved and no result cache -
-// with the batch-interleaved layout an operand re-read is a coalesced 1 KB load and the cache buys the expansion
+// workgroup (caps its waves per CU).  Round 2 (profiles/r2_tune_sweep.txt) switched the result cache off:
+// with the batch-interleaved layout an operand re-read is a coalesced 1 KB load and the cache bought the expansion
 // nothing (11.6 vs 11.7 ms), while the 15 KB of LDS per workgroup it held kept the value chain's replay workgroups
 // (95-135 KB of LDS each) of the next run from sharing CUs with the expansion: pipelined step 24.0 -> 20.9 ms.
 // [1] bit 1: the expansion's waves run at the chain kernels' priority (s_setprio 3) - the shared expansion stream is the
 // pipelined step's busiest resource: 16.17 -> 16.02 ms, window expansion 11.85 -> 11.4 ms; on by default.
 // [4]: persistent expansion (experiment): big expansions are launched with this many workgroups per CU, each looping over its share
 // of the blocks (0 = one workgroup per block)
-// [5]: 1 = no packed expansion for batches smaller than a wave (h2e_run_tape_packed; A/B)
-static int g_tune[6] = {0, 2, 0, 0, 0, 0};
+// [5]: 1 = no packed expansion for batches smaller than a wave (h2e_run_tape_packed; A/B), 2 = packed in tape order (no order tables)
+// [1] bit 0, the result cache, is ON again since round 4: the windows' and the accumulation loop's replays - 56-135 KB of LDS per
+// workgroup, the neighbours its 15 KB per wave kept off the expansion's CUs - are hint stores now (no LDS).  64 x 1024-point tiles,
+// alternating with it off in one box: step 15.38-15.42 -> 15.12-15.24 ms, window expansion 0.70 -> 0.71, traffic of a window launch
+// 36.95 -> 35.15 GB = 1.08 x its algorithmic bytes (the re-reads of operands the previous ops just produced).
+static int g_tune[6] = {0, 3, 0, 0, 0, 0};
 extern "C" long long H2E_UNIT(h2e_engine_scan_fallbacks)(void) {
     unsigned long long n = 0;
     if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_scan_fallbacks), sizeof(n)) != hipSuccess) return -1;
@@ -4326,7 +4336,7 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
     const InstanceDesc* inst = (const InstanceDesc*)instances;
     // batches smaller than half a wave: several sub-ranges per wave (h2e_run_tape_packed); g_tune[5] = 1 switches it off (A/B)
     int pack_log2p = -1;
-    if (per_sub <= 32 && n_sub >= 2 && g_tune[5] == 0) {
+    if (per_sub <= 32 && n_sub >= 2 && g_tune[5] != 1) {
         pack_log2p = 1;   // (at most 32 groups per wave: the kernel's op buffer holds that many chunks)
         while ((1u << pack_log2p) < per_sub) pack_log2p++;
     }
@@ -4334,6 +4344,14 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
     // (16 x bls12_381: 1.32 -> 1.30 ms, 2 x: 0.58 -> 0.52, 8 x bn256: 0.69 -> 0.61)
     const bool xcache_on = (g_tune[1] & 1) != 0 || pack_log2p >= 0;
     H2ELaunch launch_x = *launch;
+    // the packed form's order table for this group count (tape.h pk_order; g_tune[5] = 2: tape order, A/B)
+    u32 pk_grid = (n_sub + (64u >> (pack_log2p < 0 ? 0 : pack_log2p)) - 1) / (64u >> (pack_log2p < 0 ? 0 : pack_log2p));
+    launch_x.pk_order = nullptr;
+    if (pack_log2p >= 1 && pack_log2p <= 5 && launch->pk_order && launch->pk_n_sub == launch->n_sub && launch->pk_waves[5 - pack_log2p] &&
+        g_tune[5] != 2) {
+        launch_x.pk_order = launch->pk_order + launch->pk_off[5 - pack_log2p];
+        pk_grid = launch->pk_waves[5 - pack_log2p];
+    }
     if (xcache_on) launch_x.rel_refs |= 4u;
     if (g_tune[1] & 2) launch_x.rel_refs |= 8u;
     dim3 grid_x = grid;
@@ -4377,7 +4395,7 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
                            stream, *launch, inst, n_instances);                                                                \
     if ((mode & 1) && !launch->vtape) return -2;   /* a values-only replay always runs from the compiled V-tape */          \
     if ((mode & 2) && pack_log2p >= 0)                                                                                         \
-        hipLaunchKernelGGL(h2e_run_tape_packed<FP>, dim3((n_sub + (64u >> pack_log2p) - 1) / (64u >> pack_log2p)), block,              \
+        hipLaunchKernelGGL(h2e_run_tape_packed<FP>, dim3(pk_grid), block,                                                      \
                            xcache_on ? (size_t)3 * (2 * FP::L + 4) * 64 * 8 : 0, stream, launch_x, inst, n_instances, (u32)pack_log2p);  \
     else if (mode & 2)                                                                                                         \
         hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid_x, block,                                                           \
@@ -4429,6 +4447,7 @@ extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2E
         if (phase & 1)                                                                                                              \
         {                                                                                                                           \
             size_t lds = (k->f_mode == 1 ? (size_t)H2E_DP_CHUNKS * H2E_WCHUNK * 64 : (size_t)2 * H2E_WCHUNK * 32) + (size_t)k->f_slots * FP::WW * 8 + 64; \
+            if (k->f_mode == 1 && (size_t)g_tune[0] > lds && g_tune[0] <= 160 * 1024) lds = (size_t)g_tune[0];   /* keep the CU (A/B) */ \
             if (k->f_mode == 1)                                                                                                     \
                 hipLaunchKernelGGL(h2e_field_chain_digits<FP>, dim3(n_instances), dim3((H2E_DP_WAVES + 1) * 64), lds, stream, *k, args_dev, \
                                    (const u64*)params_dev, inst, n_instances);                                                     \

@@ -134,6 +134,10 @@ struct h2e_program {
     std::vector<uint32_t> h_subs;          // per segment with cuts: [0, cut_1, ..., n_ops]
     std::vector<uint32_t> seg_sub_begin;   // per segment: index into h_subs (or ~0u)
     std::vector<uint32_t> seg_n_sub;
+    // order tables of the packed expansion (tape.h H2ELaunch::pk_order), per cut segment and group count 2 << k
+    std::vector<uint32_t> h_pk_order;
+    std::vector<std::array<uint32_t, 5>> seg_pk_off, seg_pk_waves;
+    uint32_t* d_pk_order = nullptr;
     std::vector<uint8_t> seg_deferrable;   // a segment without cuts whose cells no later kernel reads: runs off the critical stream
     // compiled values-only replay (tape.h "V-tape"), per cut segment
     std::vector<H2EVRec> h_vtape;
@@ -183,6 +187,7 @@ struct h2e_program {
             (void)hipFree(d_fixups);
             (void)hipFree(d_pre_args);
             (void)hipFree(d_subs);
+            (void)hipFree(d_pk_order);
             (void)hipFree(d_vtape);
             (void)hipFree(d_vpieces);
             (void)hipFree(d_lrecs);
@@ -2699,6 +2704,70 @@ int h2e_program_shape(const h2e_program* p, h2e_shape* out) {
     return 0;
 }
 
+// Order tables of the packed expansion (tape.h H2ELaunch::pk_order).  A wave of h2e_run_tape_packed takes G sub-ranges and every
+// step runs ONE opcode for the groups whose cursor shows it, so a wave of G different opcode sequences costs up to the sum of
+// them.  The programs it serves repeat themselves (a pairing check: 8 649 sub-ranges, 391 different opcode sequences), so the
+// sub-ranges are classed by their sequence, every wave takes sub-ranges of one class (a class's last wave is padded with empty
+// slots), and the heaviest waves are dispatched first.  Replayed on the real tapes (exp/pack_sim.py): the longest SIMD's work
+// falls 2.0-2.9 x against taking the sub-ranges in tape order.
+static void build_pack_orders(h2e_program* p) {
+    const h2e::Recorder& r = *p->rec;
+    p->h_pk_order.clear();
+    p->seg_pk_off.assign(r.segments.size(), std::array<uint32_t, 5>{0, 0, 0, 0, 0});
+    p->seg_pk_waves.assign(r.segments.size(), std::array<uint32_t, 5>{0, 0, 0, 0, 0});
+    // what an op costs the wave ~ the cells it writes
+    auto op_cost = [](uint16_t opc) -> uint32_t {
+        switch (opc) {
+            case H2E_OP_DIV_CORE: return 140;
+            case H2E_OP_INT_MUL: return 125;
+            case H2E_OP_REDUCE: case H2E_OP_IS_INT_ZERO: return 40;
+            case H2E_OP_ASSIGN_W: case H2E_OP_DECOMPOSE_NATIVE: return 23;
+            case H2E_OP_BISEC_INT: case H2E_OP_SELECT_POINT: return 20;
+            case H2E_OP_INT_ADD: case H2E_OP_INT_SUB: case H2E_OP_MASK_INT: return 13;
+            case H2E_OP_INT_NEG: case H2E_OP_INT_MUL_SMALL: case H2E_OP_CACHE_INT: return 10;
+            default: return 4;
+        }
+    };
+    for (size_t si = 0; si < r.segments.size(); si++) {
+        const h2e::Segment& sg = r.segments[si];
+        uint32_t n_sub = p->seg_n_sub[si];
+        if (n_sub < 2 || sg.n_strands > 32 || n_sub > (1u << 18)) continue;   // (a packed launch has at most 32 lanes per sub-range)
+        const uint32_t* subs = p->h_subs.data() + p->seg_sub_begin[si];
+        struct Class { uint64_t cost; std::vector<uint32_t> members; };
+        std::vector<Class> classes;
+        std::unordered_map<uint64_t, uint32_t> by_hash;
+        for (uint32_t k = 0; k < n_sub; k++) {
+            uint64_t h = 0xcbf29ce484222325ull, cost = 0;
+            for (uint32_t o = subs[k]; o < subs[k + 1]; o++) {
+                uint16_t opc = r.tape[sg.tape_begin + o].opcode;
+                h = (h ^ opc) * 0x100000001b3ull;
+                cost += op_cost(opc);
+            }
+            h = (h ^ (subs[k + 1] - subs[k])) * 0x100000001b3ull;
+            auto it = by_hash.find(h);
+            if (it == by_hash.end()) {
+                it = by_hash.emplace(h, (uint32_t)classes.size()).first;
+                classes.push_back({cost, {}});
+            }
+            classes[it->second].members.push_back(k);
+        }
+        std::vector<uint32_t> by_cost(classes.size());
+        for (uint32_t c = 0; c < classes.size(); c++) by_cost[c] = c;
+        std::stable_sort(by_cost.begin(), by_cost.end(), [&](uint32_t a, uint32_t b) { return classes[a].cost > classes[b].cost; });
+        for (int k = 0; k < 5; k++) {
+            const uint32_t G = 2u << k;
+            p->seg_pk_off[si][k] = (uint32_t)p->h_pk_order.size();
+            uint32_t waves = 0;
+            for (uint32_t c : by_cost) {
+                const std::vector<uint32_t>& m = classes[c].members;
+                for (size_t i = 0; i < m.size(); i += G, waves++)
+                    for (uint32_t g = 0; g < G; g++) p->h_pk_order.push_back(i + g < m.size() ? m[i + g] : ~0u);
+            }
+            p->seg_pk_waves[si][k] = waves;
+        }
+    }
+}
+
 static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
     if (p->device == ctx->device) return 0;
     if (p->device >= 0) return fail(H2E_ERR_INVALID, "program already bound to another device");
@@ -2738,6 +2807,8 @@ static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
         p->seg_n_sub[si] = n + 1;
     }
     HIP_TRY(up((void**)&p->d_subs, p->h_subs.empty() ? nullptr : p->h_subs.data(), p->h_subs.size() * 4));
+    build_pack_orders(p);
+    HIP_TRY(up((void**)&p->d_pk_order, p->h_pk_order.empty() ? nullptr : p->h_pk_order.data(), p->h_pk_order.size() * 4));
     HIP_TRY(up((void**)&p->d_vtape, p->h_vtape.empty() ? nullptr : p->h_vtape.data(), p->h_vtape.size() * sizeof(H2EVRec)));
     HIP_TRY(up((void**)&p->d_vpieces, p->h_vpieces.empty() ? nullptr : p->h_vpieces.data(), p->h_vpieces.size() * 4));
     HIP_TRY(up((void**)&p->d_lrecs, p->h_lrecs.empty() ? nullptr : p->h_lrecs.data(), p->h_lrecs.size() * sizeof(H2EVRec)));
@@ -3046,6 +3117,16 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         L.slot_words = (uint32_t)slot_words;
         L.n_sub = p->seg_n_sub[si];
         L.sub = L.n_sub > 1 ? p->d_subs + p->seg_sub_begin[si] : nullptr;
+        L.pk_order = nullptr;
+        L.pk_n_sub = 0;
+        if (L.n_sub > 1 && si < p->seg_pk_waves.size() && p->d_pk_order) {
+            L.pk_order = p->d_pk_order;
+            L.pk_n_sub = L.n_sub;
+            for (int k = 0; k < 5; k++) {
+                L.pk_off[k] = p->seg_pk_off[si][k];
+                L.pk_waves[k] = p->seg_pk_waves[si][k];
+            }
+        }
         bool compiled = si < p->seg_n_pieces.size() && p->seg_n_pieces[si] > 0;
         L.vtape = compiled ? p->d_vtape : nullptr;
         L.vpieces = compiled ? p->d_vpieces + 2 * (size_t)p->seg_piece_begin[si] : nullptr;

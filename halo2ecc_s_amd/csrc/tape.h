@@ -200,6 +200,13 @@ typedef struct H2ELaunch {
     // behind a handful of L2 channels; h2e_digest_reduce sums the shards at the end of the run); NULL = off
     uint64_t* dg_out;
     uint32_t dg_shards;           // a power of two
+    // packed expansion (batches smaller than half a wave, engine.hip h2e_run_tape_packed): the order its waves take the sub-ranges
+    // in.  Sub-ranges with the same opcode sequence share a wave - its groups then never wait for each other's ops - and the
+    // heaviest waves come first; ~0u = an empty group slot (a class's last wave is padded).  Host side: one table per group count
+    // G = 2 << k (k = 0..4) behind each other; the launcher hands the kernel the one it runs with in pk_order.
+    const uint32_t* pk_order;     // device
+    uint32_t pk_off[5], pk_waves[5];   // first entry / waves of table k (pk_waves[k] = 0: none - tape order)
+    uint32_t pk_n_sub;            // the n_sub the tables were built for (a launch over part of the sub-ranges runs in tape order)
 } H2ELaunch;
 enum H2EStoreKind { H2E_S_W = 1, H2E_S_LIN = 2, H2E_S_FE = 3, H2E_S_CONST = 4, H2E_S_FULL = 5 };
 // leaves that do not fit a term word (kind 3: index into H2ELaunch::s_ext): strand-strided hint / selection / input slots and
