@@ -1198,8 +1198,10 @@ __global__ void __launch_bounds__(64, (FP::WW > 4 ? H2E_X_WAVES_WIDE : H2E_X_WAV
     u32 per_sub = n_instances * L.n_strands;
     u32 blocks_per_sub = (per_sub + 63) / 64;
     __shared__ TapeChunk chunk;
-    extern __shared__ u64 xcache_dyn[];   // [3][2 L + 4][64] words when the result cache is on (H2ELaunch.rel_refs bit 2)
-    __shared__ u64 dg_sums[12 * 64];      // stream digest: this lane's 3 x 4 sums, [region][word][lane]
+    extern __shared__ u64 xcache_dyn[];   // [3][2 L + 4][64] words when the result cache is on (H2ELaunch.rel_refs bit 2), then
+    // the stream digest's sums when the run has one: this lane's 3 x 4 sums, [region][word][lane].  Both dynamic: with the chunk's
+    // 4 KB a workgroup of a plain run holds 19 KB, so LDS lets a CU take the 8 waves its registers allow (as static arrays: 25 KB, 6)
+    u64* dg_sums = xcache_dyn + ((L.rel_refs & 4) ? (size_t)3 * (2 * FP::L + 4) * 64 : 0);
     if (L.rel_refs & 8) __builtin_amdgcn_s_setprio(3);   // the expansion's waves at the chain kernels' priority (g_tune[1] bit 1)
     // One workgroup (= wave) per 64 lanes, or - a launch with fewer workgroups than that (persistent form, L.x_blocks = the
     // real count) - every workgroup takes the blocks blockIdx.x, + gridDim.x, ...: the launch then holds a fixed share of every
@@ -4399,7 +4401,8 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
                            xcache_on ? (size_t)3 * (2 * FP::L + 4) * 64 * 8 : 0, stream, launch_x, inst, n_instances, (u32)pack_log2p);  \
     else if (mode & 2)                                                                                                         \
         hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid_x, block,                                                           \
-                           (xcache_on ? (size_t)3 * (2 * FP::L + 4) * 64 * 8 : 0) + (grid.x > 4096 ? (size_t)g_tune[2] : 0),   \
+                           (xcache_on ? (size_t)3 * (2 * FP::L + 4) * 64 * 8 : 0) + (launch->dg_out ? (size_t)12 * 64 * 8 : 0) +  \
+                               (grid.x > 4096 ? (size_t)g_tune[2] : 0),                                                          \
                            stream, launch_x, inst, n_instances, fc_dev);
     switch (field_pair) {
 #if H2E_HAS_FP(0)
