@@ -57,22 +57,6 @@ def simulate(ops, subs, G, rank=RANK, order=None):
     return tot_steps, tot_cost, tot_lane_cost
 
 
-if __name__ == "__main__":
-    curve = sys.argv[1] if len(sys.argv) > 1 else "bn256"
-    prog = Program.pairing_check_bn256(emit_shape=False) if curve == "bn256" else Program.pairing_check_bls12_381(emit_shape=False)
-    launches = prog.launches()
-    dom = max(range(len(launches)), key=lambda i: launches[i]["cells"])
-    ops, subs = tape(prog, dom)
-    print(curve, "launch", dom, "ops", len(ops), "sub-ranges", len(subs) - 1)
-    hist = np.bincount(ops, minlength=30)
-    print({NAMES[i]: int(hist[i]) for i in range(30) if hist[i]})
-    base_steps, base_cost, _ = simulate(ops, subs, 1)
-    print("G = 1: steps", base_steps, "cost", base_cost)
-    for G in (2, 4, 8, 32):
-        st, co, lc = simulate(ops, subs, G)
-        print(f"G = {G}: steps {st} ({st / base_steps:.2f} of separate waves), cost {co} ({co / base_cost:.2f}), lane utilisation {lc / (co * G):.2f}")
-
-
 def recut(n_ops, every):
     return np.array(list(range(0, n_ops, every)) + [n_ops], dtype=np.uint32)
 
@@ -96,3 +80,57 @@ def wave_costs(ops, subs, G):
                     pos[i] += 1
         out.append(tot)
     return np.array(out)
+
+
+def makespan(costs, slots):
+    """list scheduling: every SIMD slot takes the next wave when it is free"""
+    import heapq
+    h = [0] * slots
+    heapq.heapify(h)
+    for c in costs:
+        heapq.heappush(h, heapq.heappop(h) + int(c))
+    return max(h)
+
+
+def orders(curve, G, slots):
+    """what the order of the sub-ranges is worth (h2e_capi.cpp pack_orders_of): tape order (adjacent sub-ranges share a wave) against
+    the engine's order tables (waves of one opcode sequence, heaviest first), as the work of the longest of `slots` SIMDs"""
+    prog = Program.pairing_check_bn256(emit_shape=False) if curve == "bn256" else Program.pairing_check_bls12_381(emit_shape=False)
+    for li, l in enumerate(prog.launches()):
+        if l["n_ops"] < 1000:
+            continue
+        ops, subs = tape(prog, li)
+        nsub = len(subs) - 1
+        seq = {ops[subs[k]:subs[k + 1]].tobytes() for k in range(nsub)}
+        print(f"{curve} launch {li}: {len(ops)} ops, {nsub} sub-ranges, {len(seq)} different opcode sequences, G = {G}, {slots} SIMD slots")
+        wc = wave_costs(ops, subs, G)
+        print(f"  tape order:   {len(wc)} waves, work {wc.sum()}, longest wave {wc.max()}, longest SIMD {makespan(wc, slots)} (even split: {wc.sum() / slots:.0f})")
+        tab = prog.pack_order(li, G)
+        wc2 = []
+        for w in tab:
+            first = int(w[0])
+            wc2.append(sum(cost(o) for o in ops[subs[first]:subs[first + 1]]))   # one sequence: the wave costs what one sub-range costs
+        wc2 = np.array(wc2)
+        print(f"  order tables: {len(wc2)} waves, work {wc2.sum()}, longest wave {wc2.max()}, longest SIMD {makespan(wc2, slots)} (even split: {wc2.sum() / slots:.0f})")
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "orders":
+    orders(sys.argv[1], int(sys.argv[3]), int(sys.argv[4]))
+    sys.exit(0)
+
+if __name__ == "__main__":
+    curve = sys.argv[1] if len(sys.argv) > 1 else "bn256"
+    prog = Program.pairing_check_bn256(emit_shape=False) if curve == "bn256" else Program.pairing_check_bls12_381(emit_shape=False)
+    launches = prog.launches()
+    dom = max(range(len(launches)), key=lambda i: launches[i]["cells"])
+    ops, subs = tape(prog, dom)
+    print(curve, "launch", dom, "ops", len(ops), "sub-ranges", len(subs) - 1)
+    hist = np.bincount(ops, minlength=30)
+    print({NAMES[i]: int(hist[i]) for i in range(30) if hist[i]})
+    base_steps, base_cost, _ = simulate(ops, subs, 1)
+    print("G = 1: steps", base_steps, "cost", base_cost)
+    for G in (2, 4, 8, 32):
+        st, co, lc = simulate(ops, subs, G)
+        print(f"G = {G}: steps {st} ({st / base_steps:.2f} of separate waves), cost {co} ({co / base_cost:.2f}), lane utilisation {lc / (co * G):.2f}")
+
+

@@ -2710,11 +2710,8 @@ int h2e_program_shape(const h2e_program* p, h2e_shape* out) {
 // sub-ranges are classed by their sequence, every wave takes sub-ranges of one class (a class's last wave is padded with empty
 // slots), and the heaviest waves are dispatched first.  Replayed on the real tapes (exp/pack_sim.py): the longest SIMD's work
 // falls 2.0-2.9 x against taking the sub-ranges in tape order.
-static void build_pack_orders(h2e_program* p) {
-    const h2e::Recorder& r = *p->rec;
-    p->h_pk_order.clear();
-    p->seg_pk_off.assign(r.segments.size(), std::array<uint32_t, 5>{0, 0, 0, 0, 0});
-    p->seg_pk_waves.assign(r.segments.size(), std::array<uint32_t, 5>{0, 0, 0, 0, 0});
+static void pack_orders_of(const h2e::Recorder& r, const h2e::Segment& sg, const uint32_t* subs, uint32_t n_sub, std::vector<uint32_t>& out,
+                           std::array<uint32_t, 5>& off, std::array<uint32_t, 5>& n_waves) {
     // what an op costs the wave ~ the cells it writes
     auto op_cost = [](uint16_t opc) -> uint32_t {
         switch (opc) {
@@ -2728,43 +2725,58 @@ static void build_pack_orders(h2e_program* p) {
             default: return 4;
         }
     };
+    struct Class { uint64_t cost; std::vector<uint32_t> members; };
+    std::vector<Class> classes;
+    std::unordered_map<uint64_t, std::vector<uint32_t>> by_hash;   // hash -> classes with it (compared op by op: a collision must not mix sequences)
+    auto same_sequence = [&](uint32_t a, uint32_t b) {
+        if (subs[a + 1] - subs[a] != subs[b + 1] - subs[b]) return false;
+        for (uint32_t i = 0; i < subs[a + 1] - subs[a]; i++)
+            if (r.tape[sg.tape_begin + subs[a] + i].opcode != r.tape[sg.tape_begin + subs[b] + i].opcode) return false;
+        return true;
+    };
+    for (uint32_t k = 0; k < n_sub; k++) {
+        uint64_t h = 0xcbf29ce484222325ull, cost = 0;
+        for (uint32_t o = subs[k]; o < subs[k + 1]; o++) {
+            uint16_t opc = r.tape[sg.tape_begin + o].opcode;
+            h = (h ^ opc) * 0x100000001b3ull;
+            cost += op_cost(opc);
+        }
+        std::vector<uint32_t>& cand = by_hash[h];
+        uint32_t cls = ~0u;
+        for (uint32_t c : cand)
+            if (same_sequence(classes[c].members[0], k)) cls = c;
+        if (cls == ~0u) {
+            cls = (uint32_t)classes.size();
+            cand.push_back(cls);
+            classes.push_back({cost, {}});
+        }
+        classes[cls].members.push_back(k);
+    }
+    std::vector<uint32_t> by_cost(classes.size());
+    for (uint32_t c = 0; c < classes.size(); c++) by_cost[c] = c;
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](uint32_t a, uint32_t b) { return classes[a].cost > classes[b].cost; });
+    for (int k = 0; k < 5; k++) {
+        const uint32_t G = 2u << k;
+        off[k] = (uint32_t)out.size();
+        uint32_t waves = 0;
+        for (uint32_t c : by_cost) {
+            const std::vector<uint32_t>& m = classes[c].members;
+            for (size_t i = 0; i < m.size(); i += G, waves++)
+                for (uint32_t g = 0; g < G; g++) out.push_back(i + g < m.size() ? m[i + g] : ~0u);
+        }
+        n_waves[k] = waves;
+    }
+}
+static void build_pack_orders(h2e_program* p) {
+    const h2e::Recorder& r = *p->rec;
+    p->h_pk_order.clear();
+    p->seg_pk_off.assign(r.segments.size(), std::array<uint32_t, 5>{0, 0, 0, 0, 0});
+    p->seg_pk_waves.assign(r.segments.size(), std::array<uint32_t, 5>{0, 0, 0, 0, 0});
     for (size_t si = 0; si < r.segments.size(); si++) {
         const h2e::Segment& sg = r.segments[si];
         uint32_t n_sub = p->seg_n_sub[si];
         if (n_sub < 2 || sg.n_strands > 32 || n_sub > (1u << 18)) continue;   // (a packed launch has at most 32 lanes per sub-range)
-        const uint32_t* subs = p->h_subs.data() + p->seg_sub_begin[si];
-        struct Class { uint64_t cost; std::vector<uint32_t> members; };
-        std::vector<Class> classes;
-        std::unordered_map<uint64_t, uint32_t> by_hash;
-        for (uint32_t k = 0; k < n_sub; k++) {
-            uint64_t h = 0xcbf29ce484222325ull, cost = 0;
-            for (uint32_t o = subs[k]; o < subs[k + 1]; o++) {
-                uint16_t opc = r.tape[sg.tape_begin + o].opcode;
-                h = (h ^ opc) * 0x100000001b3ull;
-                cost += op_cost(opc);
-            }
-            h = (h ^ (subs[k + 1] - subs[k])) * 0x100000001b3ull;
-            auto it = by_hash.find(h);
-            if (it == by_hash.end()) {
-                it = by_hash.emplace(h, (uint32_t)classes.size()).first;
-                classes.push_back({cost, {}});
-            }
-            classes[it->second].members.push_back(k);
-        }
-        std::vector<uint32_t> by_cost(classes.size());
-        for (uint32_t c = 0; c < classes.size(); c++) by_cost[c] = c;
-        std::stable_sort(by_cost.begin(), by_cost.end(), [&](uint32_t a, uint32_t b) { return classes[a].cost > classes[b].cost; });
-        for (int k = 0; k < 5; k++) {
-            const uint32_t G = 2u << k;
-            p->seg_pk_off[si][k] = (uint32_t)p->h_pk_order.size();
-            uint32_t waves = 0;
-            for (uint32_t c : by_cost) {
-                const std::vector<uint32_t>& m = classes[c].members;
-                for (size_t i = 0; i < m.size(); i += G, waves++)
-                    for (uint32_t g = 0; g < G; g++) p->h_pk_order.push_back(i + g < m.size() ? m[i + g] : ~0u);
-            }
-            p->seg_pk_waves[si][k] = waves;
-        }
+        pack_orders_of(r, sg, p->h_subs.data() + p->seg_sub_begin[si], n_sub, p->h_pk_order, p->seg_pk_off[si], p->seg_pk_waves[si]);
     }
 }
 
@@ -3498,6 +3510,33 @@ int h2e_program_tape_opcodes(const h2e_program* p, uint32_t launch, uint16_t* op
         if (n_subs) *n_subs = (uint32_t)b.size();
         for (size_t i = 0; i < b.size() && i < subs_cap; i++) subs[i] = b[i];
         return (int)n_ops;
+    }
+    return fail(H2E_ERR_INVALID, "no such launch");
+}
+
+// Diagnostics: the packed expansion's order table of the k-th launch for 2 << groups_log2m1 groups per wave (the table
+// ensure_device_program uploads): returns its entries (waves x groups; ~0u = empty slot), copies at most `cap` of them
+int h2e_program_pack_order(const h2e_program* p, uint32_t launch, uint32_t groups_log2m1, uint32_t* out, uint32_t cap) {
+    if (!p || groups_log2m1 > 4) return fail(H2E_ERR_INVALID, "bad argument");
+    const h2e::Recorder& r = *p->rec;
+    uint32_t k = 0;
+    for (auto& s : r.segments) {
+        if (s.tape_end <= s.tape_begin) continue;
+        if (k++ != launch) continue;
+        uint32_t n_ops = s.tape_end - s.tape_begin;
+        std::vector<uint32_t> b{0};
+        for (uint32_t c = 0; c < s.n_cuts; c++) {
+            uint32_t at = r.cuts[s.cuts_begin + c];
+            if (at > b.back() && at < n_ops) b.push_back(at);
+        }
+        b.push_back(n_ops);
+        if (b.size() < 3) return 0;
+        std::vector<uint32_t> tab;
+        std::array<uint32_t, 5> off{}, waves{};
+        pack_orders_of(r, s, b.data(), (uint32_t)b.size() - 1, tab, off, waves);
+        uint32_t n = waves[groups_log2m1] * (2u << groups_log2m1);
+        for (uint32_t i = 0; i < n && i < cap; i++) out[i] = tab[off[groups_log2m1] + i];
+        return (int)n;
     }
     return fail(H2E_ERR_INVALID, "no such launch");
 }

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "h2e_op_bisec_point_with_curvature", "h2e_op_assign_cache_point", "h2e_op_assign_selected_point", "h2e_export_fixed", "h2e_range_table", "h2e_export_copy_constraints", "h2e_ctx_set_option", "h2e_ctx_get_stat",
     "h2e_program_msm_bn256_tile_no_select", "h2e_last_run_expansion_launches",
     "h2e_run_digest", "h2e_submit_digest", "h2e_records_attach", "h2e_op_int_mul_small_constant", "h2e_op_assign_int_constant", "h2e_op_bisec_int", "h2e_op_fq", "h2e_op_pairing",
-    "h2e_check", "h2e_program_tape_opcodes", "h2e_program_value_chain_kind",
+    "h2e_check", "h2e_program_tape_opcodes", "h2e_program_value_chain_kind", "h2e_program_pack_order",
 ]
 
 
@@ -277,6 +277,30 @@ class Program:
         n = lib().h2e_program_launches(self._h, buf, cap)
         keys = ("n_strands", "n_ops", "cells", "dbase", "drange", "dselect", "n_params", "base0")
         return [dict(zip(keys, [int(buf[8 * i + j]) for j in range(8)])) for i in range(n)]
+
+    def tape_opcodes(self, launch):
+        """diagnostics: (opcodes of the launch's tape, op indices its sub-ranges start at + the op count) as numpy arrays"""
+        L = lib()
+        L.h2e_program_tape_opcodes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        n = L.h2e_program_tape_opcodes(self._h, launch, None, 0, None, 0, None)
+        _check(min(n, 0))
+        ops = np.zeros(n, dtype=np.uint16)
+        subs = np.zeros(n + 2, dtype=np.uint32)
+        ns = C.c_uint32(0)
+        L.h2e_program_tape_opcodes(self._h, launch, ops.ctypes.data, n, subs.ctypes.data, n + 2, C.byref(ns))
+        return ops, subs[:ns.value]
+
+    def pack_order(self, launch, groups):
+        """diagnostics: the packed expansion's order table of a launch for `groups` (2..32) sub-ranges per wave, [waves][groups]
+        (0xffffffff = empty slot)"""
+        k = {2: 0, 4: 1, 8: 2, 16: 3, 32: 4}[groups]
+        L = lib()
+        L.h2e_program_pack_order.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+        n = L.h2e_program_pack_order(self._h, launch, k, None, 0)
+        _check(min(n, 0))
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        L.h2e_program_pack_order(self._h, launch, k, out.ctypes.data, n)
+        return out[:n].reshape(-1, groups)
 
     def close(self):
         if self._h:

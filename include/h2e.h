@@ -142,6 +142,9 @@ int h2e_program_launches(const h2e_program* p, uint64_t* out, uint32_t cap);
 /* diagnostics: opcodes (tape.h H2EOpcode) of the k-th launch's tape and the op indices its expansion's sub-ranges start at */
 int h2e_program_tape_opcodes(const h2e_program* p, uint32_t launch, uint16_t* opcodes, uint32_t cap, uint32_t* subs, uint32_t subs_cap,
                              uint32_t* n_subs);
+/* diagnostics: the order the packed expansion (batches smaller than half a wave) takes the k-th launch's sub-ranges in when a wave
+ * holds 2 << groups_log2m1 of them: sub-range indices wave by wave, ~0u = empty slot.  Returns the entries; copies at most cap. */
+int h2e_program_pack_order(const h2e_program* p, uint32_t launch, uint32_t groups_log2m1, uint32_t* out, uint32_t cap);
 /* diagnostics: the k-th launch's value chain: out3 = {store ops per strand of a hint store, pieces of a compiled replay, field chain 0/1} */
 int h2e_program_value_chain_kind(const h2e_program* p, uint32_t launch, uint32_t* out3);
 

@@ -86,3 +86,28 @@ def test_pairing_check_bn256_shape(oracle, h2e_built):
     assert orun.info.status == 0, orun.error   # e(a,b) * e(-a,b) == 1 held in-circuit
     compare_shape(prog, orun, patches_inputs=inputs)
     assert prog.n_advice_cells == 6165013
+
+
+@pytest.mark.parametrize("curve", ["bn256", "bls12_381"])
+def test_packed_expansion_order_tables(h2e_built, curve):
+    """the order the packed expansion takes a launch's sub-ranges in (batches smaller than half a wave: BASELINE's 8-GPU shares of
+    configs[3] / configs[4], 16 bls12_381 checks on one GPU): for every group count every sub-range exactly once, the sub-ranges of
+    a wave all have the SAME opcode sequence (so its groups never wait for each other's ops), empty slots only behind a wave's
+    sub-ranges, and the pairing programs repeat themselves enough for that to cost few extra waves"""
+    prog = (Program.pairing_check_bn256 if curve == "bn256" else Program.pairing_check_bls12_381)(emit_shape=False)
+    launches = [i for i, l in enumerate(prog.launches()) if l["n_ops"] > 1000]
+    assert len(launches) == 2   # Miller loop | final exponentiation
+    for li in launches:
+        ops, subs = prog.tape_opcodes(li)
+        n_sub = len(subs) - 1
+        seq = [ops[subs[k]:subs[k + 1]].tobytes() for k in range(n_sub)]
+        assert len(set(seq)) < n_sub // 4
+        for groups in (2, 4, 8, 16, 32):
+            tab = prog.pack_order(li, groups)
+            live = tab[tab != 0xFFFFFFFF]
+            assert np.array_equal(np.sort(live), np.arange(n_sub, dtype=np.uint32))
+            for w in tab:
+                k = int((w != 0xFFFFFFFF).sum())
+                assert k >= 1 and (w[k:] == 0xFFFFFFFF).all()
+                assert len({seq[s] for s in w[:k]}) == 1
+            assert len(tab) <= -(-n_sub // groups) + len(set(seq))   # at most one padded wave per opcode sequence
