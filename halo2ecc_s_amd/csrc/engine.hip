@@ -3135,6 +3135,8 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool loader = wave == H2E_DP_WAVES;
     const u32 instance = blockIdx.x;
+    if (K.f_started != nullptr && threadIdx.x == H2E_DP_WAVES * 64u)   // (the loader wave's first lane: the rows' memory counter stays clean)
+        __hip_atomic_fetch_add(K.f_started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     InstanceDesc d = inst[instance];
     const H2EFieldConsts* fc = &g_fc[FP::ID];
     extern __shared__ ulonglong2 f_dyn[];
@@ -3938,6 +3940,23 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_finalize_ecc(H2EPreKe
 }
 
 #if H2E_COMMON_UNIT   // kernels that do not depend on the field pair: unit 0 only
+// ------------------------------------------------------------------------------------------------
+// Gate in front of an expansion that becomes ready at the same moment as the next stage's digit chain (a pairing check's Miller-loop
+// expansion and its final-exponentiation chain both wait for the same hint store).  A chain workgroup is 15 waves and ~100 KB of
+// LDS on ONE CU; once the expansion's waves hold the SIMDs, the slots they free one by one are refilled from the expansion's own
+// grid and the chain only gets its CUs when that grid has drained - a single batch of 64 bn256 checks then takes 5.5 instead of
+// 4.2 ms, decided by which queue the dispatcher looked at first (1-2 us apart in profiles/r4_s_pairing_bn256_ring1).  The gate is one
+// wave that waits until the chain's workgroups have reported in (H2EPreKernel::f_started) - or 30 us, so that it can never hang.
+__global__ void __launch_bounds__(64) h2e_gate(const u32* counter, u32 target, u32 timeout_ticks) {
+    if (threadIdx.x != 0) return;
+    const u64 t0 = wall_clock64();   // 100 MHz
+    while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0 && wall_clock64() - t0 < timeout_ticks)
+        __builtin_amdgcn_s_sleep(8);
+}
+extern "C" int h2e_engine_gate(const uint32_t* counter, uint32_t target, hipStream_t stream) {
+    hipLaunchKernelGGL(h2e_gate, dim3(1), dim3(64), 0, stream, counter, target, 3000u);
+    return (int)hipGetLastError();
+}
 // ------------------------------------------------------------------------------------------------
 // Hand-off (device half).  The batch-interleaved advice array [row][COLS][half][instance] of a run ->
 // one array per instance in the consumer's layout: row-major [instance][row][COLS][4 words] (the reference's

@@ -42,6 +42,7 @@ extern "C" int h2e_engine_check(const H2ECheckRegion* regs, const uint64_t* dict
 extern "C" int h2e_engine_copy_constraints(const uint32_t* perms, uint64_t n, void* out, hipStream_t stream);
 extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances, uint32_t bits, hipStream_t stream);
 extern "C" int h2e_engine_digest_reduce(const void* shards, uint32_t n_shards, uint32_t n_words, void* out, hipStream_t stream);
+extern "C" int h2e_engine_gate(const uint32_t* counter, uint32_t target, hipStream_t stream);
 extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
                                  uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream);
 extern "C" int h2e_engine_predict(int field_pair, int phase, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,
@@ -2290,6 +2291,9 @@ struct JobSlot {
     // stream held at submission, so that the value chains of consecutive runs overlap each other as well - each of their
     // kernels is latency-bound and leaves most of the GPU idle.
     hipStream_t chain_stream = nullptr;
+    // start counter of the slot's digit chains and what it will read once every chain launched so far has started (engine.hip h2e_gate)
+    uint32_t* d_gate = nullptr;
+    uint32_t gate_total = 0;
     bool used = false;
     bool profiled = false;            // the last run on this slot recorded `ev`
     uint32_t n_launches = 0;
@@ -2307,6 +2311,7 @@ struct JobSlot {
         (void)hipFree(ws_sel);
         (void)hipFree(d_inst);
         (void)hipFree(dg_shards);
+        (void)hipFree(d_gate);
         if (h_inst) (void)hipHostFree(h_inst);
         if (upload_ev) (void)hipEventDestroy(upload_ev);
     }
@@ -3050,6 +3055,20 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     auto pk_params = [&](const h2e::PreKernel& pk) -> const uint32_t* {
         return pk.k.kind == H2E_PRE_FIELD_CHAIN ? (const uint32_t*)p->d_pool : p->d_params;
     };
+    // the digit chain in front of the next launched segment, if it has one (-1: none): it becomes ready together with an expansion
+    // launched now, which then gets a gate (engine.hip h2e_gate; H2E_SCHED bit 32 switches the gates off, A/B)
+    auto next_digit_chain = [&](size_t si) -> int {
+        if (ctx->sched & 32u) return -1;
+        size_t sj = si + 1;
+        while (sj < r.segments.size() && r.segments[sj].tape_end <= r.segments[sj].tape_begin) sj++;
+        if (sj >= r.segments.size()) return -1;
+        for (size_t pi = 0; pi < r.pre_kernels.size(); pi++) {
+            const h2e::PreKernel& pk = r.pre_kernels[pi];
+            if (pk.before_segment == sj && pk.k.kind == H2E_PRE_FIELD_CHAIN && pk.k.f_mode == 1 && pk.early_after_segment < 0) return (int)pi;
+        }
+        return -1;
+    };
+    int gate_for = -1;   // the pre-kernel a gate launched in this run is waiting for
     for (size_t si = 0; si < r.segments.size(); si++) {
         const h2e::Segment& s = r.segments[si];
         if (s.tape_end <= s.tape_begin) continue;
@@ -3079,7 +3098,12 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
                 HIP_TRY(hipStreamWaitEvent(sa, early_done[pi], 0));
                 continue;
             }
-            int prc = H2E_PREDICT(fp, 1, &pk.k, p->d_pre_args, pk_params(pk), p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sa);
+            H2EPreKernel k1 = pk.k;
+            if ((int)pi == gate_for) {   // a gate is waiting for this chain's workgroups
+                k1.f_started = J.d_gate;
+                gate_for = -1;
+            }
+            int prc = H2E_PREDICT(fp, 1, &k1, p->d_pre_args, pk_params(pk), p->d_aux, J.d_inst, n_instances, ctx->d_fc[fp], sa);
             if (prc != 0) return fail(H2E_ERR_HIP, std::string("predictor launch failed: ") + hipGetErrorString((hipError_t)prc));
         }
         if (have_pending && hold_longer && s.sel_stride) {
@@ -3269,6 +3293,20 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
                 for (size_t sj = si + 1; sj < r.segments.size(); sj++) later_cut = later_cut || p->seg_n_sub[sj] > 1;
                 skip_x = ctx->test_skip_expansion == (int64_t)si || (ctx->test_skip_expansion == -1 && later_cut);
             }
+            if (!skip_x && gate_for < 0) {
+                int gpi = next_digit_chain(si);
+                if (gpi >= 0) {
+                    if (!J.d_gate) {
+                        HIP_TRY(hipMalloc((void**)&J.d_gate, 4));
+                        HIP_TRY(hipMemset(J.d_gate, 0, 4));
+                        J.gate_total = 0;
+                    }
+                    J.gate_total += n_instances;   // one workgroup per instance
+                    gate_for = gpi;
+                    int grc = h2e_engine_gate(J.d_gate, J.gate_total, sx);
+                    if (grc != 0) return fail(H2E_ERR_HIP, std::string("gate launch failed: ") + hipGetErrorString((hipError_t)grc));
+                }
+            }
             if (!skip_x && (lrc = expand(sx))) return lrc;
             if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sx));
             if (!skip_x && (lrc = expand_fixup(sx))) return lrc;
@@ -3309,6 +3347,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         int frc = flush_pending();
         if (frc) return frc;
     }
+    if (gate_for >= 0) J.gate_total -= n_instances;   // (the chain a gate counted on was not launched: the gate times out)
     if (ctx->test_skip_expansion != INT64_MIN) {
         int orc = h2e_engine_or_status(J.d_inst, n_instances, H2E_ST_TEST_HOOK, sa);
         if (orc != 0) return fail(H2E_ERR_HIP, std::string("status kernel launch failed: ") + hipGetErrorString((hipError_t)orc));

@@ -216,7 +216,7 @@ struct Segment {  // one engine launch
 };
 
 struct PreKernel {  // a value-predictor launch that must run before segment `before_segment`
-    H2EPreKernel k;
+    H2EPreKernel k = {};
     uint32_t before_segment;
     // >= 0: it only depends on the predictors of that (earlier) segment, so it may start right after them on a
     // side stream and overlap that segment's replay (the MSM tail predictor only needs the windows' Jacobian sums)

@@ -304,6 +304,8 @@ typedef struct H2EPreKernel {
                                             // recorded slots lie between the two ranges
     uint32_t f_mode;            // 0 = one lane per record, records of 8 words (h2e_field_chain); 1 = one 16-lane row per record, records of
                                 // 16 words = up to 14 terms per linear combination (h2e_field_chain_digits)
+    uint32_t* f_started;        // digit chain: every workgroup adds 1 here when it starts (the gate in front of the expansion that became
+                                // ready with it, h2e_engine_gate); NULL: nobody waits
 } H2EPreKernel;
 // field chain record opcodes (field_chain.hpp FieldCompiler::F_*)
 enum H2EFieldOp { H2E_F_NOP = 0, H2E_F_LIN, H2E_F_MUL, H2E_F_DIV, H2E_F_ISZERO, H2E_F_NOT, H2E_F_AND, H2E_F_OR, H2E_F_XNOR, H2E_F_SELECT,
