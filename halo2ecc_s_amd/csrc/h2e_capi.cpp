@@ -3058,7 +3058,9 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     // the digit chain in front of the next launched segment, if it has one (-1: none): it becomes ready together with an expansion
     // launched now, which then gets a gate (engine.hip h2e_gate; H2E_SCHED bit 32 switches the gates off, A/B)
     auto next_digit_chain = [&](size_t si) -> int {
-        if (ctx->sched & 32u) return -1;
+        // (a pipelined run's expansions queue on streams they share with other runs' - a gate there would hold those up - and its
+        // chains start next to other runs' expansions whatever it does: h2e_run only)
+        if ((ctx->sched & 32u) || !join) return -1;
         size_t sj = si + 1;
         while (sj < r.segments.size() && r.segments[sj].tape_end <= r.segments[sj].tape_begin) sj++;
         if (sj >= r.segments.size()) return -1;
