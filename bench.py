@@ -207,7 +207,8 @@ def main():
                          "dealt round-robin over the N ranks (SURVEY 8d items 4-5: 8 bn256 / 2 bls12_381 checks per GPU at N = 8; shares may be ragged)")
     ap.add_argument("--total-units", type=int, default=None, help="--scaling strong: units of the whole job (default: the workload's BASELINE batch)")
     ap.add_argument("--ring", type=int, default=None, help="output-buffer sets steps rotate through = runs in flight (default: 2 for the MSM - step k+1's value chain runs under "
-                    "step k's expansion, 2 x 110 GB of arrays; 8 / 16 for the bn256 / bls12_381 pairing checks, whose value chains are latency-bound; 1: h2e_run, no overlap)")
+                    "step k's expansion, 2 x 110 GB of arrays; 4 for the pairing checks: their value chains are latency-bound, but a fifth run in flight slows "
+                    "every chain by more than it hides; 1: h2e_run, no overlap)")
     ap.add_argument("--digest", action="store_true", help="consume every step's arrays with the stream digest (h2e_submit_digest; streaming-job mode, configs[2])")
     ap.add_argument("--job-tiles", type=int, default=None, help="run one MSM job of this many tiles over all ranks (2^20 points = 1024; `--job-tiles 1024 --gpus 8` is configs[2]): "
                     "steps = job_tiles / (units x gpus), every tile with its own inputs, digest on, one gather of the job's records at the end")
@@ -240,7 +241,7 @@ def main():
         # MSM: two 110 GB buffer sets; pairing checks: three runs in flight - a run's value chain (one 1024-thread workgroup per
         # check, VALU-bound on its CU) under the expansions of the other two; deeper rings only make the chains fight each other
         # (64 x bn256: 3.7 ms / step at 3, 4.1 at 8; 16 x bls12-381: 2.4 at 3, 3.9 at 16)
-        args.ring = {"msm": 2, "pairing_bn256": 3, "pairing_bls12_381": 3}[args.workload]
+        args.ring = {"msm": 2, "pairing_bn256": 4, "pairing_bls12_381": 4}[args.workload]
     if args.job_tiles:
         args.digest = True
         args.steps = max(1, args.job_tiles // (args.units * max(1, args.gpus)))
