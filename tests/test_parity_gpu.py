@@ -675,6 +675,34 @@ def test_pairing_bls12_381_batch_16(engine, oracle):
         compare_advice(prog, orun, *rows, instance=k)
 
 
+@pytest.mark.parametrize("curve,n_inst", [("bn256", 3), ("bn256", 8), ("bls12_381", 2), ("bls12_381", 5)])
+def test_pairing_small_batches_packed_expansion(engine, oracle, curve, n_inst):
+    """batches smaller than half a wave - one GPU's share of configs[3] / configs[4] at 8 GPUs (8 / 2 checks) and ragged shares (3, 5:
+    the packed expansion's groups are padded to 4 / 8 lanes) - go through h2e_run_tape_packed and its order tables: every status 0,
+    first and last instance cell for cell against the oracle, and the run submitted through the pipeline gives the same arrays"""
+    if curve == "bn256":
+        prog, gen, orun_of = Program.pairing_check_bn256(), synth.pairing_check_bn256_inputs, oracle_lib.run_pairing_check_bn256
+    else:
+        prog, gen, orun_of = Program.pairing_check_bls12_381(), synth.pairing_check_bls12_381_inputs, oracle_lib.run_pairing_check_bls12_381
+    ins = [gen(instance=900 + k) for k in range(n_inst)]
+    d_in = engine.upload_inputs(prog, np.stack(ins))
+    arrs = engine.alloc(prog, n_inst, fill=0xFF)   # (the shape's flags mask the cells nobody assigns)
+    engine.run(prog, d_in, *arrs)
+    engine.torch.cuda.synchronize()
+    assert (arrs[3].cpu().numpy() == 0).all(), arrs[3].cpu().numpy()
+    rows = _rows(engine, prog, arrs[:3])
+    for k in sorted({0, n_inst - 1}):
+        orun = orun_of(ins[k])
+        assert orun.info.status == 0, orun.error
+        compare_advice(prog, orun, *rows, instance=k)
+    arrs2 = engine.alloc(prog, n_inst, fill=0xFF)
+    engine.wait(engine.submit(prog, d_in, *arrs2))
+    engine.torch.cuda.synchronize()
+    dg = [engine.digest(prog, region, arrs[region]).cpu().numpy() for region in range(2)]
+    dg2 = [engine.digest(prog, region, arrs2[region]).cpu().numpy() for region in range(2)]
+    assert all(np.array_equal(a, b) for a, b in zip(dg, dg2))
+
+
 @pytest.mark.parametrize("curve", ["bn256", "bls12_381"])
 def test_pairing_soak_statuses(engine, curve):
     """Every hint the value chain produces is checked by the expansion that consumes it (a differing hint sets H2E_ST_ARITH) and
