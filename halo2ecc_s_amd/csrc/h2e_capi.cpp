@@ -3234,7 +3234,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             // inversion behind every one of them made that stream the step (16 x bls12_381 at four runs in flight 1.81 -> 1.58 ms, 8 x
             // bn256 1.40 -> 1.10, 2 x bls12_381 1.22 -> 0.95; the MSM, whose small expansions run beside big ones: no difference, left
             // as it was).  H2E_SCHED & 64: in their stream as before (A/B)
-            if (fixup_in_stream && (join || run_has_big_x || (ctx->sched & 64u))) return launch_one(4, f, st);
+            if (fixup_in_stream && (join || (run_has_big_x && !(ctx->sched & 128u)) || (ctx->sched & 64u))) return launch_one(4, f, st);   // (128: to the fix-up stream whatever the run holds - experiment)
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, st));
             HIP_TRY(hipStreamWaitEvent(sd, e, 0));
