@@ -238,9 +238,9 @@ def main():
     if args.units is None:
         args.units = DEFAULT_UNITS[args.workload]
     if args.ring is None:
-        # MSM: two 110 GB buffer sets; pairing checks: three runs in flight - a run's value chain (one 1024-thread workgroup per
-        # check, VALU-bound on its CU) under the expansions of the other two; deeper rings only make the chains fight each other
-        # (64 x bn256: 3.7 ms / step at 3, 4.1 at 8; 16 x bls12-381: 2.4 at 3, 3.9 at 16)
+        # MSM: two 110 GB buffer sets; pairing checks: four runs in flight - a run's value chain (one 1024-thread workgroup per
+        # check, latency-bound on its CU) under the expansions of the others; deeper rings only make the chains fight each other
+        # (round 4, exp/r4_gpu41.sh: 16 x bls12-381 1.75 ms / step at 3, 1.6 at 4, 1.8 at 5; 8 x bn256 1.40 / 1.11 / 1.29; 64 x bn256 the same at 3 and 4)
         args.ring = {"msm": 2, "pairing_bn256": 4, "pairing_bls12_381": 4}[args.workload]
     if args.job_tiles:
         args.digest = True
