@@ -24,7 +24,8 @@ def build(force=False, verbose=True):
     objs = []
     running = []
     units = ([("engine.hip", f"engine_fp{k}.o", [f"-DH2E_FP_ONLY={k}"]) for k in range(3)] + [("h2e_capi.cpp", "h2e_capi.o", [])]
-             + [("checker.hip", "checker.o", [])])   # the device-side constraint check: a unit of its own, no code shared with the engine
+             + [("checker.hip", "checker.o", [])]   # the device-side constraint check: a unit of its own, no code shared with the engine
+             + [("handoff.hip", "handoff.o", [])])  # field-independent hand-off kernels (unit records)
     for src, obj, defs in units:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, obj)

@@ -41,6 +41,9 @@ extern "C" int h2e_engine_check(const H2ECheckRegion* regs, const uint64_t* dict
                                 uint64_t* fail, hipStream_t stream);
 extern "C" int h2e_engine_copy_constraints(const uint32_t* perms, uint64_t n, void* out, hipStream_t stream);
 extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances, uint32_t bits, hipStream_t stream);
+extern "C" int h2e_engine_unit_records(const void* base, const void* status, const void* digests, void* out, const uint64_t* offsets3,
+                                       const uint32_t* refs, uint32_t limbs, int has_point, uint32_t n_instances, uint32_t out_stride,
+                                       hipStream_t stream);   // handoff.hip
 extern "C" int h2e_engine_digest_reduce(const void* shards, uint32_t n_shards, uint32_t n_words, void* out, hipStream_t stream);
 extern "C" int h2e_engine_gate(const uint32_t* counter, uint32_t target, hipStream_t stream);
 extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
@@ -139,6 +142,7 @@ struct h2e_program {
     std::vector<uint32_t> h_pk_order;
     std::vector<std::array<uint32_t, 5>> seg_pk_off, seg_pk_waves;
     uint32_t* d_pk_order = nullptr;
+    bool pk_built = false;
     std::vector<uint8_t> seg_deferrable;   // a segment without cuts whose cells no later kernel reads: runs off the critical stream
     // compiled values-only replay (tape.h "V-tape"), per cut segment
     std::vector<H2EVRec> h_vtape;
@@ -2785,6 +2789,26 @@ static void build_pack_orders(h2e_program* p) {
     }
 }
 
+// The order tables only matter to launches with n_strands x n_instances <= 32 lanes per sub-range (engine.hip: the packed
+// expansion).  BASELINE-sized batches, the MSM's segments and most of an operator-API context's cached op programs never take
+// that path, so the tables (an op-by-op classification of the tape, five tables per segment, a device allocation) are made
+// by the first run that does.
+static int ensure_pack_orders(h2e_program* p, uint32_t n_instances) {
+    if (p->pk_built) return 0;
+    const h2e::Recorder& r = *p->rec;
+    bool need = false;
+    for (size_t si = 0; si < r.segments.size() && si < p->seg_n_sub.size(); si++)
+        need = need || (p->seg_n_sub[si] >= 2 && (uint64_t)r.segments[si].n_strands * n_instances <= 32);
+    if (!need) return 0;
+    build_pack_orders(p);
+    if (!p->h_pk_order.empty()) {
+        HIP_TRY(hipMalloc((void**)&p->d_pk_order, p->h_pk_order.size() * 4));
+        HIP_TRY(hipMemcpy(p->d_pk_order, p->h_pk_order.data(), p->h_pk_order.size() * 4, hipMemcpyHostToDevice));
+    }
+    p->pk_built = true;
+    return 0;
+}
+
 static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
     if (p->device == ctx->device) return 0;
     if (p->device >= 0) return fail(H2E_ERR_INVALID, "program already bound to another device");
@@ -2824,8 +2848,7 @@ static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
         p->seg_n_sub[si] = n + 1;
     }
     HIP_TRY(up((void**)&p->d_subs, p->h_subs.empty() ? nullptr : p->h_subs.data(), p->h_subs.size() * 4));
-    build_pack_orders(p);
-    HIP_TRY(up((void**)&p->d_pk_order, p->h_pk_order.empty() ? nullptr : p->h_pk_order.data(), p->h_pk_order.size() * 4));
+    // (the packed expansion's order tables are built by the first run that takes the packed path: ensure_pack_orders)
     HIP_TRY(up((void**)&p->d_vtape, p->h_vtape.empty() ? nullptr : p->h_vtape.data(), p->h_vtape.size() * sizeof(H2EVRec)));
     HIP_TRY(up((void**)&p->d_vpieces, p->h_vpieces.empty() ? nullptr : p->h_vpieces.data(), p->h_vpieces.size() * 4));
     HIP_TRY(up((void**)&p->d_lrecs, p->h_lrecs.empty() ? nullptr : p->h_lrecs.data(), p->h_lrecs.size() * sizeof(H2EVRec)));
@@ -2867,6 +2890,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_device_program(ctx, p);
     if (rc) return rc;
+    if ((rc = ensure_pack_orders(p, n_instances))) return rc;
     int fp = p->field_pair;
     h2e::Recorder& r = *p->rec;
     {   // constants of every W field the program's segments work in (a GeneralScalarEccContext has two)
@@ -3071,6 +3095,15 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         return -1;
     };
     int gate_for = -1;   // the pre-kernel a gate launched in this run is waiting for
+    // a gate counts on a chain that is launched later in this function: on EVERY exit on which that chain was not launched (an
+    // error return in between, or no such chain) the slot's target goes back, or every later gate of the slot would spin its
+    // whole timeout (the gate itself just times out)
+    struct GateGuard {
+        JobSlot& J;
+        const int& gate_for;
+        uint32_t n;
+        ~GateGuard() { if (gate_for >= 0) J.gate_total -= n; }
+    } gate_guard{J, gate_for, n_instances};
     bool run_has_big_x = false;
     for (size_t si = 0; si < r.segments.size(); si++)
         run_has_big_x = run_has_big_x || (p->seg_n_sub[si] > 1 && (uint64_t)p->seg_n_sub[si] * r.segments[si].n_strands * n_instances >= ctx->small_x_lanes);
@@ -3357,7 +3390,6 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         int frc = flush_pending();
         if (frc) return frc;
     }
-    if (gate_for >= 0) J.gate_total -= n_instances;   // (the chain a gate counted on was not launched: the gate times out)
     if (ctx->test_skip_expansion != INT64_MIN) {
         int orc = h2e_engine_or_status(J.d_inst, n_instances, H2E_ST_TEST_HOOK, sa);
         if (orc != 0) return fail(H2E_ERR_HIP, std::string("status kernel launch failed: ") + hipGetErrorString((hipError_t)orc));
@@ -3537,6 +3569,23 @@ int h2e_program_launches(const h2e_program* p, uint64_t* out, uint32_t cap) {
     return (int)k;
 }
 
+// First row of each advice array the k-th launch writes (a fork: of its strand 0): out[0..2] = base, range, select row.
+int h2e_program_launch_rows(const h2e_program* p, uint32_t launch, uint64_t* out) {
+    if (!p || !out) return fail(H2E_ERR_INVALID, "null argument");
+    const h2e::Recorder& r = *p->rec;
+    uint32_t k = 0;
+    for (auto& s : r.segments) {
+        if (s.tape_end <= s.tape_begin) continue;
+        if (k++ != launch) continue;
+        const auto& op = r.tape[s.tape_begin];
+        out[0] = s.is_fork ? s.base0 : op.base_row;
+        out[1] = s.is_fork ? s.range0 : op.range_row;
+        out[2] = s.is_fork ? s.select0 : op.select_row;
+        return 0;
+    }
+    return fail(H2E_ERR_INVALID, "no such launch");
+}
+
 // Diagnostics: the opcodes of one launch's tape (the k-th segment h2e_program_launches lists) and the op indices its expansion's
 // sub-ranges start at - what exp/pack_sim.py replays on the host to price a packing of sub-ranges into waves.  Returns the
 // number of ops; *n_subs = sub-range bounds written (first = 0, last = the number of ops).
@@ -3639,6 +3688,46 @@ int h2e_digest(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, c
     const uint64_t rows = region == 0 ? p->base_rows : region == 1 ? p->range_rows : p->select_rows;
     rc = h2e_engine_digest(cols, d_batch, d_flags, rows, n_instances, d_digests, (hipStream_t)stream);
     if (rc != 0) return fail(H2E_ERR_HIP, rc < 0 ? "digest: bad geometry" : std::string("digest launch failed: ") + hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
+// Words of a unit record: status, Offset (3), the result point's coordinate limbs (2 x limbs cells, 2 words each: limbs are
+// < 2^128) and z (1 word), 32-byte digest per advice array - 29 for the 3-limb curves, 33 for bls12_381 tiles.
+static uint32_t unit_record_limbs(const h2e_program* p) {
+    const h2e::Recorder& r = *p->rec;
+    if (r.outputs.size() >= 9 && (r.outputs.size() - 3) % 2 == 0) return (uint32_t)((r.outputs.size() - 3) / 2);
+    return 3;   // (a workload without a result point: the bn256 record size)
+}
+int h2e_unit_record_words(const h2e_program* p) {
+    if (!p) return fail(H2E_ERR_INVALID, "null program");
+    return (int)(1 + 3 + 4 * unit_record_limbs(p) + 1 + 12);
+}
+int h2e_unit_records(h2e_ctx* ctx, const h2e_program* p, uint32_t n_instances, const void* d_base, const void* d_status,
+                     const void* d_digests, void* d_out, uint32_t out_stride_words, void* stream) {
+    if (!ctx || !p || !d_base || !d_status || !d_out) return fail(H2E_ERR_INVALID, "null argument");
+    const h2e::Recorder& r = *p->rec;
+    const uint32_t limbs = unit_record_limbs(p);
+    const uint32_t R = 1 + 3 + 4 * limbs + 1 + 12;
+    if (out_stride_words < R) return fail(H2E_ERR_INVALID, "h2e_unit_records: out_stride_words is smaller than h2e_unit_record_words()");
+    if (n_instances == 0) return 0;
+    const bool has_point = r.outputs.size() == 2 * (size_t)limbs + 3;
+    if (!r.outputs.empty() && !has_point) return fail(H2E_ERR_INVALID, "h2e_unit_records: the program's outputs are not a point");
+    uint32_t refs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (has_point) {   // x limbs, x native, y limbs, y native, z  (h2e_program_outputs) -> x limbs, y limbs, z
+        for (uint32_t i = 0; i < limbs; i++) {
+            refs[i] = r.outputs[i];
+            refs[limbs + i] = r.outputs[limbs + 1 + i];
+        }
+        refs[2 * limbs] = r.outputs[2 * limbs + 2];
+        for (uint32_t i = 0; i <= 2 * limbs; i++)
+            if ((refs[i] >> 30) != 0) return fail(H2E_ERR_INVALID, "h2e_unit_records: a result cell outside the base array");
+    }
+    const uint64_t offs[3] = {r.base_offset, r.range_offset, r.select_offset};
+    // (no context lock: nothing of the context is touched - the kernel reads the caller's arrays on the caller's stream)
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = h2e_engine_unit_records(d_base, d_status, d_digests, d_out, offs, refs, limbs, has_point ? 1 : 0, n_instances, out_stride_words,
+                                     (hipStream_t)stream);
+    if (rc != 0) return fail(H2E_ERR_HIP, std::string("unit-records launch failed: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }
 
@@ -3771,7 +3860,7 @@ static int ensure_check_artefacts(h2e_ctx* ctx, h2e_program* p) {
             if (f.col != 8 || f.row >= rows[0]) return fail(H2E_ERR_SHAPE, "internal: a fixed patch outside the constant column");
             ck[(size_t)f.row * 9 + 8] = 0x80000000u | (uint32_t)k;
         }
-        HIP_TRY(hipMalloc((void**)&p->d_fix_ck, std::max<size_t>(16, ck.size() * 4)));
+        if (!p->d_fix_ck) HIP_TRY(hipMalloc((void**)&p->d_fix_ck, std::max<size_t>(16, ck.size() * 4)));   // (a retry after a failed call keeps what it has)
         HIP_TRY(hipMemcpy(p->d_fix_ck, ck.data(), ck.size() * 4, hipMemcpyHostToDevice));
     }
     if (!p->d_dict) {
@@ -3792,13 +3881,13 @@ static int ensure_check_artefacts(h2e_ctx* ctx, h2e_program* p) {
         const H2EFieldConsts& fc = field_pair(0).fc;
         HIP_TRY((hipError_t)h2e_engine_check_consts(fc.n, fc.n_minv, fc.n_r2));
     }
-    HIP_TRY(hipMalloc((void**)&p->d_dict_m, r.dict.size() * 32));
+    if (!p->d_dict_m) HIP_TRY(hipMalloc((void**)&p->d_dict_m, r.dict.size() * 32));
     HIP_TRY((hipError_t)h2e_engine_check_to_mont(p->d_dict, p->d_dict_m, r.dict.size(), nullptr));
     {   // 2^(18 k), k = 0..5: the range gates' shifts (range_chip.rs:160-218)
         uint64_t sh[6][4];
         std::memset(sh, 0, sizeof(sh));
         for (int k = 0; k < 6; k++) sh[k][(18 * k) / 64] = 1ull << ((18 * k) % 64);
-        HIP_TRY(hipMalloc((void**)&p->d_shifts_m, sizeof(sh)));
+        if (!p->d_shifts_m) HIP_TRY(hipMalloc((void**)&p->d_shifts_m, sizeof(sh)));
         HIP_TRY(hipMemcpy(p->d_shifts_m, sh, sizeof(sh), hipMemcpyHostToDevice));
         HIP_TRY((hipError_t)h2e_engine_check_to_mont(p->d_shifts_m, p->d_shifts_m, 6, nullptr));
     }
@@ -3835,9 +3924,9 @@ static int ensure_check_artefacts(h2e_ctx* ctx, h2e_program* p) {
             krows[k] = tab[k].row;
         }
         p->n_sel_keys = (uint32_t)tab.size();
-        HIP_TRY(hipMalloc((void**)&p->d_sel_keys, keys.size() * 8));
+        if (!p->d_sel_keys) HIP_TRY(hipMalloc((void**)&p->d_sel_keys, keys.size() * 8));
         HIP_TRY(hipMemcpy(p->d_sel_keys, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&p->d_sel_key_rows, krows.size() * 4));
+        if (!p->d_sel_key_rows) HIP_TRY(hipMalloc((void**)&p->d_sel_key_rows, krows.size() * 4));
         HIP_TRY(hipMemcpy(p->d_sel_key_rows, krows.data(), krows.size() * 4, hipMemcpyHostToDevice));
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -4223,6 +4312,8 @@ int h2e_records_create(h2e_ctx* ctx, int field_pair_id, int scalar_field, uint32
     if (!ctx || !out) return fail(H2E_ERR_INVALID, "null argument");
     if (field_pair_id < 0 || field_pair_id > 2 || scalar_field < -1 || scalar_field > 2) return fail(H2E_ERR_INVALID, "bad field pair");
     if (n_instances == 0 || base_rows == 0 || range_rows == 0 || select_rows == 0) return fail(H2E_ERR_INVALID, "empty records");
+    // a flag word, not a boolean: a caller's "true" of 2 or -1 must not silently mean "no shape" / "no select chip"
+    if (emit_shape & ~(H2E_RECORDS_EMIT_SHAPE | H2E_RECORDS_NO_SELECT_CHIP)) return fail(H2E_ERR_INVALID, "h2e_records_create: unknown bits in the flag word (H2E_RECORDS_*)");
     h2e_records* R = new h2e_records();
     R->ctx = ctx;
     R->field_pair = field_pair_id;

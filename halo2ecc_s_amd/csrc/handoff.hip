@@ -1,0 +1,72 @@
+// Hand-off kernels that do not depend on a field pair: what leaves a finished run for its consumer.
+//
+//  * h2e_engine_unit_records - the per-unit record table of a job's one collective ({status, Offset, result point
+//    cells, 32-byte digest per advice array} per MSM tile / pairing instance).  The reference has no multi-context driver - a
+//    unit is its own `Context` (src/context.rs:136-143) whose `Offset` (src/circuit/ecc_chip.rs:36-62) and result handles the
+//    caller reads back - so this is the build's definition; one kernel, one lane per (unit, word), straight into the buffer the
+//    host hands to ncclAllGather.
+//
+// A translation unit of its own (seconds to compile; engine.hip is minutes per field pair).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+struct H2EUnitRecArgs {
+    const u64* base;      // batch-interleaved base array [row][5][half][instance][2 words]
+    const u32* status;    // [instance]
+    const u64* digests;   // [3][instance][4] or null
+    u64* out;             // [instance][out_stride]
+    u64 offsets[3];       // the program's Offset (base, range, select rows consumed)
+    u32 refs[9];          // cell references (col << 27 | row) of the result point's 2 x limbs coordinate limbs, then of z
+    u32 limbs;            // 3 or 4
+    u32 has_point;        // 0: a workload without a result point (the words stay zero)
+    u32 n_instances;
+    u32 out_stride;       // words per row of `out` (>= record words; a caller's leading index column is outside the record)
+};
+
+__global__ void __launch_bounds__(256) h2e_unit_records_k(H2EUnitRecArgs a) {
+    const u32 R = 1 + 3 + 4 * a.limbs + 1 + 12;
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 unit = t / R, w = t % R;
+    if (unit >= a.n_instances) return;
+    const u32 n = a.n_instances;
+    auto cell_word = [&](u32 ref, u32 word) -> u64 {   // word 0 / 1 of the cell's low half (limbs are < 2^128)
+        u64 row = ref & 0x3FFFFFFu, col = (ref >> 27) & 7u;
+        return a.base[(((row * 5 + col) * 2 + 0) * n + unit) * 2 + word];
+    };
+    u64 v = 0;
+    if (w == 0) v = (u64)(int64_t)(int32_t)a.status[unit];   // (the status word as the int32 the boundary hands out, sign-extended)
+    else if (w < 4) v = a.offsets[w - 1];
+    else if (w < 4 + 4 * a.limbs) {
+        if (a.has_point) v = cell_word(a.refs[(w - 4) >> 1], (w - 4) & 1);
+    } else if (w == 4 + 4 * a.limbs) {
+        if (a.has_point) v = cell_word(a.refs[2 * a.limbs], 0);
+    } else if (a.digests) {
+        u32 k = w - (R - 12);
+        v = a.digests[((size_t)(k >> 2) * n + unit) * 4 + (k & 3)];
+    }
+    a.out[(size_t)unit * a.out_stride + w] = v;
+}
+
+extern "C" int h2e_engine_unit_records(const void* base, const void* status, const void* digests, void* out, const uint64_t* offsets3,
+                                       const uint32_t* refs, uint32_t limbs, int has_point, uint32_t n_instances, uint32_t out_stride,
+                                       hipStream_t stream) {
+    if (n_instances == 0) return 0;
+    H2EUnitRecArgs a;
+    a.base = (const u64*)base;
+    a.status = (const u32*)status;
+    a.digests = (const u64*)digests;
+    a.out = (u64*)out;
+    for (int i = 0; i < 3; i++) a.offsets[i] = offsets3[i];
+    for (int i = 0; i < 9; i++) a.refs[i] = (has_point && (u32)i <= 2 * limbs) ? refs[i] : 0;
+    a.limbs = limbs;
+    a.has_point = has_point ? 1 : 0;
+    a.n_instances = n_instances;
+    a.out_stride = out_stride;
+    const u32 R = 1 + 3 + 4 * limbs + 1 + 12;
+    const u32 threads = n_instances * R;
+    hipLaunchKernelGGL(h2e_unit_records_k, dim3((threads + 255) / 256), dim3(256), 0, stream, a);
+    return (int)hipGetLastError();
+}

@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = [
     "h2e_program_msm_bn256_tile_no_select", "h2e_last_run_expansion_launches",
     "h2e_run_digest", "h2e_submit_digest", "h2e_records_attach", "h2e_op_int_mul_small_constant", "h2e_op_assign_int_constant", "h2e_op_bisec_int", "h2e_op_fq", "h2e_op_pairing",
     "h2e_check", "h2e_program_tape_opcodes", "h2e_program_value_chain_kind", "h2e_program_pack_order",
+    "h2e_program_launch_rows", "h2e_unit_records", "h2e_unit_record_words",
 ]
 
 
@@ -47,8 +48,7 @@ class H2EError(RuntimeError):
 
 
 def lib_path():
-    # H2E_LIB: another build of the same sources (A/B timing experiments only)
-    return os.environ.get("H2E_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libh2e.so")
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libh2e.so")
 
 
 class _Shape(C.Structure):
@@ -163,12 +163,15 @@ def lib():
     L.h2e_last_run_expansion_launches.argtypes = [vp, C.POINTER(u32), u32]
     L.h2e_program_outputs.argtypes = [vp, C.POINTER(u32), u32]
     L.h2e_program_launches.argtypes = [vp, C.POINTER(C.c_uint64), u32]
+    L.h2e_program_launch_rows.argtypes = [vp, u32, C.POINTER(C.c_uint64)]
     L.h2e_export.argtypes = [vp, vp, u32, i32, i32, i32, vp, vp, vp]
     L.h2e_digest.argtypes = [vp, vp, u32, i32, vp, vp, vp]
     L.h2e_submit.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
     L.h2e_wait.argtypes = [vp, i32, vp]
     L.h2e_run_digest.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
     L.h2e_submit_digest.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
+    L.h2e_unit_records.argtypes = [vp, vp, u32, vp, vp, vp, vp, u32, vp]
+    L.h2e_unit_record_words.argtypes = [vp]
     L.h2e_check.argtypes = [vp, vp, u32, vp, vp, vp, vp, u32, vp, vp]
     L.h2e_ctx_set_option.argtypes = [vp, i32, C.c_int64]
     L.h2e_ctx_get_stat.argtypes = [vp, i32]
@@ -277,6 +280,12 @@ class Program:
         n = lib().h2e_program_launches(self._h, buf, cap)
         keys = ("n_strands", "n_ops", "cells", "dbase", "drange", "dselect", "n_params", "base0")
         return [dict(zip(keys, [int(buf[8 * i + j]) for j in range(8)])) for i in range(n)]
+
+    def launch_rows(self, launch):
+        """first (base, range, select) row the k-th launch writes"""
+        buf = (C.c_uint64 * 3)()
+        _check(lib().h2e_program_launch_rows(self._h, launch, buf))
+        return int(buf[0]), int(buf[1]), int(buf[2])
 
     def tape_opcodes(self, launch):
         """diagnostics: (opcodes of the launch's tape, op indices its sub-ranges start at + the op count) as numpy arrays"""
@@ -636,6 +645,20 @@ class Engine:
         if out is None:
             out = t.empty((n, 4), dtype=t.int64, device=batch.device)
         _check(lib().h2e_digest(self._h, program._h, n, region, batch.data_ptr(), out.data_ptr(), self._stream(stream).cuda_stream))
+        return out
+
+    def unit_records(self, program, base, status, digests=None, out=None, col0=0, stream=None):
+        """h2e_unit_records: the per-unit records {status, Offset, result point cells, digests} of a finished run, one kernel.
+        out: int64 [units][>= col0 + record words] (a row block of the job's table; `col0` leading columns are the caller's, e.g.
+        the global unit index of the gather) or None."""
+        t = self.torch
+        units = status.shape[0]
+        R = lib().h2e_unit_record_words(program._h)
+        if out is None:
+            out = t.zeros((units, col0 + R), dtype=t.int64, device=status.device)
+        assert out.dim() == 2 and out.shape[0] == units and out.shape[1] >= col0 + R and out.stride(1) == 1
+        _check(lib().h2e_unit_records(self._h, program._h, units, base.data_ptr(), status.data_ptr(),
+                                      None if digests is None else digests.data_ptr(), out.data_ptr() + 8 * col0, out.stride(0), self._stream(stream).cuda_stream))
         return out
 
     def check(self, program, d_inputs, base, rng, sel, classes=0, stream=None, out=None):

@@ -67,6 +67,15 @@ class GatherPlan:
         self.n_local = len(local_units)
 
 
+def job_table(plan, record_words_, device=None):
+    """The table a job's steps fill and its one collective sends as it is: int64 [plan.cap][1 + R], column 0 = the global unit
+    index of the row (-1: padding of a ragged share), the rest written per finished step by the engine's h2e_unit_records kernel
+    (Engine.unit_records(..., out=table[rows], col0=1)) - no indexing kernels on the host side of the boundary."""
+    t = torch.zeros((plan.cap, 1 + record_words_), dtype=torch.int64, device=device if device is not None else plan.idx.device)
+    t[:, 0] = plan.idx.to(t.device)
+    return t
+
+
 def gather_records(plan, local_records):
     """ONE all_gather of the job's per-unit records.  local_records: int64 [plan.n_local][R] on plan.idx's device.
     Returns (table int64 [n_units][R] with rows ordered by unit index, seen bool [n_units]) - both on the device and
@@ -76,6 +85,15 @@ def gather_records(plan, local_records):
     buf = torch.zeros((plan.cap, R + 1), dtype=torch.int64, device=dev)
     buf[:, 0] = plan.idx
     buf[:plan.n_local, 1:] = local_records
+    return gather_table(plan, buf)
+
+
+def gather_table(plan, buf):
+    """The collective itself: `buf` = a job_table (index column + records, on plan.idx's device) -> all_gather -> rows ordered
+    by unit index.  A host in another language issues the same ONE ncclAllGather on the same table."""
+    R = buf.shape[1] - 1
+    dev = plan.idx.device
+    assert buf.shape[0] == plan.cap and buf.device == dev
     if plan.world > 1:
         lst = [torch.empty_like(buf) for _ in range(plan.world)]
         dist.all_gather(lst, buf)

@@ -139,6 +139,8 @@ int h2e_program_outputs(const h2e_program* p, uint32_t* refs, uint32_t cap);
 /* One entry of 8 words per engine launch of a run: n_strands, n_ops, advice cells written per instance
  * (0 unless emit_shape), per-strand Offset (base, range, select), n_params, first base row.  Returns the count. */
 int h2e_program_launches(const h2e_program* p, uint64_t* out, uint32_t cap);
+/* first row of the base / range / select array the k-th launch writes (a forked segment: of its strand 0): out[3] */
+int h2e_program_launch_rows(const h2e_program* p, uint32_t launch, uint64_t* out);
 /* diagnostics: opcodes (tape.h H2EOpcode) of the k-th launch's tape and the op indices its expansion's sub-ranges start at */
 int h2e_program_tape_opcodes(const h2e_program* p, uint32_t launch, uint16_t* opcodes, uint32_t cap, uint32_t* subs, uint32_t subs_cap,
                              uint32_t* n_subs);
@@ -376,6 +378,21 @@ int h2e_op_pairing(h2e_records* rec, uint32_t n_pairs, const h2e_point* g1, cons
  * z = (z ^ z >> 27) * 0x94D049BB133111EB; z ^ z >> 31), w_0..w_3 the cell's canonical words.  Programs recorded
  * without their shape digest every cell of the array.  Asynchronous on `stream`. */
 int h2e_digest(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, const void* d_batch, void* d_digests, void* stream);
+
+/* The per-unit record table of a job's ONE collective (units = MSM tiles / pairing instances, each its own
+ * `Context` in reference terms, src/context.rs:136-143).  One kernel on `stream` writes, for every instance u of a finished run,
+ * h2e_unit_record_words(p) 64-bit words to d_out + u * out_stride_words:
+ *   [0]      the unit's status word (as int32, sign-extended)
+ *   [1..3]   the program's Offset: base / range / select rows consumed (src/circuit/ecc_chip.rs:36-62)
+ *   [4..]    the result point as its cells' values: x limbs, then y limbs (2 words each - a limb is < 2^128), then z (1 word);
+ *            zero for programs without a result point (the pairing checks).  3-limb curves: 13 words, bls12_381: 17
+ *   [last 12] d_digests[region][instance][4] (what h2e_run_digest / h2e_submit_digest left), zero if d_digests is NULL
+ * = 29 words (bn256 workloads) or 33 (bls12_381 tiles).  out_stride_words >= the record size lets the caller keep columns of
+ * its own in the same table (e.g. a leading global unit index, so that the table is what it hands to ncclAllGather as it is:
+ * INTEGRATION.md "The gather").  Reads d_base (batch-interleaved base array of the run) and d_status only. */
+int h2e_unit_record_words(const h2e_program* p);
+int h2e_unit_records(h2e_ctx* ctx, const h2e_program* p, uint32_t n_instances, const void* d_base, const void* d_status,
+                     const void* d_digests /* or NULL */, void* d_out, uint32_t out_stride_words, void* stream);
 
 /* The same consumer at no extra pass: the STREAM DIGEST.  h2e_run_digest / h2e_submit_digest are h2e_run / h2e_submit whose
  * expansion (and inverse fix-up) kernels add every cell they store to a position-keyed linear checksum while the value is

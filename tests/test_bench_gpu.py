@@ -27,7 +27,7 @@ def _check_contract(d, n_gpus, steps, warmup, scaling="weak"):
         assert key in d, key
     assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
     assert d["higher_is_better"] is True and d["scaling"] == scaling and d["vs_baseline"] is None
-    assert list(d)[-1] == "summary" and d["summary"]["columns"] == ["ms_per_step", "single_batch_ms", "whole_step_frac", "roofline_frac"]
+    assert list(d)[-1] == "summary" and d["summary"]["columns"] == ["ms_per_step", "single_batch_ms", "whole_step_frac", "roofline_frac", "expansion_frac"]
     assert "workload" in d["config"] and d["value"] > 0 and d["ms_per_step"] > 0
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -107,3 +107,17 @@ def test_bench_two_ranks_pairing_strong_shares_gloo(workload, total):
     _check_contract(d, 2, 2, 1, scaling="strong")
     assert d["gathered_records"]["shape"] == [2 * total, 29] and d["gathered_records"]["status_or"] == 0
     assert d["config"]["units_per_step_all_gpus"] == total and len(d["per_rank_ms_per_step"]) == 2
+
+
+def test_bench_traffic_counters_by_launch_index():
+    """`roofline.traffic`: two rocprofv3 --pmc child passes of the command, the dominant launch's dispatches picked by launch
+    index (not by grid size), KiB -> bytes.  What the window strands' expansion WRITES can be neither less than the cells it
+    stores nor much more (it stores assigned cells only, in whole 128-byte lines)."""
+    d = _bench("--units", "4", "--points", "96", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--latency-steps", "0")
+    r = d["roofline"]
+    if r["traffic"] is None:
+        pytest.skip("rocprofv3 counters not available on this box: " + str(r.get("traffic_note")))
+    td = r["traffic_detail"]
+    alg = r["algorithmic_bytes_per_launch"]
+    assert 0.999 * alg <= td["written_bytes_per_launch"] <= 1.10 * alg, (td, alg)
+    assert r["traffic"] >= td["written_bytes_per_launch"]

@@ -206,6 +206,59 @@ def test_msm_value_chain_does_not_depend_on_expansion(engine, oracle):
     assert not np.array_equal(got[:last0], ovals[:last0]), "the hook left nothing out"
 
 
+@pytest.mark.parametrize("splits", [None, "2"], ids=["two_launches", "four_launches"])
+@pytest.mark.parametrize("curve", ["bn256", "bls12_381"])
+def test_pairing_value_chain_does_not_depend_on_expansion(engine, oracle, curve, splits):
+    """A pairing check runs as several launches (Miller loop | final exponentiation; H2E_PAIRING_SPLITS=2: also after each
+    exponentiation by x).  A later launch's field chain loads hint slots an earlier chain exported (H2E_F_FROM_HINTS) and its hint
+    store reads the earlier launches' integers from their CELLS (H2E_SX_CELLS) - while the earlier launch's expansion runs on
+    another stream.  So every such cell must have been stored by a value chain (the compiler's cross-segment escape analysis):
+    with the expansion of every launch but the last left out (test hook), the last launch's rows must still equal the oracle's.
+    A missed escape would otherwise be a race the parity tests pass by luck."""
+    import os
+    from halo2ecc_s_amd import engine as E
+    make_inputs = synth.pairing_check_bn256_inputs if curve == "bn256" else synth.pairing_check_bls12_381_inputs
+    ins = [make_inputs(instance=70 + k) for k in range(2)]
+    old = os.environ.get("H2E_PAIRING_SPLITS")
+    if splits is not None:
+        os.environ["H2E_PAIRING_SPLITS"] = splits
+    try:
+        prog = Program.pairing_check_bn256(emit_shape=False) if curve == "bn256" else Program.pairing_check_bls12_381(emit_shape=False)
+    finally:
+        if splits is not None:
+            if old is None:
+                del os.environ["H2E_PAIRING_SPLITS"]
+            else:
+                os.environ["H2E_PAIRING_SPLITS"] = old
+    launches = prog.launches()
+    assert len(launches) == (2 if splits is None else 4), launches
+    engine.set_option(E.OPT_TEST_SKIP_EXPANSION, -1)
+    try:
+        # poisoned arrays: a cell the last launch's chains read without anybody having stored it reads 0xFF.., not a lucky zero
+        d_in = engine.upload_inputs(prog, np.stack(ins))
+        arrs = engine.alloc(prog, len(ins), fill=0xFF)
+        engine.run(prog, d_in, *arrs)
+        engine.torch.cuda.synchronize()
+    finally:
+        engine.set_option(E.OPT_TEST_SKIP_EXPANSION, E.OPT_OFF)
+    assert (arrs[3].cpu().numpy() == E.ST_TEST_HOOK).all(), arrs[3].cpu().numpy()
+    base0, range0, _ = prog.launch_rows(len(launches) - 1)
+    assert base0 == launches[-1]["base0"] and base0 > 0 and range0 > 0
+    k = 1
+    orun = (oracle_lib.run_pairing_check_bn256 if curve == "bn256" else oracle_lib.run_pairing_check_bls12_381)(ins[k])
+    assert orun.info.status == 0, orun.error
+    # batch-interleaved arrays [row][col][half][inst][2] -> this instance's cells [row][col][4]
+    for region, first in ((0, base0), (1, range0)):
+        ovals, oflags = orun.adv(region, (prog.base_rows, prog.range_rows)[region])
+        got = arrs[region][:, :, :, k, :].contiguous().cpu().numpy().view(np.uint64)
+        got = got.reshape(got.shape[0], got.shape[1], 4)
+        assigned = (oflags[first:] & 1).astype(bool)
+        assert np.array_equal(got[first:][assigned], ovals[first:][assigned]), f"{curve}: the last launch's rows differ in region {region} when the expansions before it are left out"
+        before = (oflags[:first] & 1).astype(bool)
+        assert not np.array_equal(got[:first][before], ovals[:first][before]), "the hook left nothing out"
+    prog.close()
+
+
 @pytest.mark.parametrize("pct", [10, 45, 90])
 def test_msm_split_expansion(engine, oracle, pct):
     """A big expansion goes out as two launches over a prefix / the rest of its sub-ranges, with the inverse fix-up of
@@ -756,11 +809,64 @@ def test_msm_batch_64_tiles_full_size(engine, oracle):
     assert orun.info.status == 0, orun.error
     for region in range(3):
         rows = arrs[region].shape[0]
-        got = arrs[region][:, :, :, k, :].cpu().numpy().view(np.uint64).reshape(rows, arrs[region].shape[1], 4)
+        got = arrs[region][:, :, :, k, :].contiguous().cpu().numpy().view(np.uint64).reshape(rows, arrs[region].shape[1], 4)
         ovals, _ = orun.adv(region, rows)
         assert np.array_equal(got, ovals), f"region {region} differs"
     del arrs
     t.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("workload", ["msm", "msm_bls12_381", "pairing_bn256"])
+def test_unit_records_kernel_matches_reference_indexing(engine, oracle, workload):
+    """h2e_unit_records (one kernel behind the C ABI: the per-unit records of a job's one collective) against
+    halo2ecc_s_amd.parallel.unit_records, the torch indexing chain the CPU gloo tests run - and against the oracle's result
+    point and Offset.  3-limb and 4-limb result points, a workload without a result point, with and without digests, into a
+    row block of a wider table (leading index column untouched)."""
+    from halo2ecc_s_amd import parallel
+    t = engine.torch
+    if workload == "msm":
+        n = 7
+        prog = Program.msm_bn256_tile(n)
+        ins = [synth.msm_bn256_tile_inputs(n, tile=300 + k)[0] for k in range(5)]
+        orun = oracle_lib.run_msm_bn256_tile(n, ins[3])
+    elif workload == "msm_bls12_381":
+        n = 2
+        prog = Program.msm_bls12_381_tile(n)
+        ins = [synth.msm_bls12_381_tile_inputs(n, tile=310 + k)[0] for k in range(3)]
+        orun = oracle_lib.run_msm_bls12_381_tile(n, ins[2])
+    else:
+        prog = Program.pairing_check_bn256()
+        ins = [synth.pairing_check_bn256_inputs(instance=320 + k) for k in range(3)]
+        orun = None
+    units = len(ins)
+    d_in = engine.upload_inputs(prog, np.stack(ins))
+    arrs = engine.alloc(prog, units)
+    dg = engine.run_digest(prog, d_in, *arrs)
+    t.cuda.synchronize()
+    refs = prog.outputs() if workload != "pairing_bn256" else []
+    L = (len(refs) - 3) // 2 if refs else 3
+    R = parallel.record_words(L)
+    offsets = t.tensor([prog.base_offset, prog.range_offset, prog.select_offset], dtype=t.int64, device=arrs[0].device)
+    want = parallel.unit_records(arrs[3], offsets, arrs[0], refs, dg, limbs=L)
+    got = engine.unit_records(prog, arrs[0], arrs[3], dg)
+    assert got.shape == (units, R) and t.equal(got, want)
+    want0 = parallel.unit_records(arrs[3], offsets, arrs[0], refs, None, limbs=L)
+    table = t.full((units + 2, R + 3), -7, dtype=t.int64, device=arrs[0].device)
+    engine.unit_records(prog, arrs[0], arrs[3], None, out=table[1:1 + units], col0=1)
+    assert t.equal(table[1:1 + units, 1:1 + R], want0)
+    assert int((table[:, 0] != -7).sum()) == 0 and int((table[0] != -7).sum()) == 0 and int((table[-1] != -7).sum()) == 0 and int((table[:, 1 + R:] != -7).sum()) == 0
+    if orun is not None:   # the record's Offset and result point are the oracle's
+        k = 3 if workload == "msm" else 2
+        assert orun.info.status == 0, orun.error
+        rec = [int(x) & (2**64 - 1) for x in got[k].cpu().tolist()]
+        assert rec[0] == 0 and rec[1:4] == [orun.info.base_offset, orun.info.range_offset, orun.info.select_offset]
+        ovals, _ = orun.adv(0, prog.base_rows)
+        for i, ref in enumerate(list(refs[0:L]) + list(refs[L + 1:2 * L + 1])):
+            assert rec[4 + 2 * i:6 + 2 * i] == [int(x) for x in ovals[ref & 0x3FFFFFF, (ref >> 27) & 7, 0:2]]
+        z = refs[2 * L + 2]
+        assert rec[4 + 4 * L] == int(ovals[z & 0x3FFFFFF, (z >> 27) & 7, 0])
+        orun.close()
+    prog.close()
 
 
 import golden_util  # noqa: E402
