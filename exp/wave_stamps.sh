@@ -1,8 +1,14 @@
 #!/bin/bash
-# diagnostic build: the bn256 engine unit with s_memtime stamps in h2e_replay_wave (cycles per round kind), as exp/_dbg/libh2e_stamps.so
+# diagnostic build: the bn256 (default) or bls12_381 (FPK=1) engine unit with s_memtime stamps in the pairings' value-chain kernels
+# (cycles per round kind, per stage of a linear combination, per computing wave, per record-count bucket) -> exp/_dbg/libh2e_stamps.so
 set -e
 cd "$(dirname "$0")/.."
+mkdir -p exp/_dbg
 D="${H2E_STAMP_DEFS:-}"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DH2E_FP_ONLY=0 -DH2E_WAVE_STAMPS $D -c halo2ecc_s_amd/csrc/engine.hip -o exp/_dbg/engine_fp0_stamps.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o exp/_dbg/libh2e_stamps.so exp/_dbg/engine_fp0_stamps.o halo2ecc_s_amd/csrc/engine_fp1.o halo2ecc_s_amd/csrc/engine_fp2.o halo2ecc_s_amd/csrc/h2e_capi.o
+K="${FPK:-0}"
+C=halo2ecc_s_amd/csrc
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DH2E_FP_ONLY=$K -DH2E_WAVE_STAMPS $D -c $C/engine.hip -o exp/_dbg/engine_fp${K}_stamps.o
+OBJS=""
+for k in 0 1 2; do if [ $k = $K ]; then OBJS="$OBJS exp/_dbg/engine_fp${K}_stamps.o"; else OBJS="$OBJS $C/engine_fp$k.o"; fi; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o exp/_dbg/libh2e_stamps.so $OBJS $C/h2e_capi.o $C/checker.o $C/handoff.o
 ls -la exp/_dbg/libh2e_stamps.so

@@ -72,7 +72,7 @@ __constant__ H2EFieldConsts g_fc[3];
 #ifdef H2E_WAVE_STAMPS
 // diagnostic build only (exp/wave_stamps.sh): cycles and rounds per round kind of workgroup 0, read back by
 // h2e_engine_wave_stamps ([0..7] cycles, [8..15] rounds of h2e_replay_wave / h2e_field_chain, [16..19] light-round detail)
-__device__ unsigned long long g_wave_stamps[32];
+__device__ unsigned long long g_wave_stamps[128];   // [32 + 4 w ..]: per computing wave of the digit chain, [96 ..]: rounds by record count
 extern "C" int H2E_UNIT(h2e_engine_wave_stamps)(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_stamps), sizeof(g_wave_stamps));
 }
@@ -3225,6 +3225,8 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
 #ifdef H2E_WAVE_STAMPS
     unsigned long long fst_cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fst_n[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fst_part[4] = {0, 0, 0, 0};
     unsigned long long dps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dpt = 0, dpn = 0;
+    unsigned long long pw[4] = {0, 0, 0, 0};          // this wave: cycles in its records, rounds it had records in, cycles at the barrier, cycles in the header part
+    unsigned long long bk_cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bk_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // whole rounds by record count: <= 4, 8, 16, 24, 32, 40, 48, more
     // stage stamps of a linear combination (wave 0; `v` = the value the stage ends with, so that the stamp stays behind it)
 #define DP_STAMP(i, v)                                        \
     do {                                                      \
@@ -3451,6 +3453,17 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
             fst_part[1] += ft2 - ft1;
             fst_part[2] += ft3 - ft2;
         } else if (kind == 2) fst_part[3] += ft3 - ft2;
+        if (!LOADS) {
+            if (wave * 4u < cnt) {
+                pw[0] += ft2 - ft1;
+                pw[1]++;
+            }
+            pw[2] += ft3 - ft2;
+            pw[3] += ft1 - ft0;
+            int b = cnt <= 4 ? 0 : cnt <= 8 ? 1 : cnt <= 16 ? 2 : cnt <= 24 ? 3 : cnt <= 32 ? 4 : cnt <= 40 ? 5 : cnt <= 48 ? 6 : 7;
+            bk_cyc[b] += ft3 - ft0;
+            bk_n[b]++;
+        }
 #endif
     };
     for (u32 round = 0; round < K.f_n_load_rounds; round++) run_round(std::true_type());
@@ -3464,7 +3477,13 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
         for (int k = 0; k < 4; k++) g_wave_stamps[16 + k] = fst_part[k];
         for (int k = 1; k < 7; k++) g_wave_stamps[20 + k] = dps[k];
         g_wave_stamps[20] = dpn;
+        for (int k = 0; k < 8; k++) {
+            g_wave_stamps[96 + k] = bk_cyc[k];
+            g_wave_stamps[104 + k] = bk_n[k];
+        }
     }
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 4; k++) g_wave_stamps[32 + 4 * wave + k] = pw[k];
 #endif
 }
 // TEST HOOK: the digit-row primitives on caller-supplied rows, one 16-lane row per case (tests/test_digit_rows_gpu.py feeds
