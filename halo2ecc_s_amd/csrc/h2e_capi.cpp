@@ -82,14 +82,30 @@ static uint32_t dbg_skip_mask() {
     static const uint32_t m = getenv("H2E_DEBUG_SKIP") ? (uint32_t)atoi(getenv("H2E_DEBUG_SKIP")) : 0u;
     return m;
 }
+// H2E_DEBUG_LOG=<file>: one line per engine call of run_impl - run number, segment, what, stream - so that a rocprofv3 kernel trace can
+// be labelled by run and segment (exp/trace_labelled.py matches them in per-stream order)
+static unsigned long long g_dbg_run = 0;
+static int g_dbg_si = -1;
+static FILE* dbg_log_file() {
+    static FILE* f = getenv("H2E_DEBUG_LOG") ? fopen(getenv("H2E_DEBUG_LOG"), "a") : nullptr;
+    return f;
+}
+static void dbg_log(const char* what, int a, unsigned b, unsigned c, unsigned d, hipStream_t st) {
+    if (FILE* f = dbg_log_file()) {
+        fprintf(f, "run %llu seg %d %s %d n_ops/kind %u strands/lanes %u n_sub %u stream %p\n", g_dbg_run, g_dbg_si, what, a, b, c, d, (void*)st);
+        fflush(f);
+    }
+}
 static int dbg_engine_launch(int fpair, int mode, const H2ELaunch* l, const void* inst, uint32_t n, const H2EFieldConsts* fc, hipStream_t st) {
     uint32_t m = dbg_skip_mask();
+    dbg_log("launch mode", mode, l->n_ops, l->n_strands, mode == 4 ? l->n_fixups : l->n_sub, st);
     if ((mode == 4 && (m & 1u)) || (mode == 1 && (m & 32u)) || (mode == 2 && l->n_sub > 1 && (m & 64u))) return 0;
     return h2e_engine_launch(fpair, mode, l, inst, n, fc, st);
 }
 static int dbg_engine_predict(int fpair, int phase, const H2EPreKernel* k, const uint32_t* a, const uint32_t* prm, const uint32_t* aux,
                               const void* inst, uint32_t n, const H2EFieldConsts* fc, hipStream_t st) {
     uint32_t m = dbg_skip_mask();
+    dbg_log("predict phase", phase, k->kind, k->n_lanes, 0, st);
     if (m & 2u) phase &= ~2;
     if ((k->kind == H2E_PRE_MSM_TAIL && (m & 4u)) || (k->kind == H2E_PRE_MSM_WINDOWS && (m & 8u)) || (k->kind == H2E_PRE_MSM_SELECT && (m & 16u)))
         phase &= ~1;
@@ -2929,6 +2945,13 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     }
     const hipStream_t sa_main = join ? stream : J.chain_stream;
     hipStream_t sa = sa_main, sb = ctx->expand_stream, sc = J.side_stream, sd = ctx->fixup_stream;
+#ifdef H2E_DEBUG_HOOKS
+    if (FILE* f = dbg_log_file()) {
+        fprintf(f, "run %llu begin slot %d join %d streams chain %p expand %p side %p fixup %p small %p\n", (unsigned long long)ctx->n_runs + 1, slot_index, join ? 1 : 0,
+                (void*)sa, (void*)sb, (void*)sc, (void*)sd, (void*)ctx->small_stream);
+        fflush(f);
+    }
+#endif
     ctx->n_runs++;
     ctx->last_slot = slot_index;
     if (slot_out) *slot_out = slot_index;
@@ -3110,6 +3133,10 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     for (size_t si = 0; si < r.segments.size(); si++) {
         const h2e::Segment& s = r.segments[si];
         if (s.tape_end <= s.tape_begin) continue;
+#ifdef H2E_DEBUG_HOOKS
+        g_dbg_run = ctx->n_runs;
+        g_dbg_si = (int)si;
+#endif
         if ((int64_t)si == p->tail_from && sa == sa_main) {
             // the serial tail of the program: from here on the value chain continues on the slot's side stream, and the
             // caller's stream is free for the next run's value chain
