@@ -237,6 +237,204 @@ struct FieldCompiler {
         return r;
     }
 
+    // The depth a combination of terms with these depths (sorted, deepest first) can be had at: a record of its own if they
+    // fit, otherwise partial sums over the earliest terms until F_MAX_TERMS entries are left.
+    uint32_t tree_depth(std::vector<uint32_t> d) const {
+        const size_t K = (size_t)F_MAX_TERMS;
+        if (d.empty()) return 1;
+        while (d.size() > K) {   // (d ascending here: the earliest terms at the front)
+            size_t m = std::min(K, d.size() - (K - 1));
+            uint32_t pd = d[m - 1] + 1;
+            d.erase(d.begin(), d.begin() + (long)m);
+            d.insert(std::upper_bound(d.begin(), d.end(), pd), pd);
+        }
+        return d.back() + 1;
+    }
+    void rebalance(bool sinks_enabled) {
+        const size_t N0 = nodes.size();
+        const size_t K = (size_t)F_MAX_TERMS;
+        std::vector<uint32_t> depth(N0, 0);
+        depth.reserve(N0 * 2);
+        std::map<std::vector<std::pair<int, int>>, int> partial_of;   // terms (sorted by node) -> the partial-sum node that holds them
+        auto dep_depth = [&](const Node& nd) {
+            uint32_t dd = 0;
+            auto see = [&](int x) { if (x >= 0) dd = std::max(dd, depth[(size_t)x]); };
+            see(nd.a);
+            see(nd.b);
+            see(nd.c);
+            for (auto& t : nd.terms) see(t.first);
+            return dd;
+        };
+        auto depths_of = [&](const std::map<int, long long>& E) {
+            std::vector<uint32_t> d;
+            d.reserve(E.size());
+            for (auto& kv : E) d.push_back(depth[(size_t)kv.first]);
+            std::sort(d.begin(), d.end());
+            return d;
+        };
+        for (size_t k = 0; k < N0; k++) {
+            if (nodes[k].opc != F_LIN) {
+                depth[k] = dep_depth(nodes[k]) + 1;
+                continue;
+            }
+            std::map<int, long long> E;
+            for (auto& t : nodes[k].terms) E[t.first] += t.second;
+            // expand the whole deepest level at a time (two operands of a sum are usually equally deep: opening one of them alone
+            // gains nothing), keep the best expression seen, give up after a few levels that did not help
+            uint32_t best = tree_depth(depths_of(E));
+            {
+                std::map<int, long long> cur = E;
+                int stale = 0;
+                for (int iter = 0; iter < 64 && stale < 3; iter++) {
+                    uint32_t dm = 0;
+                    for (auto& kv : cur) dm = std::max(dm, depth[(size_t)kv.first]);
+                    bool open = !cur.empty();
+                    for (auto& kv : cur)
+                        if (depth[(size_t)kv.first] == dm && (nodes[(size_t)kv.first].opc != F_LIN || nodes[(size_t)kv.first].terms.empty())) open = false;
+                    if (!open) break;   // a product (or an input) is what makes this level deep
+                    std::map<int, long long> nxt;
+                    bool ok = true;
+                    for (auto& kv : cur) {
+                        if (depth[(size_t)kv.first] != dm) {
+                            nxt[kv.first] += kv.second;
+                            continue;
+                        }
+                        for (auto& u : nodes[(size_t)kv.first].terms) nxt[u.first] += kv.second * u.second;
+                    }
+                    for (auto it = nxt.begin(); it != nxt.end();) {
+                        if (std::llabs(it->second) > F_MAX_COEF) ok = false;
+                        it = it->second == 0 ? nxt.erase(it) : std::next(it);
+                    }
+                    if (!ok || nxt.size() > 4 * K * K) break;
+                    cur = std::move(nxt);
+                    uint32_t d2 = tree_depth(depths_of(cur));
+                    if (d2 < best || (d2 == best && cur.size() <= K && cur.size() <= E.size())) {
+                        E = cur;
+                        best = d2;
+                        stale = 0;
+                    } else {
+                        stale++;
+                    }
+                }
+            }
+            // the tree: partial sums over the earliest terms
+            std::vector<std::pair<uint32_t, std::pair<int, int>>> T;   // (depth, (node, coef)), ascending by depth
+            for (auto& kv : E)
+                if (kv.second != 0) T.push_back({depth[(size_t)kv.first], {kv.first, (int)kv.second}});
+            std::stable_sort(T.begin(), T.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+            while (T.size() > K) {
+                size_t m = std::min(K, T.size() - (K - 1));
+                std::vector<std::pair<int, int>> g;
+                uint32_t gd = 0;
+                for (size_t q = 0; q < m; q++) {
+                    g.push_back(T[q].second);
+                    gd = std::max(gd, T[q].first);
+                }
+                std::sort(g.begin(), g.end());
+                int pn;
+                auto it = partial_of.find(g);
+                if (it != partial_of.end()) {
+                    pn = it->second;
+                } else {
+                    pn = new_node(F_LIN);
+                    nodes[(size_t)pn].terms = g;
+                    depth.push_back(gd + 1);
+                    partial_of[g] = pn;
+                }
+                T.erase(T.begin(), T.begin() + (long)m);
+                std::pair<uint32_t, std::pair<int, int>> e{depth[(size_t)pn], {pn, 1}};
+                T.insert(std::upper_bound(T.begin(), T.end(), e, [](const auto& x, const auto& y) { return x.first < y.first; }), e);
+            }
+            std::vector<std::pair<int, int>> r;
+            for (auto& e : T) r.push_back(e.second);
+            std::sort(r.begin(), r.end());
+            nodes[k].terms = r;
+            depth[k] = dep_depth(nodes[k]) + 1;
+        }
+        // hinted combinations nobody reads: over the non-combination nodes themselves (any number of terms: a sink)
+        if (sinks_enabled) {
+            std::vector<uint8_t> read(nodes.size(), 0);
+            for (auto& nd : nodes) {
+                if (nd.a >= 0) read[(size_t)nd.a] = 1;
+                if (nd.b >= 0) read[(size_t)nd.b] = 1;
+                if (nd.c >= 0) read[(size_t)nd.c] = 1;
+                for (auto& t : nd.terms) read[(size_t)t.first] = 1;
+            }
+            for (size_t k = 0; k < N0; k++) {
+                Node& nd = nodes[k];
+                if (nd.opc != F_LIN || nd.hint == 0xffffffffu || read[k]) continue;
+                std::map<int, long long> E;
+                for (auto& t : nd.terms) E[t.first] += t.second;
+                bool ok = true;
+                for (int iter = 0; iter < 4096 && ok; iter++) {
+                    int lin = -1;
+                    for (auto& kv : E)
+                        if (kv.second != 0 && nodes[(size_t)kv.first].opc == F_LIN && nodes[(size_t)kv.first].hint == 0xffffffffu) lin = kv.first;
+                    if (lin < 0) break;   // (a hinted combination stays a term: its slot holds the value anyway)
+                    const long long c = E[lin];
+                    E.erase(lin);
+                    for (auto& u : nodes[(size_t)lin].terms) E[u.first] += c * u.second;
+                    if (E.size() > 255) ok = false;
+                }
+                std::vector<std::pair<int, int>> r;
+                for (auto& kv : E) {
+                    if (kv.second == 0) continue;
+                    if (std::llabs(kv.second) > F_MAX_COEF) ok = false;
+                    r.push_back({kv.first, (int)kv.second});
+                }
+                if (ok && r.size() <= 255) nd.terms = r;
+            }
+        }
+        // back into topological order by index (partial sums were appended behind their readers)
+        {
+            const size_t N = nodes.size();
+            std::vector<int> order, new_of(N, -1);
+            std::vector<uint8_t> state(N, 0);
+            std::vector<std::pair<uint32_t, uint32_t>> st;   // (node, next dependency to visit)
+            std::vector<std::vector<int>> deps(N);
+            for (size_t k = 0; k < N; k++) {
+                const Node& nd = nodes[k];
+                if (nd.a >= 0) deps[k].push_back(nd.a);
+                if (nd.b >= 0) deps[k].push_back(nd.b);
+                if (nd.c >= 0) deps[k].push_back(nd.c);
+                for (auto& t : nd.terms) deps[k].push_back(t.first);
+            }
+            for (size_t root = 0; root < N; root++) {
+                if (state[root]) continue;
+                st.push_back({(uint32_t)root, 0});
+                state[root] = 1;
+                while (!st.empty()) {
+                    auto& top = st.back();
+                    if (top.second < deps[top.first].size()) {
+                        int x = deps[top.first][top.second++];
+                        if (!state[(size_t)x]) {
+                            state[(size_t)x] = 1;
+                            st.push_back({(uint32_t)x, 0});
+                        } else if (state[(size_t)x] == 1) {
+                            throw std::runtime_error("field chain: cycle after rebalancing");
+                        }
+                    } else {
+                        state[top.first] = 2;
+                        new_of[top.first] = (int)order.size();
+                        order.push_back((int)top.first);
+                        st.pop_back();
+                    }
+                }
+            }
+            std::vector<Node> sorted(N);
+            for (size_t q = 0; q < N; q++) {
+                Node nd = nodes[(size_t)order[q]];
+                if (nd.a >= 0) nd.a = new_of[(size_t)nd.a];
+                if (nd.b >= 0) nd.b = new_of[(size_t)nd.b];
+                if (nd.c >= 0) nd.c = new_of[(size_t)nd.c];
+                for (auto& t : nd.terms) t.first = new_of[(size_t)t.first];
+                std::sort(nd.terms.begin(), nd.terms.end());
+                sorted[q] = std::move(nd);
+            }
+            nodes = std::move(sorted);
+        }
+    }
+
     // Which ops of the segment carry a hint the replay / expansion will ask for, and can all of them be predicted?
     // `check_only`: feasibility (before the compiler's dead-op pass), nothing is built.
     bool compile(FieldChain& out, bool check_only) {
@@ -492,6 +690,17 @@ struct FieldCompiler {
                 depth[k] = dd + 1;
             }
         }
+        // ---- depth-balanced combinations (round 5) -------------------------------------------------------------------------
+        // combine() builds a sum the way the program adds it up: c = c + x, and every time the expression outgrows a record the
+        // larger side is materialised - a 54-term coefficient of an Fq12 product becomes a CHAIN L14 -> L13 -> L13 -> L12, four
+        // rounds deep, and the pass above cannot merge it (nothing fits).  The deepest path of a bn256 check's Miller loop was
+        // 248 products and 774 combinations.  Here every combination is re-associated for depth: starting from its terms, the
+        // deepest term is replaced by its own terms for as long as that lowers the depth the combination can be had at; what is
+        // left is summed as a tree - the EARLIEST terms first, fourteen at a time, into partial sums that sit off the path (the
+        // k-ary Huffman rule for the minimal maximum depth) - so the latest product is read by the final record directly.
+        // Identical partial sums are shared.  A hinted combination nobody reads any more (the reduce of a value that is only
+        // combined further: consumers flatten through it) is written over the products themselves and leaves the chain as a sink.
+        if (digit_rows && !getenv("H2E_FIELD_NO_REBALANCE")) rebalance(next_hint != nullptr && !getenv("H2E_FIELD_NO_SINKS"));
         // ---- products take over their operands' combinations (H2E_FIELD_FUSE=1: off by default) ---------------------------
         // mul -> (add, sub, ...) -> mul is the shape of the whole pairing.  A product whose operand is a linear combination can
         // compute that combination itself, in its own row, right before the multiplication: one round instead of two on every
