@@ -7,10 +7,10 @@ import sys
 
 trace, log, n_show = sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 3
 rows = [r for r in csv.DictReader(open(trace)) if "h2e_" in r["Kernel_Name"]]
-rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-PRE = {0: ("candidates", ["h2e_predict<"], ["h2e_finalize_hints"]), 1: ("windows", ["h2e_predict_windows"], ["h2e_finalize_ecc"]),
-       2: ("tail", ["h2e_predict_tail"], ["h2e_finalize_ecc"]), 3: ("select", ["h2e_select"], []),
-       4: ("field_chain", ["h2e_field_chain"], ["h2e_field_finalize", "h2e_field_sinks"])}
+rows.sort(key=lambda r: int(r["Correlation_Id"]))   # the host's API call order (Dispatch_Id is the order on the device)
+PRE = {1: ("candidates", ["h2e_predict<"], ["h2e_finalize_hints"]), 2: ("windows", ["h2e_predict_windows"], ["h2e_finalize_ecc"]),
+       3: ("tail", ["h2e_predict_tail"], ["h2e_finalize_ecc"]), 4: ("select", ["h2e_select"], []),
+       5: ("field_chain", ["h2e_field_chain"], ["h2e_field_finalize", "h2e_field_sinks"])}
 entries = []
 streams = {}
 slot_of_run = {}

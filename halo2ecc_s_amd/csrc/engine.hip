@@ -3408,15 +3408,48 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                     u32 b = (w4 & 0xffffu) != 0xffffu ? ld_value(w4 & 0xffffu) : 0u;
                     out = c0 != 0u ? a : b;
                 }
-            } else {                   // division: a / b, 0 for b = 0 (integer_chip.rs:524-527): b^(w - 2) by square and multiply
-                u32 a = ld_value(w2), b = ld_value(w3);
-                u32 e = r1j;                                                  // 1 in Montgomery form
-                for (int bit = (int)FP::K - 1; bit >= 0; bit--) {             // (w - 2's digits sit in the lanes of every row: ej)
-                    e = R.mont_mul(e, e, minv32);
-                    u32 ew = (u32)__builtin_amdgcn_readlane((int)ej, bit >> 5);
-                    if ((ew >> ((u32)bit & 31u)) & 1u) e = R.mont_mul(e, b, minv32);
+            } else {                   // division: a / b, 0 for b = 0 (integer_chip.rs:524-527)
+                // One lane of the row inverts b R (the Montgomery form the chain holds, in [0, 2 w)) by division steps (modinv62.h:
+                // ~750 steps in batches of 62, the code every batched inversion of the engine uses) while the row waits: 10-20 us where
+                // b^(w - 2) by square and multiply in digit rows took 381 / 571 dependent products (100 / 230 us - the one round of a
+                // check's final exponentiation nothing else can run beside).  (b R)^-1 R^2 by two products with R^2, then a R times it.
+                u32 a = ld_value(w2);
+                u32 yd = 0;
+#ifdef H2E_EXP_FERMAT_DIV   // (A/B: the exponentiation)
+                {
+                    u32 b = ld_value(w3);
+                    u32 e = r1j;                                              // 1 in Montgomery form
+                    for (int bit = (int)FP::K - 1; bit >= 0; bit--) {         // (w - 2's digits sit in the lanes of every row: ej)
+                        e = R.mont_mul(e, e, minv32);
+                        u32 ew = (u32)__builtin_amdgcn_readlane((int)ej, bit >> 5);
+                        if ((ew >> ((u32)bit & 31u)) & 1u) e = R.mont_mul(e, b, minv32);
+                    }
+                    out = R.mont_mul(a, e, minv32);
                 }
-                out = R.mont_mul(a, e, minv32);
+#else
+                Wd<N> y = wd_zero<N>();
+                if (j == 0u) {
+                    Wd<N> bw, ww;
+#pragma unroll
+                    for (int i = 0; i < N; i++) {
+                        bw.v[i] = pack64(fv32[w3 * (u32)D + 2u * (u32)i], fv32[w3 * (u32)D + 2u * (u32)i + 1u]);
+                        ww.v[i] = fc->w[i];
+                    }
+                    if (wd_geq<N>(bw, ww)) bw = wd_sub<N>(bw, ww);          // [0, 2 w) -> [0, w)
+                    y = wd_inv_mod<N>(bw, ww);                               // 0 for 0
+                }
+                // lane 0's words to the row's digit lanes
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    u32 lo = dpp_mov<H2E_DPP_ROW_BCAST(0)>((u32)y.v[i]), hi = dpp_mov<H2E_DPP_ROW_BCAST(0)>((u32)(y.v[i] >> 32));
+                    if (j == 2u * (u32)i) yd = lo;
+                    if (j == 2u * (u32)i + 1u) yd = hi;
+                }
+                yd = R.mont_mul(yd, r2j, minv32);                             // (b R)^-1 R
+                yd = R.mont_mul(yd, r2j, minv32);                             // (b R)^-1 R^2
+                out = R.mont_mul(a, yd, minv32);                              // a R (b R)^-1 R^2 / R = (a / b) R
+#endif
+                (void)ej;
             }
             if (dst != 0xffffu && digit_lane) ((H2E_AS_LDS u32*)fv)[dst * (u32)D + j] = out;
             if (hint) {

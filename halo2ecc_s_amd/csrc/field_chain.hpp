@@ -700,7 +700,9 @@ struct FieldCompiler {
         // k-ary Huffman rule for the minimal maximum depth) - so the latest product is read by the final record directly.
         // Identical partial sums are shared.  A hinted combination nobody reads any more (the reduce of a value that is only
         // combined further: consumers flatten through it) is written over the products themselves and leaves the chain as a sink.
-        if (digit_rows && !getenv("H2E_FIELD_NO_REBALANCE")) rebalance(next_hint != nullptr && !getenv("H2E_FIELD_NO_SINKS"));
+        // (only with the sinks kernel: inside the chain a hint-only combination waits for a free row, and while it waits it keeps the
+        // products it now reads directly alive - 10 k value slots for a bn256 Miller loop, more than the LDS holds)
+        if (digit_rows && next_hint != nullptr && !getenv("H2E_FIELD_NO_SINKS") && !getenv("H2E_FIELD_NO_REBALANCE")) rebalance(true);
         // ---- products take over their operands' combinations (H2E_FIELD_FUSE=1: off by default) ---------------------------
         // mul -> (add, sub, ...) -> mul is the shape of the whole pairing.  A product whose operand is a linear combination can
         // compute that combination itself, in its own row, right before the multiplication: one round instead of two on every
@@ -822,7 +824,10 @@ struct FieldCompiler {
         // multiple of four rows; 54 rows (51 with fused products) leave room for the padding in a pass of 60.
         const bool mixed_rounds = digit_rows && !getenv("H2E_FIELD_PURE_ROUNDS");
         const bool fuse = mixed_rounds && getenv("H2E_FIELD_FUSE");   // (fused products are a fourth kind of row: three more padding rows)
-        const size_t STEP = digit_rows ? (mixed_rounds ? (fuse ? 51 : 54) : 60) : 64;
+        // H2E_FIELD_STEP=<rows>: more than one pass of 60 rows per round (the kernel loops; experiment): once the combinations are
+        // depth-balanced the rounds are bound by their row capacity (bn256 Miller loop: depth 696, 50.7 k records = 940 rounds of 54)
+        size_t STEP = digit_rows ? (mixed_rounds ? (fuse ? 51 : 54) : 60) : 64;
+        if (digit_rows && mixed_rounds && !fuse && getenv("H2E_FIELD_STEP")) STEP = std::max<size_t>(8, std::min<size_t>(234, (size_t)atoi(getenv("H2E_FIELD_STEP"))));
         auto cls_of = [&](uint32_t k) -> int {   // 0 light, 1 loads, 2 products, 3 divisions
             switch (nodes[k].opc) {
                 case F_MUL: return mixed_rounds ? 0 : 2;   // (digit rows: a product is a row like any other - see the round emission)
@@ -996,7 +1001,7 @@ struct FieldCompiler {
                             while (padded.size() % 4) padded.push_back(PAD);
                     }
                     while (!padded.empty() && padded.back() == PAD) padded.pop_back();
-                    if (padded.size() > 60) throw std::runtime_error("field chain: a padded round exceeds a pass of the kernel");
+                    if (padded.size() > (STEP <= 54 ? 60 : 250)) throw std::runtime_error("field chain: a padded round exceeds a pass of the kernel");
                     rd = padded;
                 }
                 for (uint32_t k : rd)
