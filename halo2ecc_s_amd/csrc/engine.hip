@@ -3180,6 +3180,35 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
             }
             u32 cnt, kind, nc;
             header(pos, cnt, kind, nc);
+#ifndef H2E_EXP_FERMAT_DIV
+            if (kind == 3u) {
+                // a division round: lane k inverts the divisor of the round's k-th record - (b R), in [0, 2 w) - and leaves the plain
+                // inverse in the record's destination slot (nothing reads that slot before the round's rows have written it)
+                const Rec* cb = rbuf + (size_t)((pos / H2E_WCHUNK) % H2E_DP_CHUNKS) * H2E_WCHUNK;
+                if (lane < cnt) {
+                    const H2E_AS_LDS u32* rp = (const H2E_AS_LDS u32*)(cb + (pos % H2E_WCHUNK + 1u + lane));
+                    const u32 dslot = rp[0] >> 16, bslot = rp[3];
+                    H2E_AS_LDS u32* v32 = (H2E_AS_LDS u32*)fv;
+                    Wd<N> bw, ww;
+#pragma unroll
+                    for (int i = 0; i < N; i++) {
+                        bw.v[i] = pack64(v32[bslot * (u32)D + 2u * (u32)i], v32[bslot * (u32)D + 2u * (u32)i + 1u]);
+                        ww.v[i] = fc->w[i];
+                    }
+                    if (wd_geq<N>(bw, ww)) bw = wd_sub<N>(bw, ww);          // [0, 2 w) -> [0, w)
+                    Wd<N> y = wd_inv_mod<N>(bw, ww);                         // 0 for 0
+                    if (dslot != 0xffffu) {
+#pragma unroll
+                        for (int i = 0; i < N; i++) {
+                            v32[dslot * (u32)D + 2u * (u32)i] = (u32)y.v[i];
+                            v32[dslot * (u32)D + 2u * (u32)i + 1u] = (u32)(y.v[i] >> 32);
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+#endif
             pos += 1 + cnt + nc;
             if (pos % H2E_WCHUNK != 0) {
                 u32 c2, k2, m2;
@@ -3272,6 +3301,9 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
         }
 #ifdef H2E_WAVE_STAMPS
         unsigned long long ft1 = WAVE_STAMP();
+#endif
+#ifndef H2E_EXP_FERMAT_DIV
+        if (!LOADS && kind == 3u) __builtin_amdgcn_s_barrier();   // a division round: the loader wave has left the inverses in the destination slots
 #endif
 #ifdef H2E_EXP_NO_OPS   // timing experiment: rounds without their records (header, prefetch, barrier only)
         if (false)
@@ -3409,12 +3441,13 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                     out = c0 != 0u ? a : b;
                 }
             } else {                   // division: a / b, 0 for b = 0 (integer_chip.rs:524-527)
-                // One lane of the row inverts b R (the Montgomery form the chain holds, in [0, 2 w)) by division steps (modinv62.h:
-                // ~750 steps in batches of 62, the code every batched inversion of the engine uses) while the row waits: 10-20 us where
-                // b^(w - 2) by square and multiply in digit rows took 381 / 571 dependent products (100 / 230 us - the one round of a
-                // check's final exponentiation nothing else can run beside).  (b R)^-1 R^2 by two products with R^2, then a R times it.
+                // (b R)^-1 comes from the LOADER wave (below: division steps, modinv62.h, one lane per division of the round, while the
+                // rows wait at the extra barrier of a division round) in the record's destination slot; (b R)^-1 R^2 by two products
+                // with R^2, then a R times it.  b^(w - 2) by square and multiply in digit rows took 381 / 571 dependent products
+                // (100 / 230 us: the one round of a check's final exponentiation nothing else can run beside); the inversion code in
+                // the rows' own path cost them registers and spills in every round (bls12_381 chain 2.6 -> 4.1 ms) - the loader's
+                // path is a different branch of the kernel.
                 u32 a = ld_value(w2);
-                u32 yd = 0;
 #ifdef H2E_EXP_FERMAT_DIV   // (A/B: the exponentiation)
                 {
                     u32 b = ld_value(w3);
@@ -3427,24 +3460,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                     out = R.mont_mul(a, e, minv32);
                 }
 #else
-                Wd<N> y = wd_zero<N>();
-                if (j == 0u) {
-                    Wd<N> bw, ww;
-#pragma unroll
-                    for (int i = 0; i < N; i++) {
-                        bw.v[i] = pack64(fv32[w3 * (u32)D + 2u * (u32)i], fv32[w3 * (u32)D + 2u * (u32)i + 1u]);
-                        ww.v[i] = fc->w[i];
-                    }
-                    if (wd_geq<N>(bw, ww)) bw = wd_sub<N>(bw, ww);          // [0, 2 w) -> [0, w)
-                    y = wd_inv_mod<N>(bw, ww);                               // 0 for 0
-                }
-                // lane 0's words to the row's digit lanes
-#pragma unroll
-                for (int i = 0; i < N; i++) {
-                    u32 lo = dpp_mov<H2E_DPP_ROW_BCAST(0)>((u32)y.v[i]), hi = dpp_mov<H2E_DPP_ROW_BCAST(0)>((u32)(y.v[i] >> 32));
-                    if (j == 2u * (u32)i) yd = lo;
-                    if (j == 2u * (u32)i + 1u) yd = hi;
-                }
+                u32 yd = ld_value(dst);                                       // (b R)^-1, plain digits
                 yd = R.mont_mul(yd, r2j, minv32);                             // (b R)^-1 R
                 yd = R.mont_mul(yd, r2j, minv32);                             // (b R)^-1 R^2
                 out = R.mont_mul(a, yd, minv32);                              // a R (b R)^-1 R^2 / R = (a / b) R

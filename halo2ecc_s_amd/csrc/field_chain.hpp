@@ -824,9 +824,11 @@ struct FieldCompiler {
         // multiple of four rows; 54 rows (51 with fused products) leave room for the padding in a pass of 60.
         const bool mixed_rounds = digit_rows && !getenv("H2E_FIELD_PURE_ROUNDS");
         const bool fuse = mixed_rounds && getenv("H2E_FIELD_FUSE");   // (fused products are a fourth kind of row: three more padding rows)
-        // H2E_FIELD_STEP=<rows>: more than one pass of 60 rows per round (the kernel loops; experiment): once the combinations are
-        // depth-balanced the rounds are bound by their row capacity (bn256 Miller loop: depth 696, 50.7 k records = 940 rounds of 54)
-        size_t STEP = digit_rows ? (mixed_rounds ? (fuse ? 51 : 54) : 60) : 64;
+        // Two passes of the kernel's 60 rows per round (108 + padding; H2E_FIELD_STEP=<rows>: A/B): once the combinations are
+        // depth-balanced the rounds are bound by their row capacity (bn256 Miller loop: depth 696, 50.7 k records = 940 rounds of 54,
+        // 1 148 scheduled; 696 of 108) and a round costs ~1 340 cycles whatever is in it + ~31 per record: measured (64 x bn256, one
+        // batch after the other) 54 rows: 4.04 ms, 80: 3.86, 108: 3.79, 160: 3.81
+        size_t STEP = digit_rows ? (mixed_rounds ? (fuse ? 51 : 108) : 60) : 64;
         if (digit_rows && mixed_rounds && !fuse && getenv("H2E_FIELD_STEP")) STEP = std::max<size_t>(8, std::min<size_t>(234, (size_t)atoi(getenv("H2E_FIELD_STEP"))));
         auto cls_of = [&](uint32_t k) -> int {   // 0 light, 1 loads, 2 products, 3 divisions
             switch (nodes[k].opc) {
@@ -946,7 +948,7 @@ struct FieldCompiler {
         for (size_t r = 0; r < rounds.size(); r++) {
             for (int sl : free_at[r]) free_list.push_back(sl);
             for (uint32_t k : rounds[r]) {
-                if (succs[k].empty()) continue;   // only stored to its hint slot
+                if (succs[k].empty() && nodes[k].opc != F_DIV) continue;   // only stored to its hint slot (a division's slot also carries the inverse from the loader wave to the rows)
                 int sl;
                 if (!free_list.empty()) {
                     sl = free_list.back();
