@@ -2,7 +2,7 @@
 # round 5, call 4: division by the loader wave + two passes per round: the pairing parity / variant / digit-row / check tests, then the
 # pairing bench lines (ring 1 = the chain alone, pipelined, the 8-GPU shares)
 cd "$(dirname "$0")/.."
-O=gpurun_out/r5_4; mkdir -p $O
+O=gpurun_out/${OUT:-r5_4}; mkdir -p $O
 timeout 1500 python -m pytest tests/test_parity_gpu.py tests/test_pyref_gpu.py tests/test_digit_rows_gpu.py tests/test_check_gpu.py -m gpu -x -q -k "pairing or digit or check" > $O/pytest_pairing.log 2>&1; echo "pytest pairing rc $?"; tail -3 $O/pytest_pairing.log
 B="python bench.py --sub --suite main --traffic off --no-cpu-baseline"
 for rep in 1 2; do
@@ -15,7 +15,7 @@ timeout 300 $B --workload pairing_bn256 --units 8 > $O/pairing_bn256_share8.json
 timeout 300 $B --workload pairing_bls12_381 --units 2 > $O/pairing_bls12_381_share8.json 2> $O/pairing_bls12_381_share8.err
 python - <<'PY'
 import json, glob
-for f in sorted(glob.glob("gpurun_out/r5_4/*.json")):
+for f in sorted(glob.glob("gpurun_out/" + __import__("os").environ.get("OUT", "r5_4") + "/*.json")):
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1])
         r = d["roofline"]

@@ -3117,6 +3117,37 @@ struct DigitRow {
             mont_step<I + 1>(a, b, minv32, T);
         }
     }
+    // TWO products in one row (eight-digit fields: a value leaves half of the row's 16 lanes idle): lanes 0-7 hold the digits of
+    // a, b of the first product, lanes 8-15 those of the second; wj2 = digit j mod 8 of w in every lane.  The same nine
+    // instructions per digit round + two more broadcasts (every half takes a_i and m from its own lane 0 / 8 + i).  What crosses
+    // the halves is harmless: lane 7 takes lo(Q) of lane 8 where the one-product form takes the zero of lane D - and lo(Q) of a
+    // product's column 0 is zero by construction (that is what m is for); the columns of a result below 2 w < 2^255 leave
+    // nothing above digit 7 for lane 8 to take or for a carry to run into.
+    template <int I>
+    WI_INLINE void mont_step2(u32 a, u32 b, u32 wj2, u32 minv32, u64& T) const {
+        if constexpr (I < 8) {
+            u32 ai = (u32)__builtin_amdgcn_update_dpp(0, (int)a, H2E_DPP_ROW_BCAST(I), 0xf, 0x3, true);        // banks 0-1: lanes 0-7
+            ai = (u32)__builtin_amdgcn_update_dpp((int)ai, (int)a, H2E_DPP_ROW_BCAST(8 + I), 0xf, 0xc, true);   // banks 2-3: lanes 8-15
+            u64 c0, cq, c2;
+            u64 P = mad64_co(ai, b, T, c0);
+            u32 m0 = (u32)P * minv32;
+            u32 m = (u32)__builtin_amdgcn_update_dpp(0, (int)m0, H2E_DPP_ROW_BCAST(0), 0xf, 0x3, true);
+            m = (u32)__builtin_amdgcn_update_dpp((int)m, (int)m0, H2E_DPP_ROW_BCAST(8), 0xf, 0xc, true);
+            u64 Q = mad64_co(m, wj2, P, cq);
+            u32 down = dpp_mov<H2E_DPP_ROW_SHL1>((u32)Q);
+            u32 t_lo = add_co32((u32)(Q >> 32), down, c2);
+            u32 t_hi = addc_co32(0u, 0u, cq);
+            t_hi = addc_co32(t_hi, 0u, c2);
+            T = pack64(t_lo, t_hi);
+            mont_step2<I + 1>(a, b, wj2, minv32, T);
+        }
+    }
+    WI_INLINE u32 mont_mul2(u32 a, u32 b, u32 wj2, u32 minv32) const {
+        static_assert(D == 8, "two products per row: eight-digit fields only");
+        u64 T = 0;
+        mont_step2<0>(a, b, wj2, minv32, T);
+        return normalize((u32)T, (u32)(T >> 32));
+    }
     WI_INLINE u32 mont_mul(u32 a, u32 b, u32 minv32) const {
         u64 T = 0;
 #ifdef H2E_EXP_MUL_STEPS   // timing experiment (wrong products): only that many of the D digit rounds
@@ -3238,6 +3269,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
     const u64 beta = digit_lane ? ((const H2E_AS_GLOBAL u64*)fc->lin_bias)[jd] : 0ull;
     const u32 minv32 = (u32)fc->w_minv;
     const u32 ej = R.wj - (j == 0u ? 2u : 0u);   // digit j of w - 2 (w is odd and > 2: no borrow leaves digit 0)
+    const u32 wj2 = D == 8 ? ((const H2E_AS_GLOBAL u32*)fc->w)[j & 7u] : 0u;   // digit j mod 8 of w: the second product of a paired row (eight-digit fields)
     const u32 grp = wave * 4u + (lane >> 4);
     const H2E_AS_LDS u32* fv32 = (const H2E_AS_LDS u32*)fv;
     const u32 fv_digit_addr = (u32)(size_t)fv32 + j * 4u;   // LDS address of digit j of value slot 0
@@ -3317,6 +3349,8 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
             u32 opc = w0 & 0xfu, dst = w0 >> 16;   // (bits 4-7: terms of a combination, 8-15: a fused product's second record)
             u32 out = 0;
             bool raw = false;
+            u32 st_dst = dst, st_hint = hint, st_j = j;   // where this LANE's digit of the result goes (a pair of products: two destinations per row)
+            bool st_ok = digit_lane;
             if constexpr (LOADS) {   // values entering: inputs and pool constants
                 const u64* src = (opc == H2E_F_INPUT_W || opc == H2E_F_INPUT_FE) ? d.inputs + (size_t)w2 * K.n_params : pool + w2;
                 if (opc == H2E_F_INPUT_W && (w0 & H2E_F_FROM_HINTS)) src = d.hints + (size_t)w2 * d.ws;   // a value an earlier segment left in a hint slot
@@ -3328,12 +3362,33 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                     out = x;
                     raw = true;
                 }
-            } else if (kind == 2) {           // Montgomery products
-                out = R.mont_mul(ld_value(w2), ld_value(w3), minv32);
+            } else if (kind == 2) {           // Montgomery products (class-pure rounds: never paired)
+                out = R.mont_mul(ld_value(w2 & 0xffffu), ld_value(w3 & 0xffffu), minv32);
             } else if (kind == 0) {    // linear combinations, conditions, selections - and products (mixed rounds: the host gives every
                                        // kind its own waves)
                 if (opc == H2E_F_MUL) {
-                    out = R.mont_mul(ld_value(w2), ld_value(w3), minv32);
+                    bool packed = false;
+                    if constexpr (D == 8) {
+                        // a pair of products in one row (record flag in the term-count bits; the host pairs the products of a round):
+                        // every row of a wave that holds a pair runs the two-product form, a single product as a pair without a second half
+                        const bool pair = ((w0 >> 4) & 0xfu) == 1u;
+                        if (__builtin_amdgcn_ballot_w64(pair) != 0ull) {
+                            packed = true;
+                            const bool up = j >= 8u;
+                            const u32 w5 = dpp_mov<H2E_DPP_ROW_BCAST(5)>(rw);
+                            const u32 sa = up ? (w2 >> 16) : (w2 & 0xffffu), sb = up ? (w3 >> 16) : (w3 & 0xffffu);
+                            const bool live = !up || pair;
+                            u32 xa = fv32[sa * (u32)D + (j & 7u)], xb = fv32[sb * (u32)D + (j & 7u)];
+                            xa = live ? xa : 0u;
+                            xb = live ? xb : 0u;
+                            out = R.mont_mul2(xa, xb, wj2, minv32);
+                            st_dst = up ? (pair ? (w4 & 0xffffu) : 0xffffu) : dst;
+                            st_hint = up ? (pair ? (w5 & 0x3ffffu) : 0u) : hint;
+                            st_j = j & 7u;
+                            st_ok = true;
+                        }
+                    }
+                    if (!packed) out = R.mont_mul(ld_value(w2 & 0xffffu), ld_value(w3 & 0xffffu), minv32);
                 } else if (opc == H2E_F_LIN || opc == H2E_F_MULX) {
                     // A linear combination - or (H2E_FIELD_FUSE programs) a product whose operands are linear combinations: two
                     // records, this row's and one behind the round's rows (field_chain.hpp); the combinations one after the other,
@@ -3467,14 +3522,14 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
 #endif
                 (void)ej;
             }
-            if (dst != 0xffffu && digit_lane) ((H2E_AS_LDS u32*)fv)[dst * (u32)D + j] = out;
-            if (hint) {
+            if (st_dst != 0xffffu && st_ok) ((H2E_AS_LDS u32*)fv)[st_dst * (u32)D + st_j] = out;
+            if (__builtin_amdgcn_ballot_w64(st_hint != 0u) != 0ull) {
                 // (conditions are raw 0 / 1: stored as the Montgomery form of that number, so that the finalize kernel's
                 // conversion of the whole slot range gives 0 / 1 back)
                 u32 hv = out;
                 if (raw) hv = (dpp_mov<H2E_DPP_ROW_BCAST(0)>(out) & 1u) ? r1j : 0u;
 #ifndef H2E_EXP_NO_HINT_STORES   // (timing experiment: the chain without its global stores)
-                if (digit_lane) ((H2E_AS_GLOBAL u32*)(d.hints + (size_t)(hint - 1) * d.ws))[j] = hv;
+                if (st_ok && st_hint != 0u) ((H2E_AS_GLOBAL u32*)(d.hints + (size_t)(st_hint - 1) * d.ws))[st_j] = hv;
 #endif
             }
         }

@@ -377,12 +377,15 @@ struct FieldCompiler {
                     if (E.size() > 255) ok = false;
                 }
                 std::vector<std::pair<int, int>> r;
+                long long abs_sum = 0;
                 for (auto& kv : E) {
                     if (kv.second == 0) continue;
                     if (std::llabs(kv.second) > F_MAX_COEF) ok = false;
+                    abs_sum += std::llabs(kv.second);
                     r.push_back({kv.first, (int)kv.second});
                 }
-                if (ok && r.size() <= 255) nd.terms = r;
+                // (h2e_field_sinks accumulates |coef| x value: the sum must stay below 2^12 w - what a record of 14 terms can reach)
+                if (ok && r.size() <= 255 && abs_sum <= (long long)F_MAX_COEF * 14) nd.terms = r;
             }
         }
         // back into topological order by index (partial sums were appended behind their readers)
@@ -981,6 +984,10 @@ struct FieldCompiler {
         // headers travel through LDS with the records: a header read from global memory would make the computing wave wait
         // for every hint store it has in flight (loads and stores share one in-order counter).
         size_t term_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // Eight-digit fields (bn256 Fq, bls12_381 Fr): a product uses half of its row's 16 lanes, so the products of a round go two to
+        // a row (engine.hip DigitRow::mont_mul2): record = [MUL | 1 << 4 | dst << 16, hint, a | a2 << 16, b | b2 << 16, dst2, hint2].
+        const bool pair_products = digit_rows && mixed_rounds && !fuse && w_words == 4 && !getenv("H2E_FIELD_NO_PAIRS");
+        std::map<uint32_t, uint32_t> partner;   // first product of a paired row -> the second
         for (size_t r = 0; r < rounds.size(); r++) {
             auto& rd = rounds[r];
             // (a row of 16 lanes per record: the four records of a wave should be of one kind)
@@ -997,8 +1004,21 @@ struct FieldCompiler {
                     std::vector<uint32_t> padded;
                     for (int kd = 0; kd < 4; kd++) {
                         size_t before = padded.size();
+                        uint32_t open_pair = PAD;   // (eight-digit fields: two products per row - the second rides in the first's record)
                         for (uint32_t k : rd)
-                            if (kind_of(k) == kd) padded.push_back(k);
+                            if (kind_of(k) == kd) {
+                                if (kd == 2 && pair_products) {
+                                    if (open_pair == PAD) {
+                                        open_pair = k;
+                                        padded.push_back(k);
+                                    } else {
+                                        partner[open_pair] = k;
+                                        open_pair = PAD;
+                                    }
+                                    continue;
+                                }
+                                padded.push_back(k);
+                            }
                         if (padded.size() > before)
                             while (padded.size() % 4) padded.push_back(PAD);
                     }
@@ -1100,6 +1120,18 @@ struct FieldCompiler {
                         w[2] = slot_of(nd.a);
                         w[3] = slot_of(nd.b);
                         if (nd.opc == F_MUL) out.n_mul++;
+                        if (nd.opc == F_MUL && partner.count(k)) {   // the row's second product
+                            const uint32_t k2 = partner[k];
+                            const Node& n2 = nodes[k2];
+                            w[0] |= 1u << 4;
+                            w[2] |= slot_of(n2.a) << 16;
+                            w[3] |= slot_of(n2.b) << 16;
+                            w[4] = slot[k2] >= 0 ? (uint32_t)slot[k2] : 0xffffu;
+                            w[5] = n2.hint == 0xffffffffu ? 0u : n2.hint + 1;
+                            if (w[5] >= (1u << 18)) throw std::runtime_error("field chain: hint slot index beyond the records' 18 bits");
+                            if (n2.hint != 0xffffffffu) out.note_hint(n2.hint, hint_split);
+                            out.n_mul++;
+                        }
                         break;
                     case F_ISZERO: case F_NOT: w[2] = slot_of(nd.a); break;
                     case F_SELECT:
