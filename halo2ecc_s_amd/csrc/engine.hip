@@ -3395,11 +3395,17 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                     // then the multiplication.  Per combination: columns acc_j = beta_j + sum coef_t x_t,j.  The digits are read as
                     // x - 2^31 (one xor), which makes a term one signed multiply-add; the host put sum coef_t into the record
                     // (word 1, bits 18-31) and (sum coef_t) 2^31 goes back in at the start.
-                    auto combination = [&](u32 rwx, u32 nt, u32 v1) -> u32 {
+                    // A LONG combination (15 .. 28 terms, round 5) has a second record behind the round's rows (index in bits 8-15 of
+                    // word 0, 0 = none): its terms go into the same columns before the one reduction - a level of the program less
+                    // wherever a sum of up to 28 products would have been a partial sum and a final record.
+                    auto combination = [&](u32 rwx, u32 nt, u32 v1, u32 cidx2) -> u32 {
                         i64 acc = (i64)beta + ((i64)((int)v1 >> 18) << 31);
+                        if constexpr (D == 8) {
+                            if (j >= 8u) acc = 0;   // (beta is zero up there already; the coefficient sum goes in once)
+                        }
                         // (an unused term has coefficient 0 and slot 0; all digits are read before the first is used: one LDS
                         // round trip per combination, not one per term)
-                        auto combine = [&](auto nt_tag) {
+                        auto combine = [&](u32 rwy, auto nt_tag) {
                             constexpr int NT = decltype(nt_tag)::value;
                             if constexpr (D == 8) {
                                 // eight digits leave half of the row idle: lanes 0-7 take the even terms, lanes 8-15 the odd ones
@@ -3408,23 +3414,20 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                                 int coef[NT / 2];
                                 static_for<0, NT / 2>([&](auto tc) {
                                     constexpr int P = decltype(tc)::value;
-                                    u32 term = (u32)__builtin_amdgcn_update_dpp(0, (int)rwx, H2E_DPP_ROW_BCAST(2 + 2 * P), 0xf, 0x3, true);        // banks 0-1: lanes 0-7
-                                    term = (u32)__builtin_amdgcn_update_dpp((int)term, (int)rwx, H2E_DPP_ROW_BCAST(3 + 2 * P), 0xf, 0xc, true);   // banks 2-3: lanes 8-15
+                                    u32 term = (u32)__builtin_amdgcn_update_dpp(0, (int)rwy, H2E_DPP_ROW_BCAST(2 + 2 * P), 0xf, 0x3, true);        // banks 0-1: lanes 0-7
+                                    term = (u32)__builtin_amdgcn_update_dpp((int)term, (int)rwy, H2E_DPP_ROW_BCAST(3 + 2 * P), 0xf, 0xc, true);   // banks 2-3: lanes 8-15
                                     x[P] = *(const H2E_AS_LDS u32*)(size_t)mad_u32_u16(term, (u32)D * 4u, fv_digit_addr_half);
                                     coef[P] = (int)term >> 16;
                                 });
                                 DP_STAMP(1, x[NT / 2 - 1]);
-                                if (j >= 8u) acc = 0;   // (beta is zero up there already; the coefficient sum goes in once)
 #pragma unroll
                                 for (int t = 0; t < NT / 2; t++) acc += (i64)coef[t] * (i64)(int)(x[t] ^ 0x80000000u);
-                                u32 up_lo = dpp_mov<0x108>((u32)(u64)acc), up_hi = dpp_mov<0x108>((u32)((u64)acc >> 32));   // row_shl:8: lane j gets lane j + 8
-                                acc += (i64)pack64(up_lo, up_hi);
                             } else {
                                 u32 x[NT];
                                 int coef[NT];
                                 static_for<0, NT>([&](auto tc) {
                                     constexpr int T = decltype(tc)::value;
-                                    u32 term = dpp_mov<H2E_DPP_ROW_BCAST(2 + T)>(rwx);
+                                    u32 term = dpp_mov<H2E_DPP_ROW_BCAST(2 + T)>(rwy);
                                     x[T] = *(const H2E_AS_LDS u32*)(size_t)mad_u32_u16(term, (u32)D * 4u, fv_digit_addr);   // slot (low 16 bits) x 4 D + (slot 0's digit j)
                                     coef[T] = (int)term >> 16;
                                 });
@@ -3439,21 +3442,34 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                             }
                         };
                         // the term loop of this wave's longest combination (the host sorts a round's records by their length)
+                        auto combine_n = [&](u32 rwy, u32 n) {
 #ifdef H2E_EXP_LIN_TERMS   // timing experiment (wrong sums): every combination as if it had at most that many terms
-                        if (true) combine(std::integral_constant<int, H2E_EXP_LIN_TERMS>());
-                        else
+                            if (true) combine(rwy, std::integral_constant<int, H2E_EXP_LIN_TERMS>());
+                            else
 #endif
-                        if (__builtin_amdgcn_ballot_w64(nt > 10u)) combine(std::integral_constant<int, H2E_F_MAX_TERMS_WIDE>());
-                        else if (__builtin_amdgcn_ballot_w64(nt > 6u)) combine(std::integral_constant<int, 10>());
-                        else if (__builtin_amdgcn_ballot_w64(nt > 2u)) combine(std::integral_constant<int, 6>());
-                        else combine(std::integral_constant<int, 2>());
+                            if (__builtin_amdgcn_ballot_w64(n > 10u)) combine(rwy, std::integral_constant<int, H2E_F_MAX_TERMS_WIDE>());
+                            else if (__builtin_amdgcn_ballot_w64(n > 6u)) combine(rwy, std::integral_constant<int, 10>());
+                            else if (__builtin_amdgcn_ballot_w64(n > 2u)) combine(rwy, std::integral_constant<int, 6>());
+                            else combine(rwy, std::integral_constant<int, 2>());
+                        };
+                        combine_n(rwx, nt);
+                        if (__builtin_amdgcn_ballot_w64(cidx2 != 0u) != 0ull) {
+                            // (a row of this wave without a second record reads some record and takes none of its terms)
+                            u32 rw2 = rec_ptr(first % H2E_WCHUNK + cidx2)[j];
+                            rw2 = cidx2 != 0u ? rw2 : 0u;
+                            combine_n(rw2, (dpp_mov<H2E_DPP_ROW_BCAST(0)>(rw2) >> 4) & 0xfu);
+                        }
+                        if constexpr (D == 8) {
+                            u32 up_lo = dpp_mov<0x108>((u32)(u64)acc), up_hi = dpp_mov<0x108>((u32)((u64)acc >> 32));   // row_shl:8: lane j gets lane j + 8
+                            acc += (i64)pack64(up_lo, up_hi);
+                        }
                         u32 lo = sel_by_mask(0u, (u32)(u64)acc, R.digits), hi = sel_by_mask(0u, (u32)((u64)acc >> 32), R.digits);
                         DP_STAMP(2, lo);
                         return R.reduce_columns(lo, hi);                     // in [0, 2 w)
                     };
                     DP_STAMP(0, rw);
                     if (opc == H2E_F_LIN) {
-                        out = combination(rw, (w0 >> 4) & 0xfu, w1);
+                        out = combination(rw, (w0 >> 4) & 0xfu, w1, (w0 >> 8) & 0xffu);
                     } else {
                         const u32 cidx = (w0 >> 8) & 0xffu;
                         u32 rwx = rw, val0 = 0;
@@ -3467,7 +3483,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                                 const u32 v0 = dpp_mov<H2E_DPP_ROW_BCAST(0)>(rwx), v1 = dpp_mov<H2E_DPP_ROW_BCAST(1)>(rwx);
                                 const u32 nt = (v0 >> 4) & 0xfu;
                                 if (nt == 15u) val = ld_value(dpp_mov<H2E_DPP_ROW_BCAST(2)>(rwx) & 0xffffu);   // a plain operand: the slot in the first term word
-                                else val = combination(rwx, nt, v1);
+                                else val = combination(rwx, nt, v1, 0u);
                             }
                             if (side == 0) val0 = val;
                             out = val;

@@ -239,20 +239,24 @@ struct FieldCompiler {
 
     // The depth a combination of terms with these depths (sorted, deepest first) can be had at: a record of its own if they
     // fit, otherwise partial sums over the earliest terms until F_MAX_TERMS entries are left.
-    uint32_t tree_depth(std::vector<uint32_t> d) const {
+    // (KF: entries the final record may have - 2 F_MAX_TERMS for a LONG combination, whose second record sits behind the round's rows)
+    uint32_t tree_depth(std::vector<uint32_t> d, size_t KF) const {
         const size_t K = (size_t)F_MAX_TERMS;
         if (d.empty()) return 1;
-        while (d.size() > K) {   // (d ascending here: the earliest terms at the front)
-            size_t m = std::min(K, d.size() - (K - 1));
+        while (d.size() > KF) {   // (d ascending here: the earliest terms at the front)
+            size_t m = std::min(K, d.size() - (KF - 1));
             uint32_t pd = d[m - 1] + 1;
             d.erase(d.begin(), d.begin() + (long)m);
             d.insert(std::upper_bound(d.begin(), d.end(), pd), pd);
         }
         return d.back() + 1;
     }
+    bool long_lins = true;   // combinations of up to 2 F_MAX_TERMS terms (a second record; H2E_FIELD_NO_LONG=1: off, A/B)
     void rebalance(bool sinks_enabled) {
         const size_t N0 = nodes.size();
         const size_t K = (size_t)F_MAX_TERMS;
+        const size_t KL = long_lins ? 2 * K : K;
+        auto best_depth = [&](const std::vector<uint32_t>& d) { return std::min(tree_depth(d, K), tree_depth(d, KL)); };
         std::vector<uint32_t> depth(N0, 0);
         depth.reserve(N0 * 2);
         std::map<std::vector<std::pair<int, int>>, int> partial_of;   // terms (sorted by node) -> the partial-sum node that holds them
@@ -281,7 +285,7 @@ struct FieldCompiler {
             for (auto& t : nodes[k].terms) E[t.first] += t.second;
             // expand the whole deepest level at a time (two operands of a sum are usually equally deep: opening one of them alone
             // gains nothing), keep the best expression seen, give up after a few levels that did not help
-            uint32_t best = tree_depth(depths_of(E));
+            uint32_t best = best_depth(depths_of(E));
             {
                 std::map<int, long long> cur = E;
                 int stale = 0;
@@ -307,7 +311,7 @@ struct FieldCompiler {
                     }
                     if (!ok || nxt.size() > 4 * K * K) break;
                     cur = std::move(nxt);
-                    uint32_t d2 = tree_depth(depths_of(cur));
+                    uint32_t d2 = best_depth(depths_of(cur));
                     if (d2 < best || (d2 == best && cur.size() <= K && cur.size() <= E.size())) {
                         E = cur;
                         best = d2;
@@ -322,8 +326,20 @@ struct FieldCompiler {
             for (auto& kv : E)
                 if (kv.second != 0) T.push_back({depth[(size_t)kv.first], {kv.first, (int)kv.second}});
             std::stable_sort(T.begin(), T.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
-            while (T.size() > K) {
-                size_t m = std::min(K, T.size() - (K - 1));
+            // a long final record only where it makes the value available a level earlier, and only while the columns' bias covers
+            // its coefficients (sum |coef| <= 14 x 255, the bound of a plain record: H2EFieldConsts::lin_bias)
+            size_t KF = K;
+            {
+                std::vector<uint32_t> dd = depths_of(E);
+                if (KL > K && tree_depth(dd, KL) < tree_depth(dd, K)) {
+                    long long abs_sum = 0;
+                    size_t n_direct = std::min(T.size(), KL);   // (an upper bound: the latest terms stay in the final record, partial sums enter with coefficient 1)
+                    for (size_t q = T.size() - n_direct; q < T.size(); q++) abs_sum += std::llabs((long long)T[q].second.second);
+                    if (abs_sum + (long long)KL <= (long long)F_MAX_COEF * (long long)K) KF = KL;
+                }
+            }
+            while (T.size() > KF) {
+                size_t m = std::min(K, T.size() - (KF - 1));
                 std::vector<std::pair<int, int>> g;
                 uint32_t gd = 0;
                 for (size_t q = 0; q < m; q++) {
@@ -705,6 +721,7 @@ struct FieldCompiler {
         // combined further: consumers flatten through it) is written over the products themselves and leaves the chain as a sink.
         // (only with the sinks kernel: inside the chain a hint-only combination waits for a free row, and while it waits it keeps the
         // products it now reads directly alive - 10 k value slots for a bn256 Miller loop, more than the LDS holds)
+        long_lins = !getenv("H2E_FIELD_NO_LONG") && F_MAX_TERMS == 14;
         if (digit_rows && next_hint != nullptr && !getenv("H2E_FIELD_NO_SINKS") && !getenv("H2E_FIELD_NO_REBALANCE")) rebalance(true);
         // ---- products take over their operands' combinations (H2E_FIELD_FUSE=1: off by default) ---------------------------
         // mul -> (add, sub, ...) -> mul is the shape of the whole pairing.  A product whose operand is a linear combination can
@@ -1031,6 +1048,8 @@ struct FieldCompiler {
                         if (!mixed_rounds) throw std::runtime_error("field chain: fused products need mixed rounds");
                         if (!nodes[k].sq || !nodes[k].fa) n_conts++;   // (a square of a combination needs no second record)
                     }
+                for (uint32_t k : rd)
+                    if (k != PAD && nodes[k].opc == F_LIN && (int)nodes[k].terms.size() > F_MAX_TERMS) n_conts++;   // a long combination's second record
                 if (rd.size() + n_conts > 254) throw std::runtime_error("field chain: a round's records exceed the 8-bit record index");
             }
             size_t at = out.recs.size() / RW;
@@ -1111,9 +1130,20 @@ struct FieldCompiler {
                 }
                 switch (nd.opc) {
                     case F_LIN:
-                        if ((int)nd.terms.size() > F_MAX_TERMS) throw std::runtime_error("field chain: LIN with too many terms");
+                        if ((int)nd.terms.size() > (digit_rows ? 2 : 1) * F_MAX_TERMS) throw std::runtime_error("field chain: LIN with too many terms");
                         for (size_t t = 0; t + 2 < RW; t++)
                             w[2 + t] = t < nd.terms.size() ? (slot_of(nd.terms[t].first) | ((uint32_t)(uint16_t)(int16_t)nd.terms[t].second << 16)) : 0u;   // unused: coefficient 0 (slot 0)
+                        if ((int)nd.terms.size() > F_MAX_TERMS) {   // a long combination: the other terms in a second record behind the round's rows
+                            uint32_t w2[16] = {0};
+                            const size_t rest = nd.terms.size() - (size_t)F_MAX_TERMS;
+                            for (size_t t = 0; t < rest; t++)
+                                w2[2 + t] = slot_of(nd.terms[(size_t)F_MAX_TERMS + t].first) | ((uint32_t)(uint16_t)(int16_t)nd.terms[(size_t)F_MAX_TERMS + t].second << 16);
+                            w2[0] = head(F_CONT, (uint32_t)rest, 0, 0xffffu);
+                            const uint32_t cidx = (uint32_t)(rd.size() + conts.size() / RW);
+                            if (cidx == 0 || cidx > 255) throw std::runtime_error("field chain: second record of a long combination out of reach");
+                            w[0] |= cidx << 8;
+                            conts.insert(conts.end(), w2, w2 + RW);
+                        }
                         out.n_lin++;
                         break;
                     case F_MUL: case F_DIV: case F_AND: case F_OR: case F_XNOR:
