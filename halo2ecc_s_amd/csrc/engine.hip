@@ -3362,8 +3362,6 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                     out = x;
                     raw = true;
                 }
-            } else if (kind == 2) {           // Montgomery products (class-pure rounds: never paired)
-                out = R.mont_mul(ld_value(w2 & 0xffffu), ld_value(w3 & 0xffffu), minv32);
             } else if (kind == 0) {    // linear combinations, conditions, selections - and products (mixed rounds: the host gives every
                                        // kind its own waves)
                 if (opc == H2E_F_MUL) {
@@ -3389,10 +3387,8 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                         }
                     }
                     if (!packed) out = R.mont_mul(ld_value(w2 & 0xffffu), ld_value(w3 & 0xffffu), minv32);
-                } else if (opc == H2E_F_LIN || opc == H2E_F_MULX) {
-                    // A linear combination - or (H2E_FIELD_FUSE programs) a product whose operands are linear combinations: two
-                    // records, this row's and one behind the round's rows (field_chain.hpp); the combinations one after the other,
-                    // then the multiplication.  Per combination: columns acc_j = beta_j + sum coef_t x_t,j.  The digits are read as
+                } else if (opc == H2E_F_LIN) {
+                    // A linear combination: columns acc_j = beta_j + sum coef_t x_t,j.  The digits are read as
                     // x - 2^31 (one xor), which makes a term one signed multiply-add; the host put sum coef_t into the record
                     // (word 1, bits 18-31) and (sum coef_t) 2^31 goes back in at the start.
                     // A LONG combination (15 .. 28 terms, round 5) has a second record behind the round's rows (index in bits 8-15 of
@@ -3468,28 +3464,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                         return R.reduce_columns(lo, hi);                     // in [0, 2 w)
                     };
                     DP_STAMP(0, rw);
-                    if (opc == H2E_F_LIN) {
-                        out = combination(rw, (w0 >> 4) & 0xfu, w1, (w0 >> 8) & 0xffu);
-                    } else {
-                        const u32 cidx = (w0 >> 8) & 0xffu;
-                        u32 rwx = rw, val0 = 0;
-#pragma unroll 1
-                        for (u32 side = 0; side < 2u; side++) {
-                            u32 val;
-                            if (side == 1 && cidx == 0xffu) {   // (b = a)
-                                val = val0;
-                            } else {
-                                if (side == 1) rwx = rec_ptr(first % H2E_WCHUNK + cidx)[j];   // the second record: b's terms
-                                const u32 v0 = dpp_mov<H2E_DPP_ROW_BCAST(0)>(rwx), v1 = dpp_mov<H2E_DPP_ROW_BCAST(1)>(rwx);
-                                const u32 nt = (v0 >> 4) & 0xfu;
-                                if (nt == 15u) val = ld_value(dpp_mov<H2E_DPP_ROW_BCAST(2)>(rwx) & 0xffffu);   // a plain operand: the slot in the first term word
-                                else val = combination(rwx, nt, v1, 0u);
-                            }
-                            if (side == 0) val0 = val;
-                            out = val;
-                        }
-                        out = R.mont_mul(val0, out, minv32);
-                    }
+                    out = combination(rw, (w0 >> 4) & 0xfu, w1, (w0 >> 8) & 0xffu);
                     DP_STAMP(6, out);
                 } else if (opc == H2E_F_ISZERO) {
                     u32 x = ld_value(w2);                                    // in [0, 2 w): zero is 0 or w

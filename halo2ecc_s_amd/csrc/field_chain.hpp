@@ -93,12 +93,6 @@ struct FieldCompiler {
         uint32_t imm = 0;                                 // input slot / pool offset
         bool hint_src = false;                            // F_INPUT_W: imm is a hint slot of an earlier segment (record flag 0x100)
         uint32_t hint = 0xffffffffu;
-        // a product whose operand is a linear combination computed in the product's own row (digit rows, "fused"): the terms
-        // taken over from the LIN node that was the operand (a / b stay -1 then); sq: b is the same combination as a
-        std::vector<std::pair<int, int>> ta, tb;
-        bool fa = false, fb = false, sq = false;
-        bool fused() const { return fa || fb; }
-        int rows() const { return 1; }                    // rows of a round the node takes (a fused product's second record sits behind the round's rows)
     };
     std::vector<Node> nodes;
     struct Expr {
@@ -182,7 +176,7 @@ struct FieldCompiler {
 
     int F_MAX_TERMS = 6;   // terms of a LIN record: its words less two (compile() sets it)
     static constexpr int F_MAX_COEF = 255;
-    enum { F_NOP = 0, F_LIN, F_MUL, F_DIV, F_ISZERO, F_NOT, F_AND, F_OR, F_XNOR, F_SELECT, F_INPUT_W, F_INPUT_FE, F_CONST_W, F_CONST_FE, F_MULX, F_CONT };
+    enum { F_NOP = 0, F_LIN, F_MUL, F_DIV, F_ISZERO, F_NOT, F_AND, F_OR, F_XNOR, F_SELECT, F_INPUT_W, F_INPUT_FE, F_CONST_W, F_CONST_FE, F_RESERVED_14, F_CONT };
 
     int new_node(uint8_t opc) {
         nodes.emplace_back();
@@ -662,8 +656,6 @@ struct FieldCompiler {
             add(nd.b);
             add(nd.c);
             for (auto& kv : nd.terms) add(kv.first);
-            for (auto& kv : nd.ta) add(kv.first);
-            for (auto& kv : nd.tb) add(kv.first);
         };
         // ---- linear combinations of linear combinations ---------------------------------------------------------------
         // A LIN node exists where some consumer needed the value in a slot (an operand of a product, a hint); a later
@@ -723,31 +715,9 @@ struct FieldCompiler {
         // products it now reads directly alive - 10 k value slots for a bn256 Miller loop, more than the LDS holds)
         long_lins = !getenv("H2E_FIELD_NO_LONG") && F_MAX_TERMS == 14;
         if (digit_rows && next_hint != nullptr && !getenv("H2E_FIELD_NO_SINKS") && !getenv("H2E_FIELD_NO_REBALANCE")) rebalance(true);
-        // ---- products take over their operands' combinations (H2E_FIELD_FUSE=1: off by default) ---------------------------
-        // mul -> (add, sub, ...) -> mul is the shape of the whole pairing.  A product whose operand is a linear combination can
-        // compute that combination itself, in its own row, right before the multiplication: one round instead of two on every
-        // such path (the LIN node stays for its other readers and for its hint - where nobody reads it any more it becomes a
-        // sink or disappears).  Measured: bn256 1 950 -> 1 456 levels, 2 261 -> 1 538 rounds - and the chain 2.9 -> 3.4 ms
-        // (bls12-381: 2.7 -> 2.8): a fused round is as long as the two it replaces, because mixed rounds already run the
-        // combinations of one level next to the products of another; what a round costs is its longest row.
-        if (digit_rows && getenv("H2E_FIELD_FUSE") && !getenv("H2E_FIELD_PURE_ROUNDS")) {   // (= `fuse` below)
-            for (size_t k = 0; k < nodes.size(); k++) {
-                Node& nd = nodes[k];
-                if (nd.opc != F_MUL) continue;
-                const int oa = nd.a, ob = nd.b;
-                if (oa >= 0 && nodes[oa].opc == F_LIN) {
-                    nd.ta = nodes[oa].terms;
-                    nd.fa = true;
-                    nd.a = -1;
-                }
-                if (ob >= 0 && nodes[ob].opc == F_LIN) {
-                    if (nd.fa && ob == oa) nd.sq = true;
-                    else nd.tb = nodes[ob].terms;
-                    nd.fb = true;
-                    nd.b = -1;
-                }
-            }
-        }
+        // (Round 3 also tried products that compute their operands' combinations in their own row - two records, the second behind
+        // the round's rows: 2 261 -> 1 538 rounds and a SLOWER chain, 2.9 -> 3.4 ms, a fused round being as long as the two it
+        // replaces.  Taken out in round 5; the second-record mechanism now carries the long combinations.)
         // ---- hint-only combinations leave the chain -------------------------------------------------------------------
         // A quarter of the linear combinations feed nothing but their own hint slot (the reduce of a value nobody multiplies
         // again).  The chain is bound by its CU's instruction issue, and these are not on any path: they are computed after it
@@ -842,14 +812,13 @@ struct FieldCompiler {
         // its rows hold, one after the other).  Rounds are therefore scheduled by dependency alone (their number drops from
         // class-pure 2 808 to 2 06x for bn256, the dependency depth being 1 950) and the emission below pads each kind to a
         // multiple of four rows; 54 rows (51 with fused products) leave room for the padding in a pass of 60.
-        const bool mixed_rounds = digit_rows && !getenv("H2E_FIELD_PURE_ROUNDS");
-        const bool fuse = mixed_rounds && getenv("H2E_FIELD_FUSE");   // (fused products are a fourth kind of row: three more padding rows)
+        const bool mixed_rounds = digit_rows;   // (class-pure rounds - 2 808 instead of 2 06x for bn256 - were an A/B knob until round 5)
         // Two passes of the kernel's 60 rows per round (108 + padding; H2E_FIELD_STEP=<rows>: A/B): once the combinations are
         // depth-balanced the rounds are bound by their row capacity (bn256 Miller loop: depth 696, 50.7 k records = 940 rounds of 54,
         // 1 148 scheduled; 696 of 108) and a round costs ~1 340 cycles whatever is in it + ~31 per record: measured (64 x bn256, one
         // batch after the other) 54 rows: 4.04 ms, 80: 3.86, 108: 3.79, 160: 3.81
-        size_t STEP = digit_rows ? (mixed_rounds ? (fuse ? 51 : 108) : 60) : 64;
-        if (digit_rows && mixed_rounds && !fuse && getenv("H2E_FIELD_STEP")) STEP = std::max<size_t>(8, std::min<size_t>(234, (size_t)atoi(getenv("H2E_FIELD_STEP"))));
+        size_t STEP = digit_rows ? 108 : 64;
+        if (digit_rows && getenv("H2E_FIELD_STEP")) STEP = std::max<size_t>(8, std::min<size_t>(234, (size_t)atoi(getenv("H2E_FIELD_STEP"))));
         auto cls_of = [&](uint32_t k) -> int {   // 0 light, 1 loads, 2 products, 3 divisions
             switch (nodes[k].opc) {
                 case F_MUL: return mixed_rounds ? 0 : 2;   // (digit rows: a product is a row like any other - see the round emission)
@@ -876,7 +845,7 @@ struct FieldCompiler {
             if (alive[k] && !is_sink[k] && left[k] == 0) ready[cls_of((uint32_t)k)].push_back((uint32_t)k);
         auto rows_of = [&](const std::vector<uint32_t>& rd) {
             size_t n = 0;
-            for (uint32_t k : rd) n += (size_t)nodes[k].rows();
+            n += rd.size();
             return n;
         };
         std::vector<std::vector<uint32_t>> rounds_rev;
@@ -887,11 +856,7 @@ struct FieldCompiler {
                 if (!ready[q].empty()) c = q;
             if (c < 0) throw std::runtime_error("field chain: scheduler stalled");
             std::vector<uint32_t> rd;
-            size_t take = 0, rows_taken = 0;   // (a fused product takes two rows)
-            while (take < ready[c].size() && rows_taken + (size_t)nodes[ready[c][ready[c].size() - 1 - take]].rows() <= STEP) {
-                rows_taken += (size_t)nodes[ready[c][ready[c].size() - 1 - take]].rows();
-                take++;
-            }
+            size_t take = std::min(ready[c].size(), STEP);
             rd.assign(ready[c].end() - take, ready[c].end());
             ready[c].resize(ready[c].size() - take);
             for (uint32_t k : rd) {
@@ -921,7 +886,7 @@ struct FieldCompiler {
             int c = cls_of((uint32_t)k);
             bool placed = false;
             for (size_t r = r0; r < rounds.size() && !placed; r++)
-                if (rcls[r] == c && rows_of(rounds[r]) + (size_t)nodes[k].rows() <= STEP) {
+                if (rcls[r] == c && rows_of(rounds[r]) + 1 <= STEP) {
                     rounds[r].push_back((uint32_t)k);
                     round_of[k] = (uint32_t)r;
                     placed = true;
@@ -1003,21 +968,21 @@ struct FieldCompiler {
         size_t term_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         // Eight-digit fields (bn256 Fq, bls12_381 Fr): a product uses half of its row's 16 lanes, so the products of a round go two to
         // a row (engine.hip DigitRow::mont_mul2): record = [MUL | 1 << 4 | dst << 16, hint, a | a2 << 16, b | b2 << 16, dst2, hint2].
-        const bool pair_products = digit_rows && mixed_rounds && !fuse && w_words == 4 && !getenv("H2E_FIELD_NO_PAIRS");
+        const bool pair_products = digit_rows && w_words == 4 && !getenv("H2E_FIELD_NO_PAIRS");
         std::map<uint32_t, uint32_t> partner;   // first product of a paired row -> the second
         for (size_t r = 0; r < rounds.size(); r++) {
             auto& rd = rounds[r];
             // (a row of 16 lanes per record: the four records of a wave should be of one kind)
             const uint32_t PAD = 0xffffffffu;   // a padding row (NOP record)
-            size_t n_conts = 0;                 // second records of fused products: behind the round's rows
+            size_t n_conts = 0;                 // second records of long combinations: behind the round's rows
             if (digit_rows) {
-                auto op_terms = [&](uint32_t k) { return nodes[k].opc == F_MUL ? std::max(nodes[k].ta.size(), nodes[k].tb.size()) : nodes[k].terms.size(); };
+                auto op_terms = [&](uint32_t k) { return nodes[k].terms.size(); };
                 std::stable_sort(rd.begin(), rd.end(), [&](uint32_t x, uint32_t y) {
                     if (nodes[x].opc != nodes[y].opc) return nodes[x].opc < nodes[y].opc;
                     return op_terms(x) < op_terms(y);   // (a wave runs its longest combination's term loop)
                 });
-                if (mixed_rounds) {   // kinds: linear combinations | fused products | products | everything else, each from a wave boundary
-                    auto kind_of = [&](uint32_t k) { return nodes[k].opc == F_LIN ? 0 : nodes[k].opc == F_MUL ? (nodes[k].fused() ? 1 : 2) : 3; };
+                if (mixed_rounds) {   // kinds: linear combinations | products | everything else, each from a wave boundary
+                    auto kind_of = [&](uint32_t k) { return nodes[k].opc == F_LIN ? 0 : nodes[k].opc == F_MUL ? 2 : 3; };
                     std::vector<uint32_t> padded;
                     for (int kd = 0; kd < 4; kd++) {
                         size_t before = padded.size();
@@ -1043,11 +1008,6 @@ struct FieldCompiler {
                     if (padded.size() > (STEP <= 54 ? 60 : 250)) throw std::runtime_error("field chain: a padded round exceeds a pass of the kernel");
                     rd = padded;
                 }
-                for (uint32_t k : rd)
-                    if (k != PAD && nodes[k].fused()) {
-                        if (!mixed_rounds) throw std::runtime_error("field chain: fused products need mixed rounds");
-                        if (!nodes[k].sq || !nodes[k].fa) n_conts++;   // (a square of a combination needs no second record)
-                    }
                 for (uint32_t k : rd)
                     if (k != PAD && nodes[k].opc == F_LIN && (int)nodes[k].terms.size() > F_MAX_TERMS) n_conts++;   // a long combination's second record
                 if (rd.size() + n_conts > 254) throw std::runtime_error("field chain: a round's records exceed the 8-bit record index");
@@ -1079,42 +1039,9 @@ struct FieldCompiler {
                     continue;
                 }
                 const Node& nd = nodes[k];
-                // digit rows: word 0 = opcode (4 bits) | terms of the combination (4 bits; 15 = a plain operand) | index of the second
-                // record of a fused product, counted from the round's first record (8 bits; 0xff = b is a) | destination slot
+                // digit rows: word 0 = opcode (4 bits) | terms of the combination (4 bits; a product: 1 = a pair of products) | index of
+                // the second record of a long combination, counted from the round's first record (8 bits; 0 = none) | destination slot
                 auto head = [&](uint32_t opc, uint32_t nt, uint32_t cidx, uint32_t dst) { return opc | nt << 4 | cidx << 8 | dst << 16; };
-                if (nd.opc == F_MUL && nd.fused()) {
-                    // two records: [MULX, hint | sum of a's coefficients << 18, a's terms] and - behind the round's rows -
-                    // [CONT, sum of b's coefficients << 18, b's terms]
-                    auto side = [&](uint32_t* r, bool fused, const std::vector<std::pair<int, int>>& t, int plain) -> uint32_t {
-                        int sum = 0;
-                        if ((int)t.size() > F_MAX_TERMS) throw std::runtime_error("field chain: fused operand with too many terms");
-                        for (size_t q = 0; q < t.size(); q++) {
-                            r[2 + q] = slot_of(t[q].first) | ((uint32_t)(uint16_t)(int16_t)t[q].second << 16);
-                            sum += t[q].second;
-                        }
-                        if (!fused) r[2] = slot_of(plain);
-                        r[1] |= (uint32_t)sum << 18;
-                        return fused ? (uint32_t)t.size() : 15u;
-                    };
-                    w[1] = nd.hint == 0xffffffffu ? 0u : nd.hint + 1;
-                    if (w[1] >= (1u << 18)) throw std::runtime_error("field chain: hint slot index beyond the records' 18 bits");
-                    if (nd.hint != 0xffffffffu) {
-                        out.note_hint(nd.hint, hint_split);
-                    }
-                    uint32_t nta = side(w, nd.fa, nd.ta, nd.a);
-                    uint32_t cidx = 0xffu;
-                    if (!(nd.sq && nd.fa)) {
-                        uint32_t w2[16] = {0};
-                        uint32_t ntb = side(w2, nd.fb && !nd.sq, nd.tb, nd.b);
-                        w2[0] = head(F_CONT, ntb, 0, 0xffffu);
-                        cidx = (uint32_t)(rd.size() + conts.size() / RW);
-                        conts.insert(conts.end(), w2, w2 + RW);
-                    }
-                    w[0] = head(F_MULX, nta, cidx, slot[k] >= 0 ? (uint32_t)slot[k] : 0xffffu);
-                    out.recs.insert(out.recs.end(), w, w + RW);
-                    out.n_mul++;
-                    continue;
-                }
                 w[0] = digit_rows ? head(nd.opc, (uint32_t)std::min<size_t>(nd.terms.size(), 14), 0, slot[k] >= 0 ? (uint32_t)slot[k] : 0xffffu)
                                   : nd.opc | ((slot[k] >= 0 ? (uint32_t)slot[k] : 0xffffu) << 16);
                 w[1] = nd.hint == 0xffffffffu ? 0u : nd.hint + 1;

@@ -310,7 +310,7 @@ typedef struct H2EPreKernel {
 // field chain record opcodes (field_chain.hpp FieldCompiler::F_*)
 enum H2EFieldOp { H2E_F_NOP = 0, H2E_F_LIN, H2E_F_MUL, H2E_F_DIV, H2E_F_ISZERO, H2E_F_NOT, H2E_F_AND, H2E_F_OR, H2E_F_XNOR, H2E_F_SELECT,
                   H2E_F_INPUT_W, H2E_F_INPUT_FE, H2E_F_CONST_W, H2E_F_CONST_FE,
-                  H2E_F_MULX, H2E_F_CONT };   // a product that computes its operands' linear combinations itself: two records (field_chain.hpp)
+                  H2E_F_RESERVED_14, H2E_F_CONT };   // CONT: the second record of a long combination (15 .. 28 terms), behind the round's rows
 #define H2E_F_FROM_HINTS 0x100u   // flag in word 0 of an H2E_F_INPUT_W record: word 2 is a hint slot an earlier segment's chain left the value in
 #define H2E_F_MAX_TERMS 6        // 8-word records
 #define H2E_F_MAX_TERMS_WIDE 14   // 16-word records
