@@ -10,7 +10,9 @@
 // advice cells from the arrays a run left in HBM, masked by the shape's `assigned` flags.
 //
 // This unit shares no arithmetic with the engine (engine.hip / wide_int.h): Fr is four 64-bit words with a textbook CIOS
-// Montgomery product over unsigned __int128, so an error in the engine's wide-integer code cannot cancel out here.
+// Montgomery product over unsigned __int128, so an error in the engine's wide-integer code cannot cancel out here - the
+// constants made from instance inputs (ck_patch_values) included.  What it does share with the engine is the SHAPE: fixed
+// cells, flags and the permutation list are the recorder's (compared with the oracle's by the CPU shape tests).
 // Lanes: instance-minor like the arrays - consecutive lanes read consecutive instances of one cell (coalesced), the fixed
 // cells of a row are the same address for every lane of that row.
 #include <hip/hip_runtime.h>
@@ -388,6 +390,44 @@ extern "C" int h2e_engine_check_consts(const uint64_t n[4], uint64_t n_minv, con
 extern "C" int h2e_engine_check_to_mont(const uint64_t* in, uint64_t* out, uint64_t n, hipStream_t stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(ck_to_mont, dim3((u32)((n + 255) / 256)), dim3(256), 0, stream, in, out, n);
+    return (int)hipGetLastError();
+}
+// The base gate's constants that are made from instance inputs (the G2 coordinates of a pairing check: limbs and natives of
+// assign_int_constant, src/circuit/integer_chip.rs:580-598), computed HERE from the input words - not taken from the engine's
+// h2e_fixed_patches - so that an error in the engine's limb split / mod n cannot cancel out: patch = [base row, fixed column,
+// input slot, limb], limb >= 0: bits [108 limb, 108 limb + 108) of the slot's value, limb = -1: the value mod n (Horner over its
+// 64-bit words in this unit's Montgomery arithmetic).  out: [instance][patch][4 words], canonical.
+__global__ void __launch_bounds__(256) ck_patch_values(const u32* __restrict__ patches, u32 n_patches, const u64* __restrict__ inputs, u32 n_slots,
+                                                       u32 slot_words, u32 n_inst, u64* __restrict__ out) {
+    u32 t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_patches * n_inst) return;
+    u32 inst = t / n_patches, k = t % n_patches;
+    const u32 slot = patches[4 * k + 2];
+    const int limb = (int)patches[4 * k + 3];
+    const u64* x = inputs + ((size_t)inst * n_slots + slot) * slot_words;
+    Fr v = {{0, 0, 0, 0}};
+    if (limb >= 0) {
+        auto bit = [&](u32 b) -> u64 { return b / 64 < slot_words ? (x[b / 64] >> (b % 64)) & 1ull : 0ull; };
+        for (u32 b = 0; b < 108; b++) v.v[b / 64] |= bit(108u * (u32)limb + b) << (b % 64);   // (bit by bit: nothing to share with anybody's shift code)
+    } else {
+        Fr two64 = {{0, 1, 0, 0}};
+        const Fr two64_m = fr_to_mont(two64);
+        Fr acc = {{0, 0, 0, 0}};                       // Montgomery form
+        for (int w = (int)slot_words - 1; w >= 0; w--) {
+            Fr word = {{x[w], 0, 0, 0}};
+            acc = fr_add(fr_mont_mul(acc, two64_m), fr_to_mont(word));
+        }
+        Fr one = {{1, 0, 0, 0}};
+        v = fr_mont_mul(acc, one);                     // out of Montgomery form
+    }
+    u64* o = out + ((size_t)inst * n_patches + k) * 4;
+    for (int i = 0; i < 4; i++) o[i] = v.v[i];
+}
+extern "C" int h2e_engine_check_patch_values(const uint32_t* patches, uint32_t n_patches, const uint64_t* inputs, uint32_t n_slots, uint32_t slot_words,
+                                             uint32_t n_instances, uint64_t* out, hipStream_t stream) {
+    if (n_patches == 0 || n_instances == 0) return 0;
+    hipLaunchKernelGGL(ck_patch_values, dim3((n_patches * n_instances + 255) / 256), dim3(256), 0, stream, patches, n_patches, inputs, n_slots, slot_words,
+                       n_instances, out);
     return (int)hipGetLastError();
 }
 // classes: bit k of `classes` = run check class k (H2E_CHECK_*; the two range classes run together)

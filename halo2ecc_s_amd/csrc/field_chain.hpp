@@ -1304,9 +1304,8 @@ struct StoreCompiler {
         int prod[3] = {-1, -1, -1};
         for (int q = 0; q < n; q++)
             if (o[q].is_int) prod[q] = fcmp->int_producer(op.refs[o[q].refpos]);
-        // the integer operand q as a combination: a result of this segment, or - a context cut into several segments - a value an
-        // earlier one left in a hint slot (its limbs there are the canonical split: what the cells hold only if the value was
-        // reduced; an unreduced one would need its own limbs, so the producer exports REDUCED values only - see import_of)
+        // the integer operand q as a combination: a result of this segment, or - a context cut into several segments - an integer of
+        // an earlier one, read from its CELLS (below)
         auto operand = [&](int q) -> Lin {
             if (prod[q] >= 0) return flatten(out, (uint32_t)prod[q]);
             // an integer of an earlier segment of the same context: read as its cells hold it (that segment's own store - or its

@@ -41,6 +41,8 @@ extern "C" int h2e_engine_check(const H2ECheckRegion* regs, const uint64_t* dict
                                 uint64_t* fail, hipStream_t stream);
 extern "C" int h2e_engine_copy_constraints(const uint32_t* perms, uint64_t n, void* out, hipStream_t stream);
 extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances, uint32_t bits, hipStream_t stream);
+extern "C" int h2e_engine_check_patch_values(const uint32_t* patches, uint32_t n_patches, const uint64_t* inputs, uint32_t n_slots, uint32_t slot_words,
+                                             uint32_t n_instances, uint64_t* out, hipStream_t stream);   // checker.hip
 extern "C" int h2e_engine_unit_records(const void* base, const void* status, const void* digests, void* out, const uint64_t* offsets3,
                                        const uint32_t* refs, uint32_t limbs, int has_point, uint32_t n_instances, uint32_t out_stride,
                                        hipStream_t stream);   // handoff.hip
@@ -2353,6 +2355,7 @@ struct h2e_ctx {
     hipStream_t small_stream = nullptr;   // small expansions of pipelined runs (H2E_SCHED & 4)
     // tuning knobs, read once at h2e_ctx_create (H2E_X_SPLIT, H2E_X_SPLIT_MIN_LANES); h2e_ctx_set_option overrides
     uint32_t x_split_pct = 45;
+    uint32_t x_parts = 2;                 // launches a big expansion goes out as (H2E_X_PARTS: the part behind the first x_split_pct percent in parts - 1 equal launches)
     uint64_t x_split_min_lanes = 1ull << 21;
     uint64_t small_x_lanes = 1u << 18;   // an expansion with fewer lanes is "small" (H2E_SMALL_X_LANES)
     uint32_t sched = 4;      // scheduling experiments (H2E_SCHED bit mask): 1 = a pipelined run's small fix-ups go to the slot's side
@@ -2421,6 +2424,7 @@ int h2e_ctx_create(int device, h2e_ctx** out) {
     // tuning knobs are read once, here (nothing reads the environment while a run is being queued)
     if (const char* e1 = getenv("H2E_X_SPLIT")) c->x_split_pct = (uint32_t)std::max(0, std::min(100, atoi(e1)));
     if (const char* e2 = getenv("H2E_X_SPLIT_MIN_LANES")) c->x_split_min_lanes = (uint64_t)atoll(e2);
+    if (const char* e2b = getenv("H2E_X_PARTS")) c->x_parts = (uint32_t)std::max(2, std::min(8, atoi(e2b)));
     if (const char* e4 = getenv("H2E_TUNE")) {   // "reserve,xcache,xpad,scan test mask,persistent workgroups per CU,no packed expansion" (engine.hip g_tune)
         int a = 0, b = 0, d = 0, t = 0, pw = 0, nopack = 0;
         sscanf(e4, "%d,%d,%d,%d,%d,%d", &a, &b, &d, &t, &pw, &nopack);
@@ -3262,15 +3266,33 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         // rest of its sub-ranges: while the first one drains, the value chain that became ready meanwhile (the MSM tail's
         // replay wants most of a CU's LDS per workgroup) gets its CUs instead of waiting for the whole expansion, and the
         // inverse fix-up of the first part runs under the second.
+        // (x_parts > 2: the second part again in equal launches - the last inverse fix-up, which nothing can run under, shrinks with it)
         uint32_t split_sub = 0, split_fix = 0;
+        std::vector<uint32_t> part_sub, part_fix;   // boundaries: sub-range index / fix-up index each launch starts at (+ the end)
         {
             uint32_t pct = ctx->x_split_pct;
             if (pct > 0 && pct < 100 && L.n_sub >= 4 && (uint64_t)L.n_sub * L.n_strands * n_instances >= ctx->x_split_min_lanes) {
                 split_sub = std::min<uint32_t>(std::max<uint32_t>(2, (uint32_t)((uint64_t)L.n_sub * pct / 100)), L.n_sub - 2);
-                uint32_t row = r.tape[s.tape_begin + p->h_subs[p->seg_sub_begin[si] + split_sub]].base_row;
                 auto fb = r.fixups.begin() + s.fixups_begin;
-                // fix-up rows are recorded in tape order: those below the first row of the second part belong to the first
-                split_fix = std::is_sorted(fb, fb + s.n_fixups) ? (uint32_t)(std::lower_bound(fb, fb + s.n_fixups, row) - fb) : 0;
+                const bool sorted_fix = std::is_sorted(fb, fb + s.n_fixups);
+                // fix-up rows are recorded in tape order: those below the first row of a part belong to the parts before it
+                auto fix_at = [&](uint32_t sub) -> uint32_t {
+                    uint32_t row = r.tape[s.tape_begin + p->h_subs[p->seg_sub_begin[si] + sub]].base_row;
+                    return sorted_fix ? (uint32_t)(std::lower_bound(fb, fb + s.n_fixups, row) - fb) : 0;
+                };
+                split_fix = fix_at(split_sub);
+                part_sub = {0, split_sub};
+                part_fix = {0, split_fix};
+                uint32_t extra = std::min<uint32_t>(ctx->x_parts > 2 ? ctx->x_parts - 2 : 0, (L.n_sub - split_sub) / 2);
+                for (uint32_t q = 1; q <= extra; q++) {
+                    uint32_t at = split_sub + (uint32_t)((uint64_t)(L.n_sub - split_sub) * q / (extra + 1));
+                    if (at > part_sub.back() && at < L.n_sub) {
+                        part_sub.push_back(at);
+                        part_fix.push_back(fix_at(at));
+                    }
+                }
+                part_sub.push_back(L.n_sub);
+                part_fix.push_back(s.n_fixups);
                 ctx->last_split_segments++;
             }
         }
@@ -3309,16 +3331,18 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
                 if ((xrc = launch(2, st))) return xrc;
                 return 0;
             }
-            H2ELaunch a = L, b = L;
-            J.x_kernels[li] = 2;
-            a.n_sub = split_sub;
-            b.n_sub = L.n_sub - split_sub;
-            b.sub = L.sub + split_sub;
-            if ((xrc = launch_one(2, a, st))) return xrc;
-            if ((xrc = fixup_part(st, 0, split_fix))) return xrc;
-            return launch_one(2, b, st);
+            const size_t n_parts = part_sub.size() - 1;
+            J.x_kernels[li] = (uint32_t)n_parts;
+            for (size_t q = 0; q < n_parts; q++) {
+                H2ELaunch a = L;
+                a.n_sub = part_sub[q + 1] - part_sub[q];
+                a.sub = L.sub + part_sub[q];
+                if ((xrc = launch_one(2, a, st))) return xrc;
+                if (q + 1 < n_parts && (xrc = fixup_part(st, part_fix[q], part_fix[q + 1]))) return xrc;   // (the last part's: expand_fixup)
+            }
+            return 0;
         };
-        auto expand_fixup = [&](hipStream_t st) -> int { return fixup_part(st, split_sub ? split_fix : 0, s.n_fixups); };
+        auto expand_fixup = [&](hipStream_t st) -> int { return fixup_part(st, split_sub ? part_fix[part_fix.size() - 2] : 0, s.n_fixups); };
         if (L.n_sub > 1) {
             if ((lrc = launch(1, sa))) return lrc;
             if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
@@ -3988,8 +4012,8 @@ int h2e_check(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_
             HIP_TRY(hipMalloc((void**)&p->d_patch_vals, need));
             p->patch_vals_cap = need;
         }
-        rc = h2e_engine_patch_values(p->field_pair, p->d_patches, n_patches, (const uint64_t*)d_inputs, r.n_input_slots, (uint32_t)r.fp.w_words,
-                                     n_instances, ctx->d_fc[p->field_pair], p->d_patch_vals, (hipStream_t)stream);
+        rc = h2e_engine_check_patch_values(p->d_patches, n_patches, (const uint64_t*)d_inputs, r.n_input_slots, (uint32_t)r.fp.w_words, n_instances,
+                                           p->d_patch_vals, (hipStream_t)stream);
         if (rc != 0) return fail(H2E_ERR_HIP, "check: patch values launch failed");
     }
     H2ECheckRegion regs[3];

@@ -173,7 +173,11 @@ int h2e_submit(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d
 int h2e_wait(h2e_ctx* ctx, int job, void* stream);
 
 /* Options / statistics of a context.  Tuning knobs are read from the environment once, at h2e_ctx_create
- * (H2E_X_SPLIT, H2E_X_SPLIT_MIN_LANES); nothing reads the environment while a run is queued. */
+ * (H2E_X_SPLIT, H2E_X_SPLIT_MIN_LANES, H2E_X_PARTS); nothing reads the environment while a run is queued.
+ * PROCESS-wide, not per context (every context of a process sees the same value; set them before the first context runs):
+ * the kernel-side fields of the experiment knob H2E_TUNE and the test hook H2E_OPT_TEST_SCAN_FALLBACK / the counter
+ * H2E_STAT_SCAN_FALLBACKS.  Everything else - streams, job slots, workspaces, options, statistics, the op-program cache -
+ * belongs to its context: two contexts on one device share nothing (tests/test_threads_gpu.py). */
 #define H2E_OPT_X_SPLIT_PCT 1          /* a big expansion goes out as two launches: percent of sub-ranges in the first (0 = off) */
 #define H2E_OPT_X_SPLIT_MIN_LANES 2    /* ... if it has at least this many lanes */
 #define H2E_OPT_TEST_SKIP_EXPANSION 3  /* TEST HOOK: leave out the full expansion of cut segment <value> (-1: of every cut
@@ -253,9 +257,11 @@ int h2e_export_copy_constraints(h2e_ctx* ctx, h2e_program* p, void* d_out, void*
  * the arrays satisfy the base gate (src/circuit/base_chip.rs:50-69), the three range accumulation gates and the two range
  * lookups (src/circuit/range_chip.rs:119-220, table :230-258), the select chip's lookup_any (src/circuit/select_chip.rs:71-88)
  * and every copy constraint (src/context.rs:523-541).  h2e_check evaluates exactly those over the batch-interleaved advice
- * arrays a run (or an operator-API context) left in HBM and the program's own fixed cells, flags and permutation list
- * (unassigned / unset cells = 0, as in MockProver), for all n_instances at once; `p` must have been recorded with its shape
- * (emit_shape = 1) and d_inputs is the run's input vector (fixed cells made from instance inputs: the G2 constants).
+ * arrays a run of a PROGRAM left in HBM and the program's own fixed cells, flags and permutation list (unassigned / unset
+ * cells = 0, as in MockProver), for all n_instances at once; `p` must have been recorded with its shape (emit_shape = 1) and
+ * d_inputs is the run's input vector (fixed cells made from instance inputs - the G2 constants - are recomputed from it by
+ * the checker's own arithmetic).  (An operator-API context has no program handle to pass here: a host that wants its
+ * sequence of ops checked records it as a program.)
  * d_fail = uint64 [n_instances][2 * H2E_CHECK_CLASSES]: per instance the number of failing rows (pairs) of each class, then
  * the lowest failing row (pair index) of each class, ~0 when none.  An instance passes iff its first five words are zero.
  * `classes` = bit mask of H2E_CHECK_* to evaluate (0 = all).  Asynchronous on `stream`. */
