@@ -563,7 +563,7 @@ def main():
         except ValueError as e:
             traffic, traffic_err = None, str(e)
     total_cells = cells_per_unit * T * args.steps
-    # a big expansion goes out as two back-to-back kernel launches over a prefix / the rest of its sub-ranges (h2e.h):
+    # a big expansion goes out as several back-to-back kernel launches over consecutive parts of its sub-ranges (h2e.h):
     # the events bracket both, so the per-launch figures are bracket / n and bytes / n
     dom_ms = float(np.mean([ms[dom][1] for ms in launch_ms])) / dom_n
     dom_bytes = 32.0 * launches[dom]["cells"] * units / dom_n

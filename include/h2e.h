@@ -178,7 +178,7 @@ int h2e_wait(h2e_ctx* ctx, int job, void* stream);
  * the kernel-side fields of the experiment knob H2E_TUNE and the test hook H2E_OPT_TEST_SCAN_FALLBACK / the counter
  * H2E_STAT_SCAN_FALLBACKS.  Everything else - streams, job slots, workspaces, options, statistics, the op-program cache -
  * belongs to its context: two contexts on one device share nothing (tests/test_threads_gpu.py). */
-#define H2E_OPT_X_SPLIT_PCT 1          /* a big expansion goes out as two launches: percent of sub-ranges in the first (0 = off) */
+#define H2E_OPT_X_SPLIT_PCT 1          /* a big expansion goes out as several launches (three; H2E_X_PARTS): percent of sub-ranges in the first (0 = off) */
 #define H2E_OPT_X_SPLIT_MIN_LANES 2    /* ... if it has at least this many lanes */
 #define H2E_OPT_TEST_SKIP_EXPANSION 3  /* TEST HOOK: leave out the full expansion of cut segment <value> (-1: of every cut
                                           segment but the last; INT64_MIN: off).  Rows are missing from such a run: every
@@ -195,7 +195,7 @@ int h2e_wait(h2e_ctx* ctx, int job, void* stream);
 #define H2E_OPT_OP_CACHE_CAP 7           /* operator API: programs the context keeps for ops it has seen (default 4096, >= 1).  Beyond it the
                                           least recently used programs that no call is running are freed with their device tapes. */
 int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value);
-#define H2E_STAT_LAST_SPLIT_SEGMENTS 1 /* segments of the last run whose expansion went out as two launches */
+#define H2E_STAT_LAST_SPLIT_SEGMENTS 1 /* segments of the last run whose expansion went out as several launches */
 #define H2E_STAT_RUNS 2
 #define H2E_STAT_PIPELINE_DEPTH 3
 #define H2E_STAT_MAX_PIPELINE_DEPTH 4
