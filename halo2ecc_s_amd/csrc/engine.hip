@@ -3158,6 +3158,25 @@ struct DigitRow {
         return normalize((u32)T, (u32)(T >> 32));
     }
 };
+// 64-bit words in LDS read as WAVE-UNIFORM values (v_readfirstlane: the result is an SGPR pair, and what is computed from SGPRs is
+// computed on the scalar unit) and written by every lane alike - the accessor modinv62::inv_mem works through in the digit chain
+template <class T>
+struct UniLds {
+    H2E_AS_LDS T* p;
+    struct Ref {
+        H2E_AS_LDS T* q;
+        WI_INLINE operator T() const {
+            T v = *q;
+            return (T)pack64((u32)__builtin_amdgcn_readfirstlane((u32)(u64)v), (u32)__builtin_amdgcn_readfirstlane((u32)((u64)v >> 32)));
+        }
+        WI_INLINE const Ref& operator=(T v) const {
+            *q = v;
+            return *this;
+        }
+    };
+    WI_INLINE Ref operator[](int i) const { return Ref{p + i}; }
+    WI_INLINE UniLds operator+(int k) const { return UniLds{p + k}; }
+};
 template <class FP>
 __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, const u32* __restrict__ args, const u64* __restrict__ pool,
                                                                 const InstanceDesc* __restrict__ inst, u32 n_instances) {
@@ -3216,18 +3235,32 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                 // a division round: lane k inverts the divisor of the round's k-th record - (b R), in [0, 2 w) - and leaves the plain
                 // inverse in the record's destination slot (nothing reads that slot before the round's rows have written it)
                 const Rec* cb = rbuf + (size_t)((pos / H2E_WCHUNK) % H2E_DP_CHUNKS) * H2E_WCHUNK;
-                if (lane < cnt) {
-                    const H2E_AS_LDS u32* rp = (const H2E_AS_LDS u32*)(cb + (pos % H2E_WCHUNK + 1u + lane));
-                    const u32 dslot = rp[0] >> 16, bslot = rp[3];
+                // (the inversion's state - four numbers of NL 62-bit limbs and the modulus - lives in LDS behind the value slots and is
+                // streamed through a few registers, modinv62::inv_mem: with it in registers this kernel was allocated 120 instead of 57
+                // VGPRs for EVERY wave and a chain's CU had no room left for another run's expansion waves - 64 x bn256 pipelined 3.10
+                // against 2.98 ms per step)
+                // ... and every value it computes is WAVE-UNIFORM (the whole loader wave inverts one divisor at a time; what it reads
+                // from LDS goes through v_readfirstlane), so the compiler puts the arithmetic on the scalar unit: the division steps cost
+                // this kernel SGPRs, not VGPRs.
+                constexpr int NL = (64 * N + 61) / 62;
+                H2E_AS_LDS u64* scratch = (H2E_AS_LDS u64*)(fv + (size_t)K.f_slots * N);   // 4 NL + N + 1 words (H2E_DP_DIV_SCRATCH)
+                for (u32 r = 0; r < cnt; r++) {   // (a check has ONE division: the loop runs once)
+                    const H2E_AS_LDS u32* rp = (const H2E_AS_LDS u32*)(cb + (pos % H2E_WCHUNK + 1u + r));
+                    const u32 dslot = __builtin_amdgcn_readfirstlane(rp[0]) >> 16, bslot = __builtin_amdgcn_readfirstlane(rp[3]);
                     H2E_AS_LDS u32* v32 = (H2E_AS_LDS u32*)fv;
                     Wd<N> bw, ww;
 #pragma unroll
                     for (int i = 0; i < N; i++) {
-                        bw.v[i] = pack64(v32[bslot * (u32)D + 2u * (u32)i], v32[bslot * (u32)D + 2u * (u32)i + 1u]);
+                        bw.v[i] = pack64(__builtin_amdgcn_readfirstlane(v32[bslot * (u32)D + 2u * (u32)i]), __builtin_amdgcn_readfirstlane(v32[bslot * (u32)D + 2u * (u32)i + 1u]));
                         ww.v[i] = fc->w[i];
+                        scratch[4 * NL + i] = ww.v[i];
                     }
+                    scratch[4 * NL + N] = 0ull;
                     if (wd_geq<N>(bw, ww)) bw = wd_sub<N>(bw, ww);          // [0, 2 w) -> [0, w)
-                    Wd<N> y = wd_inv_mod<N>(bw, ww);                         // 0 for 0
+                    Wd<N> y;
+                    UniLds<long long> st{(H2E_AS_LDS long long*)scratch};
+                    modinv62::inv_mem<N, UniLds<long long>, UniLds<unsigned long long>>(bw.v, UniLds<unsigned long long>{(H2E_AS_LDS unsigned long long*)(scratch + 4 * NL)}, y.v,
+                                                                                        st, st + NL, st + 2 * NL, st + 3 * NL);   // 0 for 0
                     if (dslot != 0xffffu) {
 #pragma unroll
                         for (int i = 0; i < N; i++) {
@@ -4582,7 +4615,7 @@ extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2E
     if (k->kind == H2E_PRE_FIELD_CHAIN) {   /* params_dev carries the constant pool, n_params the words per input slot */          \
         if (phase & 1)                                                                                                              \
         {                                                                                                                           \
-            size_t lds = (k->f_mode == 1 ? (size_t)H2E_DP_CHUNKS * H2E_WCHUNK * 64 : (size_t)2 * H2E_WCHUNK * 32) + (size_t)k->f_slots * FP::WW * 8 + 64; \
+            size_t lds = (k->f_mode == 1 ? (size_t)H2E_DP_CHUNKS * H2E_WCHUNK * 64 + H2E_DP_DIV_SCRATCH : (size_t)2 * H2E_WCHUNK * 32) + (size_t)k->f_slots * FP::WW * 8 + 64; \
             if (k->f_mode == 1 && (size_t)g_tune[0] > lds && g_tune[0] <= 160 * 1024) lds = (size_t)g_tune[0];   /* keep the CU (A/B) */ \
             if (k->f_mode == 1)                                                                                                     \
                 hipLaunchKernelGGL(h2e_field_chain_digits<FP>, dim3(n_instances), dim3((H2E_DP_WAVES + 1) * 64), lds, stream, *k, args_dev, \

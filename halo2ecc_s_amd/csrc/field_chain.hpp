@@ -948,7 +948,7 @@ struct FieldCompiler {
         if (n_slots >= 0xfff0) { out.why = "too many value slots"; return false; }
         // the kernels keep their record chunks (a ring of H2E_DP_CHUNKS for the digit-row kernel, two for the lane kernel) and
         // every value slot in LDS (160 KB per workgroup on gfx950)
-        if ((size_t)(digit_rows ? H2E_DP_CHUNKS : 2u) * H2E_WCHUNK * RW * 4 + (size_t)n_slots * w_words * 8 + 64 > (size_t)160 * 1024) {
+        if ((size_t)(digit_rows ? H2E_DP_CHUNKS : 2u) * H2E_WCHUNK * RW * 4 + (digit_rows ? H2E_DP_DIV_SCRATCH : 0u) + (size_t)n_slots * w_words * 8 + 64 > (size_t)160 * 1024) {
             out.why = "the value slots (" + std::to_string(n_slots) + ") do not fit the LDS";
             return false;
         }

@@ -195,4 +195,105 @@ MI_INLINE void inv(const uint64_t* a, const uint64_t* pw, uint64_t* out) {
     from_s62<N, NL>(d, out);
 }
 
+// ---- the same inversion with its state (f, g, d, e: 4 NL limbs) in caller-provided memory ---------------------------------------
+// inv<N> keeps ~4 NL 64-bit limbs + the modulus in registers: ~120 VGPRs for N = 4.  A kernel that calls it ONCE in a cold path (the
+// pairings' digit chain: the loader wave inverts the divisors of a division round) still gets that register allocation for every wave -
+// and its CU no longer has room for another kernel's waves beside it.  Here the limbs live in memory (LDS on the device: P is a pointer
+// type into it, a plain int64_t* on the host) and are streamed through a few registers limb by limb; same steps, same result.
+template <int NL, class P>
+MI_INLINE void update_fg_mem(P f, P g, const Trans& t) {
+    i128 cf = (i128)t.u * f[0] + (i128)t.v * g[0];
+    i128 cg = (i128)t.q * f[0] + (i128)t.r * g[0];
+    cf >>= 62;
+    cg >>= 62;
+#pragma unroll 1
+    for (int i = 1; i < NL; i++) {
+        int64_t fi = f[i], gi = g[i];
+        cf += (i128)t.u * fi + (i128)t.v * gi;
+        cg += (i128)t.q * fi + (i128)t.r * gi;
+        f[i - 1] = (int64_t)cf & M62;
+        g[i - 1] = (int64_t)cg & M62;
+        cf >>= 62;
+        cg >>= 62;
+    }
+    f[NL - 1] = (int64_t)cf;
+    g[NL - 1] = (int64_t)cg;
+}
+template <int NL, class P, class PW>
+MI_INLINE void update_de_mem(P d, P e, const Trans& t, PW pw, uint64_t pinv) {
+    auto p_limb = [&](int i) -> int64_t {   // limb i of the modulus from its 64-bit words (to_s62 for one limb)
+        int bit = 62 * i, k = bit / 64, sh = bit % 64;
+        uint64_t lo = pw[k] >> sh;
+        uint64_t hi = sh > 2 ? pw[k + 1] << (64 - sh) : 0;   // (pw has one word of padding above the modulus)
+        return (int64_t)((lo | hi) & (uint64_t)M62);
+    };
+    int64_t sd = d[NL - 1] >> 63, se = e[NL - 1] >> 63;
+    int64_t md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);
+    int64_t d0 = d[0], e0 = e[0];
+    i128 cd = (i128)t.u * d0 + (i128)t.v * e0;
+    i128 ce = (i128)t.q * d0 + (i128)t.r * e0;
+    md -= (int64_t)((pinv * (uint64_t)cd + (uint64_t)md) & (uint64_t)M62);
+    me -= (int64_t)((pinv * (uint64_t)ce + (uint64_t)me) & (uint64_t)M62);
+    int64_t p0 = p_limb(0);
+    cd += (i128)p0 * md;
+    ce += (i128)p0 * me;
+    cd >>= 62;
+    ce >>= 62;
+#pragma unroll 1
+    for (int i = 1; i < NL; i++) {
+        int64_t di = d[i], ei = e[i], pi = p_limb(i);
+        cd += (i128)t.u * di + (i128)t.v * ei;
+        ce += (i128)t.q * di + (i128)t.r * ei;
+        cd += (i128)pi * md;
+        ce += (i128)pi * me;
+        d[i - 1] = (int64_t)cd & M62;
+        e[i - 1] = (int64_t)ce & M62;
+        cd >>= 62;
+        ce >>= 62;
+    }
+    d[NL - 1] = (int64_t)cd;
+    e[NL - 1] = (int64_t)ce;
+}
+// a^-1 mod p (0 for a = 0); a, out: N words; pw: N + 1 words in memory (the modulus and a zero word above it); f, g, d, e: NL limbs each
+template <int N, class P, class PW>
+MI_INLINE void inv_mem(const uint64_t* a, PW pw, uint64_t* out, P f, P g, P d, P e) {
+    constexpr int NL = (64 * N + 61) / 62;
+    static_assert(64 * N + 2 <= 62 * NL, "the signed 62-bit limbs must hold every value in (-2 p, 2 p) for p < 2^(64 N)");
+    constexpr int MAX_BATCHES = ((49 * 64 * N + 80) / 17 + 61) / 62;
+    uint64_t pl[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) pl[i] = pw[i];
+    {
+        S62<NL> ps = to_s62<N, NL>(pl), as = to_s62<N, NL>(a);
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            f[i] = ps.v[i];
+            g[i] = as.v[i];
+            d[i] = 0;
+            e[i] = i == 0 ? 1 : 0;
+        }
+    }
+    uint64_t p0 = (uint64_t)f[0], pinv = p0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) pinv *= 2 - p0 * pinv;
+    pinv &= (uint64_t)M62;
+    int64_t eta = -1;
+#pragma unroll 1
+    for (int it = 0; it < MAX_BATCHES; it++) {
+        int64_t nz = 0;
+#pragma unroll 1
+        for (int i = 0; i < NL; i++) nz |= g[i];
+        if (nz == 0) break;
+        Trans t;
+        eta = divsteps_62(eta, (uint64_t)f[0], (uint64_t)g[0], t);
+        update_de_mem<NL, P, PW>(d, e, t, pw, pinv);
+        update_fg_mem<NL, P>(f, g, t);
+    }
+    S62<NL> ds, ps = to_s62<N, NL>(pl);
+#pragma unroll
+    for (int i = 0; i < NL; i++) ds.v[i] = d[i];
+    normalize<NL>(ds, f[NL - 1], ps);
+    from_s62<N, NL>(ds, out);
+}
+
 }  // namespace modinv62

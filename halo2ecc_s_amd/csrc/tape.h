@@ -312,6 +312,7 @@ enum H2EFieldOp { H2E_F_NOP = 0, H2E_F_LIN, H2E_F_MUL, H2E_F_DIV, H2E_F_ISZERO, 
                   H2E_F_INPUT_W, H2E_F_INPUT_FE, H2E_F_CONST_W, H2E_F_CONST_FE,
                   H2E_F_RESERVED_14, H2E_F_CONT };   // CONT: the second record of a long combination (15 .. 28 terms), behind the round's rows
 #define H2E_F_FROM_HINTS 0x100u   // flag in word 0 of an H2E_F_INPUT_W record: word 2 is a hint slot an earlier segment's chain left the value in
+#define H2E_DP_DIV_SCRATCH 320u   // digit chain: LDS behind the value slots for the state of the loader wave's inversion (4 NL + N + 1 64-bit words, NL = 7, N = 6: 280 B)
 #define H2E_F_MAX_TERMS 6        // 8-word records
 #define H2E_F_MAX_TERMS_WIDE 14   // 16-word records
 // The MSM chains are walked as scans (engine.hip "scan predictors"): a window's sum over its groups in H2E_WIN_CHUNKS

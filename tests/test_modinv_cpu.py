@@ -30,8 +30,9 @@ def _words(x, n):
     return [(x >> (64 * i)) & (2**64 - 1) for i in range(n)]
 
 
+@pytest.mark.parametrize("form", ["registers", "memory"])   # memory: the state streamed through caller-provided memory (the digit chain's loader wave: LDS)
 @pytest.mark.parametrize("p,n", [(BN_FQ, 4), (BN_FR, 4), (BLS_FR, 4), (BLS_FQ, 6)])
-def test_modinv(lib, p, n):
+def test_modinv(lib, p, n, form):
     rnd = random.Random(p & 0xffff)
     vals = [0, 1, 2, 3, p - 1, p - 2, (p + 1) // 2, 2**62, 2**62 - 1, 2**124, 2**(64 * n - 3) % p, (1 << (p.bit_length() - 1))]
     vals += [rnd.randrange(p) for _ in range(3000)]
@@ -39,7 +40,7 @@ def test_modinv(lib, p, n):
     a = np.array([_words(v, n) for v in vals], dtype=np.uint64)
     out = np.zeros_like(a)
     pw = np.array(_words(p, n), dtype=np.uint64)
-    fn = getattr(lib, f"modinv_{n}")
+    fn = getattr(lib, f"modinv_{n}" if form == "registers" else f"modinv_mem_{n}")
     fn(a.ctypes.data_as(ctypes.c_void_p), pw.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), len(vals))
     for v, o in zip(vals, out):
         got = sum(int(w) << (64 * i) for i, w in enumerate(o))
