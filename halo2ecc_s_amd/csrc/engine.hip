@@ -3825,7 +3825,7 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_predict_tail(H2EPreKe
     const u32* neg_r2 = a + 2 + NR;
     u32 line0 = a[2 + 2 * NR];
     u32 nch = (windows + CH - 1) / CH;
-    u32 per_instance = phase == 0 ? nch : phase == 1 ? 1 : windows;
+    u32 per_instance = phase == 0 ? nch : (phase == 1 || phase == 3) ? 1 : windows;
     u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_instances * per_instance) return;
     u32 instance = gid % n_instances, rest = gid / n_instances;
@@ -3834,7 +3834,8 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_predict_tail(H2EPreKe
     vc_init<FP>(v, d, n_instances, nullptr, nullptr, fc, 0);
     MontW<FP> M;
     (Mont<NW>&)M = mont_w<FP>(fc);
-    u32 sB = K.scan_begin, sD = sB + windows, sA = sD + windows;
+    u32 sB = K.scan_begin, sD = sB + windows, sA = sD + windows, sX = sA + nch;   // sX: (r1.x, r1.y in Montgomery form, fallback flag) for the digit-row form of phase 1
+    if (phase == 3 && ((const u32*)(d.jac + ((size_t)sX * 3 + 2) * d.ws))[0] == 0u) return;   // (h2e_predict_tail_rows met no degenerate sum for this instance)
     Wd<NW> bx = ld_w_mont<FP>(v.c, M, neg_r2), by = ld_w_mont<FP>(v.c, M, neg_r2 + L + 1);
     auto r1_point = [&]() {
         Jac<NW> p;
@@ -3869,6 +3870,11 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_predict_tail(H2EPreKe
     };
     auto chunk_start = [&](u32 c) { return c == 0 ? r1_point() : ld_jac<FP>(v, sA + c - 1); };
     if (phase == 0) {
+        if (rest == 0) {   // the chain's start point for the digit-row kernel, and its fallback flag cleared
+            Jac<NW> r = r1_point();
+            r.z = wd_zero<NW>();
+            st_jac<FP>(v, sX, r);
+        }
         u32 w0 = rest * CH, w1 = min(w0 + CH, windows);
         Jac<NW> b;
         for (u32 w = w0; w < w1; w++) {
@@ -3878,7 +3884,7 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_predict_tail(H2EPreKe
             b = w == w0 ? t : jac_add(M, t, jac_dbl(M, b, num), num);
             st_jac<FP>(v, sB + w, b);
         }
-    } else if (phase == 1) {
+    } else if (phase == 1 || phase == 3) {
         Jac<NW> acc = r1_point();
         for (u32 c = 0; c < nch; c++) {
             u32 w0 = c * CH, w1 = min(w0 + CH, windows);
@@ -4464,6 +4470,116 @@ extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances,
 }
 
 #endif   // H2E_COMMON_UNIT
+// ------------------------------------------------------------------------------------------------
+// Phase 1 of the tail's scan in digit rows (round 5).  The doubling chain over the 254 windows is inherently serial - window 0's
+// sum is doubled 253 times - and as one lane per instance (h2e_predict_tail phase 1: ONE wave for 64 instances, 2 034 Montgomery
+// products of ~330 instructions each) it was 3.5-4 ms of every run's tail, on the path to the run's completion.  Here an instance is
+// a 16-lane row, a lane a 32-bit digit (DigitRow: the pairings' arithmetic): a product is ~90 wave instructions for four instances,
+// additions and subtractions are column sums with one lazy reduction ([0, 2 w) throughout; what is stored for the lane kernels is
+// brought to [0, w)), 16 waves on 16 CUs instead of one.  Same formulas as jac_dbl / jac_add, so the values stored are the lane
+// kernel's.  An instance that meets a degenerate sum (Z = 0; or the test knob) only raises its flag: h2e_predict_tail phase 3 then
+// redoes that instance the old way, fallback walk included.
+template <class FP>
+__global__ void __launch_bounds__(64) h2e_predict_tail_rows(H2EPreKernel K, const u32* __restrict__ args, const InstanceDesc* __restrict__ inst, u32 n_instances) {
+    constexpr int N = FP::WW, D = 2 * N;
+    constexpr u32 CH = H2E_TAIL_CHUNK;
+    __builtin_amdgcn_s_setprio(3);
+    const u32 lane = threadIdx.x & 63u;
+    u32 instance = blockIdx.x * 4u + (lane >> 4);
+    const bool live = instance < n_instances;
+    if (!live) instance = n_instances - 1u;
+    InstanceDesc d = inst[instance];
+    const H2EFieldConsts* fc = &g_fc[FP::ID];
+    DigitRow<D> R = DigitRow<D>::make(fc, lane);
+    const u32 j = R.j;
+    const bool digit_lane = j < (u32)D;
+    const u32 jd = digit_lane ? j : 0u;
+    const u32 r1j = digit_lane ? ((const H2E_AS_GLOBAL u32*)fc->w_r1)[jd] : 0u;
+    const i64 beta = digit_lane ? (i64)((const H2E_AS_GLOBAL u64*)fc->lin_bias)[jd] : 0;
+    const u32 minv32 = (u32)fc->w_minv;
+    const u32* a = args + K.args_begin;
+    const u32 windows = a[0];
+    const u32 nch = (windows + CH - 1) / CH;
+    const u32 sB = K.scan_begin, sD = sB + windows, sA = sD + windows, sX = sA + nch;
+    auto cptr = [&](u32 slot, u32 coord) { return (H2E_AS_GLOBAL u32*)(d.jac + ((size_t)slot * 3 + coord) * d.ws); };
+    auto ldc = [&](u32 slot, u32 coord) -> u32 { return digit_lane ? cptr(slot, coord)[j] : 0u; };
+    auto mul = [&](u32 x, u32 y) -> u32 { return R.mont_mul(x, y, minv32); };
+    // c1 x1 + c2 x2 + c3 x3 mod w in [0, 2 w) (|c| <= 8: the columns' bias covers far more)
+    auto lin = [&](int c1, u32 x1, int c2, u32 x2, int c3, u32 x3) -> u32 {
+        i64 acc = beta + (i64)c1 * (i64)(u64)x1 + (i64)c2 * (i64)(u64)x2 + (i64)c3 * (i64)(u64)x3;
+        return R.reduce_columns((u32)(u64)acc, (u32)((u64)acc >> 32));
+    };
+    // [0, 2 w) -> [0, w): x - w + 2^(32 D) digit by digit; its carry out of the top digit (lane D) says x >= w
+    auto canon = [&](u32 x) -> u32 {
+        u64 s2 = (u64)x + (u64)(digit_lane ? ~R.wj : 0u) + (j == 0u ? 1ull : 0ull);
+        u64 G = __builtin_amdgcn_ballot_w64((u32)(s2 >> 32) != 0u);
+        u32 t = DigitRow<D>::carry((u32)s2, G);
+        u32 ge = (u32)__builtin_amdgcn_update_dpp(0, (int)t, H2E_DPP_ROW_BCAST(D), 0xf, 0xf, true);
+        return digit_lane ? (ge ? t : x) : 0u;
+    };
+    auto is_zero = [&](u32 x) -> bool {   // a value in [0, 2 w): zero is 0 or w (row-uniform result)
+        u64 nz = __builtin_amdgcn_ballot_w64(x != 0u), nw = __builtin_amdgcn_ballot_w64(x != R.wj);
+        const u32 row_base = lane & 48u;
+        return ((u32)(nz >> row_base) & 0xffffu) == 0u || ((u32)(nw >> row_base) & 0xffffu) == 0u;
+    };
+    struct P3 {
+        u32 x, y, z;
+    };
+    auto dbl = [&](const P3& p) -> P3 {   // jac_dbl
+        u32 aa = mul(p.x, p.x), b = mul(p.y, p.y), cc = mul(b, b);
+        u32 xb = lin(1, p.x, 1, b, 0, 0u);
+        u32 dq = lin(2, mul(xb, xb), -2, aa, -2, cc);
+        u32 e = lin(3, aa, 0, 0u, 0, 0u);
+        P3 r;
+        r.x = lin(1, mul(e, e), -2, dq, 0, 0u);
+        r.y = lin(1, mul(e, lin(1, dq, -1, r.x, 0, 0u)), -8, cc, 0, 0u);
+        r.z = lin(2, mul(p.y, p.z), 0, 0u, 0, 0u);
+        return r;
+    };
+    auto add = [&](const P3& p, const P3& q) -> P3 {   // jac_add
+        u32 z1z1 = mul(p.z, p.z), z2z2 = mul(q.z, q.z);
+        u32 u1 = mul(p.x, z2z2), u2 = mul(q.x, z1z1);
+        u32 s1 = mul(mul(p.y, q.z), z2z2), s2 = mul(mul(q.y, p.z), z1z1);
+        u32 h = lin(1, u2, -1, u1, 0, 0u), r = lin(1, s2, -1, s1, 0, 0u);
+        u32 hh = mul(h, h), hhh = mul(hh, h), vv = mul(u1, hh);
+        P3 o;
+        o.x = lin(1, mul(r, r), -1, hhh, -2, vv);
+        o.y = lin(1, mul(r, lin(1, vv, -1, o.x, 0, 0u)), -1, mul(s1, hhh), 0, 0u);
+        o.z = mul(mul(p.z, q.z), h);
+        return o;
+    };
+    auto store = [&](u32 slot, const P3& p) {
+        u32 cx = canon(p.x), cy = canon(p.y), cz = canon(p.z);
+        if (live && digit_lane) {
+            cptr(slot, 0)[j] = cx;
+            cptr(slot, 1)[j] = cy;
+            cptr(slot, 2)[j] = cz;
+        }
+    };
+    P3 acc;
+    acc.x = ldc(sX, 0);
+    acc.y = ldc(sX, 1);
+    acc.z = r1j;
+    bool fallback = false;
+    for (u32 c = 0; c < nch; c++) {
+        const u32 w0 = c * CH, w1 = min(w0 + CH, windows);
+        P3 dd = acc;
+        for (u32 w = w0; w < w1; w++) {
+            dd = dbl(dd);
+            store(sD + w, dd);
+        }
+        P3 b;
+        b.x = ldc(sB + w1 - 1, 0);
+        b.y = ldc(sB + w1 - 1, 1);
+        b.z = ldc(sB + w1 - 1, 2);
+        P3 nx = add(b, dd);
+        if (is_zero(nx.z) || ((g_scan_test & 2u) && (c & 1u))) fallback = true;
+        acc = nx;
+        store(sA + c, acc);
+    }
+    if (fallback && live && j == 0u) cptr(sX, 2)[0] = 1u;
+}
+
 // Tuning knobs (h2e_capi.cpp reads H2E_TUNE once, at h2e_ctx_create): [0] LDS bytes a small predictor grid reserves so
 // that no expansion wave shares its CU, [1] expansion result cache in LDS on / off, [2] extra dynamic LDS per expansion
 // workgroup (caps its waves per CU).  Round 2 (profiles/r2_tune_sweep.txt) switched the result cache off:
@@ -4486,7 +4602,7 @@ extern "C" long long H2E_UNIT(h2e_engine_scan_fallbacks)(void) {
     return (long long)n;
 }
 extern "C" void H2E_UNIT(h2e_engine_set_tuning)(int key, int value) {
-    if ((key >= 0 && key < 3) || key == 4 || key == 5) g_tune[key] = value;
+    if (key >= 0 && key < 6) g_tune[key] = value;   // ([3]: also the device-side scan test mask below; bit 3 = the tail's phase 1 as one lane per instance, A/B)
     if (key == 3) {
         u32 m = (u32)value;
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_test), &m, sizeof(m));
@@ -4649,7 +4765,12 @@ extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2E
         u32 windows = k->ecc_ops / k->pattern_len, nch = (windows + H2E_TAIL_CHUNK - 1) / H2E_TAIL_CHUNK;                           \
         dim3 g0((n_instances * nch + 63) / 64), g2((n_instances * windows + 63) / 64);                                              \
         hipLaunchKernelGGL(h2e_predict_tail<FP>, g0, block, 0, stream, *k, 0u, args_dev, inst, n_instances, fc_dev);                \
-        hipLaunchKernelGGL(h2e_predict_tail<FP>, grid, block, lds_reserve, stream, *k, 1u, args_dev, inst, n_instances, fc_dev);    \
+        if (g_tune[3] & 8) {   /* A/B: phase 1 as one lane per instance */                                                          \
+            hipLaunchKernelGGL(h2e_predict_tail<FP>, grid, block, lds_reserve, stream, *k, 1u, args_dev, inst, n_instances, fc_dev); \
+        } else {                                                                                                                    \
+            hipLaunchKernelGGL(h2e_predict_tail_rows<FP>, dim3((n_instances + 3) / 4), block, 0, stream, *k, args_dev, inst, n_instances); \
+            hipLaunchKernelGGL(h2e_predict_tail<FP>, grid, block, 0, stream, *k, 3u, args_dev, inst, n_instances, fc_dev);           \
+        }                                                                                                                           \
         hipLaunchKernelGGL(h2e_predict_tail<FP>, g2, block, 0, stream, *k, 2u, args_dev, inst, n_instances, fc_dev);                \
     } else if (phase & 1)                                                                                                           \
         hipLaunchKernelGGL(h2e_predict<FP>, grid, block, lds_reserve, stream, *k, args_dev, params_dev, aux_dev, inst, n_instances, fc_dev); \

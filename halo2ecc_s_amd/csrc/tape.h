@@ -322,4 +322,4 @@ enum H2EFieldOp { H2E_F_NOP = 0, H2E_F_LIN, H2E_F_MUL, H2E_F_DIV, H2E_F_ISZERO, 
 #define H2E_WIN_CHUNKS 8u
 #define H2E_TAIL_CHUNK 16u
 #define H2E_WIN_SCAN_SLOTS(windows) ((windows) * 2u * H2E_WIN_CHUNKS)                                   /* S_c, O_c per window */
-#define H2E_TAIL_SCAN_SLOTS(windows) (2u * (windows) + ((windows) + H2E_TAIL_CHUNK - 1u) / H2E_TAIL_CHUNK)  /* B_w, D_w, A_c */
+#define H2E_TAIL_SCAN_SLOTS(windows) (2u * (windows) + ((windows) + H2E_TAIL_CHUNK - 1u) / H2E_TAIL_CHUNK + 1u)  /* B_w, D_w, A_c, (r1 in Montgomery form | fallback flag) */
