@@ -7,7 +7,7 @@ timeout 2400 python -m pytest tests/test_parity_gpu.py tests/test_pyref_gpu.py t
 B="python bench.py --sub --suite main --traffic off --no-cpu-baseline"
 for rep in 1 2; do
   timeout 400 $B --workload msm > $O/msm_rows_$rep.json 2> $O/msm_rows_$rep.err
-  H2E_TUNE=0,3,0,8 timeout 400 $B --workload msm > $O/msm_lanes_$rep.json 2> $O/msm_lanes_$rep.err
+  H2E_TUNE=0,3,0,16 timeout 400 $B --workload msm > $O/msm_lanes_$rep.json 2> $O/msm_lanes_$rep.err
 done
 python - <<'PY'
 import json, glob

@@ -3835,7 +3835,10 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_predict_tail(H2EPreKe
     MontW<FP> M;
     (Mont<NW>&)M = mont_w<FP>(fc);
     u32 sB = K.scan_begin, sD = sB + windows, sA = sD + windows, sX = sA + nch;   // sX: (r1.x, r1.y in Montgomery form, fallback flag) for the digit-row form of phase 1
-    if (phase == 3 && ((const u32*)(d.jac + ((size_t)sX * 3 + 2) * d.ws))[0] == 0u) return;   // (h2e_predict_tail_rows met no degenerate sum for this instance)
+    if (phase == 3) {
+        if (((const u32*)(d.jac + ((size_t)sX * 3 + 2) * d.ws))[0] == 0u) return;   // (h2e_predict_tail_rows met no degenerate sum for this instance)
+        atomicAdd(&g_scan_fallbacks, 1ull);                                       // an instance redone the lane way is a fallback
+    }
     Wd<NW> bx = ld_w_mont<FP>(v.c, M, neg_r2), by = ld_w_mont<FP>(v.c, M, neg_r2 + L + 1);
     auto r1_point = [&]() {
         Jac<NW> p;
@@ -4602,7 +4605,7 @@ extern "C" long long H2E_UNIT(h2e_engine_scan_fallbacks)(void) {
     return (long long)n;
 }
 extern "C" void H2E_UNIT(h2e_engine_set_tuning)(int key, int value) {
-    if (key >= 0 && key < 6) g_tune[key] = value;   // ([3]: also the device-side scan test mask below; bit 3 = the tail's phase 1 as one lane per instance, A/B)
+    if (key >= 0 && key < 6) g_tune[key] = value;   // ([3]: also the device-side scan test mask below; bit 4 = the tail's phase 1 as one lane per instance, A/B)
     if (key == 3) {
         u32 m = (u32)value;
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_test), &m, sizeof(m));
@@ -4765,7 +4768,7 @@ extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2E
         u32 windows = k->ecc_ops / k->pattern_len, nch = (windows + H2E_TAIL_CHUNK - 1) / H2E_TAIL_CHUNK;                           \
         dim3 g0((n_instances * nch + 63) / 64), g2((n_instances * windows + 63) / 64);                                              \
         hipLaunchKernelGGL(h2e_predict_tail<FP>, g0, block, 0, stream, *k, 0u, args_dev, inst, n_instances, fc_dev);                \
-        if (g_tune[3] & 8) {   /* A/B: phase 1 as one lane per instance */                                                          \
+        if (g_tune[3] & 16) {   /* A/B: phase 1 as one lane per instance */                                                          \
             hipLaunchKernelGGL(h2e_predict_tail<FP>, grid, block, lds_reserve, stream, *k, 1u, args_dev, inst, n_instances, fc_dev); \
         } else {                                                                                                                    \
             hipLaunchKernelGGL(h2e_predict_tail_rows<FP>, dim3((n_instances + 3) / 4), block, 0, stream, *k, args_dev, inst, n_instances); \
