@@ -2130,6 +2130,7 @@ __global__ void __launch_bounds__(64 * H2E_LEVEL_WAVES) h2e_replay_levels(H2ELau
 //  * the ceil tables sit in LDS; nothing in a round's body loads from global memory (a few hundred ops of a pairing
 //    check read cells of other kernels - they do wait);
 //  * result cells that later kernels need are stored and never waited for.
+#ifdef H2E_AB_KERNELS   // (A/B kernel: H2E_LEVEL_MODE=wave in -DH2E_DEBUG_HOOKS builds of the C-ABI layer; exp/README.md)
 template <class FP>
 __global__ void __launch_bounds__(64) h2e_replay_wave(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
     const u32 lane = threadIdx.x;
@@ -2264,6 +2265,7 @@ __global__ void __launch_bounds__(64) h2e_replay_wave(H2ELaunch L, const Instanc
         }
 #endif
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Hint store (field_chain.hpp HintStore): the cells the full expansion needs in place, straight from the hint slots.
@@ -2846,6 +2848,7 @@ WI_INLINE Wd<FP::WW> f_reduce_small(const Wd<FP::WW + 1>& A, const Wd<FP::WW>& w
     }
     return wd_resize<N>(r);
 }
+#ifdef H2E_AB_KERNELS   // (A/B kernel: H2E_FIELD_CHAIN=lanes in -DH2E_DEBUG_HOOKS builds of the C-ABI layer)
 template <class FP>
 __global__ void __launch_bounds__(128) h2e_field_chain(H2EPreKernel K, const u32* __restrict__ args, const u64* __restrict__ pool,
                                                         const InstanceDesc* __restrict__ inst, u32 n_instances) {
@@ -2993,6 +2996,7 @@ __global__ void __launch_bounds__(128) h2e_field_chain(H2EPreKernel K, const u32
         }
 #endif
 }
+#endif
 // ------------------------------------------------------------------------------------------------
 // Digit-parallel field chain.  The lane-per-record kernel above is bound by its instruction count: one lane walks a whole
 // 256 / 384-bit value through its carry chains (~600 instructions per linear combination, ~700 per Montgomery product) while
@@ -4654,18 +4658,25 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
         launch_x.x_blocks = grid.x;
         grid_x = dim3((u32)n_cu * (u32)g_tune[4]);
     }
+#ifdef H2E_AB_KERNELS
+#define H2E_AB_REPLAY_WAVE(FP)                                                                                                 \
+    if ((mode & 1) && launch->lrecs && launch->l_pair == 2) {                                                                   \
+        hipLaunchKernelGGL(h2e_replay_wave<FP>, dim3(n_instances * launch->n_strands), dim3(64),                                \
+                           (size_t)2 * H2E_WCHUNK * 32 + (64 * H2E_MAX_L * 2 + 64 * 4) * 8 + (size_t)launch->l_slots * LVals<FP>::W * 8, \
+                           stream, *launch, inst, n_instances);                                                                \
+        mode &= ~1;                                                                                                            \
+    }
+#else
+#define H2E_AB_REPLAY_WAVE(FP) \
+    if ((mode & 1) && launch->lrecs && launch->l_pair == 2) return -4;   /* a program form only A/B builds have a kernel for */
+#endif
 #define H2E_LAUNCH_FP(FP)                                                                                                     \
     if ((mode & 1) && launch->s_words) {                                                                                        \
         u32 lanes = launch->n_sops * launch->n_strands * n_instances;                                                          \
         if (lanes) hipLaunchKernelGGL(h2e_hint_store<FP>, dim3((lanes + 63) / 64), dim3(64), 0, stream, *launch, inst, n_instances); \
         mode &= ~1;                                                                                                            \
     }                                                                                                                          \
-    if ((mode & 1) && launch->lrecs && launch->l_pair == 2) {                                                                   \
-        hipLaunchKernelGGL(h2e_replay_wave<FP>, dim3(n_instances * launch->n_strands), dim3(64),                                \
-                           (size_t)2 * H2E_WCHUNK * 32 + (64 * H2E_MAX_L * 2 + 64 * 4) * 8 + (size_t)launch->l_slots * LVals<FP>::W * 8, \
-                           stream, *launch, inst, n_instances);                                                                \
-        mode &= ~1;                                                                                                            \
-    }                                                                                                                          \
+    H2E_AB_REPLAY_WAVE(FP)                                                                                                     \
     if ((mode & 1) && launch->lrecs) {                                                                                         \
         hipLaunchKernelGGL(h2e_replay_levels<FP>, dim3((n_instances * launch->n_strands + (launch->l_pair ? 1 : 0)) / (launch->l_pair ? 2 : 1)), \
                            dim3(64 * H2E_LEVEL_WAVES), (size_t)launch->l_slots * LVals<FP>::W * 8 * (launch->l_pair ? 2 : 1), stream, \
@@ -4730,6 +4741,12 @@ extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2E
     dim3 grid2((n_instances * chunks + 63) / 64);
     u32 ecc_chunks = (k->ecc_ops + ECC_CH - 1) / ECC_CH;
     dim3 grid3((n_instances * k->n_lanes * ecc_chunks + 63) / 64);
+#ifdef H2E_AB_KERNELS
+#define H2E_AB_FIELD_LANES(FP)                                                                                                     \
+    hipLaunchKernelGGL(h2e_field_chain<FP>, dim3(n_instances), dim3(128), lds, stream, *k, args_dev, (const u64*)params_dev, inst, n_instances);
+#else
+#define H2E_AB_FIELD_LANES(FP) return -4;   /* the lane-per-record form: a kernel of A/B builds only */
+#endif
 #define H2E_PREDICT_FP(FP)                                                                                                          \
     if (k->kind == H2E_PRE_FIELD_CHAIN) {   /* params_dev carries the constant pool, n_params the words per input slot */          \
         if (phase & 1)                                                                                                              \
@@ -4740,8 +4757,7 @@ extern "C" int H2E_UNIT(h2e_engine_predict)(int field_pair, int phase, const H2E
                 hipLaunchKernelGGL(h2e_field_chain_digits<FP>, dim3(n_instances), dim3((H2E_DP_WAVES + 1) * 64), lds, stream, *k, args_dev, \
                                    (const u64*)params_dev, inst, n_instances);                                                     \
             else                                                                                                                    \
-                hipLaunchKernelGGL(h2e_field_chain<FP>, dim3(n_instances), dim3(128), lds, stream, *k, args_dev,                    \
-                                   (const u64*)params_dev, inst, n_instances);                                                     \
+                H2E_AB_FIELD_LANES(FP)                                                                                              \
         }                                                                                                                           \
         if ((phase & 2) && k->hints_per_lane)                                                                                       \
             hipLaunchKernelGGL(h2e_field_finalize<FP>, dim3((n_instances * k->hints_per_lane + 63) / 64), block, 0, stream,         \

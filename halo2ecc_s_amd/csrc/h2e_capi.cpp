@@ -340,7 +340,7 @@ struct h2e_program {
             const CutSeg* cp = &c;
             fcmp.producer = [cp, &producer](uint32_t region, uint32_t row) { return producer(*cp, region, row); };
             // H2E_FIELD_CHAIN=lanes: the one-lane-per-record kernel (A/B); default: a 16-lane row per record, 60 rows per pass
-            const char* fm = getenv("H2E_FIELD_CHAIN");
+            const char* fm = dbg_env("H2E_FIELD_CHAIN");   // (debug-hook builds linked with -DH2E_AB_KERNELS engine units only: the product has no lane kernel)
             fcmp.digit_rows = !(fm && !strcmp(fm, "lanes"));
             return fcmp;
         };
@@ -1478,7 +1478,7 @@ struct h2e_program {
                     const uint32_t slot_bytes = (2 * (uint32_t)L + 4) * 8;
                     const int cap_pair = (int)((160u * 1024 - 4u * 1024) / 2 / slot_bytes), cap_single = (int)((160u * 1024 - 30u * 1024) / slot_bytes);
                     const char* mode = getenv("H2E_LEVEL_SCHED");
-                    const char* kmode = getenv("H2E_LEVEL_MODE");
+                    const char* kmode = dbg_env("H2E_LEVEL_MODE");   // ("wave": a kernel of -DH2E_AB_KERNELS engine units only)
                     const bool allow_pair = !(kmode && !strcmp(kmode, "single"));
                     wave_mode = kmode && !strcmp(kmode, "wave") && !(mode && !strcmp(mode, "levels"));
                     int forced = mode && !strcmp(mode, "classes0") ? 0 : mode && !strcmp(mode, "classes1") ? 1 : -1;
@@ -2363,10 +2363,6 @@ struct h2e_ctx {
     uint64_t small_x_lanes = 1u << 18;   // an expansion with fewer lanes is "small" (H2E_SMALL_X_LANES)
     uint32_t sched = 4;      // scheduling experiments (H2E_SCHED bit mask): 1 = a pipelined run's small fix-ups go to the slot's side
                              // stream, 2 = its small expansions too (instead of queueing on the shared expansion stream)
-    // CU partition (H2E_CU_RESERVE="n[,fixup_side]"): the value-chain streams of pipelined runs get the device's last n CUs for
-    // themselves, the expansion stream the others (fix-up stream: the expansion's CUs, or with fixup_side = 1 the chain's, 2 all)
-    uint32_t cu_reserve = 0, cu_fixup_side = 0, cu_pattern = 0;   // pattern 1: every (n_cu / n)-th CU instead of the last n
-    uint32_t cu_chain_all = 0;   // 1: the value-chain streams may use every CU (only the expansion streams are kept off the reserved ones)
     int prio_expand = 0, prio_side = 0, prio_fixup = 0;   // HIP stream priorities (H2E_STREAM_PRIORITIES="x,s,f"; lower = higher priority)
     int64_t test_skip_expansion = INT64_MIN;   // test hook (h2e_ctx_set_option): see H2E_OPT_TEST_SKIP_EXPANSION
     uint32_t last_split_segments = 0;          // segments of the last run whose expansion was split (h2e_ctx_get_stat)
@@ -2444,7 +2440,6 @@ int h2e_ctx_create(int device, h2e_ctx** out) {
     if (const char* e5 = getenv("H2E_SCHED")) c->sched = (uint32_t)atoi(e5);
     if (const char* e8 = getenv("H2E_OP_CACHE_CAP")) c->op_cache_cap = (size_t)std::max(1, atoi(e8));
     if (const char* e7 = getenv("H2E_SMALL_X_LANES")) c->small_x_lanes = (uint64_t)atoll(e7);
-    if (const char* e6 = getenv("H2E_CU_RESERVE")) sscanf(e6, "%u,%u,%u,%u", &c->cu_reserve, &c->cu_fixup_side, &c->cu_pattern, &c->cu_chain_all);
     if (const char* e3 = getenv("H2E_STREAM_PRIORITIES")) sscanf(e3, "%d,%d,%d", &c->prio_expand, &c->prio_side, &c->prio_fixup);
     *out = c;
     return 0;
@@ -2889,20 +2884,12 @@ static int ensure_device_program(h2e_ctx* ctx, h2e_program* p) {
 // caller's stream only carries the value chain and `slot.done` is recorded on the fix-up stream when the run is
 // complete (h2e_submit / h2e_wait).
 // kind: 0 expansion, 1 value chain / side, 2 fix-up
+// (CU masks for the value-chain streams - H2E_CU_RESERVE, rounds 3 and 4 - were a measured loser and are gone: a CU-masked expansion
+// stream is slow in itself, 21.5 ms per MSM step with 8 CUs set aside, and masked streams of the pairing batches did not overlap at all)
 static hipError_t make_stream(h2e_ctx* ctx, hipStream_t* out, int prio, int kind) {
-    if (!ctx->cu_reserve) return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
-    if (ctx->cu_chain_all && kind == 1) return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
-    hipDeviceProp_t prop;
-    hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
-    if (e != hipSuccess) return e;
-    uint32_t n_cu = (uint32_t)prop.multiProcessorCount, res = std::min(ctx->cu_reserve, n_cu - 1);
-    int side = kind == 2 ? (ctx->cu_fixup_side == 1 ? 1 : ctx->cu_fixup_side == 2 ? 2 : 0) : kind;
-    std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
-    for (uint32_t i = 0; i < n_cu; i++) {
-        bool chain_cu = ctx->cu_pattern == 1 ? (i % (n_cu / res) == 0 && i / (n_cu / res) < res) : i >= n_cu - res;
-        if (side == 2 || (side == 1) == chain_cu) mask[i / 32] |= 1u << (i % 32);
-    }
-    return hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
+    (void)ctx;
+    (void)kind;
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
 }
 
 static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,

@@ -437,14 +437,14 @@ def test_pairing_check_bn256(engine, oracle):
 
 
 @pytest.mark.parametrize("curve", ["bn256", "bls12_381"])
-@pytest.mark.parametrize("knob", [("H2E_FIELD_CHAIN", "lanes"), ("H2E_NO_FIELD_CHAIN", "1"), ("H2E_FIELD_NO_SINKS", "1"), ("H2E_FIELD_NO_INLINE", "1"),
+@pytest.mark.parametrize("knob", [("H2E_NO_FIELD_CHAIN", "1"), ("H2E_FIELD_NO_SINKS", "1"), ("H2E_FIELD_NO_INLINE", "1"),
                                   ("H2E_FIELD_NO_REBALANCE", "1"), ("H2E_FIELD_NO_LONG", "1"), ("H2E_FIELD_NO_PAIRS", "1"), ("H2E_FIELD_STEP", "54")],
-                         ids=["lane_kernel", "level_parallel_replay", "sinks_in_chain", "no_inlining", "no_rebalancing", "no_long_combinations", "no_product_pairs", "one_pass_rounds"])
+                         ids=["level_parallel_replay", "sinks_in_chain", "no_inlining", "no_rebalancing", "no_long_combinations", "no_product_pairs", "one_pass_rounds"])
 def test_pairing_value_chain_variants(engine, oracle, curve, knob):
     """The pairing checks' value chain has a default form (field-domain program, digit-parallel kernel, hint-only combinations
     computed after the chain, combinations inlined and depth-balanced with long records, two products per row for the eight-digit
     fields, two passes of rows per round) and fall-backs a program is compiled to when a knob says so or the field-domain compiler
-    meets an op outside its vocabulary: the lane-per-record kernel, the level-parallel replay of the integer-chip ops, the chain
+    meets an op outside its vocabulary: the level-parallel replay of the integer-chip ops, the chain
     with its sinks inside, the chain without inlining, and the round-4 forms of what round 5 changed (no re-association, no long
     combinations, one product per row, one pass per round).  Every form must give the same cells.
     (The knobs are read when the program is recorded.)"""

@@ -57,9 +57,9 @@ def test_msm_tile_no_select_shape(oracle, h2e_built, n):
     compare_shape(prog, orun)
 
 
-@pytest.mark.parametrize("knob", [("H2E_FIELD_CHAIN", "lanes"), ("H2E_NO_FIELD_CHAIN", "1"), ("H2E_FIELD_NO_SINKS", "1"), ("H2E_FIELD_NO_INLINE", "1"),
+@pytest.mark.parametrize("knob", [("H2E_NO_FIELD_CHAIN", "1"), ("H2E_FIELD_NO_SINKS", "1"), ("H2E_FIELD_NO_INLINE", "1"),
                                   ("H2E_FIELD_NO_REBALANCE", "1"), ("H2E_FIELD_NO_LONG", "1"), ("H2E_FIELD_NO_PAIRS", "1"), ("H2E_FIELD_STEP", "54")],
-                         ids=["lane_kernel", "level_parallel_replay", "sinks_in_chain", "no_inlining", "no_rebalancing", "no_long_combinations", "no_product_pairs", "one_pass_rounds"])
+                         ids=["level_parallel_replay", "sinks_in_chain", "no_inlining", "no_rebalancing", "no_long_combinations", "no_product_pairs", "one_pass_rounds"])
 def test_pairing_value_chain_variants_compile(h2e_built, knob):
     """every form of the pairing checks' value chain (tests/test_parity_gpu.py::test_pairing_value_chain_variants runs them) compiles on
     the host, for the same rows: the knobs only choose how the hints are computed"""
