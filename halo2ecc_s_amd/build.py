@@ -8,6 +8,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libh2e.so")
 DEPS = ["tape.h", "wide_int.h", "modinv62.h", "hbig.hpp", "recorder.hpp", "recorder_ecc.hpp", "recorder_pairing.hpp",
         "pairing_constants.hpp", "field_chain.hpp", os.path.join("..", "..", "include", "h2e.h")]
+# the C-ABI layer's translation unit in parts (h2e_capi.cpp includes them): only that unit depends on these
+CAPI_DEPS = ["capi_common.hpp", "program.hpp", "program_value_chain.hpp", "program_replay.hpp", "program_schedule.hpp", "run_state.hpp", "run.hpp",
+             "records_api.hpp"]
 
 
 def _stale(target, deps):
@@ -29,7 +32,7 @@ def build(force=False, verbose=True):
     for src, obj, defs in units:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, obj)
-        if force or _stale(o, [s] + deps):
+        if force or _stale(o, [s] + deps + ([os.path.join(CSRC, d) for d in CAPI_DEPS] if src == "h2e_capi.cpp" else [])):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + defs + ["-c", s, "-o", o]
             if src.endswith(".cpp"):
                 cmd.insert(1, "-x")
