@@ -153,6 +153,12 @@ extern "C" {
     pub fn h2e_export_copy_constraints(ctx: *mut c_void, p: *mut c_void, d_out: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn h2e_digest(ctx: *mut c_void, p: *mut c_void, n_instances: u32, region: c_int, d_batch: *const c_void,
                       d_digests: *mut c_void, stream: *mut c_void) -> c_int;
+    /// the per-unit record table of a multi-GPU job's ONE collective: per instance of a finished run
+    /// `h2e_unit_record_words(p)` i64 words {status, Offset (3), result point cells, 3 x 32-byte digest} at d_out + u * out_stride_words
+    /// (INTEGRATION.md "The gather": the table, with a leading unit-index column, is the send buffer of the one ncclAllGather)
+    pub fn h2e_unit_record_words(p: *const c_void) -> c_int;
+    pub fn h2e_unit_records(ctx: *mut c_void, p: *const c_void, n_instances: u32, d_base: *const c_void, d_status: *const c_void,
+                            d_digests: *const c_void, d_out: *mut c_void, out_stride_words: u32, stream: *mut c_void) -> c_int;
     /// MockProver's criterion (src/tests/mod.rs:117-132) over the arrays a run left on the device, for every instance at once:
     /// base gate, range gates + lookups, select lookup, copy constraints; `classes` = bit mask of H2E_CHECK_* (0: all)
     pub fn h2e_check(ctx: *mut c_void, p: *mut c_void, n_instances: u32, d_inputs: *const c_void, d_base: *const c_void,
