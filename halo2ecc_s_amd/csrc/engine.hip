@@ -3377,9 +3377,12 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
 #ifdef H2E_EXP_NO_OPS   // timing experiment: rounds without their records (header, prefetch, barrier only)
         if (false)
 #endif
+        u32 rw_pass = r0;
         for (u32 op = grp; op < cnt; op += H2E_DP_GROUPS) {
-            u32 rw = r0;
-            if (op != grp) rw = rec_ptr(first % H2E_WCHUNK + op)[j];   // (a round of more than H2E_DP_GROUPS records: the host does not make them)
+            const u32 rw = rw_pass;
+            // (a round of more than H2E_DP_GROUPS rows is several passes: this row's record of the next pass is read now, its LDS round
+            // trip runs under this pass's work)
+            if (op + H2E_DP_GROUPS < cnt) rw_pass = rec_ptr(first % H2E_WCHUNK + op + H2E_DP_GROUPS)[j];
             const u32 w0 = dpp_mov<H2E_DPP_ROW_BCAST(0)>(rw), w1 = dpp_mov<H2E_DPP_ROW_BCAST(1)>(rw);
             const u32 hint = w1 & 0x3ffffu;   // (bits 18-31: the sum of a linear combination's coefficients)
             const u32 w2 = dpp_mov<H2E_DPP_ROW_BCAST(2)>(rw), w3 = dpp_mov<H2E_DPP_ROW_BCAST(3)>(rw), w4 = dpp_mov<H2E_DPP_ROW_BCAST(4)>(rw);
@@ -3485,13 +3488,16 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                             else if (__builtin_amdgcn_ballot_w64(n > 2u)) combine(rwy, std::integral_constant<int, 6>());
                             else combine(rwy, std::integral_constant<int, 2>());
                         };
-                        combine_n(rwx, nt);
-                        if (__builtin_amdgcn_ballot_w64(cidx2 != 0u) != 0ull) {
-                            // (a row of this wave without a second record reads some record and takes none of its terms)
-                            u32 rw2 = rec_ptr(first % H2E_WCHUNK + cidx2)[j];
+                        // (the second record is read before the first one's terms are worked through: one LDS round trip less in the row's path;
+                        // a row of this wave without a second record reads some record and takes none of its terms)
+                        const bool any2 = __builtin_amdgcn_ballot_w64(cidx2 != 0u) != 0ull;
+                        u32 rw2 = 0u;
+                        if (any2) {
+                            rw2 = rec_ptr(first % H2E_WCHUNK + cidx2)[j];
                             rw2 = cidx2 != 0u ? rw2 : 0u;
-                            combine_n(rw2, (dpp_mov<H2E_DPP_ROW_BCAST(0)>(rw2) >> 4) & 0xfu);
                         }
+                        combine_n(rwx, nt);
+                        if (any2) combine_n(rw2, (dpp_mov<H2E_DPP_ROW_BCAST(0)>(rw2) >> 4) & 0xfu);
                         if constexpr (D == 8) {
                             u32 up_lo = dpp_mov<0x108>((u32)(u64)acc), up_hi = dpp_mov<0x108>((u32)((u64)acc >> 32));   // row_shl:8: lane j gets lane j + 8
                             acc += (i64)pack64(up_lo, up_hi);
