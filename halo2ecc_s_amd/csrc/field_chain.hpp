@@ -902,6 +902,7 @@ struct FieldCompiler {
         // depth-balanced the rounds are bound by their row capacity (bn256 Miller loop: depth 696, 50.7 k records = 940 rounds of 54,
         // 1 148 scheduled; 696 of 108) and a round costs ~1 340 cycles whatever is in it + ~31 per record: measured (64 x bn256, one
         // batch after the other) 54 rows: 4.04 ms, 80: 3.86, 108: 3.79, 160: 3.81
+        const bool pair_products = digit_rows && w_words == 4 && !getenv("H2E_FIELD_NO_PAIRS");   // (eight-digit fields: two products per row, see the emission)
         size_t STEP = digit_rows ? 108 : 64;
         if (digit_rows && getenv("H2E_FIELD_STEP")) STEP = std::max<size_t>(8, std::min<size_t>(234, (size_t)atoi(getenv("H2E_FIELD_STEP"))));
         auto cls_of = [&](uint32_t k) -> int {   // 0 light, 1 loads, 2 products, 3 divisions
@@ -929,9 +930,11 @@ struct FieldCompiler {
         for (size_t k = 0; k < N; k++)
             if (alive[k] && !is_sink[k] && left[k] == 0) ready[cls_of((uint32_t)k)].push_back((uint32_t)k);
         auto rows_of = [&](const std::vector<uint32_t>& rd) {
-            size_t n = 0;
-            n += rd.size();
-            return n;
+            size_t n_other = 0, n_mul = 0;
+            for (uint32_t k : rd)
+                if (pair_products && nodes[k].opc == F_MUL) n_mul++;
+                else n_other++;
+            return n_other + (n_mul + 1) / 2;
         };
         std::vector<std::vector<uint32_t>> rounds_rev;
         std::vector<int> rcls_rev;
@@ -941,7 +944,16 @@ struct FieldCompiler {
                 if (!ready[q].empty()) c = q;
             if (c < 0) throw std::runtime_error("field chain: scheduler stalled");
             std::vector<uint32_t> rd;
-            size_t take = std::min(ready[c].size(), STEP);
+            // capacity in ROWS: a pair of products is one row
+            size_t take = 0, n_other = 0, n_mul = 0;
+            while (take < ready[c].size()) {
+                const bool paired = pair_products && nodes[ready[c][ready[c].size() - 1 - take]].opc == F_MUL;
+                const size_t o2 = n_other + (paired ? 0 : 1), m2 = n_mul + (paired ? 1 : 0);
+                if (o2 + (m2 + 1) / 2 > STEP) break;
+                n_other = o2;
+                n_mul = m2;
+                take++;
+            }
             rd.assign(ready[c].end() - take, ready[c].end());
             ready[c].resize(ready[c].size() - take);
             for (uint32_t k : rd) {
@@ -1053,7 +1065,6 @@ struct FieldCompiler {
         size_t term_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         // Eight-digit fields (bn256 Fq, bls12_381 Fr): a product uses half of its row's 16 lanes, so the products of a round go two to
         // a row (engine.hip DigitRow::mont_mul2): record = [MUL | 1 << 4 | dst << 16, hint, a | a2 << 16, b | b2 << 16, dst2, hint2].
-        const bool pair_products = digit_rows && w_words == 4 && !getenv("H2E_FIELD_NO_PAIRS");
         std::map<uint32_t, uint32_t> partner;   // first product of a paired row -> the second
         for (size_t r = 0; r < rounds.size(); r++) {
             auto& rd = rounds[r];
