@@ -286,7 +286,6 @@ struct FieldCompiler {
                 auto it = partial_of.find(g);
                 if (it != partial_of.end()) {
                     pn = it->second;
-                    depth[(size_t)pn] = std::max(depth[(size_t)pn], gd + 1);   // (its terms may have moved since it was made: the second pass below)
                 } else {
                     pn = new_node(F_LIN);
                     nodes[(size_t)pn].terms = g;
@@ -367,85 +366,9 @@ struct FieldCompiler {
             nodes[k].terms = r;
             depth[k] = dep_depth(nodes[k]) + 1;
         }
-        // Long records only where the path needs them.  A long combination (or any fat record) makes ITS round as long as its row - half
-        // of a bn256 check's rounds held one - but only the combinations on a critical path gain from the level it saves.  Second pass:
-        // latest level every node may sit at without lengthening the program (from the hinted nodes backwards), then, in dependency
-        // order with the levels kept up to date, every long combination whose plain form - one more partial sum - still fits its
-        // latest level goes back to a record of F_MAX_TERMS entries (H2E_FIELD_LONG_EVERYWHERE=1: the first pass's choice, A/B).
-        if (KL > K && !getenv("H2E_FIELD_LONG_EVERYWHERE")) {
-            const size_t N1 = nodes.size();
-            std::vector<std::vector<int>> succ(N1);
-            std::vector<uint8_t> alive(N1, 0);
-            {
-                std::vector<int> st;
-                for (size_t k = 0; k < N1; k++)
-                    if (nodes[k].hint != 0xffffffffu) {
-                        alive[k] = 1;
-                        st.push_back((int)k);
-                    }
-                while (!st.empty()) {
-                    int k = st.back();
-                    st.pop_back();
-                    const Node& nd = nodes[(size_t)k];
-                    auto see = [&](int x) {
-                        if (x < 0) return;
-                        succ[(size_t)x].push_back(k);
-                        if (!alive[(size_t)x]) {
-                            alive[(size_t)x] = 1;
-                            st.push_back(x);
-                        }
-                    };
-                    see(nd.a);
-                    see(nd.b);
-                    see(nd.c);
-                    for (auto& t : nd.terms) see(t.first);
-                }
-            }
-            uint32_t crit = 0;
-            for (size_t k = 0; k < N1; k++)
-                if (alive[k]) crit = std::max(crit, depth[k]);
-            // latest level: by decreasing depth (a successor is deeper than its operands)
-            std::vector<uint32_t> order(N1), alap(N1, crit);
-            for (size_t k = 0; k < N1; k++) order[k] = (uint32_t)k;
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return depth[x] > depth[y]; });
-            for (uint32_t k : order) {
-                if (!alive[k]) continue;
-                for (int sx : succ[k])
-                    if (alive[(size_t)sx]) alap[k] = std::min(alap[k], alap[(size_t)sx] - 1);
-            }
-            // dependency order = increasing (current) depth; levels recomputed from final operands as the pass goes
-            std::reverse(order.begin(), order.end());
-            std::function<uint32_t(int)> level_of = [&](int x) -> uint32_t { return depth[(size_t)x]; };
-            size_t n_back = 0, n_long = 0;
-            for (uint32_t k : order) {
-                if (!alive[k]) continue;
-                Node& nd = nodes[k];
-                depth[k] = dep_depth(nd) + 1;
-                if (nd.opc != F_LIN || nd.terms.size() <= K) continue;
-                n_long++;
-                // the plain form: the earliest terms into partial sums; a level deeper at most
-                TermsByDepth T;
-                for (auto& t : nd.terms) T.push_back({depth[(size_t)t.first], t});
-                std::stable_sort(T.begin(), T.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
-                std::vector<uint32_t> dd;
-                for (auto& e : T) dd.push_back(e.first);
-                if (tree_depth(dd, K) > alap[k]) continue;   // it IS on a critical path
-                const size_t before = nodes.size();
-                merge_earliest(T, K);
-                for (size_t q = before; q < nodes.size(); q++) {   // (the new partial sums: alive, never long, as late as their reader allows)
-                    alive.push_back(1);
-                    alap.push_back(alap[k] - 1);
-                    succ.emplace_back();
-                }
-                std::vector<std::pair<int, int>> r;
-                for (auto& e : T) r.push_back(e.second);
-                std::sort(r.begin(), r.end());
-                nodes[k].terms = r;   // (nd may dangle: nodes grew)
-                depth[k] = dep_depth(nodes[k]) + 1;
-                n_back++;
-            }
-            if (getenv("H2E_FIELD_STATS")) fprintf(stderr, "field chain: %zu of %zu long combinations back to plain records (not on a critical path)\n", n_back, n_long);
-        }
+        // (Tried in round 5 and taken out again: a second pass that turned long combinations OFF a critical path - latest levels from the
+        // hinted nodes backwards - back into plain records; 18-55 % of them, rounds holding one 333 -> 273 and 339 -> 245 of a bn256 check's
+        // - and no measurable change of the chain, gpurun_out/r5_18: a round is not as long as its fattest row, it is as long as its two passes.)
         // hinted combinations nobody reads: over the non-combination nodes themselves (any number of terms: a sink)
         if (sinks_enabled) {
             std::vector<uint8_t> read(nodes.size(), 0);
