@@ -252,7 +252,7 @@ def main():
     if args.ring is None:
         # MSM: two 110 GB buffer sets; pairing checks: four runs in flight - a run's value chain (one 1024-thread workgroup per
         # check, latency-bound on its CU) under the expansions of the others; deeper rings only make the chains fight each other
-        # (round 4, exp/r4_gpu41.sh: 16 x bls12-381 1.75 ms / step at 3, 1.6 at 4, 1.8 at 5; 8 x bn256 1.40 / 1.11 / 1.29; 64 x bn256 the same at 3 and 4)
+        # (round 4: 16 x bls12-381 1.75 ms / step at 3, 1.6 at 4, 1.8 at 5; round 5, exp/r5_sessions.md 11: 1.63 / 1.61 / 1.81, 8 x bn256 1.19 / 0.96 / 1.18)
         args.ring = {"msm": 2, "pairing_bn256": 4, "pairing_bls12_381": 4}[args.workload]
     if args.job_tiles:
         args.digest = True
@@ -396,7 +396,6 @@ def main():
     step_no = [0]
     timing = [False]
     pending = []   # (job, ring slot, step index) submitted and not yet waited for
-    offsets = torch.tensor([prog.base_offset, prog.range_offset, prog.select_offset], dtype=torch.int64, device=dev)
     digests = [torch.zeros((3, units, 4), dtype=torch.int64, device=dev) for _ in range(ring)]
     digest_any = [None]
     # Per-unit records {status, Offset, result point cells, 32-byte digest per advice array} of every timed step, built on the
