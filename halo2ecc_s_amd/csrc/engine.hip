@@ -4194,29 +4194,22 @@ __global__ void __launch_bounds__(256) h2e_export_columns(const ulonglong2* __re
         if (i < ni && q < nr * 2 && assigned[q >> 1]) tile[i * PITCH + q] = in[(((row0 + (q >> 1)) * COLS + col) * 2 + (q & 1)) * n_inst + inst0 + i];
     }
     __syncthreads();
-    // Montgomery form: a thread owns a cell (both halves), the result goes back into the tile
-    if (mont) {
-        Mont<4> M = mont_n(fc);
-        for (u32 p = threadIdx.x; p < (u32)TR * TI; p += 256) {
-            u32 i = p / TR, r = p % TR;
-            if (i >= ni || r >= nr || !assigned[r]) continue;
-            ulonglong2 lo = tile[i * PITCH + 2 * r], hi = tile[i * PITCH + 2 * r + 1];
+    Mont<4> M = mont_n(fc);
+    for (u32 p = threadIdx.x; p < (u32)TR * TI; p += 256) {
+        u32 i = p / TR, r = p % TR;
+        if (i >= ni || r >= nr) continue;
+        ulonglong2 lo = tile[i * PITCH + 2 * r], hi = tile[i * PITCH + 2 * r + 1];
+        if (!assigned[r]) lo = hi = make_ulonglong2(0, 0);
+        if (mont) {
             Fe x;
             x.v[0] = lo.x; x.v[1] = lo.y; x.v[2] = hi.x; x.v[3] = hi.y;
             x = mont_mul<4>(M, x, M.r2);
-            tile[i * PITCH + 2 * r] = make_ulonglong2(x.v[0], x.v[1]);
-            tile[i * PITCH + 2 * r + 1] = make_ulonglong2(x.v[2], x.v[3]);
+            lo = make_ulonglong2(x.v[0], x.v[1]);
+            hi = make_ulonglong2(x.v[2], x.v[3]);
         }
-        __syncthreads();
-    }
-    // stores: a lane = one 16-byte piece (row, half) of ONE instance's run, so a wave instruction writes an instance's whole 1 KB run of
-    // the column (round 5; until then a lane wrote its cell's two halves with two instructions, each of which filled every other 16 bytes
-    // of the lines it touched)
-    for (u32 p = threadIdx.x; p < (u32)PER_I * TI; p += 256) {
-        u32 i = p / PER_I, q = p % PER_I;   // q = r * 2 + half
-        if (i >= ni || q >= nr * 2) continue;
-        ulonglong2 v = assigned[q >> 1] ? tile[i * PITCH + q] : make_ulonglong2(0, 0);
-        out[(((u64)(inst0 + i) * COLS + col) * rows + row0) * 2 + q] = v;
+        u64 cell = ((u64)(inst0 + i) * COLS + col) * rows + row0 + r;
+        out[cell * 2] = lo;
+        out[cell * 2 + 1] = hi;
     }
 }
 extern "C" int h2e_engine_export(uint32_t cols, int columns, int mont, const void* in, void* out, const uint8_t* flags, uint64_t rows,
