@@ -2780,10 +2780,14 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_predict(H2EPreKernel 
         u32 sz = a[0];
         u32 j0 = K.scratch_begin + lane * (1u << sz);
         const u32* prm = v.c.params;
+        // (statically indexed: a loop with a run-time trip count put this table into scratch memory - 336 / 544 bytes per lane - in the
+        // run's serial head; a group has at most five points, the ones beyond sz are never selected)
         Wd<NW> px[5], py[5];
-        for (u32 j = 0; j < sz && j < 5; j++) {
-            px[j] = ld_w_mont<FP>(v.c, M, prm + j * NR);
-            py[j] = ld_w_mont<FP>(v.c, M, prm + j * NR + L + 1);
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const u32 jj = (u32)j < sz ? (u32)j : 0u;
+            px[j] = ld_w_mont<FP>(v.c, M, prm + jj * NR);
+            py[j] = ld_w_mont<FP>(v.c, M, prm + jj * NR + L + 1);
         }
         Jac<NW> init;
         init.x = ld_w_mont<FP>(v.c, M, prm + sz * NR);
