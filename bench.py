@@ -219,8 +219,8 @@ def main():
                          "dealt round-robin over the N ranks (SURVEY 8d items 4-5: 8 bn256 / 2 bls12_381 checks per GPU at N = 8; shares may be ragged)")
     ap.add_argument("--total-units", type=int, default=None, help="--scaling strong: units of the whole job (default: the workload's BASELINE batch)")
     ap.add_argument("--ring", type=int, default=None, help="output-buffer sets steps rotate through = runs in flight (default: 2 for the MSM - step k+1's value chain runs under "
-                    "step k's expansion, 2 x 110 GB of arrays; 4 for the pairing checks: their value chains are latency-bound, but a fifth run in flight slows "
-                    "every chain by more than it hides; 1: h2e_run, no overlap)")
+                    "step k's expansion, 2 x 110 GB of arrays; 8 for the pairing checks (4 for a full 64-check bn256 batch): their value chains are latency-bound on one CU per check; "
+                    "1: h2e_run, no overlap)")
     ap.add_argument("--digest", action="store_true", help="consume every step's arrays with the stream digest (h2e_submit_digest; streaming-job mode, configs[2])")
     ap.add_argument("--job-tiles", type=int, default=None, help="run one MSM job of this many tiles over all ranks (2^20 points = 1024; `--job-tiles 1024 --gpus 8` is configs[2]): "
                     "steps = job_tiles / (units x gpus), every tile with its own inputs, digest on, one gather of the job's records at the end")
@@ -250,10 +250,14 @@ def main():
     if args.units is None:
         args.units = DEFAULT_UNITS[args.workload]
     if args.ring is None:
-        # MSM: two 110 GB buffer sets; pairing checks: four runs in flight - a run's value chain (one 1024-thread workgroup per
-        # check, latency-bound on its CU) under the expansions of the others; deeper rings only make the chains fight each other
-        # (round 4: 16 x bls12-381 1.75 ms / step at 3, 1.6 at 4, 1.8 at 5; round 5, exp/r5_sessions.md 11: 1.63 / 1.61 / 1.81, 8 x bn256 1.19 / 0.96 / 1.18)
-        args.ring = {"msm": 2, "pairing_bn256": 4, "pairing_bls12_381": 4}[args.workload]
+        # MSM: two 110 GB buffer sets.  Pairing checks: eight runs in flight - a run's value chain (one 1024-thread workgroup per
+        # check) is latency-bound on its CU for ~2 ms and a batch of a few checks leaves the rest of the GPU to the expansions of the
+        # runs before it.  (Rounds 4-5 measured "a fifth run in flight loses" - with W = 4 warm-up steps the slots beyond the fourth
+        # did their first-use allocations inside the timed region; with every slot primed, round 5: 8 x bn256 0.99 / 0.81 / 0.78 ms per
+        # step at 4 / 6 / 8, 2 x bls12_381 0.89 / 0.67 / 0.58, 16 x bls12_381 1.56 / 1.64 / 1.50, 64 x bn256 3.27 / 3.25 / 3.28; 12 runs in
+        # flight want more hardware queues than there are: 1.8-6 ms)
+        # (a full 64-check bn256 batch fills the GPU by itself: four - 20 GB of arrays per buffer set)
+        args.ring = {"msm": 2, "pairing_bn256": 8 if args.units <= 32 else 4, "pairing_bls12_381": 8}[args.workload]
     if args.job_tiles:
         args.digest = True
         args.steps = max(1, args.job_tiles // (args.units * max(1, args.gpus)))
@@ -267,7 +271,9 @@ def main():
         sys.exit(subprocess.run(cmd).returncode)
     # pipelined runs use several HIP streams (caller's, expansion, fix-up, a chain and a side stream per job slot): more than
     # the 4 hardware queues a process gets by default, and streams that share a queue serialise
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32" if args.ring > 8 else "16")
+    # (per job slot: a chain, an expansion / completion and - some programs - a side stream; + the caller's, the shared expansion,
+    # small-expansion and fix-up streams)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(16, 3 * args.ring + 6)))
     if world > 1 and args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     total_units = None
@@ -470,6 +476,11 @@ def main():
         while pending:
             retire(*pending.pop(0))
 
+    # Slot priming, before the W warm-up steps and like them untimed: a job slot's first run allocates its workspace and creates its
+    # streams (~10 ms of host work each), so every one of the `ring` slots runs once here - with W < ring the timed region used to
+    # pay for the slots the warm-up had not reached (what made rings deeper than W = 4 look slow in rounds 4-5).
+    for _ in range(max(0, ring - args.warmup) if ring > 1 else 0):
+        step()
     for _ in range(args.warmup):
         step()
     drain()

@@ -8,6 +8,7 @@
 #include <array>
 #include <set>
 #include <memory>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -46,6 +47,8 @@ extern "C" int h2e_engine_copy_constraints(const uint32_t* perms, uint64_t n, vo
 extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances, uint32_t bits, hipStream_t stream);
 extern "C" int h2e_engine_check_patch_values(const uint32_t* patches, uint32_t n_patches, const uint64_t* inputs, uint32_t n_slots, uint32_t slot_words,
                                              uint32_t n_instances, uint64_t* out, hipStream_t stream);   // checker.hip
+extern "C" int h2e_engine_instance_table(void* d_table, uint32_t n_instances, const uint64_t* first9, const uint64_t* stride9, uint32_t ws,
+                                         hipStream_t stream);
 extern "C" int h2e_engine_unit_records(const void* base, const void* status, const void* digests, void* out, const uint64_t* offsets3,
                                        const uint32_t* refs, uint32_t limbs, int has_point, uint32_t n_instances, uint32_t out_stride,
                                        hipStream_t stream);   // handoff.hip
@@ -95,9 +98,53 @@ static FILE* dbg_log_file() {
     static FILE* f = getenv("H2E_DEBUG_LOG") ? fopen(getenv("H2E_DEBUG_LOG"), "a") : nullptr;
     return f;
 }
+static double dbg_host_us() {   // host clock of a log line: the gap to the next line is what the call in between cost the host
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 static void dbg_log(const char* what, int a, unsigned b, unsigned c, unsigned d, hipStream_t st) {
     if (FILE* f = dbg_log_file()) {
-        fprintf(f, "run %llu seg %d %s %d n_ops/kind %u strands/lanes %u n_sub %u stream %p\n", g_dbg_run, g_dbg_si, what, a, b, c, d, (void*)st);
+        fprintf(f, "run %llu seg %d %s %d n_ops/kind %u strands/lanes %u n_sub %u stream %p host_us %.1f\n", g_dbg_run, g_dbg_si, what, a, b, c, d, (void*)st, dbg_host_us());
+        fflush(f);
+    }
+}
+// H2E_DEBUG_STAMPS=<file>: a DEVICE timeline that does not slow the host the way a profiler's kernel trace does (rocprofv3 costs a pipelined
+// submission ~1 ms of host time: the trace of a small batch then shows the host, not the GPU).  One-lane kernels (handoff.hip
+// h2e_engine_stamp) write the device's 100 MHz clock where the profiling events are recorded - per launched segment: 4 li + {0 chain begin,
+// 1 chain end, 2 expansion begin, 3 expansion end}; 1000 = the run is complete, 1001 = its first kernel - and h2e_debug_dump_stamps()
+// writes "run tag ticks" lines.
+extern "C" int h2e_engine_stamp(void* slot, hipStream_t stream);
+struct DbgStamps {
+    uint64_t* d = nullptr;
+    std::vector<std::pair<unsigned long long, unsigned>> labels;
+    size_t cap = 1u << 18;
+};
+static DbgStamps g_dbg_stamps;
+static void dbg_stamp(unsigned tag, hipStream_t st) {
+    static const bool on = getenv("H2E_DEBUG_STAMPS") != nullptr;
+    if (!on) return;
+    DbgStamps& S = g_dbg_stamps;
+    if (!S.d && hipMalloc((void**)&S.d, S.cap * 8) != hipSuccess) return;
+    if (S.labels.size() >= S.cap) return;
+    (void)h2e_engine_stamp(S.d + S.labels.size(), st);
+    S.labels.emplace_back(g_dbg_run, tag);
+}
+extern "C" int h2e_debug_dump_stamps() {
+    DbgStamps& S = g_dbg_stamps;
+    const char* path = getenv("H2E_DEBUG_STAMPS");
+    if (!path || !S.d) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    std::vector<uint64_t> h(S.labels.size());
+    if (hipMemcpy(h.data(), S.d, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    FILE* f = fopen(path, "w");
+    if (!f) return -1;
+    for (size_t i = 0; i < h.size(); i++) fprintf(f, "%llu %u %llu\n", S.labels[i].first, S.labels[i].second, (unsigned long long)h[i]);
+    fclose(f);
+    return (int)h.size();
+}
+#define DBG_STAMP(tag, st) dbg_stamp((unsigned)(tag), st)
+static void dbg_mark(const char* what) {
+    if (FILE* f = dbg_log_file()) {
+        fprintf(f, "run %llu mark %s host_us %.1f\n", g_dbg_run, what, dbg_host_us());
         fflush(f);
     }
 }
@@ -122,6 +169,7 @@ static int dbg_engine_predict(int fpair, int phase, const H2EPreKernel* k, const
 #else
 #define H2E_LAUNCH h2e_engine_launch
 #define H2E_PREDICT h2e_engine_predict
+#define DBG_STAMP(tag, st) ((void)0)
 #endif
 
 const h2e::FieldPair& field_pair(int id) { return h2e::field_pair_of(id); }
@@ -139,6 +187,7 @@ struct InstanceDescHost {  // must match engine.hip InstanceDesc
     uint32_t ws;     // words between consecutive workspace value slots = n_instances * words per slot (instance-minor)
     uint32_t pad_;
 };
+static_assert(sizeof(InstanceDescHost) == 80, "handoff.hip h2e_instance_table_k writes the table as ten 64-bit words per instance");
 
 }  // namespace
 

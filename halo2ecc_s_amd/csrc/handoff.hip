@@ -6,6 +6,11 @@
 //    caller reads back - so this is the build's definition; one kernel, one lane per (unit, word), straight into the buffer the
 //    host hands to ncclAllGather.
 //
+//  * h2e_engine_instance_table - a run's table of per-instance descriptors (engine.hip InstanceDesc: where instance i's cells, inputs, status
+//    word and workspace start), written ON the device from the nine base addresses and strides the host knows: every field is affine in
+//    i.  Rounds 1-4 filled a pinned host table per job slot and copied it; the host then had to wait (hipEventSynchronize) until the
+//    slot's previous copy had been read before rewriting the table - in a pipelined job that wait was where every submission stalled.
+//
 // A translation unit of its own (seconds to compile; engine.hip is minutes per field pair).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -68,5 +73,43 @@ extern "C" int h2e_engine_unit_records(const void* base, const void* status, con
     const u32 R = 1 + 3 + 4 * limbs + 1 + 12;
     const u32 threads = n_instances * R;
     hipLaunchKernelGGL(h2e_unit_records_k, dim3((threads + 255) / 256), dim3(256), 0, stream, a);
+    return (int)hipGetLastError();
+}
+
+struct H2EInstTableArgs {
+    u64 first[9];    // address of instance 0's: base, range, select cells, inputs, status word, hints, nd, jac, sel workspace
+    u64 stride[9];   // bytes from one instance to the next
+    u64* out;        // [n_instances][10 words]: the nine pointers, then {ws, 0} as two 32-bit words
+    u32 ws;
+    u32 n_instances;
+};
+__global__ void __launch_bounds__(256) h2e_instance_table_k(H2EInstTableArgs a) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 i = t / 10u, w = t % 10u;
+    if (i >= a.n_instances) return;
+    a.out[(size_t)i * 10u + w] = w < 9u ? a.first[w] + (u64)i * a.stride[w] : (u64)a.ws;
+}
+extern "C" int h2e_engine_instance_table(void* d_table, uint32_t n_instances, const uint64_t* first9, const uint64_t* stride9, uint32_t ws,
+                                         hipStream_t stream) {
+    if (n_instances == 0) return 0;
+    H2EInstTableArgs a;
+    for (int k = 0; k < 9; k++) {
+        a.first[k] = first9[k];
+        a.stride[k] = stride9[k];
+    }
+    a.out = (u64*)d_table;
+    a.ws = ws;
+    a.n_instances = n_instances;
+    const u32 threads = n_instances * 10u;
+    hipLaunchKernelGGL(h2e_instance_table_k, dim3((threads + 255) / 256), dim3(256), 0, stream, a);
+    return (int)hipGetLastError();
+}
+
+// (debug builds: the device's constant-rate clock at this point of a stream - capi_common.hpp H2E_DEBUG_STAMPS)
+__global__ void __launch_bounds__(64) h2e_stamp_k(u64* slot) {
+    if (threadIdx.x == 0) *slot = wall_clock64();
+}
+extern "C" int h2e_engine_stamp(void* slot, hipStream_t stream) {
+    hipLaunchKernelGGL(h2e_stamp_k, dim3(1), dim3(64), 0, stream, (u64*)slot);
     return (int)hipGetLastError();
 }

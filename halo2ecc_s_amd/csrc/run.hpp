@@ -217,6 +217,9 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     }
 #endif
     ctx->n_runs++;
+#ifdef H2E_DEBUG_HOOKS
+    g_dbg_run = ctx->n_runs;
+#endif
     ctx->last_slot = slot_index;
     if (slot_out) *slot_out = slot_index;
     if (!J.done) HIP_TRY(hipEventCreateWithFlags(&J.done, hipEventDisableTiming));
@@ -231,15 +234,8 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             J.d_inst = nullptr;
         }
         HIP_TRY(hipMalloc((void**)&J.d_inst, (size_t)n_instances * sizeof(InstanceDescHost)));
-        if (J.h_inst) HIP_TRY(hipHostFree(J.h_inst));
-        J.h_inst = nullptr;
-        HIP_TRY(hipHostMalloc((void**)&J.h_inst, (size_t)n_instances * sizeof(InstanceDescHost), hipHostMallocDefault));
         J.inst_cap = n_instances;
     }
-    // the table is uploaded from pinned memory by an asynchronous copy: the copy of the slot's previous run (ring depth
-    // submissions ago) must have read it before the host writes the new one - a host wait that never waits in a pipeline
-    if (!J.upload_ev) HIP_TRY(hipEventCreateWithFlags(&J.upload_ev, hipEventDisableTiming));
-    else HIP_TRY(hipEventSynchronize(J.upload_ev));
     size_t slot_words = r.fp.w_words;
     // workspace
     auto grow = [&](uint64_t** buf, size_t* have, size_t need) -> hipError_t {
@@ -266,23 +262,19 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     HIP_TRY(grow(&J.ws_nd, &J.ws_nd_words, std::max<size_t>(1, nd_words * n_instances)));
     HIP_TRY(grow(&J.ws_jac, &J.ws_jac_words, std::max<size_t>(1, jac_words * n_instances)));
     HIP_TRY(grow(&J.ws_sel, &J.ws_sel_words, std::max<size_t>(1, sel_words * n_instances)));
-    for (uint32_t i = 0; i < n_instances; i++) {
-        InstanceDescHost& d = J.h_inst[i];
+    {   // the table of per-instance descriptors, written on the device (handoff.hip: every field is affine in the instance index; no
+        // pinned staging table, so nothing here makes the host wait for an earlier run of the slot)
         // batch-interleaved advice arrays [row][col][half][instance][2 words]: instance i starts 2 words in
-        d.base = (uint64_t*)d_base + (size_t)i * 2;
-        d.range = (uint64_t*)d_range + (size_t)i * 2;
-        d.select = (uint64_t*)d_select + (size_t)i * 2;
-        d.inputs = (const uint64_t*)d_inputs + (size_t)i * r.n_input_slots * slot_words;
-        d.status = (uint32_t*)d_status + i;
-        d.hints = J.ws_hints + (size_t)i * wsw;
-        d.nd = J.ws_nd + (size_t)i * wsw;
-        d.jac = J.ws_jac + (size_t)i * wsw;
-        d.sel = J.ws_sel + (size_t)i * wsw;
-        d.ws = (uint32_t)(n_instances * wsw);
-        d.pad_ = 0;
+        const uint64_t first[9] = {(uint64_t)d_base, (uint64_t)d_range, (uint64_t)d_select, (uint64_t)d_inputs, (uint64_t)d_status,
+                                   (uint64_t)J.ws_hints, (uint64_t)J.ws_nd, (uint64_t)J.ws_jac, (uint64_t)J.ws_sel};
+        const uint64_t stride[9] = {16, 16, 16, (uint64_t)r.n_input_slots * slot_words * 8, 4, wsw * 8, wsw * 8, wsw * 8, wsw * 8};
+        int trc = h2e_engine_instance_table(J.d_inst, n_instances, first, stride, (uint32_t)(n_instances * wsw), sa);
+        if (trc != 0) return fail(H2E_ERR_HIP, std::string("instance table kernel launch failed: ") + hipGetErrorString((hipError_t)trc));
     }
-    HIP_TRY(hipMemcpyAsync(J.d_inst, J.h_inst, (size_t)n_instances * sizeof(InstanceDescHost), hipMemcpyHostToDevice, sa));
-    HIP_TRY(hipEventRecord(J.upload_ev, sa));
+#ifdef H2E_DEBUG_HOOKS
+    dbg_mark("table queued");
+#endif
+    DBG_STAMP(1001u, sa);
     // stream digest: the expansion and fix-up kernels of this run add to it (every other stream starts behind this point)
     if (d_digests) {
         if (J.dg_cap < n_instances) {
@@ -329,7 +321,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     std::vector<hipEvent_t> seg_ev(r.segments.size(), nullptr), side_done(r.segments.size(), nullptr);
     hipEvent_t run_begin = sync_event();
     HIP_TRY(hipEventRecord(run_begin, sa));
-    bool used_se = false, used_small = false;
+    bool used_se = false, used_small = false, used_x = false;
     H2ELaunch pending_L;
     uint32_t pending_li = 0;
     bool have_pending = false;
@@ -347,10 +339,10 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         hipEvent_t e0 = sync_event();
         HIP_TRY(hipEventRecord(e0, sa));
         HIP_TRY(hipStreamWaitEvent(sp, e0, 0));
-        if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 2), sp));
+        if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 2), sp)); DBG_STAMP(4 * pending_li + 2, sp);
         int prc2 = H2E_LAUNCH((int)pending_L.field_pair, 2, &pending_L, J.d_inst, n_instances, ctx->d_fc[pending_L.field_pair], sp);
         if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
-        if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 3), sp));
+        if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 3), sp)); DBG_STAMP(4 * pending_li + 3, sp);
         if (pending_L.n_fixups) {
             hipEvent_t e1 = sync_event();
             HIP_TRY(hipEventRecord(e1, sp));
@@ -418,7 +410,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             }
         uint32_t li = J.n_launches;
         if (J.x_kernels.size() <= li) J.x_kernels.resize(li + 1, 1);
-        if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 0), sa));
+        if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 0), sa)); DBG_STAMP(4 * li + 0, sa);
         // this segment's predictors: chains first, then (after the early starters below) their finalize kernels
         for (size_t pi = 0; pi < r.pre_kernels.size(); pi++) {
             const h2e::PreKernel& pk = r.pre_kernels[pi];
@@ -576,7 +568,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             // inversion behind every one of them made that stream the step (16 x bls12_381 at four runs in flight 1.81 -> 1.58 ms, 8 x
             // bn256 1.40 -> 1.10, 2 x bls12_381 1.22 -> 0.95; the MSM, whose small expansions run beside big ones: no difference, left
             // as it was).  H2E_SCHED & 64: in their stream as before (A/B)
-            if (fixup_in_stream && (join || (run_has_big_x && !(ctx->sched & 128u)) || (ctx->sched & 64u))) return launch_one(4, f, st);   // (128: to the fix-up stream whatever the run holds - experiment)
+            if (fixup_in_stream && (join || (run_has_big_x && !(ctx->sched & 128u)) || (ctx->sched & 64u) || (used_x && st == J.x_stream))) return launch_one(4, f, st);   // (128: to the fix-up stream whatever the run holds - experiment)
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, st));
             HIP_TRY(hipStreamWaitEvent(sd, e, 0));
@@ -605,7 +597,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         auto expand_fixup = [&](hipStream_t st) -> int { return fixup_part(st, split_sub ? part_fix[part_fix.size() - 2] : 0, s.n_fixups); };
         if (L.n_sub > 1) {
             if ((lrc = launch(1, sa))) return lrc;
-            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa)); DBG_STAMP(4 * li + 1, sa);
             if (have_pending && !hold_longer && (lrc = flush_pending())) return lrc;
             // (H2E_SCHED & 16: pipelined runs do not hold the expansion back - measured 0.35 ms per step worse)
             if (s.expand_after_next && si + 1 < r.segments.size() && p->seg_n_sub[si + 1] > 1 && (join || !(ctx->sched & 16u))) {
@@ -629,15 +621,25 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             if (small_x && !join && (ctx->sched & 4u)) {
                 // pipelined: the shared expansion stream only carries the big expansions - the small ones (latency-bound: a few
                 // hundred waves and their inverse fix-ups) run beside them on their own stream instead of between them
-                if (!ctx->small_stream) HIP_TRY(make_stream(ctx, &ctx->small_stream, ctx->prio_expand, 0));
-                sx = ctx->small_stream;
-                used_small = true;
+                if (!run_has_big_x && !(ctx->sched & 256u)) {
+                    // ... and a run WITHOUT a big expansion (a pairing batch of a few checks) keeps them in a stream of its slot, fix-ups
+                    // behind them: on one stream for all runs in flight the small expansions - one wave per SIMD each, 0.2-0.35 ms, plus
+                    // ~0.1 ms of event latency between them - came to 0.95 ms per run and WERE the step of the 8-GPU shares (device
+                    // timeline, exp/dev_timeline.py: a run's expansions started 3.3 ms after its chain had finished).  H2E_SCHED & 256: off (A/B)
+                    if (!J.x_stream) HIP_TRY(make_stream(ctx, &J.x_stream, ctx->prio_expand, 0));
+                    sx = J.x_stream;
+                    used_x = true;
+                } else {
+                    if (!ctx->small_stream) HIP_TRY(make_stream(ctx, &ctx->small_stream, ctx->prio_expand, 0));
+                    sx = ctx->small_stream;
+                    used_small = true;
+                }
             }
             fixup_in_stream = small_x;
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, sa));
             HIP_TRY(hipStreamWaitEvent(sx, e, 0));
-            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sx));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sx)); DBG_STAMP(4 * li + 2, sx);
             // test hook (H2E_OPT_TEST_SKIP_EXPANSION): leave out the expansion of cut segment <si> (or, with -1, of every cut
             // segment but the last): whatever the value chain reads must have been stored by the value chain itself.  The
             // run's status words get H2E_ST_TEST_HOOK, so its arrays cannot be mistaken for a witness.
@@ -662,35 +664,35 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
                 }
             }
             if (!skip_x && (lrc = expand(sx))) return lrc;
-            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sx));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sx)); DBG_STAMP(4 * li + 3, sx);
             if (!skip_x && (lrc = expand_fixup(sx))) return lrc;
         } else if (p->seg_side_dep[si] != -2) {
             // runs beside the value chain: after the last segment it reads, before the first segment that reads it
             int32_t depi = p->seg_side_dep[si];
             HIP_TRY(hipStreamWaitEvent(se, depi >= 0 && seg_ev[depi] ? seg_ev[depi] : run_begin, 0));
             used_se = true;
-            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
-            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), se));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa)); DBG_STAMP(4 * li + 1, sa);
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), se)); DBG_STAMP(4 * li + 2, se);
             if ((lrc = launch(2, se))) return lrc;
-            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), se));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), se)); DBG_STAMP(4 * li + 3, se);
             if ((lrc = fixup_after(se))) return lrc;
             side_done[si] = sync_event();
             HIP_TRY(hipEventRecord(side_done[si], se));
         } else if (p->seg_deferrable[si]) {
             // nothing later reads this segment's cells: off the critical stream
-            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa)); DBG_STAMP(4 * li + 1, sa);
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, sa));
             HIP_TRY(hipStreamWaitEvent(sb, e, 0));
-            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sb));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sb)); DBG_STAMP(4 * li + 2, sb);
             if ((lrc = launch(2, sb))) return lrc;
-            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sb));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sb)); DBG_STAMP(4 * li + 3, sb);
             if ((lrc = fixup_after(sb))) return lrc;
         } else {
-            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa));
-            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sa));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 1), sa)); DBG_STAMP(4 * li + 1, sa);
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 2), sa)); DBG_STAMP(4 * li + 2, sa);
             if ((lrc = launch(2, sa))) return lrc;
-            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sa));
+            if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * li + 3), sa)); DBG_STAMP(4 * li + 3, sa);
             if ((lrc = fixup_after(sa))) return lrc;
         }
         seg_ev[si] = sync_event();
@@ -705,33 +707,54 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         int orc = h2e_engine_or_status(J.d_inst, n_instances, H2E_ST_TEST_HOOK, sa);
         if (orc != 0) return fail(H2E_ERR_HIP, std::string("status kernel launch failed: ") + hipGetErrorString((hipError_t)orc));
     }
-    // completion: the fix-up stream collects the other streams and records the slot's `done` event; h2e_run then makes
-    // the caller's stream wait for it, h2e_submit leaves that to h2e_wait
+    // completion: one stream collects the others and records the slot's `done` event; h2e_run then makes the caller's stream wait for
+    // it, h2e_submit leaves that to h2e_wait.  h2e_run: the fix-up stream.  h2e_submit: a stream of the SLOT - on the shared fix-up
+    // stream the collectors of all runs in flight stand in submission order, and a run whose slot came free late held back the `done`
+    // of every run submitted after it (device timeline of 8-check batches at eight runs in flight, exp/dev_timeline.py: `done` 3-4 ms
+    // after the run's last kernel; the slots then came free in bursts and the runs started in bursts)
     {
+        hipStream_t sdone = sd;
+        if (!join) {
+            if (!J.x_stream) HIP_TRY(make_stream(ctx, &J.x_stream, ctx->prio_expand, 0));
+            sdone = J.x_stream;
+            if (used_sd) {   // the run's fix-ups on the shared fix-up stream
+                hipEvent_t e6 = sync_event();
+                HIP_TRY(hipEventRecord(e6, sd));
+                HIP_TRY(hipStreamWaitEvent(sdone, e6, 0));
+            }
+        }
         hipEvent_t ea = sync_event();
         HIP_TRY(hipEventRecord(ea, sa_main));
-        HIP_TRY(hipStreamWaitEvent(sd, ea, 0));
+        HIP_TRY(hipStreamWaitEvent(sdone, ea, 0));
         hipEvent_t eb = sync_event();
         HIP_TRY(hipEventRecord(eb, sb));
-        HIP_TRY(hipStreamWaitEvent(sd, eb, 0));
+        HIP_TRY(hipStreamWaitEvent(sdone, eb, 0));
         if (used_se) {
             hipEvent_t e3 = sync_event();
             HIP_TRY(hipEventRecord(e3, se));
-            HIP_TRY(hipStreamWaitEvent(sd, e3, 0));
+            HIP_TRY(hipStreamWaitEvent(sdone, e3, 0));
         }
         if (used_small) {
             hipEvent_t e4 = sync_event();
             HIP_TRY(hipEventRecord(e4, ctx->small_stream));
-            HIP_TRY(hipStreamWaitEvent(sd, e4, 0));
+            HIP_TRY(hipStreamWaitEvent(sdone, e4, 0));
         }
-        (void)used_sd;
+        if (used_x && sdone != J.x_stream) {
+            hipEvent_t e5 = sync_event();
+            HIP_TRY(hipEventRecord(e5, J.x_stream));
+            HIP_TRY(hipStreamWaitEvent(sdone, e5, 0));
+        }
         if (d_digests) {   // every kernel that adds to the digest shards has finished here
-            int drc = h2e_engine_digest_reduce(J.dg_shards, H2E_DG_SHARDS, 3 * n_instances * 4, d_digests, sd);
+            int drc = h2e_engine_digest_reduce(J.dg_shards, H2E_DG_SHARDS, 3 * n_instances * 4, d_digests, sdone);
             if (drc != 0) return fail(H2E_ERR_HIP, std::string("digest kernel launch failed: ") + hipGetErrorString((hipError_t)drc));
         }
-        HIP_TRY(hipEventRecord(J.done, sd));
+        HIP_TRY(hipEventRecord(J.done, sdone));
+        DBG_STAMP(1000u, sdone);
         if (join) HIP_TRY(hipStreamWaitEvent(sa_main, J.done, 0));
     }
+#ifdef H2E_DEBUG_HOOKS
+    dbg_mark("queued");
+#endif
     return 0;
 }
 

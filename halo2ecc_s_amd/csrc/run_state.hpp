@@ -10,12 +10,10 @@ struct JobSlot {
     // engine workspace (grow-only): quotient hints, numerator/denominator pairs, Jacobian scratch, selected points
     uint64_t *ws_hints = nullptr, *ws_nd = nullptr, *ws_jac = nullptr, *ws_sel = nullptr;
     size_t ws_hints_words = 0, ws_nd_words = 0, ws_jac_words = 0, ws_sel_words = 0;
-    InstanceDescHost* d_inst = nullptr;
+    InstanceDescHost* d_inst = nullptr;   // the run's table of per-instance descriptors (written on the device: handoff.hip)
     uint32_t inst_cap = 0;
     uint64_t* dg_shards = nullptr;    // stream digest accumulators of the slot's run: [H2E_DG_SHARDS][3][instances][4] words
     uint32_t dg_cap = 0;              // instances they are sized for
-    InstanceDescHost* h_inst = nullptr;   // pinned (hipHostMalloc): the upload below is a real asynchronous copy ...
-    hipEvent_t upload_ev = nullptr;       // ... and this event says when the host may rewrite the table
     std::vector<hipEvent_t> ev;       // profiling: 4 per launched segment (value-chain begin/end, expansion begin/end)
     std::vector<hipEvent_t> sync_ev;  // cross-stream dependencies
     hipEvent_t done = nullptr;        // recorded when every stream of the slot's last run has finished
@@ -28,6 +26,8 @@ struct JobSlot {
     // stream held at submission, so that the value chains of consecutive runs overlap each other as well - each of their
     // kernels is latency-bound and leaves most of the GPU idle.
     hipStream_t chain_stream = nullptr;
+    // expansion stream of the slot: the small expansions and inverse fix-ups of a pipelined run that has no big expansion (run.hpp)
+    hipStream_t x_stream = nullptr;
     // start counter of the slot's digit chains and what it will read once every chain launched so far has started (engine.hip h2e_gate)
     uint32_t* d_gate = nullptr;
     uint32_t gate_total = 0;
@@ -42,6 +42,7 @@ struct JobSlot {
         if (order_ev) (void)hipEventDestroy(order_ev);
         if (side_stream) (void)hipStreamDestroy(side_stream);
         if (chain_stream) (void)hipStreamDestroy(chain_stream);
+        if (x_stream) (void)hipStreamDestroy(x_stream);
         (void)hipFree(ws_hints);
         (void)hipFree(ws_nd);
         (void)hipFree(ws_jac);
@@ -49,8 +50,6 @@ struct JobSlot {
         (void)hipFree(d_inst);
         (void)hipFree(dg_shards);
         (void)hipFree(d_gate);
-        if (h_inst) (void)hipHostFree(h_inst);
-        if (upload_ev) (void)hipEventDestroy(upload_ev);
     }
 };
 
