@@ -1292,16 +1292,21 @@ static __constant__ unsigned char g_pk_rank_of[H2E_OP_COUNT] = {
 static_assert(H2E_OP_COUNT == 30, "g_pk_rank_of lists every opcode of tape.h");
 template <class FP>
 __global__ void __launch_bounds__(64, H2E_XP_WAVES) h2e_run_tape_packed(H2ELaunch L, const InstanceDesc* inst, u32 n_instances, u32 log2p) {
-    __shared__ u32x4 opbuf[H2E_PK_BUF_OPS * 4];   // [group][op in chunk][4 x 16 bytes]
-    __shared__ u64 dg_sums[12 * 64];
     __shared__ u32 rank_lds[32];                  // g_pk_rank_of, read per lane in the loop: from LDS (a global load there would wait
                                                   // for every store the wave has in flight - one counter, in order)
-    extern __shared__ u64 xcache_dyn[];           // [3][2 L + 4][64] words when the result cache is on (H2ELaunch.rel_refs bit 2)
+    // dynamic LDS, sized by the launch (pk_lds_bytes below): the op buffer [group][op in chunk][4 x 16 bytes] - G x CH ops: 16 KB for eight
+    // groups and more, 8 KB for four -, the digest sums (6 KB, only a run with a stream digest), the result cache [3][2 L + 4][64] words
+    // (H2ELaunch.rel_refs bit 2).  With 16 KB + 6 KB static whatever the launch needed, a wave of 16 bls12_381 checks held 41 KB and a CU
+    // took THREE of them - one of its four SIMDs idle, and none next to a chain's workgroup.
+    extern __shared__ u64 pk_dyn[];
     if (L.rel_refs & 8) __builtin_amdgcn_s_setprio(3);
     const u32 lane = threadIdx.x, P = 1u << log2p, G = 64u >> log2p;
     if (lane < 32u) rank_lds[lane] = lane < (u32)H2E_OP_COUNT ? (u32)g_pk_rank_of[lane] : 0xffu;
     const u32 g = lane >> log2p, ii = lane & (P - 1u);
     const u32 CH = min(32u, H2E_PK_BUF_OPS / G);   // ops per group and chunk (sub-ranges of the pairing programs: 8 or 16-17 ops)
+    u32x4* opbuf = (u32x4*)pk_dyn;
+    u64* dg_sums = pk_dyn + (size_t)G * CH * 8u;
+    u64* xcache_dyn = dg_sums + (L.dg_out != nullptr ? 12u * 64u : 0u);
     const u32 per_sub = n_instances * L.n_strands;
     const u32 n_sub = L.n_sub > 1 ? L.n_sub : 1;
     const u32 sub = L.pk_order ? L.pk_order[blockIdx.x * G + g] : blockIdx.x * G + g;   // (~0u: an empty slot of the order table)
@@ -4626,6 +4631,11 @@ extern "C" void H2E_UNIT(h2e_engine_set_tuning)(int key, int value) {
     }
 }
 
+// dynamic LDS of h2e_run_tape_packed in front of its result cache: op buffer (G groups x min(32, 256 / G) ops x 64 bytes) + digest sums
+static size_t pk_lds_bytes(int log2p, bool digest) {
+    const u32 G = 64u >> log2p, CH = std::min(32u, H2E_PK_BUF_OPS / G);
+    return (size_t)G * CH * 64u + (digest ? (size_t)12 * 64 * 8 : 0);
+}
 // mode: 1 = values-only replay (whole tape per lane), 2 = full expansion (sub-ranges if any), 4 = inverse fix-up
 extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
                                  uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream) {
@@ -4704,7 +4714,8 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(int field_pair, int mode, const H2ELa
     if ((mode & 1) && !launch->vtape) return -2;   /* a values-only replay always runs from the compiled V-tape */          \
     if ((mode & 2) && pack_log2p >= 0)                                                                                         \
         hipLaunchKernelGGL(h2e_run_tape_packed<FP>, dim3(pk_grid), block,                                                      \
-                           xcache_on ? (size_t)3 * (2 * FP::L + 4) * 64 * 8 : 0, stream, launch_x, inst, n_instances, (u32)pack_log2p);  \
+                           pk_lds_bytes(pack_log2p, launch->dg_out != nullptr) + (xcache_on ? (size_t)3 * (2 * FP::L + 4) * 64 * 8 : 0), \
+                           stream, launch_x, inst, n_instances, (u32)pack_log2p);                                              \
     else if (mode & 2)                                                                                                         \
         hipLaunchKernelGGL((h2e_run_tape<FP, false>), grid_x, block,                                                           \
                            (xcache_on ? (size_t)3 * (2 * FP::L + 4) * 64 * 8 : 0) + (launch->dg_out ? (size_t)12 * 64 * 8 : 0) +  \
