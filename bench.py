@@ -219,7 +219,7 @@ def main():
                          "dealt round-robin over the N ranks (SURVEY 8d items 4-5: 8 bn256 / 2 bls12_381 checks per GPU at N = 8; shares may be ragged)")
     ap.add_argument("--total-units", type=int, default=None, help="--scaling strong: units of the whole job (default: the workload's BASELINE batch)")
     ap.add_argument("--ring", type=int, default=None, help="output-buffer sets steps rotate through = runs in flight (default: 2 for the MSM - step k+1's value chain runs under "
-                    "step k's expansion, 2 x 110 GB of arrays; 8 for the pairing checks (4 for a full 64-check bn256 batch): their value chains are latency-bound on one CU per check; "
+                    "step k's expansion, 2 x 110 GB of arrays; 16 for the pairing checks (4 for a full 64-check bn256 batch): their value chains are latency-bound on one CU per check; "
                     "1: h2e_run, no overlap)")
     ap.add_argument("--digest", action="store_true", help="consume every step's arrays with the stream digest (h2e_submit_digest; streaming-job mode, configs[2])")
     ap.add_argument("--job-tiles", type=int, default=None, help="run one MSM job of this many tiles over all ranks (2^20 points = 1024; `--job-tiles 1024 --gpus 8` is configs[2]): "
@@ -250,14 +250,14 @@ def main():
     if args.units is None:
         args.units = DEFAULT_UNITS[args.workload]
     if args.ring is None:
-        # MSM: two 110 GB buffer sets.  Pairing checks: eight runs in flight - a run's value chain (one 1024-thread workgroup per
-        # check) is latency-bound on its CU for ~2 ms and a batch of a few checks leaves the rest of the GPU to the expansions of the
-        # runs before it.  (Rounds 4-5 measured "a fifth run in flight loses" - with W = 4 warm-up steps the slots beyond the fourth
-        # did their first-use allocations inside the timed region; with every slot primed, round 5: 8 x bn256 0.99 / 0.81 / 0.78 ms per
-        # step at 4 / 6 / 8, 2 x bls12_381 0.89 / 0.67 / 0.58, 16 x bls12_381 1.56 / 1.64 / 1.50, 64 x bn256 3.27 / 3.25 / 3.28; 12 runs in
-        # flight want more hardware queues than there are: 1.8-6 ms)
-        # (a full 64-check bn256 batch fills the GPU by itself: four - 20 GB of arrays per buffer set)
-        args.ring = {"msm": 2, "pairing_bn256": 8 if args.units <= 32 else 4, "pairing_bls12_381": 8}[args.workload]
+        # MSM: two 110 GB buffer sets.  Pairing checks: sixteen runs in flight - a run's value chain (one 1024-thread workgroup per
+        # check) is latency-bound on its CU for ~2 ms and a batch of a few checks leaves the rest of the GPU to the runs around it; such a
+        # run lives in ONE stream (run.hpp), so sixteen of them fit the hardware queues.  (Rounds 4-5 measured "a fifth run in flight
+        # loses" - with W = 4 warm-up steps the slots beyond the fourth did their first-use allocations inside the timed region.  With
+        # every slot primed, round 5: 8 x bn256 1.01 / 0.76 / 0.64 ms per step at 4 / 8 / 16, 2 x bls12_381 0.90 / 0.59 / 0.44, 16 x
+        # bls12_381 1.47 / 1.37 / 1.25.)  A full 64-check bn256 batch fills the GPU by itself (3.27 / 3.25 / 3.28 at 4 / 6 / 8): four -
+        # 20 GB of arrays per buffer set.
+        args.ring = {"msm": 2, "pairing_bn256": 16 if args.units <= 32 else 4, "pairing_bls12_381": 16}[args.workload]
     if args.job_tiles:
         args.digest = True
         args.steps = max(1, args.job_tiles // (args.units * max(1, args.gpus)))
@@ -271,9 +271,10 @@ def main():
         sys.exit(subprocess.run(cmd).returncode)
     # pipelined runs use several HIP streams (caller's, expansion, fix-up, a chain and a side stream per job slot): more than
     # the 4 hardware queues a process gets by default, and streams that share a queue serialise
-    # (per job slot: a chain, an expansion / completion and - some programs - a side stream; + the caller's, the shared expansion,
-    # small-expansion and fix-up streams)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(16, 3 * args.ring + 6)))
+    # (per job slot: a chain stream - the whole run of a small pairing batch -, for the big batches a completion and, some programs,
+    # a side stream; + the caller's, the shared expansion, small-expansion and fix-up streams.  Streams in USE beyond ~24 are
+    # time-sliced: 12 slots of two streams each took 1.8 instead of 0.7 ms per step)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(16, args.ring + 12)))
     if world > 1 and args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     total_units = None

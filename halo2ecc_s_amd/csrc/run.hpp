@@ -321,7 +321,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     std::vector<hipEvent_t> seg_ev(r.segments.size(), nullptr), side_done(r.segments.size(), nullptr);
     hipEvent_t run_begin = sync_event();
     HIP_TRY(hipEventRecord(run_begin, sa));
-    bool used_se = false, used_small = false, used_x = false;
+    bool used_se = false, used_small = false, used_x = false, merged_x = false;
     H2ELaunch pending_L;
     uint32_t pending_li = 0;
     bool have_pending = false;
@@ -568,7 +568,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
             // inversion behind every one of them made that stream the step (16 x bls12_381 at four runs in flight 1.81 -> 1.58 ms, 8 x
             // bn256 1.40 -> 1.10, 2 x bls12_381 1.22 -> 0.95; the MSM, whose small expansions run beside big ones: no difference, left
             // as it was).  H2E_SCHED & 64: in their stream as before (A/B)
-            if (fixup_in_stream && (join || (run_has_big_x && !(ctx->sched & 128u)) || (ctx->sched & 64u) || (used_x && st == J.x_stream))) return launch_one(4, f, st);   // (128: to the fix-up stream whatever the run holds - experiment)
+            if (fixup_in_stream && (join || (run_has_big_x && !(ctx->sched & 128u)) || (ctx->sched & 64u) || (used_x && st == J.x_stream) || (merged_x && st == sa))) return launch_one(4, f, st);   // (128: to the fix-up stream whatever the run holds - experiment)
             hipEvent_t e = sync_event();
             HIP_TRY(hipEventRecord(e, st));
             HIP_TRY(hipStreamWaitEvent(sd, e, 0));
@@ -622,13 +622,22 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
                 // pipelined: the shared expansion stream only carries the big expansions - the small ones (latency-bound: a few
                 // hundred waves and their inverse fix-ups) run beside them on their own stream instead of between them
                 if (!run_has_big_x && !(ctx->sched & 256u)) {
-                    // ... and a run WITHOUT a big expansion (a pairing batch of a few checks) keeps them in a stream of its slot, fix-ups
-                    // behind them: on one stream for all runs in flight the small expansions - one wave per SIMD each, 0.2-0.35 ms, plus
-                    // ~0.1 ms of event latency between them - came to 0.95 ms per run and WERE the step of the 8-GPU shares (device
-                    // timeline, exp/dev_timeline.py: a run's expansions started 3.3 ms after its chain had finished).  H2E_SCHED & 256: off (A/B)
-                    if (!J.x_stream) HIP_TRY(make_stream(ctx, &J.x_stream, ctx->prio_expand, 0));
-                    sx = J.x_stream;
-                    used_x = true;
+                    // ... and a run WITHOUT a big expansion (a pairing batch of a few checks) keeps them, fix-ups behind them, in its
+                    // own chain stream: on one stream for all runs in flight the small expansions - one wave per SIMD each, 0.2-0.35 ms,
+                    // plus ~0.1 ms of event latency between them - came to 0.95 ms per run and WERE the step of the 8-GPU shares (device
+                    // timeline, exp/dev_timeline.py: a run's expansions started 3.3 ms after its chain had finished).  In the chain
+                    // stream a segment's expansion stands in front of the next segment's chain - the run takes ~0.5 ms longer - but a run
+                    // in flight costs ONE hardware queue, and what a batch of a few checks needs is runs in flight: beyond ~24 streams in
+                    // use the queues are time-sliced (12 runs with an expansion stream each: 1.8 ms per step of 8 bn256 checks; 16 runs
+                    // of one stream: 0.64, 2 x bls12_381 0.44).  H2E_SCHED & 512: a stream of the slot (A/B); & 256: the shared small stream
+                    if (!(ctx->sched & 512u)) {
+                        sx = sa;
+                        merged_x = true;
+                    } else {
+                        if (!J.x_stream) HIP_TRY(make_stream(ctx, &J.x_stream, ctx->prio_expand, 0));
+                        sx = J.x_stream;
+                        used_x = true;
+                    }
                 } else {
                     if (!ctx->small_stream) HIP_TRY(make_stream(ctx, &ctx->small_stream, ctx->prio_expand, 0));
                     sx = ctx->small_stream;
@@ -714,7 +723,8 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     // after the run's last kernel; the slots then came free in bursts and the runs started in bursts)
     {
         hipStream_t sdone = sd;
-        if (!join) {
+        if (!join && merged_x && !used_x) sdone = sa_main;
+        else if (!join) {
             if (!J.x_stream) HIP_TRY(make_stream(ctx, &J.x_stream, ctx->prio_expand, 0));
             sdone = J.x_stream;
             if (used_sd) {   // the run's fix-ups on the shared fix-up stream

@@ -26,7 +26,8 @@ struct JobSlot {
     // stream held at submission, so that the value chains of consecutive runs overlap each other as well - each of their
     // kernels is latency-bound and leaves most of the GPU idle.
     hipStream_t chain_stream = nullptr;
-    // expansion stream of the slot: the small expansions and inverse fix-ups of a pipelined run that has no big expansion (run.hpp)
+    // completion stream of the slot (h2e_submit): collects the run's streams and records `done` (run.hpp) - unless the run lives in its
+    // chain stream alone (a pipelined run without a big expansion)
     hipStream_t x_stream = nullptr;
     // start counter of the slot's digit chains and what it will read once every chain launched so far has started (engine.hip h2e_gate)
     uint32_t* d_gate = nullptr;
@@ -58,9 +59,9 @@ struct h2e_ctx {
     H2EFieldConsts* d_fc[3] = {nullptr, nullptr, nullptr};
     std::map<std::string, h2e_program*> cache;
     bool profiling = false;
-    static constexpr int N_SLOTS = 16;
-    uint32_t depth = 2;      // job slots in use = runs in flight (H2E_OPT_PIPELINE_DEPTH); each slot brings its own streams   // runs in flight (h2e_submit): 2 hide an MSM step's value chain; the pairing checks' 34 ms
-                                        // level-parallel chains (one workgroup per instance) want 4
+    static constexpr int N_SLOTS = 32;
+    uint32_t depth = 2;      // job slots in use = runs in flight (H2E_OPT_PIPELINE_DEPTH); each slot brings its own streams: 2 hide an MSM
+                             // step's value chain, a pairing batch of a few checks wants 16 (its chains are latency-bound on one CU per check)
     JobSlot slots[N_SLOTS];
     uint64_t n_runs = 0;     // runs submitted so far: run k uses slot k % N_SLOTS
     int last_slot = -1;
