@@ -187,10 +187,14 @@ def run_children(args):
             # the headline batch all the way to what halo2 consumes: per-instance advice columns
             ("msm_consumer_ready", ["--workload", "msm", "--ring", "1", "--steps", "3", "--warmup", "1", "--latency-steps", "0", "--consumer-ready", "3",
                                     "--no-cpu-baseline"] + off)]
+    # (every child sizes its own hardware-queue request by its own ring: this process's setting - the MSM's two slots - must not reach it)
+    env = dict(os.environ)
+    if not getattr(args, "user_set_queues", False):
+        env.pop("GPU_MAX_HW_QUEUES", None)
     for name, extra in jobs:
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=args.child_timeout, cwd=ROOT)
+            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=args.child_timeout, cwd=ROOT, env=env)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
             if r.returncode != 0 or not lines:
                 also[name] = {"error": f"rc {r.returncode}: {r.stderr[-400:]}"}
@@ -274,6 +278,7 @@ def main():
     # (per job slot: a chain stream - the whole run of a small pairing batch -, for the big batches a completion and, some programs,
     # a side stream; + the caller's, the shared expansion, small-expansion and fix-up streams.  Streams in USE beyond ~24 are
     # time-sliced: 12 slots of two streams each took 1.8 instead of 0.7 ms per step)
+    args.user_set_queues = "GPU_MAX_HW_QUEUES" in os.environ
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(16, args.ring + 12)))
     if world > 1 and args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
@@ -529,6 +534,7 @@ def main():
 
     # single-batch latency: one batch alone through h2e_run (nothing else in flight), inputs resident -> arrays complete
     single_ms = None
+    alone_ms = []       # the same launches with nothing else in flight
     timing[0] = False
     if args.latency_steps > 0:
         lat = []
@@ -540,6 +546,7 @@ def main():
             eng.run(prog, batches[i % n_batches], base, rng, sel, status)
             torch.cuda.synchronize()
             lat.append(1e3 * (time.perf_counter() - t1))
+            alone_ms.append(eng.last_run_launch_ms())
             if not args.no_check:
                 assert int(status.abs().max()) == 0
         single_ms = float(np.median(lat))
@@ -610,6 +617,16 @@ def main():
         roof = x_roof
     roof["value_chain_ms"] = [float(x) for x in np.mean(np.array([[a for a, _ in ms] for ms in launch_ms]), axis=0)]
     roof["expansion_ms"] = [float(x) for x in np.mean(np.array([[b for _, b in ms] for ms in launch_ms]), axis=0)]
+    # The brackets above are those of launches that SHARE the GPU with the ring's other runs (sixteen in flight for a small pairing batch:
+    # a launch then lasts several times what it does alone, while the step gets shorter).  `alone`: the same launches of the single-batch
+    # steps - h2e_run, nothing else in flight - and the dominant expansion launch priced with that duration.
+    alone_ms = [ms for ms in alone_ms if len(ms) > dom]
+    if alone_ms:
+        a_dom = float(np.median([ms[dom][1] for ms in alone_ms])) / dom_n
+        roof["alone"] = {"value_chain_ms": [float(x) for x in np.median(np.array([[a for a, _ in ms] for ms in alone_ms]), axis=0)],
+                         "expansion_ms": [float(x) for x in np.median(np.array([[b for _, b in ms] for ms in alone_ms]), axis=0)],
+                         "expansion_launch_ms": a_dom, "expansion_frac": dom_bytes / (a_dom * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "single-batch steps (h2e_run, nothing else in flight); the figures outside this block are launches next to the ring's other runs"}
     out = {
         "metric": "witness_cells_per_sec",
         "value": total_cells / elapsed,
@@ -672,8 +689,9 @@ def main():
     # [ms_per_step, single_batch_ms, whole-step fraction of the HBM roof, dominant kernel's roofline fraction]
     brief = lambda d: [round(d["ms_per_step"], 3), None if d.get("single_batch_ms") is None else round(d["single_batch_ms"], 3),   # noqa: E731
                        round(d["whole_step"]["frac"], 4), round(d["roofline"]["frac"], 4),
-                       round(d["roofline"].get("expansion", d["roofline"])["frac"], 4)]
-    summary = {"columns": ["ms_per_step", "single_batch_ms", "whole_step_frac", "roofline_frac", "expansion_frac"],
+                       round(d["roofline"].get("expansion", d["roofline"])["frac"], 4),
+                       None if "alone" not in d["roofline"] else round(d["roofline"]["alone"]["expansion_frac"], 4)]
+    summary = {"columns": ["ms_per_step", "single_batch_ms", "whole_step_frac", "roofline_frac", "expansion_frac", "expansion_frac_alone"],
                "msm_2e16" if not job_mode else "msm_job": brief(out)}
     for name, blk in (also or {}).items():
         summary[name] = brief(blk) if "ms_per_step" in blk else blk.get("error", "failed")[:80]

@@ -27,7 +27,7 @@ def _check_contract(d, n_gpus, steps, warmup, scaling="weak"):
         assert key in d, key
     assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
     assert d["higher_is_better"] is True and d["scaling"] == scaling and d["vs_baseline"] is None
-    assert list(d)[-1] == "summary" and d["summary"]["columns"] == ["ms_per_step", "single_batch_ms", "whole_step_frac", "roofline_frac", "expansion_frac"]
+    assert list(d)[-1] == "summary" and d["summary"]["columns"] == ["ms_per_step", "single_batch_ms", "whole_step_frac", "roofline_frac", "expansion_frac", "expansion_frac_alone"]
     assert "workload" in d["config"] and d["value"] > 0 and d["ms_per_step"] > 0
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
