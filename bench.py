@@ -253,15 +253,6 @@ def main():
         args.suite = "all" if plain else "main"
     if args.units is None:
         args.units = DEFAULT_UNITS[args.workload]
-    if args.ring is None:
-        # MSM: two 110 GB buffer sets.  Pairing checks: sixteen runs in flight - a run's value chain (one 1024-thread workgroup per
-        # check) is latency-bound on its CU for ~2 ms and a batch of a few checks leaves the rest of the GPU to the runs around it; such a
-        # run lives in ONE stream (run.hpp), so sixteen of them fit the hardware queues.  (Rounds 4-5 measured "a fifth run in flight
-        # loses" - with W = 4 warm-up steps the slots beyond the fourth did their first-use allocations inside the timed region.  With
-        # every slot primed, round 5: 8 x bn256 1.01 / 0.76 / 0.64 ms per step at 4 / 8 / 16, 2 x bls12_381 0.90 / 0.59 / 0.44, 16 x
-        # bls12_381 1.47 / 1.37 / 1.25.)  A full 64-check bn256 batch fills the GPU by itself (3.27 / 3.25 / 3.28 at 4 / 6 / 8): four -
-        # 20 GB of arrays per buffer set.
-        args.ring = {"msm": 2, "pairing_bn256": 16 if args.units <= 32 else 4, "pairing_bls12_381": 16}[args.workload]
     if args.job_tiles:
         args.digest = True
         args.steps = max(1, args.job_tiles // (args.units * max(1, args.gpus)))
@@ -273,13 +264,6 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(29500 + os.getpid() % 1000), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd).returncode)
-    # pipelined runs use several HIP streams (caller's, expansion, fix-up, a chain and a side stream per job slot): more than
-    # the 4 hardware queues a process gets by default, and streams that share a queue serialise
-    # (per job slot: a chain stream - the whole run of a small pairing batch -, for the big batches a completion and, some programs,
-    # a side stream; + the caller's, the shared expansion, small-expansion and fix-up streams.  Streams in USE beyond ~24 are
-    # time-sliced: 12 slots of two streams each took 1.8 instead of 0.7 ms per step)
-    args.user_set_queues = "GPU_MAX_HW_QUEUES" in os.environ
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(16, args.ring + 12)))
     if world > 1 and args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     total_units = None
@@ -291,6 +275,25 @@ def main():
         args.units = len(range(rank, total_units, world))
         if args.units == 0:
             sys.exit(f"bench.py: rank {rank} has no unit of {total_units} (more ranks than units)")
+
+    if args.ring is None:
+        # (strong scaling: by the largest share, so that every rank decides alike)
+        ring_units = args.units if total_units is None else (total_units + world - 1) // world
+        # MSM: two 110 GB buffer sets.  Pairing checks: sixteen runs in flight - a run's value chain (one 1024-thread workgroup per
+        # check) is latency-bound on its CU for ~2 ms and a batch of a few checks leaves the rest of the GPU to the runs around it; such a
+        # run lives in ONE stream (run.hpp), so sixteen of them fit the hardware queues.  (Rounds 4-5 measured "a fifth run in flight
+        # loses" - with W = 4 warm-up steps the slots beyond the fourth did their first-use allocations inside the timed region.  With
+        # every slot primed, round 5: 8 x bn256 1.01 / 0.76 / 0.64 ms per step at 4 / 8 / 16, 2 x bls12_381 0.90 / 0.59 / 0.44, 16 x
+        # bls12_381 1.47 / 1.37 / 1.25.)  A full 64-check bn256 batch fills the GPU by itself (3.27 / 3.25 / 3.28 at 4 / 6 / 8): four -
+        # 20 GB of arrays per buffer set.
+        args.ring = {"msm": 2, "pairing_bn256": 16 if ring_units <= 32 else 4, "pairing_bls12_381": 16}[args.workload]
+    # pipelined runs use several HIP streams (caller's, expansion, fix-up, a chain and a side stream per job slot): more than
+    # the 4 hardware queues a process gets by default, and streams that share a queue serialise
+    # (per job slot: a chain stream - the whole run of a small pairing batch -, for the big batches a completion and, some programs,
+    # a side stream; + the caller's, the shared expansion, small-expansion and fix-up streams.  Streams in USE beyond ~24 are
+    # time-sliced: 12 slots of two streams each took 1.8 instead of 0.7 ms per step)
+    args.user_set_queues = "GPU_MAX_HW_QUEUES" in os.environ
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(16, args.ring + 12)))
 
     also = None
     if args.suite == "all" and rank == 0 and world == 1 and not args.pmc_child and not args.sub:

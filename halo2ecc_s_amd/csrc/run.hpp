@@ -209,6 +209,10 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     }
     const hipStream_t sa_main = join ? stream : J.chain_stream;
     hipStream_t sa = sa_main, sb = ctx->expand_stream, sc = J.side_stream, sd = ctx->fixup_stream;
+    if (!join && (ctx->sched & 1024u) && (slot_index & 1)) {   // (experiment: the big expansions of odd slots on a second stream)
+        if (!ctx->expand_stream2) HIP_TRY(make_stream(ctx, &ctx->expand_stream2, ctx->prio_expand, 0));
+        sb = ctx->expand_stream2;
+    }
 #ifdef H2E_DEBUG_HOOKS
     if (FILE* f = dbg_log_file()) {
         fprintf(f, "run %llu begin slot %d join %d streams chain %p expand %p side %p fixup %p small %p\n", (unsigned long long)ctx->n_runs + 1, slot_index, join ? 1 : 0,
