@@ -209,9 +209,19 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     }
     const hipStream_t sa_main = join ? stream : J.chain_stream;
     hipStream_t sa = sa_main, sb = ctx->expand_stream, sc = J.side_stream, sd = ctx->fixup_stream;
-    if (!join && (ctx->sched & 1024u) && (slot_index & 1)) {   // (experiment: the big expansions of odd slots on a second stream)
-        if (!ctx->expand_stream2) HIP_TRY(make_stream(ctx, &ctx->expand_stream2, ctx->prio_expand, 0));
-        sb = ctx->expand_stream2;
+    {
+        // Pipelined runs whose expansions are big but not huge (a full 64-check bn256 batch: two launches of ~5 500 waves, 1.2-1.7 ms each)
+        // alternate between TWO expansion streams by slot: on one stream ~0.1 ms of event latency stood between any two launches, and the
+        // stream was the step (device timeline: busy 3.0 of every 3.3 ms) - 64 x bn256 3.07 -> 2.93 ms per step.  An expansion that is split
+        // into parts (the MSM windows: 10 ms of stores) keeps the one stream: two of those side by side only share the store bandwidth
+        // (15.48 -> 15.6 ms).  H2E_SCHED & 1024: one stream for all (A/B)
+        bool huge_x = false;
+        for (size_t si = 0; si < r.segments.size() && si < p->seg_n_sub.size(); si++)
+            huge_x = huge_x || (p->seg_n_sub[si] > 1 && (uint64_t)p->seg_n_sub[si] * r.segments[si].n_strands * n_instances >= ctx->x_split_min_lanes);
+        if (!join && !huge_x && !(ctx->sched & 1024u) && (slot_index & 1)) {
+            if (!ctx->expand_stream2) HIP_TRY(make_stream(ctx, &ctx->expand_stream2, ctx->prio_expand, 0));
+            sb = ctx->expand_stream2;
+        }
     }
 #ifdef H2E_DEBUG_HOOKS
     if (FILE* f = dbg_log_file()) {

@@ -66,7 +66,7 @@ struct h2e_ctx {
     uint64_t n_runs = 0;     // runs submitted so far: run k uses slot k % N_SLOTS
     int last_slot = -1;
     hipStream_t expand_stream = nullptr;
-    hipStream_t expand_stream2 = nullptr;   // (H2E_SCHED & 1024, experiment)
+    hipStream_t expand_stream2 = nullptr;   // the big (not huge) expansions of odd job slots (run.hpp)
     hipStream_t fixup_stream = nullptr;
     hipStream_t small_stream = nullptr;   // small expansions of pipelined runs (H2E_SCHED & 4)
     // tuning knobs, read once at h2e_ctx_create (H2E_X_SPLIT, H2E_X_SPLIT_MIN_LANES); h2e_ctx_set_option overrides
