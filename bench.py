@@ -178,11 +178,14 @@ def run_children(args):
     base = [sys.executable, os.path.abspath(__file__), "--sub", "--suite", "main", "--gpus", "1"]
     off = ["--traffic", "off"]
     # (the two pairing batches also take their expansion's HBM traffic from the counters: two rocprofv3 --pmc child passes each)
+    # (sixteen runs in flight: 120 steps, so that the pipeline's fill and drain - a run's latency, inside the timed region - and a
+    # stray hiccup of the box weigh a few percent, not a fifth)
+    deep = ["--steps", "120"]
     jobs = [("pairing_bn256", ["--workload", "pairing_bn256"]),
-            ("pairing_bls12_381", ["--workload", "pairing_bls12_381"]),
+            ("pairing_bls12_381", ["--workload", "pairing_bls12_381"] + deep),
             # one GPU's share of configs[3] / configs[4] when the batch is dealt over 8 GPUs: batches smaller than a wave
-            ("pairing_bn256_share8", ["--workload", "pairing_bn256", "--units", "8", "--no-cpu-baseline"] + off),
-            ("pairing_bls12_381_share8", ["--workload", "pairing_bls12_381", "--units", "2", "--no-cpu-baseline"] + off),
+            ("pairing_bn256_share8", ["--workload", "pairing_bn256", "--units", "8", "--no-cpu-baseline"] + deep + off),
+            ("pairing_bls12_381_share8", ["--workload", "pairing_bls12_381", "--units", "2", "--no-cpu-baseline"] + deep + off),
             ("msm_job_2e20", ["--workload", "msm", "--job-tiles", "1024", "--no-cpu-baseline"] + off),
             # the headline batch all the way to what halo2 consumes: per-instance advice columns
             ("msm_consumer_ready", ["--workload", "msm", "--ring", "1", "--steps", "3", "--warmup", "1", "--latency-steps", "0", "--consumer-ready", "3",
