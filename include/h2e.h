@@ -183,8 +183,13 @@ int h2e_wait(h2e_ctx* ctx, int job, void* stream);
 #define H2E_OPT_TEST_SKIP_EXPANSION 3  /* TEST HOOK: leave out the full expansion of cut segment <value> (-1: of every cut
                                           segment but the last; INT64_MIN: off).  Rows are missing from such a run: every
                                           status word gets H2E_ST_TEST_HOOK. */
-#define H2E_OPT_PIPELINE_DEPTH 4       /* job slots in use = runs h2e_submit keeps in flight (1 .. H2E_STAT_MAX_PIPELINE_DEPTH, default 2).
-                                          Every slot has its own workspace and streams; call with no run in flight. */
+#define H2E_OPT_PIPELINE_DEPTH 4       /* job slots in use = runs h2e_submit keeps in flight (1 .. H2E_STAT_MAX_PIPELINE_DEPTH = 32, default 2).
+                                          Every slot has its own workspace and streams; call with no run in flight.  2 for the 64-tile
+                                          MSM (a buffer set is 110 GB), 4 for a full 64-check bn256 batch, 16 for smaller pairing
+                                          batches (a check's value chain is ~2 ms of latency on one compute unit; such a run lives in one
+                                          stream).  A slot's FIRST run allocates its workspace and creates its streams (~10 ms on the
+                                          host); the process wants GPU_MAX_HW_QUEUES >= depth + 12 set before HIP initialises, and more
+                                          than ~24 streams in use are time-sliced by the hardware. */
 #define H2E_OPT_TEST_SCAN_FALLBACK 5    /* TEST HOOK: bit mask - the MSM scan predictors treat some of their (valid) start values as degenerate
                                           and walk the real chain instead (1 window chunks, 2 tail chunk sums, 4 tail in-chunk starts).
                                           The results are the same; what it covers is the fallback path.  Process-wide; 0 = off. */
