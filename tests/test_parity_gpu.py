@@ -757,6 +757,63 @@ def test_pairing_small_batches_packed_expansion(engine, oracle, curve, n_inst):
     assert all(np.array_equal(a, b) for a, b in zip(dg, dg2))
 
 
+@pytest.mark.parametrize("curve,n_inst", [("bn256", 8), ("bls12_381", 2)])
+def test_pairing_small_batches_sixteen_runs_in_flight(engine, oracle, curve, n_inst):
+    """what a host does with one GPU's share of configs[3] / configs[4]: sixteen job slots (H2E_OPT_PIPELINE_DEPTH), 24 submissions of
+    DIFFERENT batches back to back without a host wait - every run in its own chain stream, expansions and fix-ups behind the
+    chains, `done` per slot, slots re-used by the last eight.  Every batch must come out as the same batch through h2e_run alone does
+    (32-byte digests of the three arrays per instance), every status 0, and one run of the re-used slots cell for cell as the oracle's."""
+    if curve == "bn256":
+        prog, gen, orun_of = Program.pairing_check_bn256(), synth.pairing_check_bn256_inputs, oracle_lib.run_pairing_check_bn256
+    else:
+        prog, gen, orun_of = Program.pairing_check_bls12_381(), synth.pairing_check_bls12_381_inputs, oracle_lib.run_pairing_check_bls12_381
+    t = engine.torch
+    depth, n_runs, n_batches = 16, 24, 3
+    batches = [[gen(instance=1200 + 50 * b + k) for k in range(n_inst)] for b in range(n_batches)]
+    d_in = [engine.upload_inputs(prog, np.stack(ins)) for ins in batches]
+    # the reference: each batch alone through h2e_run
+    want = []
+    ref = engine.alloc(prog, n_inst, fill=0xFF)
+    for b in range(n_batches):
+        ref[3].zero_()
+        engine.run(prog, d_in[b], *ref)
+        t.cuda.synchronize()
+        assert (ref[3].cpu().numpy() == 0).all()
+        want.append([engine.digest(prog, region, ref[region]).cpu().numpy() for region in range(3)])
+    old_depth = engine.get_stat(3)   # H2E_STAT_PIPELINE_DEPTH
+    engine.set_option(4, depth)      # H2E_OPT_PIPELINE_DEPTH
+    try:
+        bufs = [engine.alloc(prog, n_inst, fill=0xFF) for _ in range(depth)]
+        got, pending = {}, []
+        for k in range(n_runs):
+            slot = k % depth
+            if len(pending) >= depth:    # the slot's previous run: consume it (on the stream, not on the host) before its arrays are reused
+                k0, job0 = pending.pop(0)
+                engine.wait(job0)
+                got[k0] = ([engine.digest(prog, region, bufs[k0 % depth][region]) for region in range(3)], bufs[k0 % depth][3].clone())
+            bufs[slot][3].zero_()
+            pending.append((k, engine.submit(prog, d_in[k % n_batches], *bufs[slot])))
+        keep = None
+        for k0, job0 in pending:
+            engine.wait(job0)
+            got[k0] = ([engine.digest(prog, region, bufs[k0 % depth][region]) for region in range(3)], bufs[k0 % depth][3].clone())
+            if k0 == n_runs - 3:
+                keep = (k0, _rows(engine, prog, bufs[k0 % depth][:3]))
+        t.cuda.synchronize()
+    finally:
+        engine.set_option(4, old_depth)
+    for k in range(n_runs):
+        dg, status = got[k]
+        assert (status.cpu().numpy() == 0).all(), (k, status.cpu().numpy())
+        for region in range(3):
+            assert np.array_equal(dg[region].cpu().numpy(), want[k % n_batches][region]), (k, region)
+    k0, rows = keep
+    orun = orun_of(batches[k0 % n_batches][n_inst - 1])
+    assert orun.info.status == 0, orun.error
+    compare_advice(prog, orun, *rows, instance=n_inst - 1)
+    orun.close()
+
+
 @pytest.mark.parametrize("curve", ["bn256", "bls12_381"])
 def test_pairing_soak_statuses(engine, curve):
     """Every hint the value chain produces is checked by the expansion that consumes it (a differing hint sets H2E_ST_ARITH) and
