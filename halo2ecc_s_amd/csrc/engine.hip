@@ -1181,7 +1181,10 @@ WI_INLINE H2EOp chunk_op(const TapeChunk* tc, u32 k) {
 #define H2E_X_WAVES_WIDE 1   // the same for the 6-word fields (bls12_381: 299 + 43 registers; 2 = capped at 256, 32 of them spilled)
 #endif
 #ifndef H2E_XP_WAVES
-#define H2E_XP_WAVES 1       // the packed expansion (bn256 260 + 4 registers, bls12_381 304 + 48)
+#define H2E_XP_WAVES 2       // the packed expansion: capped at 256 registers (bn256 260 + 4 uncapped: 4 spilled; bls12_381 304 + 48: 50 spilled).
+                             // Round 4 measured "1 is better" - under an LDS footprint (41 KB per wave) that let a CU take three waves whatever
+                             // the registers allowed; with the op buffer sized by the launch (round 5) a second wave per SIMD fits: 16 x
+                             // bls12_381 pipelined 1.199 -> 1.13 ms per step, 8 x bn256 0.587 -> 0.572, 2 x bls12_381 unchanged
 #endif
 #ifndef H2E_REPLAY_WAVES
 #define H2E_REPLAY_WAVES 2
