@@ -737,10 +737,12 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     // after the run's last kernel; the slots then came free in bursts and the runs started in bursts)
     {
         hipStream_t sdone = sd;
-        if (!join && merged_x && !used_x) sdone = sa_main;
-        else if (!join) {
-            if (!J.x_stream) HIP_TRY(make_stream(ctx, &J.x_stream, ctx->prio_expand, 0));
-            sdone = J.x_stream;
+        if (!join) {
+            if (merged_x && !used_x) sdone = sa_main;   // (a run that lives in its chain stream)
+            else {
+                if (!J.x_stream) HIP_TRY(make_stream(ctx, &J.x_stream, ctx->prio_expand, 0));
+                sdone = J.x_stream;
+            }
             if (used_sd) {   // the run's fix-ups on the shared fix-up stream
                 hipEvent_t e6 = sync_event();
                 HIP_TRY(hipEventRecord(e6, sd));
