@@ -13,12 +13,24 @@ pytestmark = pytest.mark.gpu
 
 
 def _bench(*args, env=None, launcher=None):
-    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + list(args)
+    """-> (the headline = the LAST stdout line, the driver's record; the whole measurement from the detail file it names)"""
+    import tempfile
+    detail = tempfile.NamedTemporaryFile(prefix="h2e_bench_detail_", suffix=".json", delete=False).name
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + list(args) + ["--detail-file", detail]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    out = r.stdout.splitlines()
+    lines = [ln for ln in out if ln.startswith('{"metric"')]
+    assert len(lines) == 1 and (launcher is not None or out[-1] == lines[0]), r.stdout[-2000:]
+    assert len(lines[0]) < 4096, len(lines[0])      # the driver gave up on round 5's 25 KB line (BENCH_r05.json: parsed null)
+    d = json.loads(lines[0])
+    assert d["detail_file"] == detail
+    with open(detail) as f:
+        full = json.load(f)
+    os.unlink(detail)
+    for k in ("metric", "value", "ms_per_step", "steps", "warmup", "n_gpus"):
+        assert full[k] == d[k], k
+    return d, full
 
 
 def _check_contract(d, n_gpus, steps, warmup, scaling="weak"):
@@ -30,13 +42,13 @@ def _check_contract(d, n_gpus, steps, warmup, scaling="weak"):
     assert list(d)[-1] == "summary" and d["summary"]["columns"] == ["ms_per_step", "single_batch_ms", "whole_step_frac", "roofline_frac", "expansion_frac", "expansion_frac_alone"]
     assert "workload" in d["config"] and d["value"] > 0 and d["ms_per_step"] > 0
     r = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "launch_ms"):
         assert key in r, key
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
 
 
 def test_bench_small_msm_with_cpu_baseline():
-    d = _bench("--units", "2", "--points", "33", "--steps", "3", "--warmup", "1", "--traffic", "off", "--cpu-sample-points", "33")
+    d, full = _bench("--units", "2", "--points", "33", "--steps", "3", "--warmup", "1", "--traffic", "off", "--cpu-sample-points", "33")
     _check_contract(d, 1, 3, 1)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
@@ -44,16 +56,17 @@ def test_bench_small_msm_with_cpu_baseline():
 
 def test_bench_streaming_job_digest_and_records():
     # 8 tiles of 33 points through a ring of two 2-tile buffer sets: 4 steps, digest consumer on, records gathered
-    d = _bench("--units", "2", "--points", "33", "--job-tiles", "8", "--warmup", "1", "--traffic", "off", "--no-cpu-baseline")
+    d, full = _bench("--units", "2", "--points", "33", "--job-tiles", "8", "--warmup", "1", "--traffic", "off", "--no-cpu-baseline")
     _check_contract(d, 1, 4, 1)
     assert d["gathered_records"]["shape"] == [8, 29] and d["gathered_records"]["status_or"] == 0   # one gather of the whole job
     assert len(d["digest_sample"]) == 4 and any(d["digest_sample"])
+    assert "value_chain_ms" in full["roofline"] and "alone" in full["roofline"]   # (per-segment arrays: detail file only)
     assert d["single_batch_ms"] > 0
 
 
 @pytest.mark.parametrize("workload", ["pairing_bn256", "pairing_bls12_381"])
 def test_bench_small_pairing(workload):
-    d = _bench("--workload", workload, "--units", "2", "--steps", "3", "--warmup", "1", "--ring", "2", "--traffic", "off", "--no-cpu-baseline")
+    d, full = _bench("--workload", workload, "--units", "2", "--steps", "3", "--warmup", "1", "--ring", "2", "--traffic", "off", "--no-cpu-baseline")
     _check_contract(d, 1, 3, 1)
 
 
@@ -67,7 +80,7 @@ def test_bench_job_128_tiles_ring_digest_vs_oracle(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     dump = str(tmp_path / "job.npz")
-    d = _bench("--job-tiles", "128", "--warmup", "1", "--traffic", "off", "--no-cpu-baseline", "--latency-steps", "0",
+    d, full = _bench("--job-tiles", "128", "--warmup", "1", "--traffic", "off", "--no-cpu-baseline", "--latency-steps", "0",
                "--dump-records", dump, "--dump-tiles", "5,100")
     _check_contract(d, 1, 2, 1)
     assert d["gathered_records"]["shape"] == [128, 29] and d["gathered_records"]["status_or"] == 0
@@ -88,7 +101,7 @@ def test_bench_job_128_tiles_ring_digest_vs_oracle(tmp_path):
 def test_bench_two_ranks_one_gpu_gloo():
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                 "--master-port", str(29600 + os.getpid() % 300)]
-    d = _bench("--gpus", "2", "--units", "2", "--points", "33", "--job-tiles", "8", "--warmup", "1", "--traffic", "off", "--no-cpu-baseline",
+    d, full = _bench("--gpus", "2", "--units", "2", "--points", "33", "--job-tiles", "8", "--warmup", "1", "--traffic", "off", "--no-cpu-baseline",
                "--dist-backend", "gloo", "--device", "0", launcher=launcher)   # configs[2]'s command at a small size: --job-tiles N --gpus G
     _check_contract(d, 2, 2, 1)
     assert d["gathered_records"]["shape"] == [8, 29] and d["gathered_records"]["status_or"] == 0   # 2 steps x 2 ranks x 2 units
@@ -102,7 +115,7 @@ def test_bench_two_ranks_pairing_strong_shares_gloo(workload, total):
     gather per job - two ranks on one GPU over gloo"""
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                 "--master-port", str(29900 + os.getpid() % 90)]
-    d = _bench("--gpus", "2", "--workload", workload, "--scaling", "strong", "--total-units", str(total), "--steps", "2", "--warmup", "1",
+    d, full = _bench("--gpus", "2", "--workload", workload, "--scaling", "strong", "--total-units", str(total), "--steps", "2", "--warmup", "1",
                "--ring", "2", "--latency-steps", "0", "--traffic", "off", "--no-cpu-baseline", "--dist-backend", "gloo", "--device", "0", launcher=launcher)
     _check_contract(d, 2, 2, 1, scaling="strong")
     assert d["gathered_records"]["shape"] == [2 * total, 29] and d["gathered_records"]["status_or"] == 0
@@ -113,8 +126,9 @@ def test_bench_traffic_counters_by_launch_index():
     """`roofline.traffic`: two rocprofv3 --pmc child passes of the command, the dominant launch's dispatches picked by launch
     index (not by grid size), KiB -> bytes.  What the window strands' expansion WRITES can be neither less than the cells it
     stores nor much more (it stores assigned cells only, in whole 128-byte lines)."""
-    d = _bench("--units", "4", "--points", "96", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--latency-steps", "0")
-    r = d["roofline"].get("expansion", d["roofline"])   # (at this size the value chain is the time-dominant kernel: the expansion's figures nest under it)
+    d, full = _bench("--units", "4", "--points", "96", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--latency-steps", "0")
+    assert d["roofline"].get("expansion", d["roofline"])["traffic"] == full["roofline"].get("expansion", full["roofline"])["traffic"]
+    r = full["roofline"].get("expansion", full["roofline"])   # (at this size the value chain is the time-dominant kernel: the expansion's figures nest under it)
     if r["traffic"] is None:
         pytest.skip("rocprofv3 counters not available on this box: " + str(r.get("traffic_note")))
     td = r["traffic_detail"]
