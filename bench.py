@@ -303,6 +303,8 @@ def main():
                          "column-major Montgomery-form arrays) -> consumer_ready_ms_per_step; needs a second copy of the arrays in HBM (use --ring 1)")
     ap.add_argument("--no-check", action="store_true", help="A/B experiments with deliberately broken arithmetic")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on GPUs; gloo only to exercise the N>1 path on one GPU")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group and take the collective path (device-resident gather_table, all_reduce of the "
+                    "ranks' clocks, barriers) even with ONE rank: `--dist-backend nccl` then loads RCCL and creates a communicator on one GPU (tests)")
     ap.add_argument("--device", type=int, default=None, help="override the CUDA device index (default: LOCAL_RANK)")
     args = ap.parse_args()
     plain = (args.workload == "msm" and args.units is None and args.job_tiles is None and args.points == 1024 and args.ring is None
@@ -384,8 +386,10 @@ def main():
 
     if args.device is not None:
         local_rank = args.device
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 1000))
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
         else:
@@ -475,7 +479,7 @@ def main():
     # device as the steps retire (no host synchronisation), gathered ONCE at the end of the timed region: the one collective
     # of the path (RCCL all_gather over xGMI).  Global unit index of step k's unit t on this rank:
     # gidx(k, t).
-    want_records = world > 1 or args.digest or args.dump_records
+    want_records = dist_on or args.digest or args.dump_records
     R = parallel.record_words(L)
     job_rec, scratch_rec, plan = None, None, None
     if want_records:
@@ -565,7 +569,7 @@ def main():
     timing[0] = True
     timed_from[0] = step_no[0]
     gathered, seen = None, None
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -575,7 +579,7 @@ def main():
     if want_records:   # the final gather: one collective per job, inside the timed region
         gathered, seen = parallel.gather_table(plan, job_rec.to(coll_dev))
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if args.pmc_child:
@@ -586,7 +590,7 @@ def main():
             assert bool(seen.all()), "some units were not produced by any rank"
     rank_ms = 1e3 * elapsed / args.steps
     per_rank_ms = [rank_ms]
-    if world > 1:
+    if dist_on:
         allms = torch.zeros((world,), device=coll_dev, dtype=torch.float64)
         allms[rank] = rank_ms
         dist.all_reduce(allms, op=dist.ReduceOp.SUM)
@@ -719,6 +723,13 @@ def main():
         out["config"]["consumer"] = ("stream digest of the three advice arrays of every step (h2e_submit_digest: 32 B per array and unit, accumulated by the "
                                      "expansion while it stores), inside the timed region")
         out["digest_sample"] = [int(x) & 0xFFFFFFFFFFFFFFFF for x in digest_any[0][0, 0].cpu().tolist()] if digest_any[0] is not None else None
+    if dist_on:
+        # (is librccl mapped into this process?  the nccl backend dlopens it when the communicator is created)
+        with open("/proc/self/maps") as f:
+            rccl = any("librccl" in ln for ln in f)
+        out["collective"] = {"backend": args.dist_backend, "world": world, "device": str(coll_dev), "rccl_loaded": rccl}
+        if args.dist_backend == "nccl":
+            out["collective"]["rccl_version"] = list(torch.cuda.nccl.version())
     if gathered is not None:
         out["gathered_records"] = {"shape": list(gathered.shape), "status_or": int(gathered[:, 0].abs().max())}
         if args.dump_records and rank == 0:
@@ -776,7 +787,7 @@ def main():
             line = json.dumps(headline(out, detail))
             assert len(line) < HEADLINE_MAX_BYTES, f"bench.py: headline line is {len(line)} bytes (limit {HEADLINE_MAX_BYTES})"
             print(line, flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -13,6 +13,23 @@ CAPI_DEPS = ["capi_common.hpp", "program.hpp", "program_value_chain.hpp", "progr
              "records_api.hpp"]
 
 
+EXPORT_MAP = os.path.join(CSRC, "libh2e.map")
+
+
+def write_export_map():
+    """The library's ABI surface is include/h2e.h and nothing else: a linker version script with the header's function names as the
+    only global symbols (the engine units' h2e_engine_* launchers stay internal to the shared object)."""
+    import re
+    with open(os.path.join(HERE, "..", "include", "h2e.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(h2e_[a-z0-9_]+)\s*\(", text)))
+    body = "{\n  global:\n" + "".join(f"    {n};\n" for n in names) + "  local:\n    *;\n};\n"
+    if not os.path.exists(EXPORT_MAP) or open(EXPORT_MAP).read() != body:
+        with open(EXPORT_MAP, "w") as f:
+            f.write(body)
+    return EXPORT_MAP
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -44,8 +61,9 @@ def build(force=False, verbose=True):
     for cmd, proc in running:
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    emap = write_export_map()
+    if force or _stale(LIB, objs + [emap]):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={emap}", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

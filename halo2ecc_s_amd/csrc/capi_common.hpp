@@ -10,6 +10,7 @@
 #include <memory>
 #include <chrono>
 #include <mutex>
+#include <atomic>
 #include <string>
 #include <unordered_map>
 #include <cstring>
@@ -63,6 +64,7 @@ extern "C" int h2e_engine_predict(int field_pair, int phase, const H2EPreKernel*
 namespace {
 
 thread_local std::string g_last_error;
+thread_local std::string g_last_warning;
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;

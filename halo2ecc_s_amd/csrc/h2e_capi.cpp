@@ -12,6 +12,23 @@
 extern "C" {
 
 const char* h2e_last_error(void) { return g_last_error.c_str(); }
+extern "C" int h2e_engine_digit_rows_selftest_fp0(int, uint32_t, uint32_t, const void*, void*, hipStream_t);
+extern "C" int h2e_engine_digit_rows_selftest_fp1(int, uint32_t, uint32_t, const void*, void*, hipStream_t);
+int h2e_selftest_digit_rows(int field_pair, uint32_t op, uint32_t n_cases, const void* d_in, void* d_out, void* stream) {
+    if (!d_in || !d_out) return fail(H2E_ERR_INVALID, "null argument");
+    int rc = field_pair == 0   ? h2e_engine_digit_rows_selftest_fp0(field_pair, op, n_cases, d_in, d_out, (hipStream_t)stream)
+             : field_pair == 1 ? h2e_engine_digit_rows_selftest_fp1(field_pair, op, n_cases, d_in, d_out, (hipStream_t)stream)
+                               : -1;
+    return rc == 0 ? 0 : fail(rc < 0 ? H2E_ERR_INVALID : H2E_ERR_HIP, "digit-row self-test: no such field pair / launch failed");
+}
+const char* h2e_last_warning(void) { return g_last_warning.c_str(); }
+// hardware queues this process's HIP runtime maps its streams onto: GPU_MAX_HW_QUEUES as the runtime read it when it initialised
+// (the environment is the only place it can be set; default 4)
+static int64_t process_hw_queues() {
+    const char* e = getenv("GPU_MAX_HW_QUEUES");
+    int64_t v = e ? atoll(e) : 0;
+    return v > 0 ? v : 4;
+}
 const char* h2e_version(void) { return "h2e 0.2 (gfx950, batch-interleaved advice)"; }
 
 int h2e_ctx_create(int device, h2e_ctx** out) {
@@ -350,6 +367,16 @@ int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value) {
             HIP_TRY(hipDeviceSynchronize());   // no run may be in flight while the slots are renumbered
             ctx->depth = (uint32_t)value;
             ctx->n_runs = 0;
+            g_last_warning.clear();
+            if (value > 1 && process_hw_queues() < value + 12) {
+                // a process-global knob the library cannot set for itself (the runtime reads it once, before the first HIP call): a
+                // pipelined host that gets it wrong loses silently (8 x bn256 checks: 1.8 instead of 0.7 ms per step) - so say it
+                g_last_warning = "pipeline depth " + std::to_string(value) + " wants GPU_MAX_HW_QUEUES >= " + std::to_string(value + 12) +
+                                 " in the environment before HIP initialises; this process runs with " + std::to_string(process_hw_queues()) +
+                                 ": streams that share a hardware queue serialise (INTEGRATION.md, threading and streams)";
+                static std::atomic<bool> said{false};
+                if (!said.exchange(true)) fprintf(stderr, "libh2e: warning: %s\n", g_last_warning.c_str());
+            }
             return 0;
         case H2E_OPT_TEST_SCAN_FALLBACK:
             HIP_TRY(hipSetDevice(ctx->device));
@@ -396,6 +423,8 @@ int64_t h2e_ctx_get_stat(h2e_ctx* ctx, int stat) {
             return (int64_t)h2e_engine_scan_fallbacks();
         case H2E_STAT_PIPELINE_DEPTH: return ctx->depth;
         case H2E_STAT_MAX_PIPELINE_DEPTH: return h2e_ctx::N_SLOTS;
+        case H2E_STAT_HW_QUEUES: return process_hw_queues();
+        case H2E_STAT_HW_QUEUES_WANTED: return ctx->depth > 1 ? (int64_t)ctx->depth + 12 : 1;
         case H2E_STAT_OP_CACHE_HITS: {
             std::lock_guard<std::mutex> g2(ctx->op_mu);
             return (int64_t)ctx->op_hits;

@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "h2e_program_msm_bn256_tile_no_select", "h2e_last_run_expansion_launches",
     "h2e_run_digest", "h2e_submit_digest", "h2e_records_attach", "h2e_op_int_mul_small_constant", "h2e_op_assign_int_constant", "h2e_op_bisec_int", "h2e_op_fq", "h2e_op_pairing",
     "h2e_check", "h2e_program_tape_opcodes", "h2e_program_value_chain_kind", "h2e_program_pack_order",
-    "h2e_program_launch_rows", "h2e_unit_records", "h2e_unit_record_words",
+    "h2e_program_launch_rows", "h2e_unit_records", "h2e_unit_record_words", "h2e_selftest_digit_rows", "h2e_last_warning",
 ]
 
 
@@ -86,6 +86,7 @@ INT_NEG, INT_SQUARE, INT_UNSAFE_INVERT, INT_IS_ZERO, INT_IS_EQUAL, INT_ASSERT_EQ
 (FQ_ADD, FQ_SUB, FQ_MUL, FQ_SQUARE, FQ_NEG, FQ_DOUBLE, FQ_CONJUGATE, FQ_UNSAFE_INVERT, FQ_MUL_BY_NONRESIDUE, FQ_FROBENIUS_MAP,
  FQ_CYCLOTOMIC_SQUARE, FQ_REDUCE, FQ_ASSERT_EQUAL) = range(13)
 STAT_OP_CACHE_HITS, STAT_OP_CACHE_MISSES, STAT_OP_CACHE_EVICTIONS, STAT_OP_CACHE_SIZE = 6, 7, 8, 9
+STAT_HW_QUEUES, STAT_HW_QUEUES_WANTED = 10, 11
 
 _lib = None
 
@@ -102,6 +103,7 @@ def lib():
     L = C.CDLL(path)
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
     L.h2e_last_error.restype = C.c_char_p
+    L.h2e_last_warning.restype = C.c_char_p
     L.h2e_version.restype = C.c_char_p
     L.h2e_ctx_create.argtypes = [i32, C.POINTER(vp)]
     L.h2e_ctx_destroy.argtypes = [vp]
@@ -708,6 +710,10 @@ class Engine:
 
     def set_option(self, option, value):
         _check(lib().h2e_ctx_set_option(self._h, option, value))
+
+    def last_warning(self):
+        """"" or why the last call of this thread will not perform as asked (h2e.h h2e_last_warning)"""
+        return lib().h2e_last_warning().decode()
 
     def get_stat(self, stat):
         return int(lib().h2e_ctx_get_stat(self._h, stat))

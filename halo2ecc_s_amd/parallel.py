@@ -94,7 +94,9 @@ def gather_table(plan, buf):
     R = buf.shape[1] - 1
     dev = plan.idx.device
     assert buf.shape[0] == plan.cap and buf.device == dev
-    if plan.world > 1:
+    # (a one-rank process group still runs the collective: on a GPU that is RCCL's communicator and all_gather kernel, the exact
+    # code an N-rank job executes - tests/test_bench_gpu.py::test_bench_one_rank_rccl)
+    if plan.world > 1 or (dist.is_available() and dist.is_initialized()):
         lst = [torch.empty_like(buf) for _ in range(plan.world)]
         dist.all_gather(lst, buf)
         parts = torch.cat(lst)

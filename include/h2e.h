@@ -209,7 +209,14 @@ int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value);
 #define H2E_STAT_OP_CACHE_MISSES 7     /* operand handles, cursors, heights, msm prefix) / ops that had to be recorded */
 #define H2E_STAT_OP_CACHE_EVICTIONS 8  /* programs the cache let go (H2E_OPT_OP_CACHE_CAP) */
 #define H2E_STAT_OP_CACHE_SIZE 9
+#define H2E_STAT_HW_QUEUES 10          /* hardware queues the process's streams are mapped onto (GPU_MAX_HW_QUEUES as the environment had it when HIP
+                                          initialised; default 4) */
+#define H2E_STAT_HW_QUEUES_WANTED 11   /* ... and what the context's pipeline depth wants (depth + 12; 1 without pipelining).  h2e_ctx_set_option(
+                                          H2E_OPT_PIPELINE_DEPTH) succeeds either way, but leaves a text in h2e_last_warning() and one line on stderr
+                                          when the process has fewer: streams that share a queue serialise */
 int64_t h2e_ctx_get_stat(h2e_ctx* ctx, int stat);
+/* text of the last call's warning on this thread ("" if it had none): a call that succeeded but will not perform as asked */
+const char* h2e_last_warning(void);
 
 /* Named entry points of SURVEY.md §8(b): build-or-reuse the program for the shape, then run it. */
 int h2e_int_mul_batch(h2e_ctx* ctx, int field_pair, uint32_t n, uint32_t n_instances, const void* d_inputs, void* d_base,
@@ -430,6 +437,14 @@ int h2e_job_launch_ms(h2e_ctx* ctx, int job, float* ms, uint32_t cap);
 /* Companion of h2e_last_run_launch_ms: counts[i] = kernel launches the full expansion of segment i went out as in the
  * last run (1, or 2 when a big expansion was split - ms[2i+1] then brackets both; see h2e_capi.cpp `expand`). */
 int h2e_last_run_expansion_launches(h2e_ctx* ctx, uint32_t* counts, uint32_t cap);
+
+/* ---- test hook ----------------------------------------------------------------------------------
+ * The digit-row primitives of the pairings' value chain (csrc/engine.hip DigitRow: one 16-lane row per number, one lane per
+ * 32-bit digit) on caller-chosen operands - the patterns random data never produces (a carry through a run of 0xffffffff digits,
+ * quotient estimates at exact multiples of w): tests/test_digit_rows_gpu.py.  op 0: normalize(columns lo, hi), 2: Montgomery
+ * product, else: reduce_columns; d_in = [n_cases][2][16] u32, d_out = [n_cases][16] u32; field_pair 0 or 1, whose constants a
+ * run of any program of that pair has put on the device. */
+int h2e_selftest_digit_rows(int field_pair, uint32_t op, uint32_t n_cases, const void* d_in, void* d_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,8 @@ pub const H2E_FQ_REDUCE: c_int = 11;
 pub const H2E_FQ_ASSERT_EQUAL: c_int = 12;
 pub const H2E_OPT_PIPELINE_DEPTH: c_int = 4;
 pub const H2E_OPT_PREFAULT_HBM: c_int = 6;
+pub const H2E_STAT_HW_QUEUES: c_int = 10;
+pub const H2E_STAT_HW_QUEUES_WANTED: c_int = 11;
 
 /// AssignedInteger (src/assign.rs:31-37) as cell references (region << 30 | col << 27 | row) + `times`
 #[repr(C)]
@@ -122,6 +124,9 @@ pub struct h2e_shape {
 extern "C" {
     pub fn h2e_last_error() -> *const c_char;
     pub fn h2e_version() -> *const c_char;
+    /// "" or why the last call on this thread, though it succeeded, will not perform as asked (GPU_MAX_HW_QUEUES too small for the
+    /// pipeline depth: the one process-wide knob the library cannot set for itself)
+    pub fn h2e_last_warning() -> *const c_char;
     pub fn h2e_ctx_create(device: c_int, out: *mut *mut c_void) -> c_int;
     pub fn h2e_ctx_destroy(ctx: *mut c_void);
     pub fn h2e_ctx_set_option(ctx: *mut c_void, option: c_int, value: i64) -> c_int;
@@ -138,12 +143,51 @@ extern "C" {
     pub fn h2e_program_destroy(p: *mut c_void);
     pub fn h2e_program_shape(p: *const c_void, out: *mut h2e_shape) -> c_int;
     pub fn h2e_program_outputs(p: *const c_void, refs: *mut u32, cap: u32) -> c_int;
+    /// one entry of 8 words per engine launch of a run: n_strands, n_ops, advice cells written per instance (0 unless emit_shape),
+    /// per-strand Offset (base, range, select), n_params, first base row; returns the count
+    pub fn h2e_program_launches(p: *const c_void, out: *mut u64, cap: u32) -> c_int;
+    pub fn h2e_program_launch_rows(p: *const c_void, launch: u32, out: *mut u64) -> c_int;
+    // diagnostics
+    pub fn h2e_program_tape_opcodes(p: *const c_void, launch: u32, opcodes: *mut u16, cap: u32, subs: *mut u32, subs_cap: u32,
+                                    n_subs: *mut u32) -> c_int;
+    pub fn h2e_program_pack_order(p: *const c_void, launch: u32, groups_log2m1: u32, out: *mut u32, cap: u32) -> c_int;
+    pub fn h2e_program_value_chain_kind(p: *const c_void, launch: u32, out3: *mut u32) -> c_int;
     // ---- execution ----
     pub fn h2e_run(ctx: *mut c_void, p: *mut c_void, n_instances: u32, d_inputs: *const c_void, d_base: *mut c_void,
                    d_range: *mut c_void, d_select: *mut c_void, d_status: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn h2e_submit(ctx: *mut c_void, p: *mut c_void, n_instances: u32, d_inputs: *const c_void, d_base: *mut c_void,
                       d_range: *mut c_void, d_select: *mut c_void, d_status: *mut c_void, stream: *mut c_void, job: *mut c_int) -> c_int;
     pub fn h2e_wait(ctx: *mut c_void, job: c_int, stream: *mut c_void) -> c_int;
+    /// the same with the stream digest as the consumer: d_digests = [3][n_instances][4] u64, accumulated by the expansion while it
+    /// stores (a streaming job's consumer: no second pass over the cells; INTEGRATION.md "A stream of batches")
+    pub fn h2e_run_digest(ctx: *mut c_void, p: *mut c_void, n_instances: u32, d_inputs: *const c_void, d_base: *mut c_void,
+                          d_range: *mut c_void, d_select: *mut c_void, d_status: *mut c_void, d_digests: *mut c_void,
+                          stream: *mut c_void) -> c_int;
+    pub fn h2e_submit_digest(ctx: *mut c_void, p: *mut c_void, n_instances: u32, d_inputs: *const c_void, d_base: *mut c_void,
+                             d_range: *mut c_void, d_select: *mut c_void, d_status: *mut c_void, d_digests: *mut c_void,
+                             stream: *mut c_void, job: *mut c_int) -> c_int;
+    // ---- the named entry points of SURVEY.md 8(b): program recorded and cached per shape inside the context ----
+    /// IntegerChipOps::int_mul on n (a, b) pairs per instance (src/circuit/integer_chip.rs:466-483)
+    pub fn h2e_int_mul_batch(ctx: *mut c_void, field_pair: c_int, n: u32, n_instances: u32, d_inputs: *const c_void,
+                             d_base: *mut c_void, d_range: *mut c_void, d_select: *mut c_void, d_status: *mut c_void,
+                             stream: *mut c_void) -> c_int;
+    /// EccChipScalarOps::msm_unsafe on a tile of n_points (src/circuit/ecc_chip.rs:373-408), test body of
+    /// src/tests/native_scalar_ecc_chip.rs:34-47 per tile
+    pub fn h2e_msm_bn256_tile(ctx: *mut c_void, n_points: u32, n_tiles: u32, d_inputs: *const c_void, d_base: *mut c_void,
+                              d_range: *mut c_void, d_select: *mut c_void, d_status: *mut c_void, stream: *mut c_void) -> c_int;
+    /// PairingChipOps::check_pairing (src/circuit/pairing_chip.rs:173-176) on the reference's two-pair test shape
+    pub fn h2e_pairing_check_bn256(ctx: *mut c_void, n_instances: u32, d_inputs: *const c_void, d_base: *mut c_void,
+                                   d_range: *mut c_void, d_select: *mut c_void, d_status: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn h2e_pairing_check_bls12_381(ctx: *mut c_void, n_instances: u32, d_inputs: *const c_void, d_base: *mut c_void,
+                                       d_range: *mut c_void, d_select: *mut c_void, d_status: *mut c_void, stream: *mut c_void) -> c_int;
+    // ---- timing hooks (HIP events the engine records on its own streams) ----
+    pub fn h2e_set_profiling(ctx: *mut c_void, enable: c_int) -> c_int;
+    pub fn h2e_last_run_launch_ms(ctx: *mut c_void, ms: *mut f32, cap: u32) -> c_int;
+    pub fn h2e_job_launch_ms(ctx: *mut c_void, job: c_int, ms: *mut f32, cap: u32) -> c_int;
+    pub fn h2e_last_run_expansion_launches(ctx: *mut c_void, counts: *mut u32, cap: u32) -> c_int;
+    /// test hook: the value chain's digit-row primitives on caller-chosen operands (tests/test_digit_rows_gpu.py)
+    pub fn h2e_selftest_digit_rows(field_pair: c_int, op: u32, n_cases: u32, d_in: *const c_void, d_out: *mut c_void,
+                                   stream: *mut c_void) -> c_int;
     // ---- hand-off ----
     pub fn h2e_export(ctx: *mut c_void, p: *mut c_void, n_instances: u32, region: c_int, layout: c_int, form: c_int,
                       d_batch: *const c_void, d_out: *mut c_void, stream: *mut c_void) -> c_int;

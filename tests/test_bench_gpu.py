@@ -108,6 +108,28 @@ def test_bench_two_ranks_one_gpu_gloo():
     assert len(d["per_rank_ms_per_step"]) == 2
 
 
+def test_bench_one_rank_rccl(tmp_path):
+    """The `nccl` branch of the multi-GPU path on the one GPU there is: torch.distributed.run with ONE rank, `--force-dist` ->
+    init_process_group("nccl") (RCCL loaded, a communicator created on the device), the job's table stays on the device, `all_gather` of
+    cuda tensors, `all_reduce` of the ranks' clocks, device barriers.  The gathered records equal those of the same job without a process
+    group (same tiles, same digests) - and of the gloo path, which test_bench_two_ranks_one_gpu_gloo runs."""
+    import numpy as np
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                "--master-port", str(29300 + os.getpid() % 200)]
+    common = ["--units", "2", "--points", "33", "--job-tiles", "8", "--warmup", "1", "--traffic", "off", "--no-cpu-baseline", "--latency-steps", "0"]
+    a, b = str(tmp_path / "rccl.npz"), str(tmp_path / "plain.npz")
+    d, full = _bench("--gpus", "1", *common, "--dist-backend", "nccl", "--force-dist", "--dump-records", a, launcher=launcher,
+                     env={"NCCL_DEBUG": "VERSION", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    _check_contract(d, 1, 4, 1)
+    c = full["collective"]
+    assert (c["backend"], c["world"], c["device"], c["rccl_loaded"]) == ("nccl", 1, "cuda:0", True) and c["rccl_version"][0] >= 2
+    assert d["gathered_records"]["shape"] == [8, 29] and d["gathered_records"]["status_or"] == 0
+    d2, _ = _bench(*common, "--dump-records", b)
+    ra, rb = np.load(a)["records"], np.load(b)["records"]
+    assert ra.shape == (8, 29) and np.array_equal(ra, rb)
+    assert len({tuple(r[17:29]) for r in ra}) == 8
+
+
 @pytest.mark.parametrize("workload,total", [("pairing_bn256", 5), ("pairing_bls12_381", 3)])
 def test_bench_two_ranks_pairing_strong_shares_gloo(workload, total):
     """configs[3] / configs[4] as the N > 1 launch deals them: BASELINE's batch round-robin over the ranks (--scaling strong; here 5

@@ -2,7 +2,7 @@
 digit) against Python integers, on the patterns the parity tests never produce: a carry that has to ripple through a run of
 0xffffffff digits (probability 2^-32 per digit on random data), quotient
 estimates on the boundary (exact multiples of w and their neighbours), operands at the ends of the lazy range [0, 2w).
-Through the engine's test hook h2e_engine_digit_rows_selftest_fp<k> (one row per case)."""
+Through the boundary's test hook h2e_selftest_digit_rows (include/h2e.h; one row per case)."""
 import ctypes as C
 import random
 
@@ -41,7 +41,7 @@ def rows(engine):
     torch.cuda.synchronize()
 
     def run(fp, op, cases):
-        fn = getattr(lib(), f"h2e_engine_digit_rows_selftest_fp{fp}")
+        fn = lib().h2e_selftest_digit_rows
         fn.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         fn.restype = C.c_int
         a = np.zeros((len(cases), 2, 16), dtype=np.uint32)

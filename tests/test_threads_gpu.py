@@ -131,3 +131,30 @@ def test_same_program_from_two_threads(engine, oracle):
     assert not errors, errors
     for tid in range(2):
         _compare(shared, results[tid])
+
+
+def test_pipeline_depth_warns_when_the_process_has_too_few_hardware_queues():
+    """GPU_MAX_HW_QUEUES is read by the HIP runtime once, from the environment, before the first HIP call: the library cannot set it
+    for a host that pipelines.  h2e_ctx_set_option(H2E_OPT_PIPELINE_DEPTH) therefore says so - h2e_last_warning(), one line on
+    stderr, H2E_STAT_HW_QUEUES / _WANTED - instead of letting the streams serialise silently (1.8 instead of 0.7 ms per 8-check step).
+    Child processes: the knob is per process."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from halo2ecc_s_amd import Engine\n"
+            "from halo2ecc_s_amd.engine import OPT_PIPELINE_DEPTH, STAT_HW_QUEUES, STAT_HW_QUEUES_WANTED\n"
+            "e = Engine(0)\n"
+            "e.set_option(OPT_PIPELINE_DEPTH, 16)\n"
+            "print('W16', repr(e.last_warning()), e.get_stat(STAT_HW_QUEUES), e.get_stat(STAT_HW_QUEUES_WANTED))\n"
+            "e.set_option(OPT_PIPELINE_DEPTH, 1)\n"
+            "print('W1', repr(e.last_warning()), e.get_stat(STAT_HW_QUEUES_WANTED))\n") % ROOT
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    w16, w1 = [ln for ln in r.stdout.splitlines() if ln.startswith("W")]
+    assert "GPU_MAX_HW_QUEUES >= 28" in w16 and w16.endswith(" 4 28") and "libh2e: warning" in r.stderr
+    assert w1 == "W1 '' 1"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, GPU_MAX_HW_QUEUES="28"), timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert [ln for ln in r.stdout.splitlines() if ln.startswith("W16")] == ["W16 '' 28 28"] and "libh2e: warning" not in r.stderr
