@@ -193,7 +193,8 @@ def headline(out, detail_path):
                              "dtype", "data")}
     c = out["config"]
     h["config"] = {"workload": short(c["workload"], 200), "units_per_gpu": c["units_per_gpu"], "units_per_step_all_gpus": c["units_per_step_all_gpus"],
-                   "cells_per_unit": c["cells_per_unit"], "pipeline": short(c["pipeline"], 80)}
+                   "cells_per_unit": c["cells_per_unit"], "pipeline": short(c["pipeline"], 120), "steps_per_run": c.get("steps_per_run", 1),
+                   "output_arrays": short(c.get("output_arrays", ""), 140)}
     r = out["roofline"]
     h["roofline"] = roof(r)
     if "expansion" in r:   # (the value chain is the time-dominant kernel: the expansion's own figure, with the counters' traffic, beside it)
@@ -234,11 +235,18 @@ def run_children(args):
     # times single batches (run + export) one after the other: min(K, 3).  Every child's block carries its own "steps" / "warmup".
     sw = ["--steps", str(args.steps), "--warmup", str(args.warmup)]
     deep = ["--steps", str(6 * args.steps), "--warmup", str(args.warmup)]
+    deep8 = ["--steps", str(48 * args.steps), "--warmup", str(8 * args.warmup)]
     jobs = [("pairing_bn256", ["--workload", "pairing_bn256"] + sw),
             ("pairing_bls12_381", ["--workload", "pairing_bls12_381"] + deep),
             # one GPU's share of configs[3] / configs[4] when the batch is dealt over 8 GPUs: batches smaller than a wave
             ("pairing_bn256_share8", ["--workload", "pairing_bn256", "--units", "8", "--no-cpu-baseline"] + deep + off),
             ("pairing_bls12_381_share8", ["--workload", "pairing_bls12_381", "--units", "2", "--no-cpu-baseline"] + deep + off),
+            # ... and the same shares with the steps submitted eight at a time as one run (h2e_submit_batches): a stream of small
+            # batches then costs runs, not instances - what a host with one GPU's share of an 8-GPU job does
+            # (8 x as many steps: the timed region then holds as many RUNS as the ungrouped lines' - with fewer runs than job slots the
+            # figure would be the pipeline's fill and drain)
+            ("pairing_bn256_share8_grouped", ["--workload", "pairing_bn256", "--units", "8", "--group", "8", "--no-cpu-baseline"] + deep8 + off),
+            ("pairing_bls12_381_share8_grouped", ["--workload", "pairing_bls12_381", "--units", "2", "--group", "8", "--no-cpu-baseline"] + deep8 + off),
             ("msm_job_2e20", ["--workload", "msm", "--job-tiles", "1024", "--warmup", str(args.warmup), "--no-cpu-baseline"] + off),
             # the headline batch all the way to what halo2 consumes: per-instance advice columns
             ("msm_consumer_ready", ["--workload", "msm", "--ring", "1", "--steps", str(min(args.steps, 3)), "--warmup", "1", "--latency-steps", "0",
@@ -303,6 +311,13 @@ def main():
                          "column-major Montgomery-form arrays) -> consumer_ready_ms_per_step; needs a second copy of the arrays in HBM (use --ring 1)")
     ap.add_argument("--no-check", action="store_true", help="A/B experiments with deliberately broken arithmetic")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on GPUs; gloo only to exercise the N>1 path on one GPU")
+    ap.add_argument("--shared-rows", default="auto", choices=["auto", "on", "off"],
+                    help="h2e_ring: the ring's runs share the rows of the program's biggest launch (the MSM's window strands: 83 %% of a tile's cells) between runs k "
+                         "and k + 2 - THREE runs in flight in 2.2 array sets of memory (3 full sets of 64 tiles do not fit 288 GB).  auto: the MSM with a ring of 3 or more")
+    ap.add_argument("--group", type=int, default=1, metavar="G",
+                    help="submit the steps G at a time as ONE run (h2e_submit_batches): every step keeps its own inputs, arrays and status words - a step is still one "
+                         "batch of --units - but a stream of small batches then costs runs, not instances (one GPU's share of a pairing job at 8 GPUs: 2 / 8 checks "
+                         "per step); steps and warm-up are rounded up to whole groups")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and take the collective path (device-resident gather_table, all_reduce of the "
                     "ranks' clocks, barriers) even with ONE rank: `--dist-backend nccl` then loads RCCL and creates a communicator on one GPU (tests)")
     ap.add_argument("--device", type=int, default=None, help="override the CUDA device index (default: LOCAL_RANK)")
@@ -313,6 +328,14 @@ def main():
         args.suite = "all" if plain else "main"
     if args.units is None:
         args.units = DEFAULT_UNITS[args.workload]
+    G = max(1, args.group)
+    if G > 1:
+        if args.job_tiles or args.digest:
+            sys.exit("bench.py: --group runs have no stream digest (h2e_submit_batches)")
+        if G > 16:
+            sys.exit("bench.py: --group is at most 16 (h2e.h)")
+        args.steps = (args.steps + G - 1) // G * G
+        args.warmup = (args.warmup + G - 1) // G * G
     if args.job_tiles:
         args.digest = True
         args.steps = max(1, args.job_tiles // (args.units * max(1, args.gpus)))
@@ -338,7 +361,7 @@ def main():
 
     if args.ring is None:
         # (strong scaling: by the largest share, so that every rank decides alike)
-        ring_units = args.units if total_units is None else (total_units + world - 1) // world
+        ring_units = (args.units if total_units is None else (total_units + world - 1) // world) * G   # (instances of a run)
         # MSM: two 110 GB buffer sets.  Pairing checks: sixteen runs in flight - a run's value chain (one 1024-thread workgroup per
         # check) is latency-bound on its CU for ~2 ms and a batch of a few checks leaves the rest of the GPU to the runs around it; such a
         # run lives in ONE stream (run.hpp), so sixteen of them fit the hardware queues.  (Rounds 4-5 measured "a fifth run in flight
@@ -346,7 +369,9 @@ def main():
         # every slot primed, round 5: 8 x bn256 1.01 / 0.76 / 0.64 ms per step at 4 / 8 / 16, 2 x bls12_381 0.90 / 0.59 / 0.44, 16 x
         # bls12_381 1.47 / 1.37 / 1.25.)  A full 64-check bn256 batch fills the GPU by itself (3.27 / 3.25 / 3.28 at 4 / 6 / 8): four -
         # 20 GB of arrays per buffer set.
-        args.ring = {"msm": 2, "pairing_bn256": 16 if ring_units <= 32 else 4, "pairing_bls12_381": 16}[args.workload]
+        # MSM: three runs in flight (h2e_ring: two physical copies of the window strands' rows + three of the rest = 240 GB for 64 tiles;
+        # with two full sets - all that fits without sharing - the step was half a run's latency: 15.1-15.7 ms, rounds 3-5)
+        args.ring = {"msm": 3 if args.shared_rows != "off" and args.consumer_ready == 0 else 2, "pairing_bn256": 16 if ring_units <= 32 else 4, "pairing_bls12_381": 16}[args.workload]
     # pipelined runs use several HIP streams (caller's, expansion, fix-up, a chain and a side stream per job slot): more than
     # the 4 hardware queues a process gets by default, and streams that share a queue serialise
     # (per job slot: a chain stream - the whole run of a small pairing batch -, for the big batches a completion and, some programs,
@@ -364,7 +389,7 @@ def main():
     # never pass on data a previous step left behind; a streaming job has one batch per step: tile (step * world + rank) * units + t.
     # MSM tiles are generated by a process pool *before* this process initialises HIP (fork is only safe until then).
     job_mode = bool(args.job_tiles)
-    n_batches = args.steps if job_mode else 2
+    n_batches = args.steps if job_mode else 2 * G   # (grouped steps: two groups of G different batches alternate)
     # units of one step over all ranks, and the global index of this rank's unit t of step / batch k (weak: rank-major blocks
     # of `units`; strong: round-robin shares of BASELINE's batch, possibly ragged)
     T = total_units if total_units is not None else units * world
@@ -432,7 +457,24 @@ def main():
             eng.set_option(6, 92)
         except Exception as e:   # noqa: BLE001  (somebody else is using the device: not an error)
             print(f"bench.py: first-touch pass skipped ({str(e).splitlines()[0]})", file=sys.stderr)
-    bufs = [eng.alloc(prog, units) for _ in range(ring)]   # (base, range, select, status) per ring slot
+    # (base, range, select, status) per ring slot and step of a group (one step per run unless --group)
+    shared = args.shared_rows == "on" or (args.shared_rows == "auto" and args.workload == "msm" and ring >= 3)
+    if shared and (G > 1 or ring < 2):
+        sys.exit("bench.py: --shared-rows needs a ring of at least 2 and no --group")
+    h2e_ring = None
+    if shared:
+        from halo2ecc_s_amd import Ring
+        h2e_ring = Ring(eng, prog, units, ring)
+        bufs = None
+        ring_status = [torch.zeros((units,), dtype=torch.int32, device=dev) for _ in range(ring)]
+    else:
+        bufs = [[eng.alloc(prog, units) for _ in range(G)] for _ in range(ring)]
+
+    def arrays_of(k, g=0):
+        """(base, range, select, status) of step k (+ g inside a grouped run)"""
+        if h2e_ring is not None:
+            return h2e_ring.arrays(k) + (ring_status[k % ring],)
+        return bufs[(k // G) % ring][g]
     out_refs = prog.outputs()
     # the MSM's result point as cell references (x limbs, x native, y limbs, y native, z): 3-limb coordinates for bn256, 4-limb
     # ones for a bls12_381 tile; a pairing check has no result point (its records carry status, Offset and digests)
@@ -451,7 +493,7 @@ def main():
         if args.workload == "msm" and not args.pmc_child:
             # pass 0: learn each tile's MSM result, then feed it back as the `expected` input so that the in-circuit
             # ecc_assert_equal holds in every timed pass (the reference test computes it with the native library)
-            base, rng, sel, status = bufs[0]
+            base, rng, sel, status = arrays_of(0)
             eng.run(prog, d_in, base, rng, sel, status)
             torch.cuda.synchronize()
             exp = np.zeros((units, 3, 4), dtype=np.uint64)
@@ -469,7 +511,7 @@ def main():
             d_in[:, 4 * n + 6:4 * n + 9, :] = torch.from_numpy(exp.view(np.int64)).to(dev)
         batches.append(d_in)
     host_batches = None
-    status_any = torch.zeros_like(bufs[0][3])   # OR of every step's status words
+    status_any = torch.zeros_like(arrays_of(0)[3])   # OR of every step's status words
     step_no = [0]
     timing = [False]
     pending = []   # (job, ring slot, step index) submitted and not yet waited for
@@ -493,14 +535,15 @@ def main():
     def consume(slot, k):
         """what happens to a finished step's arrays: status OR, optional on-device digest (the consumer of a streaming
         job: SURVEY 8d cfg 3), and its rows of the job's record table"""
-        base, rng, sel, status = bufs[slot]
-        status_any.bitwise_or_(status)
-        if args.digest:   # (the stream digest was accumulated by the run itself: nothing to launch here)
-            digest_any[0] = digests[slot]
-        if want_records:   # (warm-up steps write a scratch block)
-            k0 = (k - timed_from[0]) * units
-            rows = job_rec[k0:k0 + units] if timing[0] else scratch_rec
-            eng.unit_records(prog, base, status, digests[slot] if args.digest else None, out=rows, col0=1)
+        for g in range(G):   # (a run holds G steps: k, k + 1, ...)
+            base, rng, sel, status = arrays_of(k, g)
+            status_any.bitwise_or_(status)
+            if args.digest:   # (the stream digest was accumulated by the run itself: nothing to launch here)
+                digest_any[0] = digests[slot]
+            if want_records:   # (warm-up steps write a scratch block)
+                k0 = (k + g - timed_from[0]) * units
+                rows = job_rec[k0:k0 + units] if timing[0] else scratch_rec
+                eng.unit_records(prog, base, status, digests[slot] if args.digest else None, out=rows, col0=1)
 
     launch_ms = []      # per timed step: (value chain ms, expansion ms) per launched segment, from the engine's HIP events
     timed_from = [0]
@@ -516,13 +559,19 @@ def main():
         return batches[(k - timed_from[0]) % n_batches] if (job_mode and timing[0]) else batches[k % n_batches]
 
     def step():
+        """one run = G steps (G = 1 unless --group)"""
         k = step_no[0]
-        step_no[0] += 1
-        slot = k % ring
-        base, rng, sel, status = bufs[slot]
+        step_no[0] += G
+        slot = (k // G) % ring
+        base, rng, sel, status = arrays_of(k)
+        group = [(batch_of(k + g),) + tuple(arrays_of(k, g)) for g in range(G)] if G > 1 else None
+        for g in range(1, G):
+            arrays_of(k, g)[3].zero_()
         if ring == 1:
             status.zero_()
-            if args.digest:
+            if group:
+                eng.run_batches(prog, group)
+            elif args.digest:
                 eng.run_digest(prog, batch_of(k), base, rng, sel, status, digests[slot])
             else:
                 eng.run(prog, batch_of(k), base, rng, sel, status)
@@ -534,7 +583,11 @@ def main():
         while len(pending) >= ring:                     # the slot's previous step must have been consumed
             retire(*pending.pop(0))
         status.zero_()
-        if args.digest:
+        if h2e_ring is not None:    # (runs of a ring are numbered from 0: step_no is)
+            job = h2e_ring.submit(k, batch_of(k), status, digests[slot] if args.digest else None)
+        elif group:
+            job = eng.submit_batches(prog, group)
+        elif args.digest:
             job = eng.submit_digest(prog, batch_of(k), base, rng, sel, status, digests[slot])
         else:
             job = eng.submit(prog, batch_of(k), base, rng, sel, status)
@@ -550,9 +603,9 @@ def main():
     # Slot priming, before the W warm-up steps and like them untimed: a job slot's first run allocates its workspace and creates its
     # streams (~10 ms of host work each), so every one of the `ring` slots runs once here - with W < ring the timed region used to
     # pay for the slots the warm-up had not reached (what made rings deeper than W = 4 look slow in rounds 4-5).
-    for _ in range(max(0, ring - args.warmup) if ring > 1 else 0):
+    for _ in range(max(0, ring - args.warmup // G) if ring > 1 else 0):
         step()
-    for _ in range(args.warmup):
+    for _ in range(args.warmup // G):
         step()
     drain()
     torch.cuda.synchronize()
@@ -573,7 +626,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // G):
         step()
     drain()
     if want_records:   # the final gather: one collective per job, inside the timed region
@@ -603,7 +656,7 @@ def main():
     timing[0] = False
     if args.latency_steps > 0:
         lat = []
-        base, rng, sel, status = bufs[0]
+        base, rng, sel, status = arrays_of(0)
         for i in range(args.latency_steps):
             status.zero_()
             torch.cuda.synchronize()
@@ -620,7 +673,7 @@ def main():
     consumer_ms = None
     if args.consumer_ready > 0:
         from halo2ecc_s_amd.engine import FORM_MONTGOMERY, LAYOUT_COLUMNS
-        base, rng, sel, status = bufs[0]
+        base, rng, sel, status = arrays_of(0)
         outs = [None, None, None]
         lat = []
         for i in range(args.consumer_ready + 1):   # (the first pass allocates the column arrays and is not counted)
@@ -649,7 +702,7 @@ def main():
     # a big expansion goes out as several back-to-back kernel launches over consecutive parts of its sub-ranges (h2e.h):
     # the events bracket both, so the per-launch figures are bracket / n and bytes / n
     dom_ms = float(np.mean([ms[dom][1] for ms in launch_ms])) / dom_n
-    dom_bytes = 32.0 * launches[dom]["cells"] * units / dom_n
+    dom_bytes = 32.0 * launches[dom]["cells"] * units * G / dom_n   # (a launch of a grouped run holds G steps' instances)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     chain_ms = float(np.mean([ms[dom][0] for ms in launch_ms]))
     ms_per_step = 1e3 * elapsed / args.steps
@@ -663,7 +716,7 @@ def main():
                     f"(2^{int(np.log2(max(1, args.job_tiles * n)))} points) over {world} GPU(s): {units} tiles per step and GPU, every tile its own inputs")
     else:
         desc = f"{units} x {args.workload} check_pairing (2 pairs, G2 constant) per GPU, reference test shape"
-    packed = args.workload != "msm" and units <= 32   # (batches smaller than half a wave: several sub-ranges per wave, engine.hip)
+    packed = args.workload != "msm" and units * G <= 32   # (batches smaller than half a wave: several sub-ranges per wave, engine.hip)
     x_kernel = (f"h2e_run_tape_packed<{fpname}>" if packed else f"h2e_run_tape<{fpname}, false>") + " (full expansion of " + (
         "the MSM window strands)" if args.workload == "msm" else "the pairing check: one launch per segment of the check)")
     x_roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -690,7 +743,7 @@ def main():
         a_dom = float(np.median([ms[dom][1] for ms in alone_ms])) / dom_n
         roof["alone"] = {"value_chain_ms": [float(x) for x in np.median(np.array([[a for a, _ in ms] for ms in alone_ms]), axis=0)],
                          "expansion_ms": [float(x) for x in np.median(np.array([[b for _, b in ms] for ms in alone_ms]), axis=0)],
-                         "expansion_launch_ms": a_dom, "expansion_frac": dom_bytes / (a_dom * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "expansion_launch_ms": a_dom, "expansion_frac": dom_bytes / G / (a_dom * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "note": "single-batch steps (h2e_run, nothing else in flight); the figures outside this block are launches next to the ring's other runs"}
     out = {
         "metric": "witness_cells_per_sec",
@@ -706,7 +759,12 @@ def main():
         "dtype": "u64",
         "data": "synthetic",
         "config": {"workload": desc, "units_per_gpu": units, "units_per_step_all_gpus": T, "cells_per_unit": cells_per_unit,
-                   "pipeline": f"ring of {ring} output-buffer sets, steps submitted with h2e_submit" if ring > 1 else "h2e_run, one step after the other",
+                   "pipeline": (f"ring of {ring} output-buffer sets, steps submitted with h2e_submit" if ring > 1 else "h2e_run, one step after the other")
+                               + (f"; {G} steps per run (h2e_submit_batches: every step its own inputs, arrays and status words)" if G > 1 else ""),
+                   "steps_per_run": G,
+                   "output_arrays": (f"h2e_ring: {ring} runs in flight in {h2e_ring.info['physical_bytes'] / sum(h2e_ring.info['set_bytes']):.2f} array sets "
+                                     f"({h2e_ring.info['physical_bytes'] / 1e9:.0f} GB): the rows of launch {h2e_ring.info['shared_launch']} shared by runs k and k + 2"
+                                     if h2e_ring is not None else f"{ring} x {G} plain array sets"),
                    "sharding": f"units round-robin over {world} GPU(s); one all_gather of the job's per-unit records at the end of the timed region"},
         "single_batch_ms": single_ms,
         "consumer_ready_ms_per_step": consumer_ms,
@@ -747,6 +805,8 @@ def main():
     else:
         x_roof["traffic_note"] = traffic_err
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if h2e_ring is not None:
+            h2e_ring.close()
         del bufs, digests   # (the oracle needs host memory only; drop the device arrays first)
         torch.cuda.empty_cache()
         msm_inputs = None

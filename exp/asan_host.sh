@@ -13,11 +13,7 @@ C=halo2ecc_s_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -o exp/_dbg/libh2e_asan.so \
     $C/engine_fp0.o $C/engine_fp1.o $C/engine_fp2.o exp/_dbg/h2e_capi_asan.o $C/checker.o $C/handoff.o
 ASAN_LIB=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so)
-cp halo2ecc_s_amd/libh2e.so exp/_dbg/libh2e_shipped.so
-cp exp/_dbg/libh2e_asan.so halo2ecc_s_amd/libh2e.so
 set +e
 LD_PRELOAD=$ASAN_LIB ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
-    python -m pytest tests/test_shape_cpu.py -x -q -m "not gpu" "$@"
-rc=$?
-cp exp/_dbg/libh2e_shipped.so halo2ecc_s_amd/libh2e.so
-exit $rc
+    bash exp/with_lib.sh exp/_dbg/libh2e_asan.so -- python -m pytest tests/test_shape_cpu.py -x -q -m "not gpu" "$@"
+exit $?

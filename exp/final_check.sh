@@ -7,14 +7,12 @@ timeout 3000 python -m pytest tests -m gpu -q -rs > $O/pytest.log 2>&1; echo "py
 bash exp/r5_profiles.sh $TAG > $O/profiles.log 2>&1; tail -3 $O/profiles.log | cut -c1-1200
 # device timelines (debug build's stamp kernels: no profiler in the way of the host) of the pipelined lines
 if [ -f exp/_dbg/libh2e_dbg.so ]; then
-  cp halo2ecc_s_amd/libh2e.so /tmp/libh2e_keep.so
-  cp exp/_dbg/libh2e_dbg.so halo2ecc_s_amd/libh2e.so
+  W="bash exp/with_lib.sh exp/_dbg/libh2e_dbg.so --"   # (the debug build stands in for the product only while one command runs)
   B="--sub --suite main --traffic off --no-cpu-baseline --latency-steps 0"
-  python exp/bench_timeline.py 30 18 -- $B --workload pairing_bn256 --units 8 2>&1 | grep -v "^{" > $O/dev_timeline_bn256_share8.txt
-  python exp/bench_timeline.py 30 18 -- $B --workload pairing_bls12_381 --units 2 2>&1 | grep -v "^{" > $O/dev_timeline_bls12_381_share8.txt
-  python exp/bench_timeline.py 30 18 -- $B --workload pairing_bls12_381 2>&1 | grep -v "^{" > $O/dev_timeline_bls12_381.txt
-  python exp/bench_timeline.py 24 8 -- $B --workload pairing_bn256 2>&1 | grep -v "^{" > $O/dev_timeline_bn256.txt
-  python exp/bench_timeline.py 20 6 -- $B --workload msm --steps 16 2>&1 | grep -v "^{" > $O/dev_timeline_msm.txt
-  cp /tmp/libh2e_keep.so halo2ecc_s_amd/libh2e.so
+  $W python exp/bench_timeline.py 30 18 -- $B --workload pairing_bn256 --units 8 2>&1 | grep -v "^{" > $O/dev_timeline_bn256_share8.txt
+  $W python exp/bench_timeline.py 30 18 -- $B --workload pairing_bls12_381 --units 2 2>&1 | grep -v "^{" > $O/dev_timeline_bls12_381_share8.txt
+  $W python exp/bench_timeline.py 30 18 -- $B --workload pairing_bls12_381 2>&1 | grep -v "^{" > $O/dev_timeline_bls12_381.txt
+  $W python exp/bench_timeline.py 24 8 -- $B --workload pairing_bn256 2>&1 | grep -v "^{" > $O/dev_timeline_bn256.txt
+  $W python exp/bench_timeline.py 20 6 -- $B --workload msm --steps 16 2>&1 | grep -v "^{" > $O/dev_timeline_msm.txt
   wc -l $O/dev_timeline_*.txt
 fi

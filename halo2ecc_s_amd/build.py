@@ -10,7 +10,7 @@ DEPS = ["tape.h", "wide_int.h", "modinv62.h", "hbig.hpp", "recorder.hpp", "recor
         "pairing_constants.hpp", "field_chain.hpp", os.path.join("..", "..", "include", "h2e.h")]
 # the C-ABI layer's translation unit in parts (h2e_capi.cpp includes them): only that unit depends on these
 CAPI_DEPS = ["capi_common.hpp", "program.hpp", "program_value_chain.hpp", "program_replay.hpp", "program_schedule.hpp", "run_state.hpp", "run.hpp",
-             "records_api.hpp"]
+             "ring.hpp", "records_api.hpp"]
 
 
 EXPORT_MAP = os.path.join(CSRC, "libh2e.map")

@@ -48,7 +48,7 @@ extern "C" int h2e_engine_copy_constraints(const uint32_t* perms, uint64_t n, vo
 extern "C" int h2e_engine_or_status(const void* instances, uint32_t n_instances, uint32_t bits, hipStream_t stream);
 extern "C" int h2e_engine_check_patch_values(const uint32_t* patches, uint32_t n_patches, const uint64_t* inputs, uint32_t n_slots, uint32_t slot_words,
                                              uint32_t n_instances, uint64_t* out, hipStream_t stream);   // checker.hip
-extern "C" int h2e_engine_instance_table(void* d_table, uint32_t n_instances, const uint64_t* first9, const uint64_t* stride9, uint32_t ws,
+extern "C" int h2e_engine_instance_table(void* d_table, uint32_t n_instances, uint32_t arr_n, const uint64_t* bfirst5, const uint64_t* first9, const uint64_t* stride9, uint32_t ws,
                                          hipStream_t stream);
 extern "C" int h2e_engine_unit_records(const void* base, const void* status, const void* digests, void* out, const uint64_t* offsets3,
                                        const uint32_t* refs, uint32_t limbs, int has_point, uint32_t n_instances, uint32_t out_stride,
@@ -187,7 +187,7 @@ struct InstanceDescHost {  // must match engine.hip InstanceDesc
     uint64_t* jac;
     uint64_t* sel;
     uint32_t ws;     // words between consecutive workspace value slots = n_instances * words per slot (instance-minor)
-    uint32_t pad_;
+    uint32_t hs;     // words between the two halves of a cell in the caller's arrays = 2 x instances per array (h2e_submit_batches: per batch)
 };
 static_assert(sizeof(InstanceDescHost) == 80, "handoff.hip h2e_instance_table_k writes the table as ten 64-bit words per instance");
 

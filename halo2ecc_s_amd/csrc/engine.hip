@@ -69,15 +69,6 @@ static constexpr int NK = 254;  // bit length of bn256 Fr modulus
 // device pointer each modulus / Barrett / ceil-table word was a dependent VMEM round trip: ~90 of them per
 // ecc_add_unsafe in the value chain (PMC: 47 % of that kernel's cycles in s_waitcnt).
 __constant__ H2EFieldConsts g_fc[3];
-#ifdef H2E_WAVE_STAMPS
-// diagnostic build only (exp/wave_stamps.sh): cycles and rounds per round kind of workgroup 0, read back by
-// h2e_engine_wave_stamps ([0..7] cycles, [8..15] rounds of h2e_replay_wave / h2e_field_chain, [16..19] light-round detail)
-__device__ unsigned long long g_wave_stamps[128];   // [32 + 4 w ..]: per computing wave of the digit chain, [96 ..]: rounds by record count
-extern "C" int H2E_UNIT(h2e_engine_wave_stamps)(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_stamps), sizeof(g_wave_stamps));
-}
-#define WAVE_STAMP() __builtin_amdgcn_s_memtime()
-#endif
 
 typedef Wd<2> Limb;   // <= 114 bit
 typedef Wd<4> Fe;     // canonical bn256-Fr value
@@ -96,7 +87,8 @@ struct InstanceDesc {
     u64* jac;           // [n_jac_slots][3] Jacobian scratch of the V kernels
     u64* sel;           // [n_sel_slots][2] points picked by the select pre-kernel (x, y canonical)
     u32 ws;             // words between consecutive value slots
-    u32 pad_;
+    u32 hs;             // words between the two halves of a cell = 2 x the instances of the array the cell is in: the run's instances, or -
+                        // a run made of several caller batches (h2e.h h2e_submit_batches) - those of one batch; the same for every instance
 };
 // Address spaces.  Pointers that come out of InstanceDesc / H2ELaunch are generic to the compiler, and an access through a
 // generic pointer is a FLAT instruction: it counts in the vector-memory AND the LDS counter and completes out of order, so
@@ -1242,7 +1234,7 @@ __global__ void __launch_bounds__(64, (FP::WW > 4 ? H2E_X_WAVES_WIDE : H2E_X_WAV
     c.hints = d.hints;
     c.ws = d.ws;
     c.hint_stride = L.hint_stride;
-    c.hs = 2 * n_instances;
+    c.hs = inst[0].hs;
     c.active = active;
     c.xc = (L.rel_refs & 4) ? xcache_dyn : nullptr;
     if (!VALUES_ONLY && L.dg_out != nullptr) {
@@ -1341,7 +1333,7 @@ __global__ void __launch_bounds__(64, H2E_XP_WAVES) h2e_run_tape_packed(H2ELaunc
     c.hints = d.hints;
     c.ws = d.ws;
     c.hint_stride = L.hint_stride;
-    c.hs = 2 * n_instances;
+    c.hs = inst[0].hs;
     c.active = group_on && ii < per_sub;
     c.xc = (L.rel_refs & 4) ? xcache_dyn : nullptr;
     if (L.dg_out != nullptr) {
@@ -1811,7 +1803,7 @@ __global__ void __launch_bounds__(64, (FP::WW > 4 ? 1 : H2E_REPLAY_WAVES)) h2e_r
     c.hint_stride = L.hint_stride;
     c.sel = d.sel;
     c.sel_stride = L.sel_stride;
-    c.hs = 2 * n_instances;
+    c.hs = inst[0].hs;
     __shared__ H2EVRec chunk[2][H2E_VCHUNK];
     extern __shared__ ulonglong2 v_dyn[];
     VSlots<FP> slots;
@@ -2085,7 +2077,7 @@ __global__ void __launch_bounds__(64 * H2E_LEVEL_WAVES) h2e_replay_levels(H2ELau
     c.hint_stride = L.hint_stride;
     c.sel = d.sel;
     c.sel_stride = L.sel_stride;
-    c.hs = 2 * n_instances;
+    c.hs = inst[0].hs;
     extern __shared__ ulonglong2 l_dyn[];
     LVals<FP> lv;
     lv.v = (u64*)l_dyn + (size_t)half * L.l_slots * LVals<FP>::W;
@@ -2166,7 +2158,7 @@ __global__ void __launch_bounds__(64) h2e_replay_wave(H2ELaunch L, const Instanc
     c.hint_stride = L.hint_stride;
     c.sel = d.sel;
     c.sel_stride = L.sel_stride;
-    c.hs = 2 * n_instances;
+    c.hs = inst[0].hs;
     c.active = true;
     extern __shared__ ulonglong2 w_dyn[];
     H2EVRec* rbuf = (H2EVRec*)w_dyn;                                   // [2][H2E_WCHUNK]
@@ -2193,13 +2185,7 @@ __global__ void __launch_bounds__(64) h2e_replay_wave(H2ELaunch L, const Instanc
     __syncthreads();
     u32 cur_chunk = 0;
     const uint2* rounds = (const uint2*)L.lrounds;
-#ifdef H2E_WAVE_STAMPS
-    unsigned long long st_cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_n[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_light[4] = {0, 0, 0, 0};
-#endif
     for (u32 round = 0; round < L.l_steps; round++) {
-#ifdef H2E_WAVE_STAMPS
-        unsigned long long t_begin = WAVE_STAMP();
-#endif
         uint2 rd = rounds[round];                      // wave-uniform: scalar loads
         u32 first = __builtin_amdgcn_readfirstlane(rd.x), meta = __builtin_amdgcn_readfirstlane(rd.y);
         u32 cnt = meta & 0xffu, kind = meta >> 8;
@@ -2210,16 +2196,7 @@ __global__ void __launch_bounds__(64) h2e_replay_wave(H2ELaunch L, const Instanc
             __syncthreads();
             cur_chunk = chunk;
             if (chunk + 1 < n_chunks) load_chunk(chunk + 1);   // into the buffer the wave has just left
-#ifdef H2E_WAVE_STAMPS
-            unsigned long long t_sw = WAVE_STAMP();
-            st_cyc[5] += t_sw - t_begin;
-            st_n[5]++;
-            t_begin = t_sw;
-#endif
         }
-#ifdef H2E_WAVE_STAMPS
-        unsigned long long t_hdr = WAVE_STAMP(), t_rec = t_hdr, t_exec = t_hdr;
-#endif
         if (kind == H2E_V_FULL) {
             // a tape op that goes through cells, run by lane 0: what it reads may have been stored in earlier rounds, and
             // later rounds read its rows
@@ -2238,40 +2215,11 @@ __global__ void __launch_bounds__(64) h2e_replay_wave(H2ELaunch L, const Instanc
             VHdr h;
             h.w[0] = a.x; h.w[1] = a.y; h.w[2] = a.z; h.w[3] = a.w;
             h.w[4] = b.x; h.w[5] = b.y; h.w[6] = b.z; h.w[7] = b.w;
-#ifdef H2E_WAVE_STAMPS
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            t_rec = WAVE_STAMP();
-#endif
             if (kind == 0) exec_lop_light<FP>(lv, c, h.w[0] & 0xffu, h, L.lrefs);
             else exec_lop<FP>(lv, c, kind, h, L.lrefs);
-#ifdef H2E_WAVE_STAMPS
-            t_exec = WAVE_STAMP();
-#endif
         }
         lds_round_barrier_wave();   // (one wave: only the LDS accesses of the round are ordered; global stores stay in flight)
-#ifdef H2E_WAVE_STAMPS
-        {
-            u32 k = kind == 0 ? 0u : kind == H2E_V_MUL ? 2u : kind == H2E_V_DIV ? 3u : kind == H2E_V_FULL ? 4u : 1u;
-            unsigned long long t_end = WAVE_STAMP();
-            st_cyc[k] += t_end - t_begin;
-            st_n[k]++;
-            if (kind == 0 && lane == 0) {   // light rounds, lane 0's view: header, record, op, barrier
-                st_light[0] += t_hdr - t_begin;
-                st_light[1] += t_rec - t_hdr;
-                st_light[2] += t_exec - t_rec;
-                st_light[3] += t_end - t_exec;
-            }
-        }
-#endif
     }
-#ifdef H2E_WAVE_STAMPS
-    if (blockIdx.x == 0 && lane == 0)
-        for (int k = 0; k < 8; k++) {
-            g_wave_stamps[k] = st_cyc[k];
-            g_wave_stamps[8 + k] = st_n[k];
-            if (k < 4) g_wave_stamps[16 + k] = st_light[k];
-        }
-#endif
 }
 #endif
 
@@ -2330,7 +2278,7 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_hint_store(H2ELaunch 
     c.hint_stride = L.hint_stride;
     c.sel = d.sel;
     c.sel_stride = L.sel_stride;
-    c.hs = 2 * n_instances;
+    c.hs = inst[0].hs;
     c.active = active;
     const u32* ext = L.s_ext;
     const u32* rec = L.s_words + L.s_offsets[sop];
@@ -2565,7 +2513,7 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_fixup_inverses(H2ELau
     // instance minor: the lanes of a wave read / write the same cell of consecutive instances (contiguous)
     u32 instance = gid % n_instances, strand = (gid / n_instances) % L.n_strands, chunk = gid / (n_instances * L.n_strands);
     u64* base = inst[instance].base;
-    u32 hs = 2 * n_instances;
+    u32 hs = inst[0].hs;
     u32 ob = L.strand_base0 + strand * L.delta_base;
     Mont<4> M = mont_n(fc);
     u32 lo = chunk * FIXUP_K, hi = min(lo + FIXUP_K, L.n_fixups);
@@ -2767,7 +2715,7 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_predict(H2EPreKernel 
     v.c.inputs = d.inputs;
     v.c.status = d.status;
     v.c.ob = v.c.orr = v.c.os = 0;
-    v.c.hs = 2 * n_instances;
+    v.c.hs = inst[0].hs;
     v.c.params = params_all + K.params_begin + (size_t)lane * K.n_params;
     v.c.aux = aux;
     v.c.pool = nullptr;
@@ -2906,17 +2854,11 @@ __global__ void __launch_bounds__(128) h2e_field_chain(H2EPreKernel K, const u32
     const double inv_w_top = 1.0 / (double)(wd_shr<1, FP::K - 52>(w).v[0] + 1);
     __builtin_amdgcn_s_barrier();
     u32 cur_chunk = 0;
-#ifdef H2E_WAVE_STAMPS
-    unsigned long long fst_cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fst_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
     u32 pos = 0;   // record index of the next round's header (wave-uniform)
     // one round; LOADS = the leading rounds that bring inputs and constants in (global loads), otherwise everything else:
     // two loops, so that the main loop's body contains no global load
     auto run_round = [&](auto loads_tag) {
         constexpr bool LOADS = decltype(loads_tag)::value;
-#ifdef H2E_WAVE_STAMPS
-        unsigned long long ft0 = WAVE_STAMP();
-#endif
         u32 chunk = pos / H2E_WCHUNK;
         if (chunk != cur_chunk) {   // (chunks follow each other: chunk == cur_chunk + 1)
             lds_round_barrier_workgroup();   // barrier `chunk`: the loader had this chunk in LDS before the previous barrier
@@ -2989,10 +2931,6 @@ __global__ void __launch_bounds__(128) h2e_field_chain(H2EPreKernel K, const u32
             }
         }
         lds_round_barrier_wave();
-#ifdef H2E_WAVE_STAMPS
-        fst_cyc[kind & 7] += WAVE_STAMP() - ft0;
-        fst_n[kind & 7]++;
-#endif
         return true;
     };
     for (u32 round = 0; round < K.f_n_load_rounds;)
@@ -3000,13 +2938,6 @@ __global__ void __launch_bounds__(128) h2e_field_chain(H2EPreKernel K, const u32
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loads are done: from here on the wave only stores to global memory
     for (u32 round = K.f_n_load_rounds; round < K.f_n_rounds;)
         if (run_round(std::false_type())) round++;
-#ifdef H2E_WAVE_STAMPS
-    if (blockIdx.x == 0 && lane == 0)
-        for (int k = 0; k < 8; k++) {
-            g_wave_stamps[k] = fst_cyc[k];
-            g_wave_stamps[8 + k] = fst_n[k];
-        }
-#endif
 }
 #endif
 // ------------------------------------------------------------------------------------------------
@@ -3166,11 +3097,7 @@ struct DigitRow {
     }
     WI_INLINE u32 mont_mul(u32 a, u32 b, u32 minv32) const {
         u64 T = 0;
-#ifdef H2E_EXP_MUL_STEPS   // timing experiment (wrong products): only that many of the D digit rounds
-        mont_step<D - H2E_EXP_MUL_STEPS>(a, b, minv32, T);
-#else
         mont_step<0>(a, b, minv32, T);
-#endif
         return normalize((u32)T, (u32)(T >> 32));
     }
 };
@@ -3246,7 +3173,6 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
             }
             u32 cnt, kind, nc;
             header(pos, cnt, kind, nc);
-#ifndef H2E_EXP_FERMAT_DIV
             if (kind == 3u) {
                 // a division round: lane k inverts the divisor of the round's k-th record - (b R), in [0, 2 w) - and leaves the plain
                 // inverse in the record's destination slot (nothing reads that slot before the round's rows have written it)
@@ -3288,7 +3214,6 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-#endif
             pos += 1 + cnt + nc;
             if (pos % H2E_WCHUNK != 0) {
                 u32 c2, k2, m2;
@@ -3332,28 +3257,9 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
     u32 pos = 0, n_cnt = 0, n_kind = 0, n_nc = 0;
     bool n_valid = false;
     u32 n_rec = 0;   // this row's record of the next round: lane j holds word j (a word is broadcast over the row by DPP when it is used)
-#ifdef H2E_WAVE_STAMPS
-    unsigned long long fst_cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fst_n[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fst_part[4] = {0, 0, 0, 0};
-    unsigned long long dps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dpt = 0, dpn = 0;
-    unsigned long long pw[4] = {0, 0, 0, 0};          // this wave: cycles in its records, rounds it had records in, cycles at the barrier, cycles in the header part
-    unsigned long long bk_cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bk_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // whole rounds by record count: <= 4, 8, 16, 24, 32, 40, 48, more
-    // stage stamps of a linear combination (wave 0; `v` = the value the stage ends with, so that the stamp stays behind it)
-#define DP_STAMP(i, v)                                        \
-    do {                                                      \
-        asm volatile("" : "+v"(v));                           \
-        unsigned long long t_ = WAVE_STAMP();                 \
-        if ((i) > 0) dps[i] += t_ - dpt;                      \
-        else dpn++;                                           \
-        dpt = t_;                                             \
-    } while (0)
-#else
 #define DP_STAMP(i, v)
-#endif
     auto run_round = [&](auto loads_tag) {
         constexpr bool LOADS = decltype(loads_tag)::value;
-#ifdef H2E_WAVE_STAMPS
-        unsigned long long ft0 = WAVE_STAMP();
-#endif
         u32 chunk = pos / H2E_WCHUNK;
         u32 cnt = n_cnt, kind = n_kind, n_conts = n_nc;
         const Rec* cbuf = rbuf + (size_t)(chunk % H2E_DP_CHUNKS) * H2E_WCHUNK;
@@ -3380,15 +3286,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
             ph1 = hp[1];
             pr = rec_ptr(pos % H2E_WCHUNK + 1u + grp)[j];
         }
-#ifdef H2E_WAVE_STAMPS
-        unsigned long long ft1 = WAVE_STAMP();
-#endif
-#ifndef H2E_EXP_FERMAT_DIV
         if (!LOADS && kind == 3u) __builtin_amdgcn_s_barrier();   // a division round: the loader wave has left the inverses in the destination slots
-#endif
-#ifdef H2E_EXP_NO_OPS   // timing experiment: rounds without their records (header, prefetch, barrier only)
-        if (false)
-#endif
         u32 rw_pass = r0;
         for (u32 op = grp; op < cnt; op += H2E_DP_GROUPS) {
             const u32 rw = rw_pass;
@@ -3491,10 +3389,6 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                         };
                         // the term loop of this wave's longest combination (the host sorts a round's records by their length)
                         auto combine_n = [&](u32 rwy, u32 n) {
-#ifdef H2E_EXP_LIN_TERMS   // timing experiment (wrong sums): every combination as if it had at most that many terms
-                            if (true) combine(rwy, std::integral_constant<int, H2E_EXP_LIN_TERMS>());
-                            else
-#endif
                             if (__builtin_amdgcn_ballot_w64(n > 10u)) combine(rwy, std::integral_constant<int, H2E_F_MAX_TERMS_WIDE>());
                             else if (__builtin_amdgcn_ballot_w64(n > 6u)) combine(rwy, std::integral_constant<int, 10>());
                             else if (__builtin_amdgcn_ballot_w64(n > 2u)) combine(rwy, std::integral_constant<int, 6>());
@@ -3549,23 +3443,10 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                 // the rows' own path cost them registers and spills in every round (bls12_381 chain 2.6 -> 4.1 ms) - the loader's
                 // path is a different branch of the kernel.
                 u32 a = ld_value(w2);
-#ifdef H2E_EXP_FERMAT_DIV   // (A/B: the exponentiation)
-                {
-                    u32 b = ld_value(w3);
-                    u32 e = r1j;                                              // 1 in Montgomery form
-                    for (int bit = (int)FP::K - 1; bit >= 0; bit--) {         // (w - 2's digits sit in the lanes of every row: ej)
-                        e = R.mont_mul(e, e, minv32);
-                        u32 ew = (u32)__builtin_amdgcn_readlane((int)ej, bit >> 5);
-                        if ((ew >> ((u32)bit & 31u)) & 1u) e = R.mont_mul(e, b, minv32);
-                    }
-                    out = R.mont_mul(a, e, minv32);
-                }
-#else
                 u32 yd = ld_value(dst);                                       // (b R)^-1, plain digits
                 yd = R.mont_mul(yd, r2j, minv32);                             // (b R)^-1 R
                 yd = R.mont_mul(yd, r2j, minv32);                             // (b R)^-1 R^2
                 out = R.mont_mul(a, yd, minv32);                              // a R (b R)^-1 R^2 / R = (a / b) R
-#endif
                 (void)ej;
             }
             if (st_dst != 0xffffu && st_ok) ((H2E_AS_LDS u32*)fv)[st_dst * (u32)D + st_j] = out;
@@ -3574,9 +3455,7 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
                 // conversion of the whole slot range gives 0 / 1 back)
                 u32 hv = out;
                 if (raw) hv = (dpp_mov<H2E_DPP_ROW_BCAST(0)>(out) & 1u) ? r1j : 0u;
-#ifndef H2E_EXP_NO_HINT_STORES   // (timing experiment: the chain without its global stores)
                 if (st_ok && st_hint != 0u) ((H2E_AS_GLOBAL u32*)(d.hints + (size_t)(st_hint - 1) * d.ws))[st_j] = hv;
-#endif
             }
         }
         n_valid = false;
@@ -3589,52 +3468,10 @@ __global__ void __launch_bounds__(1024) h2e_field_chain_digits(H2EPreKernel K, c
             else n_valid = true;
             n_rec = pr;
         }
-#ifdef H2E_WAVE_STAMPS
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        unsigned long long ft2 = WAVE_STAMP();
-#endif
         lds_round_barrier_workgroup();
-#ifdef H2E_WAVE_STAMPS
-        unsigned long long ft3 = WAVE_STAMP();
-        fst_cyc[kind & 7] += ft3 - ft0;
-        fst_n[kind & 7]++;
-        if (kind == 0) {
-            fst_part[0] += ft1 - ft0;
-            fst_part[1] += ft2 - ft1;
-            fst_part[2] += ft3 - ft2;
-        } else if (kind == 2) fst_part[3] += ft3 - ft2;
-        if (!LOADS) {
-            if (wave * 4u < cnt) {
-                pw[0] += ft2 - ft1;
-                pw[1]++;
-            }
-            pw[2] += ft3 - ft2;
-            pw[3] += ft1 - ft0;
-            int b = cnt <= 4 ? 0 : cnt <= 8 ? 1 : cnt <= 16 ? 2 : cnt <= 24 ? 3 : cnt <= 32 ? 4 : cnt <= 40 ? 5 : cnt <= 48 ? 6 : 7;
-            bk_cyc[b] += ft3 - ft0;
-            bk_n[b]++;
-        }
-#endif
     };
     for (u32 round = 0; round < K.f_n_load_rounds; round++) run_round(std::true_type());
     for (u32 round = K.f_n_load_rounds; round < K.f_n_rounds; round++) run_round(std::false_type());
-#ifdef H2E_WAVE_STAMPS
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        for (int k = 0; k < 8; k++) {
-            g_wave_stamps[k] = fst_cyc[k];
-            g_wave_stamps[8 + k] = fst_n[k];
-        }
-        for (int k = 0; k < 4; k++) g_wave_stamps[16 + k] = fst_part[k];
-        for (int k = 1; k < 7; k++) g_wave_stamps[20 + k] = dps[k];
-        g_wave_stamps[20] = dpn;
-        for (int k = 0; k < 8; k++) {
-            g_wave_stamps[96 + k] = bk_cyc[k];
-            g_wave_stamps[104 + k] = bk_n[k];
-        }
-    }
-    if (blockIdx.x == 0 && lane == 0)
-        for (int k = 0; k < 4; k++) g_wave_stamps[32 + 4 * wave + k] = pw[k];
-#endif
 }
 // TEST HOOK: the digit-row primitives on caller-supplied rows, one 16-lane row per case (tests/test_digit_rows_gpu.py feeds
 // the patterns random data never produces: runs of 0xffffffff digits under a carry, quotient estimates on the boundary).  in: [cases][2][16] words, out: [cases][16] words.
@@ -3728,7 +3565,7 @@ WI_INLINE void vc_init(VC& v, const InstanceDesc& d, u32 n_instances, const u32*
     v.c.inputs = d.inputs;
     v.c.status = d.status;
     v.c.ob = v.c.orr = v.c.os = 0;
-    v.c.hs = 2 * n_instances;
+    v.c.hs = d.hs;
     v.c.params = params;
     v.c.aux = aux;
     v.c.pool = nullptr;
@@ -3966,7 +3803,7 @@ __global__ void __launch_bounds__(64) h2e_select(H2EPreKernel K, const u32* args
     c.range = d.range;
     c.select = d.select;
     c.ob = c.orr = c.os = 0;
-    c.hs = 2 * n_instances;
+    c.hs = inst[0].hs;
     c.params = params_all + K.params_begin + (size_t)w * K.n_params;
     u32 lo = g * group_size, hi = min(n_points, lo + group_size), idx = 0;
     for (u32 j = lo; j < hi; j++) idx |= (u32)(ld_limb(c, H2E_MAKE_REF(H2E_REGION_PARAM, 0, 0, j)).v[0] & 1) << (j - lo);

@@ -29,7 +29,13 @@ static int64_t process_hw_queues() {
     int64_t v = e ? atoll(e) : 0;
     return v > 0 ? v : 4;
 }
-const char* h2e_version(void) { return "h2e 0.2 (gfx950, batch-interleaved advice)"; }
+const char* h2e_version(void) {
+#ifdef H2E_DEBUG_HOOKS
+    return "h2e 0.3 (gfx950, batch-interleaved advice) [debug hooks]";   // exp/build_dbg.sh: launch log, stamp kernels - never the shipped library
+#else
+    return "h2e 0.3 (gfx950, batch-interleaved advice)";
+#endif
+}
 
 int h2e_ctx_create(int device, h2e_ctx** out) {
     if (!out) return fail(H2E_ERR_INVALID, "out is null");
@@ -353,6 +359,7 @@ int h2e_program_shape(const h2e_program* p, h2e_shape* out) {
 }
 
 #include "run.hpp"
+#include "ring.hpp"
 
 int h2e_ctx_set_option(h2e_ctx* ctx, int option, int64_t value) {
     if (!ctx) return fail(H2E_ERR_INVALID, "null ctx");
@@ -623,9 +630,14 @@ int h2e_unit_records(h2e_ctx* ctx, const h2e_program* p, uint32_t n_instances, c
             refs[limbs + i] = r.outputs[limbs + 1 + i];
         }
         refs[2 * limbs] = r.outputs[2 * limbs + 2];
-        for (uint32_t i = 0; i <= 2 * limbs; i++)
-            if ((refs[i] >> 30) != 0) return fail(H2E_ERR_INVALID, "h2e_unit_records: a result cell outside the base array");
+        for (uint32_t i = 0; i <= 2 * limbs; i++) {
+            // the kernel reads refs as ABSOLUTE rows of the base array: anything else would be read out of place (or out of bounds)
+            if (H2E_REF_REGION(refs[i]) != 0) return fail(H2E_ERR_INVALID, "h2e_unit_records: a result cell outside the base array");
+            if (H2E_REF_REL(refs[i])) return fail(H2E_ERR_INVALID, "h2e_unit_records: a strand-relative result cell (the outputs of a program are absolute references)");
+            if (H2E_REF_ROW(refs[i]) >= p->base_rows) return fail(H2E_ERR_INVALID, "h2e_unit_records: a result cell beyond the program's base rows");
+        }
     }
+    if (p->device >= 0 && p->device != ctx->device) return fail(H2E_ERR_INVALID, "program bound to another device");
     const uint64_t offs[3] = {r.base_offset, r.range_offset, r.select_offset};
     // (no context lock: nothing of the context is touched - the kernel reads the caller's arrays on the caller's stream)
     HIP_TRY(hipSetDevice(ctx->device));

@@ -76,30 +76,47 @@ extern "C" int h2e_engine_unit_records(const void* base, const void* status, con
     return (int)hipGetLastError();
 }
 
+// A run may be made of several caller batches (h2e.h h2e_submit_batches): every batch has its own arrays, inputs and status words, each
+// batch-interleaved over ITS instances - so the caller-side pointers are piecewise affine in the instance index (instance i = batch
+// i / arr_n, position i % arr_n), the engine's workspace stays affine over the whole run.  One batch: arr_n = n_instances.
+#define H2E_MAX_BATCHES 16
 struct H2EInstTableArgs {
-    u64 first[9];    // address of instance 0's: base, range, select cells, inputs, status word, hints, nd, jac, sel workspace
-    u64 stride[9];   // bytes from one instance to the next
-    u64* out;        // [n_instances][10 words]: the nine pointers, then {ws, 0} as two 32-bit words
-    u32 ws;
+    u64 bfirst[5][H2E_MAX_BATCHES];   // per batch: address of its instance 0's base, range, select cells, inputs, status word
+    u64 first[9];    // [5..8]: address of instance 0's hints, nd, jac, sel workspace ([0..4] unused: bfirst)
+    u64 stride[9];   // bytes from one instance to the next (caller-side: inside a batch)
+    u64* out;        // [n_instances][10 words]: the nine pointers, then {ws, hs} as two 32-bit words
+    u32 ws;          // words between consecutive workspace value slots
+    u32 hs;          // words between the two halves of a cell in the caller's arrays = 2 x instances per array
     u32 n_instances;
+    u32 arr_n;
 };
 __global__ void __launch_bounds__(256) h2e_instance_table_k(H2EInstTableArgs a) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     u32 i = t / 10u, w = t % 10u;
     if (i >= a.n_instances) return;
-    a.out[(size_t)i * 10u + w] = w < 9u ? a.first[w] + (u64)i * a.stride[w] : (u64)a.ws;
+    u64 v;
+    if (w < 5u) v = a.bfirst[w][i / a.arr_n] + (u64)(i % a.arr_n) * a.stride[w];
+    else if (w < 9u) v = a.first[w] + (u64)i * a.stride[w];
+    else v = (u64)a.ws | ((u64)a.hs << 32);
+    a.out[(size_t)i * 10u + w] = v;
 }
-extern "C" int h2e_engine_instance_table(void* d_table, uint32_t n_instances, const uint64_t* first9, const uint64_t* stride9, uint32_t ws,
-                                         hipStream_t stream) {
+extern "C" int h2e_engine_instance_table(void* d_table, uint32_t n_instances, uint32_t arr_n, const uint64_t* bfirst5 /* [5][n_batches] */,
+                                         const uint64_t* first9, const uint64_t* stride9, uint32_t ws, hipStream_t stream) {
     if (n_instances == 0) return 0;
+    if (arr_n == 0 || n_instances % arr_n != 0 || n_instances / arr_n > H2E_MAX_BATCHES) return -1;
+    const u32 nb = n_instances / arr_n;
     H2EInstTableArgs a;
     for (int k = 0; k < 9; k++) {
         a.first[k] = first9[k];
         a.stride[k] = stride9[k];
     }
+    for (int w = 0; w < 5; w++)
+        for (u32 b = 0; b < H2E_MAX_BATCHES; b++) a.bfirst[w][b] = b < nb ? bfirst5[(size_t)w * nb + b] : 0;
     a.out = (u64*)d_table;
     a.ws = ws;
+    a.hs = 2u * arr_n;
     a.n_instances = n_instances;
+    a.arr_n = arr_n;
     const u32 threads = n_instances * 10u;
     hipLaunchKernelGGL(h2e_instance_table_k, dim3((threads + 255) / 256), dim3(256), 0, stream, a);
     return (int)hipGetLastError();

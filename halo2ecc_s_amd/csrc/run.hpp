@@ -162,10 +162,27 @@ static hipError_t make_stream(h2e_ctx* ctx, hipStream_t* out, int prio, int kind
     return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
 }
 
+// A run made of several caller batches (h2e_submit_batches): k batches of arr_n instances each, every batch with its own inputs,
+// arrays and status words; the run's instance i is instance i % arr_n of batch i / arr_n.
+struct RunBatches {
+    uint32_t k = 0, arr_n = 0;
+    const void* const* inputs = nullptr;
+    void* const* base = nullptr;
+    void* const* range = nullptr;
+    void* const* select = nullptr;
+    void* const* status = nullptr;
+};
+// One more edge in a run's schedule (ring.hpp): whatever of the run writes the rows of segment `seg` - its value chain's stores, its
+// expansion, its fix-ups, all ordered behind the chain stream at that point - waits for `ev` first.
+struct RunFence {
+    int seg = -1;
+    hipEvent_t ev = nullptr;
+};
 static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
-                    void* d_select, void* d_status, hipStream_t stream, bool join, int* slot_out, void* d_digests = nullptr) {
+                    void* d_select, void* d_status, hipStream_t stream, bool join, int* slot_out, void* d_digests = nullptr,
+                    const RunBatches* batches = nullptr, const RunFence* fence = nullptr) {
     if (!ctx || !p) return fail(H2E_ERR_INVALID, "null ctx/program");
-    if (!d_inputs || !d_base || !d_range || !d_select || !d_status) return fail(H2E_ERR_INVALID, "null device pointer");
+    if (!batches && (!d_inputs || !d_base || !d_range || !d_select || !d_status)) return fail(H2E_ERR_INVALID, "null device pointer");
     std::lock_guard<std::mutex> guard(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_device_program(ctx, p);
@@ -279,10 +296,20 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     {   // the table of per-instance descriptors, written on the device (handoff.hip: every field is affine in the instance index; no
         // pinned staging table, so nothing here makes the host wait for an earlier run of the slot)
         // batch-interleaved advice arrays [row][col][half][instance][2 words]: instance i starts 2 words in
-        const uint64_t first[9] = {(uint64_t)d_base, (uint64_t)d_range, (uint64_t)d_select, (uint64_t)d_inputs, (uint64_t)d_status,
-                                   (uint64_t)J.ws_hints, (uint64_t)J.ws_nd, (uint64_t)J.ws_jac, (uint64_t)J.ws_sel};
+        // (several caller batches in one run: the caller-side pointers per batch, inside a batch affine as before)
+        const uint64_t first[9] = {0, 0, 0, 0, 0, (uint64_t)J.ws_hints, (uint64_t)J.ws_nd, (uint64_t)J.ws_jac, (uint64_t)J.ws_sel};
         const uint64_t stride[9] = {16, 16, 16, (uint64_t)r.n_input_slots * slot_words * 8, 4, wsw * 8, wsw * 8, wsw * 8, wsw * 8};
-        int trc = h2e_engine_instance_table(J.d_inst, n_instances, first, stride, (uint32_t)(n_instances * wsw), sa);
+        const uint32_t nb = batches ? batches->k : 1, arr_n = batches ? batches->arr_n : n_instances;
+        std::vector<uint64_t> bfirst(5 * (size_t)nb);
+        for (uint32_t b = 0; b < nb; b++) {
+            bfirst[0 * nb + b] = (uint64_t)(batches ? batches->base[b] : d_base);
+            bfirst[1 * nb + b] = (uint64_t)(batches ? batches->range[b] : d_range);
+            bfirst[2 * nb + b] = (uint64_t)(batches ? batches->select[b] : d_select);
+            bfirst[3 * nb + b] = (uint64_t)(batches ? batches->inputs[b] : d_inputs);
+            bfirst[4 * nb + b] = (uint64_t)(batches ? batches->status[b] : d_status);
+        }
+        int trc = h2e_engine_instance_table(J.d_inst, n_instances, arr_n, bfirst.data(), first, stride, (uint32_t)(n_instances * wsw), sa);
+        if (trc < 0) return fail(H2E_ERR_INVALID, "instance table: bad batch geometry");
         if (trc != 0) return fail(H2E_ERR_HIP, std::string("instance table kernel launch failed: ") + hipGetErrorString((hipError_t)trc));
     }
 #ifdef H2E_DEBUG_HOOKS
@@ -564,6 +591,8 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         }
         // the inverse fix-up of a segment only touches cells nothing else reads or writes: own stream, after the expansion
         // (a small expansion keeps its fix-up in its own stream)
+        // (the predictors above only touch the slot's workspace; from here on the segment's cells are written)
+        if (fence && fence->ev && fence->seg == (int)si) HIP_TRY(hipStreamWaitEvent(sa, fence->ev, 0));
         bool fixup_in_stream = false;
         auto fixup_part = [&](hipStream_t st, uint32_t lo, uint32_t hi) -> int {
             if (hi <= lo) return 0;
@@ -811,6 +840,42 @@ int h2e_submit_digest(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const 
     if (n_instances == 0) return fail(H2E_ERR_INVALID, "n_instances must be > 0");
     if (!d_digests) return fail(H2E_ERR_INVALID, "d_digests is null");
     return run_impl(ctx, p, n_instances, d_inputs, d_base, d_range, d_select, d_status, (hipStream_t)stream_, false, job, d_digests);
+}
+
+// Several caller batches as ONE run.  What a stream of small batches costs is runs, not instances: a pairing check's value chain is ~2 ms
+// of latency on one compute unit whatever the batch (a 2-check bls12_381 batch 0.20 ms per check pipelined, a 16-check batch 0.07), and
+// streams in use beyond ~24 are time-sliced, so more runs in flight are not to be had.  Eight 2-check batches submitted together execute
+// as one 16-instance run - same kernels, same launches - and every batch's cells land in its own arrays.
+static int check_batches(uint32_t n_batches, uint32_t n_each, const void* const* d_inputs, void* const* d_base, void* const* d_range,
+                         void* const* d_select, void* const* d_status) {
+    if (n_batches == 0 || n_batches > 16) return fail(H2E_ERR_INVALID, "n_batches must be 1 .. 16");
+    if (n_each == 0) return fail(H2E_ERR_INVALID, "n_instances_each must be > 0");
+    if (!d_inputs || !d_base || !d_range || !d_select || !d_status) return fail(H2E_ERR_INVALID, "null pointer table");
+    for (uint32_t b = 0; b < n_batches; b++) {
+        if (!d_inputs[b] || !d_base[b] || !d_range[b] || !d_select[b] || !d_status[b]) return fail(H2E_ERR_INVALID, "null device pointer in a batch");
+        for (uint32_t c = 0; c < b; c++)
+            if (d_base[b] == d_base[c] || d_range[b] == d_range[c] || d_select[b] == d_select[c] || d_status[b] == d_status[c])
+                return fail(H2E_ERR_INVALID, "two batches of a run share an output array");
+    }
+    return 0;
+}
+int h2e_run_batches(h2e_ctx* ctx, h2e_program* p, uint32_t n_batches, uint32_t n_instances_each, const void* const* d_inputs,
+                    void* const* d_base, void* const* d_range, void* const* d_select, void* const* d_status, void* stream_) {
+    int rc = check_batches(n_batches, n_instances_each, d_inputs, d_base, d_range, d_select, d_status);
+    if (rc) return rc;
+    RunBatches bs;
+    bs.k = n_batches; bs.arr_n = n_instances_each; bs.inputs = d_inputs; bs.base = d_base; bs.range = d_range; bs.select = d_select; bs.status = d_status;
+    return run_impl(ctx, p, n_batches * n_instances_each, nullptr, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream_, true, nullptr, nullptr, &bs);
+}
+int h2e_submit_batches(h2e_ctx* ctx, h2e_program* p, uint32_t n_batches, uint32_t n_instances_each, const void* const* d_inputs,
+                       void* const* d_base, void* const* d_range, void* const* d_select, void* const* d_status, void* stream_, int* job) {
+    if (!job) return fail(H2E_ERR_INVALID, "job is null");
+    *job = -1;
+    int rc = check_batches(n_batches, n_instances_each, d_inputs, d_base, d_range, d_select, d_status);
+    if (rc) return rc;
+    RunBatches bs;
+    bs.k = n_batches; bs.arr_n = n_instances_each; bs.inputs = d_inputs; bs.base = d_base; bs.range = d_range; bs.select = d_select; bs.status = d_status;
+    return run_impl(ctx, p, n_batches * n_instances_each, nullptr, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream_, false, job, nullptr, &bs);
 }
 
 int h2e_wait(h2e_ctx* ctx, int job, void* stream_) {

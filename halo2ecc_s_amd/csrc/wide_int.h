@@ -19,11 +19,6 @@ struct Wd {
 // 64 x 64 -> 128 from four 32 x 32 -> 64 products (each one v_mad_u64_u32 / v_mul_{lo,hi}_u32 pair); the
 // compiler's own lowering of `a * b` next to `__umul64hi(a, b)` repeats the partial products.
 WI_INLINE void mul_wide64(u64 a, u64 b, u64& lo, u64& hi) {
-#ifdef H2E_COMPILER_MUL64
-    lo = a * b;
-    hi = __umul64hi(a, b);
-    return;
-#endif
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     u64 p00 = (u64)a0 * b0, p01 = (u64)a0 * b1, p10 = (u64)a1 * b0, p11 = (u64)a1 * b1;
     u64 mid = (p00 >> 32) + (u32)p01 + (u32)p10;
@@ -110,17 +105,6 @@ WI_INLINE u64 pack64(u32 lo, u32 hi) { return (u64)lo | ((u64)hi << 32); }
 // a >= b
 template <int N>
 WI_INLINE bool wd_geq(const Wd<N>& a, const Wd<N>& b) {
-#ifdef H2E_PLAIN_CARRY
-    u64 borrow = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        u64 d = a.v[i] - b.v[i];
-        u64 b1 = a.v[i] < b.v[i];
-        u64 b2 = d < borrow;
-        borrow = b1 | b2;
-    }
-    return borrow == 0;
-#else
     u64 c;
     (void)sub_co32((u32)a.v[0], (u32)b.v[0], c);
     (void)subb_co32((u32)(a.v[0] >> 32), (u32)(b.v[0] >> 32), c);
@@ -130,24 +114,10 @@ WI_INLINE bool wd_geq(const Wd<N>& a, const Wd<N>& b) {
         (void)subb_co32((u32)(a.v[i] >> 32), (u32)(b.v[i] >> 32), c);
     }
     return carry_bit(c) == 0;
-#endif
 }
 template <int N>
 WI_INLINE Wd<N> wd_add_c(const Wd<N>& a, const Wd<N>& b, u64& carry_out) {
     Wd<N> r;
-#ifdef H2E_PLAIN_CARRY
-    u64 c = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        u64 s = a.v[i] + b.v[i];
-        u64 c1 = s < a.v[i];
-        u64 s2 = s + c;
-        u64 c2 = s2 < s;
-        r.v[i] = s2;
-        c = c1 | c2;
-    }
-    carry_out = c;
-#else
     u64 c;
     u32 lo = add_co32((u32)a.v[0], (u32)b.v[0], c);
     u32 hi = addc_co32((u32)(a.v[0] >> 32), (u32)(b.v[0] >> 32), c);
@@ -159,15 +129,10 @@ WI_INLINE Wd<N> wd_add_c(const Wd<N>& a, const Wd<N>& b, u64& carry_out) {
         r.v[i] = pack64(lo, hi);
     }
     carry_out = carry_bit(c);
-#endif
     return r;
 }
 template <int N>
 WI_INLINE Wd<N> wd_add(const Wd<N>& a, const Wd<N>& b) {
-#ifdef H2E_PLAIN_CARRY
-    u64 c;
-    return wd_add_c<N>(a, b, c);
-#else
     Wd<N> r;
     u64 c;
     u32 lo = add_co32((u32)a.v[0], (u32)b.v[0], c);
@@ -180,23 +145,10 @@ WI_INLINE Wd<N> wd_add(const Wd<N>& a, const Wd<N>& b) {
         r.v[i] = pack64(lo, hi);
     }
     return r;
-#endif
 }
 template <int N>
 WI_INLINE Wd<N> wd_sub(const Wd<N>& a, const Wd<N>& b) {
     Wd<N> r;
-#ifdef H2E_PLAIN_CARRY
-    u64 borrow = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        u64 d = a.v[i] - b.v[i];
-        u64 b1 = a.v[i] < b.v[i];
-        u64 d2 = d - borrow;
-        u64 b2 = d < borrow;
-        r.v[i] = d2;
-        borrow = b1 | b2;
-    }
-#else
     u64 c;
     u32 lo = sub_co32((u32)a.v[0], (u32)b.v[0], c);
     u32 hi = subb_co32((u32)(a.v[0] >> 32), (u32)(b.v[0] >> 32), c);
@@ -207,7 +159,6 @@ WI_INLINE Wd<N> wd_sub(const Wd<N>& a, const Wd<N>& b) {
         hi = subb_co32((u32)(a.v[i] >> 32), (u32)(b.v[i] >> 32), c);
         r.v[i] = pack64(lo, hi);
     }
-#endif
     return r;
 }
 // acc += a * m for a 32-bit multiplier: one v_mad_u64_u32 and one 64-bit add per 32-bit limb of a
@@ -402,9 +353,6 @@ __device__ __attribute__((noinline)) Wd<N> wd_inv_mod_divsteps(Wd<N> a, Wd<N> p)
 }
 template <int N>
 WI_INLINE Wd<N> wd_inv_mod(const Wd<N>& a, const Wd<N>& p) {
-#ifdef H2E_EXPERIMENT_NO_INV
-    return a;
-#endif
     if constexpr (N == 4 || N == 6) return wd_inv_mod_divsteps<N>(a, p);
     else return wd_inv_mod_euclid<N>(a, p);
 }

@@ -39,12 +39,73 @@ EXPORTED_SYMBOLS = [
     "h2e_program_msm_bn256_tile_no_select", "h2e_last_run_expansion_launches",
     "h2e_run_digest", "h2e_submit_digest", "h2e_records_attach", "h2e_op_int_mul_small_constant", "h2e_op_assign_int_constant", "h2e_op_bisec_int", "h2e_op_fq", "h2e_op_pairing",
     "h2e_check", "h2e_program_tape_opcodes", "h2e_program_value_chain_kind", "h2e_program_pack_order",
-    "h2e_program_launch_rows", "h2e_unit_records", "h2e_unit_record_words", "h2e_selftest_digit_rows", "h2e_last_warning",
+    "h2e_program_launch_rows", "h2e_unit_records", "h2e_unit_record_words", "h2e_selftest_digit_rows", "h2e_last_warning", "h2e_run_batches", "h2e_submit_batches",
+    "h2e_ring_create", "h2e_ring_destroy", "h2e_ring_arrays", "h2e_ring_info", "h2e_ring_submit", "h2e_ring_submit_digest",
 ]
 
 
 class H2EError(RuntimeError):
     pass
+
+
+class _DevArray:
+    """a device allocation torch did not make (h2e_ring's mapped array sets), as torch.as_tensor takes it"""
+
+    def __init__(self, ptr, shape, keep):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<i8", "data": (int(ptr), False), "version": 3, "strides": None}
+        self._keep = keep
+
+
+class Ring:
+    """h2e_ring (include/h2e.h): output arrays for `depth` runs in flight in less than `depth` array sets - the rows of the program's
+    biggest launch are shared by runs k and k + 2.  Runs are submitted in order: submit(0, ...), submit(1, ...), ..."""
+
+    def __init__(self, engine, program, n_instances, depth):
+        self.engine, self.program, self.n, self.depth = engine, program, n_instances, depth
+        h = C.c_void_p()
+        _check(lib().h2e_ring_create(engine._h, program._h, n_instances, depth, C.byref(h)))
+        self._h = h
+        buf = (C.c_uint64 * 10)()
+        _check(min(0, lib().h2e_ring_info(self._h, buf, 10)))
+        v = [int(x) for x in buf]
+        self.info = {"set_bytes": v[0:3], "shared_bytes": v[3:6], "physical_bytes": v[6], "shared_launch": v[7], "virtual_sets": v[8], "depth": v[9]}
+        self._arrays = {}
+
+    def arrays(self, k):
+        """run k's (base, range, select) as tensors [rows][cols][half][instance][2 words]"""
+        v = k % self.info["virtual_sets"]
+        if v not in self._arrays:
+            ptrs = [C.c_void_p() for _ in range(3)]
+            _check(lib().h2e_ring_arrays(self._h, k, *[C.byref(p) for p in ptrs]))
+            t = self.engine.torch
+            out = []
+            for ptr, rows, cols in zip(ptrs, (self.program.base_rows, self.program.range_rows, self.program.select_rows), COLS):
+                out.append(t.as_tensor(_DevArray(ptr.value, (max(1, rows), cols, 2, self.n, 2), self), device=f"cuda:{self.engine.device}")[:rows])
+            self._arrays[v] = tuple(out)
+        return self._arrays[v]
+
+    def submit(self, k, d_inputs, status, digests=None, stream=None):
+        assert d_inputs.shape[0] == self.n and status.shape[0] == self.n
+        job = C.c_int(-1)
+        st = self.engine._stream(stream).cuda_stream
+        if digests is None:
+            _check(lib().h2e_ring_submit(self._h, k, d_inputs.data_ptr(), status.data_ptr(), st, C.byref(job)))
+        else:
+            assert tuple(digests.shape) == (3, self.n, 4) and digests.is_contiguous()
+            _check(lib().h2e_ring_submit_digest(self._h, k, d_inputs.data_ptr(), status.data_ptr(), digests.data_ptr(), st, C.byref(job)))
+        return job.value
+
+    def close(self):
+        if self._h:
+            self._arrays = {}
+            lib().h2e_ring_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass
 
 
 def lib_path():
@@ -170,6 +231,17 @@ def lib():
     L.h2e_digest.argtypes = [vp, vp, u32, i32, vp, vp, vp]
     L.h2e_submit.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
     L.h2e_wait.argtypes = [vp, i32, vp]
+    pvp = C.POINTER(vp)
+    L.h2e_run_batches.argtypes = [vp, vp, u32, u32, pvp, pvp, pvp, pvp, pvp, vp]
+    L.h2e_submit_batches.argtypes = [vp, vp, u32, u32, pvp, pvp, pvp, pvp, pvp, vp, C.POINTER(i32)]
+    L.h2e_selftest_digit_rows.argtypes = [i32, u32, u32, vp, vp, vp]
+    L.h2e_ring_create.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
+    L.h2e_ring_destroy.argtypes = [vp]
+    L.h2e_ring_destroy.restype = None
+    L.h2e_ring_arrays.argtypes = [vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.h2e_ring_info.argtypes = [vp, C.POINTER(C.c_uint64), u32]
+    L.h2e_ring_submit.argtypes = [vp, C.c_uint64, vp, vp, vp, C.POINTER(i32)]
+    L.h2e_ring_submit_digest.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, C.POINTER(i32)]
     L.h2e_run_digest.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
     L.h2e_submit_digest.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
     L.h2e_unit_records.argtypes = [vp, vp, u32, vp, vp, vp, vp, u32, vp]
@@ -599,6 +671,27 @@ class Engine:
         job = C.c_int(-1)
         _check(lib().h2e_submit(self._h, program._h, n, d_inputs.data_ptr(), base.data_ptr(), rng.data_ptr(),
                                 sel.data_ptr(), status.data_ptr(), self._stream(stream).cuda_stream, C.byref(job)))
+        return job.value
+
+    def _batch_tables(self, batches):
+        """batches: [(d_inputs, base, rng, sel, status), ...] of equal instance counts -> (k, n_each, five ctypes pointer tables)"""
+        k = len(batches)
+        n = batches[0][0].shape[0]
+        for d_in, base, rng, sel, status in batches:
+            assert d_in.shape[0] == n and base.shape[3] == n and rng.shape[3] == n and sel.shape[3] == n and status.shape[0] == n
+        tabs = [(C.c_void_p * k)(*[b[j].data_ptr() for b in batches]) for j in range(5)]
+        return k, n, tabs
+
+    def run_batches(self, program, batches, stream=None):
+        """h2e_run_batches: several caller batches (own inputs, arrays, status words each) as ONE run"""
+        k, n, t = self._batch_tables(batches)
+        _check(lib().h2e_run_batches(self._h, program._h, k, n, t[0], t[1], t[2], t[3], t[4], self._stream(stream).cuda_stream))
+
+    def submit_batches(self, program, batches, stream=None):
+        """h2e_submit_batches: the pipelined form; returns the job id to pass to wait()"""
+        k, n, t = self._batch_tables(batches)
+        job = C.c_int(-1)
+        _check(lib().h2e_submit_batches(self._h, program._h, k, n, t[0], t[1], t[2], t[3], t[4], self._stream(stream).cuda_stream, C.byref(job)))
         return job.value
 
     def run_digest(self, program, d_inputs, base, rng, sel, status, digests=None, stream=None):

@@ -167,10 +167,50 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
  * engine's expansion streams: the value chain of the next h2e_submit overlaps this run's expansion.  *job identifies
  * the run; h2e_wait(job, s) makes stream `s` wait until every array of that run is complete.  At most
  * H2E_STAT_PIPELINE_DEPTH runs are in flight: a further submit first waits (on `stream`, not on the host) for the run
- * that used the same slot.  Runs in flight must use different advice arrays and status words. */
+ * that used the same slot.  Runs in flight must use different advice arrays and status words.
+ * RE-USE OF OUTPUT ARRAYS is ordered through `stream`: the run's kernels start behind the work queued on `stream` at the time of
+ * the call (and behind the slot's previous run) and behind nothing else.  A caller that reads a finished run's arrays on ANOTHER
+ * stream (export, digest, unit records) and then submits into the same arrays must make `stream` wait for those reads
+ * (hipEventRecord on the reader's stream + hipStreamWaitEvent on `stream`) - or use one stream for both, as bench.py does. */
 int h2e_submit(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
                void* d_select, void* d_status, void* stream, int* job);
 int h2e_wait(h2e_ctx* ctx, int job, void* stream);
+
+/* SEVERAL CALLER BATCHES AS ONE RUN.  n_batches (1 .. 16) batches of n_instances_each instances, every batch with its own inputs, its
+ * own batch-interleaved arrays (over ITS n_instances_each instances) and its own status words - d_inputs[b], d_base[b], ... are host
+ * arrays of n_batches device pointers, read before the call returns - executed as ONE run of n_batches x n_instances_each instances:
+ * the same kernels and launches as a single batch of that size, every batch's cells in its own arrays (cell for cell what h2e_run of
+ * that batch alone writes).  For a host with a STREAM of small batches - one GPU's share of a pairing job dealt over 8 GPUs is 2 (bls12_381)
+ * or 8 (bn256) checks per step: a run's value chain costs ~2 ms of latency on one compute unit however small the batch, so eight 2-check
+ * batches submitted together cost what one 16-check batch costs (0.07 instead of 0.20 ms per check, bench.py --group).  The consumer's
+ * calls (h2e_export, h2e_digest, h2e_unit_records, h2e_check) take one batch's arrays at a time, as ever.  No stream digest. */
+int h2e_run_batches(h2e_ctx* ctx, h2e_program* p, uint32_t n_batches, uint32_t n_instances_each, const void* const* d_inputs,
+                    void* const* d_base, void* const* d_range, void* const* d_select, void* const* d_status, void* stream);
+int h2e_submit_batches(h2e_ctx* ctx, h2e_program* p, uint32_t n_batches, uint32_t n_instances_each, const void* const* d_inputs,
+                       void* const* d_base, void* const* d_range, void* const* d_select, void* const* d_status, void* stream, int* job);
+
+/* MORE RUNS IN FLIGHT THAN ARRAY SETS FIT: h2e_ring.  A pipelined run holds its output arrays from its first kernel to its completion
+ * and its value chain must be finished before its big expansion can stream; with two array sets (2 x 110 GB for 64 x 1024-point MSM
+ * tiles) the step is half a run's latency, and a third set does not fit 288 GB.  But ONE launch of such a program owns most rows (the MSM's
+ * window strands: 81-89 % of every array) and nothing writes them before that launch's own value chain stores its operand cells, late in
+ * the run.  A ring backs the rows of the program's biggest launch by TWO physical copies and all other rows by `depth`, mapped (HIP
+ * virtual-memory API) into lcm(2, depth) virtual array sets: run k uses set k - rest copy k mod depth, big-launch copy k mod 2 - and
+ * whatever of run k writes the big launch's rows waits for the completion of run k - 2.  depth 3: three runs in flight in 2.2 sets.
+ *   - set H2E_OPT_PIPELINE_DEPTH = depth first; submit the ring's runs in order (k = 0, 1, 2, ...) and nothing else on the context meanwhile;
+ *   - h2e_ring_arrays(k) are run k's arrays for the consumer's calls (h2e_export, h2e_digest, h2e_unit_records, h2e_check): ordinary
+ *     batch-interleaved arrays.  The rows of the big launch (h2e_ring_info: launch index; h2e_program_launch_rows) are valid from the
+ *     completion of run k until run k + 2 is SUBMITTED; every other row until run k + depth is.  A consumer that needs the big launch's
+ *     rows longer takes them through the stream digest (h2e_ring_submit_digest) or uses plain array sets with h2e_submit;
+ *   - h2e_wait(job) as for h2e_submit.  Errors: H2E_ERR_HIP if the device cannot map the memory (no fallback: use h2e_submit). */
+typedef struct h2e_ring h2e_ring;
+int h2e_ring_create(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, uint32_t depth, h2e_ring** out);
+void h2e_ring_destroy(h2e_ring* ring);
+int h2e_ring_arrays(const h2e_ring* ring, uint64_t k, void** d_base, void** d_range, void** d_select);
+/* out[0..2] = bytes of a full array set (base, range, select), [3..5] = of each, the bytes the two shared copies back, [6] = physical
+ * bytes of the ring, [7] = the shared launch (index in h2e_program_launches), [8] = virtual array sets, [9] = depth.  Returns 10. */
+int h2e_ring_info(const h2e_ring* ring, uint64_t* out, uint32_t cap);
+int h2e_ring_submit(h2e_ring* ring, uint64_t k, const void* d_inputs, void* d_status, void* stream, int* job);
+int h2e_ring_submit_digest(h2e_ring* ring, uint64_t k, const void* d_inputs, void* d_status, void* d_digests, void* stream, int* job);
 
 /* Options / statistics of a context.  Tuning knobs are read from the environment once, at h2e_ctx_create
  * (H2E_X_SPLIT, H2E_X_SPLIT_MIN_LANES, H2E_X_PARTS); nothing reads the environment while a run is queued.
@@ -407,7 +447,10 @@ int h2e_digest(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, int region, c
  *   [last 12] d_digests[region][instance][4] (what h2e_run_digest / h2e_submit_digest left), zero if d_digests is NULL
  * = 29 words (bn256 workloads) or 33 (bls12_381 tiles).  out_stride_words >= the record size lets the caller keep columns of
  * its own in the same table (e.g. a leading global unit index, so that the table is what it hands to ncclAllGather as it is:
- * INTEGRATION.md "The gather").  Reads d_base (batch-interleaved base array of the run) and d_status only. */
+ * INTEGRATION.md "The gather").  Reads d_base (batch-interleaved base array of the run) and d_status only.
+ * A program without outputs (no result point) gets the 3-limb record size - 29 words, point words zero - by convention; a program
+ * whose outputs are not a point (h2e_program_pairing: an Fq12), or whose output references are not absolute base-array cells inside
+ * the program's rows, is refused (H2E_ERR_INVALID). */
 int h2e_unit_record_words(const h2e_program* p);
 int h2e_unit_records(h2e_ctx* ctx, const h2e_program* p, uint32_t n_instances, const void* d_base, const void* d_status,
                      const void* d_digests /* or NULL */, void* d_out, uint32_t out_stride_words, void* stream);

@@ -158,6 +158,14 @@ extern "C" {
     pub fn h2e_submit(ctx: *mut c_void, p: *mut c_void, n_instances: u32, d_inputs: *const c_void, d_base: *mut c_void,
                       d_range: *mut c_void, d_select: *mut c_void, d_status: *mut c_void, stream: *mut c_void, job: *mut c_int) -> c_int;
     pub fn h2e_wait(ctx: *mut c_void, job: c_int, stream: *mut c_void) -> c_int;
+    /// several caller batches (own inputs, arrays, status words each; `d_*` = host arrays of n_batches device pointers) as ONE run:
+    /// a stream of small batches costs runs, not instances (include/h2e.h)
+    pub fn h2e_run_batches(ctx: *mut c_void, p: *mut c_void, n_batches: u32, n_instances_each: u32, d_inputs: *const *const c_void,
+                           d_base: *const *mut c_void, d_range: *const *mut c_void, d_select: *const *mut c_void,
+                           d_status: *const *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn h2e_submit_batches(ctx: *mut c_void, p: *mut c_void, n_batches: u32, n_instances_each: u32, d_inputs: *const *const c_void,
+                              d_base: *const *mut c_void, d_range: *const *mut c_void, d_select: *const *mut c_void,
+                              d_status: *const *mut c_void, stream: *mut c_void, job: *mut c_int) -> c_int;
     /// the same with the stream digest as the consumer: d_digests = [3][n_instances][4] u64, accumulated by the expansion while it
     /// stores (a streaming job's consumer: no second pass over the cells; INTEGRATION.md "A stream of batches")
     pub fn h2e_run_digest(ctx: *mut c_void, p: *mut c_void, n_instances: u32, d_inputs: *const c_void, d_base: *mut c_void,
@@ -185,6 +193,14 @@ extern "C" {
     pub fn h2e_last_run_launch_ms(ctx: *mut c_void, ms: *mut f32, cap: u32) -> c_int;
     pub fn h2e_job_launch_ms(ctx: *mut c_void, job: c_int, ms: *mut f32, cap: u32) -> c_int;
     pub fn h2e_last_run_expansion_launches(ctx: *mut c_void, counts: *mut u32, cap: u32) -> c_int;
+    // ---- h2e_ring: three runs in flight in 2.2 array sets (the rows of the program's biggest launch shared by runs k and k + 2) ----
+    pub fn h2e_ring_create(ctx: *mut c_void, p: *mut c_void, n_instances: u32, depth: u32, out: *mut *mut c_void) -> c_int;
+    pub fn h2e_ring_destroy(ring: *mut c_void);
+    pub fn h2e_ring_arrays(ring: *const c_void, k: u64, d_base: *mut *mut c_void, d_range: *mut *mut c_void, d_select: *mut *mut c_void) -> c_int;
+    pub fn h2e_ring_info(ring: *const c_void, out: *mut u64, cap: u32) -> c_int;
+    pub fn h2e_ring_submit(ring: *mut c_void, k: u64, d_inputs: *const c_void, d_status: *mut c_void, stream: *mut c_void, job: *mut c_int) -> c_int;
+    pub fn h2e_ring_submit_digest(ring: *mut c_void, k: u64, d_inputs: *const c_void, d_status: *mut c_void, d_digests: *mut c_void,
+                                  stream: *mut c_void, job: *mut c_int) -> c_int;
     /// test hook: the value chain's digit-row primitives on caller-chosen operands (tests/test_digit_rows_gpu.py)
     pub fn h2e_selftest_digit_rows(field_pair: c_int, op: u32, n_cases: u32, d_in: *const c_void, d_out: *mut c_void,
                                    stream: *mut c_void) -> c_int;

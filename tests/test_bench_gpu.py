@@ -70,6 +70,16 @@ def test_bench_small_pairing(workload):
     _check_contract(d, 1, 3, 1)
 
 
+@pytest.mark.parametrize("workload", ["pairing_bn256", "pairing_bls12_381"])
+def test_bench_small_pairing_grouped(workload):
+    """--group: the steps go out three at a time as ONE run (h2e_submit_batches); a step is still one batch of --units with its own
+    arrays; steps / warm-up are rounded up to whole groups and reported as run"""
+    d, full = _bench("--workload", workload, "--units", "2", "--group", "3", "--steps", "4", "--warmup", "1", "--ring", "2", "--traffic", "off",
+                     "--no-cpu-baseline")
+    _check_contract(d, 1, 6, 3)
+    assert d["config"]["steps_per_run"] == 3 and d["single_batch_ms"] > 0
+
+
 def test_bench_job_128_tiles_ring_digest_vs_oracle(tmp_path):
     """configs[2]'s per-GPU share at size: 128 tiles x 1024 points as one streaming job through the ring of two 64-tile
     buffer sets (2 steps, 220 GB of arrays), every tile its own inputs, stream-digest consumer on (accumulated by the

@@ -42,8 +42,6 @@ def rows(engine):
 
     def run(fp, op, cases):
         fn = lib().h2e_selftest_digit_rows
-        fn.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
-        fn.restype = C.c_int
         a = np.zeros((len(cases), 2, 16), dtype=np.uint32)
         for k, (x, y) in enumerate(cases):
             a[k, 0], a[k, 1] = x, y

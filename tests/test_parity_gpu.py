@@ -946,3 +946,182 @@ def test_engine_matches_golden_fixtures(engine, doc):
     flags = (prog.base_flags(), prog.range_flags(), prog.select_flags())
     for f, name in zip(flags, ("base", "range", "select")):
         assert golden_util.sha(f) == doc[name + "_flags_sha256"]
+
+
+@pytest.mark.parametrize("what,k,n_each", [("bls12_381", 8, 2), ("bn256", 8, 8), ("bn256", 3, 5), ("msm", 4, 16), ("msm", 2, 3), ("int_mul", 16, 1)])
+def test_several_caller_batches_as_one_run(engine, oracle, what, k, n_each):
+    """h2e_run_batches / h2e_submit_batches: k caller batches - own inputs, own batch-interleaved arrays over n_each instances, own
+    status words - executed as ONE run of k x n_each instances (a stream of small batches costs runs, not instances: one GPU's share of
+    configs[3] / configs[4] at 8 GPUs is 8 / 2 checks per step).  Every batch's three arrays must be what h2e_run of that batch alone
+    writes (32-byte digests per instance; arrays 0xFF-poisoned: nothing but the assigned cells may change), every status 0, and one
+    instance of the last batch cell for cell as the oracle's - through the packed expansion (pairing batches of <= 32 instances in
+    all), the plain one (64 MSM instances) and ragged sizes."""
+    if what == "bn256":
+        prog, gen, orun_of = Program.pairing_check_bn256(), synth.pairing_check_bn256_inputs, oracle_lib.run_pairing_check_bn256
+        make = lambda i: gen(instance=i)   # noqa: E731
+    elif what == "bls12_381":
+        prog, gen, orun_of = Program.pairing_check_bls12_381(), synth.pairing_check_bls12_381_inputs, oracle_lib.run_pairing_check_bls12_381
+        make = lambda i: gen(instance=i)   # noqa: E731
+    elif what == "msm":
+        prog = Program.msm_bn256_tile(12)
+        make = lambda i: synth.msm_bn256_tile_inputs(12, tile=i)[0]   # noqa: E731
+        orun_of = lambda inp: oracle_lib.run_msm_bn256_tile(12, inp)   # noqa: E731
+    else:
+        prog = Program.int_mul_batch(1, 3)
+        make = lambda i: synth.int_mul_batch_inputs(1, 3, seed_index=i)   # noqa: E731
+        orun_of = lambda inp: oracle_lib.run_int_mul_batch(1, 3, inp)   # noqa: E731
+    t = engine.torch
+    ins = [[make(3000 + 40 * b + j) for j in range(n_each)] for b in range(k)]
+    d_in = [engine.upload_inputs(prog, np.stack(x)) for x in ins]
+    want = []
+    ref = engine.alloc(prog, n_each, fill=0xFF)
+    for b in range(k):
+        ref[3].zero_()
+        engine.run(prog, d_in[b], *ref)
+        t.cuda.synchronize()
+        assert (ref[3].cpu().numpy() == 0).all(), ref[3].cpu().numpy()
+        want.append([engine.digest(prog, region, ref[region]).cpu().numpy() for region in range(3)])
+    raw_ref = [a.clone() for a in ref[:3]]   # batch k - 1 alone, poison included
+    for mode in ("run", "submit"):
+        bufs = [engine.alloc(prog, n_each, fill=0xFF) for _ in range(k)]
+        for b in range(k):
+            bufs[b][3].zero_()
+        batches = [(d_in[b],) + tuple(bufs[b]) for b in range(k)]
+        if mode == "run":
+            engine.run_batches(prog, batches)
+        else:
+            engine.wait(engine.submit_batches(prog, batches))
+        t.cuda.synchronize()
+        for b in range(k):
+            assert (bufs[b][3].cpu().numpy() == 0).all(), (mode, b, bufs[b][3].cpu().numpy())
+            for region in range(3):
+                got = engine.digest(prog, region, bufs[b][region]).cpu().numpy()
+                assert np.array_equal(got, want[b][region]), (mode, b, region)
+        for region in range(3):   # bytes, not only assigned cells: the poison around them is untouched exactly as in the single run
+            assert t.equal(bufs[k - 1][region], raw_ref[region]), (mode, region)
+    orun = orun_of(ins[k - 1][n_each - 1])
+    assert orun.info.status == 0, orun.error
+    compare_advice(prog, orun, *_rows(engine, prog, bufs[k - 1][:3]), instance=n_each - 1)
+    orun.close()
+
+
+def test_batches_argument_checks(engine):
+    prog = Program.int_mul_batch(0, 1)
+    d_in = engine.upload_inputs(prog, np.stack([synth.int_mul_batch_inputs(0, 1)]))
+    a, b = engine.alloc(prog, 1), engine.alloc(prog, 1)
+    from halo2ecc_s_amd.engine import H2EError
+    with pytest.raises(H2EError, match="share an output array"):
+        engine.run_batches(prog, [(d_in,) + tuple(a), (d_in,) + tuple(a)])
+    with pytest.raises(H2EError, match="n_batches"):
+        engine.run_batches(prog, [(d_in,) + tuple(engine.alloc(prog, 1)) for _ in range(17)])
+    engine.run_batches(prog, [(d_in,) + tuple(a), (d_in,) + tuple(b)])
+    engine.torch.cuda.synchronize()
+    assert engine.torch.equal(a[0], b[0]) and int(a[3][0]) == 0
+
+
+@pytest.mark.parametrize("what,n_inst,depth", [("msm", 5, 3), ("msm", 64, 3), ("msm", 3, 4)])
+def test_ring_three_runs_in_flight_share_the_big_launch_rows(engine, oracle, what, n_inst, depth):
+    """h2e_ring: `depth` runs in flight whose biggest launch's rows (the MSM's window strands) are backed by TWO physical copies - run k
+    and run k + 2 write the same physical rows - with everything of run k that writes them fenced behind the completion of run k - 2.
+    Nine runs of DIFFERENT batches back to back, `depth` of them in flight, consumed the way the ring is made for: the STREAM DIGEST of
+    every run (all three arrays, every assigned cell, accumulated by the expansion while it stores - the shared rows of run k may be
+    gone once run k + 2 is submitted) must equal the stream digest of the same batch through h2e_run_digest into plain arrays, every
+    status 0, and the last run - nothing submitted after it - cell for cell as the oracle's; and the aliasing is real (set k and set
+    k + 2 share addresses in the big launch's rows, and only there)."""
+    from halo2ecc_s_amd import Ring
+    if what == "msm":
+        prog = Program.msm_bn256_tile(33)
+        make = lambda i: synth.msm_bn256_tile_inputs(33, tile=i)[0]   # noqa: E731
+        orun_of = lambda inp: oracle_lib.run_msm_bn256_tile(33, inp)   # noqa: E731
+    else:
+        prog = Program.pairing_check_bn256()
+        make = lambda i: synth.pairing_check_bn256_inputs(instance=i)   # noqa: E731
+        orun_of = oracle_lib.run_pairing_check_bn256
+    t = engine.torch
+    n_runs, n_batches = 9, 4
+    ins = [[make(5000 + 70 * b + j) for j in range(n_inst)] for b in range(n_batches)]
+    d_in = [engine.upload_inputs(prog, np.stack(x)) for x in ins]
+    want = []
+    ref = engine.alloc(prog, n_inst, fill=0xFF)
+    for b in range(n_batches):
+        ref[3].zero_()
+        want.append(engine.run_digest(prog, d_in[b], *ref).cpu().numpy().copy())
+        t.cuda.synchronize()
+        assert (ref[3].cpu().numpy() == 0).all()
+    del ref
+    old_depth = engine.get_stat(3)
+    engine.set_option(4, depth)
+    ring = None
+    try:
+        ring = Ring(engine, prog, n_inst, depth)
+        info = ring.info
+        assert info["depth"] == depth and info["virtual_sets"] == (depth if depth % 2 == 0 else 2 * depth)
+        full = sum(info["set_bytes"])
+        assert info["physical_bytes"] == 2 * sum(info["shared_bytes"]) + depth * (full - sum(info["shared_bytes"])) < depth * full
+        if what == "msm":
+            assert sum(info["shared_bytes"]) > 0.5 * full       # the window strands own most rows
+        rows = prog.launch_rows(info["shared_launch"])
+        # the aliasing: a cell of the shared launch written through set 0 reads back through set 2 (and not through set 1); a cell
+        # outside it does not
+        a0, a1, a2 = ring.arrays(0)[0], ring.arrays(1)[0], ring.arrays(2)[0]
+        r_in, r_out = int(rows[0]) + 10, 0
+        for a in (a0, a1, a2):
+            a[r_in].zero_()
+            a[r_out].zero_()
+        a0[r_in] += 7
+        a0[r_out] += 9
+        t.cuda.synchronize()
+        assert int(a2[r_in].flatten()[0]) == 7 and int(a1[r_in].flatten()[0]) == 0
+        assert int(a2[r_out].flatten()[0]) == 0 and int(a1[r_out].flatten()[0]) == 0
+        for v in range(info["virtual_sets"]):
+            for a in ring.arrays(v):
+                a.fill_(-1)                              # poison: only assigned cells may change
+        status = [t.zeros((n_inst,), dtype=t.int32, device=a0.device) for _ in range(depth)]
+        dgs = [t.zeros((3, n_inst, 4), dtype=t.int64, device=a0.device) for _ in range(depth)]
+        got, pending = {}, []
+
+        def retire(k0, job0):
+            engine.wait(job0)
+            got[k0] = (dgs[k0 % depth].clone(), status[k0 % depth].clone())
+
+        for k in range(n_runs):
+            while len(pending) >= depth:
+                retire(*pending.pop(0))
+            status[k % depth].zero_()
+            pending.append((k, ring.submit(k, d_in[k % n_batches], status[k % depth], digests=dgs[k % depth])))
+            while len(pending) > depth - 1:              # as bench.py: consume the oldest while the newer ones are in flight
+                retire(*pending.pop(0))
+        for k0, job0 in pending:
+            retire(k0, job0)
+        t.cuda.synchronize()
+        for k in range(n_runs):
+            dg, st = got[k]
+            assert (st.cpu().numpy() == 0).all(), (k, st.cpu().numpy())
+            assert np.array_equal(dg.cpu().numpy(), want[k % n_batches]), k
+        last = n_runs - 1
+        orun = orun_of(ins[last % n_batches][n_inst - 1])
+        assert orun.info.status == 0, orun.error
+        compare_advice(prog, orun, *_rows(engine, prog, ring.arrays(last)), instance=n_inst - 1)
+        orun.close()
+        from halo2ecc_s_amd.engine import H2EError
+        with pytest.raises(H2EError, match="in order"):
+            ring.submit(n_runs + 3, d_in[0], status[0])
+    finally:
+        t.cuda.synchronize()
+        if ring is not None:
+            ring.close()
+        engine.set_option(4, old_depth)
+
+
+def test_ring_needs_a_forked_launch_and_the_matching_depth(engine):
+    from halo2ecc_s_amd import Ring
+    from halo2ecc_s_amd.engine import H2EError
+    old_depth = engine.get_stat(3)
+    try:
+        engine.set_option(4, 3)
+        with pytest.raises(H2EError, match="no forked launch"):
+            Ring(engine, Program.integer_chip_st(0), 2, 3)
+        with pytest.raises(H2EError, match="PIPELINE_DEPTH"):
+            Ring(engine, Program.msm_bn256_tile(4), 2, 2)
+    finally:
+        engine.set_option(4, old_depth)

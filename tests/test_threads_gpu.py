@@ -8,6 +8,7 @@ cloned contexts (`unsafe impl Send`, native_scalar_ecc_chip.rs:92), then one Moc
   * two contexts on one device run from two threads at the same time;
 every result is compared cell for cell with the oracle afterwards.  ctypes releases the GIL for the duration of a C call, so
 the threads really are inside libh2e.so together."""
+import os
 import threading
 
 import numpy as np
@@ -18,6 +19,7 @@ from halo2ecc_s_amd import Engine, Program, synth
 from parity import compare_advice
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _jobs():
