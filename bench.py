@@ -206,6 +206,10 @@ def headline(out, detail_path):
         h["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": short(cb["sample"], 260)}
         if "points_per_s" in cb:
             h["cpu_baseline"]["points_per_s"] = cb["points_per_s"]
+    fp = out.get("consumer_ready_first_pass") or (out.get("also", {}).get("msm_consumer_ready", {}) or {}).get("consumer_ready_first_pass")
+    if fp:
+        h["consumer_ready_first_pass_ms"] = fp.get("ms_per_step")
+        h["consumer_ready_two_pass_canonical_ms"] = fp.get("two_pass_canonical_ms")
     for k in ("msm_points_per_sec", "single_batch_ms", "consumer_ready_ms_per_step", "per_rank_ms_per_step"):
         if k in out:
             h[k] = out[k]
@@ -671,6 +675,7 @@ def main():
 
     # consumer-ready output: the batch as halo2's advice columns (one array per instance, column-major, Montgomery-form cells)
     consumer_ms = None
+    first_pass = None
     if args.consumer_ready > 0:
         from halo2ecc_s_amd.engine import FORM_MONTGOMERY, LAYOUT_COLUMNS
         base, rng, sel, status = arrays_of(0)
@@ -687,6 +692,47 @@ def main():
             if i > 0:
                 lat.append(1e3 * (time.perf_counter() - t1))
         consumer_ms = float(np.median(lat))
+        # ... and the same columns straight out of the expansion (h2e_run_columns: no second pass; canonical cells): the arrays of the
+        # export are the column arrays - zeroed once -, the check is a wrap-around sum of every word of every array against the
+        # export's of the same batch (the cell-for-cell comparison is tests/test_parity_gpu.py's)
+        from halo2ecc_s_amd.engine import FORM_CANONICAL
+        first_pass = {"form": "canonical", "note": "h2e_run_columns: the expansion stores the per-instance columns itself (four rows staged in LDS, 128-byte "
+                                                   "runs per instance); the batch-interleaved arrays stay the working copy"}
+        try:
+            n_cr = args.consumer_ready
+            status.zero_()
+            eng.run(prog, batches[n_cr % n_batches], base, rng, sel, status)
+            want = []
+            for region, arr in enumerate((base, rng, sel)):
+                eng.export(prog, region, arr, layout=LAYOUT_COLUMNS, form=FORM_CANONICAL, out=outs[region])
+                want.append(int(outs[region].sum()))
+            lat_exp = []
+            for i in range(2):   # (run + export with canonical cells: the two-pass figure the first-pass one stands against)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                eng.run(prog, batches[n_cr % n_batches], base, rng, sel, status)
+                for region, arr in enumerate((base, rng, sel)):
+                    eng.export(prog, region, arr, layout=LAYOUT_COLUMNS, form=FORM_CANONICAL, out=outs[region])
+                torch.cuda.synchronize()
+                lat_exp.append(1e3 * (time.perf_counter() - t1))
+            for o in outs:
+                o.zero_()
+            lat = []
+            for i in range(n_cr + 1):
+                status.zero_()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                eng.run_columns(prog, batches[i % n_batches], base, rng, sel, status, outs)
+                torch.cuda.synchronize()
+                if i > 0:
+                    lat.append(1e3 * (time.perf_counter() - t1))
+                    first_pass.setdefault("launch_ms", []).append([list(x) for x in eng.last_run_launch_ms()])
+                assert args.no_check or int(status.abs().max()) == 0
+            got = [int(o.sum()) for o in outs]
+            assert args.no_check or got == want, f"h2e_run_columns: checksums {got} != the export's {want}"
+            first_pass.update(ms_per_step=float(np.median(lat)), two_pass_canonical_ms=float(min(lat_exp)), checksums_equal_export=(got == want))
+        except Exception as e:   # noqa: BLE001  (a program the column unit does not serve must not cost the line)
+            first_pass["error"] = f"{type(e).__name__}: {str(e)[:300]}"
         del outs
 
     # per-launch times of every timed step (HIP events recorded by the engine on the launching streams)
@@ -768,6 +814,7 @@ def main():
                    "sharding": f"units round-robin over {world} GPU(s); one all_gather of the job's per-unit records at the end of the timed region"},
         "single_batch_ms": single_ms,
         "consumer_ready_ms_per_step": consumer_ms,
+        "consumer_ready_first_pass": first_pass if args.consumer_ready > 0 else None,
         "per_rank_ms_per_step": per_rank_ms,
         "whole_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                        "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -829,6 +876,9 @@ def main():
         summary[name] = brief(blk) if "ms_per_step" in blk else blk.get("error", "failed")[:80]
     if out.get("consumer_ready_ms_per_step") is not None:
         summary["consumer_ready_ms_per_step"] = round(out["consumer_ready_ms_per_step"], 3)
+    fpass = out.get("consumer_ready_first_pass") or ((also or {}).get("msm_consumer_ready", {}) or {}).get("consumer_ready_first_pass")
+    if fpass and fpass.get("ms_per_step") is not None:
+        summary["consumer_ready_first_pass_ms"] = round(fpass["ms_per_step"], 3)
     out["summary"] = summary
     if rank == 0:
         if args.sub or args.full_line:

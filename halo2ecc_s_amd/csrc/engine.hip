@@ -25,10 +25,20 @@
 #define H2E_FP_ONLY -1
 #endif
 #define H2E_HAS_FP(id) (H2E_FP_ONLY < 0 || H2E_FP_ONLY == (id))
-#define H2E_COMMON_UNIT (H2E_FP_ONLY <= 0)
+// The COLUMN-EMISSION unit (-DH2E_COLS, with H2E_FP_ONLY = k): this file once more for pair k, holding ONE kernel - the full expansion
+// that stores halo2's per-instance advice columns itself (h2e_run_tape_cols, behind h2e_engine_launch_cols_fpK) - with the emission layer
+// below compiled in its staging form.  A unit of its own, so that the plain expansion's register allocation (249 of 256) sees none of it.
+#ifdef H2E_COLS
+#define H2E_COLS_ON 1
+#else
+#define H2E_COLS_ON 0
+#endif
+#define H2E_COMMON_UNIT (H2E_FP_ONLY <= 0 && !H2E_COLS_ON)
 #define H2E_CAT2(a, b) a##b
 #define H2E_CAT(a, b) H2E_CAT2(a, b)
-#if H2E_FP_ONLY >= 0
+#if H2E_COLS_ON
+#define H2E_UNIT(name) H2E_CAT(name##_colsfp, H2E_FP_ONLY)
+#elif H2E_FP_ONLY >= 0
 #define H2E_UNIT(name) H2E_CAT(name##_fp, H2E_FP_ONLY)
 #else
 #define H2E_UNIT(name) name
@@ -171,6 +181,31 @@ struct LC {  // lane context
     // LDS ([region][word][lane], this lane's words at dg + (4 region + word) * 64), flushed to the run's digest array when
     // the lane is done.  nullptr = off.
     u64* dg = nullptr;
+#if H2E_COLS_ON
+    // Column emission.  The wave's 64 lanes are 64 consecutive instances (inst0 ..) at the same rows, and a column's cells reach HBM as
+    // 128-byte runs of ONE instance - four consecutive rows - because a write request costs the memory system the same whatever it
+    // carries up to a line (exp/ubench/colrun.hip, colpolicy.hip: ~43 G requests/s; per-lane 32-byte stores 1.2 TB/s).  So the rows are
+    // staged in LDS by blocks of four: base [5 cols][4 rows][64 lanes][32 B] = 40 KB, range compact ([4][64] x 16 B for the
+    // accumulator column, x 4 B for the two chunk columns) = 6 KB; a block is flushed - eight lanes per instance and store instruction
+    // - when the rows move on.  Unassigned cells inside the rows the sub-range has passed are written as zeros (whole lines; nobody
+    // else ever writes an unassigned cell), rows outside are left alone.  52 KB of LDS = three waves per compute unit (+22 % on the
+    // window launch; four would be +2 %, two +50 %: exp/r6_occupancy.sh), which leaves each wave a SIMD's registers: the result cache
+    // lives in VGPRs here.
+    u64* colB = nullptr;   // instance 0's column arrays [col][rows][4 words]
+    u64* colR = nullptr;
+    u64* colS = nullptr;
+    u64 csB = 0, csR = 0, csS = 0;     // words to the next instance's arrays
+    u32 crB = 0, crR = 0, crS = 0;     // rows per column
+    u32 inst0 = 0;                      // instance of lane 0
+    u64* stgB = nullptr;                // LDS
+    u64* stgR0 = nullptr;
+    u32* stgR12 = nullptr;
+    u32 loB = 0, loR = 0;               // first row (absolute) of the sub-range in the base / range array
+    mutable u32 blkB = ~0u, validB = 0, hiB = 0;   // the open block (its first row), its staged cells (bit 4 col + row), rows passed
+    mutable u32 blkR = ~0u, validR = 0, hiR = 0;
+    mutable bool nodual = false;        // rows no op ever reads back (the mul equation's): not written to the working copy
+    mutable u64 xr[3][2 * H2E_MAX_L + 4];
+#endif
 };
 // key of a cell position and the digest contribution of one 64-bit word of its value (h2e.h: stream digest)
 WI_INLINE void dg_keys(u32 pos, u32& k0, u32& k1) {
@@ -296,8 +331,103 @@ WI_INLINE Fe inv_n(const LC& c, const Fe& a) { return wd_inv_mod<4>(a, n_of(c));
 // staging), and cells the shape leaves unassigned cost nothing.  `mask` = assigned columns (compile-time at nearly
 // every call site).  Round 1 kept the reference's per-instance row-major layout: 160 / 96 / 64-byte segments per lane,
 // LDS-staged whole-row flushes, 1.48 x the algorithmic bytes written (zero cells) at 0.35 of the HBM roof.
+#if H2E_COLS_ON
+WI_INLINE u32 uni(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
+// flush the open base block: per column with staged cells, eight store instructions of 16 bytes per lane - lane = (instance 8 s +
+// lane / 8, piece lane % 8 = row 2 bits, half 1 bit): 128 contiguous bytes per instance
+WI_INLINE void colB_flush(const LC& c, u32 hi) {
+    const u32 vb = c.validB, blk = c.blkB;
+    if (vb == 0) return;
+    const u32 lane = threadIdx.x, piece = lane & 7u, j = piece >> 1, half = piece & 1u;
+    const u32 row = blk + j;
+    const bool own = row >= c.loB && row < hi && row < c.crB;
+#pragma unroll
+    for (int col = 0; col < 5; col++) {
+        const u32 vm = (vb >> (4 * col)) & 15u;
+        if (vm == 0) continue;
+        const bool has = (vm >> j) & 1u;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) {
+            const u32 inst = 8u * s8 + (lane >> 3);
+            u64x2 v = {0, 0};
+            if (has) v = l_ld16(c.stgB + (((size_t)(col * 4 + j) * 64 + inst) * 4 + half * 2));
+            if (has || own) g_st16(c.colB + (size_t)(c.inst0 + inst) * c.csB + ((size_t)col * c.crB + row) * 4 + half * 2, v.x, v.y);
+        }
+    }
+    c.validB = 0;
+}
+WI_INLINE void colR_flush(const LC& c, u32 hi) {
+    const u32 vb = c.validR, blk = c.blkR;
+    if (vb == 0) return;
+    const u32 lane = threadIdx.x, piece = lane & 7u, j = piece >> 1, half = piece & 1u;
+    const u32 row = blk + j;
+    const bool own = row >= c.loR && row < hi && row < c.crR;
+#pragma unroll
+    for (int col = 0; col < 3; col++) {
+        const u32 vm = (vb >> (4 * col)) & 15u;
+        if (vm == 0) continue;
+        const bool has = (vm >> j) & 1u;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) {
+            const u32 inst = 8u * s8 + (lane >> 3);
+            u64x2 v = {0, 0};
+            if (has && half == 0) {   // (range cells are below 2^128: the high half is zero)
+                if (col == 0) v = l_ld16(c.stgR0 + ((size_t)j * 64 + inst) * 2);
+                else v.x = (u64) * (const H2E_AS_LDS u32*)(c.stgR12 + ((size_t)(col - 1) * 4 + j) * 64 + inst);
+            }
+            if (has || own) g_st16(c.colR + (size_t)(c.inst0 + inst) * c.csR + ((size_t)col * c.crR + row) * 4 + half * 2, v.x, v.y);
+        }
+    }
+    c.validR = 0;
+}
+WI_INLINE void colB_open(const LC& c, u32 arow) {
+    if ((arow & ~3u) != c.blkB) {
+        if (arow < c.blkB && c.blkB != ~0u) atomicOr(c.status, H2E_STATUS_ARITH);   // rows of a sub-range only move forward
+        colB_flush(c, arow);       // (every row below the new one has been passed)
+        c.blkB = arow & ~3u;
+    }
+    c.hiB = arow + 1;
+}
+WI_INLINE void colR_open(const LC& c, u32 arow) {
+    if ((arow & ~3u) != c.blkR) {
+        if (arow < c.blkR && c.blkR != ~0u) atomicOr(c.status, H2E_STATUS_ARITH);
+        colR_flush(c, arow);
+        c.blkR = arow & ~3u;
+    }
+    c.hiR = arow + 1;
+}
+WI_INLINE void colB_stage(const LC& c, int col, u32 j, const Fe& v) {
+    u64* p = c.stgB + (((size_t)(col * 4) + j) * 64 + threadIdx.x) * 4;
+    l_st16(p, v.v[0], v.v[1]);
+    l_st16(p + 2, v.v[2], v.v[3]);
+}
+// one range row: which of the three cells are assigned, the accumulator (< 2^128) and the two small values
+WI_INLINE void colR_row(const LC& c, u32 arow, u32 mask, u64 a0, u64 a1, u32 tagged, u32 common) {
+    colR_open(c, arow);
+    const u32 j = arow & 3u;
+    if (mask & 1) l_st16(c.stgR0 + ((size_t)j * 64 + threadIdx.x) * 2, a0, a1);
+    if (mask & 2) *(H2E_AS_LDS u32*)(c.stgR12 + ((size_t)j) * 64 + threadIdx.x) = tagged;
+    if (mask & 4) *(H2E_AS_LDS u32*)(c.stgR12 + ((size_t)4 + j) * 64 + threadIdx.x) = common;
+    c.validR |= ((mask & 1) ? 1u << j : 0u) | ((mask & 2) ? 16u << j : 0u) | ((mask & 4) ? 256u << j : 0u);
+}
+#endif
 WI_INLINE void rowB(const LC& c, u32 row, u32 mask, const Fe& v0, const Fe& v1, const Fe& v2, const Fe& v3, const Fe& v4) {
     if (!c.active) return;
+#if H2E_COLS_ON
+    {
+        const u32 arow = uni(row + c.ob);
+        colB_open(c, arow);
+        const u32 j = arow & 3u;
+        if (mask & 1) colB_stage(c, 0, j, v0);
+        if (mask & 2) colB_stage(c, 1, j, v1);
+        if (mask & 4) colB_stage(c, 2, j, v2);
+        if (mask & 8) colB_stage(c, 3, j, v3);
+        if (mask & 16) colB_stage(c, 4, j, v4);
+        c.validB |= ((mask & 1) ? 1u << j : 0u) | ((mask & 2) ? 16u << j : 0u) | ((mask & 4) ? 256u << j : 0u) | ((mask & 8) ? 4096u << j : 0u) |
+                    ((mask & 16) ? 65536u << j : 0u);
+        if (c.nodual) return;
+    }
+#endif
     u64* p = rowB_ptr(c, row);
     u32 hs = c.hs;
     if (mask & 1) st_cell(p, hs, v0);
@@ -318,6 +448,11 @@ WI_INLINE void rowR(const LC& c, u32 row, u32 mask, const Fe& acc, const Fe& tag
     if (!c.active) return;
     u64* p = rowR_ptr(c, row);
     u32 hs = c.hs;
+#if H2E_COLS_ON
+    colR_row(c, uni(row + c.orr), mask, acc.v[0], acc.v[1], (u32)tagged.v[0], (u32)common.v[0]);
+    if (!c.nodual && (mask & 1)) st_cell(p, hs, acc);   // (the working copy keeps what an op may read back: accumulator cells - limbs of integers)
+    return;
+#endif
     if (mask & 1) st_cell(p, hs, acc);
     if (mask & 2) st_cell(p + (size_t)2 * hs, hs, tagged);
     if (mask & 4) st_cell(p + (size_t)4 * hs, hs, common);
@@ -332,6 +467,14 @@ WI_INLINE void rowS(const LC& c, u32 row, u32 mask, const Fe& value, const Fe& s
     if (!c.active) return;
     u64* p = rowS_ptr(c, row);
     u32 hs = c.hs;
+#if H2E_COLS_ON
+    {   // the select array (3 % of a tile's cells): straight from the lane, 32 bytes at a time
+        const u32 arow = row + c.os;
+        u64* q = c.colS + (size_t)(c.inst0 + threadIdx.x) * c.csS + (size_t)arow * 4;
+        if ((mask & 1) && arow < c.crS) { g_st16(q, value.v[0], value.v[1]); g_st16(q + 2, value.v[2], value.v[3]); }
+        if ((mask & 2) && arow < c.crS) { g_st16(q + (size_t)c.crS * 4, selector.v[0], selector.v[1]); g_st16(q + (size_t)c.crS * 4 + 2, selector.v[2], selector.v[3]); }
+    }
+#endif
     if (mask & 1) st_cell(p, hs, value);
     if (mask & 2) st_cell(p + (size_t)2 * hs, hs, selector);
     if (c.dg != nullptr) {
@@ -376,6 +519,16 @@ WI_INLINE void emit_limb3(const LC& c, u32 row, const Limb& x) {
     if (!c.active) return;
     u32 hs = c.hs;
     u64* p = rowR_ptr(c, row);
+#if H2E_COLS_ON
+    {
+        const u32 arow = uni(row + c.orr);
+        colR_row(c, arow, 7, x.v[0], x.v[1], (u32)chunk18(x, 3), (u32)chunk18(x, 0));
+        colR_row(c, arow + 1, 6, 0, 0, (u32)chunk18(x, 4), (u32)chunk18(x, 1));
+        colR_row(c, arow + 2, 6, 0, 0, (u32)chunk18(x, 5), (u32)chunk18(x, 2));
+        if (!c.nodual) st_limb(p, hs, x);
+        return;
+    }
+#endif
     size_t cs = (size_t)2 * hs, rs = (size_t)6 * hs;
     st_limb(p, hs, x);
     st_small(p + cs, hs, chunk18(x, 3));
@@ -402,6 +555,15 @@ WI_INLINE void emit_lead2(const LC& c, u32 row, const Limb& x) {
     if (!c.active) return;
     u32 hs = c.hs;
     u64* p = rowR_ptr(c, row);
+#if H2E_COLS_ON
+    {
+        const u32 arow = uni(row + c.orr);
+        colR_row(c, arow, 7, x.v[0], x.v[1], (u32)chunk18(x, 2), (u32)chunk18(x, 0));
+        colR_row(c, arow + 1, 6, 0, 0, (u32)chunk18(x, 3), (u32)chunk18(x, 1));
+        if (!c.nodual) st_limb(p, hs, x);
+        return;
+    }
+#endif
     size_t cs = (size_t)2 * hs, rs = (size_t)6 * hs;
     st_limb(p, hs, x);
     st_small(p + cs, hs, chunk18(x, 2));
@@ -425,6 +587,11 @@ WI_INLINE void emit_lead2(const LC& c, u32 row, const Limb& x) {
 WI_INLINE void emit_common(const LC& c, u32 row, u64 x) {
     if (!c.active) return;
     u64* p = rowR_ptr(c, row);
+#if H2E_COLS_ON
+    colR_row(c, uni(row + c.orr), 3, x, 0, (u32)x, 0);
+    if (!c.nodual) st_small(p, c.hs, x);
+    return;
+#endif
     st_small(p, c.hs, x);
     st_small(p + (size_t)2 * c.hs, c.hs, x);
     if (c.dg != nullptr) {
@@ -452,6 +619,25 @@ WI_INLINE IntVal<FP> ld_int(const LC& c, const u32* refs) {
 template <class FP>
 WI_INLINE IntVal<FP> ld_int_x(const LC& c, const H2EOp& op, int refpos, int which) {
     u32 code = (op.flags >> (10 + 2 * which)) & 3u;
+#if H2E_COLS_ON
+    if (code != 0) {   // the result cache in registers (a wave has a SIMD's register file to itself here); code is wave-uniform
+        IntVal<FP> r;
+        const u64* e = code == 1 ? c.xr[0] : code == 2 ? c.xr[1] : c.xr[2];
+        u64 w[2 * H2E_MAX_L + 4];
+        if (code == 1) { _Pragma("unroll") for (int i = 0; i < 2 * FP::L + 4; i++) w[i] = c.xr[0][i]; }
+        else if (code == 2) { _Pragma("unroll") for (int i = 0; i < 2 * FP::L + 4; i++) w[i] = c.xr[1][i]; }
+        else { _Pragma("unroll") for (int i = 0; i < 2 * FP::L + 4; i++) w[i] = c.xr[2][i]; }
+        (void)e;
+#pragma unroll
+        for (int i = 0; i < FP::L; i++) {
+            r.l[i].v[0] = w[2 * i];
+            r.l[i].v[1] = w[2 * i + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.native.v[i] = w[2 * FP::L + i];
+        return r;
+    }
+#endif
     if (c.xc != nullptr && code != 0) {
         IntVal<FP> r;
         const u64* p = c.xc + (size_t)(code - 1) * (2 * FP::L + 4) * 64 + threadIdx.x;
@@ -473,6 +659,22 @@ WI_INLINE IntVal<FP> ld_int_x(const LC& c, const H2EOp& op, int refpos, int whic
 template <class FP>
 WI_INLINE void xc_put_x(const LC& c, const H2EOp& op, const Limb* l, const Fe& native) {
     u32 code = (op.flags >> 8) & 3u;
+#if H2E_COLS_ON
+    if (code != 0) {
+        u64 w[2 * H2E_MAX_L + 4];
+#pragma unroll
+        for (int i = 0; i < FP::L; i++) {
+            w[2 * i] = l[i].v[0];
+            w[2 * i + 1] = l[i].v[1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) w[2 * FP::L + i] = native.v[i];
+        if (code == 1) { _Pragma("unroll") for (int i = 0; i < 2 * FP::L + 4; i++) c.xr[0][i] = w[i]; }
+        else if (code == 2) { _Pragma("unroll") for (int i = 0; i < 2 * FP::L + 4; i++) c.xr[1][i] = w[i]; }
+        else { _Pragma("unroll") for (int i = 0; i < 2 * FP::L + 4; i++) c.xr[2][i] = w[i]; }
+    }
+    return;
+#endif
     if (c.xc == nullptr || code == 0) return;
     u64* p = c.xc + (size_t)(code - 1) * (2 * FP::L + 4) * 64 + threadIdx.x;
 #pragma unroll
@@ -566,6 +768,10 @@ template <class FP>
 WI_INLINE void emit_mul_equation(const LC& c, u32 brow, u32 rrow, const IntVal<FP>& a, const IntVal<FP>& b,
                                  const Limb* d, const Fe& d_native, const Limb* rem, const Fe& rem_native) {
     constexpr int L = FP::L;
+#if H2E_COLS_ON
+    const bool nodual_was = c.nodual;   // no op reads these rows back
+    c.nodual = true;
+#endif
     Wd<4> lv[FP::MC];
     Limb wl[L];
 #pragma unroll
@@ -627,6 +833,9 @@ WI_INLINE void emit_mul_equation(const LC& c, u32 brow, u32 rrow, const IntVal<F
     }
     // native row (integer_chip.rs:195-215)
     rowB(c, brow, 0x0f, a.native, b.native, d_native, rem_native, FE0);
+#if H2E_COLS_ON
+    c.nodual = nodual_was;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -751,8 +960,14 @@ WI_INLINE void op_int_mul(const LC& c, const H2EOp& op) {
     u32 rr = op.range_row;
     xc_put_x<FP>(c, op, rl, rem_native);
     rr += emit_assigned<FP>(c, op.base_row, rr, rl, rem_native);
+#if H2E_COLS_ON
+    c.nodual = true;    // (the quotient's cells are nobody's operand)
+#endif
     rr += emit_assigned<FP>(c, op.base_row + 1, rr, dl, d_native);
     emit_mul_equation<FP>(c, op.base_row + 2, rr, a, b, dl, d_native, rl, rem_native);
+#if H2E_COLS_ON
+    c.nodual = false;
+#endif
 }
 
 template <class FP>
@@ -770,6 +985,9 @@ WI_INLINE void op_reduce(const LC& c, const H2EOp& op) {
     u32 rr = op.range_row, br = op.base_row;
     xc_put_x<FP>(c, op, rl, rem_native);
     rr += emit_assigned<FP>(c, br, rr, rl, rem_native);
+#if H2E_COLS_ON
+    c.nodual = true;   // quotient and carries: nobody's operands
+#endif
     emit_common(c, rr, d);
     rr += 1;
     // native row: [d * w_native, rem.native * 1 | a.native * (-1)]   (integer_chip.rs:303-311)
@@ -795,6 +1013,9 @@ WI_INLINE void op_reduce(const LC& c, const H2EOp& op) {
         br += 1;
         last_v = v;
     }
+#if H2E_COLS_ON
+    c.nodual = false;
+#endif
 }
 
 // invert rows for one value (base_chip.rs:298-321): [a, c] ; [a, b | c].  b = a^-1 (row + 1, col 1) is left to
@@ -889,12 +1110,18 @@ WI_INLINE void op_div_core(const LC& c, const H2EOp& op) {
     u32 rr = op.range_row;
     xc_put_x<FP>(c, op, cl, c_native);
     rr += emit_assigned<FP>(c, op.base_row, rr, cl, c_native);
+#if H2E_COLS_ON
+    c.nodual = true;
+#endif
     rr += emit_assigned<FP>(c, op.base_row + 1, rr, dl, d_native);
     IntVal<FP> cvv;
 #pragma unroll
     for (int i = 0; i < L; i++) cvv.l[i] = cl[i];
     cvv.native = c_native;
     emit_mul_equation<FP>(c, op.base_row + 2, rr, b, cvv, dl, d_native, a.l, a.native);
+#if H2E_COLS_ON
+    c.nodual = false;
+#endif
 }
 
 template <class FP>
@@ -1262,6 +1489,97 @@ __global__ void __launch_bounds__(64, (FP::WW > 4 ? H2E_X_WAVES_WIDE : H2E_X_WAV
     }
     }
 }
+
+#if H2E_COLS_ON
+// ------------------------------------------------------------------------------------------------
+// The full expansion that stores halo2's advice columns itself (h2e.h h2e_run_columns; the reference's Records::_assign_to_*_chip,
+// src/context.rs:310-541, without the pass).  Same lanes, ops and arithmetic as h2e_run_tape<FP, false>; the emission layer above is
+// compiled in its staging form.  n_instances is a multiple of 64: a wave = 64 consecutive instances of one strand and sub-range.
+template <class FP>
+__global__ void __launch_bounds__(64, 1) h2e_run_tape_cols(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
+    const u32 per_sub = n_instances * L.n_strands, blocks_per_sub = per_sub / 64;
+    __shared__ TapeChunk chunk;
+    extern __shared__ u64 stg_dyn[];   // base staging [5][4][64][4 words], range: [4][64][2 words], 2 x [4][64] dwords
+    const u32 blk = blockIdx.x;
+    const u32 sub = blk / blocks_per_sub, idx = (blk % blocks_per_sub) * 64 + threadIdx.x;
+    const u32 instance = idx % n_instances, strand = idx / n_instances;
+    u32 op_lo = 0, op_hi = L.n_ops;
+    if (L.n_sub > 1) {
+        op_lo = L.sub[sub];
+        op_hi = L.sub[sub + 1];
+    }
+    InstanceDesc d = inst[instance];
+    LC c;
+    c.base = d.base;
+    c.range = d.range;
+    c.select = d.select;
+    c.inputs = d.inputs;
+    c.status = d.status;
+    c.ob = L.strand_base0 + strand * L.delta_base;
+    c.orr = L.strand_range0 + strand * L.delta_range;
+    c.os = L.strand_select0 + strand * L.delta_select;
+    c.params = L.params + (size_t)strand * L.n_params;
+    c.aux = L.aux;
+    c.pool = L.const_pool;
+    c.fc = &g_fc[FP::ID];
+    c.strand = strand;
+    c.input_stride = L.input_stride;
+    c.sw = L.slot_words;
+    c.hints = d.hints;
+    c.ws = d.ws;
+    c.hint_stride = L.hint_stride;
+    c.hs = inst[0].hs;
+    c.active = true;
+    c.xc = nullptr;
+    c.colB = L.col[0]; c.colR = L.col[1]; c.colS = L.col[2];
+    c.csB = L.col_stride[0]; c.csR = L.col_stride[1]; c.csS = L.col_stride[2];
+    c.crB = L.col_rows[0]; c.crR = L.col_rows[1]; c.crS = L.col_rows[2];
+    c.inst0 = uni(instance - threadIdx.x);
+    c.stgB = stg_dyn;
+    c.stgR0 = stg_dyn + (size_t)5 * 4 * 64 * 4;
+    c.stgR12 = (u32*)(c.stgR0 + (size_t)4 * 64 * 2);
+    {
+        const H2EOp* first = L.tape + op_lo;
+        c.loB = uni(first->base_row + c.ob);
+        c.loR = uni(first->range_row + c.orr);
+        c.hiB = c.loB;
+        c.hiR = c.loR;
+    }
+    for (u32 i0 = op_lo; i0 < op_hi; i0 += 64) {
+        load_chunk(&chunk, L.tape, i0, op_hi);
+        u32 n = min(64u, op_hi - i0);
+        for (u32 k = 0; k < n; k++) {
+            H2EOp op = chunk_op(&chunk, k);
+            exec_op<FP, false>(c, op);
+        }
+    }
+    colB_flush(c, c.hiB);
+    colR_flush(c, c.hiR);
+}
+extern "C" int H2E_UNIT(h2e_engine_set_consts)(int field_pair, const H2EFieldConsts* host) {
+    if (field_pair < 0 || field_pair > 2) return -1;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fc), host, sizeof(H2EFieldConsts), (size_t)field_pair * sizeof(H2EFieldConsts),
+                                  hipMemcpyHostToDevice);
+}
+// the expansion of one launch (all its sub-ranges, or sub-ranges [launch->sub ...) of a part) in column-emission form
+extern "C" int H2E_UNIT(h2e_engine_launch)(const H2ELaunch* launch, const void* instances, uint32_t n_instances, hipStream_t stream) {
+    const u32 per_sub = n_instances * launch->n_strands;
+    if (per_sub == 0 || launch->n_ops == 0) return 0;
+    if (n_instances % 64 != 0 || !launch->col[0] || !launch->col[1] || !launch->col[2]) return -5;
+    const u32 n_sub = launch->n_sub > 1 ? launch->n_sub : 1;
+    const size_t lds = ((size_t)5 * 4 * 64 * 4 + (size_t)4 * 64 * 2) * 8 + (size_t)2 * 4 * 64 * 4;
+    H2ELaunch l = *launch;
+    l.rel_refs &= ~4u;
+#if H2E_FP_ONLY == 0
+    hipLaunchKernelGGL(h2e_run_tape_cols<FP_BN256_FQ>, dim3(per_sub / 64 * n_sub), dim3(64), lds, stream, l, (const InstanceDesc*)instances, n_instances);
+#elif H2E_FP_ONLY == 1
+    hipLaunchKernelGGL(h2e_run_tape_cols<FP_BLS_FQ>, dim3(per_sub / 64 * n_sub), dim3(64), lds, stream, l, (const InstanceDesc*)instances, n_instances);
+#else
+    hipLaunchKernelGGL(h2e_run_tape_cols<FP_BLS_FR>, dim3(per_sub / 64 * n_sub), dim3(64), lds, stream, l, (const InstanceDesc*)instances, n_instances);
+#endif
+    return (int)hipGetLastError();
+}
+#else   // everything below: the plain units only
 
 // ------------------------------------------------------------------------------------------------
 // Packed expansion: batches smaller than a wave.  h2e_run_tape's lanes are (strand, instance) of ONE sub-range, so a launch
@@ -2561,6 +2879,11 @@ __global__ void __launch_bounds__(64, H2E_CHAIN_WAVES) h2e_fixup_inverses(H2ELau
                     ainv = mont_mul<4>(M, ainv, xs[j]);
                 }
                 st_cell(rows[j] + (size_t)2 * hs, hs, out);
+                if (L.col[0] != nullptr) {   // column emission (h2e_run_columns): the witness also into the instance's base column 1
+                    u64* q = L.col[0] + (size_t)instance * L.col_stride[0] + ((size_t)L.col_rows[0] + L.fixups[i1 - 1 - j] + ob) * 4;
+                    g_st16(q, out.v[0], out.v[1]);
+                    g_st16(q + 2, out.v[2], out.v[3]);
+                }
                 if (L.dg_out != nullptr) {   // the inverse witness is a cell of the base array: (row, column 1)
                     u32 k0, k1;
                     dg_keys((L.fixups[i1 - 1 - j] + ob) * 5u + 1u, k0, k1);
@@ -4726,3 +5049,4 @@ extern "C" int h2e_engine_predict(int field_pair, int phase, const H2EPreKernel*
     }
 }
 #endif
+#endif   // !H2E_COLS_ON

@@ -178,9 +178,15 @@ struct RunFence {
     int seg = -1;
     hipEvent_t ev = nullptr;
 };
+// Column emission (h2e_run_columns): the run's expansions store halo2's per-instance advice columns themselves; the batch-interleaved
+// arrays stay the working copy operands are read from.
+struct RunColumns {
+    void* col[3] = {nullptr, nullptr, nullptr};   // [instance][col][rows][4 words] per region
+    int form = 0;
+};
 static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,
                     void* d_select, void* d_status, hipStream_t stream, bool join, int* slot_out, void* d_digests = nullptr,
-                    const RunBatches* batches = nullptr, const RunFence* fence = nullptr) {
+                    const RunBatches* batches = nullptr, const RunFence* fence = nullptr, const RunColumns* columns = nullptr) {
     if (!ctx || !p) return fail(H2E_ERR_INVALID, "null ctx/program");
     if (!batches && (!d_inputs || !d_base || !d_range || !d_select || !d_status)) return fail(H2E_ERR_INVALID, "null device pointer");
     std::lock_guard<std::mutex> guard(ctx->mu);
@@ -200,6 +206,15 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
                 HIP_TRY(hipMemcpy(ctx->d_fc[f], &field_pair(f).fc, sizeof(H2EFieldConsts), hipMemcpyHostToDevice));
                 HIP_TRY((hipError_t)h2e_engine_set_consts(f, &field_pair(f).fc));
             }
+    }
+    if (columns) {
+        if (n_instances % 64 != 0) return fail(H2E_ERR_INVALID, "h2e_run_columns: n_instances must be a multiple of 64 (a wave is 64 instances at one row)");
+        for (auto& sg : r.segments)
+            if (sg.tape_end > sg.tape_begin && sg.field_pair != 0) return fail(H2E_ERR_INVALID, "h2e_run_columns: bn256 Fq programs only (the column-emission unit of the other field pairs is not built)");
+        if (!ctx->cols_consts) {
+            HIP_TRY((hipError_t)h2e_engine_set_consts_colsfp0(0, &field_pair(0).fc));
+            ctx->cols_consts = true;
+        }
     }
     if (!ctx->expand_stream) HIP_TRY(make_stream(ctx, &ctx->expand_stream, ctx->prio_expand, 0));
     if (!ctx->fixup_stream) HIP_TRY(make_stream(ctx, &ctx->fixup_stream, ctx->prio_fixup, 2));
@@ -381,7 +396,8 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         HIP_TRY(hipEventRecord(e0, sa));
         HIP_TRY(hipStreamWaitEvent(sp, e0, 0));
         if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 2), sp)); DBG_STAMP(4 * pending_li + 2, sp);
-        int prc2 = H2E_LAUNCH((int)pending_L.field_pair, 2, &pending_L, J.d_inst, n_instances, ctx->d_fc[pending_L.field_pair], sp);
+        int prc2 = columns ? h2e_engine_launch_colsfp0(&pending_L, J.d_inst, n_instances, sp)
+                           : H2E_LAUNCH((int)pending_L.field_pair, 2, &pending_L, J.d_inst, n_instances, ctx->d_fc[pending_L.field_pair], sp);
         if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
         if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 3), sp)); DBG_STAMP(4 * pending_li + 3, sp);
         if (pending_L.n_fixups) {
@@ -545,12 +561,24 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         L.s_ext = hstore && si < p->seg_sx_begin.size() ? p->d_sext + p->seg_sx_begin[si] : nullptr;
         L.dg_out = d_digests ? J.dg_shards : nullptr;
         L.dg_shards = H2E_DG_SHARDS;
+        {
+            const uint64_t rows3[3] = {p->base_rows, p->range_rows, p->select_rows};
+            const uint64_t cols3[3] = {5, 3, 2};
+            for (int q = 0; q < 3; q++) {
+                L.col[q] = columns ? (uint64_t*)columns->col[q] : nullptr;
+                L.col_stride[q] = cols3[q] * rows3[q] * 4;
+                L.col_rows[q] = (uint32_t)rows3[q];
+            }
+            L.col_form = columns ? (uint32_t)columns->form : 0;
+        }
         L.l_steps = levels ? p->seg_l_steps[si] : 0;
         L.l_slots = levels ? p->seg_l_slots[si] : 0;
         L.l_pair = levels ? p->seg_l_pair[si] : 0;
         int lrc;
         auto launch_one = [&](int mode, const H2ELaunch& l, hipStream_t st) -> int {
-            int rc2 = H2E_LAUNCH((int)l.field_pair, mode, &l, J.d_inst, n_instances, ctx->d_fc[l.field_pair], st);
+            // (the full expansion of a column-emission run: the column unit's kernel; value chains and fix-ups are the plain ones)
+            int rc2 = (columns && mode == 2) ? h2e_engine_launch_colsfp0(&l, J.d_inst, n_instances, st)
+                                             : H2E_LAUNCH((int)l.field_pair, mode, &l, J.d_inst, n_instances, ctx->d_fc[l.field_pair], st);
             if (rc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc2));
             return 0;
         };
@@ -817,6 +845,18 @@ int h2e_run(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_in
             void* d_select, void* d_status, void* stream_) {
     if (n_instances == 0) return 0;
     return run_impl(ctx, p, n_instances, d_inputs, d_base, d_range, d_select, d_status, (hipStream_t)stream_, true, nullptr);
+}
+
+// h2e_run with halo2's advice columns coming straight out of the expansion (no h2e_export pass): see include/h2e.h
+int h2e_run_columns(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range, void* d_select,
+                    void* d_cols_base, void* d_cols_range, void* d_cols_select, int form, void* d_status, void* stream_) {
+    if (n_instances == 0) return 0;
+    if (!d_cols_base || !d_cols_range || !d_cols_select) return fail(H2E_ERR_INVALID, "null column array");
+    if (form != H2E_FORM_CANONICAL) return fail(H2E_ERR_INVALID, "h2e_run_columns: canonical cells only so far (H2E_FORM_MONTGOMERY: h2e_export)");
+    RunColumns rc;
+    rc.col[0] = d_cols_base; rc.col[1] = d_cols_range; rc.col[2] = d_cols_select;
+    rc.form = form;
+    return run_impl(ctx, p, n_instances, d_inputs, d_base, d_range, d_select, d_status, (hipStream_t)stream_, true, nullptr, nullptr, nullptr, nullptr, &rc);
 }
 
 int h2e_submit(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range,

@@ -59,6 +59,7 @@ struct h2e_ctx {
     H2EFieldConsts* d_fc[3] = {nullptr, nullptr, nullptr};
     std::map<std::string, h2e_program*> cache;
     bool profiling = false;
+    bool cols_consts = false;   // the column-emission unit has its field constants (its own constant memory)
     static constexpr int N_SLOTS = 32;
     uint32_t depth = 2;      // job slots in use = runs in flight (H2E_OPT_PIPELINE_DEPTH); each slot brings its own streams: 2 hide an MSM
                              // step's value chain, a pairing batch of a few checks wants 16 (its chains are latency-bound on one CU per check)

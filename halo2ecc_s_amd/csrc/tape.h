@@ -207,6 +207,13 @@ typedef struct H2ELaunch {
     const uint32_t* pk_order;     // device
     uint32_t pk_off[5], pk_waves[5];   // first entry / waves of table k (pk_waves[k] = 0: none - tape order)
     uint32_t pk_n_sub;            // the n_sub the tables were built for (a launch over part of the sub-ranges runs in tape order)
+    // column emission (h2e.h h2e_run_columns): halo2's advice columns straight out of the expansion.  col[region] = instance 0's
+    // per-instance column-major array [col][col_rows[region]][4 words] of the region (base, range, select), col_stride words to the
+    // next instance's; NULL = off.  The batch-interleaved arrays stay the working copy operands are read from.
+    uint64_t* col[3];
+    uint64_t col_stride[3];
+    uint32_t col_rows[3];
+    uint32_t col_form;            // 0 canonical, 1 Montgomery
 } H2ELaunch;
 enum H2EStoreKind { H2E_S_W = 1, H2E_S_LIN = 2, H2E_S_FE = 3, H2E_S_CONST = 4, H2E_S_FULL = 5 };
 // leaves that do not fit a term word (kind 3: index into H2ELaunch::s_ext): strand-strided hint / selection / input slots and

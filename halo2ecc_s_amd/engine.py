@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "h2e_run_digest", "h2e_submit_digest", "h2e_records_attach", "h2e_op_int_mul_small_constant", "h2e_op_assign_int_constant", "h2e_op_bisec_int", "h2e_op_fq", "h2e_op_pairing",
     "h2e_check", "h2e_program_tape_opcodes", "h2e_program_value_chain_kind", "h2e_program_pack_order",
     "h2e_program_launch_rows", "h2e_unit_records", "h2e_unit_record_words", "h2e_selftest_digit_rows", "h2e_last_warning", "h2e_run_batches", "h2e_submit_batches",
-    "h2e_ring_create", "h2e_ring_destroy", "h2e_ring_arrays", "h2e_ring_info", "h2e_ring_submit", "h2e_ring_submit_digest",
+    "h2e_ring_create", "h2e_ring_destroy", "h2e_ring_arrays", "h2e_ring_info", "h2e_ring_submit", "h2e_ring_submit_digest", "h2e_run_columns",
 ]
 
 
@@ -235,6 +235,7 @@ def lib():
     L.h2e_run_batches.argtypes = [vp, vp, u32, u32, pvp, pvp, pvp, pvp, pvp, vp]
     L.h2e_submit_batches.argtypes = [vp, vp, u32, u32, pvp, pvp, pvp, pvp, pvp, vp, C.POINTER(i32)]
     L.h2e_selftest_digit_rows.argtypes = [i32, u32, u32, vp, vp, vp]
+    L.h2e_run_columns.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
     L.h2e_ring_create.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
     L.h2e_ring_destroy.argtypes = [vp]
     L.h2e_ring_destroy.restype = None
@@ -672,6 +673,21 @@ class Engine:
         _check(lib().h2e_submit(self._h, program._h, n, d_inputs.data_ptr(), base.data_ptr(), rng.data_ptr(),
                                 sel.data_ptr(), status.data_ptr(), self._stream(stream).cuda_stream, C.byref(job)))
         return job.value
+
+    def alloc_columns(self, program, n_instances):
+        """zeroed per-instance column-major arrays [instances][cols][rows][4] for run_columns (zero them once: a run writes assigned cells only)"""
+        t = self.torch
+        return tuple(t.zeros((n_instances, cols, rows, 4), dtype=t.int64, device=f"cuda:{self.device}")
+                     for rows, cols in zip((program.base_rows, program.range_rows, program.select_rows), COLS))
+
+    def run_columns(self, program, d_inputs, base, rng, sel, status, columns, form=FORM_CANONICAL, stream=None):
+        """h2e_run_columns: the run's expansions store halo2's advice columns themselves (no export pass)"""
+        n = d_inputs.shape[0]
+        for a, (rows, cols) in zip(columns, zip((program.base_rows, program.range_rows, program.select_rows), COLS)):
+            assert tuple(a.shape) == (n, cols, rows, 4) and a.is_contiguous()
+        _check(lib().h2e_run_columns(self._h, program._h, n, d_inputs.data_ptr(), base.data_ptr(), rng.data_ptr(), sel.data_ptr(),
+                                     columns[0].data_ptr(), columns[1].data_ptr(), columns[2].data_ptr(), form, status.data_ptr(),
+                                     self._stream(stream).cuda_stream))
 
     def _batch_tables(self, batches):
         """batches: [(d_inputs, base, rng, sel, status), ...] of equal instance counts -> (k, n_each, five ctypes pointer tables)"""

@@ -176,6 +176,19 @@ int h2e_submit(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d
                void* d_select, void* d_status, void* stream, int* job);
 int h2e_wait(h2e_ctx* ctx, int job, void* stream);
 
+/* HALO2'S ADVICE COLUMNS STRAIGHT OUT OF THE EXPANSION (the reference's Records::_assign_to_*_chip, src/context.rs:
+ * 310-541, without a pass of its own).  h2e_run whose full expansions store every assigned cell into per-instance column-major arrays
+ * - d_cols_X = [n_instances][cols][rows][4 words], cols = 5 / 3 / 2, rows as h2e_program_shape reports, exactly what
+ * h2e_export(H2E_LAYOUT_COLUMNS) of the run's arrays would give - while d_base / d_range / d_select stay the engine's working copy (the
+ * cells ops read back are still written there; their contents after the run are NOT a witness).  The column arrays must be ZERO where the
+ * shape leaves cells unassigned: the run writes assigned cells (and zeros around them inside the rows it passes) only; zero them once,
+ * re-use them for every batch of the same program.  A wave's 64 lanes are 64 instances at one row and a column's cells reach memory as
+ * 128-byte runs of one instance (four rows staged in LDS), the rate HBM takes write requests at.
+ * n_instances: a multiple of 64; bn256-Fq programs (MSM tiles, bn256 pairing checks, integer chip over pair 0); form: H2E_FORM_CANONICAL
+ * (H2E_FORM_MONTGOMERY: h2e_export). */
+int h2e_run_columns(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range, void* d_select,
+                    void* d_cols_base, void* d_cols_range, void* d_cols_select, int form, void* d_status, void* stream);
+
 /* SEVERAL CALLER BATCHES AS ONE RUN.  n_batches (1 .. 16) batches of n_instances_each instances, every batch with its own inputs, its
  * own batch-interleaved arrays (over ITS n_instances_each instances) and its own status words - d_inputs[b], d_base[b], ... are host
  * arrays of n_batches device pointers, read before the call returns - executed as ONE run of n_batches x n_instances_each instances:

@@ -158,6 +158,11 @@ extern "C" {
     pub fn h2e_submit(ctx: *mut c_void, p: *mut c_void, n_instances: u32, d_inputs: *const c_void, d_base: *mut c_void,
                       d_range: *mut c_void, d_select: *mut c_void, d_status: *mut c_void, stream: *mut c_void, job: *mut c_int) -> c_int;
     pub fn h2e_wait(ctx: *mut c_void, job: c_int, stream: *mut c_void) -> c_int;
+    /// h2e_run whose expansion stores halo2's per-instance advice columns itself (`d_cols_*`: zeroed once, [instance][col][row][4 words]);
+    /// base / range / select stay the engine's working copy
+    pub fn h2e_run_columns(ctx: *mut c_void, p: *mut c_void, n_instances: u32, d_inputs: *const c_void, d_base: *mut c_void,
+                           d_range: *mut c_void, d_select: *mut c_void, d_cols_base: *mut c_void, d_cols_range: *mut c_void,
+                           d_cols_select: *mut c_void, form: c_int, d_status: *mut c_void, stream: *mut c_void) -> c_int;
     /// several caller batches (own inputs, arrays, status words each; `d_*` = host arrays of n_batches device pointers) as ONE run:
     /// a stream of small batches costs runs, not instances (include/h2e.h)
     pub fn h2e_run_batches(ctx: *mut c_void, p: *mut c_void, n_batches: u32, n_instances_each: u32, d_inputs: *const *const c_void,

@@ -1125,3 +1125,48 @@ def test_ring_needs_a_forked_launch_and_the_matching_depth(engine):
             Ring(engine, Program.msm_bn256_tile(4), 2, 2)
     finally:
         engine.set_option(4, old_depth)
+
+
+@pytest.mark.parametrize("what", ["int_mul", "integer_chip", "msm", "pairing"])
+def test_columns_straight_out_of_the_expansion(engine, oracle, what):
+    """h2e_run_columns: the expansion stores halo2's per-instance advice columns itself (LDS-staged 128-byte runs per instance) - the
+    arrays must equal h2e_export(H2E_LAYOUT_COLUMNS) of a plain run of the same batch bit for bit: every assigned cell, zeros everywhere
+    else (the column arrays are zeroed once and re-used: a second, different batch into the same arrays must come out right as well),
+    every status 0; and one instance against the oracle through the exported rows of the plain run (same batch)."""
+    from halo2ecc_s_amd.engine import LAYOUT_COLUMNS, FORM_CANONICAL
+    n = 64
+    if what == "int_mul":
+        prog = Program.int_mul_batch(0, 5)
+        make = lambda i: synth.int_mul_batch_inputs(0, 5, seed_index=i)   # noqa: E731
+    elif what == "integer_chip":
+        prog = Program.integer_chip_st(0)
+        make = lambda i: synth.integer_chip_st_inputs(0, seed_index=i)   # noqa: E731
+    elif what == "msm":
+        prog = Program.msm_bn256_tile(33)
+        make = lambda i: synth.msm_bn256_tile_inputs(33, tile=i)[0]   # noqa: E731
+    else:
+        prog = Program.pairing_check_bn256()
+        make = lambda i: synth.pairing_check_bn256_inputs(instance=i)   # noqa: E731
+    t = engine.torch
+    cols = engine.alloc_columns(prog, n)
+    for batch in range(2):
+        ins = [make(7000 + 100 * batch + j) for j in range(n)]
+        d_in = engine.upload_inputs(prog, np.stack(ins))
+        plain = engine.alloc(prog, n, fill=0xFF)
+        plain[3].zero_()
+        engine.run(prog, d_in, *plain)
+        t.cuda.synchronize()
+        assert (plain[3].cpu().numpy() == 0).all(), plain[3].cpu().numpy()
+        want = [engine.export(prog, region, plain[region], layout=LAYOUT_COLUMNS, form=FORM_CANONICAL) for region in range(3)]
+        t.cuda.synchronize()
+        del plain
+        work = engine.alloc(prog, n, fill=0xFF)
+        work[3].zero_()
+        engine.run_columns(prog, d_in, *work, cols)
+        t.cuda.synchronize()
+        assert (work[3].cpu().numpy() == 0).all(), work[3].cpu().numpy()
+        for region in range(3):
+            if not t.equal(cols[region], want[region]):
+                bad = (cols[region] != want[region]).any(dim=3).nonzero()
+                raise AssertionError(f"batch {batch} region {region}: {bad.shape[0]} cells differ, first (instance, col, row) {bad[:8].tolist()}")
+        del work, want
