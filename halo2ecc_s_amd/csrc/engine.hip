@@ -204,6 +204,13 @@ struct LC {  // lane context
     mutable u32 blkB = ~0u, validB = 0, hiB = 0;   // the open block (its first row), its staged cells (bit 4 col + row), rows passed
     mutable u32 blkR = ~0u, validR = 0, hiR = 0;
     mutable bool nodual = false;        // rows no op ever reads back (the mul equation's): not written to the working copy
+    u32 fj = 0, fhalf = 0;              // this lane's piece of a flushed run: row of the block, half of the cell
+    u64* fB[8];                         // ... of instance inst0 + 8 s + lane / 8: its base / range column array at that piece (col 0, row 0)
+    u64* fR[8];
+    u64* lB = nullptr;                  // ... and where the piece sits in the staging (column 0, s = 0)
+    u64* lR0 = nullptr;
+    u32* lR12 = nullptr;
+    u32 cdbg = 0;                       // timing experiments (H2E_COLS_DBG, wrong results): 1 no working-copy stores, 2 no column stores, 4 no zero fill
     mutable u64 xr[3][2 * H2E_MAX_L + 4];
 #endif
 };
@@ -334,50 +341,67 @@ WI_INLINE Fe inv_n(const LC& c, const Fe& a) { return wd_inv_mod<4>(a, n_of(c));
 #if H2E_COLS_ON
 WI_INLINE u32 uni(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
 // flush the open base block: per column with staged cells, eight store instructions of 16 bytes per lane - lane = (instance 8 s +
-// lane / 8, piece lane % 8 = row 2 bits, half 1 bit): 128 contiguous bytes per instance
-WI_INLINE void colB_flush(const LC& c, u32 hi) {
-    const u32 vb = c.validB, blk = c.blkB;
-    if (vb == 0) return;
-    const u32 lane = threadIdx.x, piece = lane & 7u, j = piece >> 1, half = piece & 1u;
-    const u32 row = blk + j;
-    const bool own = row >= c.loB && row < hi && row < c.crB;
+// lane / 8, piece lane % 8 = row 2 bits, half 1 bit): 128 contiguous bytes per instance.  Every per-lane part of the addresses (the
+// instance's array, the piece) is made once per wave (fB / fR / lB ...): per store a uniform offset is added - with the whole
+// expression per store the 64-bit multiplications made the flush 400 instructions per row and the launch ALU-bound (17 + 18 ms).
+// (called, not inlined: the emission layer has 60 call sites of the row writers, and with the 40 + 24 stores of a flush behind each
+// of them the kernel was 137 k instructions - 0.8 MB against a 64 KB instruction cache)
+struct ColFlushArgs {
+    u32 vb, blk, lo, hi, fj, fhalf, rows, cdbg;
+};
+__device__ __attribute__((noinline)) void colB_flush_fn(ColFlushArgs a, const u64* lB, u64* f0, u64* f1, u64* f2, u64* f3, u64* f4, u64* f5, u64* f6, u64* f7) {
+    u64* const f[8] = {f0, f1, f2, f3, f4, f5, f6, f7};
+    const u32 row = a.blk + a.fj;
+    const bool own = row >= a.lo && row < a.hi && !(a.cdbg & 4u);
+    const bool st_on = !(a.cdbg & 2u);
 #pragma unroll
     for (int col = 0; col < 5; col++) {
-        const u32 vm = (vb >> (4 * col)) & 15u;
+        const u32 vm = (a.vb >> (4 * col)) & 15u;
         if (vm == 0) continue;
-        const bool has = (vm >> j) & 1u;
+        const bool has = (vm >> a.fj) & 1u;
+        const size_t off = ((size_t)col * a.rows + a.blk) * 4;   // wave-uniform
 #pragma unroll
         for (int s8 = 0; s8 < 8; s8++) {
-            const u32 inst = 8u * s8 + (lane >> 3);
             u64x2 v = {0, 0};
-            if (has) v = l_ld16(c.stgB + (((size_t)(col * 4 + j) * 64 + inst) * 4 + half * 2));
-            if (has || own) g_st16(c.colB + (size_t)(c.inst0 + inst) * c.csB + ((size_t)col * c.crB + row) * 4 + half * 2, v.x, v.y);
+            if (has) v = l_ld16(lB + (size_t)(col * 4 * 64 + 8 * s8) * 4);
+            if ((has || own) && st_on) g_st16(f[s8] + off, v.x, v.y);
         }
     }
+}
+__device__ __attribute__((noinline)) void colR_flush_fn(ColFlushArgs a, const u64* lR0, const u32* lR12, u64* f0, u64* f1, u64* f2, u64* f3, u64* f4, u64* f5, u64* f6,
+                                                        u64* f7) {
+    u64* const f[8] = {f0, f1, f2, f3, f4, f5, f6, f7};
+    const u32 row = a.blk + a.fj;
+    const bool own = row >= a.lo && row < a.hi && !(a.cdbg & 4u);
+    const bool st_on = !(a.cdbg & 2u);
+#pragma unroll
+    for (int col = 0; col < 3; col++) {
+        const u32 vm = (a.vb >> (4 * col)) & 15u;
+        if (vm == 0) continue;
+        const bool has = ((vm >> a.fj) & 1u) && a.fhalf == 0;   // (range cells are below 2^128: the high half is zero)
+        const bool wr = ((vm >> a.fj) & 1u) || own;
+        const size_t off = ((size_t)col * a.rows + a.blk) * 4;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) {
+            u64x2 v = {0, 0};
+            if (has) {
+                if (col == 0) v = l_ld16(lR0 + (size_t)(8 * s8) * 2);
+                else v.x = (u64) * (const H2E_AS_LDS u32*)(lR12 + (size_t)(col - 1) * 4 * 64 + 8 * s8);
+            }
+            if (wr && st_on) g_st16(f[s8] + off, v.x, v.y);
+        }
+    }
+}
+WI_INLINE void colB_flush(const LC& c, u32 hi) {
+    if (c.validB == 0) return;
+    ColFlushArgs a = {c.validB, c.blkB, c.loB, hi, c.fj, c.fhalf, c.crB, c.cdbg};
+    colB_flush_fn(a, c.lB, c.fB[0], c.fB[1], c.fB[2], c.fB[3], c.fB[4], c.fB[5], c.fB[6], c.fB[7]);
     c.validB = 0;
 }
 WI_INLINE void colR_flush(const LC& c, u32 hi) {
-    const u32 vb = c.validR, blk = c.blkR;
-    if (vb == 0) return;
-    const u32 lane = threadIdx.x, piece = lane & 7u, j = piece >> 1, half = piece & 1u;
-    const u32 row = blk + j;
-    const bool own = row >= c.loR && row < hi && row < c.crR;
-#pragma unroll
-    for (int col = 0; col < 3; col++) {
-        const u32 vm = (vb >> (4 * col)) & 15u;
-        if (vm == 0) continue;
-        const bool has = (vm >> j) & 1u;
-#pragma unroll
-        for (int s8 = 0; s8 < 8; s8++) {
-            const u32 inst = 8u * s8 + (lane >> 3);
-            u64x2 v = {0, 0};
-            if (has && half == 0) {   // (range cells are below 2^128: the high half is zero)
-                if (col == 0) v = l_ld16(c.stgR0 + ((size_t)j * 64 + inst) * 2);
-                else v.x = (u64) * (const H2E_AS_LDS u32*)(c.stgR12 + ((size_t)(col - 1) * 4 + j) * 64 + inst);
-            }
-            if (has || own) g_st16(c.colR + (size_t)(c.inst0 + inst) * c.csR + ((size_t)col * c.crR + row) * 4 + half * 2, v.x, v.y);
-        }
-    }
+    if (c.validR == 0) return;
+    ColFlushArgs a = {c.validR, c.blkR, c.loR, hi, c.fj, c.fhalf, c.crR, c.cdbg};
+    colR_flush_fn(a, c.lR0, c.lR12, c.fR[0], c.fR[1], c.fR[2], c.fR[3], c.fR[4], c.fR[5], c.fR[6], c.fR[7]);
     c.validR = 0;
 }
 WI_INLINE void colB_open(const LC& c, u32 arow) {
@@ -425,7 +449,7 @@ WI_INLINE void rowB(const LC& c, u32 row, u32 mask, const Fe& v0, const Fe& v1, 
         if (mask & 16) colB_stage(c, 4, j, v4);
         c.validB |= ((mask & 1) ? 1u << j : 0u) | ((mask & 2) ? 16u << j : 0u) | ((mask & 4) ? 256u << j : 0u) | ((mask & 8) ? 4096u << j : 0u) |
                     ((mask & 16) ? 65536u << j : 0u);
-        if (c.nodual) return;
+        if (c.nodual || (c.cdbg & 1u)) return;
     }
 #endif
     u64* p = rowB_ptr(c, row);
@@ -938,6 +962,9 @@ WI_INLINE u32 hint_slot_of(const LC& c, const H2EOp& op) {
 }
 template <class FP>
 WI_INLINE void check_value_hint(const LC& c, const H2EOp& op, const Wd<FP::WW>& rem) {
+#if H2E_COLS_ON
+    if (c.cdbg & 8u) return;   // (timing experiment: no hint load)
+#endif
     if (op.flags & H2E_FLAG_HINTED) {
         Wd<FP::WW> h = ws_load<FP::WW>(c.hints + (size_t)hint_slot_of<FP>(c, op) * c.ws);
         if (!wd_eq<FP::WW>(h, rem)) flag(c, H2E_STATUS_ARITH);
@@ -1535,9 +1562,23 @@ __global__ void __launch_bounds__(64, 1) h2e_run_tape_cols(H2ELaunch L, const In
     c.csB = L.col_stride[0]; c.csR = L.col_stride[1]; c.csS = L.col_stride[2];
     c.crB = L.col_rows[0]; c.crR = L.col_rows[1]; c.crS = L.col_rows[2];
     c.inst0 = uni(instance - threadIdx.x);
+    c.cdbg = L.col_form >> 8;
+    {
+        const u32 lane = threadIdx.x, il = lane >> 3;
+        c.fj = (lane & 7u) >> 1;
+        c.fhalf = lane & 1u;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) {
+            c.fB[s8] = L.col[0] + (size_t)(c.inst0 + 8 * s8 + il) * L.col_stride[0] + c.fj * 4 + c.fhalf * 2;
+            c.fR[s8] = L.col[1] + (size_t)(c.inst0 + 8 * s8 + il) * L.col_stride[1] + c.fj * 4 + c.fhalf * 2;
+        }
+    }
     c.stgB = stg_dyn;
     c.stgR0 = stg_dyn + (size_t)5 * 4 * 64 * 4;
     c.stgR12 = (u32*)(c.stgR0 + (size_t)4 * 64 * 2);
+    c.lB = c.stgB + ((size_t)c.fj * 64 + (threadIdx.x >> 3)) * 4 + c.fhalf * 2;
+    c.lR0 = c.stgR0 + ((size_t)c.fj * 64 + (threadIdx.x >> 3)) * 2;
+    c.lR12 = c.stgR12 + (size_t)c.fj * 64 + (threadIdx.x >> 3);
     {
         const H2EOp* first = L.tape + op_lo;
         c.loB = uni(first->base_row + c.ob);

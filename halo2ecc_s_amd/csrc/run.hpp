@@ -570,6 +570,8 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
                 L.col_rows[q] = (uint32_t)rows3[q];
             }
             L.col_form = columns ? (uint32_t)columns->form : 0;
+            if (columns)
+                if (const char* e = getenv("H2E_COLS_DBG")) L.col_form |= (uint32_t)atoi(e) << 8;   // timing experiments of the column unit (wrong results)
         }
         L.l_steps = levels ? p->seg_l_steps[si] : 0;
         L.l_slots = levels ? p->seg_l_slots[si] : 0;
