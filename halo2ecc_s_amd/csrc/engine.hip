@@ -203,6 +203,9 @@ struct LC {  // lane context
     u32 loB = 0, loR = 0;               // first row (absolute) of the sub-range in the base / range array
     mutable u32 blkB = ~0u, validB = 0, hiB = 0;   // the open block (its first row), its staged cells (bit 4 col + row), rows passed
     mutable u32 blkR = ~0u, validR = 0, hiR = 0;
+    mutable u64 c3[4][4];               // base column 3 (the rarest: a3 of the four-term rows) is staged in registers - 32 KB + 6 KB + 2 KB of
+                                        // LDS = 40 KB let a compute unit take FOUR waves (exp/r6_occupancy.sh: +2 % against +22 % at three)
+    mutable u32 dualmask = 0x1fu;       // of the rows an op may read back, the base columns whose cells are handles (limb-wise results: column 4)
     mutable bool nodual = false;        // rows no op ever reads back (the mul equation's): not written to the working copy
     u32 fj = 0, fhalf = 0;              // this lane's piece of a flushed run: row of the block, half of the cell
     u64* fB[8];                         // ... of instance inst0 + 8 s + lane / 8: its base / range column array at that piece (col 0, row 0)
@@ -349,23 +352,31 @@ WI_INLINE u32 uni(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
 struct ColFlushArgs {
     u32 vb, blk, lo, hi, fj, fhalf, rows, cdbg;
 };
-__device__ __attribute__((noinline)) void colB_flush_fn(ColFlushArgs a, const u64* lB, u64* f0, u64* f1, u64* f2, u64* f3, u64* f4, u64* f5, u64* f6, u64* f7) {
+// only3: column 3 alone, bounced through the staging slot of column 0 (free once that column's stores have been issued)
+__device__ __attribute__((noinline)) void colB_flush_fn(ColFlushArgs a, u32 only3, const u64* lB, u64* f0, u64* f1, u64* f2, u64* f3, u64* f4, u64* f5, u64* f6,
+                                                        u64* f7) {
     u64* const f[8] = {f0, f1, f2, f3, f4, f5, f6, f7};
     const u32 row = a.blk + a.fj;
     const bool own = row >= a.lo && row < a.hi && !(a.cdbg & 4u);
     const bool st_on = !(a.cdbg & 2u);
 #pragma unroll
     for (int col = 0; col < 5; col++) {
+        if ((col == 3) != (only3 != 0)) continue;
         const u32 vm = (a.vb >> (4 * col)) & 15u;
         if (vm == 0) continue;
+        const int slot = col == 3 ? 0 : col == 4 ? 3 : col;
         const bool has = (vm >> a.fj) & 1u;
         const size_t off = ((size_t)col * a.rows + a.blk) * 4;   // wave-uniform
+        u64x2 v[8];
 #pragma unroll
-        for (int s8 = 0; s8 < 8; s8++) {
-            u64x2 v = {0, 0};
-            if (has) v = l_ld16(lB + (size_t)(col * 4 * 64 + 8 * s8) * 4);
-            if ((has || own) && st_on) g_st16(f[s8] + off, v.x, v.y);
+        for (int s8 = 0; s8 < 8; s8++) {   // (the eight LDS reads as one batch, then the eight stores)
+            v[s8].x = 0;
+            v[s8].y = 0;
+            if (has) v[s8] = l_ld16(lB + (size_t)(slot * 4 * 64 + 8 * s8) * 4);
         }
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++)
+            if ((has || own) && st_on) g_st16(f[s8] + off, v[s8].x, v[s8].y);
     }
 }
 __device__ __attribute__((noinline)) void colR_flush_fn(ColFlushArgs a, const u64* lR0, const u32* lR12, u64* f0, u64* f1, u64* f2, u64* f3, u64* f4, u64* f5, u64* f6,
@@ -395,7 +406,16 @@ __device__ __attribute__((noinline)) void colR_flush_fn(ColFlushArgs a, const u6
 WI_INLINE void colB_flush(const LC& c, u32 hi) {
     if (c.validB == 0) return;
     ColFlushArgs a = {c.validB, c.blkB, c.loB, hi, c.fj, c.fhalf, c.crB, c.cdbg};
-    colB_flush_fn(a, c.lB, c.fB[0], c.fB[1], c.fB[2], c.fB[3], c.fB[4], c.fB[5], c.fB[6], c.fB[7]);
+    if (c.validB & ~0xf000u) colB_flush_fn(a, 0, c.lB, c.fB[0], c.fB[1], c.fB[2], c.fB[3], c.fB[4], c.fB[5], c.fB[6], c.fB[7]);
+    if (c.validB & 0xf000u) {   // column 3: this lane's four rows out of its registers into column 0's slot, then the same flush
+        u64* p = c.stgB + (size_t)threadIdx.x * 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            l_st16(p + (size_t)j * 64 * 4, c.c3[j][0], c.c3[j][1]);
+            l_st16(p + (size_t)j * 64 * 4 + 2, c.c3[j][2], c.c3[j][3]);
+        }
+        colB_flush_fn(a, 1, c.lB, c.fB[0], c.fB[1], c.fB[2], c.fB[3], c.fB[4], c.fB[5], c.fB[6], c.fB[7]);
+    }
     c.validB = 0;
 }
 WI_INLINE void colR_flush(const LC& c, u32 hi) {
@@ -421,7 +441,15 @@ WI_INLINE void colR_open(const LC& c, u32 arow) {
     c.hiR = arow + 1;
 }
 WI_INLINE void colB_stage(const LC& c, int col, u32 j, const Fe& v) {
-    u64* p = c.stgB + (((size_t)(col * 4) + j) * 64 + threadIdx.x) * 4;
+    if (col == 3) {   // j is wave-uniform: a scalar branch per row of the block
+        if (j == 0) { _Pragma("unroll") for (int i = 0; i < 4; i++) c.c3[0][i] = v.v[i]; }
+        else if (j == 1) { _Pragma("unroll") for (int i = 0; i < 4; i++) c.c3[1][i] = v.v[i]; }
+        else if (j == 2) { _Pragma("unroll") for (int i = 0; i < 4; i++) c.c3[2][i] = v.v[i]; }
+        else { _Pragma("unroll") for (int i = 0; i < 4; i++) c.c3[3][i] = v.v[i]; }
+        return;
+    }
+    const int slot = col == 4 ? 3 : col;   // LDS staging: columns 0, 1, 2, 4
+    u64* p = c.stgB + (((size_t)(slot * 4) + j) * 64 + threadIdx.x) * 4;
     l_st16(p, v.v[0], v.v[1]);
     l_st16(p + 2, v.v[2], v.v[3]);
 }
@@ -450,6 +478,7 @@ WI_INLINE void rowB(const LC& c, u32 row, u32 mask, const Fe& v0, const Fe& v1, 
         c.validB |= ((mask & 1) ? 1u << j : 0u) | ((mask & 2) ? 16u << j : 0u) | ((mask & 4) ? 256u << j : 0u) | ((mask & 8) ? 4096u << j : 0u) |
                     ((mask & 16) ? 65536u << j : 0u);
         if (c.nodual || (c.cdbg & 1u)) return;
+        mask &= c.dualmask;
     }
 #endif
     u64* p = rowB_ptr(c, row);
@@ -752,7 +781,14 @@ WI_INLINE u32 emit_assigned(const LC& c, u32 brow, u32 rrow, const Limb* l, cons
     }
     emit_lead2(c, r, l[FP::L - 1]);
     r += 2;
+#if H2E_COLS_ON
+    const u32 dm_was = c.dualmask;
+    c.dualmask = 0x10u;   // (the limbs' handles are the range cells; of this row only the native is read back)
+#endif
     row_limbs<FP>(c, brow, l, native);
+#if H2E_COLS_ON
+    c.dualmask = dm_was;
+#endif
     return r - rrow;
 }
 
@@ -891,6 +927,9 @@ WI_INLINE void op_const_int(const LC& c, const H2EOp& op, bool from_input) {
 
 template <class FP>
 WI_INLINE void op_int_add(const LC& c, const H2EOp& op) {
+#if H2E_COLS_ON
+    c.dualmask = 0x10u;   // (limb-wise op: the result's handles are the column-4 cells of its rows; the other columns hold copies)
+#endif
     IntVal<FP> a = ld_int_x<FP>(c, op, 0, 0), b = ld_int_x<FP>(c, op, FP::L + 1, 1);
     u32 r = op.base_row;
     Limb s[FP::L];
@@ -902,10 +941,16 @@ WI_INLINE void op_int_add(const LC& c, const H2EOp& op) {
     Fe nat = addmod_n(c, a.native, b.native);
     row_limbs<FP>(c, r + FP::L, s, nat);
     xc_put_x<FP>(c, op, s, nat);
+#if H2E_COLS_ON
+    c.dualmask = 0x1fu;
+#endif
 }
 
 template <class FP>
 WI_INLINE void op_int_sub(const LC& c, const H2EOp& op) {
+#if H2E_COLS_ON
+    c.dualmask = 0x10u;   // (limb-wise op: the result's handles are the column-4 cells of its rows; the other columns hold copies)
+#endif
     IntVal<FP> a = ld_int_x<FP>(c, op, 0, 0), b = ld_int_x<FP>(c, op, FP::L + 1, 1);
     u32 r = op.base_row, t = op.imm;
     Limb s[FP::L];
@@ -919,10 +964,16 @@ WI_INLINE void op_int_sub(const LC& c, const H2EOp& op) {
     Fe nat = addmod_n(c, submod_n(c, a.native, b.native), un);
     row_limbs<FP>(c, r + FP::L, s, nat);
     xc_put_x<FP>(c, op, s, nat);
+#if H2E_COLS_ON
+    c.dualmask = 0x1fu;
+#endif
 }
 
 template <class FP>
 WI_INLINE void op_int_neg(const LC& c, const H2EOp& op) {
+#if H2E_COLS_ON
+    c.dualmask = 0x10u;   // (limb-wise op: the result's handles are the column-4 cells of its rows; the other columns hold copies)
+#endif
     IntVal<FP> a = ld_int_x<FP>(c, op, 0, 0);
     u32 r = op.base_row, t = op.imm;
     Limb s[FP::L];
@@ -936,10 +987,16 @@ WI_INLINE void op_int_neg(const LC& c, const H2EOp& op) {
     Fe nat = submod_n(c, un, a.native);
     row_limbs<FP>(c, r + FP::L, s, nat);
     xc_put_x<FP>(c, op, s, nat);
+#if H2E_COLS_ON
+    c.dualmask = 0x1fu;
+#endif
 }
 
 template <class FP>
 WI_INLINE void op_int_mul_small(const LC& c, const H2EOp& op) {
+#if H2E_COLS_ON
+    c.dualmask = 0x10u;   // (limb-wise op: the result's handles are the column-4 cells of its rows; the other columns hold copies)
+#endif
     IntVal<FP> a = ld_int_x<FP>(c, op, 0, 0);
     u32 r = op.base_row;
     Wd<1> k = wd_from_u64<1>(op.imm);
@@ -952,6 +1009,9 @@ WI_INLINE void op_int_mul_small(const LC& c, const H2EOp& op) {
     Fe nat = mod_n<5>(c, wd_mul<4, 1>(a.native, k));
     row_limbs<FP>(c, r + FP::L, s, nat);
     xc_put_x<FP>(c, op, s, nat);
+#if H2E_COLS_ON
+    c.dualmask = 0x1fu;
+#endif
 }
 
 // A hinted INT_MUL / REDUCE: the values-only replay took the result from the hint slot, so every later op was fed
@@ -1382,12 +1442,17 @@ WI_INLINE void exec_op(const LC& c, const H2EOp& op) {
 // trip per 64 ops instead of one per op, which matters for the latency-bound value chain - and each op is then
 // read from LDS at a uniform address and moved to SGPRs, so the opcode switch is a scalar branch and refs / rows
 // are scalar operands of the address arithmetic.
+#if H2E_COLS_ON
+#define H2E_CHUNK_OPS 32u   // (the column unit's LDS is spoken for: 2 KB of ops)
+#else
+#define H2E_CHUNK_OPS 64u
+#endif
 struct TapeChunk {
-    uint4 w[64][4];  // [op in chunk][4 x 16 bytes]
+    uint4 w[H2E_CHUNK_OPS][4];  // [op in chunk][4 x 16 bytes]
 };
 WI_INLINE void load_chunk(TapeChunk* tc, const H2EOp* tape, u32 first, u32 end) {
     u32 lane = threadIdx.x;
-    if (first + lane < end) {
+    if (lane < H2E_CHUNK_OPS && first + lane < end) {
         const uint4* src = (const uint4*)(tape + first + lane);
 #pragma unroll
         for (int k = 0; k < 4; k++) tc->w[lane][k] = src[k];
@@ -1526,7 +1591,7 @@ template <class FP>
 __global__ void __launch_bounds__(64, 1) h2e_run_tape_cols(H2ELaunch L, const InstanceDesc* inst, u32 n_instances) {
     const u32 per_sub = n_instances * L.n_strands, blocks_per_sub = per_sub / 64;
     __shared__ TapeChunk chunk;
-    extern __shared__ u64 stg_dyn[];   // base staging [5][4][64][4 words], range: [4][64][2 words], 2 x [4][64] dwords
+    extern __shared__ u64 stg_dyn[];   // base staging [4 slots: columns 0, 1, 2, 4][4][64][4 words], range: [4][64][2 words], 2 x [4][64] dwords
     const u32 blk = blockIdx.x;
     const u32 sub = blk / blocks_per_sub, idx = (blk % blocks_per_sub) * 64 + threadIdx.x;
     const u32 instance = idx % n_instances, strand = idx / n_instances;
@@ -1574,7 +1639,7 @@ __global__ void __launch_bounds__(64, 1) h2e_run_tape_cols(H2ELaunch L, const In
         }
     }
     c.stgB = stg_dyn;
-    c.stgR0 = stg_dyn + (size_t)5 * 4 * 64 * 4;
+    c.stgR0 = stg_dyn + (size_t)4 * 4 * 64 * 4;
     c.stgR12 = (u32*)(c.stgR0 + (size_t)4 * 64 * 2);
     c.lB = c.stgB + ((size_t)c.fj * 64 + (threadIdx.x >> 3)) * 4 + c.fhalf * 2;
     c.lR0 = c.stgR0 + ((size_t)c.fj * 64 + (threadIdx.x >> 3)) * 2;
@@ -1586,9 +1651,9 @@ __global__ void __launch_bounds__(64, 1) h2e_run_tape_cols(H2ELaunch L, const In
         c.hiB = c.loB;
         c.hiR = c.loR;
     }
-    for (u32 i0 = op_lo; i0 < op_hi; i0 += 64) {
+    for (u32 i0 = op_lo; i0 < op_hi; i0 += H2E_CHUNK_OPS) {
         load_chunk(&chunk, L.tape, i0, op_hi);
-        u32 n = min(64u, op_hi - i0);
+        u32 n = min(H2E_CHUNK_OPS, op_hi - i0);
         for (u32 k = 0; k < n; k++) {
             H2EOp op = chunk_op(&chunk, k);
             exec_op<FP, false>(c, op);
@@ -1608,7 +1673,7 @@ extern "C" int H2E_UNIT(h2e_engine_launch)(const H2ELaunch* launch, const void* 
     if (per_sub == 0 || launch->n_ops == 0) return 0;
     if (n_instances % 64 != 0 || !launch->col[0] || !launch->col[1] || !launch->col[2]) return -5;
     const u32 n_sub = launch->n_sub > 1 ? launch->n_sub : 1;
-    const size_t lds = ((size_t)5 * 4 * 64 * 4 + (size_t)4 * 64 * 2) * 8 + (size_t)2 * 4 * 64 * 4;
+    const size_t lds = ((size_t)4 * 4 * 64 * 4 + (size_t)4 * 64 * 2) * 8 + (size_t)2 * 4 * 64 * 4;   // 32 KB + 4 KB + 2 KB (+ 2 KB of ops): four waves per CU
     H2ELaunch l = *launch;
     l.rel_refs &= ~4u;
 #if H2E_FP_ONLY == 0
