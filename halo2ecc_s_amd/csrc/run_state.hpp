@@ -78,7 +78,11 @@ struct h2e_ctx {
     uint32_t x_parts = 3;
     uint64_t x_split_min_lanes = 1ull << 21;
     uint64_t small_x_lanes = 1u << 18;   // an expansion with fewer lanes is "small" (H2E_SMALL_X_LANES)
-    uint32_t sched = 4;      // scheduling experiments (H2E_SCHED bit mask): 1 = a pipelined run's small fix-ups go to the slot's side
+    uint32_t sched = 4;      // (bit 8, round 6: a pipelined run's held-back expansion - the MSM's candidate tables - beside the other runs' big expansions on
+                             // the small-expansion stream instead of between them: 14.65 -> 14.45 ms per step with three runs in flight, alternating in
+                             // one box - but the window launches then share the store stream and their own rate, the record's roofline figure,
+                             // falls from 0.66 to 0.59 of the roof: left off)
+                             // scheduling experiments (H2E_SCHED bit mask): 1 = a pipelined run's small fix-ups go to the slot's side
                              // stream, 2 = its small expansions too (instead of queueing on the shared expansion stream)
     int prio_expand = 0, prio_side = 0, prio_fixup = 0;   // HIP stream priorities (H2E_STREAM_PRIORITIES="x,s,f"; lower = higher priority)
     int64_t test_skip_expansion = INT64_MIN;   // test hook (h2e_ctx_set_option): see H2E_OPT_TEST_SKIP_EXPANSION

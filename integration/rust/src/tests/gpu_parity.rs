@@ -331,3 +331,117 @@ fn gpu_parity_engine_records_equal_reference() {
     assert_eq!(got.flags_sha256, want.flags_sha256);
     assert_eq!(got.permutations_sha256, want.permutations_sha256);
 }
+
+/// One case through each NAMED entry point of SURVEY.md 8(b) - `h2e_int_mul_batch`, `h2e_msm_bn256_tile`, `h2e_pairing_check_bn256`,
+/// `h2e_pairing_check_bls12_381` (include/h2e.h: program recorded and cached per shape inside the context) - on the fixtures' inputs:
+/// the 32-byte digest of every advice array the engine left on the device (`h2e_digest`) equals the crate's own `Records`' digest.
+/// UNVERIFIED source like the rest of this file (no Rust toolchain in the build image); the same four comparisons run against the
+/// C++ oracle and the pyref fixtures in the engine's `-m gpu` suite (tests/test_parity_gpu.py::test_named_entry_points,
+/// tests/test_pyref_gpu.py).
+#[test]
+#[ignore = "needs a GPU: cargo test -- --ignored"]
+fn gpu_parity_named_entry_points_equal_reference() {
+    use crate::gpu::ffi::*;
+    use std::os::raw::c_void;
+    use std::ptr::null_mut;
+    // device buffers of a run: inputs (canonical words of every slot), the three batch-interleaved arrays for ONE instance, status
+    struct Dev(*mut c_void);
+    impl Dev {
+        fn zeroed(bytes: usize) -> Dev {
+            let mut p = null_mut();
+            unsafe {
+                assert_eq!(hipMalloc(&mut p, bytes.max(16)), 0);
+                assert_eq!(hipMemset(p, 0, bytes.max(16)), 0);
+            }
+            Dev(p)
+        }
+        fn upload(words: &[u64]) -> Dev {
+            let d = Dev::zeroed(words.len() * 8);
+            unsafe { assert_eq!(hipMemcpy(d.0, words.as_ptr() as *const c_void, words.len() * 8, 1), 0) };
+            d
+        }
+        fn words(&self, n: usize) -> Vec<u64> {
+            let mut v = vec![0u64; n];
+            unsafe {
+                assert_eq!(hipDeviceSynchronize(), 0);
+                assert_eq!(hipMemcpy(v.as_mut_ptr() as *mut c_void, self.0, n * 8, 2), 0);
+            }
+            v
+        }
+    }
+    impl Drop for Dev {
+        fn drop(&mut self) {
+            unsafe { hipFree(self.0) };
+        }
+    }
+    let slot_words = |doc: &serde_json::Value| -> Vec<u64> {
+        doc["inputs_hex"].as_array().unwrap().iter().flat_map(|slot| {
+            slot.as_array().unwrap().iter().map(|w| u64::from_str_radix(w.as_str().unwrap().trim_start_matches("0x"), 16).unwrap()).collect::<Vec<_>>()
+        }).collect()
+    };
+    let mut ctx = null_mut();
+    unsafe { assert_eq!(h2e_ctx_create(0, &mut ctx), 0) };
+    // (name of the fixture, the crate's own run of the same body, program constructor for the shape, the named entry point)
+    type Named = Box<dyn Fn(*mut c_void, *const c_void, *mut c_void, *mut c_void, *mut c_void, *mut c_void) -> i32>;
+    let cases: Vec<(&str, Context<Fr>, Box<dyn Fn(*mut *mut c_void) -> i32>, Named)> = vec![
+        ("pairing_check_bn256_i1", pairing_check_bn256(&load("pairing_check_bn256_i1")),
+         Box::new(|p| unsafe { h2e_program_pairing_check_bn256(1, p) }),
+         Box::new(|c, i, b, r, s, st| unsafe { h2e_pairing_check_bn256(c, 1, i, b, r, s, st, null_mut()) })),
+        ("pairing_check_bls12_381_i1", pairing_check_bls12_381(&load("pairing_check_bls12_381_i1")),
+         Box::new(|p| unsafe { h2e_program_pairing_check_bls12_381(1, p) }),
+         Box::new(|c, i, b, r, s, st| unsafe { h2e_pairing_check_bls12_381(c, 1, i, b, r, s, st, null_mut()) })),
+        ("msm_bn256_tile_n33", msm_bn256_tile(&load("msm_bn256_tile_n33"), true),
+         Box::new(|p| unsafe { h2e_program_msm_bn256_tile(33, 1, p) }),
+         Box::new(|c, i, b, r, s, st| unsafe { h2e_msm_bn256_tile(c, 33, 1, i, b, r, s, st, null_mut()) })),
+    ];
+    for (name, reference, make, run) in cases {
+        let doc = load(name);
+        let mut prog = null_mut();
+        assert_eq!(make(&mut prog), 0, "{}", name);
+        let mut shape: h2e_shape = unsafe { std::mem::zeroed() };
+        unsafe { assert_eq!(h2e_program_shape(prog, &mut shape), 0) };
+        let d_in = Dev::upload(&slot_words(&doc));
+        let rows = [shape.base_rows as usize, shape.range_rows as usize, shape.select_rows as usize];
+        let arr: Vec<Dev> = (0..3).map(|k| Dev::zeroed(rows[k] * ADV_COLS[k] * 32)).collect();
+        let status = Dev::zeroed(4);
+        assert_eq!(run(ctx, d_in.0, arr[0].0, arr[1].0, arr[2].0, status.0), 0, "{}", name);
+        assert_eq!(status.words(1)[0] & 0xffff_ffff, 0, "{}: status word", name);
+        let want = summarize(&reference);
+        for region in 0..3 {
+            let dg = Dev::zeroed(32);
+            unsafe { assert_eq!(h2e_digest(ctx, prog, 1, region as i32, arr[region].0, dg.0, null_mut()), 0) };
+            assert_eq!(dg.words(4), want.adv_digest[region].to_vec(), "{}: advice array {}", name, region);
+        }
+        unsafe { h2e_program_destroy(prog) };
+    }
+    // h2e_int_mul_batch: n (a, b) pairs of the integer chip's fixture inputs through IntegerChipOps::int_mul on both sides
+    {
+        let doc = load("integer_chip_st_fp0");
+        let v = inputs(&doc);
+        let ctx_ref = Rc::new(RefCell::new(Context::<Fr>::new()));
+        let mut ictx = IntegerContext::<halo2_proofs::pairing::bn256::Fq, Fr>::new(ctx_ref.clone());
+        let a = ictx.assign_w(&v[0]);
+        let b = ictx.assign_w(&v[1]);
+        ictx.int_mul(&a, &b);
+        drop(ictx);
+        let reference = Rc::try_unwrap(ctx_ref).ok().unwrap().into_inner();
+        let mut prog = null_mut();
+        unsafe { assert_eq!(h2e_program_int_mul_batch(H2E_FIELD_BN256_FQ, 1, 1, &mut prog), 0) };
+        let mut shape: h2e_shape = unsafe { std::mem::zeroed() };
+        unsafe { assert_eq!(h2e_program_shape(prog, &mut shape), 0) };
+        let words: Vec<u64> = slot_words(&doc)[..2 * shape.slot_words as usize].to_vec();
+        let d_in = Dev::upload(&words);
+        let rows = [shape.base_rows as usize, shape.range_rows as usize, shape.select_rows as usize];
+        let arr: Vec<Dev> = (0..3).map(|k| Dev::zeroed(rows[k] * ADV_COLS[k] * 32)).collect();
+        let status = Dev::zeroed(4);
+        unsafe { assert_eq!(h2e_int_mul_batch(ctx, H2E_FIELD_BN256_FQ, 1, 1, d_in.0, arr[0].0, arr[1].0, arr[2].0, status.0, null_mut()), 0) };
+        let want = summarize(&reference);
+        for region in 0..2 {
+            let dg = Dev::zeroed(32);
+            unsafe { assert_eq!(h2e_digest(ctx, prog, 1, region as i32, arr[region].0, dg.0, null_mut()), 0) };
+            assert_eq!(dg.words(4), want.adv_digest[region].to_vec(), "int_mul_batch: advice array {}", region);
+        }
+        unsafe { h2e_program_destroy(prog) };
+    }
+    unsafe { h2e_ctx_destroy(ctx) };
+}
