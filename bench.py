@@ -465,13 +465,22 @@ def main():
     shared = args.shared_rows == "on" or (args.shared_rows == "auto" and args.workload == "msm" and ring >= 3)
     if shared and (G > 1 or ring < 2):
         sys.exit("bench.py: --shared-rows needs a ring of at least 2 and no --group")
-    h2e_ring = None
+    h2e_ring, bufs = None, None
     if shared:
-        from halo2ecc_s_amd import Ring
-        h2e_ring = Ring(eng, prog, units, ring)
-        bufs = None
-        ring_status = [torch.zeros((units,), dtype=torch.int32, device=dev) for _ in range(ring)]
-    else:
+        from halo2ecc_s_amd import H2EError, Ring
+        try:
+            h2e_ring = Ring(eng, prog, units, ring)
+            ring_status = [torch.zeros((units,), dtype=torch.int32, device=dev) for _ in range(ring)]
+        except H2EError as e:
+            # (the device could not map the ring's memory - somebody else on the GPU, or no virtual-memory API: two plain array sets, the
+            # schedule of rounds 2-5, rather than no measurement; --shared-rows on makes this an error)
+            if args.shared_rows == "on":
+                raise
+            print(f"bench.py: h2e_ring unavailable ({str(e).splitlines()[0][:200]}): two plain array sets", file=sys.stderr)
+            h2e_ring, shared = None, False
+            ring = min(ring, 2)
+            eng.set_option(4, ring)
+    if not shared:
         bufs = [[eng.alloc(prog, units) for _ in range(G)] for _ in range(ring)]
 
     def arrays_of(k, g=0):

@@ -44,7 +44,7 @@ def build(force=False, verbose=True):
     objs = []
     running = []
     units = ([("engine.hip", f"engine_fp{k}.o", [f"-DH2E_FP_ONLY={k}"]) for k in range(3)] + [("h2e_capi.cpp", "h2e_capi.o", [])]
-             + [("engine.hip", "engine_cols_fp0.o", ["-DH2E_FP_ONLY=0", "-DH2E_COLS"])]   # the column-emission unit (bn256 Fq)
+             + [("engine.hip", f"engine_cols_fp{k}.o", [f"-DH2E_FP_ONLY={k}", "-DH2E_COLS"]) for k in range(3)]   # the column-emission units
              + [("checker.hip", "checker.o", [])]   # the device-side constraint check: a unit of its own, no code shared with the engine
              + [("handoff.hip", "handoff.o", [])])  # field-independent hand-off kernels (unit records)
     for src, obj, defs in units:

@@ -55,9 +55,21 @@ extern "C" int h2e_engine_unit_records(const void* base, const void* status, con
                                        hipStream_t stream);   // handoff.hip
 extern "C" int h2e_engine_digest_reduce(const void* shards, uint32_t n_shards, uint32_t n_words, void* out, hipStream_t stream);
 extern "C" int h2e_engine_gate(const uint32_t* counter, uint32_t target, hipStream_t stream);
-// the column-emission unit of pair 0 (engine.hip -DH2E_COLS): the expansion that stores halo2's advice columns itself
+// the column-emission units (engine.hip -DH2E_COLS, one per field pair): the expansion that stores halo2's advice columns itself
 extern "C" int h2e_engine_set_consts_colsfp0(int field_pair, const H2EFieldConsts* host);
+extern "C" int h2e_engine_set_consts_colsfp1(int field_pair, const H2EFieldConsts* host);
+extern "C" int h2e_engine_set_consts_colsfp2(int field_pair, const H2EFieldConsts* host);
 extern "C" int h2e_engine_launch_colsfp0(const H2ELaunch* launch, const void* instances, uint32_t n_instances, hipStream_t stream);
+extern "C" int h2e_engine_launch_colsfp1(const H2ELaunch* launch, const void* instances, uint32_t n_instances, hipStream_t stream);
+extern "C" int h2e_engine_launch_colsfp2(const H2ELaunch* launch, const void* instances, uint32_t n_instances, hipStream_t stream);
+static int h2e_engine_launch_cols(const H2ELaunch* launch, const void* instances, uint32_t n_instances, hipStream_t stream) {
+    switch (launch->field_pair) {
+        case 0: return h2e_engine_launch_colsfp0(launch, instances, n_instances, stream);
+        case 1: return h2e_engine_launch_colsfp1(launch, instances, n_instances, stream);
+        case 2: return h2e_engine_launch_colsfp2(launch, instances, n_instances, stream);
+        default: return -1;
+    }
+}
 extern "C" int h2e_engine_launch(int field_pair, int mode, const H2ELaunch* launch, const void* instances,
                                  uint32_t n_instances, const H2EFieldConsts* fc_dev, hipStream_t stream);
 extern "C" int h2e_engine_predict(int field_pair, int phase, const H2EPreKernel* k, const uint32_t* args_dev, const uint32_t* params_dev,

@@ -209,10 +209,12 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
     }
     if (columns) {
         if (n_instances % 64 != 0) return fail(H2E_ERR_INVALID, "h2e_run_columns: n_instances must be a multiple of 64 (a wave is 64 instances at one row)");
-        for (auto& sg : r.segments)
-            if (sg.tape_end > sg.tape_begin && sg.field_pair != 0) return fail(H2E_ERR_INVALID, "h2e_run_columns: bn256 Fq programs only (the column-emission unit of the other field pairs is not built)");
-        if (!ctx->cols_consts) {
-            HIP_TRY((hipError_t)h2e_engine_set_consts_colsfp0(0, &field_pair(0).fc));
+        if (!ctx->cols_consts) {   // (every column unit has its own constant memory: each gets the pairs its segments may work in)
+            for (int f = 0; f < 3; f++) {
+                HIP_TRY((hipError_t)h2e_engine_set_consts_colsfp0(f, &field_pair(f).fc));
+                HIP_TRY((hipError_t)h2e_engine_set_consts_colsfp1(f, &field_pair(f).fc));
+                HIP_TRY((hipError_t)h2e_engine_set_consts_colsfp2(f, &field_pair(f).fc));
+            }
             ctx->cols_consts = true;
         }
     }
@@ -396,7 +398,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         HIP_TRY(hipEventRecord(e0, sa));
         HIP_TRY(hipStreamWaitEvent(sp, e0, 0));
         if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 2), sp)); DBG_STAMP(4 * pending_li + 2, sp);
-        int prc2 = columns ? h2e_engine_launch_colsfp0(&pending_L, J.d_inst, n_instances, sp)
+        int prc2 = columns ? h2e_engine_launch_cols(&pending_L, J.d_inst, n_instances, sp)
                            : H2E_LAUNCH((int)pending_L.field_pair, 2, &pending_L, J.d_inst, n_instances, ctx->d_fc[pending_L.field_pair], sp);
         if (prc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)prc2));
         if (profiling) HIP_TRY(hipEventRecord(prof_event(4 * pending_li + 3), sp)); DBG_STAMP(4 * pending_li + 3, sp);
@@ -579,7 +581,7 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
         int lrc;
         auto launch_one = [&](int mode, const H2ELaunch& l, hipStream_t st) -> int {
             // (the full expansion of a column-emission run: the column unit's kernel; value chains and fix-ups are the plain ones)
-            int rc2 = (columns && mode == 2) ? h2e_engine_launch_colsfp0(&l, J.d_inst, n_instances, st)
+            int rc2 = (columns && mode == 2) ? h2e_engine_launch_cols(&l, J.d_inst, n_instances, st)
                                              : H2E_LAUNCH((int)l.field_pair, mode, &l, J.d_inst, n_instances, ctx->d_fc[l.field_pair], st);
             if (rc2 != 0) return fail(H2E_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc2));
             return 0;

@@ -161,6 +161,9 @@ def lib():
     if not os.path.exists(path):
         raise H2EError(f"{path} not found: build it with `python -m halo2ecc_s_amd.build` "
                        "(hipcc, gfx950); the witness engine has no CPU fallback")
+    # torch first: it brings its own HIP runtime, and that has to be the one the process binds - with libh2e.so (linked against the
+    # system's libamdhip64) loaded before it, h2e_ctx_create found no device (round 6: smoke() touched the library before Engine())
+    import torch  # noqa: F401
     L = C.CDLL(path)
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
     L.h2e_last_error.restype = C.c_char_p

@@ -184,8 +184,9 @@ int h2e_wait(h2e_ctx* ctx, int job, void* stream);
  * shape leaves cells unassigned: the run writes assigned cells (and zeros around them inside the rows it passes) only; zero them once,
  * re-use them for every batch of the same program.  A wave's 64 lanes are 64 instances at one row and a column's cells reach memory as
  * 128-byte runs of one instance (four rows staged in LDS), the rate HBM takes write requests at.
- * n_instances: a multiple of 64; bn256-Fq programs (MSM tiles, bn256 pairing checks, integer chip over pair 0); form: H2E_FORM_CANONICAL
- * (H2E_FORM_MONTGOMERY: h2e_export). */
+ * n_instances: a multiple of 64; every program (each field pair has its column-emission unit); form: H2E_FORM_CANONICAL (H2E_FORM_MONTGOMERY:
+ * h2e_export - Montgomery cells in the first pass would need 32-byte staging for the range array as well: 18 KB more LDS per wave, two
+ * waves per compute unit instead of four). */
 int h2e_run_columns(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const void* d_inputs, void* d_base, void* d_range, void* d_select,
                     void* d_cols_base, void* d_cols_range, void* d_cols_select, int form, void* d_status, void* stream);
 

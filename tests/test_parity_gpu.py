@@ -1127,7 +1127,7 @@ def test_ring_needs_a_forked_launch_and_the_matching_depth(engine):
         engine.set_option(4, old_depth)
 
 
-@pytest.mark.parametrize("what", ["int_mul", "integer_chip", "msm", "pairing"])
+@pytest.mark.parametrize("what", ["int_mul", "integer_chip", "msm", "pairing", "integer_chip_bls_fr", "msm_bls12_381", "pairing_bls12_381"])
 def test_columns_straight_out_of_the_expansion(engine, oracle, what):
     """h2e_run_columns: the expansion stores halo2's per-instance advice columns itself (LDS-staged 128-byte runs per instance) - the
     arrays must equal h2e_export(H2E_LAYOUT_COLUMNS) of a plain run of the same batch bit for bit: every assigned cell, zeros everywhere
@@ -1144,6 +1144,15 @@ def test_columns_straight_out_of_the_expansion(engine, oracle, what):
     elif what == "msm":
         prog = Program.msm_bn256_tile(33)
         make = lambda i: synth.msm_bn256_tile_inputs(33, tile=i)[0]   # noqa: E731
+    elif what == "integer_chip_bls_fr":   # (3-limb bls12_381 Fr over bn256 Fr: the third field pair's unit)
+        prog = Program.integer_chip_st(2)
+        make = lambda i: synth.integer_chip_st_inputs(2, seed_index=i)   # noqa: E731
+    elif what == "msm_bls12_381":         # (a general-scalar tile: 4-limb bls12_381 Fq segments and 3-limb Fr segments in one program)
+        prog = Program.msm_bls12_381_tile(7)
+        make = lambda i: synth.msm_bls12_381_tile_inputs(7, tile=i)[0]   # noqa: E731
+    elif what == "pairing_bls12_381":
+        prog = Program.pairing_check_bls12_381()
+        make = lambda i: synth.pairing_check_bls12_381_inputs(instance=i)   # noqa: E731
     else:
         prog = Program.pairing_check_bn256()
         make = lambda i: synth.pairing_check_bn256_inputs(instance=i)   # noqa: E731
