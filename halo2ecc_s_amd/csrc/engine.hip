@@ -213,7 +213,6 @@ struct LC {  // lane context
     u64* lB = nullptr;                  // ... and where the piece sits in the staging (column 0, s = 0)
     u64* lR0 = nullptr;
     u32* lR12 = nullptr;
-    u32 cdbg = 0;                       // timing experiments (H2E_COLS_DBG, wrong results): 1 no working-copy stores, 2 no column stores, 4 no zero fill
     mutable u64 xr[3][2 * H2E_MAX_L + 4];
 #endif
 };
@@ -350,15 +349,15 @@ WI_INLINE u32 uni(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
 // (called, not inlined: the emission layer has 60 call sites of the row writers, and with the 40 + 24 stores of a flush behind each
 // of them the kernel was 137 k instructions - 0.8 MB against a 64 KB instruction cache)
 struct ColFlushArgs {
-    u32 vb, blk, lo, hi, fj, fhalf, rows, cdbg;
+    u32 vb, blk, lo, hi, fj, fhalf, rows;
 };
 // only3: column 3 alone, bounced through the staging slot of column 0 (free once that column's stores have been issued)
 __device__ __attribute__((noinline)) void colB_flush_fn(ColFlushArgs a, u32 only3, const u64* lB, u64* f0, u64* f1, u64* f2, u64* f3, u64* f4, u64* f5, u64* f6,
                                                         u64* f7) {
     u64* const f[8] = {f0, f1, f2, f3, f4, f5, f6, f7};
     const u32 row = a.blk + a.fj;
-    const bool own = row >= a.lo && row < a.hi && !(a.cdbg & 4u);
-    const bool st_on = !(a.cdbg & 2u);
+    const bool own = row >= a.lo && row < a.hi;
+    const bool st_on = true;
 #pragma unroll
     for (int col = 0; col < 5; col++) {
         if ((col == 3) != (only3 != 0)) continue;
@@ -383,8 +382,8 @@ __device__ __attribute__((noinline)) void colR_flush_fn(ColFlushArgs a, const u6
                                                         u64* f7) {
     u64* const f[8] = {f0, f1, f2, f3, f4, f5, f6, f7};
     const u32 row = a.blk + a.fj;
-    const bool own = row >= a.lo && row < a.hi && !(a.cdbg & 4u);
-    const bool st_on = !(a.cdbg & 2u);
+    const bool own = row >= a.lo && row < a.hi;
+    const bool st_on = true;
 #pragma unroll
     for (int col = 0; col < 3; col++) {
         const u32 vm = (a.vb >> (4 * col)) & 15u;
@@ -405,7 +404,7 @@ __device__ __attribute__((noinline)) void colR_flush_fn(ColFlushArgs a, const u6
 }
 WI_INLINE void colB_flush(const LC& c, u32 hi) {
     if (c.validB == 0) return;
-    ColFlushArgs a = {c.validB, c.blkB, c.loB, hi, c.fj, c.fhalf, c.crB, c.cdbg};
+    ColFlushArgs a = {c.validB, c.blkB, c.loB, hi, c.fj, c.fhalf, c.crB};
     if (c.validB & ~0xf000u) colB_flush_fn(a, 0, c.lB, c.fB[0], c.fB[1], c.fB[2], c.fB[3], c.fB[4], c.fB[5], c.fB[6], c.fB[7]);
     if (c.validB & 0xf000u) {   // column 3: this lane's four rows out of its registers into column 0's slot, then the same flush
         u64* p = c.stgB + (size_t)threadIdx.x * 4;
@@ -420,7 +419,7 @@ WI_INLINE void colB_flush(const LC& c, u32 hi) {
 }
 WI_INLINE void colR_flush(const LC& c, u32 hi) {
     if (c.validR == 0) return;
-    ColFlushArgs a = {c.validR, c.blkR, c.loR, hi, c.fj, c.fhalf, c.crR, c.cdbg};
+    ColFlushArgs a = {c.validR, c.blkR, c.loR, hi, c.fj, c.fhalf, c.crR};
     colR_flush_fn(a, c.lR0, c.lR12, c.fR[0], c.fR[1], c.fR[2], c.fR[3], c.fR[4], c.fR[5], c.fR[6], c.fR[7]);
     c.validR = 0;
 }
@@ -477,7 +476,7 @@ WI_INLINE void rowB(const LC& c, u32 row, u32 mask, const Fe& v0, const Fe& v1, 
         if (mask & 16) colB_stage(c, 4, j, v4);
         c.validB |= ((mask & 1) ? 1u << j : 0u) | ((mask & 2) ? 16u << j : 0u) | ((mask & 4) ? 256u << j : 0u) | ((mask & 8) ? 4096u << j : 0u) |
                     ((mask & 16) ? 65536u << j : 0u);
-        if (c.nodual || (c.cdbg & 1u)) return;
+        if (c.nodual) return;
         mask &= c.dualmask;
     }
 #endif
@@ -1022,9 +1021,6 @@ WI_INLINE u32 hint_slot_of(const LC& c, const H2EOp& op) {
 }
 template <class FP>
 WI_INLINE void check_value_hint(const LC& c, const H2EOp& op, const Wd<FP::WW>& rem) {
-#if H2E_COLS_ON
-    if (c.cdbg & 8u) return;   // (timing experiment: no hint load)
-#endif
     if (op.flags & H2E_FLAG_HINTED) {
         Wd<FP::WW> h = ws_load<FP::WW>(c.hints + (size_t)hint_slot_of<FP>(c, op) * c.ws);
         if (!wd_eq<FP::WW>(h, rem)) flag(c, H2E_STATUS_ARITH);
@@ -1627,7 +1623,6 @@ __global__ void __launch_bounds__(64, 1) h2e_run_tape_cols(H2ELaunch L, const In
     c.csB = L.col_stride[0]; c.csR = L.col_stride[1]; c.csS = L.col_stride[2];
     c.crB = L.col_rows[0]; c.crR = L.col_rows[1]; c.crS = L.col_rows[2];
     c.inst0 = uni(instance - threadIdx.x);
-    c.cdbg = L.col_form >> 8;
     {
         const u32 lane = threadIdx.x, il = lane >> 3;
         c.fj = (lane & 7u) >> 1;

@@ -572,8 +572,10 @@ static int run_impl(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, const vo
                 L.col_rows[q] = (uint32_t)rows3[q];
             }
             L.col_form = columns ? (uint32_t)columns->form : 0;
-            if (columns)
-                if (const char* e = getenv("H2E_COLS_DBG")) L.col_form |= (uint32_t)atoi(e) << 8;   // timing experiments of the column unit (wrong results)
+#ifdef H2E_DEBUG_HOOKS
+            if (columns)   // timing experiments of the column unit (exp/r6_cols_dbg.sh: an engine built with exp/engine_experiments.patch reads bits 8..)
+                if (const char* e = dbg_env("H2E_COLS_DBG")) L.col_form |= (uint32_t)atoi(e) << 8;
+#endif
         }
         L.l_steps = levels ? p->seg_l_steps[si] : 0;
         L.l_slots = levels ? p->seg_l_slots[si] : 0;
