@@ -25,6 +25,8 @@ struct h2e_ring {
         uint64_t row0 = 0, row1 = 0;                 // the big launch's rows
     } arr[3];
     std::vector<int> jobs;                           // job of run k mod depth
+    std::vector<hipEvent_t> released;                // [depth]: recorded by h2e_ring_release(k) on the consumer's stream
+    std::vector<uint64_t> released_k;                // ... for which run (~0: none)
     uint64_t next = 0;
     size_t gran = 0;
 };
@@ -33,6 +35,8 @@ static void ring_free(h2e_ring* r) {
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
     (void)hipDeviceSynchronize();
+    for (hipEvent_t e : r->released)
+        if (e) (void)hipEventDestroy(e);
     for (auto& a : r->arr) {
         for (void* va : a.va)
             if (va) {
@@ -75,6 +79,8 @@ int h2e_ring_create(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, uint32_t
     r->n_virtual = depth % 2 == 0 ? depth : 2 * depth;
     r->big_seg = big; r->big_launch = launch;
     r->jobs.assign(depth, -1);
+    r->released.assign(depth, nullptr);
+    r->released_k.assign(depth, ~0ull);
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
@@ -181,8 +187,17 @@ static int ring_submit(h2e_ring* r, uint64_t k, const void* d_inputs, void* d_st
         // not re-used before run k - 2 + depth > k)
         if (k >= 2 && r->jobs[(k - 2) % r->depth] >= 0) {
             fence.seg = r->big_seg;
-            fence.ev = ctx->slots[r->jobs[(k - 2) % r->depth]].done;
+            // ... or, when the consumer of run k - 2 said where its reads end (h2e_ring_release), that point of ITS stream - which lies
+            // behind the run's completion (the consumer waited for it with h2e_wait)
+            const uint32_t q = (uint32_t)((k - 2) % r->depth);
+            fence.ev = r->released_k[q] == k - 2 ? r->released[q] : ctx->slots[r->jobs[q]].done;
         }
+    }
+    // the other rows of set k were run k - depth's: if its consumer said where its reads end, this run starts behind that point
+    // (otherwise the caller orders the re-use through the submission stream, as with h2e_submit)
+    if (k >= r->depth && r->released_k[k % r->depth] == k - r->depth) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream_, r->released[k % r->depth], 0));
     }
     void *b, *g, *s;
     h2e_ring_arrays(r, k, &b, &g, &s);
@@ -191,6 +206,19 @@ static int ring_submit(h2e_ring* r, uint64_t k, const void* d_inputs, void* d_st
     if (rc) return rc;
     r->jobs[k % r->depth] = *job;
     r->next = k + 1;
+    return 0;
+}
+// The consumer of run k is done with the run's arrays at this point of `stream`: run k + 2, which writes the same physical rows of the
+// shared launch, waits for it (instead of for run k's completion alone).  Call it before h2e_ring_submit(k + 2).
+int h2e_ring_release(h2e_ring* r, uint64_t k, void* stream) {
+    if (!r) return fail(H2E_ERR_INVALID, "null ring");
+    if (k >= r->next) return fail(H2E_ERR_INVALID, "h2e_ring_release: run k has not been submitted");
+    if (k + 2 < r->next) return fail(H2E_ERR_INVALID, "h2e_ring_release: run k + 2 has been submitted already");
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    const uint32_t q = (uint32_t)(k % r->depth);
+    if (!r->released[q]) HIP_TRY(hipEventCreateWithFlags(&r->released[q], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(r->released[q], (hipStream_t)stream));
+    r->released_k[q] = k;
     return 0;
 }
 int h2e_ring_submit(h2e_ring* r, uint64_t k, const void* d_inputs, void* d_status, void* stream, int* job) {

@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "h2e_run_digest", "h2e_submit_digest", "h2e_records_attach", "h2e_op_int_mul_small_constant", "h2e_op_assign_int_constant", "h2e_op_bisec_int", "h2e_op_fq", "h2e_op_pairing",
     "h2e_check", "h2e_program_tape_opcodes", "h2e_program_value_chain_kind", "h2e_program_pack_order",
     "h2e_program_launch_rows", "h2e_unit_records", "h2e_unit_record_words", "h2e_selftest_digit_rows", "h2e_last_warning", "h2e_run_batches", "h2e_submit_batches",
-    "h2e_ring_create", "h2e_ring_destroy", "h2e_ring_arrays", "h2e_ring_info", "h2e_ring_submit", "h2e_ring_submit_digest", "h2e_run_columns",
+    "h2e_ring_create", "h2e_ring_destroy", "h2e_ring_arrays", "h2e_ring_info", "h2e_ring_submit", "h2e_ring_submit_digest", "h2e_run_columns", "h2e_ring_release",
 ]
 
 
@@ -94,6 +94,10 @@ class Ring:
             assert tuple(digests.shape) == (3, self.n, 4) and digests.is_contiguous()
             _check(lib().h2e_ring_submit_digest(self._h, k, d_inputs.data_ptr(), status.data_ptr(), digests.data_ptr(), st, C.byref(job)))
         return job.value
+
+    def release(self, k, stream=None):
+        """h2e_ring_release: the consumer's reads of run k end at this point of `stream` (run k + 2 waits for it)"""
+        _check(lib().h2e_ring_release(self._h, k, self.engine._stream(stream).cuda_stream))
 
     def close(self):
         if self._h:
@@ -244,6 +248,7 @@ def lib():
     L.h2e_ring_destroy.restype = None
     L.h2e_ring_arrays.argtypes = [vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.h2e_ring_info.argtypes = [vp, C.POINTER(C.c_uint64), u32]
+    L.h2e_ring_release.argtypes = [vp, C.c_uint64, vp]
     L.h2e_ring_submit.argtypes = [vp, C.c_uint64, vp, vp, vp, C.POINTER(i32)]
     L.h2e_ring_submit_digest.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, C.POINTER(i32)]
     L.h2e_run_digest.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]

@@ -212,9 +212,15 @@ int h2e_submit_batches(h2e_ctx* ctx, h2e_program* p, uint32_t n_batches, uint32_
  * whatever of run k writes the big launch's rows waits for the completion of run k - 2.  depth 3: three runs in flight in 2.2 sets.
  *   - set H2E_OPT_PIPELINE_DEPTH = depth first; submit the ring's runs in order (k = 0, 1, 2, ...) and nothing else on the context meanwhile;
  *   - h2e_ring_arrays(k) are run k's arrays for the consumer's calls (h2e_export, h2e_digest, h2e_unit_records, h2e_check): ordinary
- *     batch-interleaved arrays.  The rows of the big launch (h2e_ring_info: launch index; h2e_program_launch_rows) are valid from the
- *     completion of run k until run k + 2 is SUBMITTED; every other row until run k + depth is.  A consumer that needs the big launch's
- *     rows longer takes them through the stream digest (h2e_ring_submit_digest) or uses plain array sets with h2e_submit;
+ *     batch-interleaved arrays.  Run k + 2 writes the rows of the big launch (h2e_ring_info: launch index; h2e_program_launch_rows) of
+ *     the same physical memory; all other rows are run k + depth's.  What orders the two: by default run k + 2's writers of those rows
+ *     wait for run k's COMPLETION - enough for a consumer that takes the shared rows through the stream digest (h2e_ring_submit_digest)
+ *     or not at all (status words, unit records: the result cells lie outside the shared launch).  A consumer that READS them after
+ *     the run (export, h2e_digest, h2e_check) says where its reads end: h2e_ring_release(ring, k, consumer_stream), called before
+ *     h2e_ring_submit(k + 2) - run k + 2's writers of the shared rows, and run k + depth as a whole, then wait for that point of the
+ *     consumer's stream.  Submit on ANOTHER stream than the
+ *     consumer's (a run starts behind what its submission stream holds: on the consumer's stream it would start behind run k's
+ *     completion and two runs would be in flight, not three);
  *   - h2e_wait(job) as for h2e_submit.  Errors: H2E_ERR_HIP if the device cannot map the memory (no fallback: use h2e_submit). */
 typedef struct h2e_ring h2e_ring;
 int h2e_ring_create(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, uint32_t depth, h2e_ring** out);
@@ -223,6 +229,7 @@ int h2e_ring_arrays(const h2e_ring* ring, uint64_t k, void** d_base, void** d_ra
 /* out[0..2] = bytes of a full array set (base, range, select), [3..5] = of each, the bytes the two shared copies back, [6] = physical
  * bytes of the ring, [7] = the shared launch (index in h2e_program_launches), [8] = virtual array sets, [9] = depth.  Returns 10. */
 int h2e_ring_info(const h2e_ring* ring, uint64_t* out, uint32_t cap);
+int h2e_ring_release(h2e_ring* ring, uint64_t k, void* stream);
 int h2e_ring_submit(h2e_ring* ring, uint64_t k, const void* d_inputs, void* d_status, void* stream, int* job);
 int h2e_ring_submit_digest(h2e_ring* ring, uint64_t k, const void* d_inputs, void* d_status, void* d_digests, void* stream, int* job);
 

@@ -203,6 +203,8 @@ extern "C" {
     pub fn h2e_ring_destroy(ring: *mut c_void);
     pub fn h2e_ring_arrays(ring: *const c_void, k: u64, d_base: *mut *mut c_void, d_range: *mut *mut c_void, d_select: *mut *mut c_void) -> c_int;
     pub fn h2e_ring_info(ring: *const c_void, out: *mut u64, cap: u32) -> c_int;
+    /// the consumer's reads of run k end at this point of `stream`: run k + 2 (same physical rows of the shared launch) waits for it
+    pub fn h2e_ring_release(ring: *mut c_void, k: u64, stream: *mut c_void) -> c_int;
     pub fn h2e_ring_submit(ring: *mut c_void, k: u64, d_inputs: *const c_void, d_status: *mut c_void, stream: *mut c_void, job: *mut c_int) -> c_int;
     pub fn h2e_ring_submit_digest(ring: *mut c_void, k: u64, d_inputs: *const c_void, d_status: *mut c_void, d_digests: *mut c_void,
                                   stream: *mut c_void, job: *mut c_int) -> c_int;

@@ -1179,3 +1179,63 @@ def test_columns_straight_out_of_the_expansion(engine, oracle, what):
                 bad = (cols[region] != want[region]).any(dim=3).nonzero()
                 raise AssertionError(f"batch {batch} region {region}: {bad.shape[0]} cells differ, first (instance, col, row) {bad[:8].tolist()}")
         del work, want
+
+
+def test_ring_with_a_consumer_that_reads_the_shared_rows(engine, oracle):
+    """h2e_ring_release: a consumer that READS every array of a finished run (h2e_digest - the same reads an export makes) while three
+    runs are in flight: it works on its own stream (`h2e_wait` + digests + release there), the submissions go out on another, and run
+    k + 2 - the next writer of the shared launch's physical rows - waits for the point where run k's reads end.  Ten runs of different
+    batches: every run's post-run digests of all three arrays equal the same batch's through h2e_run into plain arrays."""
+    from halo2ecc_s_amd import Ring
+    prog = Program.msm_bn256_tile(33)
+    t = engine.torch
+    n_inst, depth, n_runs, n_batches = 64, 3, 10, 4
+    ins = [[synth.msm_bn256_tile_inputs(33, tile=9000 + 70 * b + j)[0] for j in range(n_inst)] for b in range(n_batches)]
+    d_in = [engine.upload_inputs(prog, np.stack(x)) for x in ins]
+    want = []
+    ref = engine.alloc(prog, n_inst, fill=0xFF)
+    for b in range(n_batches):
+        ref[3].zero_()
+        engine.run(prog, d_in[b], *ref)
+        t.cuda.synchronize()
+        assert (ref[3].cpu().numpy() == 0).all()
+        want.append([engine.digest(prog, region, ref[region]).cpu().numpy() for region in range(3)])
+    del ref
+    old_depth = engine.get_stat(3)
+    engine.set_option(4, depth)
+    ring = None
+    try:
+        ring = Ring(engine, prog, n_inst, depth)
+        for v in range(ring.info["virtual_sets"]):
+            for a in ring.arrays(v):
+                a.fill_(-1)
+        status = [t.zeros((n_inst,), dtype=t.int32, device="cuda") for _ in range(n_runs)]   # (one per run: nothing of the test's own to order)
+        submit_s, consume_s = t.cuda.Stream(), t.cuda.Stream()
+        t.cuda.synchronize()
+        got, jobs = {}, {}
+
+        def consume(k0):
+            engine.wait(jobs[k0], stream=consume_s)
+            arrs = ring.arrays(k0)
+            got[k0] = ([engine.digest(prog, region, arrs[region], stream=consume_s) for region in range(3)], None)
+            with t.cuda.stream(consume_s):
+                got[k0] = (got[k0][0], status[k0].clone())
+            ring.release(k0, stream=consume_s)
+
+        for k in range(n_runs):
+            if k >= 2:
+                consume(k - 2)          # enqueued on the consumer's stream: the host does not wait, the submission stream knows nothing of it
+            jobs[k] = ring.submit(k, d_in[k % n_batches], status[k], stream=submit_s)
+        consume(n_runs - 2)
+        consume(n_runs - 1)
+        t.cuda.synchronize()
+        for k in range(n_runs):
+            dg, st = got[k]
+            assert (st.cpu().numpy() == 0).all(), (k, st.cpu().numpy())
+            for region in range(3):
+                assert np.array_equal(dg[region].cpu().numpy(), want[k % n_batches][region]), (k, region)
+    finally:
+        t.cuda.synchronize()
+        if ring is not None:
+            ring.close()
+        engine.set_option(4, old_depth)
