@@ -86,7 +86,10 @@ int h2e_ring_create(h2e_ctx* ctx, h2e_program* p, uint32_t n_instances, uint32_t
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = ctx->device;
     HIP_TRY(hipMemGetAllocationGranularity(&r->gran, &prop, hipMemAllocationGranularityRecommended));
-    const size_t g = std::max<size_t>(r->gran, 4096);
+    // Pieces meet at 2 MB boundaries, whatever the (4 KB) mapping granularity: the GPU's page tables describe contiguous virtual ranges by
+    // fragments of up to 2 MB, and a shared piece that begins inside such a range was seen - once in five runs of the small test shapes,
+    // never at 64 instances - to read through the neighbouring piece (a cell written through set 0 not visible through set 2).
+    const size_t g = std::max<size_t>(r->gran, (size_t)2 << 20);
     hipMemAccessDesc acc = {};
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;

@@ -1058,21 +1058,23 @@ def test_ring_three_runs_in_flight_share_the_big_launch_rows(engine, oracle, wha
         assert info["depth"] == depth and info["virtual_sets"] == (depth if depth % 2 == 0 else 2 * depth)
         full = sum(info["set_bytes"])
         assert info["physical_bytes"] == 2 * sum(info["shared_bytes"]) + depth * (full - sum(info["shared_bytes"])) < depth * full
-        if what == "msm":
-            assert sum(info["shared_bytes"]) > 0.5 * full       # the window strands own most rows
+        if what == "msm" and n_inst == 64:
+            assert sum(info["shared_bytes"]) > 0.5 * full       # the window strands own most rows (pieces meet at 2 MB boundaries: small shapes share less)
         rows = prog.launch_rows(info["shared_launch"])
-        # the aliasing: a cell of the shared launch written through set 0 reads back through set 2 (and not through set 1); a cell
-        # outside it does not
         a0, a1, a2 = ring.arrays(0)[0], ring.arrays(1)[0], ring.arrays(2)[0]
-        r_in, r_out = int(rows[0]) + 10, 0
-        for a in (a0, a1, a2):
-            a[r_in].zero_()
-            a[r_out].zero_()
-        a0[r_in] += 7
-        a0[r_out] += 9
-        t.cuda.synchronize()
-        assert int(a2[r_in].flatten()[0]) == 7 and int(a1[r_in].flatten()[0]) == 0
-        assert int(a2[r_out].flatten()[0]) == 0 and int(a1[r_out].flatten()[0]) == 0
+        if info["shared_bytes"][0] > 0:
+            # the aliasing: a cell of the shared launch written through set 0 reads back through set 2 (and not through set 1); a cell
+            # outside it does not (a row 2 MB into the launch's rows: inside the shared piece wherever its boundary was rounded to)
+            row_bytes = 5 * 32 * n_inst
+            r_in, r_out = int(rows[0]) + (2 << 20) // row_bytes + 1, 0
+            for a in (a0, a1, a2):
+                a[r_in].zero_()
+                a[r_out].zero_()
+            a0[r_in] += 7
+            a0[r_out] += 9
+            t.cuda.synchronize()
+            assert int(a2[r_in].flatten()[0]) == 7 and int(a1[r_in].flatten()[0]) == 0
+            assert int(a2[r_out].flatten()[0]) == 0 and int(a1[r_out].flatten()[0]) == 0
         for v in range(info["virtual_sets"]):
             for a in ring.arrays(v):
                 a.fill_(-1)                              # poison: only assigned cells may change
