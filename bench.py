@@ -433,13 +433,17 @@ def main():
         make = lambda shape: Program.pairing_check_bn256(emit_shape=shape)   # noqa: E731
     else:
         make = lambda shape: Program.pairing_check_bls12_381(emit_shape=shape)   # noqa: E731
+    t_build = time.perf_counter()
     shape_prog = make(True)  # shape-only artefacts, once per shape (not timed)
+    program_build_s = {"with_shape": round(time.perf_counter() - t_build, 3)}   # host side: record the circuit, compile its value chain
     cells_per_unit = shape_prog.n_advice_cells
     launches = shape_prog.launches()
     if args.consumer_ready > 0:   # (the export masks with the shape's flags and does not read the cells they leave out)
         prog = shape_prog
     else:
+        t_build = time.perf_counter()
         prog = make(False)
+        program_build_s["without_shape"] = round(time.perf_counter() - t_build, 3)
         shape_prog.close()
     # the launch with the most cells (MSM: the window strands; pairing: the whole check)
     dom = max(range(len(launches)), key=lambda i: launches[i]["cells"])
@@ -833,6 +837,7 @@ def main():
         out["msm_points_per_sec"] = n * T * args.steps / elapsed
         out["config"].update(tiles_per_gpu=units, points_per_tile=n, cells_per_tile=cells_per_unit,
                              points_note="per-tile-batch rate; the test body's assign_point / assign rows are part of every tile")
+    out["program_build_s"] = program_build_s   # (untimed, once per shape and process: detail file only)
     if args.digest:
         out["config"]["consumer"] = ("stream digest of the three advice arrays of every step (h2e_submit_digest: 32 B per array and unit, accumulated by the "
                                      "expansion while it stores), inside the timed region")

@@ -1338,7 +1338,8 @@ struct StoreCompiler {
             if (o[q].is_int) prod[q] = fcmp->int_producer(op.refs[o[q].refpos]);
         // the integer operand q as a combination: a result of this segment, or - a context cut into several segments - an integer of
         // an earlier one, read from its CELLS (below)
-        auto operand = [&](int q) -> Lin {
+        Lin imported[3];
+        auto operand = [&](int q) -> const Lin& {   // (a reference: copying an operand's map per use was most of a pairing shape's 3.6 s of compile time)
             if (prod[q] >= 0) return flatten(out, (uint32_t)prod[q]);
             // an integer of an earlier segment of the same context: read as its cells hold it (that segment's own store - or its
             // expansion's inputs before it - put them in place before this segment's value chain starts).  Not through a hint slot:
@@ -1358,7 +1359,8 @@ struct StoreCompiler {
                 out.ext_index[e] = idx;
             }
             if (idx >= (1u << 22)) throw std::runtime_error("hint store: leaf index out of range");
-            Lin x;
+            Lin& x = imported[q];
+            x.leaf.clear();
             x.leaf[(3u << 30) | idx] = 1;
             return x;
         };
@@ -1395,7 +1397,16 @@ struct StoreCompiler {
         return lin[p];
     }
     std::map<std::vector<uint64_t>, uint32_t> k_index;
+    std::map<std::map<uint32_t, int>, uint32_t> k_memo;   // the ceil multiplicities of a combination -> its K table entry (a few dozen
+                                                          // distinct ones per segment; the big-number arithmetic below once for each)
     uint32_t k_of(HintStore& out, const Lin& e) {
+        auto memo = k_memo.find(e.ceil);
+        if (memo != k_memo.end()) return memo->second;
+        uint32_t idx = k_build(out, e);
+        k_memo[e.ceil] = idx;
+        return idx;
+    }
+    uint32_t k_build(HintStore& out, const Lin& e) {
         // K = sum mult_t * C_t: limbs modulo 2^128 (the true limb values are non-negative and below 2^128), native modulo n
         std::vector<uint64_t> k((size_t)2 * L + 4, 0);
         for (int i = 0; i < L; i++) {

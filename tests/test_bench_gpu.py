@@ -68,6 +68,8 @@ def test_bench_streaming_job_digest_and_records():
 def test_bench_small_pairing(workload):
     d, full = _bench("--workload", workload, "--units", "2", "--steps", "3", "--warmup", "1", "--ring", "2", "--traffic", "off", "--no-cpu-baseline")
     _check_contract(d, 1, 3, 1)
+    b = full["program_build_s"]   # host side, once per shape: recording + value-chain compilation (detail file only)
+    assert "program_build_s" not in d and 0 < b["without_shape"] < 30 and 0 < b["with_shape"] < 30
 
 
 @pytest.mark.parametrize("workload", ["pairing_bn256", "pairing_bls12_381"])
