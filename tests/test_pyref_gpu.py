@@ -6,7 +6,12 @@ oracle, whose L4 text the recorder's tower / pairing ops resemble (w
 engine arrays in HBM -> h2e_digest (include/h2e.h: the position-keyed 32-byte digest of every assigned cell of an array)
 == the fixture's `adv_digest`, for both pairing checks, pairing() == expected, the MSM tiles (select chip, no select chip,
 bls12_381 with general scalars, BASELINE's 1024-point tile) and the integer chip on the three field pairs.  Offsets, heights,
-cell and permutation counts and the permutation list itself are compared with the fixture as well.  Nothing here loads oracle/."""
+cell and permutation counts and the permutation list itself are compared with the fixture as well.  Nothing here loads oracle/.
+
+What the digest covers: the cells the RECORDER's own flag arrays mark as assigned (h2e_digest masks with the program's flags).  Those
+flags themselves are pinned to the Python restatement on the CPU side - tests/test_pyref_cpu.py compares the recorder's assigned /
+flags (SHA-256 per region), offsets, heights, cell count and permutation list with the same fixtures (`assert_recorder_matches`) - so a cell the recorder wrongly left unflagged would fail there (and its
+count here: `n_advice_cells` is compared with the fixture's), not silently drop out of this digest."""
 import glob
 import hashlib
 import json
